@@ -1,0 +1,93 @@
+"""Pin the CPU oracle (oracle/videoseal_ref.py) against golden vectors produced by the
+UNMODIFIED reference (tests/golden/make_golden.py).  CPU only."""
+import json
+import os
+
+import pytest
+import torch
+
+from oracle import videoseal_ref as R
+from oracle.inputs import synthetic_frames, synthetic_msgs
+from oracle.weights import make_state_dict, spec_from_card, state_dict_layout, tiny_spec
+from tests._util import GOLDEN, check_sub, load_golden, psnr_np
+
+CARDS = os.path.join(os.path.dirname(GOLDEN), "..", "videoseal_amd", "cards")
+
+TINY = ["tiny_img", "tiny_img_resize", "tiny_vid_repeat", "tiny_vid_alternate", "tiny_vid_interpolate"]
+FULL = ["vs10_img256", "vs10_img_odd", "vs10_img_lowres", "vs10_vid", "vs10_vid_lowres", "vs10_img_uniform"]
+
+
+def _run(spec, sd, meta):
+    imgs = synthetic_frames(meta["n"], meta["h"], meta["w"], seed=meta["seed"], kind=meta["kind"])
+    msgs = synthetic_msgs(1 if meta["is_video"] else meta["n"], spec.nbits, seed=meta["seed"])
+    if meta["is_video"]:
+        out = R.embed_video(sd, spec, imgs, msgs, lowres_attenuation=meta["lowres"], chunk_size=meta["chunk"],
+                            step_size=meta["step"], video_mode=meta["video_mode"])
+    else:
+        out = R.embed_image(sd, spec, imgs, msgs, lowres_attenuation=meta["lowres"])
+    return imgs, msgs, out
+
+
+@pytest.fixture(scope="module")
+def tiny():
+    s = tiny_spec()
+    return s, make_state_dict(s, seed=3)
+
+
+@pytest.fixture(scope="module")
+def vs10():
+    s = spec_from_card(os.path.join(CARDS, "videoseal_1.0.yaml"))
+    return s, make_state_dict(s, seed=0)
+
+
+def _check_case(spec, sd, name):
+    g = load_golden(name)
+    meta = g["meta"]
+    with torch.no_grad():
+        imgs, msgs, out = _run(spec, sd, meta)
+        assert (msgs.numpy() == g["msgs"]).all()
+        check_sub(g, "imgs_w", out["imgs_w"], 2e-6, name + " ")
+        if "preds_w.sub" in g:
+            check_sub(g, "preds_w", out["preds_w"], 2e-6, name + " ")
+        preds = R.detect(sd, spec, out["imgs_w"])["preds"]
+        assert (preds - torch.from_numpy(g["preds"])).abs().max() < 2e-5
+        assert ((preds > 0).numpy() == (g["preds"] > 0)).all(), "bit decisions differ from the reference"
+        clean = R.detect(sd, spec, imgs)["preds"]
+        assert (clean - torch.from_numpy(g["preds_clean"])).abs().max() < 2e-5
+        assert abs(psnr_np(out["imgs_w"], imgs) - meta["psnr"]) < 1e-3
+        if meta["is_video"]:
+            mh = R.extract_message(sd, spec, out["imgs_w"])
+            assert (mh.numpy() == g["msg_hat"]).all()
+        if "delta.sub" in g:
+            y = R.rgb2y(sd, imgs) if spec.yuv else imgs
+            check_sub(g, "delta", R.embedder_forward(sd, spec, y, msgs), 2e-6, name + " ")
+            check_sub(g, "hmaps", R.jnd_heatmaps(sd, spec, imgs), 1e-6, name + " ")
+
+
+@pytest.mark.parametrize("name", TINY)
+def test_tiny_oracle_matches_reference(tiny, name):
+    _check_case(*tiny, name)
+
+
+@pytest.mark.parametrize("name", FULL)
+def test_vs10_oracle_matches_reference(vs10, name):
+    _check_case(*vs10, name)
+
+
+def test_state_dict_layout_matches_reference_cards():
+    keys = json.load(open(os.path.join(GOLDEN, "state_dict_keys.json")))
+    for card, ref in keys.items():
+        spec = spec_from_card(os.path.join(CARDS, card + ".yaml"))
+        mine = {k: list(v) for k, v in state_dict_layout(spec).items()}
+        assert mine == ref and list(mine) == list(ref), card
+    assert len(keys["videoseal_1.0"]) == 434
+
+
+def test_metrics():
+    a = torch.rand(2, 3, 8, 8)
+    b = (a + 0.01).clamp(0, 1)
+    p = R.psnr(a, b)
+    assert p.shape == (2,) and (p > 30).all()
+    assert R.psnr(a, b, is_video=True).ndim == 0
+    preds = torch.tensor([[0.3, -0.2, 1.0, -5.0]])
+    assert R.bit_accuracy(preds, torch.tensor([[1, 0, 0, 0]])).item() == 0.75
