@@ -1,0 +1,158 @@
+/*
+ * videoseal_hip.h -- C-ABI of libvideoseal_hip.so: the MI355X (gfx950) kernels behind the
+ * VideoSeal embed -> (augment) -> extract hot path.
+ *
+ * The reference (facebookresearch/videoseal) has no FFI/plugin seam: callers bind to a Python
+ * nn.Module.  This header is therefore the boundary a maintainer would add:
+ * plain pointers + sizes, no torch types, no allocation, no ownership transfer, no hidden sync.
+ * Every entry point is stream-ordered (`stream` is a hipStream_t passed as void*), returns
+ * VS_OK (0) or a negative VS_ERR_* code, and never touches host memory behind the pointers.
+ * INTEGRATION.md shows the ctypes stub that binds it (videoseal_amd/native.py is that stub).
+ *
+ * Layout conventions
+ *   full-resolution frames   : NCHW float32 in [0,1]  (the reference API contract, wam.py:134-204)
+ *   network activations      : NHWC float32, channel stride `ld` (floats, multiple of 4); channels in
+ *                              [C, ld) are zero and every producer keeps them zero
+ *   conv / linear weights    : packed row-major [N][Ktot], Ktot = KH*KW*CinP, CinP = Cin rounded up to 16,
+ *                              k = (ky*KW + kx)*CinP + c   (videoseal_amd/packing.py builds them, BN folded)
+ */
+#ifndef VIDEOSEAL_HIP_H
+#define VIDEOSEAL_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VS_OK 0
+#define VS_ERR_BAD_ARG (-1)      /* null pointer, non-positive size, misaligned ld            */
+#define VS_ERR_UNSUPPORTED (-2)  /* configuration outside what the kernels implement          */
+#define VS_ERR_LAUNCH (-3)       /* hipGetLastError() != hipSuccess after the launch          */
+
+#define VS_ACT_NONE 0
+#define VS_ACT_RELU 1
+#define VS_ACT_GELU 2            /* exact erf GELU (nn.GELU default)                          */
+#define VS_ACT_TANH 3
+
+#define VS_PAD_ZERO 0
+#define VS_PAD_REFLECT 1
+
+#define VS_VIDEO_REPEAT 0        /* videoseal.py:92-94  */
+#define VS_VIDEO_ALTERNATE 1     /* videoseal.py:95-100 */
+#define VS_VIDEO_INTERPOLATE 2   /* videoseal.py:101-117 */
+
+/* library / device introspection */
+int vs_version(void);                       /* ABI version, currently 1 */
+const char* vs_arch(void);                  /* "gfx950" */
+const char* vs_error_string(int code);
+
+/*
+ * Implicit-GEMM convolution on the fp32 matrix cores (v_mfma_f32_32x32x2_f32):
+ *   out[m, n] = epilogue( sum_k A[m,k] * wt[n,k] )    m = (b, oy, ox), n = output channel
+ * Replaces every dense conv / nn.Linear of the path:
+ *   unet.py:24-39 (ResnetBlock 3x3 + folded BN + ReLU, fused 1x1 res_conv via phase 2),
+ *   unet.py:74-76 (3x3 stride-2 down), common.py:45-52 (reflect-pad 3x3 of Upsample),
+ *   convnext.py:108-119 (4x4 s4 stem, 2x2 s2 downsample), convnext.py:32-35,47-51 (pwconv1/2).
+ * Epilogue order: v = acc + bias; v = act(v); [phase 2: v += bias2 + in2 (1x1) wt2]; v += res; store.
+ */
+typedef struct vs_conv_desc {
+  const float* in;          /* input activations                                                   */
+  int64_t in_sb, in_sy, in_sx; /* strides in floats: frame, row, pixel                             */
+  int32_t B, H, W, Cin;     /* Cin = floats read per tap (multiple of 4)                           */
+  int32_t KH, KW, SH, SW, PH, PW, pad_mode;
+  int32_t Ho, Wo;
+  const float* wt;          /* [N][KH*KW*CinP]                                                     */
+  int32_t CinP, N;
+  const float* a_scale;     /* optional A transform a' = a*a_scale[b*a_scale_ld + c] + a_shift[c]  */
+  int64_t a_scale_ld;       /*   (GRN apply, common.py:166-169); KH=KW=1 only                      */
+  const float* a_shift;
+  const float* bias;        /* [N] or NULL                                                         */
+  int32_t act;
+  int32_t n_store;          /* columns written (>= N, <= out_ld - out_coff); extra columns get 0   */
+  const float* res;         /* optional residual [M][res_ld], added after act                      */
+  int64_t res_ld;
+  const float* in2;         /* optional phase 2: pointwise conv of a second tensor [M][in2_ld]     */
+  int64_t in2_ld;
+  int32_t Cin2, Cin2P;
+  const float* wt2;         /* [N][Cin2P]                                                          */
+  const float* bias2;
+  float* out;               /* [M][out_ld], written at column offset out_coff                      */
+  int64_t out_ld;
+  int32_t out_coff;
+  int32_t tile_hint;        /* 0 = auto; 1 = 128x128, 2 = 128x64, 3 = 256x32 block tile            */
+} vs_conv_desc_t;
+int vs_conv_gemm(const vs_conv_desc_t* d, void* stream);
+
+/* LayerNorm over the channel dim of [rows][ld] (+ optional activation).  common.py:131-155 (both data formats). */
+int vs_layernorm_act(const float* x, int64_t rows, int C, int64_t ld, const float* w, const float* b, float eps,
+                     int act, float* out, int64_t out_ld, void* stream);
+
+/* ConvNeXt-V2 block front: depthwise 7x7 (pad 3, bias) fused with LayerNorm(C).  convnext.py:43-46.
+ * wdw is packed [49][C]. */
+int vs_dwconv7_ln(const float* x, int B, int H, int W, int C, int64_t ld, const float* wdw, const float* bdw,
+                  const float* lnw, const float* lnb, float eps, float* out, int64_t out_ld, void* stream);
+
+/* GRN statistics: scale[b][c] = 1 + gamma[c] * Gx[b][c] / (mean_c Gx[b][.] + 1e-6), Gx = ||h[b,:,c]||_2.
+ * common.py:166-168.  `partial` is workspace of nchunk*B*C floats, nchunk = ceil(HW/64). */
+int vs_grn_scale(const float* h, int B, int HW, int C, int64_t ld, const float* gamma, float* partial,
+                 float* scale, void* stream);
+
+/* Bilinear x2 (align_corners=False) of cat(x, skip*skip_scale) along channels.  unet.py:186-191 + common.py:46. */
+int vs_upcat2x(const float* x, int C1, int64_t ld1, const float* skip, int C2, int64_t ld2, float skip_scale,
+               int B, int H, int W, float* out, int64_t out_ld, void* stream);
+
+/* Message latent: lat[b][c] = sum_k table[2k + msg[b][k]][c].  msg_processor.py:88-98.  msgs are int32 0/1. */
+int vs_msg_latent(const float* table, const int32_t* msgs, int Bm, int nbits, int hidden, float* lat, void* stream);
+/* Broadcast lat[b or 0][0:hidden] over H*W pixels into channels [coff, coff+hidden) of dst.  msg_processor.py:96-115. */
+int vs_broadcast_channels(const float* lat, int Bm, int hidden, float* dst, int B, int HW, int64_t ld, int coff,
+                          void* stream);
+
+/* 1x1 conv C -> Cout (Cout <= 4) + bias + optional tanh, NHWC in, planar [B][Cout][HW] out.  unet.py:166,194-196. */
+int vs_outc_tanh(const float* x, int64_t rows_per_frame, int B, int C, int64_t ld, const float* w, const float* bias,
+                 int Cout, int use_tanh, float* out, void* stream);
+
+/* Mean over HW then Linear.  pixel_decoder.py:76-79.  w is [N][C] row-major (native nn.Linear layout). */
+int vs_pool_linear(const float* x, int B, int HW, int C, int64_t ld, const float* w, const float* bias, int N,
+                   float* out, void* stream);
+
+/*
+ * Resize (bilinear, align_corners=False, antialias on/off -- ATen's separable triangle filter,
+ * wam.py:161-164, 222-225; videoseal.py:303-306) of NCHW frames fused with the layout change and
+ * the pre-processing of the consumers:
+ *   dst_rgb [B][oh][ow][4]  = (r,g,b,0) * mul + add             (detector: x*2-1, extractor.py:164;
+ *                                                                 low-res JND: raw, mul=1 add=0)
+ *   dst_y   [Bk][oh][ow][4] = ((yr*r + yg*g + yb*b) * 2 - 1, 0,0,0) for frames f % y_step == 0
+ *                             (data/transforms.py:23-27 row 0 + embedder.py:163)
+ * Either destination may be NULL.
+ */
+int vs_resize_pre(const float* src, int B, int C, int H, int W, int oh, int ow, int antialias, float* dst_rgb, float mul,
+                  float add, float* dst_y, int y_step, const float* ymat3, void* stream);
+
+/* JND heat-map (jnd.py:63-108, in_channels=1/out_channels=1) of an RGB image addressed by strides
+ * (floats): frame, channel, row, pixel.  taps: [0..24] 5x5 lum, [25..33] sobel x, [34..42] sobel y. */
+int vs_jnd_heatmap(const float* img, int B, int H, int W, int64_t sb, int64_t sc, int64_t sy, int64_t sx,
+                   const float* taps43, float* hmap, void* stream);
+
+/*
+ * Embed tail (wam.py:182-197, videoseal.py:316-344): for every full-resolution pixel
+ *   d      = resize(video_mode(delta))             delta: [Fk][Cd][S][S], Cd in {1,3}
+ *   d     *= hmap_lowres (before the resize) or JND(imgs) (after it)       (hmap_lowres may be NULL,
+ *                                                                           attenuate=0 disables JND)
+ *   out    = clamp(scaling_i*imgs + scaling_w*d, 0, 1)
+ * imgs/out: NCHW [F][3][H][W]; preds_w (optional) [F][Cd][H][W].
+ */
+typedef struct vs_tail_desc {
+  const float* imgs; float* out; float* preds_w;
+  const float* delta; const float* hmap_lowres; const float* taps43;
+  int32_t F, H, W, S_h, S_w, Cd;
+  int32_t step, video_mode, total_key;      /* key-frame expansion                         */
+  int32_t attenuate, clamp, antialias;
+  float scaling_i, scaling_w;
+} vs_tail_desc_t;
+int vs_embed_tail(const vs_tail_desc_t* d, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VIDEOSEAL_HIP_H */

@@ -1,0 +1,319 @@
+"""Per-kernel parity: every C-ABI entry point against the same op computed by torch fp32 on the CPU
+(ATen is what the reference runs).  Tolerances are written next to each check.  Needs an MI355X."""
+import ctypes as C
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from videoseal_amd import native as N  # noqa: E402
+from videoseal_amd.engine import Act, ConvW, HipEngine, pack_conv, pack_patch_conv, rup  # noqa: E402
+
+DEV = "cuda"
+
+
+def to_nhwc(x, ld=None):
+    B, Cc, H, W = x.shape
+    ld = ld or rup(Cc, 4)
+    t = torch.zeros(B, H, W, ld)
+    t[..., :Cc] = x.permute(0, 2, 3, 1)
+    return Act(t.to(DEV).contiguous(), B, H, W, Cc, ld)
+
+
+def from_nhwc(a: Act, Cc=None):
+    Cc = Cc or a.C
+    return a.t.view(a.B, a.H, a.W, a.ld)[..., :Cc].permute(0, 3, 1, 2).cpu()
+
+
+class Eng(HipEngine):
+    """engine without a model: only the kernel wrappers + workspace."""
+
+    def __init__(self):
+        self.dev = torch.device(DEV)
+        self.lib = N.lib()
+        self._ws = {}
+
+
+@pytest.fixture(scope="module")
+def eng():
+    return Eng()
+
+
+def rel_err(a, b):
+    return ((a - b).abs().max() / (b.abs().max() + 1e-12)).item()
+
+
+CONV_CASES = [
+    # B, Cin, H, W, Cout, k, stride, pad, pad_mode, act, tile
+    (2, 16, 17, 23, 16, 3, 1, 1, 0, 1, 0),
+    (1, 1, 32, 32, 16, 3, 1, 1, 0, 1, 0),
+    (3, 32, 20, 20, 64, 3, 2, 1, 0, 0, 0),
+    (2, 64, 16, 16, 136, 3, 1, 1, 1, 0, 0),
+    (2, 384, 8, 8, 384, 3, 1, 1, 0, 1, 1),
+    (1, 48, 9, 11, 40, 1, 1, 0, 0, 2, 2),
+    (2, 24, 12, 12, 20, 3, 1, 1, 1, 3, 3),
+    (2, 64, 33, 31, 96, 3, 1, 1, 0, 1, 2),
+]
+
+
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv_gemm_matches_conv2d(eng, case):
+    B, Cin, H, W, Cout, k, s, p, pm, act, tile = case
+    g = torch.Generator().manual_seed(hash(case) % 1000)
+    x = torch.randn(B, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, k, k, generator=g) / math.sqrt(Cin * k * k)
+    b = torch.randn(Cout, generator=g)
+    xp = F.pad(x, (p, p, p, p), mode="reflect") if (pm and p) else x
+    ref = F.conv2d(xp, w, b, stride=s, padding=0 if pm else p)
+    ref = {0: ref, 1: F.relu(ref), 2: F.gelu(ref), 3: torch.tanh(ref)}[act]
+    xa = to_nhwc(x)
+    wt, cp = pack_conv(w.to(DEV), xa.ld)
+    out = eng.new_act("o", B, ref.shape[2], ref.shape[3], Cout)
+    out.t.fill_(float("nan"))
+    eng.conv(xa, ConvW(wt, b.to(DEV), Cout, k, k, cp), out, stride=s, pad=p, pad_mode=pm, act=act, tile_hint=tile)
+    torch.cuda.synchronize()
+    got = from_nhwc(out)
+    assert rel_err(got, ref) < 2e-5          # fp32 accumulate, different summation order only
+    full = out.t.view(B, out.H, out.W, out.ld).cpu()
+    assert torch.isfinite(full).all() and (full[..., Cout:] == 0).all()   # pad lanes written as zero
+
+
+def test_conv_two_phase_residual_block(eng):
+    """ResnetBlock tail: relu(conv3x3(t)+b) + (conv1x1(x)+b2), written at a channel offset of a wider buffer."""
+    g = torch.Generator().manual_seed(5)
+    B, Cm, Cx, H, W, Co = 2, 32, 16, 14, 18, 32
+    t = torch.randn(B, Cm, H, W, generator=g)
+    x = torch.randn(B, Cx, H, W, generator=g)
+    w1 = torch.randn(Co, Cm, 3, 3, generator=g) / math.sqrt(Cm * 9)
+    b1 = torch.randn(Co, generator=g)
+    w2 = torch.randn(Co, Cx, 1, 1, generator=g) / math.sqrt(Cx)
+    b2 = torch.randn(Co, generator=g)
+    ref = F.relu(F.conv2d(t, w1, b1, padding=1)) + F.conv2d(x, w2, b2)
+    ta, xa = to_nhwc(t), to_nhwc(x)
+    wt1, cp1 = pack_conv(w1.to(DEV), ta.ld)
+    wt2, cp2 = pack_conv(w2.to(DEV), xa.ld)
+    out = eng.new_act("wide", B, H, W, 48)
+    out.t.fill_(7.0)
+    eng.conv(ta, ConvW(wt1, b1.to(DEV), Co, 3, 3, cp1), out, pad=1, act=N.ACT_RELU, in2=xa, w2=ConvW(wt2, b2.to(DEV), Co, 1, 1, cp2),
+             out_coff=8, n_store=Co)
+    torch.cuda.synchronize()
+    full = out.t.view(B, H, W, 48).cpu()
+    assert rel_err(full[..., 8:40].permute(0, 3, 1, 2), ref) < 2e-5
+    assert (full[..., :8] == 7.0).all() and (full[..., 40:] == 7.0).all()   # neighbours untouched
+
+
+def test_conv_grn_transform_and_residual(eng):
+    """pwconv2 with the GRN apply folded into the A load and the block residual (convnext.py:50-56)."""
+    g = torch.Generator().manual_seed(6)
+    B, HW, K, Nn = 3, 50, 72, 20
+    h = torch.randn(B, HW, K, generator=g)
+    sc = 1 + 0.3 * torch.randn(B, K, generator=g)
+    sh = 0.1 * torch.randn(K, generator=g)
+    w = torch.randn(Nn, K, generator=g) / math.sqrt(K)
+    bias = torch.randn(Nn, generator=g)
+    res = torch.randn(B, HW, Nn, generator=g)
+    ref = res + F.linear(h * sc[:, None, :] + sh, w, bias)
+    ha = Act(h.to(DEV).contiguous(), B, HW, 1, K, K)
+    wt, cp = pack_conv(w[:, :, None, None].to(DEV), K)
+    ra = Act(res.to(DEV).contiguous(), B, HW, 1, Nn, Nn)
+    shp = torch.zeros(cp); shp[:K] = sh
+    eng.conv(ha, ConvW(wt, bias.to(DEV), Nn, 1, 1, cp), ra, res=ra, a_scale=sc.to(DEV).contiguous(), a_scale_ld=K, a_shift=shp.to(DEV))
+    torch.cuda.synchronize()
+    assert rel_err(ra.t.cpu().view(B, HW, Nn), ref) < 2e-5
+
+
+@pytest.mark.parametrize("stride", [4, 2])
+def test_patch_conv_stem(eng, stride):
+    """4x4 stem (stride 4, and ChunkySeal's stride 2) as a 4x1 conv over 16-float pixel runs."""
+    g = torch.Generator().manual_seed(7)
+    B, S, Co = 2, 36, 24
+    x = torch.randn(B, 3, S, S, generator=g)
+    w = torch.randn(Co, 3, 4, 4, generator=g) / 7
+    b = torch.randn(Co, generator=g)
+    ref = F.conv2d(x, w, b, stride=stride)
+    xa = to_nhwc(x, 4)
+    wt, cp = pack_patch_conv(w.to(DEV), 4)
+    Ho = (S - 4) // stride + 1
+    out = eng.new_act("stem", B, Ho, Ho, Co)
+    eng.conv(xa, ConvW(wt, b.to(DEV), Co, 4, 1, cp), out, geom=(Ho, stride * 4, 16, stride, 1, 0, 0))
+    torch.cuda.synchronize()
+    assert rel_err(from_nhwc(out), ref) < 2e-5
+
+
+@pytest.mark.parametrize("hw", [(16, 16), (15, 13)])
+def test_patch_conv_downsample(eng, hw):
+    g = torch.Generator().manual_seed(8)
+    B, Cc, Co = 2, 24, 40
+    H, W = hw
+    x = torch.randn(B, Cc, H, W, generator=g)
+    w = torch.randn(Co, Cc, 2, 2, generator=g) / 10
+    b = torch.randn(Co, generator=g)
+    ref = F.conv2d(x, w, b, stride=2)
+    xa = to_nhwc(x)
+    wt, cp = pack_patch_conv(w.to(DEV), xa.ld)
+    out = eng.new_act("dn", B, H // 2, W // 2, Co)
+    eng.conv(xa, ConvW(wt, b.to(DEV), Co, 2, 1, cp), out, geom=(W // 2, 2 * xa.ld, 2 * xa.ld, 2, 1, 0, 0))
+    torch.cuda.synchronize()
+    assert rel_err(from_nhwc(out), ref) < 2e-5
+
+
+@pytest.mark.parametrize("C_,act", [(16, 1), (96, 0), (362, 2), (768, 2)])
+def test_layernorm_act(eng, C_, act):
+    g = torch.Generator().manual_seed(C_)
+    x = torch.randn(2, C_, 9, 7, generator=g) * 3 + 1
+    w, b = torch.rand(C_, generator=g) + 0.5, torch.randn(C_, generator=g)
+    u = x.mean(1, keepdim=True); s = (x - u).pow(2).mean(1, keepdim=True)
+    ref = w[:, None, None] * ((x - u) / torch.sqrt(s + 1e-6)) + b[:, None, None]
+    ref = {0: ref, 1: F.relu(ref), 2: F.gelu(ref)}[act]
+    xa = to_nhwc(x)
+    out = eng.new_act("ln", 2, 9, 7, C_)
+    eng.layernorm(xa, w.to(DEV), b.to(DEV), out, act=act)
+    torch.cuda.synchronize()
+    assert (from_nhwc(out) - ref).abs().max() < 2e-5
+
+
+@pytest.mark.parametrize("C_,H,W", [(96, 16, 16), (24, 9, 13), (362, 7, 7), (768, 8, 8)])
+def test_dwconv7_ln(eng, C_, H, W):
+    g = torch.Generator().manual_seed(C_ + H)
+    B = 2
+    x = torch.randn(B, C_, H, W, generator=g)
+    wd = torch.randn(C_, 1, 7, 7, generator=g) / 7
+    bd = torch.randn(C_, generator=g) * 0.1
+    lw, lb = torch.rand(C_, generator=g) + 0.5, torch.randn(C_, generator=g) * 0.1
+    ref = F.conv2d(x, wd, bd, padding=3, groups=C_).permute(0, 2, 3, 1)
+    ref = F.layer_norm(ref, (C_,), lw, lb, 1e-6).permute(0, 3, 1, 2)
+    xa = to_nhwc(x)
+    ld = xa.ld
+    wp = torch.zeros(49, ld); wp[:, :C_] = wd.reshape(C_, 49).t()
+    pad = lambda v: torch.cat([v, torch.zeros(ld - C_)]).to(DEV)   # noqa: E731
+    out = eng.new_act("dw", B, H, W, C_)
+    N.check(eng.lib.vs_dwconv7_ln(N.ptr(xa.t), B, H, W, C_, ld, N.ptr(wp.to(DEV)), N.ptr(pad(bd)), N.ptr(pad(lw)), N.ptr(pad(lb)), 1e-6,
+                                  N.ptr(out.t), out.ld, N.stream()), "dw")
+    torch.cuda.synchronize()
+    assert (from_nhwc(out) - ref).abs().max() < 3e-5
+
+
+@pytest.mark.parametrize("C_,HW", [(384, 4096), (100, 37), (1448, 225)])
+def test_grn_scale(eng, C_, HW):
+    g = torch.Generator().manual_seed(C_)
+    B = 3
+    h = torch.randn(B, HW, C_, generator=g)
+    gamma = torch.randn(C_, generator=g)
+    gx = torch.norm(h, p=2, dim=1, keepdim=True)
+    ref = 1 + gamma * (gx / (gx.mean(dim=-1, keepdim=True) + 1e-6))
+    ld = rup(C_, 4)
+    hp = torch.zeros(B, HW, ld); hp[..., :C_] = h
+    part = torch.empty(((HW + 63) // 64) * B * C_, device=DEV)
+    scale = torch.full((B, ld), float("nan"), device=DEV)
+    N.check(eng.lib.vs_grn_scale(N.ptr(hp.to(DEV)), B, HW, C_, ld, N.ptr(gamma.to(DEV)), N.ptr(part), N.ptr(scale), N.stream()), "grn")
+    torch.cuda.synchronize()
+    assert (scale.cpu()[:, :C_] - ref[:, 0]).abs().max() < 1e-5
+    assert (scale.cpu()[:, C_:] == 0).all()
+
+
+def test_upcat2x(eng):
+    g = torch.Generator().manual_seed(9)
+    B, C1, C2, H, W = 2, 24, 8, 7, 9
+    x, sk = torch.randn(B, C1, H, W, generator=g), torch.randn(B, C2, H, W, generator=g)
+    ref = F.interpolate(torch.cat((x, sk * 2 ** -0.5), 1), scale_factor=2, mode="bilinear", align_corners=False)
+    xa, sa = to_nhwc(x), to_nhwc(sk)
+    out = eng.new_act("uc", B, 2 * H, 2 * W, C1 + C2)
+    N.check(eng.lib.vs_upcat2x(N.ptr(xa.t), C1, xa.ld, N.ptr(sa.t), C2, sa.ld, 2 ** -0.5, B, H, W, N.ptr(out.t), out.ld, N.stream()), "uc")
+    torch.cuda.synchronize()
+    assert (from_nhwc(out) - ref).abs().max() < 1e-6
+
+
+def test_msg_latent_and_broadcast(eng):
+    g = torch.Generator().manual_seed(10)
+    B, k, hid = 3, 40, 24
+    table = torch.randn(2 * k, hid, generator=g)
+    msgs = torch.randint(0, 2, (B, k), generator=g)
+    ref = F.embedding(2 * torch.arange(k)[None] + msgs, table).sum(-2)
+    lat = torch.empty(B, hid, device=DEV)
+    N.check(eng.lib.vs_msg_latent(N.ptr(table.to(DEV)), N.ptr(msgs.to(torch.int32).to(DEV)), B, k, hid, N.ptr(lat), N.stream()), "ml")
+    dst = torch.zeros(B, 6, 32, device=DEV)
+    N.check(eng.lib.vs_broadcast_channels(N.ptr(lat), B, hid, N.ptr(dst), B, 6, 32, 8, N.stream()), "bc")
+    torch.cuda.synchronize()
+    assert (lat.cpu() - ref).abs().max() < 1e-5
+    d = dst.cpu()
+    assert (d[:, :, 8:] == lat.cpu()[:, None, :]).all() and (d[:, :, :8] == 0).all()
+
+
+@pytest.mark.parametrize("Cout", [1, 3])
+def test_outc_tanh(eng, Cout):
+    g = torch.Generator().manual_seed(11)
+    B, Cc, H, W = 2, 16, 10, 12
+    x = torch.randn(B, Cc, H, W, generator=g)
+    w, b = torch.randn(Cout, Cc, 1, 1, generator=g) / 4, torch.randn(Cout, generator=g)
+    ref = torch.tanh(F.conv2d(x, w, b))
+    xa = to_nhwc(x)
+    out = torch.empty(B, Cout, H, W, device=DEV)
+    N.check(eng.lib.vs_outc_tanh(N.ptr(xa.t), H * W, B, Cc, xa.ld, N.ptr(w.reshape(Cout, Cc).contiguous().to(DEV)), N.ptr(b.to(DEV)), Cout, 1,
+                                 N.ptr(out), N.stream()), "outc")
+    torch.cuda.synchronize()
+    assert (out.cpu() - ref).abs().max() < 1e-6
+
+
+def test_pool_linear(eng):
+    g = torch.Generator().manual_seed(12)
+    B, Cc, H, W, Nn = 3, 76, 8, 8, 33
+    x = torch.randn(B, Cc, H, W, generator=g)
+    w, b = torch.randn(Nn, Cc, generator=g) / 8, torch.randn(Nn, generator=g)
+    ref = F.linear(x.mean(dim=[-2, -1]), w, b)
+    xa = to_nhwc(x)
+    out = torch.empty(B, Nn, device=DEV)
+    N.check(eng.lib.vs_pool_linear(N.ptr(xa.t), B, H * W, Cc, xa.ld, N.ptr(w.to(DEV)), N.ptr(b.to(DEV)), Nn, N.ptr(out), N.stream()), "pl")
+    torch.cuda.synchronize()
+    assert (out.cpu() - ref).abs().max() < 1e-5
+
+
+RESIZE_CASES = [(768, 768, 256, 256, 1), (200, 328, 256, 256, 1), (144, 176, 64, 64, 1), (64, 64, 64, 64, 1),
+                (768, 768, 256, 256, 0), (90, 130, 64, 64, 0), (1080, 1920, 256, 256, 1), (100, 60, 256, 256, 1), (31, 45, 64, 64, 0)]
+
+
+@pytest.mark.parametrize("case", RESIZE_CASES)
+def test_resize_pre(eng, case):
+    H, W, oh, ow, aa = case
+    g = torch.Generator().manual_seed(H + W)
+    B = 3
+    x = torch.rand(B, 3, H, W, generator=g)
+    ref = F.interpolate(x, size=(oh, ow), mode="bilinear", align_corners=False, antialias=bool(aa))
+    M0 = torch.tensor([0.299, 0.587, 0.114])
+    yref = (torch.matmul(ref.permute(0, 2, 3, 1), M0) * 2 - 1)[::2]
+    xd = x.to(DEV)
+    rgb = torch.full((B, oh, ow, 4), float("nan"), device=DEV)
+    key = torch.full((2, oh, ow, 4), float("nan"), device=DEV)
+    ymat = (C.c_float * 3)(0.299, 0.587, 0.114)
+    N.check(eng.lib.vs_resize_pre(N.ptr(xd), B, 3, H, W, oh, ow, aa, N.ptr(rgb), 2.0, -1.0, N.ptr(key), 2, ymat, N.stream()), "rs")
+    torch.cuda.synchronize()
+    got = rgb.cpu()
+    assert (got[..., :3].permute(0, 3, 1, 2) - (ref * 2 - 1)).abs().max() < 2e-6     # ATen separable filter restated
+    assert (got[..., 3] == 0).all()
+    assert (key.cpu()[..., 0] - yref).abs().max() < 2e-6
+
+
+def _jnd_ref(x):
+    lum = 0.299 * (255 * x[:, 0:1]) + 0.587 * (255 * x[:, 1:2]) + 0.114 * (255 * x[:, 2:3])
+    kx = torch.tensor([[-1., 0., 1.], [-2., 0., 2.], [-1., 0., 1.]])[None, None]
+    ky = torch.tensor([[1., 2., 1.], [0., 0., 0.], [-1., -2., -1.]])[None, None]
+    kl = torch.tensor([[1., 1., 1., 1., 1.], [1., 2., 2., 2., 1.], [1., 2., 0., 2., 1.], [1., 2., 2., 2., 1.], [1., 1., 1., 1., 1.]])[None, None]
+    la = F.conv2d(lum, kl, padding=2) / 32
+    la = torch.where(la <= 127, 17 * (1 - torch.sqrt(la / 127 + 1e-5)), 3 / 128 * (la - 127) + 3)
+    gx, gy = F.conv2d(lum, kx, padding=1), F.conv2d(lum, ky, padding=1)
+    cm = torch.sqrt(gx ** 2 + gy ** 2)
+    cm = 0.117 * (16 * cm ** 2.4 / (cm ** 2 + 26 ** 2))
+    return torch.clamp_min(la + cm - 0.3 * torch.minimum(la, cm), 0) / 255, torch.cat([kl.flatten(), kx.flatten(), ky.flatten()])
+
+
+def test_jnd_heatmap_nchw(eng):
+    from oracle.inputs import synthetic_frames
+    x = synthetic_frames(2, 70, 101, seed=3)
+    ref, taps = _jnd_ref(x)
+    t43 = (C.c_float * 43)(*[float(v) for v in taps])
+    h = torch.empty(2, 1, 70, 101, device=DEV)
+    N.check(eng.lib.vs_jnd_heatmap(N.ptr(x.to(DEV)), 2, 70, 101, 3 * 70 * 101, 70 * 101, 101, 1, t43, N.ptr(h), N.stream()), "jnd")
+    torch.cuda.synchronize()
+    assert (h.cpu() - ref).abs().max() < 2e-6      # heat-maps are O(0.05); powf/sqrtf ulp differences only

@@ -1,0 +1,14 @@
+// Library introspection entry points of libvideoseal_hip.so.
+#include "vs_common.h"
+
+extern "C" int vs_version(void) { return 1; }
+extern "C" const char* vs_arch(void) { return "gfx950"; }
+extern "C" const char* vs_error_string(int code) {
+  switch (code) {
+    case VS_OK: return "ok";
+    case VS_ERR_BAD_ARG: return "bad argument (null pointer, non-positive size or misaligned stride)";
+    case VS_ERR_UNSUPPORTED: return "unsupported configuration";
+    case VS_ERR_LAUNCH: return "kernel launch failed";
+    default: return "unknown error";
+  }
+}

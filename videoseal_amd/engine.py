@@ -1,0 +1,377 @@
+"""Host-side driver of the HIP kernels: weight pre-packing and the launch sequence of the
+U-Net embedder, the ConvNeXt-V2 extractor and the full-resolution shell.
+
+Python here is plumbing only (pointer/shape bookkeeping, torch for device memory and streams);
+every arithmetic stage of the hot path is a hand-written gfx950 kernel reached through the C-ABI
+(native.py).  Weight packing (BN folding, NCHW -> [N][tap][C] re-layout) happens once per
+state_dict on the device.
+
+Reference stages replaced (file:line in /root/reference/videoseal):
+  modules/unet.py:170-197  UNetMsg.forward            -> HipEngine.embedder_forward
+  modules/convnext.py:146-156 + pixel_decoder.py:61-83 -> HipEngine.extractor_forward
+  models/wam.py:161-197 / videoseal.py:303-344         -> HipEngine.resize_pre / jnd_lowres / embed_tail
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+from dataclasses import dataclass
+from typing import Dict, List, Optional, Tuple
+
+import torch
+
+from . import native as N
+
+
+def rup(x: int, m: int) -> int:
+    return (x + m - 1) // m * m
+
+
+@dataclass
+class Act:
+    """NHWC fp32 activation: t is a flat/ND device tensor of B*H*W*ld floats."""
+    t: torch.Tensor
+    B: int
+    H: int
+    W: int
+    C: int
+    ld: int
+
+    @property
+    def rows(self) -> int:
+        return self.B * self.H * self.W
+
+
+@dataclass
+class ConvW:
+    wt: torch.Tensor          # [N][KH*KW*CinP]
+    bias: Optional[torch.Tensor]
+    N: int
+    KH: int
+    KW: int
+    CinP: int
+
+
+def pack_conv(w: torch.Tensor, in_ld: int, scale: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, int]:
+    """[N,Cin,KH,KW] -> [N][KH*KW*CinP] with k = (ky*KW+kx)*CinP + c; channels >= Cin are zero.
+    `scale` (per output channel, e.g. folded BatchNorm) multiplies the rows."""
+    n, cin, kh, kw = w.shape
+    cinp = rup(max(in_ld, cin), 16)
+    out = torch.zeros(n, kh * kw, cinp, device=w.device, dtype=torch.float32)
+    wk = w.float().permute(0, 2, 3, 1).reshape(n, kh * kw, cin)
+    if scale is not None:
+        wk = wk * scale.float()[:, None, None]
+    out[:, :, :cin] = wk
+    return out.reshape(n, kh * kw * cinp).contiguous(), cinp
+
+
+def pack_patch_conv(w: torch.Tensor, pix_ld: int) -> Tuple[torch.Tensor, int]:
+    """Non-/partly-overlapping k x k conv whose kx taps are contiguous in NHWC memory: the kw pixels of a
+    row are read as one run of kw*pix_ld floats, so the conv becomes KH x 1 with Cin' = kw*pix_ld.
+    [N,Cin,KH,KW] -> [N][KH*CinP'], k = ky*CinP' + kx*pix_ld + c."""
+    n, cin, kh, kw = w.shape
+    run = kw * pix_ld
+    cinp = rup(run, 16)
+    out = torch.zeros(n, kh, cinp, device=w.device, dtype=torch.float32)
+    tmp = torch.zeros(n, kh, kw, pix_ld, device=w.device, dtype=torch.float32)
+    tmp[..., :cin] = w.float().permute(0, 2, 3, 1)
+    out[:, :, :run] = tmp.reshape(n, kh, run)
+    return out.reshape(n, kh * cinp).contiguous(), cinp
+
+
+def padvec(v: torch.Tensor, n: int) -> torch.Tensor:
+    out = torch.zeros(n, device=v.device, dtype=torch.float32)
+    out[: v.numel()] = v.float().reshape(-1)
+    return out
+
+
+class HipEngine:
+    """Packed weights + launch sequences for one architecture (ModelCfg) on one device."""
+
+    def __init__(self, cfg, sd: Dict[str, torch.Tensor], device: torch.device):
+        self.cfg = cfg
+        self.dev = device
+        self.lib = N.lib()
+        self._ws: Dict[tuple, torch.Tensor] = {}
+        g = lambda k: sd[k].detach().to(device)   # noqa: E731
+        self._pack_embedder(g)
+        self._pack_extractor(g)
+        m = g("rgb2yuv.M").float().cpu()
+        self.ymat = (C.c_float * 3)(*[float(v) for v in m[0]])
+        taps = torch.cat([g("attenuation.conv_lum.weight")[0, 0].reshape(-1), g("attenuation.conv_x.weight")[0, 0].reshape(-1),
+                          g("attenuation.conv_y.weight")[0, 0].reshape(-1)]).float().cpu()
+        self.taps43 = (C.c_float * 43)(*[float(v) for v in taps])
+
+    # ------------------------------------------------------------------ packing
+    def _bn_fold(self, g, p):
+        s = g(p + ".weight").float() / torch.sqrt(g(p + ".running_var").float() + 1e-5)
+        return s, g(p + ".bias").float() - g(p + ".running_mean").float() * s
+
+    def _pack_resblock(self, g, p, cin):
+        w0 = g(p + ".double_conv.0.weight")
+        cout = w0.shape[0]
+        s0, b0 = self._bn_fold(g, p + ".double_conv.1")
+        s1, b1 = self._bn_fold(g, p + ".double_conv.4")
+        wt0, cp0 = pack_conv(w0, rup(cin, 4), s0)
+        wt1, cp1 = pack_conv(g(p + ".double_conv.3.weight"), rup(cout, 4), s1)
+        wr, cpr = pack_conv(g(p + ".res_conv.weight"), rup(cin, 4))
+        return dict(c0=ConvW(wt0, b0.contiguous(), cout, 3, 3, cp0), c1=ConvW(wt1, b1.contiguous(), cout, 3, 3, cp1),
+                    res=ConvW(wr, g(p + ".res_conv.bias").float().contiguous(), cout, 1, 1, cpr), cout=cout)
+
+    def _pack_embedder(self, g):
+        c = self.cfg
+        u = "embedder.unet"
+        zc = c.zc
+        E = {}
+        E["inc"] = self._pack_resblock(g, u + ".inc", c.in_ch)
+        E["downs"] = []
+        for i in range(len(zc) - 1):
+            wd, cp = pack_conv(g(f"{u}.downs.{i}.down.weight"), rup(zc[i], 4))
+            E["downs"].append(dict(down=ConvW(wd, g(f"{u}.downs.{i}.down.bias").float().contiguous(), zc[i + 1], 3, 3, cp),
+                                   rb=self._pack_resblock(g, f"{u}.downs.{i}.conv", zc[i + 1])))
+        E["bott"] = [self._pack_resblock(g, f"{u}.bottleneck.model.{j}", c.bott) for j in range(c.num_blocks)]
+        zz = zc[:-1] + [c.bott]
+        E["ups"] = []
+        for k, i in enumerate(reversed(range(len(zz) - 1))):
+            cin, cout = 2 * zz[i + 1], zz[i]
+            wu, cp = pack_conv(g(f"{u}.ups.{k}.up.upsample_block.2.weight"), rup(cin, 4))
+            E["ups"].append(dict(conv=ConvW(wu, None, cout, 3, 3, cp), lnw=g(f"{u}.ups.{k}.up.upsample_block.3.weight").float().contiguous(),
+                                 lnb=g(f"{u}.ups.{k}.up.upsample_block.3.bias").float().contiguous(),
+                                 rb=self._pack_resblock(g, f"{u}.ups.{k}.conv", cout)))
+        E["outc_w"] = g(u + ".outc.weight").float().reshape(c.out_ch, zc[0]).contiguous()
+        E["outc_b"] = g(u + ".outc.bias").float().contiguous()
+        E["table"] = g(u + ".msg_processor.msg_embeddings.weight").float().contiguous()
+        for ch in zc + [c.bott]:
+            if ch % 4:
+                raise N.NativeError(f"U-Net channel count {ch} is not a multiple of 4 (unsupported by the HIP path)")
+        self.E = E
+
+    def _pack_extractor(self, g):
+        c = self.cfg
+        cn = "detector.convnext"
+        d = c.dims
+        X = {}
+        ws, cps = pack_patch_conv(g(f"{cn}.downsample_layers.0.0.weight"), 4)
+        X["stem"] = ConvW(ws, g(f"{cn}.downsample_layers.0.0.bias").float().contiguous(), d[0], 4, 1, cps)
+        X["stem_ln"] = (g(f"{cn}.downsample_layers.0.1.weight").float().contiguous(), g(f"{cn}.downsample_layers.0.1.bias").float().contiguous())
+        X["down"] = []
+        for i in range(3):
+            wd, cp = pack_patch_conv(g(f"{cn}.downsample_layers.{i+1}.1.weight"), rup(d[i], 4))
+            X["down"].append(dict(lnw=g(f"{cn}.downsample_layers.{i+1}.0.weight").float().contiguous(),
+                                  lnb=g(f"{cn}.downsample_layers.{i+1}.0.bias").float().contiguous(),
+                                  conv=ConvW(wd, g(f"{cn}.downsample_layers.{i+1}.1.bias").float().contiguous(), d[i + 1], 2, 1, cp)))
+        X["stages"] = []
+        for st in range(4):
+            blocks = []
+            Cc = d[st]
+            ld, ld4 = rup(Cc, 4), rup(4 * Cc, 4)
+            for j in range(c.depths[st]):
+                p = f"{cn}.stages.{st}.{j}"
+                wdw = torch.zeros(49, ld, device=self.dev)
+                wdw[:, :Cc] = g(p + ".dwconv.weight").float().reshape(Cc, 49).t()
+                w1, cp1 = pack_conv(g(p + ".pwconv1.weight").float()[:, :, None, None], ld)
+                w2, cp2 = pack_conv(g(p + ".pwconv2.weight").float()[:, :, None, None], ld4)
+                blocks.append(dict(wdw=wdw.contiguous(), bdw=padvec(g(p + ".dwconv.bias"), ld), lnw=padvec(g(p + ".norm.weight"), ld),
+                                   lnb=padvec(g(p + ".norm.bias"), ld),
+                                   pw1=ConvW(w1, g(p + ".pwconv1.bias").float().contiguous(), 4 * Cc, 1, 1, cp1),
+                                   gamma=g(p + ".grn.gamma").float().reshape(-1).contiguous(), beta=padvec(g(p + ".grn.beta"), rup(ld4, 16)),
+                                   pw2=ConvW(w2, g(p + ".pwconv2.bias").float().contiguous(), Cc, 1, 1, cp2)))
+            X["stages"].append(blocks)
+        pd = "detector.pixel_decoder"
+        wh, cph = pack_conv(g(pd + ".output_upscaling.0.upsample_block.2.weight"), rup(d[-1], 4))
+        X["head_conv"] = ConvW(wh, None, d[-1], 3, 3, cph)
+        X["head_ln"] = (g(pd + ".output_upscaling.0.upsample_block.3.weight").float().contiguous(), g(pd + ".output_upscaling.0.upsample_block.3.bias").float().contiguous())
+        X["lin_w"] = g(pd + ".linear.weight").float().contiguous()
+        X["lin_b"] = g(pd + ".linear.bias").float().contiguous()
+        self.X = X
+
+    # ------------------------------------------------------------------ workspace
+    def buf(self, tag: str, numel: int, zero: bool = False) -> torch.Tensor:
+        key = (tag, numel)
+        t = self._ws.get(key)
+        if t is None:
+            t = torch.zeros(numel, device=self.dev, dtype=torch.float32) if zero else torch.empty(numel, device=self.dev, dtype=torch.float32)
+            self._ws[key] = t
+        return t
+
+    def release_workspace(self):
+        self._ws.clear()
+
+    def new_act(self, tag: str, B: int, H: int, W: int, Cc: int, ld: Optional[int] = None) -> Act:
+        ld = ld or rup(Cc, 4)
+        return Act(self.buf(tag, B * H * W * ld), B, H, W, Cc, ld)
+
+    # ------------------------------------------------------------------ kernel wrappers
+    def conv(self, x: Act, w: ConvW, out: Act, *, stride=1, pad=0, pad_mode=N.PAD_ZERO, act=N.ACT_NONE, out_coff=0,
+             n_store=None, res: Optional[Act] = None, in2: Optional[Act] = None, w2: Optional[ConvW] = None,
+             a_scale=None, a_scale_ld=0, a_shift=None, geom=None, tile_hint=0):
+        d = N.ConvDesc()
+        if geom is None:
+            sh = sw = stride
+            ph = pw = pad
+            H, W, sx = x.H, x.W, x.ld
+            cin = x.ld
+        else:           # patch conv: (W', sx, cin, sh, sw, ph, pw)
+            W, sx, cin, sh, sw, ph, pw = geom
+            H = x.H
+        d.inp = N.ptr(x.t)
+        d.in_sb, d.in_sy, d.in_sx = x.H * x.W * x.ld, x.W * x.ld, sx
+        d.B, d.H, d.W, d.Cin = x.B, H, W, cin
+        d.KH, d.KW, d.SH, d.SW, d.PH, d.PW, d.pad_mode = w.KH, w.KW, sh, sw, ph, pw, pad_mode
+        d.Ho, d.Wo = out.H, out.W
+        d.wt, d.CinP, d.N = N.ptr(w.wt), w.CinP, w.N
+        d.a_scale, d.a_scale_ld, d.a_shift = N.ptr(a_scale), a_scale_ld, N.ptr(a_shift)
+        d.bias, d.act = N.ptr(w.bias), act
+        d.n_store = n_store if n_store is not None else (out.ld - out_coff if out_coff == 0 else w.N)
+        if res is not None:
+            d.res, d.res_ld = N.ptr(res.t), res.ld
+        if in2 is not None:
+            d.in2, d.in2_ld, d.Cin2, d.Cin2P = N.ptr(in2.t), in2.ld, in2.ld, w2.CinP
+            d.wt2, d.bias2 = N.ptr(w2.wt), N.ptr(w2.bias)
+        d.out, d.out_ld, d.out_coff, d.tile_hint = N.ptr(out.t), out.ld, out_coff, tile_hint
+        N.check(self.lib.vs_conv_gemm(C.byref(d), N.stream()), "vs_conv_gemm")
+        return out
+
+    def layernorm(self, x: Act, w, b, out: Act, act=N.ACT_NONE):
+        N.check(self.lib.vs_layernorm_act(N.ptr(x.t), x.rows, x.C, x.ld, N.ptr(w), N.ptr(b), 1e-6, act, N.ptr(out.t), out.ld,
+                                          N.stream()), "vs_layernorm_act")
+        return out
+
+    def resblock(self, x: Act, p, tag: str, out: Optional[Act] = None, out_coff=0) -> Act:
+        """unet.py:38-39  relu(bn(conv(relu(bn(conv(x)))))) + res_conv(x); the 1x1 rides in the 2nd conv's K loop."""
+        cout = p["cout"]
+        t = self.new_act(tag + ".t", x.B, x.H, x.W, cout)
+        self.conv(x, p["c0"], t, pad=1, act=N.ACT_RELU)
+        if out is None:
+            out = self.new_act(tag + ".o", x.B, x.H, x.W, cout)
+        self.conv(t, p["c1"], out, pad=1, act=N.ACT_RELU, in2=x, w2=p["res"], out_coff=out_coff,
+                  n_store=(cout if out.ld != rup(cout, 4) else None))
+        return out
+
+    # ------------------------------------------------------------------ embedder
+    def embedder_forward(self, x: Act, msgs_i32: torch.Tensor) -> torch.Tensor:
+        """x: key frames, NHWC(ld 4), already mapped to [-1,1]. Returns delta [B][out_ch][S_h][S_w] (planar)."""
+        c, E, L = self.cfg, self.E, self.lib
+        B = x.B
+        st = N.stream()
+        hid: List[Act] = [self.resblock(x, E["inc"], "inc")]
+        nlev = len(c.zc) - 1
+        for i in range(nlev):
+            src = hid[-1]
+            Ho, Wo = (src.H - 1) // 2 + 1, (src.W - 1) // 2 + 1
+            dwn = self.new_act(f"down{i}.d", B, Ho, Wo, c.zc[i + 1])
+            self.conv(src, E["downs"][i]["down"], dwn, stride=2, pad=1)
+            if i == nlev - 1:     # last level lands in the message-augmented latent [lat | msg]
+                h3 = self.new_act("h3", B, Ho, Wo, c.bott)
+                self.resblock(dwn, E["downs"][i]["rb"], f"down{i}", out=h3)
+                hid.append(h3)
+            else:
+                hid.append(self.resblock(dwn, E["downs"][i]["rb"], f"down{i}"))
+        h3 = hid[-1]
+        Bm = msgs_i32.shape[0]
+        lat = self.buf("msg.lat", Bm * c.hidden)
+        N.check(L.vs_msg_latent(N.ptr(E["table"]), N.ptr(msgs_i32), Bm, c.nbits, c.hidden, N.ptr(lat), st), "vs_msg_latent")
+        N.check(L.vs_broadcast_channels(N.ptr(lat), Bm, c.hidden, N.ptr(h3.t), B, h3.H * h3.W, h3.ld, c.zc[-1], st),
+                "vs_broadcast_channels")
+        xcur = h3
+        for j in range(c.num_blocks):
+            xcur = self.resblock(xcur, E["bott"][j], f"bott{j & 1}")
+        for k in range(nlev):
+            skip = hid.pop()
+            up = E["ups"][k]
+            cat = self.new_act(f"up{k}.cat", B, 2 * xcur.H, 2 * xcur.W, xcur.C + skip.C)
+            N.check(L.vs_upcat2x(N.ptr(xcur.t), xcur.C, xcur.ld, N.ptr(skip.t), skip.C, skip.ld, 2 ** -0.5, B, xcur.H, xcur.W,
+                                 N.ptr(cat.t), cat.ld, st), "vs_upcat2x")
+            cv = self.new_act(f"up{k}.conv", B, cat.H, cat.W, up["conv"].N)
+            self.conv(cat, up["conv"], cv, pad=1, pad_mode=N.PAD_REFLECT)
+            ln = self.new_act(f"up{k}.ln", B, cat.H, cat.W, up["conv"].N)
+            self.layernorm(cv, up["lnw"], up["lnb"], ln, act=N.ACT_RELU)
+            xcur = self.resblock(ln, up["rb"], f"up{k}")
+        delta = self.buf("delta", B * c.out_ch * xcur.H * xcur.W)
+        N.check(L.vs_outc_tanh(N.ptr(xcur.t), xcur.H * xcur.W, B, xcur.C, xcur.ld, N.ptr(E["outc_w"]), N.ptr(E["outc_b"]), c.out_ch,
+                               1 if c.last_tanh else 0, N.ptr(delta), st), "vs_outc_tanh")
+        return delta.view(B, c.out_ch, xcur.H, xcur.W)
+
+    # ------------------------------------------------------------------ extractor
+    def extractor_forward(self, x: Act) -> torch.Tensor:
+        """x: NHWC(ld 4) RGB already mapped to [-1,1]. Returns logits [B][1+nbits]."""
+        c, X, L = self.cfg, self.X, self.lib
+        st = N.stream()
+        B = x.B
+        s = c.stem_stride
+        Ho, Wo = (x.H - 4) // s + 1, (x.W - 4) // s + 1
+        d = c.dims
+        t = self.new_act("stem.c", B, Ho, Wo, d[0])
+        self.conv(x, X["stem"], t, geom=(Wo, s * 4, 16, s, 1, 0, 0))
+        cur = self.new_act("st0.x", B, Ho, Wo, d[0])
+        self.layernorm(t, X["stem_ln"][0], X["stem_ln"][1], cur)
+        for sti in range(4):
+            if sti > 0:
+                dn = X["down"][sti - 1]
+                ln = self.new_act(f"st{sti}.dln", B, cur.H, cur.W, cur.C)
+                self.layernorm(cur, dn["lnw"], dn["lnb"], ln)
+                Ho, Wo = cur.H // 2, cur.W // 2
+                nxt = self.new_act(f"st{sti}.x", B, Ho, Wo, d[sti])
+                self.conv(ln, dn["conv"], nxt, geom=(Wo, 2 * ln.ld, 2 * ln.ld, 2, 1, 0, 0))
+                cur = nxt
+            Cc = d[sti]
+            HW = cur.H * cur.W
+            tn = self.new_act(f"st{sti}.n", B, cur.H, cur.W, Cc)
+            hh = self.new_act(f"st{sti}.h", B, cur.H, cur.W, 4 * Cc)
+            nchunk = (HW + 63) // 64
+            part = self.buf(f"st{sti}.gp", nchunk * B * 4 * Cc)
+            scale = self.buf(f"st{sti}.gs", B * hh.ld)
+            for blk in X["stages"][sti]:
+                N.check(L.vs_dwconv7_ln(N.ptr(cur.t), B, cur.H, cur.W, Cc, cur.ld, N.ptr(blk["wdw"]), N.ptr(blk["bdw"]), N.ptr(blk["lnw"]),
+                                        N.ptr(blk["lnb"]), 1e-6, N.ptr(tn.t), tn.ld, st), "vs_dwconv7_ln")
+                self.conv(tn, blk["pw1"], hh, act=N.ACT_GELU)
+                N.check(L.vs_grn_scale(N.ptr(hh.t), B, HW, 4 * Cc, hh.ld, N.ptr(blk["gamma"]), N.ptr(part), N.ptr(scale), st),
+                        "vs_grn_scale")
+                self.conv(hh, blk["pw2"], cur, res=cur, a_scale=scale, a_scale_ld=hh.ld, a_shift=blk["beta"])
+        hc = self.new_act("head.c", B, cur.H, cur.W, d[-1])
+        self.conv(cur, X["head_conv"], hc, pad=1, pad_mode=N.PAD_REFLECT)
+        hl = self.new_act("head.l", B, cur.H, cur.W, d[-1])
+        self.layernorm(hc, X["head_ln"][0], X["head_ln"][1], hl, act=N.ACT_GELU)
+        out = torch.empty(B, c.nbits + 1, device=self.dev, dtype=torch.float32)
+        N.check(L.vs_pool_linear(N.ptr(hl.t), B, hl.H * hl.W, hl.C, hl.ld, N.ptr(X["lin_w"]), N.ptr(X["lin_b"]), c.nbits + 1, N.ptr(out), st),
+                "vs_pool_linear")
+        return out
+
+    # ------------------------------------------------------------------ shell
+    def resize_pre(self, imgs: torch.Tensor, S: Tuple[int, int], antialias: bool, *, want_rgb: bool, mul=1.0, add=0.0,
+                   want_key: bool = False, key_step: int = 1, tag="rs") -> Tuple[Optional[Act], Optional[Act]]:
+        """imgs NCHW on device -> (rgb Act [B,S,S,4] or None, key Act [ceil(B/step),S,S,4] or None)."""
+        B, Cc, H, W = imgs.shape
+        rgb = self.new_act(tag + ".rgb", B, S[0], S[1], 3, 4) if want_rgb else None
+        nk = (B + key_step - 1) // key_step
+        key = self.new_act(tag + ".key", nk, S[0], S[1], self.cfg.in_ch, 4) if want_key else None
+        ymat = self.ymat if self.cfg.yuv else None
+        N.check(self.lib.vs_resize_pre(N.ptr(imgs), B, Cc, H, W, S[0], S[1], 1 if antialias else 0, N.ptr(rgb.t) if rgb else None,
+                                       mul, add, N.ptr(key.t) if key else None, key_step, ymat, N.stream()), "vs_resize_pre")
+        return rgb, key
+
+    def jnd_lowres(self, rgb: Act) -> torch.Tensor:
+        h = self.buf("jnd.low", rgb.B * rgb.H * rgb.W)
+        N.check(self.lib.vs_jnd_heatmap(N.ptr(rgb.t), rgb.B, rgb.H, rgb.W, rgb.H * rgb.W * rgb.ld, 1, rgb.W * rgb.ld, rgb.ld,
+                                        self.taps43, N.ptr(h), N.stream()), "vs_jnd_heatmap")
+        return h
+
+    def jnd_full(self, imgs: torch.Tensor) -> torch.Tensor:
+        B, _, H, W = imgs.shape
+        h = torch.empty(B, 1, H, W, device=self.dev, dtype=torch.float32)
+        N.check(self.lib.vs_jnd_heatmap(N.ptr(imgs), B, H, W, 3 * H * W, H * W, W, 1, self.taps43, N.ptr(h), N.stream()),
+                "vs_jnd_heatmap")
+        return h
+
+    def embed_tail(self, imgs, out, delta, *, step, video_mode, hmap_low, attenuate, clamp, antialias, scaling_i, scaling_w,
+                   preds_w=None):
+        d = N.TailDesc()
+        F_, _, H, W = imgs.shape
+        d.imgs, d.out, d.preds_w = N.ptr(imgs), N.ptr(out), N.ptr(preds_w)
+        d.delta, d.hmap_lowres = N.ptr(delta), N.ptr(hmap_low)
+        d.taps43 = C.cast(self.taps43, C.c_void_p)
+        d.F, d.H, d.W, d.S_h, d.S_w, d.Cd = F_, H, W, delta.shape[-2], delta.shape[-1], delta.shape[1]
+        d.step, d.video_mode, d.total_key = step, video_mode, delta.shape[0]
+        d.attenuate, d.clamp, d.antialias = int(attenuate), int(clamp), int(antialias)
+        d.scaling_i, d.scaling_w = float(scaling_i), float(scaling_w)
+        N.check(self.lib.vs_embed_tail(C.byref(d), N.stream()), "vs_embed_tail")

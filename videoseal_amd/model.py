@@ -1,0 +1,384 @@
+"""The ``Videoseal`` nn.Module surface on top of the HIP engine.
+
+Drop-in boundary: same constructor products, attributes, method signatures, state_dict
+keys and error behaviour as the reference's ``videoseal.models.Videoseal`` (models/videoseal.py:15-428,
+models/wam.py:18-234) for the inference path ``embed / detect / extract_message`` plus the forward-only
+``forward``; all arithmetic runs in hand-written gfx950 kernels (engine.py -> native.py -> csrc/).
+
+Deliberate differences, each loud rather than silent:
+  * no CPU / ATen execution path: the model must live on a ROCm device (``.to('cuda')``) and in ``.eval()``
+    mode (batch-statistics BatchNorm and autograd are the training row);
+  * frames handed over on the CPU are copied to the model's device, processed there end to end and the
+    results are copied back to ``imgs.device`` (the reference keeps the full-resolution shell on the CPU).
+"""
+from __future__ import annotations
+
+from typing import Dict, Optional
+
+import torch
+import torch.nn as nn
+
+from . import native as N
+from .engine import Act, HipEngine
+from .layout import ModelCfg, build_tree, detector_entries, embedder_entries
+
+_DEFAULT_INTERP = {"mode": "bilinear", "align_corners": False, "antialias": True}
+
+
+def _antialias_flag(interpolation: Optional[dict]) -> bool:
+    it = dict(_DEFAULT_INTERP if interpolation is None else interpolation)
+    if it.get("mode", "bilinear") != "bilinear" or it.get("align_corners", False):
+        raise NotImplementedError(f"interpolation {it}: the HIP path implements mode='bilinear', align_corners=False "
+                                  f"(antialias True/False)")
+    return bool(it.get("antialias", False))
+
+
+class _EngineOwner:
+    """Lazily (re)builds the packed-weight engine when parameters, device or mode change."""
+
+    def _engine_for(self, root: "Wam") -> HipEngine:
+        return root._engine()
+
+
+class Embedder(nn.Module):
+    """``model.embedder(imgs01, msgs) -> delta`` (models/embedder.py:130-165).  Holds ``unet`` / ``msg_processor``
+    parameter trees; ``yuv`` tells Wam to feed the Y channel (embedder.py:281)."""
+
+    def __init__(self, cfg: ModelCfg, seed: int = 0):
+        super().__init__()
+        tree = build_tree(embedder_entries(cfg), seed)
+        self.unet = tree.unet
+        self.msg_processor = tree.msg_processor
+        self.cfg = cfg
+        self.yuv = cfg.yuv
+        self._root = None      # set by Wam (plain attribute holder, avoids a module cycle)
+
+    def get_random_msg(self, bsz: int = 1, nb_repetitions: int = 1) -> torch.Tensor:
+        k = self.cfg.nbits                                   # msg_processor.py:45-59
+        if nb_repetitions != 1:
+            assert k % nb_repetitions == 0, f"nbits must be divisible by nb_repetitions, got {k} and {nb_repetitions}"
+            aux = torch.randint(0, 2, (bsz, k // nb_repetitions))
+            return aux.unsqueeze(1).repeat(1, nb_repetitions, 1).view(bsz, k)
+        return torch.randint(0, 2, (bsz, k))
+
+    def get_last_layer(self) -> torch.Tensor:
+        return self.unet.outc.weight                         # embedder.py:147-149
+
+    def forward(self, imgs: torch.Tensor, msgs: torch.Tensor) -> torch.Tensor:
+        root = self._root[0]
+        eng = root._engine()
+        x = N.f32c(imgs.to(eng.dev))
+        B, Cc, H, W = x.shape
+        if Cc != self.cfg.in_ch:
+            raise ValueError(f"embedder expects {self.cfg.in_ch} input channel(s), got {Cc}")
+        ident = (1.0, 0.0, 0.0)
+        import ctypes as C
+        key = eng.new_act("emb.in", B, H, W, Cc, 4)
+        ymat = (C.c_float * 3)(*ident) if Cc == 1 else None
+        N.check(eng.lib.vs_resize_pre(N.ptr(x), B, Cc, H, W, H, W, 0, None, 1.0, 0.0, N.ptr(key.t), 1, ymat, N.stream()), "vs_resize_pre")
+        delta = eng.embedder_forward(key, _msgs_i32(msgs, eng.dev))
+        return delta.clone().to(imgs.device)
+
+
+class Extractor(nn.Module):
+    """``model.detector(imgs01) -> logits [b, 1+nbits]`` (models/extractor.py:140-167)."""
+
+    def __init__(self, cfg: ModelCfg, seed: int = 0):
+        super().__init__()
+        tree = build_tree(detector_entries(cfg), seed + 1)
+        self.convnext = tree.convnext
+        self.pixel_decoder = tree.pixel_decoder
+        self.cfg = cfg
+        self._root = None
+
+    def forward(self, imgs: torch.Tensor) -> torch.Tensor:
+        root = self._root[0]
+        eng = root._engine()
+        x = N.f32c(imgs.to(eng.dev))
+        rgb, _ = eng.resize_pre(x, (x.shape[-2], x.shape[-1]), False, want_rgb=True, mul=2.0, add=-1.0, tag="det.in")
+        return eng.extractor_forward(rgb).to(imgs.device)
+
+
+class Blender(nn.Module):
+    """models/blender.py:12-68: only the additive mode is used by the released cards."""
+    AVAILABLE_BLENDING_METHODS = ["additive"]
+
+    def __init__(self, scaling_i: float, scaling_w: float, method: str = "additive"):
+        super().__init__()
+        if method != "additive":
+            raise NotImplementedError(f"blending method '{method}': only 'additive' is implemented in the HIP path")
+        self.method, self.scaling_i, self.scaling_w = method, scaling_i, scaling_w
+
+
+class RGB2YUV(nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.register_buffer("M", torch.tensor([[0.299, 0.587, 0.114], [-0.14713, -0.28886, 0.436], [0.615, -0.51499, -0.10001]],
+                                               dtype=torch.float32))
+
+
+class _Kernel2d(nn.Module):
+    def __init__(self, k):
+        super().__init__()
+        self.weight = nn.Parameter(k, requires_grad=False)
+
+
+class JND(nn.Module):
+    """modules/jnd.py:11-114 parameter holder (frozen 3x3 Sobel / 5x5 luminance taps live in the state_dict);
+    ``heatmaps`` runs the HIP kernel."""
+
+    def __init__(self, in_channels: int = 1, out_channels: int = 3):
+        super().__init__()
+        if (in_channels, out_channels) != (1, 1):
+            raise NotImplementedError("JND: only in_channels=1, out_channels=1 (jnd_1_1, used by every released card)")
+        self.in_channels, self.out_channels = in_channels, out_channels
+        kx = torch.tensor([[-1., 0., 1.], [-2., 0., 2.], [-1., 0., 1.]])
+        ky = torch.tensor([[1., 2., 1.], [0., 0., 0.], [-1., -2., -1.]])
+        kl = torch.tensor([[1., 1., 1., 1., 1.], [1., 2., 2., 2., 1.], [1., 2., 0., 2., 1.], [1., 2., 2., 2., 1.], [1., 1., 1., 1., 1.]])
+        self.conv_x = _Kernel2d(kx[None, None].repeat(in_channels, 1, 1, 1))
+        self.conv_y = _Kernel2d(ky[None, None].repeat(in_channels, 1, 1, 1))
+        self.conv_lum = _Kernel2d(kl[None, None].repeat(in_channels, 1, 1, 1))
+        self._root = None
+
+    def heatmaps(self, imgs: torch.Tensor, clc: float = 0.3) -> torch.Tensor:
+        if clc != 0.3:
+            raise NotImplementedError("clc != 0.3")
+        eng = self._root[0]._engine()
+        return eng.jnd_full(N.f32c(imgs.to(eng.dev))).to(imgs.device)
+
+
+class IdentityAugmenter(nn.Module):
+    """augmentation/augmenter.py get_dummy_augmenter(): returns the watermarked frames unchanged."""
+
+    def forward(self, imgs_w, imgs, masks, is_video=True, do_resize=True):
+        return imgs_w, masks, "identity"
+
+
+def _msgs_i32(msgs: torch.Tensor, dev) -> torch.Tensor:
+    m = msgs.to(dev)
+    if m.is_floating_point():
+        m = m.long()            # msg_processor.py:92 `(indices + msg).long()` truncation
+    return m.to(torch.int32).contiguous()
+
+
+class Wam(nn.Module):
+    """Image path (models/wam.py:18-234)."""
+
+    def __init__(self, embedder: Embedder, detector: Extractor, augmenter: nn.Module, attenuation: Optional[JND] = None,
+                 scaling_w: float = 1.0, scaling_i: float = 1.0, clamp: bool = True, img_size: int = 256,
+                 blending_method: str = "additive") -> None:
+        super().__init__()
+        self.embedder, self.detector, self.augmenter = embedder, detector, augmenter
+        self.img_size = img_size
+        self.rgb2yuv = RGB2YUV()
+        self.blender = Blender(scaling_i, scaling_w, blending_method)
+        self.attenuation = attenuation
+        self.clamp = clamp
+        self._eng: Optional[HipEngine] = None
+        self._eng_key = None
+        holder = [self]
+        embedder._root = detector._root = holder
+        if attenuation is not None:
+            attenuation._root = holder
+
+    # ---- plumbing
+    @property
+    def device(self):
+        return next(self.parameters()).device
+
+    def get_random_msg(self, bsz: int = 1, nb_repetitions=1) -> torch.Tensor:
+        return self.embedder.get_random_msg(bsz, nb_repetitions)
+
+    def _engine(self) -> HipEngine:
+        dev = self.device
+        if dev.type != "cuda":
+            raise N.NativeError("Videoseal (MI355X build) has no CPU execution path: move the model to a ROCm device "
+                                "with .to('cuda') before embed()/detect().")
+        if self.training:
+            raise NotImplementedError("the HIP path implements inference (folded BatchNorm): call model.eval() first; "
+                                      "batch-statistics BatchNorm / backward are not implemented yet")
+        key = (str(dev), sum(p._version for p in self.parameters()) + sum(b._version for b in self.buffers()),
+               tuple(id(p) for p in list(self.parameters())[:4]))
+        if self._eng is None or self._eng_key != key:
+            self._eng = HipEngine(self.embedder.cfg, self.state_dict(), dev)
+            self._eng_key = key
+        return self._eng
+
+    def repack(self) -> None:
+        """Force re-packing of the weights (after in-place edits that bypass tensor versioning)."""
+        self._eng = None
+
+    # ---- core of embed: one chunk of frames on the device
+    def _embed_frames(self, eng: HipEngine, fr: torch.Tensor, msgs_i32: torch.Tensor, out: torch.Tensor, *, step: int,
+                      video_mode: int, antialias: bool, lowres: bool, preds_w: Optional[torch.Tensor] = None) -> None:
+        S = (self.img_size, self.img_size)
+        att = self.attenuation is not None
+        rgb, key = eng.resize_pre(fr, S, antialias, want_rgb=(att and lowres), want_key=True, key_step=step)
+        delta = eng.embedder_forward(key, msgs_i32)
+        hmap = eng.jnd_lowres(rgb) if (att and lowres) else None
+        eng.embed_tail(fr, out, delta, step=step, video_mode=video_mode, hmap_low=hmap, attenuate=att, clamp=self.clamp,
+                       antialias=antialias, scaling_i=self.blender.scaling_i, scaling_w=self.blender.scaling_w, preds_w=preds_w)
+
+    @torch.no_grad()
+    def embed(self, imgs: torch.Tensor, msgs: torch.Tensor = None, interpolation: dict = None,
+              lowres_attenuation: bool = False) -> dict:
+        """wam.py:134-204."""
+        if msgs is None:
+            msgs = self.get_random_msg(imgs.shape[0])
+        eng = self._engine()
+        aa = _antialias_flag(interpolation)
+        x = N.f32c(imgs.to(eng.dev))
+        B = x.shape[0]
+        if msgs.shape[0] != B:
+            raise ValueError(f"msgs has {msgs.shape[0]} rows for {B} images")
+        out = torch.empty_like(x)
+        cd = self.embedder.cfg.out_ch
+        preds_w = torch.empty(B, cd, x.shape[-2], x.shape[-1], device=eng.dev, dtype=torch.float32)
+        mi = _msgs_i32(msgs, eng.dev)
+        ck = max(1, int(getattr(self, "chunk_size", 32)))
+        for a in range(0, B, ck):
+            b = min(B, a + ck)
+            self._embed_frames(eng, x[a:b], mi[a:b], out[a:b], step=1, video_mode=0, antialias=aa, lowres=lowres_attenuation,
+                               preds_w=preds_w[a:b])
+        return {"msgs": msgs, "preds_w": preds_w.to(imgs.device), "imgs_w": out.to(imgs.device)}
+
+    @torch.no_grad()
+    def detect(self, imgs: torch.Tensor, interpolation: dict = None) -> dict:
+        """wam.py:206-234."""
+        eng = self._engine()
+        aa = _antialias_flag(interpolation)
+        x = N.f32c(imgs.to(eng.dev))
+        rgb, _ = eng.resize_pre(x, (self.img_size, self.img_size), aa, want_rgb=True, mul=2.0, add=-1.0, tag="det.in")
+        return {"preds": eng.extractor_forward(rgb).to(imgs.device)}
+
+    @torch.no_grad()
+    def forward(self, imgs: torch.Tensor, masks: torch.Tensor, msgs: torch.Tensor = None, interpolation: dict = None) -> dict:
+        """wam.py:68-132, forward-only (no autograd): embed (full-res attenuation) -> augment -> detect."""
+        if msgs is None:
+            msgs = self.get_random_msg(imgs.shape[0]).to(imgs.device)
+        if self.blender.scaling_i != 1.0 and self.attenuation is not None:
+            raise NotImplementedError("forward() with scaling_i != 1 and JND attenuation")
+        emb = self.embed(imgs, msgs, interpolation, lowres_attenuation=False)
+        imgs_aug, masks, selected = self.augmenter(emb["imgs_w"], imgs, masks, is_video=False, do_resize=False)
+        preds = self.detect(imgs_aug, interpolation)["preds"]
+        return {"msgs": msgs, "masks": masks, "preds_w": emb["preds_w"], "imgs_w": emb["imgs_w"], "imgs_aug": imgs_aug,
+                "preds": preds, "selected_aug": selected}
+
+
+class Videoseal(Wam):
+    """Video path (models/videoseal.py:15-428): key-frame stepping, chunking, frame aggregation."""
+
+    def __init__(self, embedder, detector, augmenter, attenuation=None, scaling_w: float = 1.0, scaling_i: float = 1.0,
+                 img_size: int = 256, clamp: bool = True, chunk_size: int = 8, step_size: int = 4,
+                 blending_method: str = "additive", video_mode: str = "repeat", lowres_attenuation: bool = False) -> None:
+        super().__init__(embedder, detector, augmenter, attenuation, scaling_w, scaling_i, clamp, img_size, blending_method)
+        self.chunk_size, self.step_size = chunk_size, step_size
+        self.video_mode = video_mode
+        self.lowres_attenuation = lowres_attenuation
+
+    @torch.no_grad()
+    def embed(self, imgs: torch.Tensor, msgs: torch.Tensor = None, is_video: bool = True, interpolation: dict = None,
+              lowres_attenuation: bool = False) -> dict:
+        """videoseal.py:258-350."""
+        if not is_video:
+            return super().embed(imgs, msgs, interpolation, lowres_attenuation)
+        if msgs is None:
+            msgs = self.get_random_msg()
+        else:
+            assert msgs.shape[0] == 1, "Message should be unique"
+        if self.video_mode not in N.VIDEO_MODES:
+            raise ValueError(f"unknown video_mode {self.video_mode}")
+        eng = self._engine()
+        aa = _antialias_flag(interpolation)
+        x = N.f32c(imgs.to(eng.dev))
+        out = torch.empty_like(x)
+        mi = _msgs_i32(msgs, eng.dev)
+        step, ck = int(self.step_size), int(self.chunk_size)
+        span = ck * step                      # frames per chunk (videoseal.py:292-297)
+        for a in range(0, x.shape[0], span):
+            b = min(x.shape[0], a + span)
+            self._embed_frames(eng, x[a:b], mi, out[a:b], step=step, video_mode=N.VIDEO_MODES[self.video_mode], antialias=aa,
+                               lowres=lowres_attenuation)
+        return {"imgs_w": out.to(imgs.device), "msgs": msgs[0:1].repeat(len(imgs), 1)}
+
+    @torch.no_grad()
+    def detect(self, imgs: torch.Tensor, is_video: bool = True, interpolation: dict = None) -> dict:
+        """videoseal.py:352-388."""
+        if not is_video:
+            return super().detect(imgs) if interpolation is None else super().detect(imgs, interpolation)
+        eng = self._engine()
+        aa = _antialias_flag(interpolation)
+        x = N.f32c(imgs.to(eng.dev))
+        S = (self.img_size, self.img_size)
+        preds = []
+        ck = max(1, int(self.chunk_size))
+        for a in range(0, x.shape[0], ck):
+            rgb, _ = eng.resize_pre(x[a:a + ck], S, aa, want_rgb=True, mul=2.0, add=-1.0, tag="det.in")
+            preds.append(eng.extractor_forward(rgb))
+        return {"preds": torch.cat(preds, dim=0).to(imgs.device)}
+
+    def extract_message(self, imgs: torch.Tensor, aggregation: str = "avg",
+                        interpolation: dict = {"mode": "bilinear", "align_corners": False, "antialias": False}) -> torch.Tensor:
+        """videoseal.py:390-428."""
+        preds = self.detect(imgs, is_video=True, interpolation=interpolation)["preds"]
+        bit_preds = preds[:, 1:]
+        decoded = aggregate_bits(bit_preds, aggregation)
+        return (decoded > 0).squeeze().unsqueeze(0)
+
+    @torch.no_grad()
+    def forward(self, imgs: torch.Tensor, masks: torch.Tensor, msgs: torch.Tensor = None, is_video: bool = True):
+        """videoseal.py:120-256, forward-only."""
+        assert not (is_video and len(imgs.shape) not in [4, 5]), \
+            "If is_video is True, input shape should be [b, frames, c, h, w] or [frames, c, h, w]"
+        assert not (not is_video and len(imgs.shape) != 4), "If is_video is False, input shape should be [b, c, h, w]"
+        if not is_video:
+            return super().forward(imgs, masks, msgs)
+        if imgs.dim() == 5:
+            return [self.video_forward(imgs[i], masks[i] if masks is not None else None, msgs[i] if msgs is not None else None)
+                    for i in range(imgs.shape[0])]
+        return self.video_forward(imgs, masks, msgs)
+
+    @torch.no_grad()
+    def video_forward(self, imgs, masks, msgs=None, interpolation: dict = None) -> dict:
+        """videoseal.py:163-256: whole clip in one chunk, key frames every step_size."""
+        if msgs is None:
+            msgs = self.get_random_msg()
+        else:
+            assert msgs.shape[0] == 1, "Message should be unique"
+        msgs = msgs.to(imgs.device)
+        eng = self._engine()
+        aa = _antialias_flag(interpolation)
+        x = N.f32c(imgs.to(eng.dev))
+        out = torch.empty_like(x)
+        self._embed_frames(eng, x, _msgs_i32(msgs, eng.dev), out, step=int(self.step_size),
+                           video_mode=N.VIDEO_MODES[self.video_mode], antialias=aa, lowres=bool(self.lowres_attenuation))
+        imgs_w = out.to(imgs.device)
+        imgs_aug, masks, selected = self.augmenter(imgs_w, imgs, masks, is_video=True, do_resize=False)
+        rgb, _ = eng.resize_pre(N.f32c(imgs_aug.to(eng.dev)), (self.img_size, self.img_size), aa, want_rgb=True, mul=2.0, add=-1.0,
+                                tag="det.in")
+        preds = eng.extractor_forward(rgb).to(imgs.device)
+        return {"msgs": msgs.expand(imgs.shape[0], -1), "masks": masks, "imgs_w": imgs_w, "imgs_aug": imgs_aug, "preds": preds,
+                "selected_aug": selected}
+
+
+def aggregate_bits(bit_preds: torch.Tensor, aggregation: Optional[str]) -> torch.Tensor:
+    """Frame aggregation of videoseal.py:411-426 (tiny [F,k] reduction, plain torch on the caller's device)."""
+    if aggregation is None:
+        return bit_preds
+    if aggregation == "avg":
+        return bit_preds.mean(dim=0)
+    if aggregation == "squared_avg":
+        return (bit_preds * bit_preds.abs()).mean(dim=0)
+    if aggregation == "l1norm_avg":
+        return (bit_preds * torch.norm(bit_preds, p=1, dim=1).unsqueeze(1)).mean(dim=0)
+    if aggregation == "l2norm_avg":
+        return (bit_preds * torch.norm(bit_preds, p=2, dim=1).unsqueeze(1)).mean(dim=0)
+    raise ValueError(f"unknown aggregation {aggregation}")
+
+
+def build_model(cfg: ModelCfg, seed: int = 0) -> Videoseal:
+    """cfg.py:120-144: embedder + extractor + identity augmenter + JND -> Videoseal (train mode, CPU, like the reference)."""
+    return Videoseal(Embedder(cfg, seed), Extractor(cfg, seed), IdentityAugmenter(),
+                     attenuation=JND(in_channels=cfg.jnd_in, out_channels=cfg.jnd_out), scaling_w=cfg.scaling_w,
+                     scaling_i=cfg.scaling_i, img_size=cfg.img_size, chunk_size=cfg.chunk_size, step_size=cfg.step_size,
+                     blending_method=cfg.blending_method)

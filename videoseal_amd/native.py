@@ -1,0 +1,122 @@
+"""ctypes binding of libvideoseal_hip.so (the C-ABI declared in include/videoseal_hip.h).
+
+This is the stub a maintainer of the reference would add to call the MI355X kernels
+(INTEGRATION.md).  There is NO fallback: if the shared library is missing or an entry
+point fails, the call raises -- the product path never silently runs on ATen / CPU.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libvideoseal_hip.so")
+
+ACT_NONE, ACT_RELU, ACT_GELU, ACT_TANH = 0, 1, 2, 3
+PAD_ZERO, PAD_REFLECT = 0, 1
+VIDEO_MODES = {"repeat": 0, "alternate": 1, "interpolate": 2}
+
+EXPORTS = [
+    "vs_version", "vs_arch", "vs_error_string", "vs_conv_gemm", "vs_layernorm_act", "vs_dwconv7_ln", "vs_grn_scale",
+    "vs_upcat2x", "vs_msg_latent", "vs_broadcast_channels", "vs_outc_tanh", "vs_pool_linear", "vs_resize_pre",
+    "vs_jnd_heatmap", "vs_embed_tail",
+]
+
+
+class NativeError(RuntimeError):
+    pass
+
+
+class ConvDesc(C.Structure):
+    """mirror of vs_conv_desc_t"""
+    _fields_ = [
+        ("inp", C.c_void_p), ("in_sb", C.c_int64), ("in_sy", C.c_int64), ("in_sx", C.c_int64),
+        ("B", C.c_int32), ("H", C.c_int32), ("W", C.c_int32), ("Cin", C.c_int32),
+        ("KH", C.c_int32), ("KW", C.c_int32), ("SH", C.c_int32), ("SW", C.c_int32), ("PH", C.c_int32), ("PW", C.c_int32),
+        ("pad_mode", C.c_int32), ("Ho", C.c_int32), ("Wo", C.c_int32),
+        ("wt", C.c_void_p), ("CinP", C.c_int32), ("N", C.c_int32),
+        ("a_scale", C.c_void_p), ("a_scale_ld", C.c_int64), ("a_shift", C.c_void_p),
+        ("bias", C.c_void_p), ("act", C.c_int32), ("n_store", C.c_int32),
+        ("res", C.c_void_p), ("res_ld", C.c_int64),
+        ("in2", C.c_void_p), ("in2_ld", C.c_int64), ("Cin2", C.c_int32), ("Cin2P", C.c_int32),
+        ("wt2", C.c_void_p), ("bias2", C.c_void_p),
+        ("out", C.c_void_p), ("out_ld", C.c_int64), ("out_coff", C.c_int32), ("tile_hint", C.c_int32),
+    ]
+
+
+class TailDesc(C.Structure):
+    """mirror of vs_tail_desc_t"""
+    _fields_ = [
+        ("imgs", C.c_void_p), ("out", C.c_void_p), ("preds_w", C.c_void_p),
+        ("delta", C.c_void_p), ("hmap_lowres", C.c_void_p), ("taps43", C.c_void_p),
+        ("F", C.c_int32), ("H", C.c_int32), ("W", C.c_int32), ("S_h", C.c_int32), ("S_w", C.c_int32), ("Cd", C.c_int32),
+        ("step", C.c_int32), ("video_mode", C.c_int32), ("total_key", C.c_int32),
+        ("attenuate", C.c_int32), ("clamp", C.c_int32), ("antialias", C.c_int32),
+        ("scaling_i", C.c_float), ("scaling_w", C.c_float),
+    ]
+
+
+_lib: Optional[C.CDLL] = None
+
+
+def lib() -> C.CDLL:
+    """Load the shared library once; raise loudly if it is not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise NativeError(f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                          f"(or `make -C videoseal_amd/csrc`). There is no CPU/ATen fallback for the VideoSeal hot path.")
+    L = C.CDLL(LIB_PATH)
+    L.vs_version.restype = C.c_int
+    L.vs_arch.restype = C.c_char_p
+    L.vs_error_string.restype = C.c_char_p
+    L.vs_error_string.argtypes = [C.c_int]
+    P, I, I64, F = C.c_void_p, C.c_int, C.c_int64, C.c_float
+    sig = {
+        "vs_conv_gemm": [C.POINTER(ConvDesc), P],
+        "vs_layernorm_act": [P, I64, I, I64, P, P, F, I, P, I64, P],
+        "vs_dwconv7_ln": [P, I, I, I, I, I64, P, P, P, P, F, P, I64, P],
+        "vs_grn_scale": [P, I, I, I, I64, P, P, P, P],
+        "vs_upcat2x": [P, I, I64, P, I, I64, F, I, I, I, P, I64, P],
+        "vs_msg_latent": [P, P, I, I, I, P, P],
+        "vs_broadcast_channels": [P, I, I, P, I, I, I64, I, P],
+        "vs_outc_tanh": [P, I64, I, I, I64, P, P, I, I, P, P],
+        "vs_pool_linear": [P, I, I, I, I64, P, P, I, P, P],
+        "vs_resize_pre": [P, I, I, I, I, I, I, I, P, F, F, P, I, P, P],
+        "vs_jnd_heatmap": [P, I, I, I, I64, I64, I64, I64, P, P, P],
+        "vs_embed_tail": [C.POINTER(TailDesc), P],
+    }
+    for name, args in sig.items():
+        fn = getattr(L, name)
+        fn.argtypes = args
+        fn.restype = C.c_int
+    _lib = L
+    return L
+
+
+def check(code: int, what: str) -> None:
+    if code != 0:
+        raise NativeError(f"{what} failed: {lib().vs_error_string(code).decode()} (code {code})")
+
+
+def ptr(t: Optional[torch.Tensor]) -> Optional[int]:
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise NativeError("HIP kernels need device tensors (got a CPU tensor); move the model/inputs to cuda first")
+    return t.data_ptr()
+
+
+def stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def f32c(t: torch.Tensor) -> torch.Tensor:
+    """contiguous float32 view/copy (plumbing)."""
+    if t.dtype != torch.float32:
+        t = t.float()
+    return t if t.is_contiguous() else t.contiguous()
