@@ -76,10 +76,16 @@ def _run_case(spec, sd, model, name):
     assert (clean - gclean).abs().max() < 1e-4
     assert ((clean > 0) == (gclean > 0)).all(), "bit decisions differ from the reference on identical frames"
     if meta["is_video"]:
+        # extract_message (antialias=False resize + frame mean): the oracle on OUR frames is the checker
+        na = {"mode": "bilinear", "align_corners": False, "antialias": False}
+        agg = model.detect(imgs_w, is_video=True, interpolation=na)["preds"][:, 1:].mean(dim=0).cpu()
+        ref_agg = R.detect(sd, spec, imgs_w.cpu(), na)["preds"][:, 1:].mean(dim=0)
+        assert (agg - ref_agg).abs().max() < 1e-4
         mh = model.extract_message(imgs_w).cpu()
-        # aggregated logits of the reference (antialias=False path) are not stored: compare with the oracle on our frames
-        ref_mh = R.extract_message(sd, spec, imgs_w.cpu())
-        assert (mh == ref_mh).all()
+        ref_mh = (ref_agg > 0)[None]
+        margin = ref_agg.abs() > 1e-4          # a mean logit closer to 0 than the fp32 re-ordering noise may flip
+        assert (mh == ref_mh)[:, margin].all()
+        assert (mh != ref_mh).sum() <= 1
 
 
 @pytest.mark.parametrize("name", TINY)

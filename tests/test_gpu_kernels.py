@@ -35,11 +35,26 @@ class Eng(HipEngine):
         self.dev = torch.device(DEV)
         self.lib = N.lib()
         self._ws = {}
+        self.kernel_timers = None
 
 
 @pytest.fixture(scope="module")
 def eng():
     return Eng()
+
+
+_KEEP = []
+
+
+def dv(t):
+    """device copy that stays referenced until the test module is torn down (the C-ABI only sees raw pointers,
+    so a temporary freed by Python could be recycled by the caching allocator before the kernel runs)."""
+    t = t.to(DEV).contiguous()
+    _KEEP.append(t)
+    if len(_KEEP) > 256:
+        torch.cuda.synchronize()
+        del _KEEP[:128]
+    return t
 
 
 def rel_err(a, b):
@@ -188,9 +203,9 @@ def test_dwconv7_ln(eng, C_, H, W):
     xa = to_nhwc(x)
     ld = xa.ld
     wp = torch.zeros(49, ld); wp[:, :C_] = wd.reshape(C_, 49).t()
-    pad = lambda v: torch.cat([v, torch.zeros(ld - C_)]).to(DEV)   # noqa: E731
+    pad = lambda v: dv(torch.cat([v, torch.zeros(ld - C_)]))   # noqa: E731
     out = eng.new_act("dw", B, H, W, C_)
-    N.check(eng.lib.vs_dwconv7_ln(N.ptr(xa.t), B, H, W, C_, ld, N.ptr(wp.to(DEV)), N.ptr(pad(bd)), N.ptr(pad(lw)), N.ptr(pad(lb)), 1e-6,
+    N.check(eng.lib.vs_dwconv7_ln(N.ptr(xa.t), B, H, W, C_, ld, N.ptr(dv(wp)), N.ptr(pad(bd)), N.ptr(pad(lw)), N.ptr(pad(lb)), 1e-6,
                                   N.ptr(out.t), out.ld, N.stream()), "dw")
     torch.cuda.synchronize()
     assert (from_nhwc(out) - ref).abs().max() < 3e-5
@@ -208,7 +223,7 @@ def test_grn_scale(eng, C_, HW):
     hp = torch.zeros(B, HW, ld); hp[..., :C_] = h
     part = torch.empty(((HW + 63) // 64) * B * C_, device=DEV)
     scale = torch.full((B, ld), float("nan"), device=DEV)
-    N.check(eng.lib.vs_grn_scale(N.ptr(hp.to(DEV)), B, HW, C_, ld, N.ptr(gamma.to(DEV)), N.ptr(part), N.ptr(scale), N.stream()), "grn")
+    N.check(eng.lib.vs_grn_scale(N.ptr(dv(hp)), B, HW, C_, ld, N.ptr(dv(gamma)), N.ptr(part), N.ptr(scale), N.stream()), "grn")
     torch.cuda.synchronize()
     assert (scale.cpu()[:, :C_] - ref[:, 0]).abs().max() < 1e-5
     assert (scale.cpu()[:, C_:] == 0).all()
@@ -233,7 +248,7 @@ def test_msg_latent_and_broadcast(eng):
     msgs = torch.randint(0, 2, (B, k), generator=g)
     ref = F.embedding(2 * torch.arange(k)[None] + msgs, table).sum(-2)
     lat = torch.empty(B, hid, device=DEV)
-    N.check(eng.lib.vs_msg_latent(N.ptr(table.to(DEV)), N.ptr(msgs.to(torch.int32).to(DEV)), B, k, hid, N.ptr(lat), N.stream()), "ml")
+    N.check(eng.lib.vs_msg_latent(N.ptr(dv(table)), N.ptr(dv(msgs.to(torch.int32))), B, k, hid, N.ptr(lat), N.stream()), "ml")
     dst = torch.zeros(B, 6, 32, device=DEV)
     N.check(eng.lib.vs_broadcast_channels(N.ptr(lat), B, hid, N.ptr(dst), B, 6, 32, 8, N.stream()), "bc")
     torch.cuda.synchronize()
@@ -251,7 +266,7 @@ def test_outc_tanh(eng, Cout):
     ref = torch.tanh(F.conv2d(x, w, b))
     xa = to_nhwc(x)
     out = torch.empty(B, Cout, H, W, device=DEV)
-    N.check(eng.lib.vs_outc_tanh(N.ptr(xa.t), H * W, B, Cc, xa.ld, N.ptr(w.reshape(Cout, Cc).contiguous().to(DEV)), N.ptr(b.to(DEV)), Cout, 1,
+    N.check(eng.lib.vs_outc_tanh(N.ptr(xa.t), H * W, B, Cc, xa.ld, N.ptr(dv(w.reshape(Cout, Cc))), N.ptr(dv(b)), Cout, 1,
                                  N.ptr(out), N.stream()), "outc")
     torch.cuda.synchronize()
     assert (out.cpu() - ref).abs().max() < 1e-6
@@ -265,7 +280,7 @@ def test_pool_linear(eng):
     ref = F.linear(x.mean(dim=[-2, -1]), w, b)
     xa = to_nhwc(x)
     out = torch.empty(B, Nn, device=DEV)
-    N.check(eng.lib.vs_pool_linear(N.ptr(xa.t), B, H * W, Cc, xa.ld, N.ptr(w.to(DEV)), N.ptr(b.to(DEV)), Nn, N.ptr(out), N.stream()), "pl")
+    N.check(eng.lib.vs_pool_linear(N.ptr(xa.t), B, H * W, Cc, xa.ld, N.ptr(dv(w)), N.ptr(dv(b)), Nn, N.ptr(out), N.stream()), "pl")
     torch.cuda.synchronize()
     assert (out.cpu() - ref).abs().max() < 1e-5
 
@@ -314,6 +329,6 @@ def test_jnd_heatmap_nchw(eng):
     ref, taps = _jnd_ref(x)
     t43 = (C.c_float * 43)(*[float(v) for v in taps])
     h = torch.empty(2, 1, 70, 101, device=DEV)
-    N.check(eng.lib.vs_jnd_heatmap(N.ptr(x.to(DEV)), 2, 70, 101, 3 * 70 * 101, 70 * 101, 101, 1, t43, N.ptr(h), N.stream()), "jnd")
+    N.check(eng.lib.vs_jnd_heatmap(N.ptr(dv(x)), 2, 70, 101, 3 * 70 * 101, 70 * 101, 101, 1, t43, N.ptr(h), N.stream()), "jnd")
     torch.cuda.synchronize()
     assert (h.cpu() - ref).abs().max() < 2e-6      # heat-maps are O(0.05); powf/sqrtf ulp differences only

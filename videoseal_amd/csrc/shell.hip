@@ -54,6 +54,7 @@ __device__ __forceinline__ float tap_w(const Taps& t, int j) {
     const float w = tri((j + t.lo - t.center + 0.5f) * t.inv);
     return t.total != 0.f ? w / t.total : w;
   }
+  if (t.n == 1) return 1.f;   // last row/column: ATen blends the border pixel with itself
   return j == 0 ? 1.f - t.l1 : t.l1;
 }
 

@@ -1,0 +1,69 @@
+"""Multi-GPU sharding of the embed / extract path: one process per GPU, frames partitioned, one collective.
+
+Frames are independent given the message; every `step_size`-aligned group of frames
+reproduces the reference's key-frame positions, so a video is split into contiguous frame ranges whose
+boundaries are multiples of `align` (16 = the streaming chunk of inference_streaming.py:180-184, itself a
+multiple of step_size).  Embedding needs no collective.  Extraction ends with ONE exchange: an all-gather
+of the per-frame bit logits (RCCL over xGMI on MI355X, `gloo` in the CPU tests), after which every rank
+aggregates the full [F, k] matrix exactly like videoseal.py:411-428.
+"""
+from __future__ import annotations
+
+from typing import List, Optional, Tuple
+
+import torch
+import torch.distributed as dist
+
+
+def shard_range(n_frames: int, rank: int, world: int, align: int = 16) -> Tuple[int, int]:
+    """Contiguous [start, end) frame range of `rank`; all boundaries are multiples of `align`
+    (the tail goes to the last non-empty rank).  Ranges cover [0, n_frames) without overlap."""
+    if n_frames < 0 or world < 1 or not (0 <= rank < world) or align < 1:
+        raise ValueError("bad shard arguments")
+    units = (n_frames + align - 1) // align          # aligned groups (last one may be ragged)
+    base, extra = divmod(units, world)
+    u0 = rank * base + min(rank, extra)
+    u1 = u0 + base + (1 if rank < extra else 0)
+    return min(u0 * align, n_frames), min(u1 * align, n_frames)
+
+
+def all_shards(n_frames: int, world: int, align: int = 16) -> List[Tuple[int, int]]:
+    return [shard_range(n_frames, r, world, align) for r in range(world)]
+
+
+def gather_frame_logits(local: torch.Tensor, n_frames: int, align: int = 16, group=None) -> torch.Tensor:
+    """all-gather of ragged per-rank [f_local, k] logits into the full [n_frames, k] matrix (frame order kept).
+    Ranks pad to the largest shard so a single fixed-size all_gather is issued."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return local
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    shards = all_shards(n_frames, world, align)
+    a, b = shards[rank]
+    if local.shape[0] != b - a:
+        raise ValueError(f"rank {rank} holds {local.shape[0]} frames, expected {b - a}")
+    biggest = max(e - s for s, e in shards)
+    k = local.shape[1]
+    pad = torch.zeros(biggest, k, device=local.device, dtype=local.dtype)
+    pad[: b - a] = local
+    out = [torch.empty_like(pad) for _ in range(world)]
+    dist.all_gather(out, pad, group=group)
+    return torch.cat([out[r][: e - s] for r, (s, e) in enumerate(shards)], dim=0)
+
+
+def extract_message_sharded(model, local_frames: torch.Tensor, n_frames: int, aggregation: str = "avg", align: int = 16,
+                            interpolation: Optional[dict] = None, group=None) -> torch.Tensor:
+    """Distributed `Videoseal.extract_message`: detect on the local shard, all-gather the logits, aggregate."""
+    from .model import aggregate_bits
+    it = interpolation or {"mode": "bilinear", "align_corners": False, "antialias": False}
+    if local_frames.shape[0] > 0:
+        local = model.detect(local_frames, is_video=True, interpolation=it)["preds"]
+    else:
+        local = torch.zeros(0, model.embedder.cfg.nbits + 1, device=local_frames.device)
+    full = gather_frame_logits(local, n_frames, align, group)
+    return (aggregate_bits(full[:, 1:], aggregation) > 0).squeeze().unsqueeze(0)
+
+
+def embed_sharded(model, local_frames: torch.Tensor, msgs: torch.Tensor, **kw) -> torch.Tensor:
+    """Embedding of the local shard; shard starts are multiples of step_size so key frames match the
+    single-process run.  No collective: outputs stay sharded (or are written to disjoint file ranges)."""
+    return model.embed(local_frames, msgs, is_video=True, **kw)["imgs_w"]

@@ -93,6 +93,7 @@ class HipEngine:
         self.dev = device
         self.lib = N.lib()
         self._ws: Dict[tuple, torch.Tensor] = {}
+        self.kernel_timers = None        # list of (name, start_event, end_event, flops) when bench.py enables it
         g = lambda k: sd[k].detach().to(device)   # noqa: E731
         self._pack_embedder(g)
         self._pack_extractor(g)
@@ -204,7 +205,7 @@ class HipEngine:
     # ------------------------------------------------------------------ kernel wrappers
     def conv(self, x: Act, w: ConvW, out: Act, *, stride=1, pad=0, pad_mode=N.PAD_ZERO, act=N.ACT_NONE, out_coff=0,
              n_store=None, res: Optional[Act] = None, in2: Optional[Act] = None, w2: Optional[ConvW] = None,
-             a_scale=None, a_scale_ld=0, a_shift=None, geom=None, tile_hint=0):
+             a_scale=None, a_scale_ld=0, a_shift=None, geom=None, tile_hint=0, prof: Optional[str] = None):
         d = N.ConvDesc()
         if geom is None:
             sh = sw = stride
@@ -229,7 +230,15 @@ class HipEngine:
             d.in2, d.in2_ld, d.Cin2, d.Cin2P = N.ptr(in2.t), in2.ld, in2.ld, w2.CinP
             d.wt2, d.bias2 = N.ptr(w2.wt), N.ptr(w2.bias)
         d.out, d.out_ld, d.out_coff, d.tile_hint = N.ptr(out.t), out.ld, out_coff, tile_hint
+        timed = prof is not None and self.kernel_timers is not None
+        if timed:   # HIP events on the launch stream, used by bench.py for the per-kernel roofline
+            ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            ev0.record()
         N.check(self.lib.vs_conv_gemm(C.byref(d), N.stream()), "vs_conv_gemm")
+        if timed:
+            ev1.record()
+            k_total = w.KH * w.KW * w.CinP + (w2.CinP if w2 is not None else 0)
+            self.kernel_timers.append((prof, ev0, ev1, 2.0 * out.rows * w.N * k_total))
         return out
 
     def layernorm(self, x: Act, w, b, out: Act, act=N.ACT_NONE):
@@ -241,7 +250,7 @@ class HipEngine:
         """unet.py:38-39  relu(bn(conv(relu(bn(conv(x)))))) + res_conv(x); the 1x1 rides in the 2nd conv's K loop."""
         cout = p["cout"]
         t = self.new_act(tag + ".t", x.B, x.H, x.W, cout)
-        self.conv(x, p["c0"], t, pad=1, act=N.ACT_RELU)
+        self.conv(x, p["c0"], t, pad=1, act=N.ACT_RELU, prof=("bott.conv3x3" if tag.startswith("bott") else None))
         if out is None:
             out = self.new_act(tag + ".o", x.B, x.H, x.W, cout)
         self.conv(t, p["c1"], out, pad=1, act=N.ACT_RELU, in2=x, w2=p["res"], out_coff=out_coff,
