@@ -46,6 +46,8 @@ extern "C" {
 int vs_version(void);                       /* ABI version, currently 1 */
 const char* vs_arch(void);                  /* "gfx950" */
 const char* vs_error_string(int code);
+int vs_sizeof_conv_desc(void);              /* sizeof(vs_conv_desc_t): lets a binding verify its struct mirror */
+int vs_sizeof_tail_desc(void);              /* sizeof(vs_tail_desc_t) */
 
 /*
  * Implicit-GEMM convolution on the fp32 matrix cores (v_mfma_f32_32x32x2_f32):
@@ -124,13 +126,15 @@ int vs_pool_linear(const float* x, int B, int HW, int C, int64_t ld, const float
  *                                                                 low-res JND: raw, mul=1 add=0)
  *   dst_y   [Bk][oh][ow][4] = ((yr*r + yg*g + yb*b) * 2 - 1, 0,0,0) for frames f % y_step == 0
  *                             (data/transforms.py:23-27 row 0 + embedder.py:163)
- * Either destination may be NULL.
+ * Either destination may be NULL.  ymat3 is a HOST array of 3 floats (row 0 of rgb2yuv.M) or NULL, in
+ * which case dst_y receives (r,g,b,0)*2-1 of the key frames (RGB embedders such as ChunkySeal's).
  */
 int vs_resize_pre(const float* src, int B, int C, int H, int W, int oh, int ow, int antialias, float* dst_rgb, float mul,
                   float add, float* dst_y, int y_step, const float* ymat3, void* stream);
 
 /* JND heat-map (jnd.py:63-108, in_channels=1/out_channels=1) of an RGB image addressed by strides
- * (floats): frame, channel, row, pixel.  taps: [0..24] 5x5 lum, [25..33] sobel x, [34..42] sobel y. */
+ * (floats): frame, channel, row, pixel.  taps43 is a HOST array (copied into the kernel arguments):
+ * [0..24] 5x5 lum, [25..33] sobel x, [34..42] sobel y -- the values of attenuation.conv_{lum,x,y}.weight. */
 int vs_jnd_heatmap(const float* img, int B, int H, int W, int64_t sb, int64_t sc, int64_t sy, int64_t sx,
                    const float* taps43, float* hmap, void* stream);
 
@@ -144,7 +148,7 @@ int vs_jnd_heatmap(const float* img, int B, int H, int W, int64_t sb, int64_t sc
  */
 typedef struct vs_tail_desc {
   const float* imgs; float* out; float* preds_w;
-  const float* delta; const float* hmap_lowres; const float* taps43;
+  const float* delta; const float* hmap_lowres; const float* taps43;   /* taps43: HOST pointer */
   int32_t F, H, W, S_h, S_w, Cd;
   int32_t step, video_mode, total_key;      /* key-frame expansion                         */
   int32_t attenuate, clamp, antialias;

@@ -1,0 +1,61 @@
+"""N > 1 path on CPU: frame sharding + the single logits all-gather, world_size 2 over gloo."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from videoseal_amd.dist import all_shards, gather_frame_logits, shard_range
+from videoseal_amd.model import aggregate_bits
+
+
+@pytest.mark.parametrize("n,world,align", [(1024, 8, 16), (100, 3, 16), (5, 4, 16), (0, 2, 16), (33, 2, 4), (128, 1, 16)])
+def test_shards_cover_without_overlap(n, world, align):
+    sh = all_shards(n, world, align)
+    assert sh[0][0] == 0 and sh[-1][1] == n
+    for (a, b), (c, d) in zip(sh, sh[1:]):
+        assert b == c and a <= b
+    for a, b in sh:
+        assert a % align == 0 or a == n          # every shard starts on a key-frame boundary
+    assert sum(b - a for a, b in sh) == n
+    if n == 1024 and world == 8:
+        assert sh == [(i * 128, (i + 1) * 128) for i in range(8)]      # BASELINE config 4
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+def _worker(rank, world, port, n_frames, k, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    g = torch.Generator().manual_seed(0)
+    full = torch.randn(n_frames, k, generator=g)            # what a single process would have computed
+    a, b = shard_range(n_frames, rank, world, 16)
+    gathered = gather_frame_logits(full[a:b].clone(), n_frames, 16)
+    ok = torch.equal(gathered, full)
+    msg = (aggregate_bits(gathered, "avg") > 0)
+    q.put((rank, ok, msg.tolist()))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n_frames", [64, 50])
+def test_gather_frame_logits_world2(n_frames):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, n_frames, 12, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    g = torch.Generator().manual_seed(0)
+    full = torch.randn(n_frames, 12, generator=g)
+    want = (full.mean(0) > 0).tolist()
+    for rank, ok, msg in res:
+        assert ok, f"rank {rank}: gathered logits differ from the single-process matrix"
+        assert msg == want                                   # every rank decodes the same message

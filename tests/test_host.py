@@ -1,0 +1,116 @@
+"""CPU-only checks of the host side: module surface / state_dict contract, card parsing, error behaviour,
+and that the C-ABI library loads and exports every symbol include/videoseal_hip.h declares."""
+import ctypes
+import json
+import os
+import re
+
+import pytest
+import torch
+
+import videoseal_amd
+from videoseal_amd import native
+from videoseal_amd.layout import cfg_from_card, load_card
+from videoseal_amd.model import Videoseal, aggregate_bits
+from tests._util import GOLDEN
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.parametrize("card", ["videoseal_1.0", "pixelseal"])
+def test_state_dict_contract(card):
+    """keys, ORDER and shapes equal the reference's state_dict (dumped by tests/golden/make_golden.py)."""
+    ref = json.load(open(os.path.join(GOLDEN, "state_dict_keys.json")))[card]
+    m = videoseal_amd.build(card)
+    sd = m.state_dict()
+    assert list(sd) == list(ref)
+    assert {k: list(v.shape) for k, v in sd.items()} == ref
+    # the message table is ONE tensor registered twice (embedder.py:141-142 + unet.py:128)
+    assert sd["embedder.msg_processor.msg_embeddings.weight"].data_ptr() == sd["embedder.unet.msg_processor.msg_embeddings.weight"].data_ptr()
+    # strict=False load of a reference-format checkpoint dict round-trips
+    sd2 = {k: torch.randn_like(v) if v.is_floating_point() else v for k, v in sd.items()}
+    msg = m.load_state_dict(sd2, strict=False)
+    assert not msg.missing_keys and not msg.unexpected_keys
+    assert torch.equal(m.embedder.unet.outc.weight, sd2["embedder.unet.outc.weight"])
+
+
+def test_chunkyseal_cfg_and_keys():
+    ref = json.load(open(os.path.join(GOLDEN, "state_dict_keys.json")))["chunkyseal"]
+    cfg = cfg_from_card(load_card(os.path.join(ROOT, "videoseal_amd", "cards", "chunkyseal.yaml")))
+    assert cfg.dims == [362, 724, 1448, 2896] and cfg.depths == [3, 3, 27, 3] and cfg.stem_stride == 2
+    assert cfg.hidden == 2048 and cfg.bott == 2560 and cfg.in_ch == 3 and cfg.out_ch == 3 and not cfg.yuv
+    assert cfg.chunk_size == 32 and cfg.step_size == 8        # legacy videowam_* keys (cfg.py:112-118)
+    from videoseal_amd.layout import detector_entries, embedder_entries
+    mine = {"embedder." + n: list(s) for n, s, _ in embedder_entries(cfg)}
+    mine.update({"detector." + n: list(s) for n, s, _ in detector_entries(cfg)})
+    for k, v in mine.items():
+        assert ref[k] == v, k
+    assert len(ref) == len(mine) + 4                          # + rgb2yuv.M and the three JND kernels
+
+
+def test_module_surface():
+    m = videoseal_amd.build("videoseal_1.0")
+    assert isinstance(m, Videoseal) and isinstance(m, torch.nn.Module)
+    assert m.training                                          # load()/build() return train mode like the reference
+    for name in ("embedder", "detector", "augmenter", "blender", "attenuation", "rgb2yuv"):
+        assert isinstance(getattr(m, name), torch.nn.Module)
+    assert (m.img_size, m.clamp, m.chunk_size, m.step_size, m.video_mode, m.lowres_attenuation) == (256, True, 32, 4, "repeat", False)
+    assert m.blender.scaling_w == 0.2 and m.blender.scaling_i == 1.0 and m.embedder.yuv is True
+    assert m.device.type == "cpu"
+    msg = m.get_random_msg(3)
+    assert msg.shape == (3, 256) and msg.dtype == torch.int64 and set(msg.unique().tolist()) <= {0, 1}
+    rep = m.get_random_msg(2, nb_repetitions=4)
+    assert torch.equal(rep[:, :64], rep[:, 64:128])
+    assert m.embedder.get_last_layer() is m.embedder.unet.outc.weight
+    n_emb = sum(p.numel() for p in m.embedder.parameters())
+    n_ext = sum(p.numel() for p in m.detector.parameters())
+    assert abs(n_emb / 1e6 - 23.66) < 0.05 and abs(n_ext / 1e6 - 33.37) < 0.05
+    assert not m.attenuation.conv_lum.weight.requires_grad
+    m.eval()
+    assert not m.training and not m.embedder.training
+
+
+def test_no_cpu_fallback_and_loud_errors():
+    m = videoseal_amd.build("videoseal_1.0").eval()
+    x = torch.rand(2, 3, 64, 64)
+    with pytest.raises(native.NativeError, match="no CPU execution path"):
+        m.embed(x, is_video=True)
+    with pytest.raises(native.NativeError):
+        m.detect(x)
+    with pytest.raises(FileNotFoundError):
+        videoseal_amd.load("no_such_card")
+    with pytest.raises(TypeError):
+        videoseal_amd.load(3)
+    with pytest.raises(FileNotFoundError, match="Checkpoint"):
+        videoseal_amd.load("videoseal")                        # card resolves, checkpoint is not available offline
+    with pytest.raises(NotImplementedError):
+        cfg_from_card({"args": {"nbits": 96, "img_size_proc": 256, "attenuation": "jnd_1_1"},
+                       "embedder": {"model": "vae_small", "params": {}}, "extractor": {"model": "sam_small", "params": {}}})
+
+
+def test_aggregation_variants():
+    p = torch.tensor([[1.0, -2.0], [3.0, 0.5], [-1.0, 0.25]])
+    assert torch.allclose(aggregate_bits(p, "avg"), p.mean(0))
+    assert torch.allclose(aggregate_bits(p, "squared_avg"), (p * p.abs()).mean(0))
+    assert torch.allclose(aggregate_bits(p, "l1norm_avg"), (p * p.abs().sum(1, keepdim=True)).mean(0))
+    assert torch.allclose(aggregate_bits(p, "l2norm_avg"), (p * p.norm(dim=1, keepdim=True)).mean(0))
+    assert aggregate_bits(p, None) is p
+    with pytest.raises(ValueError):
+        aggregate_bits(p, "median")
+
+
+def test_c_abi_exports_every_declared_symbol():
+    """the shared library loads on a machine without a GPU and exports exactly what the header declares."""
+    header = open(os.path.join(ROOT, "include", "videoseal_hip.h")).read()
+    declared = sorted(set(re.findall(r"\b(vs_[a-z0-9_]+)\s*\(", header)))
+    assert declared, "no prototypes found"
+    lib = native.lib()
+    for sym in declared:
+        assert hasattr(lib, sym), f"{sym} declared in include/videoseal_hip.h but not exported"
+    assert sorted(native.EXPORTS) == declared
+    assert lib.vs_version() == 1 and lib.vs_arch() == b"gfx950"
+    assert b"bad argument" in lib.vs_error_string(-1)
+    # argument validation happens on the host before any launch: null pointers are rejected without a GPU
+    assert lib.vs_layernorm_act(None, 4, 8, 8, None, None, 1e-6, 0, None, 8, None) == -1
+    assert lib.vs_conv_gemm(None, None) == -1
+    assert lib.vs_sizeof_conv_desc() == ctypes.sizeof(native.ConvDesc) and lib.vs_sizeof_tail_desc() == ctypes.sizeof(native.TailDesc)

@@ -12,3 +12,7 @@ extern "C" const char* vs_error_string(int code) {
     default: return "unknown error";
   }
 }
+
+// struct sizes, so a binding (ctypes / cgo / JNI) can verify its mirror of the descriptors at load time
+extern "C" int vs_sizeof_conv_desc(void) { return (int)sizeof(vs_conv_desc_t); }
+extern "C" int vs_sizeof_tail_desc(void) { return (int)sizeof(vs_tail_desc_t); }

@@ -20,7 +20,7 @@ PAD_ZERO, PAD_REFLECT = 0, 1
 VIDEO_MODES = {"repeat": 0, "alternate": 1, "interpolate": 2}
 
 EXPORTS = [
-    "vs_version", "vs_arch", "vs_error_string", "vs_conv_gemm", "vs_layernorm_act", "vs_dwconv7_ln", "vs_grn_scale",
+    "vs_version", "vs_arch", "vs_error_string", "vs_sizeof_conv_desc", "vs_sizeof_tail_desc", "vs_conv_gemm", "vs_layernorm_act", "vs_dwconv7_ln", "vs_grn_scale",
     "vs_upcat2x", "vs_msg_latent", "vs_broadcast_channels", "vs_outc_tanh", "vs_pool_linear", "vs_resize_pre",
     "vs_jnd_heatmap", "vs_embed_tail",
 ]
@@ -94,6 +94,10 @@ def lib() -> C.CDLL:
         fn = getattr(L, name)
         fn.argtypes = args
         fn.restype = C.c_int
+    L.vs_sizeof_conv_desc.restype = C.c_int
+    L.vs_sizeof_tail_desc.restype = C.c_int
+    if L.vs_sizeof_conv_desc() != C.sizeof(ConvDesc) or L.vs_sizeof_tail_desc() != C.sizeof(TailDesc):
+        raise NativeError("ctypes mirrors of vs_conv_desc_t / vs_tail_desc_t are out of date with the shared library")
     _lib = L
     return L
 
