@@ -50,7 +50,9 @@ int vs_sizeof_conv_desc(void);              /* sizeof(vs_conv_desc_t): lets a bi
 int vs_sizeof_tail_desc(void);              /* sizeof(vs_tail_desc_t) */
 
 /*
- * Implicit-GEMM convolution on the fp32 matrix cores (v_mfma_f32_32x32x2_f32):
+ * Implicit-GEMM convolution on the matrix cores, fp32 in / fp32 out.  Two arithmetic back-ends with
+ * fp32-rounding-level accuracy: v_mfma_f32_32x32x2_f32 (exact fmaf chain, 157 TF) and the "3 x bf16" split
+ * (every operand = sum of three bf16 terms, six v_mfma_f32_32x32x16_bf16 per K chunk, 2.67x faster):
  *   out[m, n] = epilogue( sum_k A[m,k] * wt[n,k] )    m = (b, oy, ox), n = output channel
  * Replaces every dense conv / nn.Linear of the path:
  *   unet.py:24-39 (ResnetBlock 3x3 + folded BN + ReLU, fused 1x1 res_conv via phase 2),
@@ -82,8 +84,13 @@ typedef struct vs_conv_desc {
   float* out;               /* [M][out_ld], written at column offset out_coff                      */
   int64_t out_ld;
   int32_t out_coff;
-  int32_t tile_hint;        /* 0 = auto; 1 = 128x128, 2 = 128x64, 3 = 256x32 block tile            */
+  int32_t tile_hint;        /* low nibble: 0 = auto, 1 = 128x128, 2 = 128x64, 3 = 256x32 block tile;   */
+                            /* | VS_CONV_FORCE_F32: v_mfma_f32_32x32x2_f32 path; | VS_CONV_FORCE_SPLIT */
+  const void* wt_split;     /* optional [3][N][Ktot] bf16: wt split exactly into 3 bf16 terms; when set */
+  const void* wt2_split;    /*   (and wt2_split for phase 2) the 6-product bf16-MFMA path is used       */
 } vs_conv_desc_t;
+#define VS_CONV_FORCE_F32 0x10
+#define VS_CONV_FORCE_SPLIT 0x20
 int vs_conv_gemm(const vs_conv_desc_t* d, void* stream);
 
 /* LayerNorm over the channel dim of [rows][ld] (+ optional activation).  common.py:131-155 (both data formats). */

@@ -31,16 +31,18 @@ def from_nhwc(a: Act, Cc=None):
 class Eng(HipEngine):
     """engine without a model: only the kernel wrappers + workspace."""
 
-    def __init__(self):
+    def __init__(self, use_split=True):
         self.dev = torch.device(DEV)
         self.lib = N.lib()
         self._ws = {}
         self.kernel_timers = None
+        self.use_split = use_split
 
 
-@pytest.fixture(scope="module")
-def eng():
-    return Eng()
+@pytest.fixture(scope="module", params=["split", "f32"])
+def eng(request):
+    """both arithmetic back-ends of vs_conv_gemm: 3 x bf16 split (default) and the fp32-input MFMA"""
+    return Eng(use_split=(request.param == "split"))
 
 
 _KEEP = []

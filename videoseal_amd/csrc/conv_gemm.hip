@@ -247,6 +247,8 @@ int launch(const vs_conv_desc_t& d, hipStream_t st) {
 
 }  // namespace
 
+int vs_conv_gemm_split_dispatch(const vs_conv_desc_t& d, int tile, hipStream_t st);   // conv_gemm_split.hip
+
 extern "C" int vs_conv_gemm(const vs_conv_desc_t* dp, void* stream) {
   VS_REQUIRE(dp && dp->in && dp->wt && dp->out);
   const vs_conv_desc_t& d = *dp;
@@ -261,8 +263,11 @@ extern "C" int vs_conv_gemm(const vs_conv_desc_t* dp, void* stream) {
   if (d.in2) VS_REQUIRE(d.wt2 && d.Cin2 > 0 && d.Cin2 % 4 == 0 && d.Cin2P % BK == 0 && d.Cin2P >= d.Cin2 && d.in2_ld % 4 == 0);
   if (d.res) VS_REQUIRE(d.res_ld >= d.N);
   hipStream_t st = (hipStream_t)stream;
-  int tile = d.tile_hint;
+  int tile = d.tile_hint & 0xf;
   if (tile == 0) tile = d.N <= 32 ? 3 : (d.N <= 64 ? 2 : 1);
+  const bool can_split = d.wt_split && (!d.in2 || d.wt2_split) && ((uintptr_t)d.wt_split & 15) == 0;
+  if (d.tile_hint & VS_CONV_FORCE_SPLIT) VS_REQUIRE(can_split);
+  if (can_split && !(d.tile_hint & VS_CONV_FORCE_F32)) return vs_conv_gemm_split_dispatch(d, tile, st);
   switch (tile) {
     case 1: return launch<2, 2, 2, 2>(d, st);   // 128 x 128
     case 2: return launch<2, 2, 2, 1>(d, st);   // 128 x 64

@@ -15,6 +15,7 @@ from __future__ import annotations
 
 import ctypes as C
 import math
+import os
 from dataclasses import dataclass
 from typing import Dict, List, Optional, Tuple
 
@@ -50,6 +51,25 @@ class ConvW:
     KH: int
     KW: int
     CinP: int
+    split: Optional[torch.Tensor] = None   # [3][N][Ktot] bf16 bit patterns (int16): exact 3-term split of wt
+
+    def with_split(self) -> "ConvW":
+        if self.split is None:
+            self.split = split_bf16x3(self.wt)
+        return self
+
+
+def split_bf16x3(w: torch.Tensor) -> torch.Tensor:
+    """fp32 -> three bf16 terms by truncation, w == t1 + t2 + t3 exactly (8+8+8 mantissa bits).
+    Returned as int16 bit patterns [3, *w.shape] (the kernel reads them as __bf16)."""
+    w = w.float().contiguous()
+    planes = []
+    r = w
+    for _ in range(3):
+        hi = (r.view(torch.int32) & -65536).view(torch.float32)
+        planes.append((hi.view(torch.int32) >> 16).to(torch.int16))
+        r = r - hi
+    return torch.stack(planes, 0).contiguous()
 
 
 def pack_conv(w: torch.Tensor, in_ld: int, scale: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, int]:
@@ -94,6 +114,7 @@ class HipEngine:
         self.lib = N.lib()
         self._ws: Dict[tuple, torch.Tensor] = {}
         self.kernel_timers = None        # list of (name, start_event, end_event, flops) when bench.py enables it
+        self.use_split = os.environ.get("VIDEOSEAL_CONV", "split") != "f32"   # arithmetic back-end of vs_conv_gemm
         g = lambda k: sd[k].detach().to(device)   # noqa: E731
         self._pack_embedder(g)
         self._pack_extractor(g)
@@ -230,6 +251,10 @@ class HipEngine:
             d.in2, d.in2_ld, d.Cin2, d.Cin2P = N.ptr(in2.t), in2.ld, in2.ld, w2.CinP
             d.wt2, d.bias2 = N.ptr(w2.wt), N.ptr(w2.bias)
         d.out, d.out_ld, d.out_coff, d.tile_hint = N.ptr(out.t), out.ld, out_coff, tile_hint
+        if self.use_split and not (tile_hint & N.CONV_FORCE_F32):
+            d.wt_split = N.ptr(w.with_split().split)
+            if in2 is not None:
+                d.wt2_split = N.ptr(w2.with_split().split)
         timed = prof is not None and self.kernel_timers is not None
         if timed:   # HIP events on the launch stream, used by bench.py for the per-kernel roofline
             ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

@@ -17,6 +17,7 @@ LIB_PATH = os.path.join(_HERE, "csrc", "libvideoseal_hip.so")
 
 ACT_NONE, ACT_RELU, ACT_GELU, ACT_TANH = 0, 1, 2, 3
 PAD_ZERO, PAD_REFLECT = 0, 1
+CONV_FORCE_F32, CONV_FORCE_SPLIT = 0x10, 0x20
 VIDEO_MODES = {"repeat": 0, "alternate": 1, "interpolate": 2}
 
 EXPORTS = [
@@ -44,6 +45,7 @@ class ConvDesc(C.Structure):
         ("in2", C.c_void_p), ("in2_ld", C.c_int64), ("Cin2", C.c_int32), ("Cin2P", C.c_int32),
         ("wt2", C.c_void_p), ("bias2", C.c_void_p),
         ("out", C.c_void_p), ("out_ld", C.c_int64), ("out_coff", C.c_int32), ("tile_hint", C.c_int32),
+        ("wt_split", C.c_void_p), ("wt2_split", C.c_void_p),
     ]
 
 
