@@ -68,7 +68,8 @@ typedef struct vs_conv_desc {
   int32_t Ho, Wo;
   const float* wt;          /* [N][KH*KW*CinP]                                                     */
   int32_t CinP, N;
-  const float* a_scale;     /* optional A transform a' = a*a_scale[b*a_scale_ld + c] + a_shift[c]  */
+  const float* a_scale;     /* optional A transform a' = a*a_scale[b*a_scale_ld + c] + a_shift[c]; both  */
+                            /*   arrays must be readable up to CinP entries per row (16-float chunks)     */
   int64_t a_scale_ld;       /*   (GRN apply, common.py:166-169); KH=KW=1 only                      */
   const float* a_shift;
   const float* bias;        /* [N] or NULL                                                         */
@@ -84,10 +85,14 @@ typedef struct vs_conv_desc {
   float* out;               /* [M][out_ld], written at column offset out_coff                      */
   int64_t out_ld;
   int32_t out_coff;
-  int32_t tile_hint;        /* low nibble: 0 = auto, 1 = 128x128, 2 = 128x64, 3 = 256x32 block tile;   */
+  int32_t tile_hint;        /* low nibble: 0 = auto, 1 = 128x128, 2 = 128x64, 3 = 256x32, 4 = 128x192, 5 = 128x96,   */
+                            /* 6 = 256x128, 7 = 128x128, 8 = 128x64, 9 = 256x64 (producer/consumer, need wt_blk);   */
                             /* | VS_CONV_FORCE_F32: v_mfma_f32_32x32x2_f32 path; | VS_CONV_FORCE_SPLIT */
   const void* wt_split;     /* optional [3][N][Ktot] bf16: wt split exactly into 3 bf16 terms; when set */
   const void* wt2_split;    /*   (and wt2_split for phase 2) the 6-product bf16-MFMA path is used       */
+  const void* wt_blk;       /* optional: the same split weights in LDS-image order [ceil(N/32)][Ktot/16][3][1 KiB]  */
+  const void* wt2_blk;      /*   (slot of (row r, k-half h) inside a block = 2r + (h ^ ((r>>3)&1)), rows >= N zero);  */
+                            /*   enables the producer/consumer kernels, tile codes 6..9                              */
 } vs_conv_desc_t;
 #define VS_CONV_FORCE_F32 0x10
 #define VS_CONV_FORCE_SPLIT 0x20

@@ -37,6 +37,8 @@ class Eng(HipEngine):
         self._ws = {}
         self.kernel_timers = None
         self.use_split = use_split
+        self.autotune = False
+        self._tile_cache = {}
 
 
 @pytest.fixture(scope="module", params=["split", "f32"])
@@ -73,12 +75,23 @@ CONV_CASES = [
     (1, 48, 9, 11, 40, 1, 1, 0, 0, 2, 2),
     (2, 24, 12, 12, 20, 3, 1, 1, 1, 3, 3),
     (2, 64, 33, 31, 96, 3, 1, 1, 0, 1, 2),
+    # producer/consumer kernels (tile codes 6..9), incl. ragged M / N, reflect, stride 2, tiny K
+    (2, 384, 16, 16, 384, 3, 1, 1, 0, 1, 6),
+    (3, 64, 19, 23, 136, 3, 1, 1, 1, 2, 7),
+    (2, 32, 20, 20, 64, 3, 2, 1, 0, 0, 8),
+    (1, 16, 40, 24, 40, 1, 1, 0, 0, 3, 9),
+    (2, 1, 32, 32, 16, 3, 1, 1, 0, 1, 8),
+    (2, 96, 9, 9, 200, 3, 1, 1, 0, 1, 6),
+    (2, 128, 16, 16, 96, 1, 1, 0, 0, 2, 5),
+    (2, 128, 16, 16, 192, 3, 1, 1, 0, 1, 4),
 ]
 
 
 @pytest.mark.parametrize("case", CONV_CASES)
 def test_conv_gemm_matches_conv2d(eng, case):
     B, Cin, H, W, Cout, k, s, p, pm, act, tile = case
+    if tile >= 6 and not eng.use_split:
+        pytest.skip("producer/consumer kernels exist for the split back-end only")
     g = torch.Generator().manual_seed(hash(case) % 1000)
     x = torch.randn(B, Cin, H, W, generator=g)
     w = torch.randn(Cout, Cin, k, k, generator=g) / math.sqrt(Cin * k * k)
@@ -98,8 +111,11 @@ def test_conv_gemm_matches_conv2d(eng, case):
     assert torch.isfinite(full).all() and (full[..., Cout:] == 0).all()   # pad lanes written as zero
 
 
-def test_conv_two_phase_residual_block(eng):
+@pytest.mark.parametrize("tile", [0, 7, 8])
+def test_conv_two_phase_residual_block(eng, tile):
     """ResnetBlock tail: relu(conv3x3(t)+b) + (conv1x1(x)+b2), written at a channel offset of a wider buffer."""
+    if tile >= 6 and not eng.use_split:
+        pytest.skip("split back-end only")
     g = torch.Generator().manual_seed(5)
     B, Cm, Cx, H, W, Co = 2, 32, 16, 14, 18, 32
     t = torch.randn(B, Cm, H, W, generator=g)
@@ -115,15 +131,18 @@ def test_conv_two_phase_residual_block(eng):
     out = eng.new_act("wide", B, H, W, 48)
     out.t.fill_(7.0)
     eng.conv(ta, ConvW(wt1, b1.to(DEV), Co, 3, 3, cp1), out, pad=1, act=N.ACT_RELU, in2=xa, w2=ConvW(wt2, b2.to(DEV), Co, 1, 1, cp2),
-             out_coff=8, n_store=Co)
+             out_coff=8, n_store=Co, tile_hint=tile)
     torch.cuda.synchronize()
     full = out.t.view(B, H, W, 48).cpu()
     assert rel_err(full[..., 8:40].permute(0, 3, 1, 2), ref) < 2e-5
     assert (full[..., :8] == 7.0).all() and (full[..., 40:] == 7.0).all()   # neighbours untouched
 
 
-def test_conv_grn_transform_and_residual(eng):
+@pytest.mark.parametrize("tile", [0, 8])
+def test_conv_grn_transform_and_residual(eng, tile):
     """pwconv2 with the GRN apply folded into the A load and the block residual (convnext.py:50-56)."""
+    if tile >= 6 and not eng.use_split:
+        pytest.skip("split back-end only")
     g = torch.Generator().manual_seed(6)
     B, HW, K, Nn = 3, 50, 72, 20
     h = torch.randn(B, HW, K, generator=g)
@@ -137,7 +156,7 @@ def test_conv_grn_transform_and_residual(eng):
     wt, cp = pack_conv(w[:, :, None, None].to(DEV), K)
     ra = Act(res.to(DEV).contiguous(), B, HW, 1, Nn, Nn)
     shp = torch.zeros(cp); shp[:K] = sh
-    eng.conv(ha, ConvW(wt, bias.to(DEV), Nn, 1, 1, cp), ra, res=ra, a_scale=sc.to(DEV).contiguous(), a_scale_ld=K, a_shift=shp.to(DEV))
+    eng.conv(ha, ConvW(wt, bias.to(DEV), Nn, 1, 1, cp), ra, res=ra, a_scale=sc.to(DEV).contiguous(), a_scale_ld=K, a_shift=shp.to(DEV), tile_hint=tile)
     torch.cuda.synchronize()
     assert rel_err(ra.t.cpu().view(B, HW, Nn), ref) < 2e-5
 

@@ -15,7 +15,7 @@ from videoseal_amd.engine import Act, ConvW, HipEngine, pack_conv, rup  # noqa: 
 
 class Eng(HipEngine):
     def __init__(self):
-        self.dev = torch.device("cuda"); self.lib = N.lib(); self._ws = {}; self.kernel_timers = None; self.use_split = True
+        self.dev = torch.device("cuda"); self.lib = N.lib(); self._ws = {}; self.kernel_timers = None; self.use_split = True; self.autotune = False; self._tile_cache = {}
 
 
 def bench(eng, name, B, Cin, H, W, Cout, k, variants, reps=10, check=True):
@@ -24,7 +24,7 @@ def bench(eng, name, B, Cin, H, W, Cout, k, variants, reps=10, check=True):
     w = (torch.randn(Cout, Cin, k, k, generator=g) / math.sqrt(Cin * k * k)).cuda()
     xa = Act(x, B, H, W, Cin, Cin)
     wt, cp = pack_conv(w, Cin)
-    cw = ConvW(wt, None, Cout, k, k, cp).with_split()
+    cw = ConvW(wt, None, Cout, k, k, cp).with_blk()
     out = eng.new_act("o", B, H, W, Cout)
     flops = 2.0 * B * H * W * Cout * Cin * k * k
     ref = None
@@ -52,8 +52,16 @@ def bench(eng, name, B, Cin, H, W, Cout, k, variants, reps=10, check=True):
 if __name__ == "__main__":
     eng = Eng()
     F32, SP = N.CONV_FORCE_F32, N.CONV_FORCE_SPLIT
-    V = [("f32 128x128", F32 | 1), ("split 128x128", SP | 1), ("split 128x64", SP | 2)]
+    V = [("f32 128x128", F32 | 1), ("split 128x128", SP | 1), ("split 128x64", SP | 2), ("split 128x96", SP | 5),
+         ("pc 256x128", 6), ("pc 128x128", 7), ("pc 128x64", 8), ("pc 256x64", 9),
+         ("pc 256x128 prod-idle", 6 | 0x400), ("pc 256x128 no-mfma", 6 | 0x800), ("pc 128x128 prod-idle", 7 | 0x400), ("pc 128x128 no-mfma", 7 | 0x800),
+         ("pc 256x64 prod-idle", 9 | 0x400), ("pc 256x64 no-mfma", 9 | 0x800)]
     bench(eng, "bottleneck 384->384 32^2 B32", 32, 384, 32, 32, 384, 3, V)
+    AB = [("split128x64 full", SP | 2), ("  no-global", SP | 2 | 0x100), ("  no-mfma", SP | 2 | 0x200), ("  no-ldsstore", SP | 2 | 0x400),
+          ("  no-global,no-store", SP | 2 | 0x500), ("  only-mfma+ldsread", SP | 2 | 0xD00), ("  no-mfma,no-global", SP | 2 | 0x300),
+          ("split128x128 full", SP | 1), ("  no-global", SP | 1 | 0x100), ("  no-mfma", SP | 1 | 0x200), ("  only-mfma+ldsread", SP | 1 | 0xD00),
+          ("f32 128x64 full", F32 | 2), ("  no-global", F32 | 2 | 0x100), ("  no-mfma", F32 | 2 | 0x200), ("  only-mfma+ldsread", F32 | 2 | 0xD00)]
+    bench(eng, "ABLATE bottleneck B32", 32, 384, 32, 32, 384, 3, AB, check=False)
     bench(eng, "bottleneck 384->384 32^2 B8", 8, 384, 32, 32, 384, 3, V)
     bench(eng, "up0 768->64 64^2 B32", 32, 768, 64, 64, 64, 3, [("f32 128x64", F32 | 2), ("split 128x64", SP | 2), ("split 256x32", SP | 3)])
     bench(eng, "pw1 96->384 64^2 B32", 32, 96, 64, 64, 384, 1, V)

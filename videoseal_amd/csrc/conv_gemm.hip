@@ -1,36 +1,50 @@
-// Implicit-GEMM convolution / linear layer on the gfx950 fp32 matrix cores.
+// Implicit-GEMM convolution / linear layer on the gfx950 matrix cores, fp32 in / fp32 out.
 //
 //   out[m][n] = epilogue( sum_k A[m][k] * wt[n][k] ),  m = (frame, oy, ox) row-major, k = (tap, channel)
 //
-// Design (MI355X_MICROARCH.md: f32-input MFMA = 64 FLOP/clk/SIMD = 157 TF, exact fmaf chain):
-//   * v_mfma_f32_32x32x2_f32; a 4-wave workgroup owns a BM x BN output tile, each wave TM x TN tiles of 32x32.
-//   * K is walked in chunks of 16 channels of one filter tap.  The A chunk is gathered straight from the NHWC
-//     activation (zero or reflect padding resolved per row), the B chunk from the pre-packed [N][Ktot] weight.
-//     Both are staged global -> registers -> LDS with two LDS buffers: the global loads of chunk s+1 are in
-//     flight while chunk s is multiplied; one barrier per chunk.
-//   * LDS rows are [row][16 + 4 pad] floats: a lane reads its 8 k-values with two ds_read_b128 and the 20-dword
-//     row stride makes every 16-lane service group of ds_read_b128 hit 16 distinct 4-bank slots (conflict-free).
-//     Lanes 0-31 take k 0..7 and lanes 32-63 k 8..15 of the chunk; MFMA j multiplies k-pair (j, 8+j).
-//   * Epilogue in registers: bias, ReLU/GELU/tanh, optional second K phase (the ResnetBlock's 1x1 res_conv on
-//     the block input, accumulated on top of relu(bn(conv))), optional residual, coalesced 128-B row stores.
-#include "vs_common.h"
+// Two arithmetic back-ends (template parameter SPLIT), both with fp32-rounding-level accuracy:
+//   SPLIT = false : v_mfma_f32_32x32x2_f32 -- exact fmaf chain at the f32 vector rate (157 TF peak).
+//   SPLIT = true  : "3 x bf16".  Every fp32 operand is split EXACTLY into three bf16 terms by truncation,
+//                   x = x1 + x2 + x3 (8+8+8 mantissa bits), and a product is accumulated as its six partial products
+//                   of weight >= 2^-16:  a1b1 + (a1b2 + a2b1) + (a2b2 + a1b3 + a3b1)   (dropped: <= 2^-24 |ab|),
+//                   each one v_mfma_f32_32x32x16_bf16 with fp32 accumulation.  bf16 MFMA has 16x the rate of the
+//                   f32-input MFMA, so six of them are 2.67x faster at the same accuracy (417 TF-equivalent peak).
+//                   Weights are pre-split at pack time ([3][N][Ktot] bf16); activations are split while they are
+//                   staged global -> registers -> LDS (2 v_and + 2 v_sub + 1.5 v_perm per element).
+//
+// Common structure (MI355X: 64-lane waves, 4 SIMDs/CU, 160 KB LDS):
+//   * a 4-wave workgroup owns a BM x BN output tile, each wave TM x TN MFMA tiles of 32x32;
+//   * K is walked in chunks of 16 channels of one filter tap.  A is gathered straight from the NHWC activation,
+//     B from the packed weight; both go global -> registers -> LDS with two LDS buffers (loads of chunk s+1 are in
+//     flight while chunk s is multiplied; one barrier per chunk);
+//   * addresses are a uniform (SGPR) base + a per-lane 32-bit byte offset, so a chunk costs no per-lane address
+//     arithmetic; the per-row tap validity (zero padding) / reflected pixel offset is refreshed only when the tap
+//     changes; loads are unconditional (out-of-range rows are clamped to valid memory and masked afterwards);
+//   * LDS rows are padded (f32: 16+4 floats, bf16: 16+8 halves) so that the 16 lanes of every ds_read_b128 service
+//     group hit 16 distinct 4-bank slots;
+//   * epilogue in registers: bias, ReLU/GELU/tanh, optional second K phase (the ResnetBlock's 1x1 res_conv on the
+//     block input accumulated on top of relu(bn(conv))), optional residual, coalesced 128-byte row stores.
+#include "conv_common.h"
 
 namespace {
 
-constexpr int BK = 16;
-constexpr int LDK = BK + 4;   // padded LDS row (floats)
-constexpr int NT = 256;
+using namespace vsconv;
 
-template <int WM, int WN, int TM, int TN>
-__global__ __launch_bounds__(NT) void conv_gemm_kernel(const vs_conv_desc_t d, const int M, const int mtiles) {
+template <int WM, int WN, int TM, int TN, bool SPLIT>
+__global__ __launch_bounds__(NT, (TM * TN > 4 ? 1 : 2)) void conv_gemm_kernel(const vs_conv_desc_t d, const int M, const int mtiles) {
   constexpr int BM = WM * TM * 32;
   constexpr int BN = WN * TN * 32;
-  constexpr int NA = (BM * 4 + NT - 1) / NT;   // float4 A loads per thread per chunk
-  constexpr int NB = (BN * 4 + NT - 1) / NT;
-  static_assert(WM * WN == 4, "4 waves per workgroup");
+  constexpr int NA = BM * 4 / NT;                       // float4 A loads per thread per chunk
+  constexpr int BSLOTS = SPLIT ? BN * 2 : BN * 4;       // 16-byte B slots per plane per chunk
+  constexpr int NB = (BSLOTS + NT - 1) / NT;
+  constexpr int NP = SPLIT ? 3 : 1;                     // weight planes
+  static_assert(WM * WN == 4 && (BM * 4) % NT == 0, "4 waves, whole A tile per pass");
 
-  __shared__ __attribute__((aligned(16))) float As[2][BM][LDK];
-  __shared__ __attribute__((aligned(16))) float Bs[2][BN][LDK];
+  constexpr int A_BYTES = SPLIT ? 3 * BM * ROWB : BM * LDKF * 4;
+  constexpr int B_BYTES = SPLIT ? 3 * BN * ROWB : BN * LDKF * 4;
+  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * (A_BYTES + B_BYTES)];
+  unsigned char* const As0 = smem;
+  unsigned char* const Bs0 = smem + 2 * A_BYTES;
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -46,107 +60,184 @@ __global__ __launch_bounds__(NT) void conv_gemm_kernel(const vs_conv_desc_t d, c
   const int spt = d.CinP / BK;                  // chunks per tap
   const int n1 = d.KH * d.KW * spt;
   const int n2 = d.in2 ? d.Cin2P / BK : 0;
-  const int total = n1 + n2;
+  const int n1e = n2 > 0 ? ((n1 + 1) & ~1) : n1;   // the 2-deep pipeline switches phase on an even step: pad with a null chunk
+  const int total = n1e + n2;
   const int64_t Ktot = (int64_t)d.KH * d.KW * d.CinP;
   const int HoWo = d.Ho * d.Wo;
+  const bool reflect = d.pad_mode == VS_PAD_REFLECT;
+  const int abl = d.tile_hint >> 8;   // debug ablation mask (tools/bench_conv.py): 1 no global loads, 2 no MFMA, 4 no LDS stores, 8 no barrier
+  const bool chk_c = (d.Cin % BK) != 0 || (d.in2 && (d.Cin2 % BK) != 0);   // partial channel chunks exist
 
-  // ---- per-thread A rows (fixed for the whole K loop)
-  int a_row[NA];
+  // ---- A rows of this thread (fixed for the whole K loop)
   bool a_ok[NA];
-  int a_iy0[NA], a_ix0[NA], a_b[NA];
-  int64_t a_m[NA];
+  int a_oy[NA], a_ox[NA];
+  unsigned a_pix[NA];       // byte offset of (frame, oy*SH, ox*SW, k4)
+  unsigned a_cur[NA];       // byte offset used for the current tap (tap offset folded in, 0 when the tap is padding)
+  bool a_tap[NA];           // current tap is inside the image for this row
+  unsigned a_off2[NA];      // byte offset of row m in in2
+  unsigned a_soff[NA];      // byte offset of (frame, k4) in a_scale
   const int k4 = (tid & 3) * 4;
 #pragma unroll
   for (int i = 0; i < NA; ++i) {
-    const int idx = tid + i * NT;
-    const int row = idx >> 2;
-    a_row[i] = row;
+    const int row = (tid + i * NT) >> 2;
     const int64_t m = m0 + row;
-    a_m[i] = m;
-    a_ok[i] = (row < BM) && (m < M);
+    a_ok[i] = m < M;
     const int64_t mm = a_ok[i] ? m : 0;
     const int b = (int)(mm / HoWo);
     const int rem = (int)(mm - (int64_t)b * HoWo);
     const int oy = rem / d.Wo, ox = rem - oy * d.Wo;
-    a_b[i] = b;
-    a_iy0[i] = oy * d.SH - d.PH;
-    a_ix0[i] = ox * d.SW - d.PW;
+    a_oy[i] = oy * d.SH;
+    a_ox[i] = ox * d.SW;
+    a_pix[i] = (unsigned)(((int64_t)b * d.in_sb + (int64_t)a_oy[i] * d.in_sy + (int64_t)a_ox[i] * d.in_sx + k4) * 4);
+    a_off2[i] = (unsigned)((mm * d.in2_ld + k4) * 4);
+    a_soff[i] = (unsigned)(((int64_t)b * d.a_scale_ld + k4) * 4);
+    a_cur[i] = 0;
+    a_tap[i] = false;
   }
-  int b_row[NB];
-  bool b_ok[NB];
+  // ---- B slots of this thread: rows beyond N are clamped to row N-1 (masked in the epilogue)
+  unsigned b_off[NB], b_off2[NB];
+  int b_lds[NB];
+  bool b_have[NB];
 #pragma unroll
   for (int i = 0; i < NB; ++i) {
     const int idx = tid + i * NT;
-    b_row[i] = idx >> 2;
-    b_ok[i] = (b_row[i] < BN) && (n0 + b_row[i] < d.N);
+    b_have[i] = idx < BSLOTS;
+    const int row = SPLIT ? (idx >> 1) : (idx >> 2);
+    const int sub = SPLIT ? (idx & 1) : (idx & 3);
+    int nrow = n0 + row;
+    nrow = nrow < d.N ? nrow : d.N - 1;
+    if (SPLIT) {
+      b_off[i] = (unsigned)(((int64_t)nrow * Ktot + sub * 8) * 2);
+      b_off2[i] = (unsigned)(((int64_t)nrow * d.Cin2P + sub * 8) * 2);
+      b_lds[i] = row * ROWB + sub * 16;
+    } else {
+      b_off[i] = (unsigned)(((int64_t)nrow * Ktot + sub * 4) * 4);
+      b_off2[i] = (unsigned)(((int64_t)nrow * d.Cin2P + sub * 4) * 4);
+      b_lds[i] = (row * LDKF + sub * 4) * 4;
+    }
   }
+  const int64_t plane1 = (int64_t)d.N * Ktot * 2;        // bytes per bf16 weight plane
+  const int64_t plane2 = (int64_t)d.N * d.Cin2P * 2;
+  const char* const wbase = SPLIT ? reinterpret_cast<const char*>(d.wt_split) : reinterpret_cast<const char*>(d.wt);
+  const char* const wbase2 = SPLIT ? reinterpret_cast<const char*>(d.wt2_split) : reinterpret_cast<const char*>(d.wt2);
+  constexpr int WELT = SPLIT ? 2 : 4;                    // bytes per weight element
 
-  // running position of the loader inside phase 1
   int ld_ky = 0, ld_kx = 0, ld_cc = 0, ld_step = 0;
-  f32x4 ra[NA], rb[NB];
+  // two register sets: global loads run two chunks ahead of the MFMAs (chunk c lives in set c&1, LDS buffer c&1)
+  struct Regs { f32x4 a[NA]; u32x4 b[NB][NP]; };
+  Regs R0, R1;
 
-  auto load_chunk = [&]() {
+  auto refresh_tap = [&]() __attribute__((always_inline)) {
+    const int64_t tap_delta = ((int64_t)(ld_ky - d.PH) * d.in_sy + (int64_t)(ld_kx - d.PW) * d.in_sx) * 4;
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+      int iy = a_oy[i] - d.PH + ld_ky, ix = a_ox[i] - d.PW + ld_kx;
+      if (reflect) {
+        const int ry = iy < 0 ? -iy : (iy >= d.H ? 2 * d.H - 2 - iy : iy);
+        const int rx = ix < 0 ? -ix : (ix >= d.W ? 2 * d.W - 2 - ix : ix);
+        const int64_t refl = ((int64_t)(ry - iy) * d.in_sy + (int64_t)(rx - ix) * d.in_sx) * 4;
+        a_tap[i] = a_ok[i];
+        a_cur[i] = a_ok[i] ? (unsigned)((int64_t)a_pix[i] + tap_delta + refl) : 0u;
+      } else {
+        a_tap[i] = a_ok[i] && (iy >= 0) && (iy < d.H) && (ix >= 0) && (ix < d.W);
+        a_cur[i] = a_tap[i] ? (unsigned)((int64_t)a_pix[i] + tap_delta) : 0u;
+      }
+    }
+  };
+
+  auto load_chunk = [&](Regs& R) __attribute__((always_inline)) {
+    f32x4 (&ra)[NA] = R.a;
+    u32x4 (&rb)[NB][NP] = R.b;
     const int s = ld_step;
     if (s < n1) {
-      const int c = ld_cc + k4;
+      if (ld_cc == 0) refresh_tap();
+      const char* abase = reinterpret_cast<const char*>(d.in) + (int64_t)ld_cc * 4;   // uniform
+      if (!chk_c) {
 #pragma unroll
-      for (int i = 0; i < NA; ++i) {
-        f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        int iy = a_iy0[i] + ld_ky, ix = a_ix0[i] + ld_kx;
-        bool ok = a_ok[i] && (c < d.Cin);
-        if (d.pad_mode == VS_PAD_REFLECT) {
-          iy = iy < 0 ? -iy : (iy >= d.H ? 2 * d.H - 2 - iy : iy);
-          ix = ix < 0 ? -ix : (ix >= d.W ? 2 * d.W - 2 - ix : ix);
-        } else {
-          ok = ok && (iy >= 0) && (iy < d.H) && (ix >= 0) && (ix < d.W);
-        }
-        if (ok) {
-          v = *reinterpret_cast<const f32x4*>(d.in + (int64_t)a_b[i] * d.in_sb + (int64_t)iy * d.in_sy +
-                                              (int64_t)ix * d.in_sx + c);
-          if (d.a_scale) {
-            const f32x4 sc = *reinterpret_cast<const f32x4*>(d.a_scale + (int64_t)a_b[i] * d.a_scale_ld + c);
-            const f32x4 sh = *reinterpret_cast<const f32x4*>(d.a_shift + c);
-            v = v * sc + sh;
-          }
-        }
-        ra[i] = v;
-      }
-      const int64_t koff = (int64_t)s * BK + k4;
+        for (int i = 0; i < NA; ++i) ra[i] = *reinterpret_cast<const f32x4*>(abase + a_cur[i]);
+      } else {
+        const bool cok = (ld_cc + k4) < d.Cin;
 #pragma unroll
-      for (int i = 0; i < NB; ++i) {
-        f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if (b_ok[i]) v = *reinterpret_cast<const f32x4*>(d.wt + (int64_t)(n0 + b_row[i]) * Ktot + koff);
-        rb[i] = v;
+        for (int i = 0; i < NA; ++i) {
+          f32x4 v = {0.f, 0.f, 0.f, 0.f};
+          if (cok) v = *reinterpret_cast<const f32x4*>(abase + a_cur[i]);
+          ra[i] = v;
+        }
       }
+      if (d.a_scale) {   // GRN apply (1x1 convs only)
+        const char* sbase = reinterpret_cast<const char*>(d.a_scale) + (int64_t)ld_cc * 4;
+        const f32x4 sh = *reinterpret_cast<const f32x4*>(d.a_shift + ld_cc + k4);
+#pragma unroll
+        for (int i = 0; i < NA; ++i) ra[i] = ra[i] * *reinterpret_cast<const f32x4*>(sbase + a_soff[i]) + sh;
+      }
+#pragma unroll
+      for (int i = 0; i < NA; ++i)
+        if (!a_tap[i]) ra[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+      const char* bbase = wbase + (int64_t)s * (BK * WELT);
+#pragma unroll
+      for (int i = 0; i < NB; ++i)
+        if (b_have[i]) {
+#pragma unroll
+          for (int p = 0; p < NP; ++p) rb[i][p] = *reinterpret_cast<const u32x4*>(bbase + p * plane1 + b_off[i]);
+        }
       ld_cc += BK;
       if (ld_cc >= d.CinP) {
         ld_cc = 0;
         if (++ld_kx == d.KW) { ld_kx = 0; ++ld_ky; }
       }
+    } else if (s < n1e) {   // null chunk
+#pragma unroll
+      for (int i = 0; i < NA; ++i) ra[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int i = 0; i < NB; ++i)
+#pragma unroll
+        for (int p = 0; p < NP; ++p) rb[i][p] = u32x4{0u, 0u, 0u, 0u};
     } else {
-      const int c = (s - n1) * BK + k4;
+      const int cb = (s - n1e) * BK;
+      const char* abase = reinterpret_cast<const char*>(d.in2) + (int64_t)cb * 4;
+      const bool cok = (cb + k4) < d.Cin2;
 #pragma unroll
       for (int i = 0; i < NA; ++i) {
         f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if (a_ok[i] && c < d.Cin2) v = *reinterpret_cast<const f32x4*>(d.in2 + a_m[i] * d.in2_ld + c);
+        if (a_ok[i] && cok) v = *reinterpret_cast<const f32x4*>(abase + a_off2[i]);
         ra[i] = v;
       }
+      const char* bbase = wbase2 + (int64_t)cb * WELT;
 #pragma unroll
-      for (int i = 0; i < NB; ++i) {
-        f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if (b_ok[i]) v = *reinterpret_cast<const f32x4*>(d.wt2 + (int64_t)(n0 + b_row[i]) * d.Cin2P + c);
-        rb[i] = v;
-      }
+      for (int i = 0; i < NB; ++i)
+        if (b_have[i]) {
+#pragma unroll
+          for (int p = 0; p < NP; ++p) rb[i][p] = *reinterpret_cast<const u32x4*>(bbase + p * plane2 + b_off2[i]);
+        }
     }
     ++ld_step;
   };
-  auto store_chunk = [&](int buf) {
+
+  auto store_chunk = [&](const Regs& R, int buf) __attribute__((always_inline)) {
+    const f32x4 (&ra)[NA] = R.a;
+    const u32x4 (&rb)[NB][NP] = R.b;
+    unsigned char* Ab = As0 + buf * A_BYTES;
+    unsigned char* Bb = Bs0 + buf * B_BYTES;
 #pragma unroll
-    for (int i = 0; i < NA; ++i)
-      if (a_row[i] < BM) *reinterpret_cast<f32x4*>(&As[buf][a_row[i]][k4]) = ra[i];
+    for (int i = 0; i < NA; ++i) {
+      const int row = (tid + i * NT) >> 2;
+      if (SPLIT) {
+        u32x2 p1, p2, p3;
+        split4(ra[i], p1, p2, p3);
+        const int off = row * ROWB + k4 * 2;
+        *reinterpret_cast<u32x2*>(Ab + off) = p1;
+        *reinterpret_cast<u32x2*>(Ab + BM * ROWB + off) = p2;
+        *reinterpret_cast<u32x2*>(Ab + 2 * BM * ROWB + off) = p3;
+      } else {
+        *reinterpret_cast<f32x4*>(Ab + (row * LDKF + k4) * 4) = ra[i];
+      }
+    }
 #pragma unroll
     for (int i = 0; i < NB; ++i)
-      if (b_row[i] < BN) *reinterpret_cast<f32x4*>(&Bs[buf][b_row[i]][k4]) = rb[i];
+      if (b_have[i]) {
+#pragma unroll
+        for (int p = 0; p < NP; ++p) *reinterpret_cast<u32x4*>(Bb + p * BN * ROWB + b_lds[i]) = rb[i][p];
+      }
   };
 
   f32x16 acc[TM][TN];
@@ -157,7 +248,6 @@ __global__ __launch_bounds__(NT) void conv_gemm_kernel(const vs_conv_desc_t d, c
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-  // per-lane epilogue constants: one output column per (tn)
   int col[TN];
   float bias1[TN], bias2[TN];
 #pragma unroll
@@ -168,54 +258,99 @@ __global__ __launch_bounds__(NT) void conv_gemm_kernel(const vs_conv_desc_t d, c
     bias2[j] = (ok && d.bias2) ? d.bias2[col[j]] : 0.f;
   }
 
-  load_chunk();
-  store_chunk(0);
-  __syncthreads();
+  auto compute = [&](const int buf) __attribute__((always_inline)) {
+    const unsigned char* Ab = As0 + buf * A_BYTES;
+    const unsigned char* Bb = Bs0 + buf * B_BYTES;
+    if (abl & 2) {
+    } else if (SPLIT) {
+      bf16x8 af[TM][3], bf[TN][3];
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int p = 0; p < 3; ++p)
+          af[i][p] = *reinterpret_cast<const bf16x8*>(Ab + p * BM * ROWB + ((wm * TM + i) * 32 + r) * ROWB + g * 16);
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int p = 0; p < 3; ++p)
+          bf[j][p] = *reinterpret_cast<const bf16x8*>(Bb + p * BN * ROWB + ((wn * TN + j) * 32 + r) * ROWB + g * 16);
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {   // smallest terms first
+          f32x16 c = acc[i][j];
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][2], bf[j][0], c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[j][2], c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][1], bf[j][1], c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][1], bf[j][0], c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[j][1], c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[j][0], c, 0, 0, 0);
+          acc[i][j] = c;
+        }
+    } else {
+      // lanes 0-31 hold k 0..7, lanes 32-63 k 8..15 of the chunk; MFMA q multiplies the k pair (q, 8+q)
+      f32x4 alo[TM], ahi[TM], blo[TN], bhi[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        const float* p = reinterpret_cast<const float*>(Ab) + ((wm * TM + i) * 32 + r) * LDKF + g * 8;
+        alo[i] = *reinterpret_cast<const f32x4*>(p);
+        ahi[i] = *reinterpret_cast<const f32x4*>(p + 4);
+      }
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const float* p = reinterpret_cast<const float*>(Bb) + ((wn * TN + j) * 32 + r) * LDKF + g * 8;
+        blo[j] = *reinterpret_cast<const f32x4*>(p);
+        bhi[j] = *reinterpret_cast<const f32x4*>(p + 4);
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(alo[i][q], blo[j][q], acc[i][j], 0, 0, 0);
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(ahi[i][q], bhi[j][q], acc[i][j], 0, 0, 0);
+    }
+  };
 
-  for (int s = 0; s < total; ++s) {
-    const int buf = s & 1;
-    if (s + 1 < total) load_chunk();
-    if (s == n1) {   // entering phase 2: finish phase 1 in registers, keep accumulating on top of it
-#pragma unroll
-      for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-#pragma unroll
-          for (int e = 0; e < 16; ++e) acc[i][j][e] = vs_apply_act(acc[i][j][e] + bias1[j], d.act) + bias2[j];
+  // ---- software pipeline, prefetch distance 2:   step s:  MFMA(chunk s) | store(chunk s+1 -> LDS) | barrier | load(chunk s+3)
+  load_chunk(R0);
+  store_chunk(R0, 0);
+  if (total > 1) load_chunk(R1);
+  if (total > 2) load_chunk(R0);
+  __syncthreads();
+  auto k_loop = [&](const int s_begin, const int s_end) __attribute__((always_inline)) {   // s_begin is even
+    for (int s = s_begin; s < s_end; s += 2) {
+      compute(0);
+      if (s + 1 < total && !(abl & 4)) store_chunk(R1, 1);
+      if (!(abl & 8)) __syncthreads();
+      if (s + 3 < total && !(abl & 1)) load_chunk(R1);
+      if (s + 1 >= s_end) break;
+      compute(1);
+      if (s + 2 < total && !(abl & 4)) store_chunk(R0, 0);
+      if (!(abl & 8)) __syncthreads();
+      if (s + 4 < total && !(abl & 1)) load_chunk(R0);
     }
-    f32x4 alo[TM], ahi[TM], blo[TN], bhi[TN];
-#pragma unroll
-    for (int i = 0; i < TM; ++i) {
-      const float* p = &As[buf][(wm * TM + i) * 32 + r][g * 8];
-      alo[i] = *reinterpret_cast<const f32x4*>(p);
-      ahi[i] = *reinterpret_cast<const f32x4*>(p + 4);
-    }
-#pragma unroll
-    for (int j = 0; j < TN; ++j) {
-      const float* p = &Bs[buf][(wn * TN + j) * 32 + r][g * 8];
-      blo[j] = *reinterpret_cast<const f32x4*>(p);
-      bhi[j] = *reinterpret_cast<const f32x4*>(p + 4);
-    }
-#pragma unroll
-    for (int k = 0; k < 4; ++k)
-#pragma unroll
-      for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(alo[i][k], blo[j][k], acc[i][j], 0, 0, 0);
-#pragma unroll
-    for (int k = 0; k < 4; ++k)
-#pragma unroll
-      for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(ahi[i][k], bhi[j][k], acc[i][j], 0, 0, 0);
-    if (s + 1 < total) store_chunk(buf ^ 1);
-    __syncthreads();
+  };
+  k_loop(0, n1e);
+  if (n2 > 0) {   // phase 2: finish phase 1 in registers (bias, activation) and keep accumulating the 1x1 conv on top
+    apply_act_all<TM, TN>(acc, bias1, bias2, d.act);
+    k_loop(n1e, total);
   }
 
-  // ---- epilogue: C/D layout of the 32x32 MFMA: col = lane&31, row = (e&3) + 8*(e>>2) + 4*(lane>>5)
-  const bool two_phase = n2 > 0;
+  // ---- epilogue.  C/D layout of the 32x32 MFMA: col = lane&31, row = (e&3) + 8*(e>>2) + 4*(lane>>5)
+  if (n2 == 0) {
+    float zero[TN];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) zero[j] = 0.f;
+    apply_act_all<TM, TN>(acc, bias1, zero, d.act);
+  }
 #pragma unroll
   for (int i = 0; i < TM; ++i) {
 #pragma unroll
@@ -226,52 +361,76 @@ __global__ __launch_bounds__(NT) void conv_gemm_kernel(const vs_conv_desc_t d, c
       for (int j = 0; j < TN; ++j) {
         const int n = col[j];
         if (n >= d.n_store) continue;
-        float v = acc[i][j][e];
-        if (!two_phase) v = vs_apply_act(v + bias1[j], d.act);
-        if (d.res && n < d.N) v += d.res[m * d.res_ld + n];
+        float v = 0.f;                      // columns in [N, n_store) are padding lanes: always zero
+        if (n < d.N) {
+          v = acc[i][j][e];
+          if (d.res) v += d.res[m * d.res_ld + n];
+        }
         d.out[m * d.out_ld + d.out_coff + n] = v;
       }
     }
   }
 }
 
-template <int WM, int WN, int TM, int TN>
+template <int WM, int WN, int TM, int TN, bool SPLIT>
 int launch(const vs_conv_desc_t& d, hipStream_t st) {
   constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
   const int64_t M = (int64_t)d.B * d.Ho * d.Wo;
   const int64_t mt = cdiv64(M, BM), nt = cdiv64(d.n_store, BN);
   if (mt * nt > 0x7fffffffLL || M > 0x7fffffffLL) return VS_ERR_UNSUPPORTED;
-  hipLaunchKernelGGL((conv_gemm_kernel<WM, WN, TM, TN>), dim3((unsigned)(mt * nt)), dim3(NT), 0, st, d, (int)M, (int)mt);
+  hipLaunchKernelGGL((conv_gemm_kernel<WM, WN, TM, TN, SPLIT>), dim3((unsigned)(mt * nt)), dim3(NT), 0, st, d, (int)M, (int)mt);
   return vs_launch_status();
 }
 
-}  // namespace
+template <bool SPLIT>
+int dispatch(const vs_conv_desc_t& d, int tile, hipStream_t st) {
+  switch (tile) {
+    case 1: return launch<2, 2, 2, 2, SPLIT>(d, st);   // 128 x 128
+    case 2: return launch<2, 2, 2, 1, SPLIT>(d, st);   // 128 x 64
+    case 3: return launch<4, 1, 2, 1, SPLIT>(d, st);   // 256 x 32
+    case 4: return launch<2, 2, 2, 3, SPLIT>(d, st);   // 128 x 192
+    case 5: return launch<4, 1, 1, 3, SPLIT>(d, st);   // 128 x 96
+    default: return VS_ERR_UNSUPPORTED;
+  }
+}
 
-int vs_conv_gemm_split_dispatch(const vs_conv_desc_t& d, int tile, hipStream_t st);   // conv_gemm_split.hip
+}  // namespace
+int vs_conv_gemm_pc_dispatch(const vs_conv_desc_t& d, int tile, hipStream_t st);   // conv_gemm_pc.hip
+namespace {
+
+inline bool fits_u32(int64_t bytes) { return bytes >= 0 && bytes < 0xffffffffLL; }
+
+}  // namespace
 
 extern "C" int vs_conv_gemm(const vs_conv_desc_t* dp, void* stream) {
   VS_REQUIRE(dp && dp->in && dp->wt && dp->out);
   const vs_conv_desc_t& d = *dp;
   VS_REQUIRE(d.B > 0 && d.H > 0 && d.W > 0 && d.Ho > 0 && d.Wo > 0 && d.N > 0 && d.Cin > 0);
-  VS_REQUIRE(d.KH > 0 && d.KW > 0 && d.SH > 0 && d.SW > 0);
+  VS_REQUIRE(d.KH > 0 && d.KW > 0 && d.SH > 0 && d.SW > 0 && d.PH >= 0 && d.PW >= 0);
   VS_REQUIRE(d.Cin % 4 == 0 && d.CinP % BK == 0 && d.CinP >= d.Cin);
-  VS_REQUIRE(d.in_sx % 4 == 0 && d.in_sy % 4 == 0 && d.in_sb % 4 == 0);
+  VS_REQUIRE(d.in_sx % 4 == 0 && d.in_sy % 4 == 0 && d.in_sb % 4 == 0 && d.in_sx > 0 && d.in_sy > 0 && d.in_sb >= 0);
   VS_REQUIRE(d.n_store >= d.N && d.out_coff >= 0 && d.out_coff + d.n_store <= d.out_ld);
   VS_REQUIRE(((uintptr_t)d.in & 15) == 0 && ((uintptr_t)d.wt & 15) == 0);
   if (d.pad_mode == VS_PAD_REFLECT) VS_REQUIRE(d.PH < d.H && d.PW < d.W);
   if (d.a_scale) VS_REQUIRE(d.a_shift && d.KH == 1 && d.KW == 1 && d.a_scale_ld % 4 == 0);
   if (d.in2) VS_REQUIRE(d.wt2 && d.Cin2 > 0 && d.Cin2 % 4 == 0 && d.Cin2P % BK == 0 && d.Cin2P >= d.Cin2 && d.in2_ld % 4 == 0);
   if (d.res) VS_REQUIRE(d.res_ld >= d.N);
+  // the kernels address every operand as base + 32-bit byte offset
+  const int64_t M = (int64_t)d.B * d.Ho * d.Wo;
+  const int64_t Ktot = (int64_t)d.KH * d.KW * d.CinP;
+  if (!fits_u32(((int64_t)d.B * d.in_sb + (int64_t)(d.H + d.PH) * d.in_sy + (int64_t)d.W * d.in_sx) * 4) ||
+      !fits_u32((int64_t)d.N * Ktot * 4) || (d.in2 && !fits_u32(M * d.in2_ld * 4)) ||
+      (d.a_scale && !fits_u32((int64_t)d.B * d.a_scale_ld * 4)))
+    return VS_ERR_UNSUPPORTED;   // > 4 GiB operand: the caller chunks the batch
   hipStream_t st = (hipStream_t)stream;
   int tile = d.tile_hint & 0xf;
-  if (tile == 0) tile = d.N <= 32 ? 3 : (d.N <= 64 ? 2 : 1);
+  if (tile == 0) tile = d.N <= 32 ? 3 : (d.N <= 64 ? 2 : (d.N <= 96 ? 5 : ((d.N % 192 == 0 || (d.N > 128 && d.N <= 192)) ? 4 : 1)));
+  if (tile >= 6) {   // producer/consumer kernels
+    VS_REQUIRE(d.wt_blk && (!d.in2 || d.wt2_blk) && ((uintptr_t)d.wt_blk & 15) == 0);
+    return vs_conv_gemm_pc_dispatch(d, tile, st);
+  }
   const bool can_split = d.wt_split && (!d.in2 || d.wt2_split) && ((uintptr_t)d.wt_split & 15) == 0;
   if (d.tile_hint & VS_CONV_FORCE_SPLIT) VS_REQUIRE(can_split);
-  if (can_split && !(d.tile_hint & VS_CONV_FORCE_F32)) return vs_conv_gemm_split_dispatch(d, tile, st);
-  switch (tile) {
-    case 1: return launch<2, 2, 2, 2>(d, st);   // 128 x 128
-    case 2: return launch<2, 2, 2, 1>(d, st);   // 128 x 64
-    case 3: return launch<4, 1, 2, 1>(d, st);   // 256 x 32
-    default: return VS_ERR_UNSUPPORTED;
-  }
+  if (can_split && !(d.tile_hint & VS_CONV_FORCE_F32)) return dispatch<true>(d, tile, st);
+  return dispatch<false>(d, tile, st);
 }

@@ -53,10 +53,37 @@ class ConvW:
     CinP: int
     split: Optional[torch.Tensor] = None   # [3][N][Ktot] bf16 bit patterns (int16): exact 3-term split of wt
 
+    blk: Optional[torch.Tensor] = None     # split weights in LDS-image order (producer/consumer kernels)
+
     def with_split(self) -> "ConvW":
         if self.split is None:
             self.split = split_bf16x3(self.wt)
         return self
+
+    def with_blk(self) -> "ConvW":
+        if self.blk is None:
+            self.blk = pack_blocked(self.with_split().split, self.KH * self.KW)
+        return self
+
+
+def pack_blocked(planes: torch.Tensor, ntaps: int = 1) -> torch.Tensor:
+    """[3][N][Ktot] bf16 patterns -> [ceil(N/32)][Ktot/16][3][64 slots][8]: every (32 rows x 16 k) block is 1 KiB in
+    the order the kernel wants it in LDS; slot of (row r, k-half h) = 2r + (h ^ ((r>>3)&1)) (bank swizzle).
+    Chunk order is (channel chunk, tap) -- the producer/consumer kernel walks all taps of a 16-channel chunk back to
+    back so that the shifted re-reads of the same activation rows hit L1/L2 -- while Ktot is laid out (tap, channel)."""
+    _, n, k = planes.shape
+    G, nch = (n + 31) // 32, k // 16
+    spt = nch // ntaps
+    pad = torch.zeros(3, G * 32, k, dtype=planes.dtype, device=planes.device)
+    pad[:, :n] = planes
+    pad = pad.view(3, G * 32, ntaps, spt, 16).permute(0, 1, 3, 2, 4).reshape(3, G * 32, k)   # k order -> (chunk, tap, 16)
+    x = pad.view(3, G, 32, nch, 2, 8).permute(1, 3, 0, 2, 4, 5).contiguous()       # [G][nch][3][r][h][8]
+    r = torch.arange(32, device=planes.device)[:, None]
+    h = torch.arange(2, device=planes.device)[None, :]
+    slot = (2 * r + (h ^ ((r >> 3) & 1))).reshape(-1)                               # [(r,h)] -> slot
+    out = torch.empty(G, nch, 3, 64, 8, dtype=planes.dtype, device=planes.device)
+    out[:, :, :, slot] = x.view(G, nch, 3, 64, 8)
+    return out.contiguous()
 
 
 def split_bf16x3(w: torch.Tensor) -> torch.Tensor:
@@ -115,6 +142,10 @@ class HipEngine:
         self._ws: Dict[tuple, torch.Tensor] = {}
         self.kernel_timers = None        # list of (name, start_event, end_event, flops) when bench.py enables it
         self.use_split = os.environ.get("VIDEOSEAL_CONV", "split") != "f32"   # arithmetic back-end of vs_conv_gemm
+        # per-shape tile selection: every candidate walks K in the same order, so the result is bit-identical whatever
+        # tile wins -- only speed changes (measure, don't guess).  VIDEOSEAL_AUTOTUNE=0 keeps the static heuristic.
+        self.autotune = os.environ.get("VIDEOSEAL_AUTOTUNE", "1") != "0"
+        self._tile_cache: Dict[tuple, int] = {}
         g = lambda k: sd[k].detach().to(device)   # noqa: E731
         self._pack_embedder(g)
         self._pack_extractor(g)
@@ -253,8 +284,12 @@ class HipEngine:
         d.out, d.out_ld, d.out_coff, d.tile_hint = N.ptr(out.t), out.ld, out_coff, tile_hint
         if self.use_split and not (tile_hint & N.CONV_FORCE_F32):
             d.wt_split = N.ptr(w.with_split().split)
+            d.wt_blk = N.ptr(w.with_blk().blk)
             if in2 is not None:
                 d.wt2_split = N.ptr(w2.with_split().split)
+                d.wt2_blk = N.ptr(w2.with_blk().blk)
+        if tile_hint == 0 and self.autotune and not torch.cuda.is_current_stream_capturing():
+            d.tile_hint = self._pick_tile(d, w, out)
         timed = prof is not None and self.kernel_timers is not None
         if timed:   # HIP events on the launch stream, used by bench.py for the per-kernel roofline
             ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -265,6 +300,38 @@ class HipEngine:
             k_total = w.KH * w.KW * w.CinP + (w2.CinP if w2 is not None else 0)
             self.kernel_timers.append((prof, ev0, ev1, 2.0 * out.rows * w.N * k_total))
         return out
+
+    def _pick_tile(self, d: "N.ConvDesc", w: ConvW, out: Act) -> int:
+        """time the 4-wave tile shapes once per conv signature (on a scratch output) and remember the fastest."""
+        key = (d.B, d.H, d.W, d.Cin, d.KH, d.KW, d.SH, d.SW, d.pad_mode, d.Ho, d.Wo, d.N, d.CinP, bool(d.in2), d.Cin2P,
+               bool(d.a_scale), bool(d.res), d.act, bool(d.wt_split))
+        best = self._tile_cache.get(key)
+        if best is not None:
+            return best
+        cands = [t for t in (1, 2, 3, 4, 5) if self._tile_ok(t, d.N)]
+        real_out, real_coff, real_ld = d.out, d.out_coff, d.out_ld
+        scratch = self.buf("autotune.out", out.rows * rup(d.n_store, 4))
+        d.out, d.out_coff, d.out_ld = N.ptr(scratch), 0, rup(d.n_store, 4)
+        times = {}
+        for t in cands:
+            d.tile_hint = t
+            N.check(self.lib.vs_conv_gemm(C.byref(d), N.stream()), "vs_conv_gemm(autotune)")       # warm
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(3):
+                N.check(self.lib.vs_conv_gemm(C.byref(d), N.stream()), "vs_conv_gemm(autotune)")
+            e1.record()
+            e1.synchronize()
+            times[t] = e0.elapsed_time(e1)
+        best = min(times, key=times.get)
+        d.out, d.out_coff, d.out_ld = real_out, real_coff, real_ld
+        self._tile_cache[key] = best
+        return best
+
+    @staticmethod
+    def _tile_ok(tile: int, n: int) -> bool:
+        bn = {1: 128, 2: 64, 3: 32, 4: 192, 5: 96}[tile]
+        return bn < 2 * n + 64 or tile == 3     # skip tiles that would be mostly padding
 
     def layernorm(self, x: Act, w, b, out: Act, act=N.ACT_NONE):
         N.check(self.lib.vs_layernorm_act(N.ptr(x.t), x.rows, x.C, x.ld, N.ptr(w), N.ptr(b), 1e-6, act, N.ptr(out.t), out.ld,
@@ -354,7 +421,7 @@ class HipEngine:
             hh = self.new_act(f"st{sti}.h", B, cur.H, cur.W, 4 * Cc)
             nchunk = (HW + 63) // 64
             part = self.buf(f"st{sti}.gp", nchunk * B * 4 * Cc)
-            scale = self.buf(f"st{sti}.gs", B * hh.ld)
+            scale = self.buf(f"st{sti}.gs", B * hh.ld + 16)   # +16: the conv A-transform reads whole 16-float chunks
             for blk in X["stages"][sti]:
                 N.check(L.vs_dwconv7_ln(N.ptr(cur.t), B, cur.H, cur.W, Cc, cur.ld, N.ptr(blk["wdw"]), N.ptr(blk["bdw"]), N.ptr(blk["lnw"]),
                                         N.ptr(blk["lnb"]), 1e-6, N.ptr(tn.t), tn.ld, st), "vs_dwconv7_ln")

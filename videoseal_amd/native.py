@@ -45,7 +45,7 @@ class ConvDesc(C.Structure):
         ("in2", C.c_void_p), ("in2_ld", C.c_int64), ("Cin2", C.c_int32), ("Cin2P", C.c_int32),
         ("wt2", C.c_void_p), ("bias2", C.c_void_p),
         ("out", C.c_void_p), ("out_ld", C.c_int64), ("out_coff", C.c_int32), ("tile_hint", C.c_int32),
-        ("wt_split", C.c_void_p), ("wt2_split", C.c_void_p),
+        ("wt_split", C.c_void_p), ("wt2_split", C.c_void_p), ("wt_blk", C.c_void_p), ("wt2_blk", C.c_void_p),
     ]
 
 
