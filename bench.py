@@ -29,6 +29,10 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 64 FLOP/clk/SIMD
+PEAK_BF16_MFMA_TFLOPS = 2500.0    # MI355X_MICROARCH.md: dense bf16 MFMA
+# default arithmetic: every fp32 product = 6 bf16 MFMA partial products (3 x bf16 exact split, fp32 accumulate), so the
+# ceiling for *algorithmic* (fp32-equivalent) FLOP/s is the bf16 peak / 6
+PEAK_SPLIT_TFLOPS = PEAK_BF16_MFMA_TFLOPS / 6.0
 
 
 def synthetic_batch(n, size, device, seed):
@@ -148,8 +152,16 @@ def main():
         flops = eng.kernel_timers[0][3]
         avg = sum(dur) / len(dur)
         ach = flops / avg / 1e12
-        roof = {"bound": "mfma", "kernel": "conv_gemm_kernel<2,2,2,2> (U-Net bottleneck 3x3 conv 384->384 @32x32, fp32 MFMA)",
-                "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4),
+        split = eng.use_split
+        peak = PEAK_SPLIT_TFLOPS if split else PEAK_F32_MFMA_TFLOPS
+        roof = {"bound": "mfma",
+                "kernel": "conv_gemm_kernel (U-Net bottleneck 3x3 conv 384->384 @32x32, " +
+                          ("3 x bf16 split on v_mfma_f32_32x32x16_bf16, fp32 accumulate)" if split else "v_mfma_f32_32x32x2_f32)"),
+                "achieved": round(ach, 2), "peak": round(peak, 1), "unit": "TFLOP/s", "frac": round(ach / peak, 4),
+                "peak_note": ("2500 TF dense bf16 MFMA / 6 partial products per fp32-accurate product" if split
+                              else "f32-input MFMA, 64 FLOP/clk/SIMD"),
+                "achieved_vs_f32_mfma_peak": round(ach / PEAK_F32_MFMA_TFLOPS, 4),
+                "mfma_issue_tflops_bf16": round(ach * 6, 1) if split else None,
                 "flops_per_launch": flops, "avg_launch_ms": round(avg * 1e3, 4), "launches_timed": len(dur), "traffic": None}
         eng.kernel_timers = None
 
@@ -161,7 +173,8 @@ def main():
         line = {
             "metric": "frames/sec embed+extract 256-bit @768x768", "value": round(fps, 2), "unit": "frames/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 3),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32 (3 x bf16 exact operand split on the bf16 matrix cores, fp32 accumulate)" if eng.use_split else "f32", "data": "synthetic",
             "config": {"workload": f"VideoSeal 1.0 256-bit, {B} frames {S}x{S} per GPU, {args.mode} mode "
                                    f"({'embedder on every frame' if not is_video else 'key frames every %d' % cfg.step_size}, "
                                    f"{'low-res' if args.lowres_attenuation else 'full-res'} JND), embed + detect"
