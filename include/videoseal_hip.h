@@ -168,6 +168,31 @@ typedef struct vs_tail_desc {
 } vs_tail_desc_t;
 int vs_embed_tail(const vs_tail_desc_t* d, void* stream);
 
+/* ------------------------------------------------------------------------------------------------------------------
+ * Augmentations (videoseal/augmentation/valuemetric.py, geometric.py, utils/image.py).  Frames are NCHW fp32 [F][3][H][W]
+ * (masks: [F][1][H][W] through the `planes` entry points).  All are forward-only (the reference's JPEG / median use a
+ * straight-through estimator whose forward value is exactly the codec / filter output).
+ */
+#define VS_COLOR_BRIGHTNESS 0   /* valuemetric.py:99-117  torchvision adjust_brightness: clamp(f*x)                      */
+#define VS_COLOR_CONTRAST 1     /* valuemetric.py:120-137 adjust_contrast: blend with the per-frame mean of gray          */
+#define VS_COLOR_SATURATION 2   /* valuemetric.py:139-155 adjust_saturation: blend with gray (0.2989, 0.587, 0.114)       */
+#define VS_COLOR_HUE 3          /* valuemetric.py:157-174 adjust_hue: RGB -> HSV, h = (h + f) mod 1, HSV -> RGB            */
+#define VS_COLOR_GRAYSCALE 4    /* valuemetric.py:196-208 0.299 R + 0.587 G + 0.114 B broadcast to 3 channels            */
+int64_t vs_aug_color_scratch_floats(int F, int H, int W);
+int vs_aug_color(const float* src, float* dst, int F, int H, int W, int op, float factor, float* scratch, void* stream);
+/* crop (geometric.py:94-124, zero fill outside) and/or horizontal flip (geometric.py:186-196) of `planes` H x W planes   */
+int vs_aug_crop_flip(const float* src, float* dst, int planes, int H, int W, int i0, int j0, int h, int w, int flip, void* stream);
+/* bilinear resize NCHW -> NCHW, align_corners=False, antialias on/off (geometric.py:62-91; augmenter.py:147-150)        */
+int vs_resize_nchw(const float* src, float* dst, int planes, int H, int W, int oh, int ow, int antialias, void* stream);
+/* torchvision gaussian_blur: k x k (odd), reflect padding, separable (valuemetric.py:53-71)                              */
+int vs_gaussian_blur(const float* src, float* tmp, float* dst, int planes, int H, int W, int k, float sigma, void* stream);
+/* median of the k row-medians of the zero-padded k x k window, k in {3,5,7} (utils/image.py:60-84)                        */
+int vs_median_filter(const float* src, float* dst, int planes, int H, int W, int k, void* stream);
+/* clamp -> uint8 (truncation) -> libjpeg baseline 4:2:0 encode+decode at `quality` (bit-exact with libjpeg-turbo's
+ * islow path used by Pillow) -> /255   (valuemetric.py:21-50, utils/image.py:13-34)                                      */
+int64_t vs_jpeg_workspace_bytes(int F, int H, int W);
+int vs_jpeg_roundtrip(const float* src, float* dst, int F, int H, int W, int quality, void* workspace, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,126 @@
+"""CPU restatement of the augmentations (TEST INFRASTRUCTURE, see oracle/__init__.py).
+
+Geometric / filter ops follow videoseal/augmentation/{geometric,valuemetric}.py and utils/image.py; the colour ops call
+torchvision.transforms.functional in the reference, which is NOT installed and not vendored: they are restated from the
+published torchvision `_functional_tensor.py` semantics -- parity for those is "unpinned".
+JPEG is the Pillow round trip itself (pinned: Pillow is the reference's codec).
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+from .jpeg_ref import pil_roundtrip
+
+
+def _blend(a, b, r):
+    return (r * a + (1.0 - r) * b).clamp(0, 1.0)
+
+
+def gray_tv(x):
+    r, g, b = x.unbind(dim=-3)
+    return (0.2989 * r + 0.587 * g + 0.114 * b).unsqueeze(-3)
+
+
+def brightness(x, f):
+    return _blend(x, torch.zeros_like(x), f)
+
+
+def contrast(x, f):
+    mean = torch.mean(gray_tv(x), dim=(-3, -2, -1), keepdim=True)
+    return _blend(x, mean, f)
+
+
+def saturation(x, f):
+    return _blend(x, gray_tv(x), f)
+
+
+def _rgb2hsv(img):
+    r, g, b = img.unbind(dim=-3)
+    maxc = torch.max(img, dim=-3).values
+    minc = torch.min(img, dim=-3).values
+    eqc = maxc == minc
+    cr = maxc - minc
+    ones = torch.ones_like(maxc)
+    s = cr / torch.where(eqc, ones, maxc)
+    cr_divisor = torch.where(eqc, ones, cr)
+    rc, gc, bc = (maxc - r) / cr_divisor, (maxc - g) / cr_divisor, (maxc - b) / cr_divisor
+    hr = (maxc == r) * (bc - gc)
+    hg = ((maxc == g) & (maxc != r)) * (2.0 + rc - bc)
+    hb = ((maxc != g) & (maxc != r)) * (4.0 + gc - rc)
+    h = torch.fmod((hr + hg + hb) / 6.0 + 1.0, 1.0)
+    return torch.stack((h, s, maxc), dim=-3)
+
+
+def _hsv2rgb(img):
+    h, s, v = img.unbind(dim=-3)
+    i = torch.floor(h * 6.0)
+    f = (h * 6.0) - i
+    i = i.to(dtype=torch.int32)
+    p = torch.clamp(v * (1.0 - s), 0.0, 1.0)
+    q = torch.clamp(v * (1.0 - s * f), 0.0, 1.0)
+    t = torch.clamp(v * (1.0 - (s * (1.0 - f))), 0.0, 1.0)
+    i = i % 6
+    mask = i.unsqueeze(dim=-3) == torch.arange(6).view(-1, 1, 1)
+    a1 = torch.stack((v, q, p, p, t, v), dim=-3)
+    a2 = torch.stack((t, v, v, q, p, p), dim=-3)
+    a3 = torch.stack((p, p, t, v, v, q), dim=-3)
+    a4 = torch.stack((a1, a2, a3), dim=-4)
+    return torch.einsum("...ijk, ...xijk -> ...xjk", mask.to(dtype=img.dtype), a4)
+
+
+def hue(x, f):
+    hsv = _rgb2hsv(x)
+    h, s, v = hsv.unbind(dim=-3)
+    h = (h + f) % 1.0
+    return _hsv2rgb(torch.stack((h, s, v), dim=-3))
+
+
+def grayscale(x):
+    """valuemetric.py:196-208."""
+    g = 0.299 * x[:, 0:1] + 0.587 * x[:, 1:2] + 0.114 * x[:, 2:3]
+    return g.expand_as(x).contiguous()
+
+
+def hflip(x):
+    return x.flip(-1)
+
+
+def crop(x, i, j, h, w):
+    return x[..., i:i + h, j:j + w].contiguous()
+
+
+def resize(x, size, antialias=True):
+    return F.interpolate(x, size=size, mode="bilinear", align_corners=False, antialias=antialias)
+
+
+def gaussian_blur(x, k):
+    sigma = 0.3 * ((k - 1) * 0.5 - 1) + 0.8
+    half = (k - 1) * 0.5
+    t = torch.linspace(-half, half, steps=k)
+    pdf = torch.exp(-0.5 * (t / sigma).pow(2))
+    k1 = pdf / pdf.sum()
+    k2 = torch.mm(k1[:, None], k1[None, :])
+    C = x.shape[-3]
+    pad = [k // 2] * 4
+    xp = F.pad(x, pad, mode="reflect")
+    return F.conv2d(xp, k2.expand(C, 1, k, k), groups=C)
+
+
+def median_filter(x, k):
+    """utils/image.py:60-84: median of row medians, zero padded."""
+    p = k // 2
+    xp = F.pad(x, (p, p, p, p))
+    blocks = xp.unfold(2, k, 1).unfold(3, k, 1)
+    return blocks.median(dim=-1).values.median(dim=-1).values
+
+
+def jpeg(x, quality):
+    """valuemetric.py:39-46 + utils/image.py:24-34: clamp, ToPILImage (mul(255).byte(): truncation), Pillow, ToTensor."""
+    x = torch.clamp(x, 0, 1)
+    out = torch.empty_like(x)
+    for i in range(x.shape[0]):
+        u8 = x[i].mul(255).byte().permute(1, 2, 0).numpy()
+        out[i] = torch.from_numpy(pil_roundtrip(np.ascontiguousarray(u8), quality).copy()).permute(2, 0, 1).float() / 255
+    return out

@@ -1,0 +1,117 @@
+"""Augmentation kernels vs the CPU oracle (torch / Pillow), and BASELINE config 3: clip -> embed -> fixed-strength chain
+(JPEG -> Crop -> Resize -> colour ops) -> detect, compared with the oracle chain on the same watermarked frames."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import augment as A  # noqa: E402
+from oracle import videoseal_ref as R  # noqa: E402
+from oracle.inputs import synthetic_frames, synthetic_msgs  # noqa: E402
+from oracle.weights import make_state_dict, tiny_spec  # noqa: E402
+from tests.test_gpu_e2e import make_model  # noqa: E402
+from videoseal_amd import augmentation as G  # noqa: E402
+
+
+@pytest.fixture(scope="module")
+def frames():
+    return synthetic_frames(3, 93, 118, seed=31)
+
+
+@pytest.mark.parametrize("hw,quality", [((64, 64), 60), ((93, 118), 40), ((50, 50), 90), ((37, 53), 75), ((256, 256), 50), ((768, 768), 80)])
+def test_jpeg_is_bit_exact_with_pillow(hw, quality):
+    x = synthetic_frames(2, hw[0], hw[1], seed=hw[0] + quality)
+    x[0, :, :5, :5] = 1.7      # out-of-range values are clamped first (valuemetric.py:41)
+    x[1, :, -3:, :] = -0.2
+    ref = A.jpeg(x, quality)
+    got, _ = G.JPEG()(x.cuda(), None, quality)
+    assert torch.equal(got.cpu(), ref), "GPU JPEG differs from the Pillow/libjpeg round trip"
+
+
+@pytest.mark.parametrize("name,op,ref,vals", [
+    ("brightness", G.Brightness, A.brightness, [0.1, 0.5, 1.5, 2.0]),
+    ("contrast", G.Contrast, A.contrast, [0.1, 0.5, 1.5, 2.0]),
+    ("saturation", G.Saturation, A.saturation, [0.0, 0.5, 1.5, 2.0]),
+    ("hue", G.Hue, A.hue, [-0.4, -0.1, 0.1, 0.25, 0.5]),
+])
+def test_colour_ops(frames, name, op, ref, vals):
+    for v in vals:
+        got, m = op()(frames.cuda(), None, v)
+        assert m is None
+        assert (got.cpu() - ref(frames, v)).abs().max() < 2e-6, (name, v)      # fp32 pointwise, torchvision semantics restated
+
+
+def test_grayscale_flip_crop_resize(frames):
+    x = frames.cuda()
+    mask = torch.rand(3, 1, 93, 118)
+    assert (G.Grayscale()(x)[0].cpu() - A.grayscale(frames)).abs().max() < 1e-6
+    im, mk = G.HorizontalFlip()(x, mask.cuda())
+    assert torch.equal(im.cpu(), A.hflip(frames)) and torch.equal(mk.cpu(), A.hflip(mask))
+    torch.manual_seed(7)
+    im, mk = G.Crop()(x, mask.cuda(), 0.71)
+    torch.manual_seed(7)
+    th, tw = int(0.71 * 93), int(0.71 * 118)
+    i = torch.randint(0, 93 - th + 1, size=(1,)).item(); j = torch.randint(0, 118 - tw + 1, size=(1,)).item()
+    assert im.shape[-2:] == (th, tw) and torch.equal(im.cpu(), A.crop(frames, i, j, th, tw)) and torch.equal(mk.cpu(), A.crop(mask, i, j, th, tw))
+    for s in (0.32, 0.71, 1.0, 1.4):
+        im, mk = G.Resize()(x, mask.cuda(), s)
+        size = (int(s * 93), int(s * 118))
+        assert (im.cpu() - A.resize(frames, size)).abs().max() < 2e-6 and (mk.cpu() - A.resize(mask, size)).abs().max() < 2e-6
+
+
+@pytest.mark.parametrize("k", [3, 5, 9, 13, 17])
+def test_gaussian_blur(frames, k):
+    got, _ = G.GaussianBlur()(frames.cuda(), None, k)
+    assert (got.cpu() - A.gaussian_blur(frames, k)).abs().max() < 2e-6
+
+
+@pytest.mark.parametrize("k", [3, 5])
+def test_median_filter(frames, k):
+    got, _ = G.MedianFilter()(frames.cuda(), None, k)
+    assert torch.equal(got.cpu(), A.median_filter(frames, k))      # selection only: exact
+
+
+def test_augmenter_picks_like_the_reference():
+    aug = G.Augmenter(masks={"kind": None}, augs={"identity": 1, "crop": 1, "brightness": 1, "jpeg": 1, "hflip": 1},
+                      augs_params={"crop": {"min_size": 0.5, "max_size": 1.0}, "brightness": {"min_factor": 0.5, "max_factor": 2},
+                                   "jpeg": {"min_quality": 40, "max_quality": 80}}, num_augs=2)
+    x = synthetic_frames(2, 64, 64, seed=3).cuda()
+    torch.manual_seed(11)
+    out, mask, names = aug(x, x, None, is_video=False, do_resize=True)
+    assert out.shape == x.shape and mask.shape == (2, 1, 64, 64) and len(names.split("+")) == 2
+    with pytest.raises(NotImplementedError):
+        G.Rotate()(x, None, 10)
+
+
+def test_config3_clip_through_the_full_chain():
+    """16-frame clip (BASELINE config 3, smaller frames for the CPU oracle) -> embed -> JPEG(60) -> Crop(0.71) -> Resize(0.8)
+    -> Brightness(0.5) -> Contrast(1.5) -> Saturation(1.5) -> Hue(0.1) -> detect; vs the oracle chain on OUR watermarked frames."""
+    spec = tiny_spec()
+    sd = make_state_dict(spec, seed=3)
+    model = make_model(spec, sd)
+    model.chunk_size, model.step_size, model.video_mode = 8, 2, "repeat"
+    imgs = synthetic_frames(16, 144, 176, seed=77)
+    msgs = synthetic_msgs(1, spec.nbits, seed=77)
+    w = model.embed(imgs.cuda(), msgs, is_video=True)["imgs_w"]
+    chain = G.Sequential(G.JPEG(), G.Crop(), G.Resize(), G.Brightness(), G.Contrast(), G.Saturation(), G.Hue())
+    args = (60, 0.71, 0.8, 0.5, 1.5, 1.5, 0.1)
+    torch.manual_seed(5)
+    aug, _ = chain(w, None, args)
+    # oracle chain on the same frames
+    wc = w.cpu()
+    torch.manual_seed(5)
+    r = A.jpeg(wc, 60)
+    th, tw = int(0.71 * 144), int(0.71 * 176)
+    i = torch.randint(0, 144 - th + 1, size=(1,)).item(); j = torch.randint(0, 176 - tw + 1, size=(1,)).item()
+    r = A.crop(r, i, j, th, tw)
+    r = A.resize(r, (int(0.8 * th), int(0.8 * tw)))
+    r = A.hue(A.saturation(A.contrast(A.brightness(r, 0.5), 1.5), 1.5), 0.1)
+    assert aug.shape == r.shape
+    assert (aug.cpu() - r).abs().max() < 1e-5
+    preds = model.detect(aug, is_video=True)["preds"].cpu()
+    pref = R.detect(sd, spec, r)["preds"]
+    assert (preds - pref).abs().max() < 1e-3
+    assert ((preds > 0) == (pref > 0))[pref.abs() > 2e-3].all()
+    acc = R.bit_accuracy(preds[:, 1:], msgs.expand(16, -1).float())
+    acc_ref = R.bit_accuracy(pref[:, 1:], msgs.expand(16, -1).float())
+    assert (acc - acc_ref).abs().max() < 1e-3

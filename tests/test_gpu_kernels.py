@@ -38,6 +38,7 @@ class Eng(HipEngine):
         self.kernel_timers = None
         self.use_split = use_split
         self.autotune = False
+        self.time_all_convs = False
         self._tile_cache = {}
 
 

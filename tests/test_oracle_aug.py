@@ -1,0 +1,40 @@
+"""Pins of the augmentation oracle (CPU only): the integer libjpeg restatement is BIT-EXACT with Pillow."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import augment as A
+from oracle.inputs import synthetic_frames
+from oracle.jpeg_ref import jpeg_roundtrip, pil_roundtrip
+
+
+@pytest.mark.parametrize("hw", [(64, 64), (100, 75), (37, 53), (50, 50), (120, 200), (17, 19), (8, 8), (1, 1), (2, 3), (256, 256)])
+@pytest.mark.parametrize("quality", [40, 60, 75, 90])
+def test_integer_jpeg_restatement_is_bit_exact_with_pillow(hw, quality):
+    H, W = hw
+    for kind in ("smooth", "uniform"):
+        x = (synthetic_frames(1, H, W, seed=H * 7 + W + quality, kind=kind)[0].permute(1, 2, 0).numpy() * 255).astype(np.uint8)
+        assert np.array_equal(jpeg_roundtrip(x, quality), pil_roundtrip(x, quality)), (hw, quality, kind)
+
+
+def test_colour_ops_identities():
+    x = synthetic_frames(2, 24, 20, seed=1)
+    assert torch.allclose(A.brightness(x, 1.0), x)
+    assert torch.allclose(A.saturation(x, 1.0), x) and torch.allclose(A.contrast(x, 1.0), x)
+    assert torch.allclose(A.hue(x, 0.0), x, atol=1e-6) and torch.allclose(A.hue(x, 1.0), x, atol=1e-5)
+    g = A.grayscale(x)
+    assert torch.equal(g[:, 0], g[:, 1]) and torch.equal(g[:, 1], g[:, 2])
+    assert torch.allclose(A.saturation(x, 0.0), A.gray_tv(x).expand_as(x).clamp(0, 1))
+    assert torch.equal(A.hflip(A.hflip(x)), x)
+
+
+def test_median_is_median_of_row_medians():
+    x = torch.rand(1, 1, 5, 5)
+    m = A.median_filter(x, 3)
+    win = x[0, 0, 1:4, 1:4]
+    assert m[0, 0, 2, 2] == win.median(dim=-1).values.median()
+
+
+def test_gaussian_blur_preserves_constants():
+    x = torch.full((1, 3, 20, 20), 0.37)
+    assert torch.allclose(A.gaussian_blur(x, 9), x, atol=1e-6)

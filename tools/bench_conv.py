@@ -15,7 +15,7 @@ from videoseal_amd.engine import Act, ConvW, HipEngine, pack_conv, rup  # noqa: 
 
 class Eng(HipEngine):
     def __init__(self):
-        self.dev = torch.device("cuda"); self.lib = N.lib(); self._ws = {}; self.kernel_timers = None; self.use_split = True; self.autotune = False; self._tile_cache = {}
+        self.dev = torch.device("cuda"); self.lib = N.lib(); self._ws = {}; self.kernel_timers = None; self.use_split = True; self.autotune = False; self._tile_cache = {}; self.time_all_convs = False
 
 
 def bench(eng, name, B, Cin, H, W, Cout, k, variants, reps=10, check=True):

@@ -1,0 +1,338 @@
+"""Augmentations of the embed -> augment -> extract path on the HIP kernels (csrc/aug.hip).
+
+Same call surface as the reference's ``videoseal.augmentation`` for the rows in scope:
+every op is ``op(image, mask=None, strength=None) -> (image, mask)``, ``Sequential(*ops)(image, mask, args)``,
+``Augmenter(masks, augs, augs_params, num_augs)`` with the multinomial pick, and the validation tables.
+Random parameters are drawn exactly like the reference (torch CPU RNG: ``torch.randint`` / ``torch.rand``),
+so a seeded run picks the same strengths.  Out of scope and loud: Rotate / Perspective (grid-sample kernels,
+SURVEY 8(f)3) and the H.264/H.265/VP9/AV1 codecs (external libx264).
+
+Forward values only: the reference wraps JPEG / MedianFilter in a straight-through estimator whose forward value
+is the codec / filter output, which is what these kernels produce; there is no autograd here.
+"""
+from __future__ import annotations
+
+from typing import Dict, List, Optional, Tuple
+
+import torch
+import torch.nn as nn
+
+from . import native as N
+
+COLOR_OPS = {"brightness": 0, "contrast": 1, "saturation": 2, "hue": 3, "grayscale": 4}
+
+
+def _dev(x: torch.Tensor) -> torch.Tensor:
+    if not x.is_cuda:
+        raise N.NativeError("augmentations run on the HIP kernels: pass device tensors (no CPU fallback)")
+    return N.f32c(x)
+
+
+def _planes(x: torch.Tensor) -> Tuple[int, int, int]:
+    return x.shape[0] * x.shape[1], x.shape[-2], x.shape[-1]
+
+
+def color_op(x: torch.Tensor, op: str, factor: float) -> torch.Tensor:
+    x = _dev(x)
+    F_, Cc, H, W = x.shape
+    if Cc != 3:
+        raise ValueError("colour augmentations expect 3-channel frames")
+    L = N.lib()
+    out = torch.empty_like(x)
+    scratch = torch.empty(int(L.vs_aug_color_scratch_floats(F_, H, W)), device=x.device, dtype=torch.float32)
+    N.check(L.vs_aug_color(N.ptr(x), N.ptr(out), F_, H, W, COLOR_OPS[op], float(factor), N.ptr(scratch), N.stream()), "vs_aug_color")
+    return out
+
+
+def crop_flip(x: torch.Tensor, i: int, j: int, h: int, w: int, flip: bool = False) -> torch.Tensor:
+    x = _dev(x)
+    planes, H, W = _planes(x)
+    out = torch.empty(x.shape[0], x.shape[1], h, w, device=x.device, dtype=torch.float32)
+    N.check(N.lib().vs_aug_crop_flip(N.ptr(x), N.ptr(out), planes, H, W, i, j, h, w, int(flip), N.stream()), "vs_aug_crop_flip")
+    return out
+
+
+def resize(x: torch.Tensor, size: Tuple[int, int], antialias: bool = True) -> torch.Tensor:
+    x = _dev(x)
+    planes, H, W = _planes(x)
+    out = torch.empty(x.shape[0], x.shape[1], size[0], size[1], device=x.device, dtype=torch.float32)
+    N.check(N.lib().vs_resize_nchw(N.ptr(x), N.ptr(out), planes, H, W, size[0], size[1], int(antialias), N.stream()), "vs_resize_nchw")
+    return out
+
+
+def gaussian_blur(x: torch.Tensor, kernel_size: int) -> torch.Tensor:
+    x = _dev(x)
+    planes, H, W = _planes(x)
+    sigma = 0.3 * ((kernel_size - 1) * 0.5 - 1) + 0.8            # torchvision default when sigma is None
+    tmp, out = torch.empty_like(x), torch.empty_like(x)
+    N.check(N.lib().vs_gaussian_blur(N.ptr(x), N.ptr(tmp), N.ptr(out), planes, H, W, kernel_size, sigma, N.stream()), "vs_gaussian_blur")
+    return out
+
+
+def median_filter(x: torch.Tensor, kernel_size: int) -> torch.Tensor:
+    if kernel_size % 2 == 0:
+        raise ValueError("Kernel size must be odd.")
+    x = _dev(x)
+    planes, H, W = _planes(x)
+    out = torch.empty_like(x)
+    N.check(N.lib().vs_median_filter(N.ptr(x), N.ptr(out), planes, H, W, kernel_size, N.stream()), "vs_median_filter")
+    return out
+
+
+def jpeg_compress(x: torch.Tensor, quality: int) -> torch.Tensor:
+    """[F,3,H,W] in [0,1] (values outside are clamped, valuemetric.py:41) -> libjpeg round trip at `quality`."""
+    x = _dev(x)
+    F_, Cc, H, W = x.shape
+    if Cc != 3:
+        raise ValueError("JPEG expects 3-channel frames")
+    L = N.lib()
+    ws = torch.empty(int(L.vs_jpeg_workspace_bytes(F_, H, W)), device=x.device, dtype=torch.uint8)
+    out = torch.empty_like(x)
+    N.check(L.vs_jpeg_roundtrip(N.ptr(x), N.ptr(out), F_, H, W, int(quality), N.ptr(ws), N.stream()), "vs_jpeg_roundtrip")
+    return out
+
+
+# ------------------------------------------------------------------------------------------------ op classes
+class _Aug(nn.Module):
+    def __repr__(self):
+        return self.__class__.__name__
+
+
+class Identity(_Aug):
+    def forward(self, image, mask=None, *args, **kwargs):
+        return image, mask
+
+
+class HorizontalFlip(_Aug):
+    def forward(self, image, mask=None, *args, **kwargs):
+        H, W = image.shape[-2:]
+        image = crop_flip(image, 0, 0, H, W, flip=True)
+        mask = crop_flip(mask, 0, 0, H, W, flip=True) if mask is not None else mask
+        return image, mask
+
+
+class _Sized(_Aug):
+    def __init__(self, min_size=None, max_size=None):
+        super().__init__()
+        self.min_size, self.max_size = min_size, max_size
+
+    def get_random_size(self, h, w):
+        if self.min_size is None or self.max_size is None:
+            raise ValueError("min_size and max_size must be provided")
+        return (torch.randint(int(self.min_size * h), int(self.max_size * h) + 1, size=(1,)).item(),
+                torch.randint(int(self.min_size * w), int(self.max_size * w) + 1, size=(1,)).item())
+
+    def _out_size(self, image, size):
+        h, w = image.shape[-2:]
+        return self.get_random_size(h, w) if size is None else (int(size * h), int(size * w))
+
+
+class Resize(_Sized):
+    def forward(self, image, mask=None, size=None):
+        out = self._out_size(image, size)
+        return resize(image, out, True), (resize(mask, out, True) if mask is not None else mask)
+
+
+class Crop(_Sized):
+    def forward(self, image, mask=None, size=None):
+        th, tw = self._out_size(image, size)
+        h, w = image.shape[-2:]
+        if h < th or w < tw:
+            raise ValueError(f"Required crop size {(th, tw)} is larger than input image size {(h, w)}")
+        if w == tw and h == th:                              # torchvision RandomCrop.get_params
+            i, j = 0, 0
+        else:
+            i = torch.randint(0, h - th + 1, size=(1,)).item()
+            j = torch.randint(0, w - tw + 1, size=(1,)).item()
+        return crop_flip(image, i, j, th, tw), (crop_flip(mask, i, j, th, tw) if mask is not None else mask)
+
+
+class _Factor(_Aug):
+    op = ""
+
+    def __init__(self, min_factor=None, max_factor=None):
+        super().__init__()
+        self.min_factor, self.max_factor = min_factor, max_factor
+
+    def get_random_factor(self):
+        if self.min_factor is None or self.max_factor is None:
+            raise ValueError("min_factor and max_factor must be provided")
+        return torch.rand(1).item() * (self.max_factor - self.min_factor) + self.min_factor
+
+    def forward(self, image, mask=None, factor=None):
+        factor = self.get_random_factor() if factor is None else factor
+        return color_op(image, self.op, factor), mask
+
+
+class Brightness(_Factor):
+    op = "brightness"
+
+
+class Contrast(_Factor):
+    op = "contrast"
+
+
+class Saturation(_Factor):
+    op = "saturation"
+
+
+class Hue(_Factor):
+    op = "hue"
+
+
+class Grayscale(_Aug):
+    def forward(self, image, mask=None, *args, **kwargs):
+        return color_op(image, "grayscale", 0.0), mask
+
+
+class _Kernel(_Aug):
+    def __init__(self, min_kernel_size=None, max_kernel_size=None, passthrough=True):
+        super().__init__()
+        self.min_kernel_size, self.max_kernel_size, self.passthrough = min_kernel_size, max_kernel_size, passthrough
+
+    def get_random_kernel_size(self):
+        if self.min_kernel_size is None or self.max_kernel_size is None:
+            raise ValueError("Kernel size range must be specified")
+        k = torch.randint(self.min_kernel_size, self.max_kernel_size + 1, size=(1,)).item()
+        return k + 1 if k % 2 == 0 else k
+
+
+class GaussianBlur(_Kernel):
+    def forward(self, image, mask=None, kernel_size=None):
+        kernel_size = kernel_size or self.get_random_kernel_size()
+        return gaussian_blur(image, kernel_size), mask
+
+
+class MedianFilter(_Kernel):
+    def forward(self, image, mask=None, kernel_size=None):
+        kernel_size = kernel_size or self.get_random_kernel_size()
+        return median_filter(image, kernel_size), mask
+
+
+class JPEG(_Aug):
+    def __init__(self, min_quality=None, max_quality=None, passthrough=True):
+        super().__init__()
+        self.min_quality, self.max_quality, self.passthrough = min_quality, max_quality, passthrough
+
+    def get_random_quality(self):
+        if self.min_quality is None or self.max_quality is None:
+            raise ValueError("Quality range must be specified")
+        return torch.randint(self.min_quality, self.max_quality + 1, size=(1,)).item()
+
+    def forward(self, image, mask=None, quality=None):
+        quality = quality or self.get_random_quality()
+        squeeze = image.dim() == 3
+        out = jpeg_compress(image[None] if squeeze else image, quality)
+        return (out[0] if squeeze else out), mask
+
+
+class _NotBuilt(_Aug):
+    why = ""
+
+    def __init__(self, *a, **k):
+        super().__init__()
+
+    def forward(self, *a, **k):
+        raise NotImplementedError(f"{self.__class__.__name__}: {self.why}")
+
+
+class Rotate(_NotBuilt):
+    why = "grid-sample kernels are a 'next' row (SURVEY.md 8(f)3)"
+
+
+class Perspective(_NotBuilt):
+    why = "grid-sample kernels are a 'next' row (SURVEY.md 8(f)3)"
+
+
+class H264(_NotBuilt):
+    why = "external libx264 codec (PyAV) -- no in-repo arithmetic to restate (SURVEY.md 8(f)2)"
+
+
+class Sequential(nn.Module):
+    """augmentation/sequential.py:8-30."""
+
+    def __init__(self, *args):
+        super().__init__()
+        self.transforms = args
+
+    def forward(self, image, mask, args):
+        args = tuple(args) + (None,) * (len(self.transforms) - len(args))
+        for transform, aug_arg in zip(self.transforms, args):
+            image, mask = transform(image, mask, aug_arg)
+        return image, mask
+
+    def __repr__(self):
+        return f"{self.transforms}".replace(", ", "_")
+
+
+name2aug = {"resize": Resize, "crop": Crop, "hflip": HorizontalFlip, "identity": Identity, "jpeg": JPEG, "gaussian_blur": GaussianBlur,
+            "median_filter": MedianFilter, "brightness": Brightness, "contrast": Contrast, "saturation": Saturation, "hue": Hue,
+            "rotate": Rotate, "perspective": Perspective, "h264": H264, "h264rgb": H264, "h265": H264, "video_compression": H264}
+video_augs = ["video_compression", "h264", "h264rgb", "h265"]
+
+
+class Augmenter(nn.Module):
+    """augmentation/augmenter.py:60-199 (train branch; masks kind None/'none' = full masks, all_augs.yaml:2-3)."""
+
+    def __init__(self, masks: dict, augs: dict, augs_params: dict, num_augs: int = 1, **kwargs) -> None:
+        super().__init__()
+        kind = (masks or {}).get("kind", None)
+        if kind not in (None, "none", "None"):
+            raise NotImplementedError("mask embedders other than the full mask are out of scope (SURVEY.md section 2, row 23)")
+        self.augs, self.aug_probs = self.parse_augmentations(augs, augs_params)
+        self.augs_video, self.aug_probs_video = self.parse_augmentations(augs, augs_params, is_video=True)
+        self.num_augs = num_augs
+
+    @staticmethod
+    def parse_augmentations(augs: Dict[str, float], augs_params: Dict[str, dict], is_video: bool = False):
+        out, probs = [], []
+        for name in augs.keys():
+            if name in video_augs and not is_video:
+                continue
+            if name not in name2aug:
+                raise ValueError(f"Augmentation {name} not found. Add it in name2aug.")
+            out.append(name2aug[name](**(augs_params.get(name, {}) or {})))
+            probs.append(float(augs[name]))
+        total = sum(probs)
+        return nn.ModuleList(out), torch.tensor([p / total for p in probs])
+
+    def augment(self, image, mask, is_video, do_resize=True):
+        augs = self.augs_video if is_video else self.augs
+        probs = self.aug_probs_video if is_video else self.aug_probs
+        aug = augs[torch.multinomial(probs, 1).item()]
+        h, w = image.shape[-2:]
+        image, mask = aug(image, mask)
+        if do_resize and image.shape[-2:] != (h, w):
+            image = resize(image, (h, w), True)
+            mask = resize(mask, (h, w), True)
+        return image, mask, aug.__class__.__name__
+
+    def forward(self, imgs_w, imgs, masks, is_video=True, do_resize=True):
+        # full mask: mask_targets = 1, imgs_aug = imgs_w (augmenter.py:171-176 with NoMaskEmbedder)
+        mask_targets = torch.ones_like(imgs_w)[:, 0:1]
+        imgs_aug = imgs_w
+        names: List[str] = []
+        for _ in range(self.num_augs):
+            imgs_aug, mask_targets, nm = self.augment(imgs_aug, mask_targets, is_video, do_resize)
+            names.append(nm)
+        return imgs_aug, mask_targets, "+".join(names)
+
+
+def get_validation_augs(is_video: bool = False, only_identity: bool = False, only_combined: bool = False) -> list:
+    """The fixed-strength evaluation table of augmentation/__init__.py:58-124 restricted to the ops built here
+    (image table; codecs / Rotate / Perspective rows are dropped)."""
+    if only_identity:
+        return [(Identity(), [0])]
+    if only_combined:
+        return [(Identity(), [0]), (Sequential(JPEG(), Crop(), Brightness()), [(40, 0.71, 0.5)])]
+    if is_video:
+        return [(Identity(), [0]), (HorizontalFlip(), [0]), (Resize(), [0.55, 0.71]), (Crop(), [0.55, 0.71]), (Brightness(), [0.5, 1.5]),
+                (Contrast(), [0.5, 1.5]), (Saturation(), [0.5, 1.5]), (Hue(), [0.25]), (Grayscale(), [-1]), (JPEG(), [40]), (GaussianBlur(), [9])]
+    return [(Identity(), [0]), (HorizontalFlip(), [0]),
+            (Resize(), [0.32, 0.45, 0.55, 0.63, 0.71, 0.77, 0.84, 0.89, 0.95, 1.00]),
+            (Crop(), [0.32, 0.45, 0.55, 0.63, 0.71, 0.77, 0.84, 0.89, 0.95, 1.00]),
+            (Brightness(), [0.1, 0.25, 0.5, 0.75, 1.0, 1.25, 1.5, 1.75, 2.0]), (Contrast(), [0.1, 0.25, 0.5, 0.75, 1.0, 1.25, 1.5, 1.75, 2.0]),
+            (Hue(), [-0.4, -0.3, -0.2, -0.1, 0.0, 0.1, 0.2, 0.3, 0.4, 0.5]), (Grayscale(), [-1]), (JPEG(), [40, 50, 60, 70, 80, 90]),
+            (GaussianBlur(), [3, 5, 9, 13, 17]),
+            (Sequential(JPEG(), Crop(), Brightness()), [(40, 0.71, 0.5)]), (Sequential(JPEG(), Crop(), Brightness()), [(60, 0.71, 0.5)]),
+            (Sequential(JPEG(), Crop(), Brightness()), [(80, 0.71, 0.5)])]

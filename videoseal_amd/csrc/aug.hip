@@ -1,0 +1,496 @@
+// Augmentation kernels of the embed -> augment -> extract path (reference: videoseal/augmentation/{valuemetric,geometric}.py
+// + utils/image.py).  All operate on NCHW fp32 frames resident in HBM; they are bandwidth-bound by construction.
+//   colour      : brightness / contrast / saturation / hue / grayscale  (torchvision _functional_tensor semantics)
+//   geometric   : hflip, crop, (anti-aliased) bilinear resize
+//   filters     : separable Gaussian blur (reflect pad), median-of-row-medians k x k (zero pad, utils/image.py:80-83)
+//   JPEG        : libjpeg(-turbo) baseline 4:2:0 encode + decode emulated bit-exactly in integer arithmetic
+//                 (fixed-point colour transform, h2v2 box down-sampling with alternating bias, jpeg_fdct_islow,
+//                 IJG quantisation, jpeg_idct_islow, h2v2 fancy up-sampling, fixed-point YCC->RGB); entropy coding is
+//                 lossless and skipped.  Pinned against Pillow in tests (oracle/jpeg_ref.py is the numpy restatement).
+#include "vs_common.h"
+
+namespace {
+
+// ------------------------------------------------------------------------------------------------ colour ops
+enum { OP_BRIGHTNESS = 0, OP_CONTRAST = 1, OP_SATURATION = 2, OP_HUE = 3, OP_GRAYSCALE = 4 };
+
+__device__ __forceinline__ float clamp01(float v) { return fminf(fmaxf(v, 0.f), 1.f); }
+__device__ __forceinline__ float tv_gray(float r, float g, float b) { return 0.2989f * r + 0.587f * g + 0.114f * b; }
+
+__device__ __forceinline__ void hue_shift(float& r, float& g, float& b, float factor) {
+  // torchvision _rgb2hsv -> h = (h + factor) % 1 -> _hsv2rgb
+  const float maxc = fmaxf(r, fmaxf(g, b)), minc = fminf(r, fminf(g, b));
+  const bool eqc = maxc == minc;
+  const float cr = maxc - minc;
+  const float s = cr / (eqc ? 1.f : maxc);
+  const float div = eqc ? 1.f : cr;
+  const float rc = (maxc - r) / div, gc = (maxc - g) / div, bc = (maxc - b) / div;
+  const float hr = (maxc == r) ? (bc - gc) : 0.f;
+  const float hg = ((maxc == g) && (maxc != r)) ? (2.0f + rc - bc) : 0.f;
+  const float hb = ((maxc != g) && (maxc != r)) ? (4.0f + gc - rc) : 0.f;
+  float h = fmodf((hr + hg + hb) / 6.0f + 1.0f, 1.0f);
+  const float v = maxc;
+  h = h + factor;
+  h = h - floorf(h);                       // python-style % 1.0
+  const float h6 = h * 6.0f;
+  const float fi = floorf(h6);
+  const float f = h6 - fi;
+  int i = (int)fi;
+  i = ((i % 6) + 6) % 6;
+  const float p = clamp01(v * (1.0f - s)), q = clamp01(v * (1.0f - s * f)), t = clamp01(v * (1.0f - s * (1.0f - f)));
+  switch (i) {
+    case 0: r = v; g = t; b = p; break;
+    case 1: r = q; g = v; b = p; break;
+    case 2: r = p; g = v; b = t; break;
+    case 3: r = p; g = q; b = v; break;
+    case 4: r = t; g = p; b = v; break;
+    default: r = v; g = p; b = q; break;
+  }
+}
+
+__global__ __launch_bounds__(256) void color_kernel(const float* __restrict__ src, float* __restrict__ dst, int64_t plane, int op,
+                                                    float factor, const float* __restrict__ means) {
+  const int f = blockIdx.y;
+  const float* s = src + (int64_t)f * 3 * plane;
+  float* d = dst + (int64_t)f * 3 * plane;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < plane; i += (int64_t)gridDim.x * 256) {
+    float r = s[i], g = s[plane + i], b = s[2 * plane + i];
+    switch (op) {
+      case OP_BRIGHTNESS: r = clamp01(factor * r); g = clamp01(factor * g); b = clamp01(factor * b); break;   // _blend(x, 0, f)
+      case OP_CONTRAST: {
+        const float m = (1.0f - factor) * means[f];
+        r = clamp01(factor * r + m); g = clamp01(factor * g + m); b = clamp01(factor * b + m);
+      } break;
+      case OP_SATURATION: {
+        const float m = (1.0f - factor) * tv_gray(r, g, b);
+        r = clamp01(factor * r + m); g = clamp01(factor * g + m); b = clamp01(factor * b + m);
+      } break;
+      case OP_HUE: hue_shift(r, g, b, factor); break;
+      default: { const float y = 0.299f * r + 0.587f * g + 0.114f * b; r = g = b = y; } break;   // valuemetric.py:205-206
+    }
+    d[i] = r; d[plane + i] = g; d[2 * plane + i] = b;
+  }
+}
+
+// per-frame mean of the torchvision gray image, deterministic two-stage reduction
+__global__ __launch_bounds__(256) void gray_partial_kernel(const float* __restrict__ src, int64_t plane, float* __restrict__ partial) {
+  __shared__ float red[256];
+  const int f = blockIdx.y;
+  const float* s = src + (int64_t)f * 3 * plane;
+  float acc = 0.f;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < plane; i += (int64_t)gridDim.x * 256)
+    acc += tv_gray(s[i], s[plane + i], s[2 * plane + i]);
+  red[threadIdx.x] = acc;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) partial[(int64_t)f * gridDim.x + blockIdx.x] = red[0];
+}
+__global__ void gray_finish_kernel(const float* __restrict__ partial, int nblk, int64_t plane, float* __restrict__ means) {
+  const int f = blockIdx.x * blockDim.x + threadIdx.x;
+  if (f >= (int)gridDim.x * (int)blockDim.x) return;
+  float s = 0.f;
+  for (int k = 0; k < nblk; ++k) s += partial[(int64_t)f * nblk + k];
+  means[f] = s / (float)plane;
+}
+
+// ------------------------------------------------------------------------------------------------ geometric
+__global__ __launch_bounds__(256) void crop_flip_kernel(const float* __restrict__ src, float* __restrict__ dst, int H, int W, int i0,
+                                                        int j0, int h, int w, int flip) {
+  const int64_t pl = blockIdx.y;
+  const float* s = src + pl * (int64_t)H * W;
+  float* d = dst + pl * (int64_t)h * w;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < (int64_t)h * w; i += (int64_t)gridDim.x * 256) {
+    const int y = (int)(i / w), x = (int)(i - (int64_t)y * w);
+    const int sy = y + i0, sx = (flip ? (w - 1 - x) : x) + j0;
+    float v = 0.f;                                           // torchvision crop pads with zeros outside the image
+    if (sy >= 0 && sy < H && sx >= 0 && sx < W) v = s[(int64_t)sy * W + sx];
+    d[i] = v;
+  }
+}
+
+// ATen-compatible taps (same as shell.hip; duplicated on purpose to keep the translation units independent)
+struct Taps { int lo, n; float center, inv, total, l1; bool aa; };
+__device__ __forceinline__ float tri(float x) { x = fabsf(x); return x < 1.f ? 1.f - x : 0.f; }
+__device__ __forceinline__ Taps make_taps(int i, int in, int out, bool antialias) {
+  Taps t; t.aa = antialias;
+  const float scale = (float)in / (float)out;
+  if (antialias) {
+    const float support = scale >= 1.f ? scale : 1.f;
+    t.center = scale * (i + 0.5f);
+    t.inv = scale >= 1.f ? 1.f / scale : 1.f;
+    int lo = (int)(t.center - support + 0.5f); lo = lo < 0 ? 0 : lo;
+    int hi = (int)(t.center + support + 0.5f); hi = hi > in ? in : hi;
+    t.lo = lo; t.n = hi - lo;
+    float tot = 0.f;
+    for (int j = 0; j < t.n; ++j) tot += tri((j + lo - t.center + 0.5f) * t.inv);
+    t.total = tot; t.l1 = 0.f;
+  } else {
+    float src = scale * (i + 0.5f) - 0.5f; src = src < 0.f ? 0.f : src;
+    int i0 = (int)src; i0 = i0 > in - 1 ? in - 1 : i0;
+    t.lo = i0; t.n = 1 + (i0 < in - 1); t.l1 = src - i0; t.center = t.inv = t.total = 0.f;
+  }
+  return t;
+}
+__device__ __forceinline__ float tap_w(const Taps& t, int j) {
+  if (t.aa) { const float w = tri((j + t.lo - t.center + 0.5f) * t.inv); return t.total != 0.f ? w / t.total : w; }
+  if (t.n == 1) return 1.f;
+  return j == 0 ? 1.f - t.l1 : t.l1;
+}
+__global__ __launch_bounds__(256) void resize_nchw_kernel(const float* __restrict__ src, float* __restrict__ dst, int H, int W, int oh,
+                                                          int ow, int antialias) {
+  const int ox = blockIdx.x * 32 + (threadIdx.x & 31), oy = blockIdx.y * 8 + (threadIdx.x >> 5);
+  if (ox >= ow || oy >= oh) return;
+  const float* s = src + (int64_t)blockIdx.z * H * W;
+  const Taps ty = make_taps(oy, H, oh, antialias), tx = make_taps(ox, W, ow, antialias);
+  float acc = 0.f;
+  for (int jy = 0; jy < ty.n; ++jy) {
+    const float* row = s + (int64_t)(ty.lo + jy) * W + tx.lo;
+    float r = 0.f;
+    for (int jx = 0; jx < tx.n; ++jx) r += tap_w(tx, jx) * row[jx];
+    acc += tap_w(ty, jy) * r;
+  }
+  dst[((int64_t)blockIdx.z * oh + oy) * ow + ox] = acc;
+}
+
+// ------------------------------------------------------------------------------------------------ filters
+struct GaussK { float w[33]; int k; };
+__device__ __forceinline__ int reflect_idx(int i, int n) { return i < 0 ? -i : (i >= n ? 2 * n - 2 - i : i); }
+__global__ __launch_bounds__(256) void blur_pass_kernel(const float* __restrict__ src, float* __restrict__ dst, int H, int W, GaussK g,
+                                                        int vertical) {
+  const int x = blockIdx.x * 32 + (threadIdx.x & 31), y = blockIdx.y * 8 + (threadIdx.x >> 5);
+  if (x >= W || y >= H) return;
+  const float* s = src + (int64_t)blockIdx.z * H * W;
+  const int half = g.k >> 1;
+  float acc = 0.f;
+  for (int j = 0; j < g.k; ++j) {
+    const int yy = vertical ? reflect_idx(y + j - half, H) : y;
+    const int xx = vertical ? x : reflect_idx(x + j - half, W);
+    acc += g.w[j] * s[(int64_t)yy * W + xx];
+  }
+  dst[((int64_t)blockIdx.z * H + y) * W + x] = acc;
+}
+
+// median of the k row-medians of the zero-padded k x k window (torch .median on an odd count = the middle element)
+template <int K>
+__global__ __launch_bounds__(256) void median_kernel(const float* __restrict__ src, float* __restrict__ dst, int H, int W) {
+  const int x = blockIdx.x * 32 + (threadIdx.x & 31), y = blockIdx.y * 8 + (threadIdx.x >> 5);
+  if (x >= W || y >= H) return;
+  const float* s = src + (int64_t)blockIdx.z * H * W;
+  constexpr int half = K / 2;
+  float rowmed[K];
+#pragma unroll
+  for (int i = 0; i < K; ++i) {
+    float v[K];
+    const int yy = y + i - half;
+#pragma unroll
+    for (int j = 0; j < K; ++j) {
+      const int xx = x + j - half;
+      v[j] = (yy >= 0 && yy < H && xx >= 0 && xx < W) ? s[(int64_t)yy * W + xx] : 0.f;
+    }
+#pragma unroll
+    for (int a = 1; a < K; ++a)          // insertion sort (K <= 7)
+#pragma unroll
+      for (int b = a; b > 0; --b) {
+        const float lo = fminf(v[b - 1], v[b]), hi = fmaxf(v[b - 1], v[b]);
+        v[b - 1] = lo; v[b] = hi;
+      }
+    rowmed[i] = v[half];
+  }
+#pragma unroll
+  for (int a = 1; a < K; ++a)
+#pragma unroll
+    for (int b = a; b > 0; --b) {
+      const float lo = fminf(rowmed[b - 1], rowmed[b]), hi = fmaxf(rowmed[b - 1], rowmed[b]);
+      rowmed[b - 1] = lo; rowmed[b] = hi;
+    }
+  dst[((int64_t)blockIdx.z * H + y) * W + x] = rowmed[half];
+}
+
+// ------------------------------------------------------------------------------------------------ JPEG (libjpeg islow, 4:2:0)
+constexpr int CONST_BITS = 13, PASS1_BITS = 2;
+#define FIX_0_298631336 2446
+#define FIX_0_390180644 3196
+#define FIX_0_541196100 4433
+#define FIX_0_765366865 6270
+#define FIX_0_899976223 7373
+#define FIX_1_175875602 9633
+#define FIX_1_501321110 12299
+#define FIX_1_847759065 15137
+#define FIX_1_961570560 16069
+#define FIX_2_053119869 16819
+#define FIX_2_562915447 20995
+#define FIX_3_072711026 25172
+__device__ __forceinline__ int descale(int x, int n) { return (x + (1 << (n - 1))) >> n; }
+
+__device__ __forceinline__ int px_u8(float v) {   // torchvision ToPILImage on float: clamp (JPEG.forward) then mul(255).byte() = truncation
+  v = fminf(fmaxf(v, 0.f), 1.f);
+  return (int)(v * 255.0f);
+}
+
+// stage 1: RGB -> Y (full res, padded to 16) and Cb, Cr (h2v2 box down-sampled, padded).  One thread per chroma sample.
+__global__ __launch_bounds__(256) void jpeg_ycc_kernel(const float* __restrict__ src, int H, int W, int Hp, int Wp,
+                                                       unsigned char* __restrict__ Y, unsigned char* __restrict__ Cb,
+                                                       unsigned char* __restrict__ Cr) {
+  const int cx = blockIdx.x * 32 + (threadIdx.x & 31), cy = blockIdx.y * 8 + (threadIdx.x >> 5);
+  const int cw = Wp / 2, ch = Hp / 2;
+  if (cx >= cw || cy >= ch) return;
+  const int f = blockIdx.z;
+  const int64_t plane = (int64_t)H * W;
+  const float* s = src + (int64_t)f * 3 * plane;
+  const int He = (H + 1) / 2;                // chroma rows backed by real pixels; below: replicate the last DOWNSAMPLED row
+  const int cys = cy < He ? cy : He - 1;
+  int sb = 0, sr = 0;
+#pragma unroll
+  for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+    for (int dx = 0; dx < 2; ++dx) {
+      // luma: pixel-domain edge replication (rows and columns)
+      const int py = 2 * cy + dy, px = 2 * cx + dx;
+      const int yy = py < H ? py : H - 1, xx = px < W ? px : W - 1;
+      const int64_t o = (int64_t)yy * W + xx;
+      const int R = px_u8(s[o]), G = px_u8(s[plane + o]), B = px_u8(s[2 * plane + o]);
+      Y[((int64_t)f * Hp + py) * Wp + px] = (unsigned char)((19595 * R + 38470 * G + 7471 * B + 32768) >> 16);
+      // chroma: rows from the (1-row replicated) real image, columns replicated
+      const int py2 = 2 * cys + dy;
+      const int yy2 = py2 < H ? py2 : H - 1;
+      const int64_t o2 = (int64_t)yy2 * W + xx;
+      const int R2 = px_u8(s[o2]), G2 = px_u8(s[plane + o2]), B2 = px_u8(s[2 * plane + o2]);
+      sb += (-11059 * R2 - 21709 * G2 + 32768 * B2 + (128 << 16) + 32767) >> 16;
+      sr += (32768 * R2 - 27439 * G2 - 5329 * B2 + (128 << 16) + 32767) >> 16;
+    }
+  const int bias = 1 + (cx & 1);             // alternating 1,2,1,2...
+  Cb[((int64_t)f * ch + cy) * cw + cx] = (unsigned char)((sb + bias) >> 2);
+  Cr[((int64_t)f * ch + cy) * cw + cx] = (unsigned char)((sr + bias) >> 2);
+}
+
+__device__ __forceinline__ void fdct8(int* d, int stride, bool first) {
+  const int d0 = d[0], d1 = d[stride], d2 = d[2 * stride], d3 = d[3 * stride], d4 = d[4 * stride], d5 = d[5 * stride],
+            d6 = d[6 * stride], d7 = d[7 * stride];
+  int t0 = d0 + d7, t7 = d0 - d7, t1 = d1 + d6, t6 = d1 - d6, t2 = d2 + d5, t5 = d2 - d5, t3 = d3 + d4, t4 = d3 - d4;
+  const int t10 = t0 + t3, t13 = t0 - t3, t11 = t1 + t2, t12 = t1 - t2;
+  const int n = first ? CONST_BITS - PASS1_BITS : CONST_BITS + PASS1_BITS;
+  d[0] = first ? ((t10 + t11) << PASS1_BITS) : descale(t10 + t11, PASS1_BITS);
+  d[4 * stride] = first ? ((t10 - t11) << PASS1_BITS) : descale(t10 - t11, PASS1_BITS);
+  int z1 = (t12 + t13) * FIX_0_541196100;
+  d[2 * stride] = descale(z1 + t13 * FIX_0_765366865, n);
+  d[6 * stride] = descale(z1 - t12 * FIX_1_847759065, n);
+  z1 = t4 + t7; int z2 = t5 + t6, z3 = t4 + t6, z4 = t5 + t7;
+  const int z5 = (z3 + z4) * FIX_1_175875602;
+  t4 *= FIX_0_298631336; t5 *= FIX_2_053119869; t6 *= FIX_3_072711026; t7 *= FIX_1_501321110;
+  z1 *= -FIX_0_899976223; z2 *= -FIX_2_562915447; z3 *= -FIX_1_961570560; z4 *= -FIX_0_390180644;
+  z3 += z5; z4 += z5;
+  d[7 * stride] = descale(t4 + z1 + z3, n); d[5 * stride] = descale(t5 + z2 + z4, n);
+  d[3 * stride] = descale(t6 + z2 + z3, n); d[stride] = descale(t7 + z1 + z4, n);
+}
+__device__ __forceinline__ void idct8(int* c, int stride, bool first) {
+  int z2 = c[2 * stride], z3 = c[6 * stride];
+  int z1 = (z2 + z3) * FIX_0_541196100;
+  int t2 = z1 - z3 * FIX_1_847759065, t3 = z1 + z2 * FIX_0_765366865;
+  z2 = c[0]; z3 = c[4 * stride];
+  int t0 = (z2 + z3) << CONST_BITS, t1 = (z2 - z3) << CONST_BITS;
+  const int t10 = t0 + t3, t13 = t0 - t3, t11 = t1 + t2, t12 = t1 - t2;
+  t0 = c[7 * stride]; t1 = c[5 * stride]; t2 = c[3 * stride]; t3 = c[stride];
+  z1 = t0 + t3; z2 = t1 + t2; z3 = t0 + t2; int z4 = t1 + t3;
+  const int z5 = (z3 + z4) * FIX_1_175875602;
+  t0 *= FIX_0_298631336; t1 *= FIX_2_053119869; t2 *= FIX_3_072711026; t3 *= FIX_1_501321110;
+  z1 *= -FIX_0_899976223; z2 *= -FIX_2_562915447; z3 *= -FIX_1_961570560; z4 *= -FIX_0_390180644;
+  z3 += z5; z4 += z5;
+  t0 += z1 + z3; t1 += z2 + z4; t2 += z2 + z3; t3 += z1 + z4;
+  const int n = first ? CONST_BITS - PASS1_BITS : CONST_BITS + PASS1_BITS + 3;
+  c[0] = descale(t10 + t3, n); c[7 * stride] = descale(t10 - t3, n);
+  c[stride] = descale(t11 + t2, n); c[6 * stride] = descale(t11 - t2, n);
+  c[2 * stride] = descale(t12 + t1, n); c[5 * stride] = descale(t12 - t1, n);
+  c[3 * stride] = descale(t13 + t0, n); c[4 * stride] = descale(t13 - t0, n);
+}
+
+struct QTab { unsigned char q[64]; };
+// stage 2: per 8x8 block: level shift, forward DCT, quantise, de-quantise, inverse DCT, range limit -- in place.
+// One thread per block (the whole block lives in registers / LDS-free private arrays with static indexing).
+__global__ __launch_bounds__(64) void jpeg_block_kernel(unsigned char* __restrict__ plane, int Wp, int bw, int64_t nblocks, QTab qt) {
+  const int64_t blk = (int64_t)blockIdx.x * 64 + threadIdx.x;
+  if (blk >= nblocks) return;
+  const int64_t by = blk / bw;
+  const int bx = (int)(blk - by * bw);
+  unsigned char* p = plane + by * 8 * Wp + bx * 8;
+  int d[64];
+#pragma unroll
+  for (int y = 0; y < 8; ++y) {
+    const uint2 v = *reinterpret_cast<const uint2*>(p + (int64_t)y * Wp);
+#pragma unroll
+    for (int x = 0; x < 4; ++x) {
+      d[y * 8 + x] = (int)((v.x >> (8 * x)) & 255) - 128;
+      d[y * 8 + 4 + x] = (int)((v.y >> (8 * x)) & 255) - 128;
+    }
+  }
+#pragma unroll
+  for (int y = 0; y < 8; ++y) fdct8(d + y * 8, 1, true);
+#pragma unroll
+  for (int x = 0; x < 8; ++x) fdct8(d + x, 8, false);
+#pragma unroll
+  for (int i = 0; i < 64; ++i) {
+    const int q = qt.q[i], qv = q << 3;
+    int t = d[i];
+    const int a = t < 0 ? -t : t;
+    const int c = (a + (qv >> 1)) / qv;
+    d[i] = (t < 0 ? -c : c) * q;
+  }
+#pragma unroll
+  for (int x = 0; x < 8; ++x) idct8(d + x, 8, true);
+#pragma unroll
+  for (int y = 0; y < 8; ++y) idct8(d + y * 8, 1, false);
+#pragma unroll
+  for (int y = 0; y < 8; ++y) {
+    uint2 v = {0u, 0u};
+#pragma unroll
+    for (int x = 0; x < 4; ++x) {
+      const int a = min(max(d[y * 8 + x] + 128, 0), 255), b = min(max(d[y * 8 + 4 + x] + 128, 0), 255);
+      v.x |= (unsigned)a << (8 * x);
+      v.y |= (unsigned)b << (8 * x);
+    }
+    *reinterpret_cast<uint2*>(p + (int64_t)y * Wp) = v;
+  }
+}
+
+// stage 3: h2v2 fancy (triangle) up-sampling of the chroma planes + fixed-point YCbCr -> RGB, output float /255.
+__device__ __forceinline__ int chroma_up(const unsigned char* __restrict__ C, int cw_alloc, int ch, int cw, int y, int x) {
+  const int cy = y >> 1, cx = x >> 1;
+  if (cw <= 2) return C[(int64_t)cy * cw_alloc + cx];            // libjpeg: fancy up-sampling only if downsampled_width > 2
+  const int fy = (y & 1) ? min(cy + 1, ch - 1) : max(cy - 1, 0); // farther row (edge rows replicate)
+  auto colsum = [&](int xx) { return 3 * (int)C[(int64_t)cy * cw_alloc + xx] + (int)C[(int64_t)fy * cw_alloc + xx]; };
+  const int cs = colsum(cx);
+  if ((x & 1) == 0) return cx == 0 ? ((cs * 4 + 8) >> 4) : ((3 * cs + colsum(cx - 1) + 8) >> 4);
+  return cx == cw - 1 ? ((cs * 4 + 7) >> 4) : ((3 * cs + colsum(cx + 1) + 7) >> 4);
+}
+__global__ __launch_bounds__(256) void jpeg_rgb_kernel(const unsigned char* __restrict__ Y, const unsigned char* __restrict__ Cb,
+                                                       const unsigned char* __restrict__ Cr, int H, int W, int Hp, int Wp,
+                                                       float* __restrict__ dst) {
+  const int x = blockIdx.x * 32 + (threadIdx.x & 31), y = blockIdx.y * 8 + (threadIdx.x >> 5);
+  if (x >= W || y >= H) return;
+  const int f = blockIdx.z;
+  const int cwa = Wp / 2, cha = Hp / 2, cw = (W + 1) / 2, ch = (H + 1) / 2;
+  const int yv = Y[((int64_t)f * Hp + y) * Wp + x];
+  const int cb = chroma_up(Cb + (int64_t)f * cha * cwa, cwa, ch, cw, y, x) - 128;
+  const int cr = chroma_up(Cr + (int64_t)f * cha * cwa, cwa, ch, cw, y, x) - 128;
+  const int R = yv + ((91881 * cr + 32768) >> 16);
+  const int B = yv + ((116130 * cb + 32768) >> 16);
+  const int G = yv + ((-22554 * cb + 32768 - 46802 * cr) >> 16);
+  const int64_t plane = (int64_t)H * W, o = (int64_t)y * W + x;
+  float* d = dst + (int64_t)f * 3 * plane;
+  d[o] = (float)min(max(R, 0), 255) / 255.0f;           // ToTensor: uint8 / 255
+  d[plane + o] = (float)min(max(G, 0), 255) / 255.0f;
+  d[2 * plane + o] = (float)min(max(B, 0), 255) / 255.0f;
+}
+
+const int BASE_L[64] = {16, 11, 10, 16, 24, 40, 51, 61, 12, 12, 14, 19, 26, 58, 60, 55, 14, 13, 16, 24, 40, 57, 69, 56, 14, 17, 22, 29, 51, 87, 80, 62,
+                        18, 22, 37, 56, 68, 109, 103, 77, 24, 35, 55, 64, 81, 104, 113, 92, 49, 64, 78, 87, 103, 121, 120, 101, 72, 92, 95, 98, 112, 100, 103, 99};
+const int BASE_C[64] = {17, 18, 24, 47, 99, 99, 99, 99, 18, 21, 26, 66, 99, 99, 99, 99, 24, 26, 56, 99, 99, 99, 99, 99, 47, 66, 99, 99, 99, 99, 99, 99,
+                        99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99};
+QTab make_qtab(const int* base, int quality) {   // IJG quality scaling (jcparam.c jpeg_quality_scaling + jpeg_add_quant_table, baseline)
+  quality = quality < 1 ? 1 : (quality > 100 ? 100 : quality);
+  const int scale = quality < 50 ? 5000 / quality : 200 - 2 * quality;
+  QTab t;
+  for (int i = 0; i < 64; ++i) {
+    int v = (base[i] * scale + 50) / 100;
+    v = v < 1 ? 1 : (v > 255 ? 255 : v);
+    t.q[i] = (unsigned char)v;
+  }
+  return t;
+}
+
+inline unsigned gridx(int64_t n, int per = 256, int64_t cap = 4096) {
+  int64_t g = cdiv64(n, per);
+  return (unsigned)(g < 1 ? 1 : (g > cap ? cap : g));
+}
+
+}  // namespace
+
+extern "C" int vs_aug_color(const float* src, float* dst, int F, int H, int W, int op, float factor, float* scratch, void* stream) {
+  VS_REQUIRE(src && dst && F > 0 && H > 0 && W > 0 && op >= 0 && op <= 4);
+  hipStream_t st = (hipStream_t)stream;
+  const int64_t plane = (int64_t)H * W;
+  const float* means = nullptr;
+  if (op == OP_CONTRAST) {           // scratch: F * (nblk + 1) floats
+    VS_REQUIRE(scratch);
+    const int nblk = (int)gridx(plane, 256, 256);
+    hipLaunchKernelGGL(gray_partial_kernel, dim3(nblk, F), dim3(256), 0, st, src, plane, scratch);
+    hipLaunchKernelGGL(gray_finish_kernel, dim3(F), dim3(1), 0, st, scratch, nblk, plane, scratch + (int64_t)F * nblk);
+    means = scratch + (int64_t)F * nblk;
+  }
+  hipLaunchKernelGGL(color_kernel, dim3(gridx(plane), F), dim3(256), 0, st, src, dst, plane, op, factor, means);
+  return vs_launch_status();
+}
+extern "C" int64_t vs_aug_color_scratch_floats(int F, int H, int W) {
+  const int64_t plane = (int64_t)H * W;
+  int64_t g = (plane + 255) / 256;
+  g = g > 256 ? 256 : (g < 1 ? 1 : g);
+  return (int64_t)F * (g + 1);
+}
+
+extern "C" int vs_aug_crop_flip(const float* src, float* dst, int planes, int H, int W, int i0, int j0, int h, int w, int flip, void* stream) {
+  VS_REQUIRE(src && dst && planes > 0 && H > 0 && W > 0 && h > 0 && w > 0);
+  hipLaunchKernelGGL(crop_flip_kernel, dim3(gridx((int64_t)h * w), planes), dim3(256), 0, (hipStream_t)stream, src, dst, H, W, i0, j0, h, w, flip);
+  return vs_launch_status();
+}
+
+extern "C" int vs_resize_nchw(const float* src, float* dst, int planes, int H, int W, int oh, int ow, int antialias, void* stream) {
+  VS_REQUIRE(src && dst && planes > 0 && H > 0 && W > 0 && oh > 0 && ow > 0);
+  hipLaunchKernelGGL(resize_nchw_kernel, dim3((ow + 31) / 32, (oh + 7) / 8, planes), dim3(256), 0, (hipStream_t)stream, src, dst, H, W, oh, ow, antialias);
+  return vs_launch_status();
+}
+
+extern "C" int vs_gaussian_blur(const float* src, float* tmp, float* dst, int planes, int H, int W, int k, float sigma, void* stream) {
+  VS_REQUIRE(src && tmp && dst && planes > 0 && H > 0 && W > 0 && k >= 1 && (k & 1) && k <= 33 && sigma > 0.f);
+  VS_REQUIRE(k / 2 < H && k / 2 < W);
+  GaussK g; g.k = k;
+  // torchvision _get_gaussian_kernel1d: x = linspace(-(k-1)/2, (k-1)/2, k); pdf = exp(-0.5 (x/sigma)^2); pdf / sum
+  float sum = 0.f;
+  const float half = (k - 1) * 0.5f;
+  for (int i = 0; i < k; ++i) {
+    const float x = (k == 1) ? 0.f : (-half + (2.f * half) * (float)i / (float)(k - 1));
+    g.w[i] = expf(-0.5f * (x / sigma) * (x / sigma));
+    sum += g.w[i];
+  }
+  for (int i = 0; i < k; ++i) g.w[i] /= sum;
+  dim3 grid((W + 31) / 32, (H + 7) / 8, planes);
+  hipLaunchKernelGGL(blur_pass_kernel, grid, dim3(256), 0, (hipStream_t)stream, src, tmp, H, W, g, 0);
+  hipLaunchKernelGGL(blur_pass_kernel, grid, dim3(256), 0, (hipStream_t)stream, tmp, dst, H, W, g, 1);
+  return vs_launch_status();
+}
+
+extern "C" int vs_median_filter(const float* src, float* dst, int planes, int H, int W, int k, void* stream) {
+  VS_REQUIRE(src && dst && planes > 0 && H > 0 && W > 0);
+  dim3 grid((W + 31) / 32, (H + 7) / 8, planes);
+  hipStream_t st = (hipStream_t)stream;
+  switch (k) {
+    case 3: hipLaunchKernelGGL(median_kernel<3>, grid, dim3(256), 0, st, src, dst, H, W); break;
+    case 5: hipLaunchKernelGGL(median_kernel<5>, grid, dim3(256), 0, st, src, dst, H, W); break;
+    case 7: hipLaunchKernelGGL(median_kernel<7>, grid, dim3(256), 0, st, src, dst, H, W); break;
+    default: return VS_ERR_UNSUPPORTED;
+  }
+  return vs_launch_status();
+}
+
+extern "C" int64_t vs_jpeg_workspace_bytes(int F, int H, int W) {
+  const int64_t Hp = (H + 15) / 16 * 16, Wp = (W + 15) / 16 * 16;
+  return (int64_t)F * (Hp * Wp + 2 * (Hp / 2) * (Wp / 2));
+}
+extern "C" int vs_jpeg_roundtrip(const float* src, float* dst, int F, int H, int W, int quality, void* workspace, void* stream) {
+  VS_REQUIRE(src && dst && workspace && F > 0 && H > 0 && W > 0 && quality >= 1 && quality <= 100);
+  hipStream_t st = (hipStream_t)stream;
+  const int Hp = (H + 15) / 16 * 16, Wp = (W + 15) / 16 * 16;
+  unsigned char* Y = (unsigned char*)workspace;
+  unsigned char* Cb = Y + (int64_t)F * Hp * Wp;
+  unsigned char* Cr = Cb + (int64_t)F * (Hp / 2) * (Wp / 2);
+  hipLaunchKernelGGL(jpeg_ycc_kernel, dim3((Wp / 2 + 31) / 32, (Hp / 2 + 7) / 8, F), dim3(256), 0, st, src, H, W, Hp, Wp, Y, Cb, Cr);
+  const QTab ql = make_qtab(BASE_L, quality), qc = make_qtab(BASE_C, quality);
+  // the frames are stacked vertically, so one launch per component covers every frame (block rows never straddle frames)
+  const int64_t nby = (int64_t)F * Hp / 8, nbc = (int64_t)F * (Hp / 2) / 8;
+  hipLaunchKernelGGL(jpeg_block_kernel, dim3((unsigned)cdiv64(nby * (Wp / 8), 64)), dim3(64), 0, st, Y, Wp, Wp / 8, nby * (Wp / 8), ql);
+  hipLaunchKernelGGL(jpeg_block_kernel, dim3((unsigned)cdiv64(nbc * (Wp / 16), 64)), dim3(64), 0, st, Cb, Wp / 2, Wp / 16, nbc * (Wp / 16), qc);
+  hipLaunchKernelGGL(jpeg_block_kernel, dim3((unsigned)cdiv64(nbc * (Wp / 16), 64)), dim3(64), 0, st, Cr, Wp / 2, Wp / 16, nbc * (Wp / 16), qc);
+  hipLaunchKernelGGL(jpeg_rgb_kernel, dim3((W + 31) / 32, (H + 7) / 8, F), dim3(256), 0, st, Y, Cb, Cr, H, W, Hp, Wp, dst);
+  return vs_launch_status();
+}

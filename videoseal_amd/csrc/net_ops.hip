@@ -34,6 +34,50 @@ __global__ __launch_bounds__(256) void layernorm_act_kernel(const float* __restr
   }
 }
 
+// Small-C flavour (C <= 64, the U-Net up-blocks at 128^2 / 256^2): one thread per row, the row lives in registers
+// (float4 loads), so a 16-channel row does not waste 48 of the 64 lanes of a wave.
+template <int C4MAX>
+__global__ __launch_bounds__(256) void layernorm_act_small_kernel(const float* __restrict__ x, int64_t rows, int C, int64_t ld,
+                                                                  const float* __restrict__ w, const float* __restrict__ b,
+                                                                  float eps, int act, float* __restrict__ out, int64_t out_ld) {
+  const int64_t row = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (row >= rows) return;
+  const int C4 = (C + 3) >> 2;
+  f32x4 v[C4MAX];
+  const float* xr = x + row * ld;
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < C4MAX; ++i)
+    if (i < C4) {
+      v[i] = *reinterpret_cast<const f32x4*>(xr + 4 * i);
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        if (4 * i + e < C) s += v[i][e];
+    }
+  const float mean = s / (float)C;
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < C4MAX; ++i)
+    if (i < C4) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        if (4 * i + e < C) { const float dlt = v[i][e] - mean; q += dlt * dlt; }
+    }
+  const float den = sqrtf(q / (float)C + eps);
+  float* orow = out + row * out_ld;
+#pragma unroll
+  for (int i = 0; i < C4MAX; ++i)
+    if (i < C4) {
+      f32x4 o;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int c = 4 * i + e;
+        o[e] = c < C ? vs_apply_act(w[c] * ((v[i][e] - mean) / den) + b[c], act) : 0.f;
+      }
+      *reinterpret_cast<f32x4*>(orow + 4 * i) = o;
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------
 // Depthwise 7x7 (pad 3) + bias, then LayerNorm over C, per pixel (convnext.py:43-46).
 // A work item = (strip of 4 consecutive x, group of 4 channels): 70 float4 loads feed 16 outputs x 4 channels,
@@ -227,6 +271,8 @@ __global__ __launch_bounds__(256) void outc_tanh_kernel(const float* __restrict_
 }
 
 // ---------------------------------------------------------------------------------------------------
+// grid = (frames, output slices): every block pools its frame (the activation is tiny and L2-resident) and then produces
+// a slice of the N outputs, one 64-lane wave per output.
 __global__ __launch_bounds__(256) void pool_linear_kernel(const float* __restrict__ x, int HW, int C, int64_t ld,
                                                           const float* __restrict__ w, const float* __restrict__ bias, int N,
                                                           float* __restrict__ out) {
@@ -240,7 +286,7 @@ __global__ __launch_bounds__(256) void pool_linear_kernel(const float* __restric
   }
   __syncthreads();
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  for (int n = wv; n < N; n += 4) {
+  for (int n = blockIdx.y * 4 + wv; n < N; n += 4 * gridDim.y) {
     const float* wr = w + (int64_t)n * C;
     float s = 0.f;
     for (int c = lane; c < C; c += 64) s += pooled[c] * wr[c];
@@ -259,6 +305,13 @@ inline unsigned grid_for(int64_t total, int per_block = 256, int64_t cap = 256 *
 extern "C" int vs_layernorm_act(const float* x, int64_t rows, int C, int64_t ld, const float* w, const float* b, float eps,
                                 int act, float* out, int64_t out_ld, void* stream) {
   VS_REQUIRE(x && w && b && out && rows > 0 && C > 0 && ld >= C && out_ld >= C);
+  if (C <= 64 && ld % 4 == 0 && out_ld % 4 == 0 && out_ld == ((C + 3) / 4) * 4 && (((uintptr_t)x | (uintptr_t)out) & 15) == 0) {
+    const unsigned g = (unsigned)cdiv64(rows, 256);
+    if (C <= 16) hipLaunchKernelGGL(layernorm_act_small_kernel<4>, dim3(g), dim3(256), 0, (hipStream_t)stream, x, rows, C, ld, w, b, eps, act, out, out_ld);
+    else if (C <= 32) hipLaunchKernelGGL(layernorm_act_small_kernel<8>, dim3(g), dim3(256), 0, (hipStream_t)stream, x, rows, C, ld, w, b, eps, act, out, out_ld);
+    else hipLaunchKernelGGL(layernorm_act_small_kernel<16>, dim3(g), dim3(256), 0, (hipStream_t)stream, x, rows, C, ld, w, b, eps, act, out, out_ld);
+    return vs_launch_status();
+  }
   hipLaunchKernelGGL(layernorm_act_kernel, dim3((unsigned)cdiv64(rows, 4)), dim3(256), 0, (hipStream_t)stream, x, rows, C, ld,
                      w, b, eps, act, out, out_ld);
   return vs_launch_status();
@@ -333,6 +386,6 @@ extern "C" int vs_pool_linear(const float* x, int B, int HW, int C, int64_t ld, 
   VS_REQUIRE(x && w && bias && out && B > 0 && HW > 0 && C > 0 && ld >= C && N > 0);
   const size_t smem = (size_t)C * sizeof(float);
   if (smem > 64 * 1024) return VS_ERR_UNSUPPORTED;
-  hipLaunchKernelGGL(pool_linear_kernel, dim3((unsigned)B), dim3(256), smem, (hipStream_t)stream, x, HW, C, ld, w, bias, N, out);
+  hipLaunchKernelGGL(pool_linear_kernel, dim3((unsigned)B, 16), dim3(256), smem, (hipStream_t)stream, x, HW, C, ld, w, bias, N, out);
   return vs_launch_status();
 }

@@ -141,6 +141,7 @@ class HipEngine:
         self.lib = N.lib()
         self._ws: Dict[tuple, torch.Tensor] = {}
         self.kernel_timers = None        # list of (name, start_event, end_event, flops) when bench.py enables it
+        self.time_all_convs = False
         self.use_split = os.environ.get("VIDEOSEAL_CONV", "split") != "f32"   # arithmetic back-end of vs_conv_gemm
         # per-shape tile selection: every candidate walks K in the same order, so the result is bit-identical whatever
         # tile wins -- only speed changes (measure, don't guess).  VIDEOSEAL_AUTOTUNE=0 keeps the static heuristic.
@@ -290,6 +291,8 @@ class HipEngine:
                 d.wt2_blk = N.ptr(w2.with_blk().blk)
         if tile_hint == 0 and self.autotune and not torch.cuda.is_current_stream_capturing():
             d.tile_hint = self._pick_tile(d, w, out)
+        if self.kernel_timers is not None and prof is None and self.time_all_convs:
+            prof = f"conv{w.KH}x{w.KW} {x.C}->{w.N} @{out.H}x{out.W}" + ("+1x1" if in2 is not None else "")
         timed = prof is not None and self.kernel_timers is not None
         if timed:   # HIP events on the launch stream, used by bench.py for the per-kernel roofline
             ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

@@ -23,7 +23,8 @@ VIDEO_MODES = {"repeat": 0, "alternate": 1, "interpolate": 2}
 EXPORTS = [
     "vs_version", "vs_arch", "vs_error_string", "vs_sizeof_conv_desc", "vs_sizeof_tail_desc", "vs_conv_gemm", "vs_layernorm_act", "vs_dwconv7_ln", "vs_grn_scale",
     "vs_upcat2x", "vs_msg_latent", "vs_broadcast_channels", "vs_outc_tanh", "vs_pool_linear", "vs_resize_pre",
-    "vs_jnd_heatmap", "vs_embed_tail",
+    "vs_jnd_heatmap", "vs_embed_tail", "vs_aug_color_scratch_floats", "vs_aug_color", "vs_aug_crop_flip", "vs_resize_nchw",
+    "vs_gaussian_blur", "vs_median_filter", "vs_jpeg_workspace_bytes", "vs_jpeg_roundtrip",
 ]
 
 
@@ -91,11 +92,21 @@ def lib() -> C.CDLL:
         "vs_resize_pre": [P, I, I, I, I, I, I, I, P, F, F, P, I, P, P],
         "vs_jnd_heatmap": [P, I, I, I, I64, I64, I64, I64, P, P, P],
         "vs_embed_tail": [C.POINTER(TailDesc), P],
+        "vs_aug_color": [P, P, I, I, I, I, F, P, P],
+        "vs_aug_crop_flip": [P, P, I, I, I, I, I, I, I, I, P],
+        "vs_resize_nchw": [P, P, I, I, I, I, I, I, P],
+        "vs_gaussian_blur": [P, P, P, I, I, I, I, F, P],
+        "vs_median_filter": [P, P, I, I, I, I, P],
+        "vs_jpeg_roundtrip": [P, P, I, I, I, I, P, P],
     }
     for name, args in sig.items():
         fn = getattr(L, name)
         fn.argtypes = args
         fn.restype = C.c_int
+    L.vs_aug_color_scratch_floats.restype = C.c_int64
+    L.vs_aug_color_scratch_floats.argtypes = [I, I, I]
+    L.vs_jpeg_workspace_bytes.restype = C.c_int64
+    L.vs_jpeg_workspace_bytes.argtypes = [I, I, I]
     L.vs_sizeof_conv_desc.restype = C.c_int
     L.vs_sizeof_tail_desc.restype = C.c_int
     if L.vs_sizeof_conv_desc() != C.sizeof(ConvDesc) or L.vs_sizeof_tail_desc() != C.sizeof(TailDesc):
