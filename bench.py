@@ -86,6 +86,7 @@ def main():
     ap.add_argument("--size", type=int, default=768)
     ap.add_argument("--card", default="videoseal_1.0")
     ap.add_argument("--lowres-attenuation", action="store_true")
+    ap.add_argument("--detect-only", action="store_true", help="time model.detect() only (BASELINE config 5: ChunkySeal extractor)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timers", action="store_true")
     args = ap.parse_args()
@@ -119,8 +120,11 @@ def main():
     model.chunk_size = max(model.chunk_size, B)
 
     def step():
-        out = model.embed(frames, msgs, is_video=is_video, lowres_attenuation=args.lowres_attenuation)
-        preds = model.detect(out["imgs_w"], is_video=True)["preds"]
+        if args.detect_only:
+            preds = model.detect(frames, is_video=True)["preds"]
+        else:
+            out = model.embed(frames, msgs, is_video=is_video, lowres_attenuation=args.lowres_attenuation)
+            preds = model.detect(out["imgs_w"], is_video=True)["preds"]
         if dist_on:
             preds = gather_frame_logits(preds, B * world, align=B)
         return preds
@@ -170,21 +174,23 @@ def main():
         fps = total_frames / elapsed
         # algorithmic work per frame: 28.28 GMAC embed (image) / 7.07 (video, step 4) + 6.16 GMAC detect
         gmac = (28.28 if not is_video else 28.28 / cfg.step_size) + 6.16
+        if args.detect_only:
+            gmac = 613.6 if args.card == "chunkyseal" else 6.16
         line = {
-            "metric": "frames/sec embed+extract 256-bit @768x768", "value": round(fps, 2), "unit": "frames/s",
+            "metric": ("frames/sec embed+extract 256-bit @768x768" if not args.detect_only else f"frames/sec extract ({args.card}) @{S}x{S}"), "value": round(fps, 2), "unit": "frames/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32 (3 x bf16 exact operand split on the bf16 matrix cores, fp32 accumulate)" if eng.use_split else "f32", "data": "synthetic",
             "config": {"workload": f"VideoSeal 1.0 256-bit, {B} frames {S}x{S} per GPU, {args.mode} mode "
                                    f"({'embedder on every frame' if not is_video else 'key frames every %d' % cfg.step_size}, "
-                                   f"{'low-res' if args.lowres_attenuation else 'full-res'} JND), embed + detect"
+                                   f"{'low-res' if args.lowres_attenuation else 'full-res'} JND), " + ("detect only" if args.detect_only else "embed + detect")
                                    + (", all-gather of bit logits" if dist_on else ""),
                        "card": args.card, "weights": "random-init (seeded), no checkpoint offline", "batch_per_gpu": B,
                        "frame": [S, S], "mode": args.mode},
             "model_tflops_per_s": round(fps * gmac * 2e9 / 1e12 / world, 2),
             "roofline": roof,
         }
-        if not args.no_cpu_baseline and world == 1:
+        if not args.no_cpu_baseline and world == 1 and not args.detect_only:
             card_path = os.path.join(ROOT, "videoseal_amd", "cards", args.card + ".yaml")
             line["cpu_baseline"] = cpu_baseline(card_path, S, args.mode, cfg.step_size)
         else:

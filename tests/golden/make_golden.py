@@ -193,6 +193,14 @@ def main():
     run_case(tm, ts, "tiny_vid_interpolate", n=9, h=70, w=66, seed=15, is_video=True, lowres=False, chunk=3, step=2,
              video_mode="interpolate")
 
+    # ---- ChunkySeal-shaped tiny architecture: RGB in/out embedder, stem stride 2, channel counts that are not multiples
+    # of 4 (18, 54, 90) and odd feature maps (31 -> 15 -> 7 -> 3), seed 4
+    tc = tiny_spec(yuv=False, in_ch=3, out_ch=3, dims=[18, 36, 54, 90], stem_stride=2, hidden=32, nbits=16)
+    tcm = build_reference(tc, card_for_spec(tc)).eval()
+    tcm.load_state_dict(make_state_dict(tc, seed=4), strict=True)
+    run_case(tcm, tc, "tinyc_img", n=2, h=64, w=64, seed=21, is_video=False, lowres=False)
+    run_case(tcm, tc, "tinyc_vid", n=7, h=96, w=80, seed=22, is_video=True, lowres=True, chunk=2, step=2)
+
 
 if __name__ == "__main__":
     main()

@@ -13,7 +13,7 @@ from oracle import videoseal_ref as R  # noqa: E402
 from oracle.inputs import synthetic_frames, synthetic_msgs  # noqa: E402
 from oracle.weights import make_state_dict, spec_from_card, tiny_spec  # noqa: E402
 from tests._util import check_sub, load_golden, psnr_np  # noqa: E402
-from tests.test_oracle_golden import CARDS, FULL, TINY  # noqa: E402
+from tests.test_oracle_golden import CARDS, FULL, TINY, TINYC  # noqa: E402
 
 import videoseal_amd  # noqa: E402
 from videoseal_amd.layout import ModelCfg  # noqa: E402
@@ -91,6 +91,19 @@ def _run_case(spec, sd, model, name):
 @pytest.mark.parametrize("name", TINY)
 def test_tiny_matches_reference_golden(tiny, name):
     _run_case(*tiny, name)
+
+
+@pytest.fixture(scope="module")
+def tinyc():
+    s = tiny_spec(yuv=False, in_ch=3, out_ch=3, dims=[18, 36, 54, 90], stem_stride=2, hidden=32, nbits=16)
+    sd = make_state_dict(s, seed=4)
+    return s, sd, make_model(s, sd)
+
+
+@pytest.mark.parametrize("name", TINYC)
+def test_tiny_chunky_matches_reference_golden(tinyc, name):
+    """ChunkySeal-shaped architecture: RGB embedder, stride-2 stem, channel counts not multiple of 4, odd feature maps."""
+    _run_case(*tinyc, name)
 
 
 @pytest.mark.parametrize("name", FULL)

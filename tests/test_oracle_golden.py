@@ -14,6 +14,7 @@ from tests._util import GOLDEN, check_sub, load_golden, psnr_np
 CARDS = os.path.join(os.path.dirname(GOLDEN), "..", "videoseal_amd", "cards")
 
 TINY = ["tiny_img", "tiny_img_resize", "tiny_vid_repeat", "tiny_vid_alternate", "tiny_vid_interpolate"]
+TINYC = ["tinyc_img", "tinyc_vid"]
 FULL = ["vs10_img256", "vs10_img_odd", "vs10_img_lowres", "vs10_vid", "vs10_vid_lowres", "vs10_img_uniform"]
 
 
@@ -67,6 +68,17 @@ def _check_case(spec, sd, name):
 @pytest.mark.parametrize("name", TINY)
 def test_tiny_oracle_matches_reference(tiny, name):
     _check_case(*tiny, name)
+
+
+@pytest.fixture(scope="module")
+def tinyc():
+    s = tiny_spec(yuv=False, in_ch=3, out_ch=3, dims=[18, 36, 54, 90], stem_stride=2, hidden=32, nbits=16)
+    return s, make_state_dict(s, seed=4)
+
+
+@pytest.mark.parametrize("name", TINYC)
+def test_tiny_chunky_oracle_matches_reference(tinyc, name):
+    _check_case(*tinyc, name)
 
 
 @pytest.mark.parametrize("name", FULL)

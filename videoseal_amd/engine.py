@@ -148,8 +148,9 @@ class HipEngine:
         self.autotune = os.environ.get("VIDEOSEAL_AUTOTUNE", "1") != "0"
         self._tile_cache: Dict[tuple, int] = {}
         g = lambda k: sd[k].detach().to(device)   # noqa: E731
-        self._pack_embedder(g)
-        self._pack_extractor(g)
+        self._g = g
+        self.E = None          # packed embedder / extractor weights, built on first use (ChunkySeal: 1.0 G + 0.77 G parameters)
+        self.X = None
         m = g("rgb2yuv.M").float().cpu()
         self.ymat = (C.c_float * 3)(*[float(v) for v in m[0]])
         taps = torch.cat([g("attenuation.conv_lum.weight")[0, 0].reshape(-1), g("attenuation.conv_x.weight")[0, 0].reshape(-1),
@@ -355,6 +356,8 @@ class HipEngine:
     # ------------------------------------------------------------------ embedder
     def embedder_forward(self, x: Act, msgs_i32: torch.Tensor) -> torch.Tensor:
         """x: key frames, NHWC(ld 4), already mapped to [-1,1]. Returns delta [B][out_ch][S_h][S_w] (planar)."""
+        if self.E is None:
+            self._pack_embedder(self._g)
         c, E, L = self.cfg, self.E, self.lib
         B = x.B
         st = N.stream()
@@ -399,6 +402,8 @@ class HipEngine:
     # ------------------------------------------------------------------ extractor
     def extractor_forward(self, x: Act) -> torch.Tensor:
         """x: NHWC(ld 4) RGB already mapped to [-1,1]. Returns logits [B][1+nbits]."""
+        if self.X is None:
+            self._pack_extractor(self._g)
         c, X, L = self.cfg, self.X, self.lib
         st = N.stream()
         B = x.B
