@@ -181,7 +181,7 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32 (3 x bf16 exact operand split on the bf16 matrix cores, fp32 accumulate)" if eng.use_split else "f32", "data": "synthetic",
-            "config": {"workload": f"VideoSeal 1.0 256-bit, {B} frames {S}x{S} per GPU, {args.mode} mode "
+            "config": {"workload": f"{args.card} {cfg.nbits}-bit, {B} frames {S}x{S} per GPU, {args.mode} mode "
                                    f"({'embedder on every frame' if not is_video else 'key frames every %d' % cfg.step_size}, "
                                    f"{'low-res' if args.lowres_attenuation else 'full-res'} JND), " + ("detect only" if args.detect_only else "embed + detect")
                                    + (", all-gather of bit logits" if dist_on else ""),

@@ -85,6 +85,14 @@ CONV_CASES = [
     (2, 96, 9, 9, 200, 3, 1, 1, 0, 1, 6),
     (2, 128, 16, 16, 96, 1, 1, 0, 0, 2, 5),
     (2, 128, 16, 16, 192, 3, 1, 1, 0, 1, 4),
+    # 3x3 patch kernel (tile codes 10..12): aligned and ragged frames, zero / reflect padding, small and large channel counts
+    (2, 16, 32, 32, 16, 3, 1, 1, 0, 1, 10),
+    (2, 384, 16, 16, 384, 3, 1, 1, 0, 1, 12),
+    (3, 64, 24, 48, 40, 3, 1, 1, 1, 2, 11),
+    (2, 32, 13, 21, 136, 3, 1, 1, 1, 0, 12),
+    (1, 1, 32, 32, 16, 3, 1, 1, 0, 1, 10),
+    (2, 100, 9, 17, 64, 3, 1, 1, 0, 3, 11),
+    (2, 48, 16, 16, 48, 3, 1, 1, 0, 1, 0),
 ]
 
 
@@ -112,7 +120,7 @@ def test_conv_gemm_matches_conv2d(eng, case):
     assert torch.isfinite(full).all() and (full[..., Cout:] == 0).all()   # pad lanes written as zero
 
 
-@pytest.mark.parametrize("tile", [0, 7, 8])
+@pytest.mark.parametrize("tile", [0, 7, 8, 10, 11, 1])
 def test_conv_two_phase_residual_block(eng, tile):
     """ResnetBlock tail: relu(conv3x3(t)+b) + (conv1x1(x)+b2), written at a channel offset of a wider buffer."""
     if tile >= 6 and not eng.use_split:

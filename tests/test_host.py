@@ -114,3 +114,16 @@ def test_c_abi_exports_every_declared_symbol():
     assert lib.vs_layernorm_act(None, 4, 8, 8, None, None, 1e-6, 0, None, 8, None) == -1
     assert lib.vs_conv_gemm(None, None) == -1
     assert lib.vs_sizeof_conv_desc() == ctypes.sizeof(native.ConvDesc) and lib.vs_sizeof_tail_desc() == ctypes.sizeof(native.TailDesc)
+
+
+def test_metrics_match_oracle():
+    from oracle import videoseal_ref as R
+    from videoseal_amd.metrics import bit_accuracy, psnr
+    a = torch.rand(3, 3, 16, 16)
+    b = (a + 0.02 * torch.randn_like(a)).clamp(0, 1)
+    assert torch.allclose(psnr(a, b), R.psnr(a, b)) and torch.allclose(psnr(a, b, True), R.psnr(a, b, True))
+    p = torch.randn(4, 32)
+    t = torch.randint(0, 2, (4, 32))
+    assert torch.equal(bit_accuracy(p, t), R.bit_accuracy(p, t))
+    pix = torch.randn(2, 8, 5, 5)
+    assert bit_accuracy(pix, torch.randint(0, 2, (2, 8))).shape == (2,)

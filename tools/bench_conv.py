@@ -61,6 +61,15 @@ if __name__ == "__main__":
           ("  no-global,no-store", SP | 2 | 0x500), ("  only-mfma+ldsread", SP | 2 | 0xD00), ("  no-mfma,no-global", SP | 2 | 0x300),
           ("split128x128 full", SP | 1), ("  no-global", SP | 1 | 0x100), ("  no-mfma", SP | 1 | 0x200), ("  only-mfma+ldsread", SP | 1 | 0xD00),
           ("f32 128x64 full", F32 | 2), ("  no-global", F32 | 2 | 0x100), ("  no-mfma", F32 | 2 | 0x200), ("  only-mfma+ldsread", F32 | 2 | 0xD00)]
+    PV = [("split best4w 128x96", SP | 5), ("patch 128x32", 10), ("patch 128x64", 11), ("patch 128x128", 12)]
+    bench(eng, "PATCH bottleneck 384 32^2 B32", 32, 384, 32, 32, 384, 3, PV)
+    bench(eng, "PATCH rb16 256^2 B32", 32, 16, 256, 256, 16, 3, [("split 256x32", SP | 3), ("patch 128x32", 10)], check=False)
+    bench(eng, "PATCH up2 64->16 256^2 B32", 32, 64, 256, 256, 16, 3, [("split 256x32", SP | 3), ("patch 128x32", 10)], check=False)
+    bench(eng, "PATCH rb32 128^2 B32", 32, 32, 128, 128, 32, 3, [("split 256x32", SP | 3), ("patch 128x32", 10)], check=False)
+    bench(eng, "PATCH up1 128->32 128^2 B32", 32, 128, 128, 128, 32, 3, [("split 256x32", SP | 3), ("patch 128x32", 10)], check=False)
+    bench(eng, "PATCH rb64 64^2 B32", 32, 64, 64, 64, 64, 3, [("split 128x64", SP | 2), ("patch 128x64", 11), ("patch 128x32", 10)], check=False)
+    bench(eng, "PATCH up0 768->64 64^2 B32", 32, 768, 64, 64, 64, 3, [("split 128x64", SP | 2), ("patch 128x64", 11), ("patch 128x32", 10)], check=False)
+    bench(eng, "PATCH rb128 32^2 B32", 32, 128, 32, 32, 128, 3, [("split 128x128", SP | 1), ("patch 128x128", 12), ("patch 128x64", 11)], check=False)
     bench(eng, "ABLATE bottleneck B32", 32, 384, 32, 32, 384, 3, AB, check=False)
     bench(eng, "bottleneck 384->384 32^2 B8", 8, 384, 32, 32, 384, 3, V)
     bench(eng, "up0 768->64 64^2 B32", 32, 768, 64, 64, 64, 3, [("f32 128x64", F32 | 2), ("split 128x64", SP | 2), ("split 256x32", SP | 3)])
