@@ -63,6 +63,10 @@ if __name__ == "__main__":
           ("f32 128x64 full", F32 | 2), ("  no-global", F32 | 2 | 0x100), ("  no-mfma", F32 | 2 | 0x200), ("  only-mfma+ldsread", F32 | 2 | 0xD00)]
     PV = [("split best4w 128x96", SP | 5), ("patch 128x32", 10), ("patch 128x64", 11), ("patch 128x128", 12)]
     bench(eng, "PATCH bottleneck 384 32^2 B32", 32, 384, 32, 32, 384, 3, PV)
+    PA = [("patch 128x128", 12), (" no-Bload", 12 | 0x100), (" no-mfma", 12 | 0x200), (" no-Bstore", 12 | 0x400), (" no-Bload,no-Bstore", 12 | 0x500),
+          (" only mfma+ldsread", 12 | 0xD00), (" no-mfma,no-Bload", 12 | 0x300), ("patch 128x64", 11), (" no-Bload", 11 | 0x100), (" no-mfma", 11 | 0x200),
+          (" only mfma+ldsread", 11 | 0xD00)]
+    bench(eng, "PABL bottleneck B32", 32, 384, 32, 32, 384, 3, PA, check=False)
     bench(eng, "PATCH rb16 256^2 B32", 32, 16, 256, 256, 16, 3, [("split 256x32", SP | 3), ("patch 128x32", 10)], check=False)
     bench(eng, "PATCH up2 64->16 256^2 B32", 32, 64, 256, 256, 16, 3, [("split 256x32", SP | 3), ("patch 128x32", 10)], check=False)
     bench(eng, "PATCH rb32 128^2 B32", 32, 32, 128, 128, 32, 3, [("split 256x32", SP | 3), ("patch 128x32", 10)], check=False)

@@ -53,6 +53,7 @@ __global__ __launch_bounds__(NTH, 2) void conv3x3_patch_kernel(const vs_conv_des
   const int n2 = d.in2 ? d.Cin2P / BK : 0;
   const int64_t Ktot = (int64_t)9 * d.CinP;
   const bool reflect = d.pad_mode == VS_PAD_REFLECT;
+  const int abl = d.tile_hint >> 8;   // debug ablation (tools/bench_conv.py): 1 no B loads, 2 no MFMA, 4 no B store, 8 no barrier
 
   // ---- patch items of this thread: (patch pixel, 4-channel group); addresses are constant across chunks
   unsigned p_off[NPI];
@@ -198,18 +199,16 @@ __global__ __launch_bounds__(NTH, 2) void conv3x3_patch_kernel(const vs_conv_des
     for (int j = 0; j < TN; ++j)
 #pragma unroll
       for (int p = 0; p < 3; ++p) bf[j][p] = *reinterpret_cast<const bf16x8*>(Bb + p * BN * ROWB + b_frag + j * 32 * ROWB);
+      // product term outermost, tiles innermost: consecutive MFMAs hit different accumulators (no dependent-issue stall);
+      // smallest terms first
 #pragma unroll
-    for (int i = 0; i < TM; ++i)
+      for (int q = 0; q < 6; ++q) {
+        constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};
 #pragma unroll
-      for (int j = 0; j < TN; ++j) {   // smallest terms first
-        f32x16 c = acc[i][j];
-        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][2], bf[j][0], c, 0, 0, 0);
-        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[j][2], c, 0, 0, 0);
-        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][1], bf[j][1], c, 0, 0, 0);
-        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][1], bf[j][0], c, 0, 0, 0);
-        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[j][1], c, 0, 0, 0);
-        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[j][0], c, 0, 0, 0);
-        acc[i][j] = c;
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][PA[q]], bf[j][PB[q]], acc[i][j], 0, 0, 0);
       }
   };
 
@@ -227,14 +226,14 @@ __global__ __launch_bounds__(NTH, 2) void conv3x3_patch_kernel(const vs_conv_des
       const int s1 = step + 1;
       if (s1 < n1) {
         const int ncc = tap == 8 ? cc + 1 : cc, ntap = tap == 8 ? 0 : tap + 1;
-        load_b(ncc, ntap);
+        if (!(abl & 1)) load_b(ncc, ntap);
       } else if (n2 > 0) {
         load_b2(0);
       }
       const int ky = tap / 3, kx = tap - ky * 3;
-      mfma_step(step & 1, (ky * PW + kx) * ROWB);
-      if (s1 < n1 || n2 > 0) store_b(s1 & 1);
-      __syncthreads();
+      if (!(abl & 2)) mfma_step(step & 1, (ky * PW + kx) * ROWB);
+      if ((s1 < n1 || n2 > 0) && !(abl & 4)) store_b(s1 & 1);
+      if (!(abl & 8)) __syncthreads();
     }
     if (cc + 1 < spt) {                                   // every wave is past tap 8: the patch may be replaced
       store_patch();
@@ -280,19 +279,17 @@ __global__ __launch_bounds__(NTH, 2) void conv3x3_patch_kernel(const vs_conv_des
         for (int j = 0; j < TN; ++j)
 #pragma unroll
           for (int p = 0; p < 3; ++p) bf[j][p] = *reinterpret_cast<const bf16x8*>(Bb + p * BN * ROWB + b_frag + j * 32 * ROWB);
+      // product term outermost, tiles innermost: consecutive MFMAs hit different accumulators (no dependent-issue stall);
+      // smallest terms first
+#pragma unroll
+      for (int q = 0; q < 6; ++q) {
+        constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
-          for (int j = 0; j < TN; ++j) {
-            f32x16 c = acc[i][j];
-            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][2], bf[j][0], c, 0, 0, 0);
-            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[j][2], c, 0, 0, 0);
-            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][1], bf[j][1], c, 0, 0, 0);
-            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][1], bf[j][0], c, 0, 0, 0);
-            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[j][1], c, 0, 0, 0);
-            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[j][0], c, 0, 0, 0);
-            acc[i][j] = c;
-          }
+          for (int j = 0; j < TN; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][PA[q]], bf[j][PB[q]], acc[i][j], 0, 0, 0);
+      }
       }
       if (c2 + 1 < n2) store_b((step + 1) & 1);
     }

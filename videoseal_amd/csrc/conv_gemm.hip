@@ -274,19 +274,17 @@ __global__ __launch_bounds__(NT, (TM * TN > 4 ? 1 : 2)) void conv_gemm_kernel(co
 #pragma unroll
         for (int p = 0; p < 3; ++p)
           bf[j][p] = *reinterpret_cast<const bf16x8*>(Bb + p * BN * ROWB + ((wn * TN + j) * 32 + r) * ROWB + g * 16);
+      // product term outermost, tiles innermost: consecutive MFMAs hit different accumulators (no dependent-issue stall);
+      // smallest terms first
 #pragma unroll
-      for (int i = 0; i < TM; ++i)
+      for (int q = 0; q < 6; ++q) {
+        constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};
 #pragma unroll
-        for (int j = 0; j < TN; ++j) {   // smallest terms first
-          f32x16 c = acc[i][j];
-          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][2], bf[j][0], c, 0, 0, 0);
-          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[j][2], c, 0, 0, 0);
-          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][1], bf[j][1], c, 0, 0, 0);
-          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][1], bf[j][0], c, 0, 0, 0);
-          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[j][1], c, 0, 0, 0);
-          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[j][0], c, 0, 0, 0);
-          acc[i][j] = c;
-        }
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][PA[q]], bf[j][PB[q]], acc[i][j], 0, 0, 0);
+      }
     } else {
       // lanes 0-31 hold k 0..7, lanes 32-63 k 8..15 of the chunk; MFMA q multiplies the k pair (q, 8+q)
       f32x4 alo[TM], ahi[TM], blo[TN], bhi[TN];
