@@ -168,6 +168,12 @@ def main():
                 "mfma_issue_tflops_bf16": round(ach * 6, 1) if split else None,
                 "flops_per_launch": flops, "avg_launch_ms": round(avg * 1e3, 4), "launches_timed": len(dur), "traffic": None}
         eng.kernel_timers = None
+        pmc = os.path.join(ROOT, "profiles", "r01c_pmc_dominant.json")
+        if os.path.exists(pmc) and B == 32 and S == 768 and split:     # counters were collected on this exact workload
+            pj = json.load(open(pmc))
+            roof["traffic"] = {"hbm_read_MB": pj["fetch_mb_per_launch"], "hbm_write_MB": pj["write_mb_per_launch"],
+                               "algorithmic_MB": pj["algorithmic_mb_per_launch"], "mfma_busy_pct_pmc": pj["mfma_busy_pct"],
+                               "source": pj["source"]}
 
     if rank == 0:
         total_frames = B * world * args.steps

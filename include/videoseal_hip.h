@@ -88,6 +88,7 @@ typedef struct vs_conv_desc {
   int32_t tile_hint;        /* low nibble: 0 = auto, 1 = 128x128, 2 = 128x64, 3 = 256x32, 4 = 128x192, 5 = 128x96,   */
                             /* 6 = 256x128, 7 = 128x128, 8 = 128x64, 9 = 256x64 (producer/consumer, need wt_blk);   */
                             /* 10 = 128x32, 11 = 128x64, 12 = 128x128: 3x3 stride-1 'patch' kernel (8x16-pixel tile);  */
+                            /* 13 = 64x64, 14 = 64x128 (generic kernel, small-M layers);                              */
                             /* | VS_CONV_FORCE_F32: v_mfma_f32_32x32x2_f32 path; | VS_CONV_FORCE_SPLIT */
   const void* wt_split;     /* optional [3][N][Ktot] bf16: wt split exactly into 3 bf16 terms; when set */
   const void* wt2_split;    /*   (and wt2_split for phase 2) the 6-product bf16-MFMA path is used       */

@@ -93,6 +93,8 @@ CONV_CASES = [
     (1, 1, 32, 32, 16, 3, 1, 1, 0, 1, 10),
     (2, 100, 9, 17, 64, 3, 1, 1, 0, 3, 11),
     (2, 48, 16, 16, 48, 3, 1, 1, 0, 1, 0),
+    (2, 96, 8, 8, 200, 1, 1, 0, 0, 2, 13),
+    (3, 160, 7, 9, 130, 3, 2, 1, 0, 1, 14),
 ]
 
 

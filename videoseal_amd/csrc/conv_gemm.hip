@@ -388,6 +388,8 @@ int dispatch(const vs_conv_desc_t& d, int tile, hipStream_t st) {
     case 3: return launch<4, 1, 2, 1, SPLIT>(d, st);   // 256 x 32
     case 4: return launch<2, 2, 2, 3, SPLIT>(d, st);   // 128 x 192
     case 5: return launch<4, 1, 1, 3, SPLIT>(d, st);   // 128 x 96
+    case 13: return launch<2, 2, 1, 1, SPLIT>(d, st);  // 64 x 64   (small-M layers: more workgroups than CUs)
+    case 14: return launch<2, 2, 1, 2, SPLIT>(d, st);  // 64 x 128
     default: return VS_ERR_UNSUPPORTED;
   }
 }
@@ -427,14 +429,14 @@ extern "C" int vs_conv_gemm(const vs_conv_desc_t* dp, void* stream) {
   // 3x3 / stride 1 / "same" convs on tile-aligned frames go to the patch kernel (input patch staged once per channel chunk)
   const bool patch_ok = can_split0 && d.KH == 3 && d.KW == 3 && d.SH == 1 && d.SW == 1 && d.PH == 1 && d.PW == 1 && d.Ho == d.H &&
                         d.Wo == d.W && !d.a_scale && !(d.tile_hint & VS_CONV_FORCE_F32);
-  if (tile >= 10) {
-    VS_REQUIRE(patch_ok && tile <= 12);
+  if (tile >= 10 && tile <= 12) {
+    VS_REQUIRE(patch_ok);
     return vs_conv3x3_patch_dispatch(d, tile, st);
   }
   if (tile == 0 && patch_ok && d.W % 16 == 0 && d.H % 8 == 0)
     return vs_conv3x3_patch_dispatch(d, d.N <= 32 ? 10 : (d.N <= 64 ? 11 : 12), st);
   if (tile == 0) tile = d.N <= 32 ? 3 : (d.N <= 64 ? 2 : (d.N <= 96 ? 5 : ((d.N % 192 == 0 || (d.N > 128 && d.N <= 192)) ? 4 : 1)));
-  if (tile >= 6) {   // producer/consumer kernels
+  if (tile >= 6 && tile <= 9) {   // producer/consumer kernels
     VS_REQUIRE(d.wt_blk && (!d.in2 || d.wt2_blk) && ((uintptr_t)d.wt_blk & 15) == 0);
     return vs_conv_gemm_pc_dispatch(d, tile, st);
   }

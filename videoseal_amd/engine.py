@@ -317,7 +317,7 @@ class HipEngine:
         if patch:     # the patch kernel walks K as (chunk, tap): candidates stay inside one K order (bit-identical results)
             cands = [t for t in (10, 11, 12) if {10: 32, 11: 64, 12: 128}[t] < 2 * d.N + 64 or t == 10]
         else:
-            cands = [t for t in (1, 2, 3, 4, 5) if self._tile_ok(t, d.N)]
+            cands = [t for t in (1, 2, 3, 4, 5, 13, 14) if self._tile_ok(t, d.N)]
         real_out, real_coff, real_ld = d.out, d.out_coff, d.out_ld
         scratch = self.buf("autotune.out", out.rows * rup(d.n_store, 4))
         d.out, d.out_coff, d.out_ld = N.ptr(scratch), 0, rup(d.n_store, 4)
@@ -339,7 +339,7 @@ class HipEngine:
 
     @staticmethod
     def _tile_ok(tile: int, n: int) -> bool:
-        bn = {1: 128, 2: 64, 3: 32, 4: 192, 5: 96}[tile]
+        bn = {1: 128, 2: 64, 3: 32, 4: 192, 5: 96, 13: 64, 14: 128}[tile]
         return bn < 2 * n + 64 or tile == 3     # skip tiles that would be mostly padding
 
     def layernorm(self, x: Act, w, b, out: Act, act=N.ACT_NONE):
