@@ -94,7 +94,7 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    dist_on = world > 1
+    dist_on = world > 1 or os.environ.get("VS_BENCH_FORCE_DIST") == "1"   # the env switch exercises the RCCL path on one GPU
     if args.gpus != world and dist_on:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if args.gpus > 1 and not dist_on:

@@ -175,3 +175,29 @@ def test_full_size_properties():
     p = model.detect(v, is_video=True)["preds"]
     perm = torch.tensor([3, 1, 7, 0, 2, 6, 5, 4])
     assert (model.detect(v[perm.cuda()], is_video=True)["preds"] - p[perm.cuda()]).abs().max() < 1e-5
+
+
+def test_edge_shapes(tiny):
+    """ragged / degenerate inputs: empty clip, a single frame, frame count not a multiple of step or chunk, frames smaller
+    than a JND tile, non-square frames, channel-last strided views; every case against the oracle."""
+    spec, sd, model = tiny
+    model.chunk_size, model.step_size, model.video_mode = 3, 2, "repeat"
+    msgs = synthetic_msgs(1, spec.nbits, seed=9)
+    empty = torch.zeros(0, 3, 48, 40, device="cuda")
+    assert model.embed(empty, msgs, is_video=True)["imgs_w"].shape == (0, 3, 48, 40)
+    assert model.detect(empty, is_video=True)["preds"].shape == (0, spec.nbits + 1)
+    for n, h, w in [(1, 64, 64), (7, 48, 40), (5, 9, 300), (2, 5, 7), (4, 130, 33)]:
+        imgs = synthetic_frames(n, h, w, seed=n + h)
+        out = model.embed(imgs.cuda(), msgs, is_video=True, lowres_attenuation=(n % 2 == 0))
+        ref = R.embed_video(sd, spec, imgs, msgs, chunk_size=3, step_size=2, lowres_attenuation=(n % 2 == 0))
+        assert (out["imgs_w"].cpu() - ref["imgs_w"]).abs().max() < TOL_IMG, (n, h, w)
+        p = model.detect(out["imgs_w"], is_video=True)["preds"].cpu()
+        assert (p - R.detect(sd, spec, ref["imgs_w"])["preds"]).abs().max() < TOL_LOGIT
+    # non-contiguous input (HWC video decoded by a caller and permuted): values must not depend on the memory layout
+    hwc = synthetic_frames(4, 64, 80, seed=3).permute(0, 2, 3, 1).contiguous().cuda()
+    a = model.embed(hwc.permute(0, 3, 1, 2), msgs, is_video=True)["imgs_w"]
+    b = model.embed(hwc.permute(0, 3, 1, 2).contiguous(), msgs, is_video=True)["imgs_w"]
+    assert torch.equal(a, b)
+    # float / bool messages are accepted like int64 ones (msg_processor.py:92)
+    c = model.embed(hwc.permute(0, 3, 1, 2), msgs.float(), is_video=True)["imgs_w"]
+    assert torch.equal(a, c)

@@ -229,6 +229,8 @@ class Wam(nn.Module):
         aa = _antialias_flag(interpolation)
         x = N.f32c(imgs.to(eng.dev))
         B = x.shape[0]
+        if B == 0:
+            return {"msgs": msgs, "preds_w": imgs.new_zeros((0, self.embedder.cfg.out_ch) + tuple(imgs.shape[-2:])), "imgs_w": imgs.clone()}
         if msgs.shape[0] != B:
             raise ValueError(f"msgs has {msgs.shape[0]} rows for {B} images")
         out = torch.empty_like(x)
@@ -248,6 +250,8 @@ class Wam(nn.Module):
         eng = self._engine()
         aa = _antialias_flag(interpolation)
         x = N.f32c(imgs.to(eng.dev))
+        if x.shape[0] == 0:
+            return {"preds": imgs.new_zeros((0, self.embedder.cfg.nbits + 1))}
         rgb, _ = eng.resize_pre(x, (self.img_size, self.img_size), aa, want_rgb=True, mul=2.0, add=-1.0, tag="det.in")
         return {"preds": eng.extractor_forward(rgb).to(imgs.device)}
 
@@ -309,6 +313,8 @@ class Videoseal(Wam):
         eng = self._engine()
         aa = _antialias_flag(interpolation)
         x = N.f32c(imgs.to(eng.dev))
+        if x.shape[0] == 0:
+            return {"preds": imgs.new_zeros((0, self.embedder.cfg.nbits + 1))}
         S = (self.img_size, self.img_size)
         preds = []
         ck = max(1, int(self.chunk_size))
