@@ -81,7 +81,10 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--mode", choices=["image", "video"], default="image")
+    ap.add_argument("--mode", choices=["image", "video", "stream"], default="image",
+                    help="stream = BASELINE config 4: --frames frames processed as 16-frame embed(lowres_attenuation)+detect calls")
+    ap.add_argument("--frames", type=int, default=1024, help="stream mode: total frames of the clip (sharded over the ranks)")
+    ap.add_argument("--graphs", action="store_true", help="replay the per-chunk launch sequences from hipGraphs")
     ap.add_argument("--batch", type=int, default=32)
     ap.add_argument("--size", type=int, default=768)
     ap.add_argument("--card", default="videoseal_1.0")
@@ -108,18 +111,36 @@ def main():
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group("nccl", device_id=dev)
 
+    if args.graphs:
+        os.environ["VIDEOSEAL_GRAPHS"] = "1"
     import videoseal_amd
-    from videoseal_amd.dist import gather_frame_logits
+    from videoseal_amd.dist import gather_frame_logits, shard_range
     model = videoseal_amd.build(args.card, seed=0).eval().to(dev)
     cfg = model.embedder.cfg
     B, S = args.batch, args.size
+    stream = args.mode == "stream"
+    if stream:       # strong scaling: the clip is split into contiguous 16-aligned frame ranges
+        f0, f1 = shard_range(args.frames, rank, world, 16)
+        B = f1 - f0
     frames = synthetic_batch(B, S, dev, seed=1000 + rank)
     gm = torch.Generator().manual_seed(5)
-    is_video = args.mode == "video"
+    is_video = args.mode in ("video", "stream")
     msgs = torch.randint(0, 2, (1 if is_video else B, cfg.nbits), generator=gm)
     model.chunk_size = max(model.chunk_size, B)
 
+    def step_stream():      # inference_streaming.py:83-107,117-164: 16-frame chunks, low-res attenuation, mean of the logits
+        logits = []
+        for a in range(0, B, 16):
+            w = model.embed(frames[a:a + 16], msgs, is_video=True, lowres_attenuation=True)["imgs_w"]
+            logits.append(model.detect(w, is_video=True)["preds"])
+        preds = torch.cat(logits, 0)
+        if dist_on:
+            preds = gather_frame_logits(preds, args.frames, align=16)
+        return preds
+
     def step():
+        if stream:
+            return step_stream()
         if args.detect_only:
             preds = model.detect(frames, is_video=True)["preds"]
         else:
@@ -176,7 +197,7 @@ def main():
                                "source": pj["source"]}
 
     if rank == 0:
-        total_frames = B * world * args.steps
+        total_frames = (args.frames if stream else B * world) * args.steps
         fps = total_frames / elapsed
         # algorithmic work per frame: 28.28 GMAC embed (image) / 7.07 (video, step 4) + 6.16 GMAC detect
         gmac = (28.28 if not is_video else 28.28 / cfg.step_size) + 6.16
@@ -185,12 +206,14 @@ def main():
         line = {
             "metric": ("frames/sec embed+extract 256-bit @768x768" if not args.detect_only else f"frames/sec extract ({args.card}) @{S}x{S}"), "value": round(fps, 2), "unit": "frames/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 3),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "higher_is_better": True, "scaling": "strong" if stream else "weak", "vs_baseline": None,
             "dtype": "f32 (3 x bf16 exact operand split on the bf16 matrix cores, fp32 accumulate)" if eng.use_split else "f32", "data": "synthetic",
             "config": {"workload": f"{args.card} {cfg.nbits}-bit, {B} frames {S}x{S} per GPU, {args.mode} mode "
                                    f"({'embedder on every frame' if not is_video else 'key frames every %d' % cfg.step_size}, "
                                    f"{'low-res' if args.lowres_attenuation else 'full-res'} JND), " + ("detect only" if args.detect_only else "embed + detect")
-                                   + (", all-gather of bit logits" if dist_on else ""),
+                                   + (", all-gather of bit logits" if dist_on else "")
+                                   + (f"; streaming: {args.frames}-frame clip as 16-frame calls, low-res JND" if stream else "")
+                                   + (", hipGraph replay" if args.graphs else ""),
                        "card": args.card, "weights": "random-init (seeded), no checkpoint offline", "batch_per_gpu": B,
                        "frame": [S, S], "mode": args.mode},
             "model_tflops_per_s": round(fps * gmac * 2e9 / 1e12 / world, 2),

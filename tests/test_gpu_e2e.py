@@ -201,3 +201,23 @@ def test_edge_shapes(tiny):
     # float / bool messages are accepted like int64 ones (msg_processor.py:92)
     c = model.embed(hwc.permute(0, 3, 1, 2), msgs.float(), is_video=True)["imgs_w"]
     assert torch.equal(a, c)
+
+
+def test_hipgraph_replay_matches_eager(tiny):
+    """VIDEOSEAL_GRAPHS path: the captured launch sequence replays bit-identically, for changing inputs and messages."""
+    spec, sd, model = tiny
+    model.chunk_size, model.step_size, model.video_mode = 8, 2, "repeat"
+    outs = {}
+    for use in (False, True):
+        model.use_graphs = use
+        res = []
+        for seed in (1, 2, 3):
+            imgs = synthetic_frames(16, 96, 80, seed=seed).cuda()
+            msgs = synthetic_msgs(1, spec.nbits, seed=seed)
+            w = model.embed(imgs, msgs, is_video=True, lowres_attenuation=True)["imgs_w"]
+            res.append((w, model.detect(w, is_video=True)["preds"]))
+        outs[use] = res
+    model.use_graphs = False
+    assert len(model._graphs) == 2          # one embed graph + one detect graph, reused for the 3 clips
+    for (w0, p0), (w1, p1) in zip(outs[False], outs[True]):
+        assert torch.equal(w0, w1) and torch.equal(p0, p1)

@@ -290,11 +290,11 @@ class HipEngine:
             if in2 is not None:
                 d.wt2_split = N.ptr(w2.with_split().split)
                 d.wt2_blk = N.ptr(w2.with_blk().blk)
-        if tile_hint == 0 and self.autotune and not torch.cuda.is_current_stream_capturing():
+        if tile_hint == 0 and self.autotune:
             d.tile_hint = self._pick_tile(d, w, out)
         if self.kernel_timers is not None and prof is None and self.time_all_convs:
             prof = f"conv{w.KH}x{w.KW} {x.C}->{w.N} @{out.H}x{out.W}" + ("+1x1" if in2 is not None else "")
-        timed = prof is not None and self.kernel_timers is not None
+        timed = prof is not None and self.kernel_timers is not None and not torch.cuda.is_current_stream_capturing()
         if timed:   # HIP events on the launch stream, used by bench.py for the per-kernel roofline
             ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             ev0.record()
@@ -312,6 +312,8 @@ class HipEngine:
         best = self._tile_cache.get(key)
         if best is not None:
             return best
+        if torch.cuda.is_current_stream_capturing():
+            return 0          # never time inside a hipGraph capture: static heuristic (same numerics)
         patch = (bool(d.wt_split) and d.KH == 3 and d.KW == 3 and d.SH == 1 and d.SW == 1 and d.PH == 1 and d.PW == 1 and
                  d.Ho == d.H and d.Wo == d.W and not d.a_scale and d.W % 16 == 0 and d.H % 8 == 0)
         if patch:     # the patch kernel walks K as (chunk, tap): candidates stay inside one K order (bit-identical results)
@@ -446,7 +448,7 @@ class HipEngine:
         self.conv(cur, X["head_conv"], hc, pad=1, pad_mode=N.PAD_REFLECT)
         hl = self.new_act("head.l", B, cur.H, cur.W, d[-1])
         self.layernorm(hc, X["head_ln"][0], X["head_ln"][1], hl, act=N.ACT_GELU)
-        out = torch.empty(B, c.nbits + 1, device=self.dev, dtype=torch.float32)
+        out = self.buf("logits", B * (c.nbits + 1)).view(B, c.nbits + 1)
         N.check(L.vs_pool_linear(N.ptr(hl.t), B, hl.H * hl.W, hl.C, hl.ld, N.ptr(X["lin_w"]), N.ptr(X["lin_b"]), c.nbits + 1, N.ptr(out), st),
                 "vs_pool_linear")
         return out

@@ -13,6 +13,7 @@ Deliberate differences, each loud rather than silent:
 """
 from __future__ import annotations
 
+import os
 from typing import Dict, Optional
 
 import torch
@@ -96,7 +97,7 @@ class Extractor(nn.Module):
         eng = root._engine()
         x = N.f32c(imgs.to(eng.dev))
         rgb, _ = eng.resize_pre(x, (x.shape[-2], x.shape[-1]), False, want_rgb=True, mul=2.0, add=-1.0, tag="det.in")
-        return eng.extractor_forward(rgb).to(imgs.device)
+        return eng.extractor_forward(rgb).clone().to(imgs.device)
 
 
 class Blender(nn.Module):
@@ -176,6 +177,10 @@ class Wam(nn.Module):
         self.clamp = clamp
         self._eng: Optional[HipEngine] = None
         self._eng_key = None
+        # hipGraph replay of the per-chunk launch sequences (fixed chunk shapes, e.g. streaming callers): the ~300 kernel
+        # launches of an embed / detect chunk are captured once per (shape, flags) and replayed with one launch
+        self.use_graphs = os.environ.get("VIDEOSEAL_GRAPHS", "0") == "1"
+        self._graphs: Dict[tuple, dict] = {}
         holder = [self]
         embedder._root = detector._root = holder
         if attenuation is not None:
@@ -202,15 +207,75 @@ class Wam(nn.Module):
         if self._eng is None or self._eng_key != key:
             self._eng = HipEngine(self.embedder.cfg, self.state_dict(), dev)
             self._eng_key = key
+            self._graphs.clear()
         return self._eng
 
     def repack(self) -> None:
         """Force re-packing of the weights (after in-place edits that bypass tensor versioning)."""
         self._eng = None
+        self._graphs.clear()
+
+    def _graphed(self, key: tuple, ins: Dict[str, torch.Tensor], run):
+        """Replay `run(static_inputs) -> dict of output tensors` from a hipGraph captured once per key.
+        The first call runs eagerly twice (workspace allocation + tile autotune), then captures."""
+        ent = self._graphs.get(key)
+        if ent is None:
+            static_in = {k: v.clone() for k, v in ins.items()}
+            run(static_in)
+            run(static_in)
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                outs = run(static_in)
+            ent = {"g": g, "in": static_in, "out": outs}
+            self._graphs[key] = ent
+        for k, v in ins.items():
+            ent["in"][k].copy_(v)
+        ent["g"].replay()
+        return ent["out"]
+
+    def _detect_frames(self, eng: HipEngine, fr: torch.Tensor, S, antialias: bool) -> torch.Tensor:
+        def run(si):
+            rgb, _ = eng.resize_pre(si["fr"], S, antialias, want_rgb=True, mul=2.0, add=-1.0, tag="det.in")
+            return {"preds": eng.extractor_forward(rgb)}
+        if self.use_graphs and not torch.cuda.is_current_stream_capturing():
+            key = ("det", tuple(fr.shape), tuple(S), antialias, id(eng))
+            return self._graphed(key, {"fr": fr}, run)["preds"].clone()
+        return run({"fr": fr})["preds"].clone()
 
     # ---- core of embed: one chunk of frames on the device
     def _embed_frames(self, eng: HipEngine, fr: torch.Tensor, msgs_i32: torch.Tensor, out: torch.Tensor, *, step: int,
                       video_mode: int, antialias: bool, lowres: bool, preds_w: Optional[torch.Tensor] = None) -> None:
+        if self.use_graphs and not torch.cuda.is_current_stream_capturing():
+            key = ("emb", tuple(fr.shape), tuple(msgs_i32.shape), step, video_mode, antialias, lowres, preds_w is not None, self.img_size,
+                   self.clamp, float(self.blender.scaling_i), float(self.blender.scaling_w), self.attenuation is not None, id(eng))
+            ent = self._graphs.get(key)
+            if ent is None:
+                sin = {"fr": fr.clone(), "msgs": msgs_i32.clone()}
+                sout = torch.empty_like(sin["fr"])
+                spw = torch.empty_like(preds_w) if preds_w is not None else None
+                for _ in range(2):
+                    self._embed_frames_eager(eng, sin["fr"], sin["msgs"], sout, step=step, video_mode=video_mode, antialias=antialias,
+                                             lowres=lowres, preds_w=spw)
+                torch.cuda.synchronize()
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    self._embed_frames_eager(eng, sin["fr"], sin["msgs"], sout, step=step, video_mode=video_mode, antialias=antialias,
+                                             lowres=lowres, preds_w=spw)
+                ent = {"g": g, "in": sin, "out": sout, "pw": spw}
+                self._graphs[key] = ent
+            ent["in"]["fr"].copy_(fr)
+            ent["in"]["msgs"].copy_(msgs_i32)
+            ent["g"].replay()
+            out.copy_(ent["out"])
+            if preds_w is not None:
+                preds_w.copy_(ent["pw"])
+            return
+        self._embed_frames_eager(eng, fr, msgs_i32, out, step=step, video_mode=video_mode, antialias=antialias, lowres=lowres,
+                                 preds_w=preds_w)
+
+    def _embed_frames_eager(self, eng: HipEngine, fr: torch.Tensor, msgs_i32: torch.Tensor, out: torch.Tensor, *, step: int,
+                            video_mode: int, antialias: bool, lowres: bool, preds_w: Optional[torch.Tensor] = None) -> None:
         S = (self.img_size, self.img_size)
         att = self.attenuation is not None
         rgb, key = eng.resize_pre(fr, S, antialias, want_rgb=(att and lowres), want_key=True, key_step=step)
@@ -252,8 +317,7 @@ class Wam(nn.Module):
         x = N.f32c(imgs.to(eng.dev))
         if x.shape[0] == 0:
             return {"preds": imgs.new_zeros((0, self.embedder.cfg.nbits + 1))}
-        rgb, _ = eng.resize_pre(x, (self.img_size, self.img_size), aa, want_rgb=True, mul=2.0, add=-1.0, tag="det.in")
-        return {"preds": eng.extractor_forward(rgb).to(imgs.device)}
+        return {"preds": self._detect_frames(eng, x, (self.img_size, self.img_size), aa).to(imgs.device)}
 
     @torch.no_grad()
     def forward(self, imgs: torch.Tensor, masks: torch.Tensor, msgs: torch.Tensor = None, interpolation: dict = None) -> dict:
@@ -319,8 +383,7 @@ class Videoseal(Wam):
         preds = []
         ck = max(1, int(self.chunk_size))
         for a in range(0, x.shape[0], ck):
-            rgb, _ = eng.resize_pre(x[a:a + ck], S, aa, want_rgb=True, mul=2.0, add=-1.0, tag="det.in")
-            preds.append(eng.extractor_forward(rgb))
+            preds.append(self._detect_frames(eng, x[a:a + ck], S, aa))
         return {"preds": torch.cat(preds, dim=0).to(imgs.device)}
 
     def extract_message(self, imgs: torch.Tensor, aggregation: str = "avg",
@@ -362,7 +425,7 @@ class Videoseal(Wam):
         imgs_aug, masks, selected = self.augmenter(imgs_w, imgs, masks, is_video=True, do_resize=False)
         rgb, _ = eng.resize_pre(N.f32c(imgs_aug.to(eng.dev)), (self.img_size, self.img_size), aa, want_rgb=True, mul=2.0, add=-1.0,
                                 tag="det.in")
-        preds = eng.extractor_forward(rgb).to(imgs.device)
+        preds = eng.extractor_forward(rgb).clone().to(imgs.device)
         return {"msgs": msgs.expand(imgs.shape[0], -1), "masks": masks, "imgs_w": imgs_w, "imgs_aug": imgs_aug, "preds": preds,
                 "selected_aug": selected}
 
