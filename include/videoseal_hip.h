@@ -89,6 +89,8 @@ typedef struct vs_conv_desc {
                             /* 6 = 256x128, 7 = 128x128, 8 = 128x64, 9 = 256x64 (producer/consumer, need wt_blk);   */
                             /* 10 = 128x32, 11 = 128x64, 12 = 128x128: 3x3 stride-1 'patch' kernel (8x16-pixel tile);  */
                             /* 13 = 64x64, 14 = 64x128 (generic kernel, small-M layers);                              */
+                            /* 15 = 128x128, 16 = 128x192: wave-specialised patch kernel (needs wt_blk);               */
+                            /* | VS_CONV_TILE_HI: tile code + 16;                                                     */
                             /* | VS_CONV_FORCE_F32: v_mfma_f32_32x32x2_f32 path; | VS_CONV_FORCE_SPLIT */
   const void* wt_split;     /* optional [3][N][Ktot] bf16: wt split exactly into 3 bf16 terms; when set */
   const void* wt2_split;    /*   (and wt2_split for phase 2) the 6-product bf16-MFMA path is used       */
@@ -98,6 +100,7 @@ typedef struct vs_conv_desc {
 } vs_conv_desc_t;
 #define VS_CONV_FORCE_F32 0x10
 #define VS_CONV_FORCE_SPLIT 0x20
+#define VS_CONV_TILE_HI 0x40
 int vs_conv_gemm(const vs_conv_desc_t* d, void* stream);
 
 /* LayerNorm over the channel dim of [rows][ld] (+ optional activation).  common.py:131-155 (both data formats). */

@@ -94,6 +94,15 @@ CONV_CASES = [
     (2, 100, 9, 17, 64, 3, 1, 1, 0, 3, 11),
     (2, 48, 16, 16, 48, 3, 1, 1, 0, 1, 0),
     (2, 96, 8, 8, 200, 1, 1, 0, 0, 2, 13),
+    # wave-specialised patch kernel (tile 15): aligned / ragged frames, ragged N, reflect, single chunk, odd chunk counts
+    (2, 384, 16, 16, 384, 3, 1, 1, 0, 1, 15),
+    (3, 48, 13, 21, 136, 3, 1, 1, 1, 2, 15),
+    (2, 16, 32, 32, 16, 3, 1, 1, 0, 1, 15),
+    (1, 1, 8, 16, 130, 3, 1, 1, 0, 3, 15),
+    (2, 100, 24, 48, 300, 3, 1, 1, 0, 0, 15),
+    (2, 384, 16, 16, 384, 3, 1, 1, 0, 1, 0x40),     # 0x40 = tile 16: 128 x 192
+    (3, 48, 13, 21, 200, 3, 1, 1, 1, 2, 0x40),
+    (1, 16, 8, 16, 16, 3, 1, 1, 0, 3, 0x40),
     (3, 160, 7, 9, 130, 3, 2, 1, 0, 1, 14),
 ]
 
@@ -122,7 +131,7 @@ def test_conv_gemm_matches_conv2d(eng, case):
     assert torch.isfinite(full).all() and (full[..., Cout:] == 0).all()   # pad lanes written as zero
 
 
-@pytest.mark.parametrize("tile", [0, 7, 8, 10, 11, 1])
+@pytest.mark.parametrize("tile", [0, 7, 8, 10, 11, 1, 15, 0x40])
 def test_conv_two_phase_residual_block(eng, tile):
     """ResnetBlock tail: relu(conv3x3(t)+b) + (conv1x1(x)+b2), written at a channel offset of a wider buffer."""
     if tile >= 6 and not eng.use_split:

@@ -1,0 +1,48 @@
+#!/usr/bin/env python
+"""Bottleneck conv: patch kernel (tile 12) vs wave-specialised patch kernel (tile 15), with and without the 1x1 second phase."""
+import math, sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch, torch.nn.functional as F
+from videoseal_amd import native as N
+from videoseal_amd.engine import Act, ConvW, pack_conv
+from tools.bench_conv import Eng
+
+def run(B, C, H, W, Co, tiles, two_phase, reps=40):
+    eng = Eng()
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(B, H, W, C, generator=g).cuda(); x2 = torch.randn(B, H, W, C, generator=g).cuda()
+    w = (torch.randn(Co, C, 3, 3, generator=g) / math.sqrt(C * 9)).cuda(); w2 = (torch.randn(Co, C, 1, 1, generator=g) / math.sqrt(C)).cuda()
+    xa, xa2 = Act(x, B, H, W, C, C), Act(x2, B, H, W, C, C)
+    wt, cp = pack_conv(w, C); wt2, cp2 = pack_conv(w2, C)
+    cw, cw2 = ConvW(wt, None, Co, 3, 3, cp), ConvW(wt2, None, Co, 1, 1, cp2)
+    out = eng.new_act("o", B, H, W, Co)
+    flops = 2.0 * B * H * W * Co * C * (10 if two_phase else 9)
+    ref = None
+    best = {t: 1e9 for t in tiles}
+    outs = {}
+    for rnd in range(5):            # interleave the variants, keep the best round of each: clocks wander by +-10 % on this box
+        for t in tiles:
+            kw = dict(pad=1, act=N.ACT_RELU, tile_hint=t)
+            if two_phase: kw.update(in2=xa2, w2=cw2)
+            for _ in range(3): eng.conv(xa, cw, out, **kw)
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(reps): eng.conv(xa, cw, out, **kw)
+            e1.record(); torch.cuda.synchronize()
+            best[t] = min(best[t], e0.elapsed_time(e1) / reps)
+            if rnd == 0: outs[t] = out.t.clone()
+    for t in tiles:
+        got = outs[t]
+        same = "" if ref is None else f" bit-identical to first: {bool((got == ref).all())}  maxdiff {(got-ref).abs().max().item():.2e}"
+        if ref is None: ref = got
+        ms = best[t]
+        print(f"B{B} {C}->{Co} {H}x{W} two_phase={two_phase} tile {(t & 15) + (16 if t & 0x40 else 0):2d} abl {t >> 8:x}: {ms:7.3f} ms {flops/ms/1e9:7.1f} TF-eq{same}", flush=True)
+
+if __name__ == "__main__":
+    run(32, 384, 32, 32, 384, [12, 15, 0x40], False)
+    run(32, 384, 32, 32, 384, [15, 15 | 0x100, 15 | 0x400, 15 | 0x500, 0x40, 0x40 | 0x100, 0x40 | 0x400, 0x40 | 0x500], False)
+    run(32, 384, 32, 32, 384, [12, 15, 0x40], True)
+    run(8, 384, 32, 32, 384, [12, 15, 0x40], False)
+    run(32, 128, 32, 32, 128, [12, 15], False)
+    run(32, 768, 64, 64, 64, [11, 15], False)

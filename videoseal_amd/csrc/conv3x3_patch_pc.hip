@@ -1,0 +1,370 @@
+// Wave-specialised version of the 3x3 patch kernel (conv3x3_patch.hip): 512 threads, one workgroup per CU.
+//   waves 0-3  consumers : nothing but ds_read_b128 fragment loads and v_mfma_f32_32x32x16_bf16 (3 x bf16 split, 6 MFMAs
+//                          per 32x32x16 block).  Fragments are double-buffered in registers: while the MFMAs of tap-step s
+//                          run, the fragment reads of step s+1 are already in flight (its weight tile was published one
+//                          barrier earlier, its A rows come from the resident input patch), so the matrix pipe does not
+//                          drain at the barriers.
+//   waves 4-5  activation producers : once per 16-channel chunk load + split the 10 x 18 input patch of the NEXT chunk
+//                          into the second patch buffer (loads at tap 0, split + ds_write at tap 4).
+//   waves 6-7  weight producers : LDS-DMA (global_load_lds_dwordx4) of the pre-split weight tile of step s+5 into a 6-deep
+//                          LDS ring, counted s_waitcnt keeps three tiles (~1 us) in flight across the barriers.
+// With the patch staging the producer work is ~1/9 of the im2col kernel's, so the consumers are never starved and the
+// workgroup is bound by the MFMA issue of its four consumer waves.  One s_barrier per tap-step.
+// Second K phase (ResnetBlock's 1x1 res_conv on the block input): the producers stage the in2 rows as plain 128-row
+// chunks in the same two buffers; consumers do not prefetch across those (short) steps.
+#include <type_traits>
+#include "conv_common.h"
+
+namespace {
+
+using namespace vsconv;
+
+constexpr int TH = 8, TW = 16, PW = TW + 2, PH = TH + 2, PROWS = PW * PH;   // 180 patch pixels
+constexpr int PITEMS = PROWS * 4;
+constexpr int BMP = TH * TW;
+constexpr int NPI = (PITEMS + 127) / 128;                                    // patch float4 items per producer thread (6)
+constexpr int P_BYTES = 3 * PROWS * ROWB;                                    // one patch buffer, three bf16 planes
+
+// one wave moves a 1 KiB block global -> LDS (lane l: 16 bytes at gp, landing at lds_base + 16*l)
+__device__ __forceinline__ void dma_1k(const char* gp, unsigned char* lds_base) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gp,
+                                   (__attribute__((address_space(3))) void*)lds_base, 16, 0, 0);
+}
+
+template <int TN>
+__global__ __launch_bounds__(512, 2) void conv3x3_patch_pc_kernel(const vs_conv_desc_t d, const int tiles_x, const int tiles_y,
+                                                                  const int mtiles) {
+  constexpr int TM = 2;
+  constexpr int BN = 64 * TN;
+  constexpr int NG = BN / 32;                            // 32-row weight groups per tile
+  constexpr int NRING = TN >= 3 ? 5 : 6;                 // weight ring depth (LDS: 2 patches + NRING tiles <= 160 KiB)
+  constexpr int B_STAGE = 3 * BN * 32;                   // three planes of [BN rows][16 bf16], rows unpadded (DMA-written)
+  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * P_BYTES + NRING * B_STAGE];
+  unsigned char* const Pbuf = smem;
+  unsigned char* const Bring = smem + 2 * P_BYTES;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r = lane & 31, g = lane >> 5;
+
+  const int bm = blockIdx.x % mtiles;
+  const int bn = blockIdx.x / mtiles;
+  const int n0 = bn * BN;
+  const int tx = bm % tiles_x;
+  const int ty = (bm / tiles_x) % tiles_y;
+  const int fb = bm / (tiles_x * tiles_y);
+  const int y0 = ty * TH, x0 = tx * TW;
+
+  const int spt = d.CinP / BK;
+  const int n1 = 9 * spt;
+  const int n2 = d.in2 ? d.Cin2P / BK : 0;
+  const int total = n1 + n2;
+  const int abl = d.tile_hint >> 8;   // debug ablation (tools/bench_ppc.py): 1 no weight DMA, 4 no activation staging
+
+  if (wave >= 6) {
+    // ================================================================== weight producers (waves 6-7): LDS-DMA only
+    // Tile t (= the [BN x 16] slice of the split weights that step t multiplies) goes to ring stage t % NRING.  It is
+    // issued NRING-1 steps before its step and must have landed one barrier before the consumers prefetch it, i.e. at
+    // the end of step s everything up to tile s+2 is complete: at most the three youngest tiles stay in flight.
+    // These waves issue no ordinary loads, so the counted s_waitcnt below is exact (hipcc would drain to vmcnt(0)).
+    const int bw = wave - 6;
+    // weights in LDS-image order (engine.pack_blocked): [N/32 groups][step t = chunk*9 + tap][3 planes][1 KiB], so every DMA
+    // instruction reads 1 KiB of consecutive memory (whole cache lines) and a tile's blocks follow each other in step order
+    const char* const wblk = reinterpret_cast<const char*>(d.wt_blk);
+    const int64_t w2delta = d.wt2_blk ? reinterpret_cast<const char*>(d.wt2_blk) - wblk : 0;
+    const int g0 = n0 / 32;
+    const int ngroups = (d.N + 31) / 32;
+    constexpr int NGW = NG / 2;                          // weight groups per producer wave
+    int gsel[NGW];
+#pragma unroll
+    for (int q = 0; q < NGW; ++q) {
+      const int gi = g0 + bw * NGW + q;
+      gsel[q] = gi < ngroups ? gi : ngroups - 1;         // tile wider than N: re-read a valid group (columns are discarded)
+    }
+    auto dma_tile = [&, n1, n2, bw, lane](const int t) __attribute__((always_inline)) {
+      unsigned char* st = Bring + (t % NRING) * B_STAGE;
+      // (never select between two captured variables here: see conv_gemm_pc.hip)
+      const int ph2 = t >= n1 ? 1 : 0;
+      const int nsel = n1 + ph2 * (__builtin_amdgcn_readfirstlane(n2) - n1);     // blocks per group in this phase
+      const int64_t off = (int64_t)ph2 * w2delta + (int64_t)(t - ph2 * n1) * 3072 + lane * 16;
+#pragma unroll
+      for (int q = 0; q < NGW; ++q) {
+        const char* gp = wblk + off + (int64_t)gsel[q] * nsel * 3072;
+#pragma unroll
+        for (int p = 0; p < 3; ++p) dma_1k(gp + p * 1024, st + p * (BN * 32) + (bw * NGW + q) * 1024);
+      }
+    };
+    constexpr int ND = 3 * NGW;                          // DMA instructions per wave per tile
+#pragma unroll
+    for (int t = 0; t < NRING - 1; ++t)
+      if (t < total) dma_tile(t);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    for (int s = 0; s < total; ++s) {
+      if (s + NRING - 1 < total) {
+        if (!(abl & 1)) dma_tile(s + NRING - 1);                         // stage of tile s-1: its fragments were consumed before the last barrier
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * ND) : "memory");
+      } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+      __builtin_amdgcn_s_barrier();
+    }
+    return;
+  }
+
+  if (wave >= 4) {
+    // ================================================================== activation producers (waves 4-5)
+    const int pt = tid & 127;
+    const bool reflect = d.pad_mode == VS_PAD_REFLECT;
+    unsigned p_off[NPI];
+    int p_lds[NPI];
+    bool p_ok[NPI], p_have[NPI];
+#pragma unroll
+    for (int i = 0; i < NPI; ++i) {
+      const int item = pt + i * 128;
+      p_have[i] = item < PITEMS;
+      const int prow = p_have[i] ? item >> 2 : 0;
+      const int k4 = (item & 3) * 4;
+      int iy = y0 - 1 + prow / PW, ix = x0 - 1 + prow % PW;
+      if (reflect) {
+        iy = iy < 0 ? -iy : (iy >= d.H ? 2 * d.H - 2 - iy : iy);
+        ix = ix < 0 ? -ix : (ix >= d.W ? 2 * d.W - 2 - ix : ix);
+      }
+      const bool ok = iy >= 0 && iy < d.H && ix >= 0 && ix < d.W;
+      p_ok[i] = ok && p_have[i];
+      p_off[i] = ok ? (unsigned)(((int64_t)fb * d.in_sb + (int64_t)iy * d.in_sy + (int64_t)ix * d.in_sx + k4) * 4) : 0u;
+      p_lds[i] = prow * ROWB + k4 * 2;
+    }
+    constexpr int NQ = BMP * 4 / 128;                    // in2 float4 items per thread per chunk (4)
+    unsigned q_off[NQ];
+    bool q_ok[NQ];
+    const int qk4 = (pt & 3) * 4;
+#pragma unroll
+    for (int i = 0; i < NQ; ++i) {
+      const int p = (pt + i * 128) >> 2;
+      const int y = y0 + (p >> 4), x = x0 + (p & 15);
+      q_ok[i] = y < d.H && x < d.W;
+      const int64_t m = ((int64_t)fb * d.H + (q_ok[i] ? y : 0)) * d.W + (q_ok[i] ? x : 0);
+      q_off[i] = (unsigned)((m * d.in2_ld + qk4) * 4);
+    }
+    f32x4 rp[NPI];          // patch registers
+    f32x4 rq[NQ];           // in2 rows
+
+    auto load_patch = [&, pt](const int cc) __attribute__((always_inline)) {
+      const char* base = reinterpret_cast<const char*>(d.in) + (int64_t)cc * (BK * 4);
+      const bool cok = (cc * BK + (pt & 3) * 4) < d.Cin;
+#pragma unroll
+      for (int i = 0; i < NPI; ++i) {
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (p_have[i] && cok) v = *reinterpret_cast<const f32x4*>(base + p_off[i]);
+        if (!p_ok[i]) v = f32x4{0.f, 0.f, 0.f, 0.f};
+        rp[i] = v;
+      }
+    };
+    // item i of the patch is split + stored at tap `first + i` (first = -1: all at once): spreading the VALU burst
+    // over six steps keeps these waves from arriving late at one barrier per chunk
+    auto store_patch = [&](const int pb, const int tap, const int first) __attribute__((always_inline)) {
+      unsigned char* Ps = Pbuf + pb * P_BYTES;
+#pragma unroll
+      for (int i = 0; i < NPI; ++i)
+        if (p_have[i] && (first < 0 || tap == first + i)) {
+          u32x2 p1, p2, p3;
+          split4(rp[i], p1, p2, p3);
+          *reinterpret_cast<u32x2*>(Ps + p_lds[i]) = p1;
+          *reinterpret_cast<u32x2*>(Ps + PROWS * ROWB + p_lds[i]) = p2;
+          *reinterpret_cast<u32x2*>(Ps + 2 * PROWS * ROWB + p_lds[i]) = p3;
+        }
+    };
+    auto load_rows2 = [&, qk4](const int c2) __attribute__((always_inline)) {      // in2 chunk c2 -> registers
+      const char* base = reinterpret_cast<const char*>(d.in2) + (int64_t)c2 * (BK * 4);
+      const bool cok = (c2 * BK + qk4) < d.Cin2;
+#pragma unroll
+      for (int i = 0; i < NQ; ++i) {
+        rq[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (q_ok[i] && cok) rq[i] = *reinterpret_cast<const f32x4*>(base + q_off[i]);
+      }
+    };
+    auto store_rows2 = [&, pt, qk4](const int pb) __attribute__((always_inline)) {  // as plain pixel rows 0..127
+      unsigned char* Ps = Pbuf + pb * P_BYTES;
+#pragma unroll
+      for (int i = 0; i < NQ; ++i) {
+        u32x2 p1, p2, p3;
+        split4(rq[i], p1, p2, p3);
+        const int off = ((pt + i * 128) >> 2) * ROWB + qk4 * 2;
+        *reinterpret_cast<u32x2*>(Ps + off) = p1;
+        *reinterpret_cast<u32x2*>(Ps + PROWS * ROWB + off) = p2;
+        *reinterpret_cast<u32x2*>(Ps + 2 * PROWS * ROWB + off) = p3;
+      }
+    };
+
+    load_patch(0);
+    store_patch(0, 0, -1);
+    __syncthreads();
+    int cc = 0, tap = 0;
+    for (int s = 0; s < total; ++s) {
+      if (abl & 4) {
+      } else if (s < n1) {
+        if (tap == 0 && cc + 1 < spt) load_patch(cc + 1);                 // next chunk's patch: loads at tap 0 ...
+        if (tap >= 2 && tap < 2 + NPI && cc + 1 < spt) store_patch((cc + 1) & 1, tap, 2);   // ... split + stored at taps 2..7 (other buffer)
+        if (n2 > 0 && cc == spt - 1) {
+          if (tap == 1) load_rows2(0);
+          if (tap == 8) { store_rows2(spt & 1); if (n2 > 1) load_rows2(1); }   // chunk "spt" = first in2 chunk
+        }
+        if (++tap == 9) { tap = 0; ++cc; }
+      } else {
+        const int c2 = s - n1;                                             // consumers are on in2 chunk c2
+        if (c2 + 1 < n2) { store_rows2((spt + c2 + 1) & 1); if (c2 + 2 < n2) load_rows2(c2 + 2); }
+      }
+      __syncthreads();
+    }
+    return;
+  }
+
+  // ==================================================================== consumers (2 x 2 waves, 64 px x 32*TN... each)
+  const int wm = wave >> 1, wn = wave & 1;
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+  int col[TN];
+  float bias1[TN], bias2[TN];
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    col[j] = n0 + (wn * TN + j) * 32 + r;
+    const bool ok = col[j] < d.N;
+    bias1[j] = (ok && d.bias) ? d.bias[col[j]] : 0.f;
+    bias2[j] = (ok && d.bias2) ? d.bias2[col[j]] : 0.f;
+  }
+  int a_patch[TM], a_plain[TM];
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+    const int p = (wm * TM + i) * 32 + r;
+    a_patch[i] = ((p >> 4) * PW + (p & 15)) * ROWB + g * 16;     // tap (0,0) row of output pixel p inside the 10 x 18 patch
+    a_plain[i] = p * ROWB + g * 16;                              // phase 2: plain pixel rows
+  }
+  const int b_frag = (wn * TN) * 1024 + (2 * r + (g ^ ((r >> 3) & 1))) * 16;   // pack_blocked's bank swizzle
+
+  struct Frags { bf16x8 a[TM][3]; bf16x8 b[TN][3]; };
+  Frags F0, F1;
+  auto load_frags = [&, n1, spt, b_frag](Frags& F, const int s) __attribute__((always_inline)) {
+    const unsigned char* Bb = Bring + (s % NRING) * B_STAGE;
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int p = 0; p < 3; ++p) F.b[j][p] = *reinterpret_cast<const bf16x8*>(Bb + p * (BN * 32) + b_frag + j * 1024);
+    int pb, toff;
+    if (s < n1) {
+      const int cc = s / 9, tap = s - cc * 9;
+      const int ky = tap / 3, kx = tap - ky * 3;
+      pb = cc & 1;
+      toff = (ky * PW + kx) * ROWB;
+    } else {
+      pb = (spt + (s - n1)) & 1;
+      toff = 0;
+    }
+    const bool ph2 = s >= n1;
+    const unsigned char* Ps = Pbuf + pb * P_BYTES + toff;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      const int ao = ph2 ? a_plain[i] : a_patch[i];
+#pragma unroll
+      for (int p = 0; p < 3; ++p) F.a[i][p] = *reinterpret_cast<const bf16x8*>(Ps + p * PROWS * ROWB + ao);
+    }
+  };
+  auto mfma_all = [&](const Frags& F) __attribute__((always_inline)) {
+#pragma unroll
+    for (int q = 0; q < 6; ++q) {   // smallest partial products first; consecutive MFMAs hit different accumulators
+      constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(F.a[i][PA[q]], F.b[j][PB[q]], acc[i][j], 0, 0, 0);
+    }
+  };
+
+  __syncthreads();                 // prologue of the producers
+  load_frags(F0, 0);
+  __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0): otherwise hipcc drains the PREFETCH below before the first MFMA of every iteration
+  // phase 1: the fragment reads of step s+1 are in flight while the MFMAs of step s issue (straight-line body, no
+  // conditionals: the compiler's waitcnt placement is exact only then)
+  int s = 0;
+  for (; s + 2 < n1; s += 2) {
+    load_frags(F1, s + 1);
+    mfma_all(F0);
+    __syncthreads();
+    load_frags(F0, s + 2);
+    mfma_all(F1);
+    __syncthreads();
+  }
+  if (s + 1 < n1) {
+    load_frags(F1, s + 1);
+    mfma_all(F0);
+    __syncthreads();
+    mfma_all(F1);
+    __syncthreads();
+  } else {
+    mfma_all(F0);
+    __syncthreads();
+  }
+  if (n2 > 0) {
+    apply_act_all<TM, TN>(acc, bias1, bias2, d.act);
+    for (s = n1; s < total; ++s) {       // short: no prefetch across these steps (the rows are published one barrier before)
+      load_frags(F0, s);
+      mfma_all(F0);
+      __syncthreads();
+    }
+  } else {
+    float zero[TN];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) zero[j] = 0.f;
+    apply_act_all<TM, TN>(acc, bias1, zero, d.act);
+  }
+
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int p = (wm * TM + i) * 32 + (e & 3) + 8 * (e >> 2) + 4 * g;
+      const int y = y0 + (p >> 4), x = x0 + (p & 15);
+      if (y >= d.H || x >= d.W) continue;
+      const int64_t m = ((int64_t)fb * d.H + y) * d.W + x;
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const int n = col[j];
+        if (n >= d.n_store) continue;
+        float v = 0.f;
+        if (n < d.N) {
+          v = acc[i][j][e];
+          if (d.res) v += d.res[m * d.res_ld + n];
+        }
+        d.out[m * d.out_ld + d.out_coff + n] = v;
+      }
+    }
+  }
+}
+
+template <int TN>
+int launch_ppc(const vs_conv_desc_t& d, hipStream_t st) {
+  constexpr int BN = 64 * TN;
+  const int tiles_x = (d.W + TW - 1) / TW, tiles_y = (d.H + TH - 1) / TH;
+  const int64_t mt = (int64_t)d.B * tiles_x * tiles_y, nt = cdiv64(d.n_store, BN);
+  if (mt * nt > 0x7fffffffLL) return VS_ERR_UNSUPPORTED;
+  hipLaunchKernelGGL((conv3x3_patch_pc_kernel<TN>), dim3((unsigned)(mt * nt)), dim3(512), 0, st, d, tiles_x, tiles_y, (int)mt);
+  return vs_launch_status();
+}
+
+}  // namespace
+
+// tile 15 = 128 pixels x 128 channels, tile 9 (alias kept free) -- called from vs_conv_gemm when patch_ok
+int vs_conv3x3_patch_pc_dispatch(const vs_conv_desc_t& d, int tile, hipStream_t st) {
+  switch (tile) {
+    case 15: return launch_ppc<2>(d, st);
+    case 16: return launch_ppc<3>(d, st);
+    default: return VS_ERR_UNSUPPORTED;
+  }
+}

@@ -397,6 +397,7 @@ int dispatch(const vs_conv_desc_t& d, int tile, hipStream_t st) {
 }  // namespace
 int vs_conv_gemm_pc_dispatch(const vs_conv_desc_t& d, int tile, hipStream_t st);   // conv_gemm_pc.hip
 int vs_conv3x3_patch_dispatch(const vs_conv_desc_t& d, int tile, hipStream_t st);  // conv3x3_patch.hip
+int vs_conv3x3_patch_pc_dispatch(const vs_conv_desc_t& d, int tile, hipStream_t st);  // conv3x3_patch_pc.hip
 namespace {
 
 inline bool fits_u32(int64_t bytes) { return bytes >= 0 && bytes < 0xffffffffLL; }
@@ -424,7 +425,7 @@ extern "C" int vs_conv_gemm(const vs_conv_desc_t* dp, void* stream) {
       (d.a_scale && !fits_u32((int64_t)d.B * d.a_scale_ld * 4)))
     return VS_ERR_UNSUPPORTED;   // > 4 GiB operand: the caller chunks the batch
   hipStream_t st = (hipStream_t)stream;
-  int tile = d.tile_hint & 0xf;
+  int tile = (d.tile_hint & 0xf) + ((d.tile_hint & VS_CONV_TILE_HI) ? 16 : 0);
   const bool can_split0 = d.wt_split && (!d.in2 || d.wt2_split) && ((uintptr_t)d.wt_split & 15) == 0;
   // 3x3 / stride 1 / "same" convs on tile-aligned frames go to the patch kernel (input patch staged once per channel chunk)
   const bool patch_ok = can_split0 && d.KH == 3 && d.KW == 3 && d.SH == 1 && d.SW == 1 && d.PH == 1 && d.PW == 1 && d.Ho == d.H &&
@@ -432,6 +433,10 @@ extern "C" int vs_conv_gemm(const vs_conv_desc_t* dp, void* stream) {
   if (tile >= 10 && tile <= 12) {
     VS_REQUIRE(patch_ok);
     return vs_conv3x3_patch_dispatch(d, tile, st);
+  }
+  if (tile == 15 || tile == 16) {   // wave-specialised patch kernel
+    VS_REQUIRE(patch_ok && d.wt_blk && (!d.in2 || d.wt2_blk) && ((uintptr_t)d.wt_blk & 15) == 0);
+    return vs_conv3x3_patch_pc_dispatch(d, tile, st);
   }
   if (tile == 0 && patch_ok && d.W % 16 == 0 && d.H % 8 == 0)
     return vs_conv3x3_patch_dispatch(d, d.N <= 32 ? 10 : (d.N <= 64 ? 11 : 12), st);

@@ -317,23 +317,27 @@ class HipEngine:
         patch = (bool(d.wt_split) and d.KH == 3 and d.KW == 3 and d.SH == 1 and d.SW == 1 and d.PH == 1 and d.PW == 1 and
                  d.Ho == d.H and d.Wo == d.W and not d.a_scale and d.W % 16 == 0 and d.H % 8 == 0)
         if patch:     # the patch kernel walks K as (chunk, tap): candidates stay inside one K order (bit-identical results)
-            cands = [t for t in (10, 11, 12) if {10: 32, 11: 64, 12: 128}[t] < 2 * d.N + 64 or t == 10]
+            # 15 / TILE_HI|0 (=16): wave-specialised variants, 128 and 192 output channels per workgroup
+            widths = {10: 32, 11: 64, 12: 128, 15: 128, N.CONV_TILE_HI: 192}
+            cands = [t for t in widths if widths[t] < 2 * d.N + 64 or t == 10]
         else:
             cands = [t for t in (1, 2, 3, 4, 5, 13, 14) if self._tile_ok(t, d.N)]
         real_out, real_coff, real_ld = d.out, d.out_coff, d.out_ld
         scratch = self.buf("autotune.out", out.rows * rup(d.n_store, 4))
         d.out, d.out_coff, d.out_ld = N.ptr(scratch), 0, rup(d.n_store, 4)
-        times = {}
-        for t in cands:
-            d.tile_hint = t
-            N.check(self.lib.vs_conv_gemm(C.byref(d), N.stream()), "vs_conv_gemm(autotune)")       # warm
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            for _ in range(3):
-                N.check(self.lib.vs_conv_gemm(C.byref(d), N.stream()), "vs_conv_gemm(autotune)")
-            e1.record()
-            e1.synchronize()
-            times[t] = e0.elapsed_time(e1)
+        times = {t: float("inf") for t in cands}
+        for rnd in range(2):          # candidates interleaved, best round of each: the box's clocks wander by ~10 %
+            for t in cands:
+                d.tile_hint = t
+                if rnd == 0:
+                    N.check(self.lib.vs_conv_gemm(C.byref(d), N.stream()), "vs_conv_gemm(autotune)")       # warm
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(3):
+                    N.check(self.lib.vs_conv_gemm(C.byref(d), N.stream()), "vs_conv_gemm(autotune)")
+                e1.record()
+                e1.synchronize()
+                times[t] = min(times[t], e0.elapsed_time(e1))
         best = min(times, key=times.get)
         d.out, d.out_coff, d.out_ld = real_out, real_coff, real_ld
         self._tile_cache[key] = best

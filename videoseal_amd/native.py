@@ -17,7 +17,7 @@ LIB_PATH = os.path.join(_HERE, "csrc", "libvideoseal_hip.so")
 
 ACT_NONE, ACT_RELU, ACT_GELU, ACT_TANH = 0, 1, 2, 3
 PAD_ZERO, PAD_REFLECT = 0, 1
-CONV_FORCE_F32, CONV_FORCE_SPLIT = 0x10, 0x20
+CONV_FORCE_F32, CONV_FORCE_SPLIT, CONV_TILE_HI = 0x10, 0x20, 0x40
 VIDEO_MODES = {"repeat": 0, "alternate": 1, "interpolate": 2}
 
 EXPORTS = [
