@@ -90,13 +90,18 @@ typedef struct vs_conv_desc {
                             /* 10 = 128x32, 11 = 128x64, 12 = 128x128: 3x3 stride-1 'patch' kernel (8x16-pixel tile);  */
                             /* 13 = 64x64, 14 = 64x128 (generic kernel, small-M layers);                              */
                             /* 15 = 128x128, 16 = 128x192: wave-specialised patch kernel (needs wt_blk);               */
+                            /* 17 = 128x128, 18 = 128x192: wave-specialised 1x1 GEMM (dense rows, Cin % 32 == 0, wt_blk);  */
                             /* | VS_CONV_TILE_HI: tile code + 16;                                                     */
                             /* | VS_CONV_FORCE_F32: v_mfma_f32_32x32x2_f32 path; | VS_CONV_FORCE_SPLIT */
   const void* wt_split;     /* optional [3][N][Ktot] bf16: wt split exactly into 3 bf16 terms; when set */
   const void* wt2_split;    /*   (and wt2_split for phase 2) the 6-product bf16-MFMA path is used       */
   const void* wt_blk;       /* optional: the same split weights in LDS-image order [ceil(N/32)][Ktot/16][3][1 KiB]  */
   const void* wt2_blk;      /*   (slot of (row r, k-half h) inside a block = 2r + (h ^ ((r>>3)&1)), rows >= N zero);  */
-                            /*   enables the producer/consumer kernels, tile codes 6..9                              */
+                            /*   enables the producer/consumer kernels, tile codes 6..9, 15..18                        */
+  float* splitk_ws;         /* split_k > 1 (tile codes 17, 18 only): workspace [split_k][M][splitk_ld] floats for the */
+  int64_t splitk_ld;        /*   partial sums of the K slices; splitk_ld >= N.  Summed in slice order (deterministic)  */
+  int32_t split_k;          /*   0 / 1 = no K split                                                                    */
+  int32_t reserved_;
 } vs_conv_desc_t;
 #define VS_CONV_FORCE_F32 0x10
 #define VS_CONV_FORCE_SPLIT 0x20

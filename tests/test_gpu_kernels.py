@@ -181,6 +181,60 @@ def test_conv_grn_transform_and_residual(eng, tile):
     assert rel_err(ra.t.cpu().view(B, HW, Nn), ref) < 2e-5
 
 
+GEMM_PC_CASES = [
+    # B, H, W, K, N, act, grn, res, tile, split_k
+    (2, 16, 16, 96, 384, 2, False, False, 1, 1),      # pwconv1-like: GELU epilogue
+    (2, 16, 16, 384, 96, 0, True, True, 1, 1),        # pwconv2-like: GRN transform on the A load + residual
+    (3, 8, 8, 768, 200, 0, True, True, 2, 1),         # 2 frames per 128-row tile, ragged M (192 rows) and N, 192-wide tile
+    (3, 8, 8, 768, 200, 1, True, True, 1, 4),         # K split in 4 slices + epilogue kernel
+    (1, 8, 8, 3072, 768, 0, True, True, 2, 8),
+    (5, 8, 8, 64, 40, 3, False, False, 1, 2),         # one K pair per slice, tanh
+    (2, 16, 24, 32, 130, 2, False, True, 2, 1),       # single pair, three N tiles of which one ragged
+]
+
+
+@pytest.mark.parametrize("case", GEMM_PC_CASES)
+def test_gemm1x1_pc(eng, case):
+    """wave-specialised 1x1 GEMM (tile codes 17 / 18) vs torch and vs the generic kernel (bit-identical when K is not split)."""
+    if not eng.use_split:
+        pytest.skip("split back-end only")
+    B, H, W, K, Nn, act, grn, use_res, tl, sk = case
+    g = torch.Generator().manual_seed(hash(case) % 1000)
+    h = torch.randn(B, H * W, K, generator=g)
+    sc = 1 + 0.3 * torch.randn(B, K, generator=g)
+    sh = 0.1 * torch.randn(K, generator=g)
+    w = torch.randn(Nn, K, generator=g) / math.sqrt(K)
+    bias = torch.randn(Nn, generator=g)
+    res = torch.randn(B, H * W, Nn, generator=g)
+    a = h * sc[:, None, :] + sh if grn else h
+    ref = F.linear(a, w, bias)
+    ref = {0: ref, 1: F.relu(ref), 2: F.gelu(ref), 3: torch.tanh(ref)}[act]
+    if use_res:
+        ref = ref + res
+    ha = Act(h.to(DEV).contiguous(), B, H, W, K, K)
+    wt, cp = pack_conv(w[:, :, None, None].to(DEV), K)
+    cw = ConvW(wt, bias.to(DEV), Nn, 1, 1, cp)
+    ld = (Nn + 3) // 4 * 4
+    kw = dict(act=act)
+    if grn:
+        kw.update(a_scale=sc.to(DEV).contiguous(), a_scale_ld=K, a_shift=sh.to(DEV).contiguous())
+    outs = []
+    for hint, k in ((N.CONV_TILE_HI | tl, sk), (1, 1)):
+        ra = Act(torch.full((B * H * W * ld,), float("nan"), device=DEV), B, H, W, Nn, ld)
+        rr = None
+        if use_res:
+            rr = Act(torch.zeros(B * H * W * ld, device=DEV), B, H, W, Nn, ld)
+            rr.t.view(B, H * W, ld)[..., :Nn] = res.to(DEV)
+        eng.conv(ha, cw, ra, res=rr, tile_hint=hint, split_k=k, **kw)
+        torch.cuda.synchronize()
+        full = ra.t.view(B, H * W, ld).cpu()
+        assert rel_err(full[..., :Nn], ref) < 2e-5
+        assert (full[..., Nn:] == 0).all()
+        outs.append(full)
+    if sk == 1:
+        assert torch.equal(outs[0], outs[1])      # same arithmetic, same K order as the generic kernel
+
+
 @pytest.mark.parametrize("stride", [4, 2])
 def test_patch_conv_stem(eng, stride):
     """4x4 stem (stride 4, and ChunkySeal's stride 2) as a 4x1 conv over 16-float pixel runs."""

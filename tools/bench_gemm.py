@@ -1,0 +1,47 @@
+#!/usr/bin/env python
+"""1x1 GEMMs of the ConvNeXt extractor (B=32 frames at 256x256): generic kernel tiles vs the wave-specialised GEMM (17/18), with K split."""
+import math, sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from videoseal_amd import native as N
+from videoseal_amd.engine import Act, ConvW, pack_conv
+from tools.bench_conv import Eng
+
+HI = N.CONV_TILE_HI
+
+def run(name, B, HW, K, Nn, variants, grn=False, reps=30):
+    eng = Eng()
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(B * HW * HW, K, generator=g).cuda()
+    w = (torch.randn(Nn, K, 1, 1, generator=g) / math.sqrt(K)).cuda()
+    xa = Act(x, B, HW, HW, K, K)
+    wt, cp = pack_conv(w, K)
+    cw = ConvW(wt, torch.zeros(Nn).cuda(), Nn, 1, 1, cp)
+    out = eng.new_act("o", B, HW, HW, Nn)
+    kw = {}
+    if grn:
+        kw = dict(a_scale=(1 + 0.1 * torch.randn(B, K, generator=g)).cuda(), a_scale_ld=K, a_shift=torch.zeros(K).cuda(), res=out)
+    flops = 2.0 * B * HW * HW * K * Nn
+    best = {v: 1e9 for v in variants}
+    for rnd in range(4):
+        for v in variants:
+            t, sk = v
+            for _ in range(2): eng.conv(xa, cw, out, tile_hint=t, split_k=sk, act=N.ACT_GELU if not grn else 0, **kw)
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(reps): eng.conv(xa, cw, out, tile_hint=t, split_k=sk, act=N.ACT_GELU if not grn else 0, **kw)
+            e1.record(); torch.cuda.synchronize()
+            best[v] = min(best[v], e0.elapsed_time(e1) / reps)
+    print(name + ": " + "  ".join(f"[t{(t & 15) + (16 if t & HI else 0)} sk{sk}] {ms*1e3:6.1f}us {flops/ms/1e9:5.0f}TF" for (t, sk), ms in best.items()), flush=True)
+
+if __name__ == "__main__":
+    G = [(1, 1), (2, 1), (5, 1), (4, 1), (13, 1), (14, 1)]
+    run("s0 pw1  96->384  M=131072", 32, 64, 96, 384, G + [(HI | 1, 1), (HI | 2, 1)])
+    run("s0 pw2 384->96   M=131072", 32, 64, 384, 96, G + [(HI | 1, 1)], grn=True)
+    run("s1 pw1 192->768  M=32768 ", 32, 32, 192, 768, G + [(HI | 1, 1), (HI | 2, 1)])
+    run("s1 pw2 768->192  M=32768 ", 32, 32, 768, 192, G + [(HI | 1, 1), (HI | 2, 1), (HI | 2, 2)], grn=True)
+    run("s2 pw1 384->1536 M=8192  ", 32, 16, 384, 1536, G + [(HI | 1, 1), (HI | 2, 1)])
+    run("s2 pw2 1536->384 M=8192  ", 32, 16, 1536, 384, G + [(HI | 1, 1), (HI | 2, 1), (HI | 1, 2), (HI | 2, 2), (HI | 2, 4)], grn=True)
+    run("s3 pw1 768->3072 M=2048  ", 32, 8, 768, 3072, G + [(HI | 1, 1), (HI | 2, 1), (HI | 2, 2)])
+    run("s3 pw2 3072->768 M=2048  ", 32, 8, 3072, 768, G + [(HI | 1, 1), (HI | 2, 1), (HI | 1, 4), (HI | 2, 4), (HI | 2, 8), (HI | 1, 8)], grn=True)

@@ -66,7 +66,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_patch_pc_kernel(const vs_conv_
     // ================================================================== weight producers (waves 6-7): LDS-DMA only
     // Tile t (= the [BN x 16] slice of the split weights that step t multiplies) goes to ring stage t % NRING.  It is
     // issued NRING-1 steps before its step and must have landed one barrier before the consumers prefetch it, i.e. at
-    // the end of step s everything up to tile s+2 is complete: at most the three youngest tiles stay in flight.
+    // the end of step s everything up to tile s+2 is complete: at most the NRING-3 youngest tiles stay in flight.
     // These waves issue no ordinary loads, so the counted s_waitcnt below is exact (hipcc would drain to vmcnt(0)).
     const int bw = wave - 6;
     // weights in LDS-image order (engine.pack_blocked): [N/32 groups][step t = chunk*9 + tap][3 planes][1 KiB], so every DMA
@@ -104,7 +104,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_patch_pc_kernel(const vs_conv_
     for (int s = 0; s < total; ++s) {
       if (s + NRING - 1 < total) {
         if (!(abl & 1)) dma_tile(s + NRING - 1);                         // stage of tile s-1: its fragments were consumed before the last barrier
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * ND) : "memory");
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NRING - 3) * ND) : "memory");   // tiles <= s+2 have landed
       } else {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       }

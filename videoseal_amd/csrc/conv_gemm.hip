@@ -398,6 +398,7 @@ int dispatch(const vs_conv_desc_t& d, int tile, hipStream_t st) {
 int vs_conv_gemm_pc_dispatch(const vs_conv_desc_t& d, int tile, hipStream_t st);   // conv_gemm_pc.hip
 int vs_conv3x3_patch_dispatch(const vs_conv_desc_t& d, int tile, hipStream_t st);  // conv3x3_patch.hip
 int vs_conv3x3_patch_pc_dispatch(const vs_conv_desc_t& d, int tile, hipStream_t st);  // conv3x3_patch_pc.hip
+int vs_gemm1x1_pc_dispatch(const vs_conv_desc_t& d, int tile, hipStream_t st);         // gemm1x1_pc.hip
 namespace {
 
 inline bool fits_u32(int64_t bytes) { return bytes >= 0 && bytes < 0xffffffffLL; }
@@ -438,6 +439,15 @@ extern "C" int vs_conv_gemm(const vs_conv_desc_t* dp, void* stream) {
     VS_REQUIRE(patch_ok && d.wt_blk && (!d.in2 || d.wt2_blk) && ((uintptr_t)d.wt_blk & 15) == 0);
     return vs_conv3x3_patch_pc_dispatch(d, tile, st);
   }
+  if (tile == 17 || tile == 18) {   // wave-specialised 1x1 GEMM: dense rows, whole 32-wide K pairs, no second phase
+    VS_REQUIRE(can_split0 && d.wt_blk && ((uintptr_t)d.wt_blk & 15) == 0 && !(d.tile_hint & VS_CONV_FORCE_F32));
+    VS_REQUIRE(d.KH == 1 && d.KW == 1 && d.SH == 1 && d.SW == 1 && d.PH == 0 && d.PW == 0 && d.Ho == d.H && d.Wo == d.W && !d.in2);
+    VS_REQUIRE(d.Cin % 32 == 0 && d.CinP == d.Cin && d.in_sy == (int64_t)d.W * d.in_sx && d.in_sb == (int64_t)d.H * d.in_sy);
+    if (d.a_scale) VS_REQUIRE((d.H * d.W) % 64 == 0);
+    if (d.split_k > 1) VS_REQUIRE(d.splitk_ws && d.splitk_ld >= d.N && d.split_k <= d.CinP / 32);
+    return vs_gemm1x1_pc_dispatch(d, tile, st);
+  }
+  VS_REQUIRE(d.split_k <= 1);
   if (tile == 0 && patch_ok && d.W % 16 == 0 && d.H % 8 == 0)
     return vs_conv3x3_patch_dispatch(d, d.N <= 32 ? 10 : (d.N <= 64 ? 11 : 12), st);
   if (tile == 0) tile = d.N <= 32 ? 3 : (d.N <= 64 ? 2 : (d.N <= 96 ? 5 : ((d.N % 192 == 0 || (d.N > 128 && d.N <= 192)) ? 4 : 1)));

@@ -1,0 +1,342 @@
+// Wave-specialised GEMM for the 1x1 convolutions (ConvNeXt pwconv1 / pwconv2 of the extractor, convnext.py:96-105 of the
+// reference): out[M][N] = act(A'[M][K] * W[N][K]^T + bias) (+ res),  A' = A or A * grn_scale[frame] + grn_shift.
+// fp32 operands, exact 3 x bf16 split, 6 v_mfma_f32_32x32x16_bf16 per 32x32x16 block, fp32 accumulate -- the same
+// arithmetic and the same K order as conv_gemm_kernel<.., SPLIT = true>, so results are bit-identical to it (split_k = 1).
+//
+// 512 threads, one workgroup per CU, one s_barrier per 16-wide K step:
+//   waves 0-3  consumers   : 2 x 2 waves, 64 rows x 32*TN columns each; fragment reads (ds_read_b128) of step s+1 are in
+//                            flight while the 24 / 36 MFMAs of step s issue.
+//   waves 4-5  A producers : read 128-byte row segments (32 fp32 = two K steps, whole cache lines), apply the GRN
+//                            transform, split into three bf16 planes, ds_write them two steps ahead of use.  Register
+//                            sets rotate three deep (loads ~4 steps ahead); the loop body is straight-line so that
+//                            hipcc's s_waitcnt vmcnt(N) placement is exact.
+//   waves 6-7  B producers : LDS-DMA (global_load_lds_dwordx4) of the pre-split, pre-swizzled weight blocks
+//                            (engine.pack_blocked) into a ring of 6 (TN=2) / 5 (TN=3) tiles, counted s_waitcnt.
+// split_k > 1 (small-M layers: 2048 / 8192 rows cannot fill 256 CUs with 128-row tiles): every K slice writes its raw
+// partial sums to the workspace, vs_conv_gemm then runs splitk_epilogue_kernel (fixed summation order -> deterministic).
+#include "conv_common.h"
+
+namespace {
+
+using namespace vsconv;
+
+constexpr int BM = 128;
+constexpr int A_STAGE = 3 * BM * ROWB;     // three bf16 planes of [128 rows][16 k], 48-byte rows (conflict-free b128 reads)
+
+__device__ __forceinline__ void dma_1k(const char* gp, unsigned char* lds_base) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gp,
+                                   (__attribute__((address_space(3))) void*)lds_base, 16, 0, 0);
+}
+
+template <int TN>
+__global__ __launch_bounds__(512, 2) void gemm1x1_pc_kernel(const vs_conv_desc_t d, const int M, const int mtiles, const int ntiles,
+                                                            const int pairs_per_split) {
+  constexpr int TM = 2;
+  constexpr int BN = 64 * TN;
+  constexpr int NG = BN / 32;
+  constexpr int NRING = TN >= 3 ? 5 : 6;
+  constexpr int B_STAGE = 3 * BN * 32;
+  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * A_STAGE + NRING * B_STAGE];
+  unsigned char* const Aring = smem;
+  unsigned char* const Bring = smem + 2 * A_STAGE;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r = lane & 31, g = lane >> 5;
+
+  const int bm = blockIdx.x % mtiles;
+  const int bn = (blockIdx.x / mtiles) % ntiles;
+  const int ks = blockIdx.x / (mtiles * ntiles);
+  const int m0 = bm * BM;
+  const int n0 = bn * BN;
+  const int pairs_total = d.CinP / 32;
+  const int pair0 = ks * pairs_per_split;
+  const int npairs = min(pairs_per_split, pairs_total - pair0);
+  const int total = 2 * npairs;                 // 16-wide K steps of this workgroup, step s <-> K chunk 2*pair0 + s
+
+  if (wave >= 6) {
+    // ================================================================== weight producers: LDS-DMA only (see conv3x3_patch_pc.hip)
+    const int bw = wave - 6;
+    const char* const wblk = reinterpret_cast<const char*>(d.wt_blk);
+    const int g0 = n0 / 32;
+    const int ngroups = (d.N + 31) / 32;
+    const int nch = d.CinP / 16;
+    constexpr int NGW = NG / 2;
+    int64_t goff[NGW];
+#pragma unroll
+    for (int q = 0; q < NGW; ++q) {
+      const int gi = g0 + bw * NGW + q;
+      goff[q] = (int64_t)(gi < ngroups ? gi : ngroups - 1) * nch * 3072 + (int64_t)(2 * pair0) * 3072 + lane * 16;
+    }
+    auto dma_tile = [&, bw](const int t) __attribute__((always_inline)) {
+      unsigned char* st = Bring + (t % NRING) * B_STAGE;
+#pragma unroll
+      for (int q = 0; q < NGW; ++q) {
+        const char* gp = wblk + goff[q] + (int64_t)t * 3072;
+#pragma unroll
+        for (int p = 0; p < 3; ++p) dma_1k(gp + p * 1024, st + p * (BN * 32) + (bw * NGW + q) * 1024);
+      }
+    };
+    constexpr int ND = 3 * NGW;
+#pragma unroll
+    for (int t = 0; t < NRING - 1; ++t)
+      if (t < total) dma_tile(t);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    for (int s = 0; s < total; ++s) {
+      if (s + NRING - 1 < total) {
+        dma_tile(s + NRING - 1);
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NRING - 3) * ND) : "memory");   // tiles <= s+2 have landed
+      } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+      __builtin_amdgcn_s_barrier();
+    }
+    return;
+  }
+
+  if (wave >= 4) {
+    // ================================================================== activation producers
+    // item (row, seg): 16 bytes = 4 fp32 of row `row`, K offset seg*4 inside the 32-wide pair; 8 consecutive lanes read one
+    // 128-byte line.  seg 0-3 belong to the even step of the pair, seg 4-7 to the odd step.
+    const int pt = tid & 127;
+    constexpr int NI = BM * 8 / 128;       // 8 items per thread per pair
+    const int seg = pt & 7;
+    const int HW = d.H * d.W;
+    unsigned a_off[NI];
+    int l_off[NI];
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      const int row = (pt >> 3) + i * 16;
+      int m = m0 + row;
+      m = m < M ? m : M - 1;                                            // ragged last tile: re-read a valid row (discarded)
+      a_off[i] = (unsigned)(((int64_t)m * d.in_sx + seg * 4) * 4);
+      l_off[i] = ((seg >> 2) * A_STAGE) + row * ROWB + (seg & 3) * 8;   // stage parity of the step + position inside it
+    }
+    // GRN scale is per (frame, channel): H*W % 64 == 0 (checked by the dispatcher), so rows 0-63 of the tile lie in one
+    // frame and rows 64-127 in one frame -> two scale vectors + one shift vector per thread and pair, loaded with the data
+    const int f_lo = min(m0 / HW, d.B - 1), f_hi = min((m0 + 64) / HW, d.B - 1);
+    const char* const abase = reinterpret_cast<const char*>(d.in) + (int64_t)pair0 * 128;
+    const bool grn = d.a_scale != nullptr;
+    const char* const sbase0 = reinterpret_cast<const char*>(d.a_scale) + ((int64_t)f_lo * d.a_scale_ld + pair0 * 32 + seg * 4) * 4;
+    const char* const sbase1 = reinterpret_cast<const char*>(d.a_scale) + ((int64_t)f_hi * d.a_scale_ld + pair0 * 32 + seg * 4) * 4;
+    const char* const hbase = reinterpret_cast<const char*>(d.a_shift) + ((int64_t)pair0 * 32 + seg * 4) * 4;
+    const int lastp = npairs - 1;
+
+    struct ASet { f32x4 r[NI]; f32x4 s0, s1, h; };
+    ASet rs0, rs1, rs2;      // three rotating register sets
+    auto load_pair = [&](ASet& R, int j) __attribute__((always_inline)) {
+      j = j < lastp ? j : lastp;                                        // past the end: harmless re-read, keeps the body branch-free
+      const char* base = abase + (int64_t)j * 128;
+#pragma unroll
+      for (int i = 0; i < NI; ++i) R.r[i] = *reinterpret_cast<const f32x4*>(base + a_off[i]);
+      if (grn) {
+        R.s0 = *reinterpret_cast<const f32x4*>(sbase0 + (int64_t)j * 128);
+        R.s1 = *reinterpret_cast<const f32x4*>(sbase1 + (int64_t)j * 128);
+        R.h = *reinterpret_cast<const f32x4*>(hbase + (int64_t)j * 128);
+      }
+    };
+    // half h of the pair in R -> stage (step parity h): seg>>2 == h for this thread's items or not at all, so each thread
+    // stores ALL its items at one of the two steps; threads with seg 0-3 store at the even step, seg 4-7 at the odd one.
+    auto store_half = [&](const ASet& R, const int h) __attribute__((always_inline)) {
+      if ((seg >> 2) == h) {
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+          f32x4 v = R.r[i];
+          if (grn) v = v * (i < NI / 2 ? R.s0 : R.s1) + R.h;            // GRN apply (same expression as conv_gemm_kernel)
+          u32x2 p1, p2, p3;
+          split4(v, p1, p2, p3);
+          unsigned char* dst = Aring + l_off[i];
+          *reinterpret_cast<u32x2*>(dst) = p1;
+          *reinterpret_cast<u32x2*>(dst + BM * ROWB) = p2;
+          *reinterpret_cast<u32x2*>(dst + 2 * BM * ROWB) = p3;
+        }
+      }
+    };
+    // A(t) (step t) is written during step t-2 and read (prefetched) during step t-1: two stages, stage = t & 1.
+    // prologue: pair 0 -> both stages; pairs 1, 2, 3 -> registers.
+    load_pair(rs0, 0);
+    load_pair(rs1, 1);
+    load_pair(rs2, 2);
+    store_half(rs0, 0);
+    store_half(rs0, 1);
+    load_pair(rs0, 3);
+    __syncthreads();
+    // steps 2j, 2j+1 (consumers on pair j): store pair j+1 (set (j+1)%3), then reload that set with pair j+4
+    for (int j = 0; j < npairs; j += 3) {
+      store_half(rs1, 0);
+      __syncthreads();
+      store_half(rs1, 1);
+      load_pair(rs1, j + 4);
+      __syncthreads();
+      if (j + 1 >= npairs) break;
+      store_half(rs2, 0);
+      __syncthreads();
+      store_half(rs2, 1);
+      load_pair(rs2, j + 5);
+      __syncthreads();
+      if (j + 2 >= npairs) break;
+      store_half(rs0, 0);
+      __syncthreads();
+      store_half(rs0, 1);
+      load_pair(rs0, j + 6);
+      __syncthreads();
+    }
+    return;
+  }
+
+  // ==================================================================== consumers
+  const int wm = wave >> 1, wn = wave & 1;
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+  const int a_frag = (wm * TM * 32 + r) * ROWB + g * 16;
+  const int b_frag = (wn * TN) * 1024 + (2 * r + (g ^ ((r >> 3) & 1))) * 16;   // pack_blocked's bank swizzle
+
+  struct Frags { bf16x8 a[TM][3]; bf16x8 b[TN][3]; };
+  Frags F0, F1;
+  auto load_frags = [&, a_frag, b_frag](Frags& F, const int s) __attribute__((always_inline)) {
+    const unsigned char* Bb = Bring + (s % NRING) * B_STAGE;
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int p = 0; p < 3; ++p) F.b[j][p] = *reinterpret_cast<const bf16x8*>(Bb + p * (BN * 32) + b_frag + j * 1024);
+    const unsigned char* Ab = Aring + (s & 1) * A_STAGE;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int p = 0; p < 3; ++p) F.a[i][p] = *reinterpret_cast<const bf16x8*>(Ab + p * BM * ROWB + a_frag + i * 32 * ROWB);
+  };
+  auto mfma_all = [&](const Frags& F) __attribute__((always_inline)) {
+#pragma unroll
+    for (int q = 0; q < 6; ++q) {   // smallest partial products first; consecutive MFMAs hit different accumulators
+      constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(F.a[i][PA[q]], F.b[j][PB[q]], acc[i][j], 0, 0, 0);
+    }
+  };
+
+  __syncthreads();
+  load_frags(F0, 0);
+  __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0), see conv3x3_patch_pc.hip
+  int s = 0;
+  for (; s + 2 < total; s += 2) {
+    load_frags(F1, s + 1);
+    mfma_all(F0);
+    __syncthreads();
+    load_frags(F0, s + 2);
+    mfma_all(F1);
+    __syncthreads();
+  }
+  load_frags(F1, s + 1);              // total is even: two steps left
+  mfma_all(F0);
+  __syncthreads();
+  mfma_all(F1);
+  __syncthreads();
+
+  // ---- epilogue.  C/D layout of the 32x32 MFMA: col = lane&31, row = (e&3) + 8*(e>>2) + 4*(lane>>5)
+  int col[TN];
+#pragma unroll
+  for (int j = 0; j < TN; ++j) col[j] = n0 + (wn * TN + j) * 32 + r;
+  if (d.split_k > 1) {                // raw partial sums -> workspace [ks][M][ws_ld]
+    float* ws = d.splitk_ws + (int64_t)ks * M * d.splitk_ld;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int m = m0 + (wm * TM + i) * 32 + (e & 3) + 8 * (e >> 2) + 4 * g;
+        if (m >= M) continue;
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          if (col[j] < d.N) ws[(int64_t)m * d.splitk_ld + col[j]] = acc[i][j][e];
+      }
+    return;
+  }
+  float bias1[TN], zero[TN];
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    bias1[j] = (col[j] < d.N && d.bias) ? d.bias[col[j]] : 0.f;
+    zero[j] = 0.f;
+  }
+  apply_act_all<TM, TN>(acc, bias1, zero, d.act);
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int64_t m = m0 + (wm * TM + i) * 32 + (e & 3) + 8 * (e >> 2) + 4 * g;
+      if (m >= M) continue;
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const int n = col[j];
+        if (n >= d.n_store) continue;
+        float v = 0.f;
+        if (n < d.N) {
+          v = acc[i][j][e];
+          if (d.res) v += d.res[m * d.res_ld + n];
+        }
+        d.out[m * d.out_ld + d.out_coff + n] = v;
+      }
+    }
+  }
+}
+
+// out = act(sum_ks ws[ks] + bias) (+ res); columns in [N, n_store) are written as zero.  One thread per (row, 4 columns).
+__global__ __launch_bounds__(256) void splitk_epilogue_kernel(const vs_conv_desc_t d, const int M) {
+  const int ncol4 = (d.n_store + 3) / 4;
+  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= (int64_t)M * ncol4) return;
+  const int64_t m = idx / ncol4;
+  const int n4 = (int)(idx % ncol4) * 4;
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    const int n = n4 + c;
+    if (n >= d.n_store) break;
+    float v = 0.f;
+    if (n < d.N) {
+      for (int k = 0; k < d.split_k; ++k) v += d.splitk_ws[((int64_t)k * M + m) * d.splitk_ld + n];
+      v += d.bias ? d.bias[n] : 0.f;
+      if (d.act == VS_ACT_RELU) v = fmaxf(v, 0.f);
+      else if (d.act == VS_ACT_GELU) v = 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
+      else if (d.act == VS_ACT_TANH) v = tanhf(v);
+      if (d.res) v += d.res[m * d.res_ld + n];
+    }
+    d.out[m * d.out_ld + d.out_coff + n] = v;
+  }
+}
+
+template <int TN>
+int launch_g(const vs_conv_desc_t& d, hipStream_t st) {
+  constexpr int BN = 64 * TN;
+  const int64_t M = (int64_t)d.B * d.H * d.W;
+  const int64_t mt = cdiv64(M, BM), nt = cdiv64(d.split_k > 1 ? d.N : d.n_store, BN);
+  const int pairs = d.CinP / 32;
+  const int sk = d.split_k > 1 ? d.split_k : 1;
+  const int pps = (pairs + sk - 1) / sk;
+  if ((int64_t)(sk - 1) * pps >= pairs) return VS_ERR_BAD_ARG;           // an empty K slice
+  if (mt * nt * sk > 0x7fffffffLL || M > 0x7fffffffLL) return VS_ERR_UNSUPPORTED;
+  hipLaunchKernelGGL((gemm1x1_pc_kernel<TN>), dim3((unsigned)(mt * nt * sk)), dim3(512), 0, st, d, (int)M, (int)mt, (int)nt, pps);
+  int rc = vs_launch_status();
+  if (rc != VS_OK || sk == 1) return rc;
+  const int64_t items = M * ((d.n_store + 3) / 4);
+  hipLaunchKernelGGL(splitk_epilogue_kernel, dim3((unsigned)cdiv64(items, 256)), dim3(256), 0, st, d, (int)M);
+  return vs_launch_status();
+}
+
+}  // namespace
+
+// tile 17 = 128 x 128, tile 18 = 128 x 192.  Preconditions are checked by vs_conv_gemm.
+int vs_gemm1x1_pc_dispatch(const vs_conv_desc_t& d, int tile, hipStream_t st) {
+  switch (tile) {
+    case 17: return launch_g<2>(d, st);
+    case 18: return launch_g<3>(d, st);
+    default: return VS_ERR_UNSUPPORTED;
+  }
+}

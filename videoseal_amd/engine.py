@@ -147,6 +147,12 @@ class HipEngine:
         # tile wins -- only speed changes (measure, don't guess).  VIDEOSEAL_AUTOTUNE=0 keeps the static heuristic.
         self.autotune = os.environ.get("VIDEOSEAL_AUTOTUNE", "1") != "0"
         self._tile_cache: Dict[tuple, int] = {}
+        # optional on-disk copy of the tile choices (VIDEOSEAL_TILE_CACHE=path.json): a profiled run then has no tuning launches
+        self._tile_cache_path = os.environ.get("VIDEOSEAL_TILE_CACHE")
+        if self._tile_cache_path and os.path.exists(self._tile_cache_path):
+            import json
+            with open(self._tile_cache_path) as f:
+                self._tile_cache = {tuple(json.loads(k)): v for k, v in json.load(f).items()}
         g = lambda k: sd[k].detach().to(device)   # noqa: E731
         self._g = g
         self.E = None          # packed embedder / extractor weights, built on first use (ChunkySeal: 1.0 G + 0.77 G parameters)
@@ -259,7 +265,8 @@ class HipEngine:
     # ------------------------------------------------------------------ kernel wrappers
     def conv(self, x: Act, w: ConvW, out: Act, *, stride=1, pad=0, pad_mode=N.PAD_ZERO, act=N.ACT_NONE, out_coff=0,
              n_store=None, res: Optional[Act] = None, in2: Optional[Act] = None, w2: Optional[ConvW] = None,
-             a_scale=None, a_scale_ld=0, a_shift=None, geom=None, tile_hint=0, prof: Optional[str] = None):
+             a_scale=None, a_scale_ld=0, a_shift=None, geom=None, tile_hint=0, prof: Optional[str] = None,
+             split_k: Optional[int] = None):
         d = N.ConvDesc()
         if geom is None:
             sh = sw = stride
@@ -290,6 +297,13 @@ class HipEngine:
             if in2 is not None:
                 d.wt2_split = N.ptr(w2.with_split().split)
                 d.wt2_blk = N.ptr(w2.with_blk().blk)
+        if split_k is None:     # static, shape-only rule (never timing-based: a K split changes the summation order)
+            split_k = self._split_k_rule(d) if (tile_hint == 0 and self._gemm_pc_ok(d)) else 1
+        if split_k > 1:
+            ws_ld = rup(w.N, 4)
+            d.splitk_ws, d.splitk_ld, d.split_k = N.ptr(self.buf("splitk.ws", split_k * out.rows * ws_ld)), ws_ld, split_k
+            if tile_hint == 0 and not self.autotune:
+                d.tile_hint = N.CONV_TILE_HI | (2 if w.N % 192 == 0 else 1)
         if tile_hint == 0 and self.autotune:
             d.tile_hint = self._pick_tile(d, w, out)
         if self.kernel_timers is not None and prof is None and self.time_all_convs:
@@ -305,23 +319,46 @@ class HipEngine:
             self.kernel_timers.append((prof, ev0, ev1, 2.0 * out.rows * w.N * k_total))
         return out
 
+    @staticmethod
+    def _gemm_pc_ok(d: "N.ConvDesc") -> bool:
+        """preconditions of the wave-specialised 1x1 GEMM (tile codes 17 / 18), mirrored from vs_conv_gemm"""
+        return (bool(d.wt_split) and bool(d.wt_blk) and d.KH == 1 and d.KW == 1 and d.SH == 1 and d.SW == 1 and d.PH == 0 and d.PW == 0
+                and not d.in2 and d.Ho == d.H and d.Wo == d.W and d.Cin % 32 == 0 and d.CinP == d.Cin
+                and d.in_sy == d.W * d.in_sx and d.in_sb == d.H * d.in_sy and (not d.a_scale or (d.H * d.W) % 64 == 0))
+
+    @staticmethod
+    def _split_k_rule(d: "N.ConvDesc") -> int:
+        """K slices for small-M GEMMs: double while 128 x 128 tiles cannot give every CU a workgroup and a slice keeps >= 4 K pairs"""
+        rows = d.B * d.H * d.W
+        blocks = ((rows + 127) // 128) * ((d.N + 127) // 128)
+        pairs = d.CinP // 32
+        sk = 1
+        while blocks * sk < 256 and pairs % (sk * 2) == 0 and pairs // (sk * 2) >= 4:
+            sk *= 2
+        return sk
+
     def _pick_tile(self, d: "N.ConvDesc", w: ConvW, out: Act) -> int:
         """time the 4-wave tile shapes once per conv signature (on a scratch output) and remember the fastest."""
         key = (d.B, d.H, d.W, d.Cin, d.KH, d.KW, d.SH, d.SW, d.pad_mode, d.Ho, d.Wo, d.N, d.CinP, bool(d.in2), d.Cin2P,
-               bool(d.a_scale), bool(d.res), d.act, bool(d.wt_split))
+               bool(d.a_scale), bool(d.res), d.act, bool(d.wt_split), d.split_k)
         best = self._tile_cache.get(key)
         if best is not None:
             return best
         if torch.cuda.is_current_stream_capturing():
-            return 0          # never time inside a hipGraph capture: static heuristic (same numerics)
+            # never time inside a hipGraph capture: static heuristic (same numerics)
+            return (N.CONV_TILE_HI | (2 if d.N % 192 == 0 else 1)) if d.split_k > 1 else 0
         patch = (bool(d.wt_split) and d.KH == 3 and d.KW == 3 and d.SH == 1 and d.SW == 1 and d.PH == 1 and d.PW == 1 and
                  d.Ho == d.H and d.Wo == d.W and not d.a_scale and d.W % 16 == 0 and d.H % 8 == 0)
         if patch:     # the patch kernel walks K as (chunk, tap): candidates stay inside one K order (bit-identical results)
             # 15 / TILE_HI|0 (=16): wave-specialised variants, 128 and 192 output channels per workgroup
             widths = {10: 32, 11: 64, 12: 128, 15: 128, N.CONV_TILE_HI: 192}
             cands = [t for t in widths if widths[t] < 2 * d.N + 64 or t == 10]
+        elif d.split_k > 1:      # K-split plan fixed by the shape rule: only the kernels that implement it
+            cands = [N.CONV_TILE_HI | 1] + ([N.CONV_TILE_HI | 2] if d.N > 128 else [])
         else:
             cands = [t for t in (1, 2, 3, 4, 5, 13, 14) if self._tile_ok(t, d.N)]
+            if self._gemm_pc_ok(d) and d.N >= 96:    # same K order as the generic kernel: bit-identical candidates
+                cands += [N.CONV_TILE_HI | 1] + ([N.CONV_TILE_HI | 2] if d.N > 128 else [])
         real_out, real_coff, real_ld = d.out, d.out_coff, d.out_ld
         scratch = self.buf("autotune.out", out.rows * rup(d.n_store, 4))
         d.out, d.out_coff, d.out_ld = N.ptr(scratch), 0, rup(d.n_store, 4)
@@ -341,6 +378,10 @@ class HipEngine:
         best = min(times, key=times.get)
         d.out, d.out_coff, d.out_ld = real_out, real_coff, real_ld
         self._tile_cache[key] = best
+        if self._tile_cache_path:
+            import json
+            with open(self._tile_cache_path, "w") as f:
+                json.dump({json.dumps(list(k)): v for k, v in self._tile_cache.items()}, f)
         return best
 
     @staticmethod

@@ -47,6 +47,7 @@ class ConvDesc(C.Structure):
         ("wt2", C.c_void_p), ("bias2", C.c_void_p),
         ("out", C.c_void_p), ("out_ld", C.c_int64), ("out_coff", C.c_int32), ("tile_hint", C.c_int32),
         ("wt_split", C.c_void_p), ("wt2_split", C.c_void_p), ("wt_blk", C.c_void_p), ("wt2_blk", C.c_void_p),
+        ("splitk_ws", C.c_void_p), ("splitk_ld", C.c_int64), ("split_k", C.c_int32), ("reserved_", C.c_int32),
     ]
 
 
