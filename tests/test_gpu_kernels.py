@@ -103,6 +103,8 @@ CONV_CASES = [
     (2, 384, 16, 16, 384, 3, 1, 1, 0, 1, 0x40),     # 0x40 = tile 16: 128 x 192
     (3, 48, 13, 21, 200, 3, 1, 1, 1, 2, 0x40),
     (1, 16, 8, 16, 16, 3, 1, 1, 0, 3, 0x40),
+    (2, 768, 16, 16, 64, 3, 1, 1, 0, 1, 0x43),      # 0x43 = tile 19: 128 x 64
+    (3, 48, 13, 21, 70, 3, 1, 1, 1, 2, 0x43),
     (3, 160, 7, 9, 130, 3, 2, 1, 0, 1, 14),
 ]
 
@@ -131,7 +133,7 @@ def test_conv_gemm_matches_conv2d(eng, case):
     assert torch.isfinite(full).all() and (full[..., Cout:] == 0).all()   # pad lanes written as zero
 
 
-@pytest.mark.parametrize("tile", [0, 7, 8, 10, 11, 1, 15, 0x40])
+@pytest.mark.parametrize("tile", [0, 7, 8, 10, 11, 1, 15, 0x40, 0x43])
 def test_conv_two_phase_residual_block(eng, tile):
     """ResnetBlock tail: relu(conv3x3(t)+b) + (conv1x1(x)+b2), written at a channel offset of a wider buffer."""
     if tile >= 6 and not eng.use_split:

@@ -1,0 +1,18 @@
+#!/bin/bash
+# Round profile: bench lines, rocprofv3 kernel stats (image + video), three --pmc passes.  usage: tools/profile_round.sh <tag>   (GPU box)
+TAG=${1:-r01x}
+R=$PWD
+export TMPDIR=/tmp VIDEOSEAL_TILE_CACHE=/tmp/tiles_$TAG.json
+O=$R/gpurun_out/$TAG; mkdir -p $O
+python bench.py --steps 30 --warmup 3 > $O/bench_image.json 2> $O/bench_image.err
+python bench.py --mode video --steps 30 --warmup 3 --no-cpu-baseline > $O/bench_video.json 2> $O/bench_video.err
+python bench.py --mode stream --no-cpu-baseline > $O/bench_stream.json 2> $O/bench_stream.err
+cd /tmp
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O -o img -- python $R/bench.py --no-cpu-baseline --no-kernel-timers --steps 10 --warmup 2 > $O/img.log 2>&1
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O -o vid -- python $R/bench.py --mode video --no-cpu-baseline --no-kernel-timers --steps 10 --warmup 2 > $O/vid.log 2>&1
+for P in "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE" "FETCH_SIZE" "WRITE_SIZE"; do
+  N=$(echo $P | cut -d' ' -f1)
+  timeout 300 rocprofv3 --pmc $P --output-format csv -d $O/pmc -o $N -- python $R/bench.py --no-cpu-baseline --no-kernel-timers --steps 2 --warmup 1 > $O/pmc_$N.log 2>&1
+done
+rm -f $O/*_kernel_trace.csv $O/*agent_info.csv
+ls $O $O/pmc

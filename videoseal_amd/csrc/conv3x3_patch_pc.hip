@@ -365,6 +365,7 @@ int vs_conv3x3_patch_pc_dispatch(const vs_conv_desc_t& d, int tile, hipStream_t 
   switch (tile) {
     case 15: return launch_ppc<2>(d, st);
     case 16: return launch_ppc<3>(d, st);
+    case 19: return launch_ppc<1>(d, st);
     default: return VS_ERR_UNSUPPORTED;
   }
 }
