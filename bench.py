@@ -178,6 +178,7 @@ def main():
     eng = model._engine()
     if not args.no_kernel_timers:
         eng.kernel_timers = []
+        eng.shell_timers = []
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -207,6 +208,15 @@ def main():
                 "mfma_issue_tflops_bf16": round(ach * 6, 1) if split else None,
                 "flops_per_launch": flops, "avg_launch_ms": round(avg * 1e3, 4), "launches_timed": len(dur), "traffic": None}
         eng.kernel_timers = None
+        # per-stage roofline of the HBM-bound shell: algorithmic bytes / HIP-event duration vs 8 TB/s
+        shell = {}
+        for name, a, b, nbytes in (eng.shell_timers or []):
+            t = shell.setdefault(name, [0, 0.0, 0])
+            t[0] += 1; t[1] += a.elapsed_time(b) * 1e-3; t[2] += nbytes
+        eng.shell_timers = None
+        roof["shell"] = [{"kernel": k, "bound": "hbm", "achieved": round(v[2] / v[1] / 1e9, 1), "peak": 8000.0, "unit": "GB/s",
+                          "frac": round(v[2] / v[1] / 8e12, 4), "avg_launch_ms": round(v[1] / v[0] * 1e3, 4),
+                          "algorithmic_MB_per_launch": round(v[2] / v[0] / 1e6, 1), "launches_timed": v[0]} for k, v in shell.items()]
         if split and rank == 0:
             # what the matrix cores of THIS box sustain on random operands (clocks are power-limited and data-dependent):
             # register-only v_mfma_f32_32x32x16_bf16 loop, 8 waves/CU, measured right here (tools/micro/mfma_peak.hip)

@@ -153,6 +153,11 @@ int vs_pool_linear(const float* x, int B, int HW, int C, int64_t ld, const float
  */
 int vs_resize_pre(const float* src, int B, int C, int H, int W, int oh, int ow, int antialias, float* dst_rgb, float mul,
                   float add, float* dst_y, int y_step, const float* ymat3, void* stream);
+/* The same for uint8 RGB24 frames [B][H][W][3] as they come off the ffmpeg pipe of inference_streaming.py:57-66:
+ * every sample is converted as float(u) / 255.0f, i.e. `torch.tensor(clip, dtype=float32).permute(0,3,1,2) / 255.0`
+ * (inference_streaming.py:26, 120) fused into the resize -- no fp32 copy of the clip is ever materialised. */
+int vs_resize_pre_u8(const unsigned char* src, int B, int H, int W, int oh, int ow, int antialias, float* dst_rgb, float mul,
+                     float add, float* dst_y, int y_step, const float* ymat3, void* stream);
 
 /* JND heat-map (jnd.py:63-108, in_channels=1/out_channels=1) of an RGB image addressed by strides
  * (floats): frame, channel, row, pixel.  taps43 is a HOST array (copied into the kernel arguments):
@@ -167,14 +172,17 @@ int vs_jnd_heatmap(const float* img, int B, int H, int W, int64_t sb, int64_t sc
  *                                                                           attenuate=0 disables JND)
  *   out    = clamp(scaling_i*imgs + scaling_w*d, 0, 1)
  * imgs/out: NCHW [F][3][H][W]; preds_w (optional) [F][Cd][H][W].
+ * io_u8 = 1: imgs and out are uint8 RGB24 [F][H][W][3]; read as float(u)/255.0f, written as (unsigned char)(v*255.0f)
+ * = `(imgs_w * 255.0).byte().permute(0,2,3,1)` of inference_streaming.py:31 (needs clamp = 1).
  */
 typedef struct vs_tail_desc {
-  const float* imgs; float* out; float* preds_w;
+  const void* imgs; void* out; float* preds_w;
   const float* delta; const float* hmap_lowres; const float* taps43;   /* taps43: HOST pointer */
   int32_t F, H, W, S_h, S_w, Cd;
   int32_t step, video_mode, total_key;      /* key-frame expansion                         */
   int32_t attenuate, clamp, antialias;
   float scaling_i, scaling_w;
+  int32_t io_u8, reserved_;
 } vs_tail_desc_t;
 int vs_embed_tail(const vs_tail_desc_t* d, void* stream);
 

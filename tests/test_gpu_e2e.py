@@ -221,3 +221,39 @@ def test_hipgraph_replay_matches_eager(tiny):
     assert len(model._graphs) == 2          # one embed graph + one detect graph, reused for the 3 clips
     for (w0, p0), (w1, p1) in zip(outs[False], outs[True]):
         assert torch.equal(w0, w1) and torch.equal(p0, p1)
+
+
+@pytest.mark.parametrize("lowres", [True, False])
+def test_uint8_rgb24_clip_path(tiny, lowres):
+    """inference_streaming.py:23-32,119-125: uint8 RGB24 clip in, uint8 RGB24 out, conversions fused into the HIP kernels.
+    Checked against the CPU oracle fed with clip/255 and against our own fp32 entry points (exactly equal before the final
+    truncation, so the uint8 results may differ from the ORACLE's by one level where x*255 lands within ~1e-5 of an integer)."""
+    spec, sd, model = tiny
+    model.chunk_size, model.step_size, model.video_mode = 2, 2, "repeat"
+    g = torch.Generator().manual_seed(11)
+    clip = (synthetic_frames(6, 72, 88, seed=5, kind="smooth") * 255).to(torch.uint8).permute(0, 2, 3, 1).contiguous()   # [F,H,W,3]
+    msgs = synthetic_msgs(1, spec.nbits, seed=5)
+    out = model.embed_u8(clip.cuda(), msgs, lowres_attenuation=lowres)
+    assert out["imgs_w"].dtype == torch.uint8 and out["imgs_w"].shape == clip.shape
+    x01 = clip.float().permute(0, 3, 1, 2) / 255.0
+    # (1) same engine, fp32 entry point: identical arithmetic up to the last conversion -> exactly equal
+    w32 = model.embed(x01.cuda(), msgs, is_video=True, lowres_attenuation=lowres)["imgs_w"]
+    assert torch.equal((w32 * 255.0).byte().permute(0, 2, 3, 1), out["imgs_w"])
+    # (2) CPU oracle
+    ref = R.embed_video(sd, spec, x01, msgs, chunk_size=2, step_size=2, lowres_attenuation=lowres)["imgs_w"]
+    ref_u8 = (ref * 255.0).byte().permute(0, 2, 3, 1)
+    diff = (ref_u8.int() - out["imgs_w"].cpu().int()).abs()
+    assert diff.max().item() <= 1 and (diff != 0).float().mean().item() < 2e-3
+    # detect on the uint8 clip == detect on clip/255
+    p8 = model.detect_u8(out["imgs_w"])["preds"]
+    # (the division runs on the CPU as in inference_streaming.py:120 -- ATen's GPU `tensor / scalar` multiplies by 1/255 instead)
+    p32 = model.detect((out["imgs_w"].cpu().float().permute(0, 3, 1, 2) / 255.0).cuda(), is_video=True)["preds"]
+    assert torch.equal(p8, p32)
+    pref = R.detect(sd, spec, ref_u8.float().permute(0, 3, 1, 2) / 255.0)["preds"]
+    sel = (diff.flatten(1).max(1).values == 0)           # frames whose pixels all agree with the oracle: logits must too
+    if sel.any():
+        assert (p8.cpu()[sel] - pref[sel]).abs().max().item() < TOL_LOGIT
+    with pytest.raises(ValueError):
+        model.embed_u8(clip.cuda().float(), msgs)
+    with pytest.raises(ValueError):
+        model.detect_u8(clip.cuda()[..., :2])

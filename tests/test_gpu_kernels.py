@@ -407,6 +407,18 @@ def test_resize_pre(eng, case):
     assert (key.cpu()[..., 0] - yref).abs().max() < 2e-6
 
 
+def test_u8_unit_conversion_is_exact(eng):
+    """uint8 -> [0,1] inside the kernels == `torch.tensor(u8, dtype=float32) / 255.0` on the CPU (inference_streaming.py:26) for all 256 values:
+    a 1:1 'resize' of a 16 x 16 RGB24 frame holding every byte value returns the conversion itself."""
+    u = torch.arange(256, dtype=torch.uint8).view(1, 16, 16, 1).repeat(1, 1, 1, 3).contiguous()
+    ref = u.float() / 255.0
+    rgb = torch.empty(1, 16, 16, 4, device=DEV)
+    for aa in (0, 1):
+        N.check(eng.lib.vs_resize_pre_u8(N.ptr(u.to(DEV)), 1, 16, 16, 16, 16, aa, N.ptr(rgb), 1.0, 0.0, None, 1, None, N.stream()), "rs")
+        torch.cuda.synchronize()
+        assert torch.equal(rgb.cpu()[..., :3], ref)
+
+
 def _jnd_ref(x):
     lum = 0.299 * (255 * x[:, 0:1]) + 0.587 * (255 * x[:, 1:2]) + 0.114 * (255 * x[:, 2:3])
     kx = torch.tensor([[-1., 0., 1.], [-2., 0., 2.], [-1., 0., 1.]])[None, None]

@@ -49,6 +49,27 @@ __device__ __forceinline__ Taps make_taps(int i, int in, int out, bool antialias
   }
   return t;
 }
+// first input index and tap count only (what make_taps computes, without the weight total)
+__device__ __forceinline__ void tap_range(int i, int in, int out, bool antialias, int& lo, int& n) {
+  const float scale = (float)in / (float)out;
+  if (antialias) {
+    const float support = scale >= 1.f ? scale : 1.f;
+    const float center = scale * (i + 0.5f);
+    int l = (int)(center - support + 0.5f);
+    l = l < 0 ? 0 : l;
+    int h = (int)(center + support + 0.5f);
+    h = h > in ? in : h;
+    lo = l;
+    n = h - l;
+  } else {
+    float src = scale * (i + 0.5f) - 0.5f;
+    src = src < 0.f ? 0.f : src;
+    int i0 = (int)src;
+    i0 = i0 > in - 1 ? in - 1 : i0;
+    lo = i0;
+    n = 1 + (i0 < in - 1);
+  }
+}
 __device__ __forceinline__ float tap_w(const Taps& t, int j) {
   if (t.aa) {
     const float w = tri((j + t.lo - t.center + 0.5f) * t.inv);
@@ -58,29 +79,135 @@ __device__ __forceinline__ float tap_w(const Taps& t, int j) {
   return j == 0 ? 1.f - t.l1 : t.l1;
 }
 
+// ---- frame element access: fp32 NCHW planes, or uint8 RGB24 (HWC, what inference_streaming.py:26 reads from the ffmpeg
+// pipe).  uint8 -> float is exactly `torch.tensor(clip, dtype=float32) / 255.0`; float -> uint8 is `(x * 255.0).byte()`
+// (truncation) of inference_streaming.py:31.
+// float(u) / 255.0f, correctly rounded, for u in 0..255: one Newton correction of u * (1/255) (checked exhaustively against IEEE
+// division in tests/test_gpu_kernels.py::test_u8_unit_conversion_is_exact); 3 VALU ops instead of the 13 of a true division
+__device__ __forceinline__ float u8_unit(float u) {
+  const float r = 1.0f / 255.0f;
+  const float q = u * r;
+  const float rem = __builtin_fmaf(-q, 255.0f, u);
+  return __builtin_fmaf(rem, r, q);
+}
+template <typename T> struct Px;
+template <> struct Px<float> {
+  static __device__ __forceinline__ float ld(const float* img, int64_t plane, int c, int64_t pix) { return img[c * plane + pix]; }
+  static __device__ __forceinline__ void st(float* img, int64_t plane, int c, int64_t pix, float v) { img[c * plane + pix] = v; }
+};
+template <> struct Px<unsigned char> {
+  static __device__ __forceinline__ float ld(const unsigned char* img, int64_t, int c, int64_t pix) { return u8_unit((float)img[pix * 3 + c]); }
+  static __device__ __forceinline__ void st(unsigned char* img, int64_t, int c, int64_t pix, float v) { img[pix * 3 + c] = (unsigned char)(v * 255.0f); }
+};
+
 // ---------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void resize_pre_kernel(const float* __restrict__ src, int B, int C, int H, int W, int oh, int ow,
+constexpr int TTW = 256, TTH = 16, TLW = TTW + 4;   // embed tail tile: 256 columns (one per thread) x 16 rows
+constexpr int DW_W = 136, DW_H = 12;      // its delta source window in LDS (covers up-resizes by >= 2x; a 3x one needs ~90 x 9)
+constexpr int RS_WW = 113, RS_WH = 32;   // LDS window of resize_pre (odd row pitch); covers down-scales up to ~3.3x
+constexpr int MAXT = 8;   // taps held in registers by the resize kernels (triangle filter support 2*scale + 1 <= 8 for scale <= 3.5)
+
+template <typename T>
+__global__ __launch_bounds__(256) void resize_pre_kernel(const T* __restrict__ src, int B, int C, int H, int W, int oh, int ow,
                                                          int antialias, float* __restrict__ dst_rgb, float mul, float add,
                                                          float* __restrict__ dst_key, int key_step, int key_mode, float y0,
                                                          float y1, float y2) {
-  const int ox = blockIdx.x * 32 + (threadIdx.x & 31);
-  const int oy = blockIdx.y * 8 + (threadIdx.x >> 5);
+  // The block's 32 x 8 outputs read an input window of about (32*scale + support) x (8*scale + support) pixels.  Reading it
+  // tap by tap from global memory is L1-bound (4-byte loads 12 bytes apart, every line touched ~7 times), so the window is
+  // staged once through LDS with coalesced loads whenever it fits; the arithmetic (and its order) is the same either way.
+  __shared__ float Lw[3 * RS_WH * RS_WW];
+  const int ox0 = blockIdx.x * 32, oy0 = blockIdx.y * 8;
   const int b = blockIdx.z;
+  const int64_t plane = (int64_t)H * W;
+  const T* base = src + (int64_t)b * C * plane;
+  int x_lo, y_lo, x_hi, y_hi, n_;
+  tap_range(ox0, W, ow, antialias, x_lo, n_);
+  tap_range(min(ox0 + 31, ow - 1), W, ow, antialias, x_hi, n_);
+  const int ww = x_hi + n_ - x_lo;
+  tap_range(oy0, H, oh, antialias, y_lo, n_);
+  tap_range(min(oy0 + 7, oh - 1), H, oh, antialias, y_hi, n_);
+  const int wh = y_hi + n_ - y_lo;
+  const bool staged = C == 3 && ww <= RS_WW && wh <= RS_WH;          // block-uniform
+  if (staged) {
+    // division-free thread -> element maps, every thread's loads issued back to back (the staging is latency-bound otherwise)
+    if (sizeof(T) == 1) {            // RGB24: the 3*ww bytes of a window row are contiguous, (x, c) interleaved
+      // aligned 4-byte loads (thread = (dword column, row parity)), unpacked into the three LDS planes
+      const int jd = threadIdx.x & 127, y0r = threadIdx.x >> 7;
+      const unsigned char* fb = reinterpret_cast<const unsigned char*>(base);
+      unsigned wrd[RS_WH / 2];
+      int mis[RS_WH / 2];
+#pragma unroll
+      for (int k = 0; k < RS_WH / 2; ++k) {
+        wrd[k] = 0u; mis[k] = 0;
+        if (y0r + 2 * k < wh) {
+          const unsigned char* rowp = fb + ((int64_t)(y_lo + y0r + 2 * k) * W + x_lo) * 3;
+          const int m = (int)(reinterpret_cast<uintptr_t>(rowp) & 3);
+          mis[k] = m;
+          if (4 * jd < 3 * ww + m) wrd[k] = *reinterpret_cast<const unsigned*>(rowp - m + 4 * jd);
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < RS_WH / 2; ++k)
+        if (y0r + 2 * k < wh) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const int bo = 4 * jd + q - mis[k];
+            if (bo >= 0 && bo < 3 * ww) {
+              const int xx = bo / 3, c = bo - xx * 3;
+              Lw[(c * RS_WH + y0r + 2 * k) * RS_WW + xx] = u8_unit((float)((wrd[k] >> (8 * q)) & 0xffu));
+            }
+          }
+        }
+    } else {                         // planar: thread = (column, row parity); 3 channels x wh/2 rows each
+      const int xx = threadIdx.x & 127, y0r = threadIdx.x >> 7;
+      if (xx < ww) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+          float v[RS_WH / 2];
+#pragma unroll
+          for (int k = 0; k < RS_WH / 2; ++k)
+            if (y0r + 2 * k < wh) v[k] = Px<T>::ld(base, plane, c, (int64_t)(y_lo + y0r + 2 * k) * W + x_lo + xx);
+#pragma unroll
+          for (int k = 0; k < RS_WH / 2; ++k)
+            if (y0r + 2 * k < wh) Lw[(c * RS_WH + y0r + 2 * k) * RS_WW + xx] = v[k];
+        }
+      }
+    }
+    __syncthreads();
+  }
+  const int ox = ox0 + (threadIdx.x & 31);
+  const int oy = oy0 + (threadIdx.x >> 5);
   if (ox >= ow || oy >= oh) return;
   const Taps ty = make_taps(oy, H, oh, antialias), tx = make_taps(ox, W, ow, antialias);
   float acc[3] = {0.f, 0.f, 0.f};
-  const int64_t plane = (int64_t)H * W;
-  const float* base = src + (int64_t)b * C * plane;
-  for (int jy = 0; jy < ty.n; ++jy) {
-    const float wy = tap_w(ty, jy);
-    const float* row = base + (int64_t)(ty.lo + jy) * W + tx.lo;
-    float r[3] = {0.f, 0.f, 0.f};
-    for (int jx = 0; jx < tx.n; ++jx) {
-      const float wx = tap_w(tx, jx);
-      for (int c = 0; c < 3; ++c)
-        if (c < C) r[c] += wx * row[c * plane + jx];
+  if (staged && tx.n <= MAXT) {
+    float wxs[MAXT];
+#pragma unroll
+    for (int jx = 0; jx < MAXT; ++jx) wxs[jx] = jx < tx.n ? tap_w(tx, jx) : 0.f;
+    const float* Lp = Lw + (ty.lo - y_lo) * RS_WW + (tx.lo - x_lo);
+    for (int jy = 0; jy < ty.n; ++jy) {
+      const float wy = tap_w(ty, jy);
+      float r[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+      for (int jx = 0; jx < MAXT; ++jx)
+        if (jx < tx.n) {
+#pragma unroll
+          for (int c = 0; c < 3; ++c) r[c] += wxs[jx] * Lp[(c * RS_WH + jy) * RS_WW + jx];
+        }
+#pragma unroll
+      for (int c = 0; c < 3; ++c) acc[c] += wy * r[c];
     }
-    for (int c = 0; c < 3; ++c) acc[c] += wy * r[c];
+  } else {
+    for (int jy = 0; jy < ty.n; ++jy) {
+      const float wy = tap_w(ty, jy);
+      const int64_t row = (int64_t)(ty.lo + jy) * W + tx.lo;
+      float r[3] = {0.f, 0.f, 0.f};
+      for (int jx = 0; jx < tx.n; ++jx) {
+        const float wx = tap_w(tx, jx);
+        for (int c = 0; c < 3; ++c)
+          if (c < C) r[c] += wx * Px<T>::ld(base, plane, c, row + jx);
+      }
+      for (int c = 0; c < 3; ++c) acc[c] += wy * r[c];
+    }
   }
   const int64_t opix = ((int64_t)oy * ow + ox);
   if (dst_rgb) {
@@ -121,7 +248,9 @@ __device__ __forceinline__ float jnd_at(const float* L, int stride, int x, int y
       gy += k.sy[i * 3 + j] * v;
     }
   float cm = sqrtf(gx * gx + gy * gy);
-  cm = 16.f * powf(cm, 2.4f) / (cm * cm + 676.f);
+  // cm^2.4 through the hardware log2/exp2 (1 ulp each): relative error <= ~1e-6 on a term that enters the frame scaled by
+  // 1/255 * delta * scaling_w, i.e. < 1e-8 absolute -- ocml's powf costs ~10x the instructions
+  cm = 16.f * (cm > 0.f ? __builtin_amdgcn_exp2f(2.4f * __builtin_amdgcn_logf(cm)) : 0.f) / (cm * cm + 676.f);
   cm = 0.117f * cm;
   const float h = la + cm - 0.3f * fminf(la, cm);
   return fmaxf(h, 0.f) / 255.f;
@@ -144,6 +273,21 @@ __device__ __forceinline__ void load_lum_tile(float* L, const float* img, int64_
   }
 }
 
+template <typename T, int ROWS>
+__device__ __forceinline__ void load_lum_tile_px(float* L, const T* img, int64_t plane, int H, int W, int x0, int y0) {
+  for (int i = threadIdx.x; i < LW * (ROWS + 2 * HALO); i += 256) {
+    const int ly = i / LW, lx = i - ly * LW;
+    const int gx = x0 + lx - HALO, gy = y0 + ly - HALO;
+    float v = 0.f;
+    if (gx >= 0 && gx < W && gy >= 0 && gy < H) {
+      const int64_t pix = (int64_t)gy * W + gx;
+      v = 0.299f * (255.f * Px<T>::ld(img, plane, 0, pix)) + 0.587f * (255.f * Px<T>::ld(img, plane, 1, pix)) +
+          0.114f * (255.f * Px<T>::ld(img, plane, 2, pix));
+    }
+    L[i] = v;
+  }
+}
+
 __global__ __launch_bounds__(256) void jnd_heatmap_kernel(const float* __restrict__ img, int H, int W, int64_t sb, int64_t sc,
                                                           int64_t sy, int64_t sx, JndTaps k, float* __restrict__ hmap) {
   __shared__ float L[LW * LH];
@@ -155,26 +299,107 @@ __global__ __launch_bounds__(256) void jnd_heatmap_kernel(const float* __restric
   if (x < W && y < H) hmap[((int64_t)b * H + y) * W + x] = jnd_at(L, LW, lx + HALO, ly + HALO, k);
 }
 
+// delta taps of one output pixel from the staged source window: d[c] = sum_jy wy * sum_jx wx * Dw[c][..] (Dw = hm*(wa*key_a+wb*key_b))
+template <int NT>
+__device__ __forceinline__ void tail_taps(float (&d)[3], const float* Dw, const int Cd, const int base, const int xn, const int yn,
+                                          const float* wxp, const float* wyp) {
+  int ox[NT], oy[NT];
+  float wx[NT], wy[NT];
+#pragma unroll
+  for (int j = 0; j < NT; ++j) {       // clamped offsets + zero weights past the real tap count: no branches, all reads in flight
+    ox[j] = j < xn ? j : xn - 1;
+    oy[j] = (j < yn ? j : yn - 1) * DW_W;
+    wx[j] = wxp[j];
+    wy[j] = wyp[j];
+  }
+  for (int c = 0; c < Cd; ++c) {
+    const float* p = Dw + c * (DW_W * DW_H) + base;
+    float v[NT][NT];
+#pragma unroll
+    for (int jy = 0; jy < NT; ++jy)
+#pragma unroll
+      for (int jx = 0; jx < NT; ++jx) v[jy][jx] = p[oy[jy] + ox[jx]];
+    float dc = 0.f;
+#pragma unroll
+    for (int jy = 0; jy < NT; ++jy) {
+      float r = 0.f;
+#pragma unroll
+      for (int jx = 0; jx < NT; ++jx) r += wx[jx] * v[jy][jx];
+      dc += wy[jy] * r;
+    }
+    d[c] = dc;
+  }
+}
+
 // ---------------------------------------------------------------------------------------------------
 struct TailArgs {
-  const float* imgs; float* out; float* preds_w; const float* delta; const float* hmap_lowres;
+  const void* imgs; void* out; float* preds_w; const float* delta; const float* hmap_lowres;
   int F, H, W, Sh, Sw, Cd, step, video_mode, total_key, attenuate, clamp, antialias;
   float scaling_i, scaling_w;
 };
 
+// Workgroup = 256 consecutive columns x TTH rows of one frame: every wave touches 256 contiguous bytes (fp32) per row and
+// plane -- 32-pixel-wide tiles (128-byte pieces at a 3 KB stride) ran at ~1.3 TB/s, a quarter of what a plain copy reaches.
+// Each thread owns one column: its horizontal taps are computed once and reused for the TTH rows; the vertical taps
+// of the TTH rows are computed by TTH threads into LDS; the source window of delta (x low-res heat-map, x key-frame
+// weights) is staged in LDS so the 4..9 taps per pixel are LDS reads.
+template <typename T>
 __global__ __launch_bounds__(256) void embed_tail_kernel(TailArgs a, JndTaps k) {
-  __shared__ float L[LW * LH];
-  const int x0 = blockIdx.x * TW, y0 = blockIdx.y * TH, f = blockIdx.z;
+  __shared__ float L[TLW * (TTH + 2 * HALO)];
+  __shared__ float Dw[3 * DW_W * DW_H];
+  __shared__ int ty_lo[TTH], ty_n[TTH];
+  __shared__ float ty_w[TTH][4];
+  __shared__ int s_xhi, s_nmax, s_xlo;
+  const int x0 = blockIdx.x * TTW, y0 = blockIdx.y * TTH, f = blockIdx.z;
   const int64_t plane = (int64_t)a.H * a.W;
-  const float* img = a.imgs + (int64_t)f * 3 * plane;
+  const T* img = static_cast<const T*>(a.imgs) + (int64_t)f * 3 * plane;
+  T* outf = static_cast<T*>(a.out) + (int64_t)f * 3 * plane;
   const bool full_jnd = a.attenuate && !a.hmap_lowres;
-  if (full_jnd) {
-    load_lum_tile(L, img, plane, a.W, 1, a.H, a.W, x0, y0);
-    __syncthreads();
+  if (threadIdx.x == 0) { s_xhi = 0; s_nmax = 0; }
+  __syncthreads();
+  if (full_jnd) {       // luminance of the tile + 2-pixel halo: thread = column (4 extra halo columns on threads 0-3), all rows
+    constexpr int NR = TTH + 2 * HALO;
+    auto lum_column = [&](const int lxx) __attribute__((always_inline)) {      // lxx: column inside the LDS tile
+      const int gx = x0 + lxx - HALO;
+      float v[NR][3];
+#pragma unroll
+      for (int rr = 0; rr < NR; ++rr) {
+        const int gy = y0 + rr - HALO;
+        const bool ok = gx >= 0 && gx < a.W && gy >= 0 && gy < a.H;
+        const int cx = gx < 0 ? 0 : (gx >= a.W ? a.W - 1 : gx), cy = gy < 0 ? 0 : (gy >= a.H ? a.H - 1 : gy);
+        const int64_t pix = (int64_t)cy * a.W + cx;          // always a valid address: unconditional loads, zeroed afterwards
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+          const float t = Px<T>::ld(img, plane, c, pix);
+          v[rr][c] = ok ? t : 0.f;
+        }
+      }
+#pragma unroll
+      for (int rr = 0; rr < NR; ++rr)
+        L[rr * TLW + lxx] = 0.299f * (255.f * v[rr][0]) + 0.587f * (255.f * v[rr][1]) + 0.114f * (255.f * v[rr][2]);
+    };
+    lum_column(threadIdx.x + HALO);
+    if (threadIdx.x < 2 * HALO) lum_column(threadIdx.x < HALO ? threadIdx.x : TTW + threadIdx.x);
   }
-  const int lx = threadIdx.x & 31, ly = threadIdx.x >> 5;
-  const int x = x0 + lx, y = y0 + ly;
-  if (x >= a.W || y >= a.H) return;
+  // taps: own column (registers), rows of the tile (LDS)
+  const int lx = threadIdx.x;
+  const int x = x0 + lx;
+  const Taps tx = make_taps(x < a.W ? x : a.W - 1, a.Sw, a.W, a.antialias);
+  float wxs[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) wxs[j] = j < tx.n ? tap_w(tx, j) : 0.f;
+  if (x < a.W) { atomicMax(&s_xhi, tx.lo + tx.n); atomicMax(&s_nmax, tx.n); }
+  if (threadIdx.x == 0) s_xlo = tx.lo;        // taps start monotonically: column 0 / row 0 of the tile come first
+  if (threadIdx.x < TTH) {
+    const int yy = y0 + threadIdx.x;
+    const Taps tp = make_taps(yy < a.H ? yy : a.H - 1, a.Sh, a.H, a.antialias);
+    ty_lo[threadIdx.x] = tp.lo;
+    ty_n[threadIdx.x] = tp.n;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) ty_w[threadIdx.x][j] = j < tp.n ? tap_w(tp, j) : 0.f;
+    if (yy < a.H) atomicMax(&s_nmax, tp.n);
+  }
+  __syncthreads();
 
   // key-frame expansion (videoseal.py:80-118): value = wa*key[ka] + wb*key[kb]
   int ka = 0, kb = 0;
@@ -197,36 +422,87 @@ __global__ __launch_bounds__(256) void embed_tail_kernel(TailArgs a, JndTaps k) 
   }
   if (ka >= a.total_key) ka = a.total_key - 1;
   if (kb >= a.total_key) kb = a.total_key - 1;
+  const int splane = a.Sh * a.Sw;
+  const float* dka = a.delta + (int64_t)ka * a.Cd * splane;
+  const float* dkb = a.delta + (int64_t)kb * a.Cd * splane;
+  const float* hml = a.hmap_lowres ? a.hmap_lowres + (int64_t)f * splane : nullptr;
 
-  const Taps ty = make_taps(y, a.Sh, a.H, a.antialias), tx = make_taps(x, a.Sw, a.W, a.antialias);
-  const int64_t splane = (int64_t)a.Sh * a.Sw;
-  float d[3] = {0.f, 0.f, 0.f};
-  for (int jy = 0; jy < ty.n; ++jy) {
-    const float wy = tap_w(ty, jy);
-    float r[3] = {0.f, 0.f, 0.f};
-    for (int jx = 0; jx < tx.n; ++jx) {
-      const float wx = tap_w(tx, jx);
-      const int64_t sp = (int64_t)(ty.lo + jy) * a.Sw + (tx.lo + jx);
-      const float hm = a.hmap_lowres ? a.hmap_lowres[(int64_t)f * splane + sp] : 1.f;
+  // source window -> LDS, already combined: Dw[c] = hm * (wa*key_a + wb*key_b)  (the per-tap operand of wam.py:184-190)
+  const int lasty = min(TTH, a.H - y0) - 1;
+  const int wx0 = s_xlo, wy0 = ty_lo[0];
+  const int dww = s_xhi - wx0, dwh = ty_lo[lasty] + ty_n[lasty] - wy0;
+  const int blk_n = s_nmax;
+  const bool staged = blk_n <= 4 && dww <= DW_W && dwh <= DW_H;
+  const int wx0b = wx0;
+  if (staged) {
+    for (int i = threadIdx.x; i < dwh * dww; i += 256) {
+      const int yy = i / dww, xx = i - yy * dww;
+      const int sp = (wy0 + yy) * a.Sw + wx0b + xx;
+      const float hm = hml ? hml[sp] : 1.f;
       for (int c = 0; c < a.Cd; ++c) {
-        float v = wa * a.delta[((int64_t)ka * a.Cd + c) * splane + sp];
-        if (wb != 0.f) v += wb * a.delta[((int64_t)kb * a.Cd + c) * splane + sp];
-        r[c] += wx * (hm * v);
+        float v = wa * dka[c * splane + sp];
+        if (wb != 0.f) v += wb * dkb[c * splane + sp];
+        Dw[c * (DW_W * DW_H) + yy * DW_W + xx] = hm * v;
       }
     }
-    for (int c = 0; c < a.Cd; ++c) d[c] += wy * r[c];
   }
-  if (full_jnd) {
-    const float hm = jnd_at(L, LW, lx + HALO, ly + HALO, k);
-    for (int c = 0; c < a.Cd; ++c) d[c] = hm * d[c];
-  }
-  const int64_t pix = (int64_t)y * a.W + x;
-  if (a.preds_w)
-    for (int c = 0; c < a.Cd; ++c) a.preds_w[((int64_t)f * a.Cd + c) * plane + pix] = d[c];
-  for (int c = 0; c < 3; ++c) {
-    float v = a.scaling_i * img[c * plane + pix] + a.scaling_w * d[a.Cd == 1 ? 0 : c];
-    if (a.clamp) v = fminf(fmaxf(v, 0.f), 1.f);
-    a.out[(int64_t)f * 3 * plane + c * plane + pix] = v;
+  __syncthreads();      // L, Dw
+  if (x >= a.W) return;
+
+  auto tap = [&](const int sp, const float wx, float (&r)[3]) __attribute__((always_inline)) {
+    const float hm = hml ? hml[sp] : 1.f;
+    for (int c = 0; c < a.Cd; ++c) {
+      float v = wa * dka[c * splane + sp];
+      if (wb != 0.f) v += wb * dkb[c * splane + sp];
+      r[c] += wx * (hm * v);
+    }
+  };
+  // rows in groups of RG: the frame loads of a whole group are issued before any of it is consumed -- with one row (3 loads) in
+  // flight per wave and ~16 waves per CU the kernel cannot cover the HBM latency (measured 2 TB/s)
+  constexpr int RG = 4;
+  for (int lyg = 0; lyg <= lasty; lyg += RG) {      // no workgroup barrier below this line
+    float px[RG][3];
+#pragma unroll
+    for (int q = 0; q < RG; ++q)
+      if (lyg + q <= lasty) {
+        const int64_t pix = (int64_t)(y0 + lyg + q) * a.W + x;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) px[q][c] = Px<T>::ld(img, plane, c, pix);
+      }
+#pragma unroll
+    for (int q = 0; q < RG; ++q) {
+      const int ly = lyg + q;
+      if (ly > lasty) break;
+      const int y = y0 + ly;
+      float d[3] = {0.f, 0.f, 0.f};
+      const int ylo = ty_lo[ly], yn = ty_n[ly];
+      if (staged) {
+        const int basep = (ylo - wy0) * DW_W + (tx.lo - wx0b);
+        if (blk_n <= 3) tail_taps<3>(d, Dw, a.Cd, basep, tx.n, yn, wxs, ty_w[ly]);
+        else tail_taps<4>(d, Dw, a.Cd, basep, tx.n, yn, wxs, ty_w[ly]);
+      } else {
+        const Taps ty = make_taps(y, a.Sh, a.H, a.antialias);
+        for (int jy = 0; jy < ty.n; ++jy) {
+          const float wy = tap_w(ty, jy);
+          float r[3] = {0.f, 0.f, 0.f};
+          for (int jx = 0; jx < tx.n; ++jx) tap((ty.lo + jy) * a.Sw + tx.lo + jx, tap_w(tx, jx), r);
+          for (int c = 0; c < a.Cd; ++c) d[c] += wy * r[c];
+        }
+      }
+      if (full_jnd) {
+        const float hm = jnd_at(L, TLW, lx + HALO, ly + HALO, k);
+        for (int c = 0; c < a.Cd; ++c) d[c] = hm * d[c];
+      }
+      const int64_t pix = (int64_t)y * a.W + x;
+      if (a.preds_w)
+        for (int c = 0; c < a.Cd; ++c) a.preds_w[((int64_t)f * a.Cd + c) * plane + pix] = d[c];
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        float v = a.scaling_i * px[q][c] + a.scaling_w * d[a.Cd == 1 ? 0 : c];
+        if (a.clamp) v = fminf(fmaxf(v, 0.f), 1.f);
+        Px<T>::st(outf, plane, c, pix, v);
+      }
+    }
   }
 }
 
@@ -246,8 +522,20 @@ extern "C" int vs_resize_pre(const float* src, int B, int C, int H, int W, int o
   const int key_mode = ymat3 ? 0 : 1;
   const float y0 = ymat3 ? ymat3[0] : 0.f, y1 = ymat3 ? ymat3[1] : 0.f, y2 = ymat3 ? ymat3[2] : 0.f;
   dim3 grid((ow + 31) / 32, (oh + 7) / 8, B);
-  hipLaunchKernelGGL(resize_pre_kernel, grid, dim3(256), 0, (hipStream_t)stream, src, B, C, H, W, oh, ow, antialias, dst_rgb, mul,
+  hipLaunchKernelGGL(resize_pre_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, src, B, C, H, W, oh, ow, antialias, dst_rgb, mul,
                      add, dst_key, key_step < 1 ? 1 : key_step, key_mode, y0, y1, y2);
+  return vs_launch_status();
+}
+
+extern "C" int vs_resize_pre_u8(const unsigned char* src, int B, int H, int W, int oh, int ow, int antialias, float* dst_rgb,
+                                float mul, float add, float* dst_key, int key_step, const float* ymat3, void* stream) {
+  VS_REQUIRE(src && B > 0 && H > 0 && W > 0 && oh > 0 && ow > 0 && (dst_rgb || dst_key));
+  VS_REQUIRE(!dst_key || key_step >= 1);
+  const int key_mode = ymat3 ? 0 : 1;
+  const float y0 = ymat3 ? ymat3[0] : 0.f, y1 = ymat3 ? ymat3[1] : 0.f, y2 = ymat3 ? ymat3[2] : 0.f;
+  dim3 grid((ow + 31) / 32, (oh + 7) / 8, B);
+  hipLaunchKernelGGL(resize_pre_kernel<unsigned char>, grid, dim3(256), 0, (hipStream_t)stream, src, B, 3, H, W, oh, ow, antialias,
+                     dst_rgb, mul, add, dst_key, key_step < 1 ? 1 : key_step, key_mode, y0, y1, y2);
   return vs_launch_status();
 }
 
@@ -269,7 +557,12 @@ extern "C" int vs_embed_tail(const vs_tail_desc_t* d, void* stream) {
              d->Cd, d->step, d->video_mode, d->total_key, d->attenuate, d->clamp, d->antialias, d->scaling_i, d->scaling_w};
   JndTaps k{};
   if (d->taps43) k = taps_from(d->taps43);
-  dim3 grid((d->W + TW - 1) / TW, (d->H + TH - 1) / TH, d->F);
-  hipLaunchKernelGGL(embed_tail_kernel, grid, dim3(256), 0, (hipStream_t)stream, a, k);
+  dim3 grid((d->W + TTW - 1) / TTW, (d->H + TTH - 1) / TTH, d->F);
+  if (d->io_u8) {
+    VS_REQUIRE(d->clamp);        // (x * 255).byte() is only defined for x in [0, 1]
+    hipLaunchKernelGGL(embed_tail_kernel<unsigned char>, grid, dim3(256), 0, (hipStream_t)stream, a, k);
+  } else {
+    hipLaunchKernelGGL(embed_tail_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, a, k);
+  }
   return vs_launch_status();
 }

@@ -146,6 +146,7 @@ class HipEngine:
         # per-shape tile selection: every candidate walks K in the same order, so the result is bit-identical whatever
         # tile wins -- only speed changes (measure, don't guess).  VIDEOSEAL_AUTOTUNE=0 keeps the static heuristic.
         self.autotune = os.environ.get("VIDEOSEAL_AUTOTUNE", "1") != "0"
+        self.shell_timers: Optional[list] = None     # bench.py: (kernel, ev0, ev1, algorithmic bytes) of the HBM-bound shell kernels
         self._tile_cache: Dict[tuple, int] = {}
         # optional on-disk copy of the tile choices (VIDEOSEAL_TILE_CACHE=path.json): a profiled run then has no tuning launches
         self._tile_cache_path = os.environ.get("VIDEOSEAL_TILE_CACHE")
@@ -501,15 +502,42 @@ class HipEngine:
     # ------------------------------------------------------------------ shell
     def resize_pre(self, imgs: torch.Tensor, S: Tuple[int, int], antialias: bool, *, want_rgb: bool, mul=1.0, add=0.0,
                    want_key: bool = False, key_step: int = 1, tag="rs") -> Tuple[Optional[Act], Optional[Act]]:
-        """imgs NCHW on device -> (rgb Act [B,S,S,4] or None, key Act [ceil(B/step),S,S,4] or None)."""
-        B, Cc, H, W = imgs.shape
+        """imgs on device, fp32 NCHW [B,3,H,W] or uint8 RGB24 [B,H,W,3] -> (rgb Act [B,S,S,4] or None, key Act [ceil(B/step),S,S,4] or None)."""
+        u8 = imgs.dtype == torch.uint8
+        if u8:
+            B, H, W, Cc = imgs.shape
+            if Cc != 3:
+                raise ValueError("uint8 frames must be RGB24 [F, H, W, 3]")
+        else:
+            B, Cc, H, W = imgs.shape
         rgb = self.new_act(tag + ".rgb", B, S[0], S[1], 3, 4) if want_rgb else None
         nk = (B + key_step - 1) // key_step
         key = self.new_act(tag + ".key", nk, S[0], S[1], self.cfg.in_ch, 4) if want_key else None
         ymat = self.ymat if self.cfg.yuv else None
-        N.check(self.lib.vs_resize_pre(N.ptr(imgs), B, Cc, H, W, S[0], S[1], 1 if antialias else 0, N.ptr(rgb.t) if rgb else None,
-                                       mul, add, N.ptr(key.t) if key else None, key_step, ymat, N.stream()), "vs_resize_pre")
+        ev = self._shell_t0()
+        if u8:
+            N.check(self.lib.vs_resize_pre_u8(N.ptr(imgs), B, H, W, S[0], S[1], 1 if antialias else 0, N.ptr(rgb.t) if rgb else None,
+                                              mul, add, N.ptr(key.t) if key else None, key_step, ymat, N.stream()), "vs_resize_pre_u8")
+        else:
+            N.check(self.lib.vs_resize_pre(N.ptr(imgs), B, Cc, H, W, S[0], S[1], 1 if antialias else 0, N.ptr(rgb.t) if rgb else None,
+                                           mul, add, N.ptr(key.t) if key else None, key_step, ymat, N.stream()), "vs_resize_pre")
+        # algorithmic HBM bytes: the frame once + the 256^2 outputs (4 floats per pixel)
+        self._shell_t1(ev, "resize_pre_kernel" + ("<u8>" if u8 else ""),
+                       imgs.numel() * imgs.element_size() + 16 * S[0] * S[1] * ((B if rgb else 0) + (nk if key else 0)))
         return rgb, key
+
+    def _shell_t0(self):
+        if self.shell_timers is None or torch.cuda.is_current_stream_capturing():
+            return None
+        ev = torch.cuda.Event(enable_timing=True)
+        ev.record()
+        return ev
+
+    def _shell_t1(self, ev0, name: str, nbytes: int):
+        if ev0 is not None:
+            ev1 = torch.cuda.Event(enable_timing=True)
+            ev1.record()
+            self.shell_timers.append((name, ev0, ev1, nbytes))
 
     def jnd_lowres(self, rgb: Act) -> torch.Tensor:
         h = self.buf("jnd.low", rgb.B * rgb.H * rgb.W)
@@ -527,7 +555,14 @@ class HipEngine:
     def embed_tail(self, imgs, out, delta, *, step, video_mode, hmap_low, attenuate, clamp, antialias, scaling_i, scaling_w,
                    preds_w=None):
         d = N.TailDesc()
-        F_, _, H, W = imgs.shape
+        u8 = imgs.dtype == torch.uint8          # RGB24 [F,H,W,3] in and out
+        if u8:
+            F_, H, W, _ = imgs.shape
+            if out.dtype != torch.uint8 or out.shape != imgs.shape:
+                raise ValueError("uint8 frames need a uint8 output of the same shape")
+            d.io_u8 = 1
+        else:
+            F_, _, H, W = imgs.shape
         d.imgs, d.out, d.preds_w = N.ptr(imgs), N.ptr(out), N.ptr(preds_w)
         d.delta, d.hmap_lowres = N.ptr(delta), N.ptr(hmap_low)
         d.taps43 = C.cast(self.taps43, C.c_void_p)
@@ -535,4 +570,8 @@ class HipEngine:
         d.step, d.video_mode, d.total_key = step, video_mode, delta.shape[0]
         d.attenuate, d.clamp, d.antialias = int(attenuate), int(clamp), int(antialias)
         d.scaling_i, d.scaling_w = float(scaling_i), float(scaling_w)
+        ev = self._shell_t0()
         N.check(self.lib.vs_embed_tail(C.byref(d), N.stream()), "vs_embed_tail")
+        # algorithmic HBM bytes: frame read + watermarked frame written (+ preds_w); the 256^2 delta / heat-map reads are cache hits
+        self._shell_t1(ev, "embed_tail_kernel" + ("<u8>" if u8 else ""), imgs.numel() * imgs.element_size() + out.numel() * out.element_size()
+                       + (preds_w.numel() * 4 if preds_w is not None else 0) + delta.numel() * 4)

@@ -239,7 +239,7 @@ class Wam(nn.Module):
             rgb, _ = eng.resize_pre(si["fr"], S, antialias, want_rgb=True, mul=2.0, add=-1.0, tag="det.in")
             return {"preds": eng.extractor_forward(rgb)}
         if self.use_graphs and not torch.cuda.is_current_stream_capturing():
-            key = ("det", tuple(fr.shape), tuple(S), antialias, id(eng))
+            key = ("det", fr.dtype, tuple(fr.shape), tuple(S), antialias, id(eng))
             return self._graphed(key, {"fr": fr}, run)["preds"].clone()
         return run({"fr": fr})["preds"].clone()
 
@@ -247,7 +247,7 @@ class Wam(nn.Module):
     def _embed_frames(self, eng: HipEngine, fr: torch.Tensor, msgs_i32: torch.Tensor, out: torch.Tensor, *, step: int,
                       video_mode: int, antialias: bool, lowres: bool, preds_w: Optional[torch.Tensor] = None) -> None:
         if self.use_graphs and not torch.cuda.is_current_stream_capturing():
-            key = ("emb", tuple(fr.shape), tuple(msgs_i32.shape), step, video_mode, antialias, lowres, preds_w is not None, self.img_size,
+            key = ("emb", fr.dtype, tuple(fr.shape), tuple(msgs_i32.shape), step, video_mode, antialias, lowres, preds_w is not None, self.img_size,
                    self.clamp, float(self.blender.scaling_i), float(self.blender.scaling_w), self.attenuation is not None, id(eng))
             ent = self._graphs.get(key)
             if ent is None:
@@ -385,6 +385,52 @@ class Videoseal(Wam):
         for a in range(0, x.shape[0], ck):
             preds.append(self._detect_frames(eng, x[a:a + ck], S, aa))
         return {"preds": torch.cat(preds, dim=0).to(imgs.device)}
+
+    # ---- uint8 RGB24 clips, the data format on either side of the path in inference_streaming.py
+    @torch.no_grad()
+    def embed_u8(self, clip: torch.Tensor, msgs: torch.Tensor = None, interpolation: dict = None,
+                 lowres_attenuation: bool = True) -> dict:
+        """inference_streaming.py:23-32 (`embed_video_clip`) in one pass: clip uint8 [F,H,W,3] (RGB24, as read from the ffmpeg
+        pipe) -> {'imgs_w': uint8 [F,H,W,3], 'msgs'}.  Equals (embed(clip.float().permute(0,3,1,2)/255, is_video=True,
+        lowres_attenuation=...)['imgs_w'] * 255).byte().permute(0,2,3,1) with the conversions fused into the resize and tail
+        kernels (3 B/pixel instead of 12 B/pixel through HBM, no fp32 copy of the clip)."""
+        if clip.dtype != torch.uint8 or clip.dim() != 4 or clip.shape[-1] != 3:
+            raise ValueError("embed_u8 wants a uint8 RGB24 clip [F, H, W, 3]")
+        if not self.clamp:
+            raise NotImplementedError("uint8 output needs clamp=True ((x * 255).byte() is undefined outside [0, 1])")
+        if msgs is None:
+            msgs = self.get_random_msg()
+        else:
+            assert msgs.shape[0] == 1, "Message should be unique"
+        if self.video_mode not in N.VIDEO_MODES:
+            raise ValueError(f"unknown video_mode {self.video_mode}")
+        eng = self._engine()
+        aa = _antialias_flag(interpolation)
+        x = clip.to(eng.dev).contiguous()
+        out = torch.empty_like(x)
+        mi = _msgs_i32(msgs, eng.dev)
+        step, ck = int(self.step_size), int(self.chunk_size)
+        span = ck * step
+        for a in range(0, x.shape[0], span):
+            b = min(x.shape[0], a + span)
+            self._embed_frames(eng, x[a:b], mi, out[a:b], step=step, video_mode=N.VIDEO_MODES[self.video_mode], antialias=aa,
+                               lowres=lowres_attenuation)
+        return {"imgs_w": out.to(clip.device), "msgs": msgs[0:1].repeat(len(clip), 1)}
+
+    @torch.no_grad()
+    def detect_u8(self, clip: torch.Tensor, interpolation: dict = None) -> dict:
+        """inference_streaming.py:119-125 (`detect_video_clip`): uint8 [F,H,W,3] -> {'preds': [F, 1+nbits]}."""
+        if clip.dtype != torch.uint8 or clip.dim() != 4 or clip.shape[-1] != 3:
+            raise ValueError("detect_u8 wants a uint8 RGB24 clip [F, H, W, 3]")
+        eng = self._engine()
+        aa = _antialias_flag(interpolation)
+        x = clip.to(eng.dev).contiguous()
+        if x.shape[0] == 0:
+            return {"preds": torch.zeros((0, self.embedder.cfg.nbits + 1), device=clip.device)}
+        S = (self.img_size, self.img_size)
+        ck = max(1, int(self.chunk_size))
+        preds = [self._detect_frames(eng, x[a:a + ck], S, aa) for a in range(0, x.shape[0], ck)]
+        return {"preds": torch.cat(preds, dim=0).to(clip.device)}
 
     def extract_message(self, imgs: torch.Tensor, aggregation: str = "avg",
                         interpolation: dict = {"mode": "bilinear", "align_corners": False, "antialias": False}) -> torch.Tensor:

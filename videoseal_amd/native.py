@@ -22,7 +22,7 @@ VIDEO_MODES = {"repeat": 0, "alternate": 1, "interpolate": 2}
 
 EXPORTS = [
     "vs_version", "vs_arch", "vs_error_string", "vs_sizeof_conv_desc", "vs_sizeof_tail_desc", "vs_conv_gemm", "vs_layernorm_act", "vs_dwconv7_ln", "vs_grn_scale",
-    "vs_upcat2x", "vs_msg_latent", "vs_broadcast_channels", "vs_outc_tanh", "vs_pool_linear", "vs_resize_pre",
+    "vs_upcat2x", "vs_msg_latent", "vs_broadcast_channels", "vs_outc_tanh", "vs_pool_linear", "vs_resize_pre", "vs_resize_pre_u8",
     "vs_jnd_heatmap", "vs_embed_tail", "vs_aug_color_scratch_floats", "vs_aug_color", "vs_aug_crop_flip", "vs_resize_nchw",
     "vs_gaussian_blur", "vs_median_filter", "vs_jpeg_workspace_bytes", "vs_jpeg_roundtrip",
 ]
@@ -59,7 +59,7 @@ class TailDesc(C.Structure):
         ("F", C.c_int32), ("H", C.c_int32), ("W", C.c_int32), ("S_h", C.c_int32), ("S_w", C.c_int32), ("Cd", C.c_int32),
         ("step", C.c_int32), ("video_mode", C.c_int32), ("total_key", C.c_int32),
         ("attenuate", C.c_int32), ("clamp", C.c_int32), ("antialias", C.c_int32),
-        ("scaling_i", C.c_float), ("scaling_w", C.c_float),
+        ("scaling_i", C.c_float), ("scaling_w", C.c_float), ("io_u8", C.c_int32), ("reserved_", C.c_int32),
     ]
 
 
@@ -91,6 +91,7 @@ def lib() -> C.CDLL:
         "vs_outc_tanh": [P, I64, I, I, I64, P, P, I, I, P, P],
         "vs_pool_linear": [P, I, I, I, I64, P, P, I, P, P],
         "vs_resize_pre": [P, I, I, I, I, I, I, I, P, F, F, P, I, P, P],
+        "vs_resize_pre_u8": [P, I, I, I, I, I, I, P, F, F, P, I, P, P],
         "vs_jnd_heatmap": [P, I, I, I, I64, I64, I64, I64, P, P, P],
         "vs_embed_tail": [C.POINTER(TailDesc), P],
         "vs_aug_color": [P, P, I, I, I, I, F, P, P],
