@@ -102,6 +102,9 @@ typedef struct vs_conv_desc {
   int64_t splitk_ld;        /*   partial sums of the K slices; splitk_ld >= N.  Summed in slice order (deterministic)  */
   int32_t split_k;          /*   0 / 1 = no K split                                                                    */
   int32_t reserved_;
+  float* sumsq_part;        /* optional (1x1, no phase 2 / residual / K split): [ceil(M/32)][N] sums of squares of the stored  */
+                            /*   values per 32-row group and column = GRN's ||x||^2 partials (common.py:166), see              */
+                            /*   vs_grn_scale_from_partials                                                                    */
 } vs_conv_desc_t;
 #define VS_CONV_FORCE_F32 0x10
 #define VS_CONV_FORCE_SPLIT 0x20
@@ -119,6 +122,10 @@ int vs_dwconv7_ln(const float* x, int B, int H, int W, int C, int64_t ld, const 
 
 /* GRN statistics: scale[b][c] = 1 + gamma[c] * Gx[b][c] / (mean_c Gx[b][.] + 1e-6), Gx = ||h[b,:,c]||_2.
  * common.py:166-168.  `partial` is workspace of nchunk*B*C floats, nchunk = ceil(HW/64). */
+/* The same from the partial sums a vs_conv_gemm launch left in sumsq_part ([B][HW/32][C], HW % 32 == 0): no second pass
+ * over the activations. */
+int vs_grn_scale_from_partials(const float* partial, int B, int HW, int C, const float* gamma, float* scale, int64_t scale_ld,
+                               void* stream);
 int vs_grn_scale(const float* h, int B, int HW, int C, int64_t ld, const float* gamma, float* partial,
                  float* scale, void* stream);
 

@@ -183,6 +183,34 @@ def test_conv_grn_transform_and_residual(eng, tile):
     assert rel_err(ra.t.cpu().view(B, HW, Nn), ref) < 2e-5
 
 
+@pytest.mark.parametrize("tile", [0, 1, 3, 5, 13, 0x41, 0x42])
+def test_conv_epilogue_grn_partials(eng, tile):
+    """pwconv1 + GELU with the GRN sum-of-squares partials written by the epilogue, then vs_grn_scale_from_partials == common.py:166-168."""
+    if tile >= 6 and not eng.use_split:
+        pytest.skip("split back-end only")
+    g = torch.Generator().manual_seed(9)
+    B, H, W, K, Nn = 3, 8, 12, 64, 200         # HW = 96 = 3 groups of 32 rows per frame
+    x = torch.randn(B, H * W, K, generator=g)
+    w = torch.randn(Nn, K, generator=g) / math.sqrt(K)
+    bias = torch.randn(Nn, generator=g)
+    gamma = torch.randn(Nn, generator=g)
+    h = F.gelu(F.linear(x, w, bias))
+    gx = torch.linalg.vector_norm(h, dim=1, keepdim=True)                     # [B,1,N]
+    ref_scale = 1 + gamma * (gx / (gx.mean(dim=-1, keepdim=True) + 1e-6))
+    xa = Act(x.to(DEV).contiguous(), B, H, W, K, K)
+    wt, cp = pack_conv(w[:, :, None, None].to(DEV), K)
+    out = eng.new_act("gh", B, H, W, Nn)
+    guard = torch.full((B * (H * W // 32) * Nn + 4096,), float("nan"), device=DEV)      # rows 288 = 2.25 tiles of 128: ragged last tile
+    part = guard[:B * (H * W // 32) * Nn]
+    eng.conv(xa, ConvW(wt, bias.to(DEV), Nn, 1, 1, cp), out, act=N.ACT_GELU, tile_hint=tile, sumsq=part)
+    scale = torch.empty(B, out.ld, device=DEV)
+    N.check(eng.lib.vs_grn_scale_from_partials(N.ptr(part), B, H * W, Nn, N.ptr(gamma.to(DEV)), N.ptr(scale), out.ld, N.stream()), "grn")
+    torch.cuda.synchronize()
+    assert rel_err(out.t.view(B, H * W, out.ld)[..., :Nn].cpu(), h) < 2e-5
+    assert rel_err(scale.cpu()[:, :Nn], ref_scale[:, 0]) < 2e-5
+    assert torch.isnan(guard[part.numel():]).all()          # nothing written past the [M/32][N] partials
+
+
 GEMM_PC_CASES = [
     # B, H, W, K, N, act, grn, res, tile, split_k
     (2, 16, 16, 96, 384, 2, False, False, 1, 1),      # pwconv1-like: GELU epilogue

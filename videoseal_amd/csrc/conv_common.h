@@ -75,4 +75,26 @@ __device__ __forceinline__ void apply_act_all(f32x16 (&acc)[TM][TN], const float
 }
 
 
+// GRN statistics fused into the producing GEMM (common.py:166): per 32-row group and output column the sum of squares of the
+// values this wave is about to store.  C/D layout of the 32x32 MFMA: col = lane&31, row = (e&3) + 8*(e>>2) + 4*(lane>>5);
+// fixed order (16 rows in a lane, then the other half-wave) -> deterministic.  part is [M/32][N].
+template <int TM, int TN>
+__device__ __forceinline__ void write_sumsq(const f32x16 (&acc)[TM][TN], float* part, const int N, const int64_t mrow0, const int M,
+                                            const int (&col)[TN], const int g) {
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      float s = 0.f;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int64_t m = mrow0 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * g;
+        const float v = acc[i][j][e];
+        s += m < M ? v * v : 0.f;
+      }
+      s += __shfl_xor(s, 32);
+      if (g == 0 && col[j] < N && mrow0 + i * 32 < M) part[((mrow0 + i * 32) >> 5) * N + col[j]] = s;   // groups past M do not exist
+    }
+}
+
 }  // namespace vsconv

@@ -349,6 +349,7 @@ __global__ __launch_bounds__(NT, (TM * TN > 4 ? 1 : 2)) void conv_gemm_kernel(co
     for (int j = 0; j < TN; ++j) zero[j] = 0.f;
     apply_act_all<TM, TN>(acc, bias1, zero, d.act);
   }
+  if (d.sumsq_part) write_sumsq<TM, TN>(acc, d.sumsq_part, d.N, m0 + (int64_t)wm * TM * 32, M, col, g);
 #pragma unroll
   for (int i = 0; i < TM; ++i) {
 #pragma unroll
@@ -444,10 +445,12 @@ extern "C" int vs_conv_gemm(const vs_conv_desc_t* dp, void* stream) {
     VS_REQUIRE(d.KH == 1 && d.KW == 1 && d.SH == 1 && d.SW == 1 && d.PH == 0 && d.PW == 0 && d.Ho == d.H && d.Wo == d.W && !d.in2);
     VS_REQUIRE(d.Cin % 32 == 0 && d.CinP == d.Cin && d.in_sy == (int64_t)d.W * d.in_sx && d.in_sb == (int64_t)d.H * d.in_sy);
     if (d.a_scale) VS_REQUIRE((d.H * d.W) % 64 == 0);
+    if (d.sumsq_part) VS_REQUIRE(d.split_k <= 1 && !d.res);
     if (d.split_k > 1) VS_REQUIRE(d.splitk_ws && d.splitk_ld >= d.N && d.split_k <= d.CinP / 32);
     return vs_gemm1x1_pc_dispatch(d, tile, st);
   }
   VS_REQUIRE(d.split_k <= 1);
+  if (d.sumsq_part) VS_REQUIRE(d.KH == 1 && d.KW == 1 && !d.in2 && !d.res && !patch_ok);
   if (tile == 0 && patch_ok && d.W % 16 == 0 && d.H % 8 == 0) {
     const bool blk_ok = d.wt_blk && (!d.in2 || d.wt2_blk) && ((uintptr_t)d.wt_blk & 15) == 0;
     if (blk_ok && d.N >= 128) return vs_conv3x3_patch_pc_dispatch(d, d.N % 192 == 0 ? 16 : 15, st);   // wave-specialised for wide layers

@@ -267,6 +267,7 @@ __global__ __launch_bounds__(512, 2) void gemm1x1_pc_kernel(const vs_conv_desc_t
     zero[j] = 0.f;
   }
   apply_act_all<TM, TN>(acc, bias1, zero, d.act);
+  if (d.sumsq_part) write_sumsq<TM, TN>(acc, d.sumsq_part, d.N, m0 + (int64_t)wm * TM * 32, M, col, g);
 #pragma unroll
   for (int i = 0; i < TM; ++i) {
 #pragma unroll

@@ -164,15 +164,17 @@ __global__ __launch_bounds__(256) void grn_partial_kernel(const float* __restric
   for (int r = r0; r < r1; ++r, p += ld) s += (*p) * (*p);
   partial[((int64_t)chunk * B + b) * C + c] = s;
 }
+// frame_major: partial is [B][nchunk][C] (written by the GEMM epilogue) instead of [nchunk][B][C]
 __global__ __launch_bounds__(256) void grn_finish_kernel(const float* __restrict__ partial, int nchunk, int B, int C,
                                                          const float* __restrict__ gamma, float* __restrict__ scale,
-                                                         int64_t sld) {
+                                                         int64_t sld, int frame_major) {
   __shared__ float red[256];
   const int b = blockIdx.x;
   float local = 0.f;
   for (int c = threadIdx.x; c < C; c += 256) {
     float s = 0.f;
-    for (int k = 0; k < nchunk; ++k) s += partial[((int64_t)k * B + b) * C + c];
+    if (frame_major) for (int k = 0; k < nchunk; ++k) s += partial[((int64_t)b * nchunk + k) * C + c];
+    else for (int k = 0; k < nchunk; ++k) s += partial[((int64_t)k * B + b) * C + c];
     const float gx = sqrtf(s);
     scale[(int64_t)b * sld + c] = gx;
     local += gx;
@@ -342,7 +344,15 @@ extern "C" int vs_grn_scale(const float* h, int B, int HW, int C, int64_t ld, co
   hipLaunchKernelGGL(grn_partial_kernel, dim3((unsigned)((C + 255) / 256), (unsigned)nchunk, (unsigned)B), dim3(256), 0,
                      (hipStream_t)stream, h, HW, C, ld, partial, B);
   hipLaunchKernelGGL(grn_finish_kernel, dim3((unsigned)B), dim3(256), 0, (hipStream_t)stream, partial, nchunk, B, C, gamma,
-                     scale, ld);
+                     scale, ld, 0);
+  return vs_launch_status();
+}
+
+extern "C" int vs_grn_scale_from_partials(const float* partial, int B, int HW, int C, const float* gamma, float* scale,
+                                          int64_t scale_ld, void* stream) {
+  VS_REQUIRE(partial && gamma && scale && B > 0 && HW > 0 && HW % 32 == 0 && C > 0 && scale_ld >= C);
+  hipLaunchKernelGGL(grn_finish_kernel, dim3((unsigned)B), dim3(256), 0, (hipStream_t)stream, partial, HW / 32, B, C, gamma,
+                     scale, scale_ld, 1);
   return vs_launch_status();
 }
 

@@ -267,7 +267,7 @@ class HipEngine:
     def conv(self, x: Act, w: ConvW, out: Act, *, stride=1, pad=0, pad_mode=N.PAD_ZERO, act=N.ACT_NONE, out_coff=0,
              n_store=None, res: Optional[Act] = None, in2: Optional[Act] = None, w2: Optional[ConvW] = None,
              a_scale=None, a_scale_ld=0, a_shift=None, geom=None, tile_hint=0, prof: Optional[str] = None,
-             split_k: Optional[int] = None):
+             split_k: Optional[int] = None, sumsq: Optional[torch.Tensor] = None):
         d = N.ConvDesc()
         if geom is None:
             sh = sw = stride
@@ -298,6 +298,9 @@ class HipEngine:
             if in2 is not None:
                 d.wt2_split = N.ptr(w2.with_split().split)
                 d.wt2_blk = N.ptr(w2.with_blk().blk)
+        if sumsq is not None:       # GRN partial sums of squares from the epilogue ([rows/32][N])
+            d.sumsq_part = N.ptr(sumsq)
+            split_k = 1
         if split_k is None:     # static, shape-only rule (never timing-based: a K split changes the summation order)
             split_k = self._split_k_rule(d) if (tile_hint == 0 and self._gemm_pc_ok(d)) else 1
         if split_k > 1:
@@ -341,7 +344,7 @@ class HipEngine:
     def _pick_tile(self, d: "N.ConvDesc", w: ConvW, out: Act) -> int:
         """time the 4-wave tile shapes once per conv signature (on a scratch output) and remember the fastest."""
         key = (d.B, d.H, d.W, d.Cin, d.KH, d.KW, d.SH, d.SW, d.pad_mode, d.Ho, d.Wo, d.N, d.CinP, bool(d.in2), d.Cin2P,
-               bool(d.a_scale), bool(d.res), d.act, bool(d.wt_split), d.split_k)
+               bool(d.a_scale), bool(d.res), d.act, bool(d.wt_split), d.split_k, bool(d.sumsq_part))
         best = self._tile_cache.get(key)
         if best is not None:
             return best
@@ -486,9 +489,15 @@ class HipEngine:
             for blk in X["stages"][sti]:
                 N.check(L.vs_dwconv7_ln(N.ptr(cur.t), B, cur.H, cur.W, Cc, cur.ld, N.ptr(blk["wdw"]), N.ptr(blk["bdw"]), N.ptr(blk["lnw"]),
                                         N.ptr(blk["lnb"]), 1e-6, N.ptr(tn.t), tn.ld, st), "vs_dwconv7_ln")
-                self.conv(tn, blk["pw1"], hh, act=N.ACT_GELU)
-                N.check(L.vs_grn_scale(N.ptr(hh.t), B, HW, 4 * Cc, hh.ld, N.ptr(blk["gamma"]), N.ptr(part), N.ptr(scale), st),
-                        "vs_grn_scale")
+                if HW % 32 == 0:      # ||h||^2 partials come out of pwconv1's epilogue: no second pass over h
+                    part32 = self.buf(f"st{sti}.gp32", B * (HW // 32) * 4 * Cc)
+                    self.conv(tn, blk["pw1"], hh, act=N.ACT_GELU, sumsq=part32)
+                    N.check(L.vs_grn_scale_from_partials(N.ptr(part32), B, HW, 4 * Cc, N.ptr(blk["gamma"]), N.ptr(scale), hh.ld, st),
+                            "vs_grn_scale_from_partials")
+                else:
+                    self.conv(tn, blk["pw1"], hh, act=N.ACT_GELU)
+                    N.check(L.vs_grn_scale(N.ptr(hh.t), B, HW, 4 * Cc, hh.ld, N.ptr(blk["gamma"]), N.ptr(part), N.ptr(scale), st),
+                            "vs_grn_scale")
                 self.conv(hh, blk["pw2"], cur, res=cur, a_scale=scale, a_scale_ld=hh.ld, a_shift=blk["beta"])
         hc = self.new_act("head.c", B, cur.H, cur.W, d[-1])
         self.conv(cur, X["head_conv"], hc, pad=1, pad_mode=N.PAD_REFLECT)

@@ -21,7 +21,7 @@ CONV_FORCE_F32, CONV_FORCE_SPLIT, CONV_TILE_HI = 0x10, 0x20, 0x40
 VIDEO_MODES = {"repeat": 0, "alternate": 1, "interpolate": 2}
 
 EXPORTS = [
-    "vs_version", "vs_arch", "vs_error_string", "vs_sizeof_conv_desc", "vs_sizeof_tail_desc", "vs_conv_gemm", "vs_layernorm_act", "vs_dwconv7_ln", "vs_grn_scale",
+    "vs_version", "vs_arch", "vs_error_string", "vs_sizeof_conv_desc", "vs_sizeof_tail_desc", "vs_conv_gemm", "vs_layernorm_act", "vs_dwconv7_ln", "vs_grn_scale", "vs_grn_scale_from_partials",
     "vs_upcat2x", "vs_msg_latent", "vs_broadcast_channels", "vs_outc_tanh", "vs_pool_linear", "vs_resize_pre", "vs_resize_pre_u8",
     "vs_jnd_heatmap", "vs_embed_tail", "vs_aug_color_scratch_floats", "vs_aug_color", "vs_aug_crop_flip", "vs_resize_nchw",
     "vs_gaussian_blur", "vs_median_filter", "vs_jpeg_workspace_bytes", "vs_jpeg_roundtrip",
@@ -48,6 +48,7 @@ class ConvDesc(C.Structure):
         ("out", C.c_void_p), ("out_ld", C.c_int64), ("out_coff", C.c_int32), ("tile_hint", C.c_int32),
         ("wt_split", C.c_void_p), ("wt2_split", C.c_void_p), ("wt_blk", C.c_void_p), ("wt2_blk", C.c_void_p),
         ("splitk_ws", C.c_void_p), ("splitk_ld", C.c_int64), ("split_k", C.c_int32), ("reserved_", C.c_int32),
+        ("sumsq_part", C.c_void_p),
     ]
 
 
@@ -85,6 +86,7 @@ def lib() -> C.CDLL:
         "vs_layernorm_act": [P, I64, I, I64, P, P, F, I, P, I64, P],
         "vs_dwconv7_ln": [P, I, I, I, I, I64, P, P, P, P, F, P, I64, P],
         "vs_grn_scale": [P, I, I, I, I64, P, P, P, P],
+        "vs_grn_scale_from_partials": [P, I, I, I, P, P, I64, P],
         "vs_upcat2x": [P, I, I64, P, I, I64, F, I, I, I, P, I64, P],
         "vs_msg_latent": [P, P, I, I, I, P, P],
         "vs_broadcast_channels": [P, I, I, P, I, I, I64, I, P],
