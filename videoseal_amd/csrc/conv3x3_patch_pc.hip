@@ -200,13 +200,14 @@ __global__ __launch_bounds__(512, 2) void conv3x3_patch_pc_kernel(const vs_conv_
 
     load_patch(0);
     store_patch(0, 0, -1);
+    if (spt > 1 && !(abl & 4)) load_patch(1);          // patch cc+1 is requested at tap 8 of chunk cc-1: three steps before its first use
     __syncthreads();
     int cc = 0, tap = 0;
     for (int s = 0; s < total; ++s) {
       if (abl & 4) {
       } else if (s < n1) {
-        if (tap == 0 && cc + 1 < spt) load_patch(cc + 1);                 // next chunk's patch: loads at tap 0 ...
-        if (tap >= 2 && tap < 2 + NPI && cc + 1 < spt) store_patch((cc + 1) & 1, tap, 2);   // ... split + stored at taps 2..7 (other buffer)
+        if (tap >= 2 && tap < 2 + NPI && cc + 1 < spt) store_patch((cc + 1) & 1, tap, 2);   // split + stored at taps 2..7 (other buffer)
+        if (tap == 8 && cc + 2 < spt) load_patch(cc + 2);                 // registers are free again: request the patch after next
         if (n2 > 0 && cc == spt - 1) {
           if (tap == 1) load_rows2(0);
           if (tap == 8) { store_rows2(spt & 1); if (n2 > 1) load_rows2(1); }   // chunk "spt" = first in2 chunk
