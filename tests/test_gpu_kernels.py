@@ -28,6 +28,39 @@ def from_nhwc(a: Act, Cc=None):
     return a.t.view(a.B, a.H, a.W, a.ld)[..., :Cc].permute(0, 3, 1, 2).cpu()
 
 
+@pytest.mark.parametrize("cfg", [(15, 2, True), (0x40, 3, True), (15, 4, False), (0x40, 6, False), (15, 8, True)])
+def test_patch_pc_split_k(eng, cfg):
+    """wave-specialised 3x3 kernel with the K loop cut into chunk slices (+ one slice for the fused 1x1 res_conv) and the
+    shared split-K epilogue: relu(conv3x3(t)+b) + conv1x1(x)+b2 + res, written at a channel offset."""
+    if not eng.use_split:
+        pytest.skip("split back-end only")
+    tile, sk, two = cfg
+    g = torch.Generator().manual_seed(17)
+    B, Cm, Cx, H, W, Co = 2, 384, 48, 16, 32, 200
+    t = torch.randn(B, Cm, H, W, generator=g)
+    x = torch.randn(B, Cx, H, W, generator=g)
+    w1 = torch.randn(Co, Cm, 3, 3, generator=g) / math.sqrt(Cm * 9)
+    b1 = torch.randn(Co, generator=g)
+    w2 = torch.randn(Co, Cx, 1, 1, generator=g) / math.sqrt(Cx)
+    b2 = torch.randn(Co, generator=g)
+    res = torch.randn(B, Co, H, W, generator=g)
+    ref = F.relu(F.conv2d(t, w1, b1, padding=1)) + res
+    if two:
+        ref = ref + F.conv2d(x, w2, b2)
+    ta, xa, ra = to_nhwc(t), to_nhwc(x), to_nhwc(res)
+    wt1, cp1 = pack_conv(w1.to(DEV), ta.ld)
+    wt2, cp2 = pack_conv(w2.to(DEV), xa.ld)
+    out = eng.new_act("wide2", B, H, W, 208)
+    out.t.fill_(7.0)
+    kw = dict(in2=xa, w2=ConvW(wt2, b2.to(DEV), Co, 1, 1, cp2)) if two else {}
+    eng.conv(ta, ConvW(wt1, b1.to(DEV), Co, 3, 3, cp1), out, pad=1, act=N.ACT_RELU, res=ra, out_coff=4, n_store=Co, tile_hint=tile,
+             split_k=sk, **kw)
+    torch.cuda.synchronize()
+    full = out.t.view(B, H, W, 208).cpu()
+    assert rel_err(full[..., 4:204].permute(0, 3, 1, 2), ref) < 2e-5
+    assert (full[..., :4] == 7.0).all() and (full[..., 204:] == 7.0).all()
+
+
 class Eng(HipEngine):
     """engine without a model: only the kernel wrappers + workspace."""
 

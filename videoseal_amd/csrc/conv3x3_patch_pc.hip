@@ -15,6 +15,8 @@
 #include <type_traits>
 #include "conv_common.h"
 
+int vs_splitk_epilogue(const vs_conv_desc_t& d, int M, hipStream_t st);   // gemm1x1_pc.hip
+
 namespace {
 
 using namespace vsconv;
@@ -33,7 +35,7 @@ __device__ __forceinline__ void dma_1k(const char* gp, unsigned char* lds_base) 
 
 template <int TN>
 __global__ __launch_bounds__(512, 2) void conv3x3_patch_pc_kernel(const vs_conv_desc_t d, const int tiles_x, const int tiles_y,
-                                                                  const int mtiles) {
+                                                                  const int mtiles, const int ntiles, const int cps) {
   constexpr int TM = 2;
   constexpr int BN = 64 * TN;
   constexpr int NG = BN / 32;                            // 32-row weight groups per tile
@@ -49,16 +51,25 @@ __global__ __launch_bounds__(512, 2) void conv3x3_patch_pc_kernel(const vs_conv_
   const int r = lane & 31, g = lane >> 5;
 
   const int bm = blockIdx.x % mtiles;
-  const int bn = blockIdx.x / mtiles;
+  const int bn = (blockIdx.x / mtiles) % ntiles;
+  const int ks = blockIdx.x / (mtiles * ntiles);        // K slice (split_k > 1), see below
   const int n0 = bn * BN;
   const int tx = bm % tiles_x;
   const int ty = (bm / tiles_x) % tiles_y;
   const int fb = bm / (tiles_x * tiles_y);
   const int y0 = ty * TH, x0 = tx * TW;
 
-  const int spt = d.CinP / BK;
+  // split_k > 1 (few output tiles, e.g. 4 key frames of a streaming chunk: 64 tiles for 256 CUs): slice ks < split_k
+  // accumulates the 16-channel chunks [ks*cps, (ks+1)*cps) of phase 1; one extra slice (ks == split_k) does the 1x1
+  // second phase.  All of them store raw partial sums; splitk_epilogue_kernel applies bias / activation / residual.
+  const int spt_all = d.CinP / BK;
+  const int n1_all = 9 * spt_all;
+  const int sk = d.split_k > 1 ? d.split_k : 1;
+  const bool p2_slice = sk > 1 && ks == sk;
+  const int c_off = (sk > 1 && !p2_slice) ? ks * cps : 0;
+  const int spt = p2_slice ? 0 : (sk > 1 ? min(cps, spt_all - c_off) : spt_all);
   const int n1 = 9 * spt;
-  const int n2 = d.in2 ? d.Cin2P / BK : 0;
+  const int n2 = (d.in2 && (sk == 1 || p2_slice)) ? d.Cin2P / BK : 0;
   const int total = n1 + n2;
   const int abl = d.tile_hint >> 8;   // debug ablation (tools/bench_ppc.py): 1 no weight DMA, 4 no activation staging
 
@@ -82,12 +93,12 @@ __global__ __launch_bounds__(512, 2) void conv3x3_patch_pc_kernel(const vs_conv_
       const int gi = g0 + bw * NGW + q;
       gsel[q] = gi < ngroups ? gi : ngroups - 1;         // tile wider than N: re-read a valid group (columns are discarded)
     }
-    auto dma_tile = [&, n1, n2, bw, lane](const int t) __attribute__((always_inline)) {
+    auto dma_tile = [&, n1, n2, n1_all, c_off, bw, lane](const int t) __attribute__((always_inline)) {
       unsigned char* st = Bring + (t % NRING) * B_STAGE;
       // (never select between two captured variables here: see conv_gemm_pc.hip)
       const int ph2 = t >= n1 ? 1 : 0;
-      const int nsel = n1 + ph2 * (__builtin_amdgcn_readfirstlane(n2) - n1);     // blocks per group in this phase
-      const int64_t off = (int64_t)ph2 * w2delta + (int64_t)(t - ph2 * n1) * 3072 + lane * 16;
+      const int nsel = n1_all + ph2 * (__builtin_amdgcn_readfirstlane(n2) - n1_all);     // blocks per group in this phase
+      const int64_t off = (int64_t)ph2 * w2delta + (int64_t)(t - ph2 * n1 + (1 - ph2) * c_off * 9) * 3072 + lane * 16;
 #pragma unroll
       for (int q = 0; q < NGW; ++q) {
         const char* gp = wblk + off + (int64_t)gsel[q] * nsel * 3072;
@@ -151,7 +162,8 @@ __global__ __launch_bounds__(512, 2) void conv3x3_patch_pc_kernel(const vs_conv_
     f32x4 rp[NPI];          // patch registers
     f32x4 rq[NQ];           // in2 rows
 
-    auto load_patch = [&, pt](const int cc) __attribute__((always_inline)) {
+    auto load_patch = [&, pt, c_off](const int ccl) __attribute__((always_inline)) {
+      const int cc = c_off + ccl;                                         // global 16-channel chunk
       const char* base = reinterpret_cast<const char*>(d.in) + (int64_t)cc * (BK * 4);
       const bool cok = (cc * BK + (pt & 3) * 4) < d.Cin;
 #pragma unroll
@@ -198,9 +210,15 @@ __global__ __launch_bounds__(512, 2) void conv3x3_patch_pc_kernel(const vs_conv_
       }
     };
 
-    load_patch(0);
-    store_patch(0, 0, -1);
-    if (spt > 1 && !(abl & 4)) load_patch(1);          // patch cc+1 is requested at tap 8 of chunk cc-1: three steps before its first use
+    if (spt > 0) {
+      load_patch(0);
+      store_patch(0, 0, -1);
+      if (spt > 1 && !(abl & 4)) load_patch(1);          // patch cc+1 is requested at tap 8 of chunk cc-1: three steps before its first use
+    } else {                                             // phase-2-only slice: first in2 chunk goes straight to buffer 0
+      load_rows2(0);
+      store_rows2(0);
+      if (n2 > 1) load_rows2(1);
+    }
     __syncthreads();
     int cc = 0, tap = 0;
     for (int s = 0; s < total; ++s) {
@@ -289,28 +307,52 @@ __global__ __launch_bounds__(512, 2) void conv3x3_patch_pc_kernel(const vs_conv_
   };
 
   __syncthreads();                 // prologue of the producers
-  load_frags(F0, 0);
-  __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0): otherwise hipcc drains the PREFETCH below before the first MFMA of every iteration
-  // phase 1: the fragment reads of step s+1 are in flight while the MFMAs of step s issue (straight-line body, no
-  // conditionals: the compiler's waitcnt placement is exact only then)
   int s = 0;
-  for (; s + 2 < n1; s += 2) {
-    load_frags(F1, s + 1);
-    mfma_all(F0);
-    __syncthreads();
-    load_frags(F0, s + 2);
-    mfma_all(F1);
-    __syncthreads();
+  if (n1 > 0) {
+    load_frags(F0, 0);
+    __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0): otherwise hipcc drains the PREFETCH below before the first MFMA of every iteration
+    // phase 1: the fragment reads of step s+1 are in flight while the MFMAs of step s issue (straight-line body, no
+    // conditionals: the compiler's waitcnt placement is exact only then)
+    for (; s + 2 < n1; s += 2) {
+      load_frags(F1, s + 1);
+      mfma_all(F0);
+      __syncthreads();
+      load_frags(F0, s + 2);
+      mfma_all(F1);
+      __syncthreads();
+    }
+    if (s + 1 < n1) {
+      load_frags(F1, s + 1);
+      mfma_all(F0);
+      __syncthreads();
+      mfma_all(F1);
+      __syncthreads();
+    } else {
+      mfma_all(F0);
+      __syncthreads();
+    }
   }
-  if (s + 1 < n1) {
-    load_frags(F1, s + 1);
-    mfma_all(F0);
-    __syncthreads();
-    mfma_all(F1);
-    __syncthreads();
-  } else {
-    mfma_all(F0);
-    __syncthreads();
+  if (sk > 1) {                    // K slice: raw partial sums -> workspace [slice][M][splitk_ld]
+    for (s = n1; s < total; ++s) {
+      load_frags(F0, s);
+      mfma_all(F0);
+      __syncthreads();
+    }
+    const int64_t Mrows = (int64_t)d.B * d.H * d.W;
+    float* ws = d.splitk_ws + (int64_t)ks * Mrows * d.splitk_ld;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int p = (wm * TM + i) * 32 + (e & 3) + 8 * (e >> 2) + 4 * g;
+        const int y = y0 + (p >> 4), x = x0 + (p & 15);
+        if (y >= d.H || x >= d.W) continue;
+        const int64_t m = ((int64_t)fb * d.H + y) * d.W + x;
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          if (col[j] < d.N) ws[m * d.splitk_ld + col[j]] = acc[i][j][e];
+      }
+    return;
   }
   if (n2 > 0) {
     apply_act_all<TM, TN>(acc, bias1, bias2, d.act);
@@ -353,10 +395,18 @@ template <int TN>
 int launch_ppc(const vs_conv_desc_t& d, hipStream_t st) {
   constexpr int BN = 64 * TN;
   const int tiles_x = (d.W + TW - 1) / TW, tiles_y = (d.H + TH - 1) / TH;
-  const int64_t mt = (int64_t)d.B * tiles_x * tiles_y, nt = cdiv64(d.n_store, BN);
-  if (mt * nt > 0x7fffffffLL) return VS_ERR_UNSUPPORTED;
-  hipLaunchKernelGGL((conv3x3_patch_pc_kernel<TN>), dim3((unsigned)(mt * nt)), dim3(512), 0, st, d, tiles_x, tiles_y, (int)mt);
-  return vs_launch_status();
+  const int sk = d.split_k > 1 ? d.split_k : 1;
+  const int64_t mt = (int64_t)d.B * tiles_x * tiles_y, nt = cdiv64(sk > 1 ? d.N : d.n_store, BN);
+  const int spt = d.CinP / BK;
+  const int cps = (spt + sk - 1) / sk;
+  if (sk > 1 && (int64_t)(sk - 1) * cps >= spt) return VS_ERR_BAD_ARG;       // an empty K slice
+  const int slices = sk > 1 ? sk + (d.in2 ? 1 : 0) : 1;
+  if (mt * nt * slices > 0x7fffffffLL) return VS_ERR_UNSUPPORTED;
+  hipLaunchKernelGGL((conv3x3_patch_pc_kernel<TN>), dim3((unsigned)(mt * nt * slices)), dim3(512), 0, st, d, tiles_x, tiles_y, (int)mt,
+                     (int)nt, cps);
+  int rc = vs_launch_status();
+  if (rc != VS_OK || sk == 1) return rc;
+  return vs_splitk_epilogue(d, (int)((int64_t)d.B * d.H * d.W), st);
 }
 
 }  // namespace

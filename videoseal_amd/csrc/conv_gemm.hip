@@ -438,6 +438,7 @@ extern "C" int vs_conv_gemm(const vs_conv_desc_t* dp, void* stream) {
   }
   if (tile == 15 || tile == 16 || tile == 19) {   // wave-specialised patch kernel
     VS_REQUIRE(patch_ok && d.wt_blk && (!d.in2 || d.wt2_blk) && ((uintptr_t)d.wt_blk & 15) == 0);
+    if (d.split_k > 1) VS_REQUIRE(d.splitk_ws && d.splitk_ld >= d.N && d.split_k <= d.CinP / 16 && !d.sumsq_part);
     return vs_conv3x3_patch_pc_dispatch(d, tile, st);
   }
   if (tile == 17 || tile == 18) {   // wave-specialised 1x1 GEMM: dense rows, whole 32-wide K pairs, no second phase

@@ -16,6 +16,8 @@
 // partial sums to the workspace, vs_conv_gemm then runs splitk_epilogue_kernel (fixed summation order -> deterministic).
 #include "conv_common.h"
 
+int vs_splitk_epilogue(const vs_conv_desc_t& d, int M, hipStream_t st);
+
 namespace {
 
 using namespace vsconv;
@@ -289,7 +291,8 @@ __global__ __launch_bounds__(512, 2) void gemm1x1_pc_kernel(const vs_conv_desc_t
   }
 }
 
-// out = act(sum_ks ws[ks] + bias) (+ res); columns in [N, n_store) are written as zero.  One thread per (row, 4 columns).
+// out = act(sum_ks ws[ks] + bias) [+ ws[split_k] + bias2 : the 1x1 second phase of the patch kernel] (+ res); columns in
+// [N, n_store) are written as zero.  One thread per (row, 4 columns).  Same epilogue order as the kernels themselves.
 __global__ __launch_bounds__(256) void splitk_epilogue_kernel(const vs_conv_desc_t d, const int M) {
   const int ncol4 = (d.n_store + 3) / 4;
   const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -307,6 +310,7 @@ __global__ __launch_bounds__(256) void splitk_epilogue_kernel(const vs_conv_desc
       if (d.act == VS_ACT_RELU) v = fmaxf(v, 0.f);
       else if (d.act == VS_ACT_GELU) v = 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
       else if (d.act == VS_ACT_TANH) v = tanhf(v);
+      if (d.in2) v += d.splitk_ws[((int64_t)d.split_k * M + m) * d.splitk_ld + n] + (d.bias2 ? d.bias2[n] : 0.f);
       if (d.res) v += d.res[m * d.res_ld + n];
     }
     d.out[m * d.out_ld + d.out_coff + n] = v;
@@ -326,12 +330,16 @@ int launch_g(const vs_conv_desc_t& d, hipStream_t st) {
   hipLaunchKernelGGL((gemm1x1_pc_kernel<TN>), dim3((unsigned)(mt * nt * sk)), dim3(512), 0, st, d, (int)M, (int)mt, (int)nt, pps);
   int rc = vs_launch_status();
   if (rc != VS_OK || sk == 1) return rc;
-  const int64_t items = M * ((d.n_store + 3) / 4);
-  hipLaunchKernelGGL(splitk_epilogue_kernel, dim3((unsigned)cdiv64(items, 256)), dim3(256), 0, st, d, (int)M);
-  return vs_launch_status();
+  return vs_splitk_epilogue(d, (int)M, st);
 }
 
 }  // namespace
+
+int vs_splitk_epilogue(const vs_conv_desc_t& d, int M, hipStream_t st) {
+  const int64_t items = (int64_t)M * ((d.n_store + 3) / 4);
+  hipLaunchKernelGGL(splitk_epilogue_kernel, dim3((unsigned)cdiv64(items, 256)), dim3(256), 0, st, d, M);
+  return vs_launch_status();
+}
 
 // tile 17 = 128 x 128, tile 18 = 128 x 192.  Preconditions are checked by vs_conv_gemm.
 int vs_gemm1x1_pc_dispatch(const vs_conv_desc_t& d, int tile, hipStream_t st) {

@@ -164,29 +164,44 @@ __global__ __launch_bounds__(256) void grn_partial_kernel(const float* __restric
   for (int r = r0; r < r1; ++r, p += ld) s += (*p) * (*p);
   partial[((int64_t)chunk * B + b) * C + c] = s;
 }
-// frame_major: partial is [B][nchunk][C] (written by the GEMM epilogue) instead of [nchunk][B][C]
-__global__ __launch_bounds__(256) void grn_finish_kernel(const float* __restrict__ partial, int nchunk, int B, int C,
-                                                         const float* __restrict__ gamma, float* __restrict__ scale,
-                                                         int64_t sld, int frame_major) {
+// frame_major: partial is [B][nchunk][C] (written by the GEMM epilogue) instead of [nchunk][B][C].
+// One workgroup of 1024 threads per frame: 256 channels x 4 groups of chunks at a time; every group adds its chunks in
+// order and the four group sums are combined in a fixed order -> deterministic, with 4x the loads in flight of a
+// one-thread-per-channel loop (frame-major partials are up to HW/32 = 128 chunks deep).
+__global__ __launch_bounds__(1024) void grn_finish_kernel(const float* __restrict__ partial, int nchunk, int B, int C,
+                                                          const float* __restrict__ gamma, float* __restrict__ scale,
+                                                          int64_t sld, int frame_major) {
+  __shared__ float grp[4][256];
   __shared__ float red[256];
   const int b = blockIdx.x;
+  const int cl = threadIdx.x & 255, kg = threadIdx.x >> 8;
+  const int kper = (nchunk + 3) / 4;
+  const int k0 = kg * kper, k1 = min(nchunk, k0 + kper);
   float local = 0.f;
-  for (int c = threadIdx.x; c < C; c += 256) {
+  for (int cb = 0; cb < C; cb += 256) {
+    const int c = cb + cl;
     float s = 0.f;
-    if (frame_major) for (int k = 0; k < nchunk; ++k) s += partial[((int64_t)b * nchunk + k) * C + c];
-    else for (int k = 0; k < nchunk; ++k) s += partial[((int64_t)k * B + b) * C + c];
-    const float gx = sqrtf(s);
-    scale[(int64_t)b * sld + c] = gx;
-    local += gx;
+    if (c < C) {
+      if (frame_major) for (int k = k0; k < k1; ++k) s += partial[((int64_t)b * nchunk + k) * C + c];
+      else for (int k = k0; k < k1; ++k) s += partial[((int64_t)k * B + b) * C + c];
+    }
+    grp[kg][cl] = s;
+    __syncthreads();
+    if (kg == 0 && c < C) {
+      const float gx = sqrtf(((grp[0][cl] + grp[1][cl]) + grp[2][cl]) + grp[3][cl]);
+      scale[(int64_t)b * sld + c] = gx;
+      local += gx;
+    }
+    __syncthreads();
   }
-  red[threadIdx.x] = local;
+  if (kg == 0) red[cl] = local;
   __syncthreads();
   for (int o = 128; o > 0; o >>= 1) {
     if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
     __syncthreads();
   }
   const float mean = red[0] / (float)C;
-  for (int c = threadIdx.x; c < (int)sld; c += 256) {
+  for (int c = threadIdx.x; c < (int)sld; c += 1024) {
     float v = 0.f;
     if (c < C) v = 1.0f + gamma[c] * (scale[(int64_t)b * sld + c] / (mean + 1e-6f));
     scale[(int64_t)b * sld + c] = v;
@@ -343,7 +358,7 @@ extern "C" int vs_grn_scale(const float* h, int B, int HW, int C, int64_t ld, co
   const int nchunk = (HW + GRN_ROWS - 1) / GRN_ROWS;
   hipLaunchKernelGGL(grn_partial_kernel, dim3((unsigned)((C + 255) / 256), (unsigned)nchunk, (unsigned)B), dim3(256), 0,
                      (hipStream_t)stream, h, HW, C, ld, partial, B);
-  hipLaunchKernelGGL(grn_finish_kernel, dim3((unsigned)B), dim3(256), 0, (hipStream_t)stream, partial, nchunk, B, C, gamma,
+  hipLaunchKernelGGL(grn_finish_kernel, dim3((unsigned)B), dim3(1024), 0, (hipStream_t)stream, partial, nchunk, B, C, gamma,
                      scale, ld, 0);
   return vs_launch_status();
 }
@@ -351,7 +366,7 @@ extern "C" int vs_grn_scale(const float* h, int B, int HW, int C, int64_t ld, co
 extern "C" int vs_grn_scale_from_partials(const float* partial, int B, int HW, int C, const float* gamma, float* scale,
                                           int64_t scale_ld, void* stream) {
   VS_REQUIRE(partial && gamma && scale && B > 0 && HW > 0 && HW % 32 == 0 && C > 0 && scale_ld >= C);
-  hipLaunchKernelGGL(grn_finish_kernel, dim3((unsigned)B), dim3(256), 0, (hipStream_t)stream, partial, HW / 32, B, C, gamma,
+  hipLaunchKernelGGL(grn_finish_kernel, dim3((unsigned)B), dim3(1024), 0, (hipStream_t)stream, partial, HW / 32, B, C, gamma,
                      scale, scale_ld, 1);
   return vs_launch_status();
 }

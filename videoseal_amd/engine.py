@@ -301,13 +301,19 @@ class HipEngine:
         if sumsq is not None:       # GRN partial sums of squares from the epilogue ([rows/32][N])
             d.sumsq_part = N.ptr(sumsq)
             split_k = 1
+        patch_pc = self._patch_pc_ok(d)
         if split_k is None:     # static, shape-only rule (never timing-based: a K split changes the summation order)
-            split_k = self._split_k_rule(d) if (tile_hint == 0 and self._gemm_pc_ok(d)) else 1
+            split_k = 1
+            if tile_hint == 0 and self._gemm_pc_ok(d):
+                split_k = self._split_k_rule(d)
+            elif tile_hint == 0 and patch_pc:
+                split_k = self._split_k_rule_patch(d)
         if split_k > 1:
             ws_ld = rup(w.N, 4)
-            d.splitk_ws, d.splitk_ld, d.split_k = N.ptr(self.buf("splitk.ws", split_k * out.rows * ws_ld)), ws_ld, split_k
+            slices = split_k + (1 if (patch_pc and in2 is not None) else 0)     # + the slice of the 1x1 second phase
+            d.splitk_ws, d.splitk_ld, d.split_k = N.ptr(self.buf("splitk.ws", slices * out.rows * ws_ld)), ws_ld, split_k
             if tile_hint == 0 and not self.autotune:
-                d.tile_hint = N.CONV_TILE_HI | (2 if w.N % 192 == 0 else 1)
+                d.tile_hint = self._static_split_tile(d)
         if tile_hint == 0 and self.autotune:
             d.tile_hint = self._pick_tile(d, w, out)
         if self.kernel_timers is not None and prof is None and self.time_all_convs:
@@ -331,6 +337,34 @@ class HipEngine:
                 and d.in_sy == d.W * d.in_sx and d.in_sb == d.H * d.in_sy and (not d.a_scale or (d.H * d.W) % 64 == 0))
 
     @staticmethod
+    def _patch_pc_ok(d: "N.ConvDesc") -> bool:
+        """preconditions of the wave-specialised 3x3 patch kernel (tile codes 15 / 16), mirrored from vs_conv_gemm"""
+        return (bool(d.wt_split) and bool(d.wt_blk) and d.KH == 3 and d.KW == 3 and d.SH == 1 and d.SW == 1 and d.PH == 1 and d.PW == 1
+                and d.Ho == d.H and d.Wo == d.W and not d.a_scale and d.W % 16 == 0 and d.H % 8 == 0 and (not d.in2 or bool(d.wt2_blk)))
+
+    @staticmethod
+    def _split_k_rule_patch(d: "N.ConvDesc") -> int:
+        """K slices (whole 16-channel chunks) for wide 3x3 layers with too few 128-pixel tiles to fill 256 CUs,
+        e.g. the 4 key frames of a 16-frame streaming chunk: 32 tiles x 2 = 64 workgroups."""
+        if d.N < 128 or d.CinP < 128:
+            return 1
+        blocks = d.B * (d.H // 8) * (d.W // 16) * ((d.N + 191) // 192 if d.N % 192 == 0 else (d.N + 127) // 128)
+        spt = d.CinP // 16
+        sk = 1
+        for cand in (2, 3, 4, 6, 8):
+            if blocks * sk >= 192:
+                break
+            if spt % cand == 0 and spt // cand >= 2:
+                sk = cand
+        return sk
+
+    @staticmethod
+    def _static_split_tile(d: "N.ConvDesc") -> int:
+        if d.KH == 3:
+            return N.CONV_TILE_HI | 0 if d.N % 192 == 0 else 15
+        return N.CONV_TILE_HI | (2 if d.N % 192 == 0 else 1)
+
+    @staticmethod
     def _split_k_rule(d: "N.ConvDesc") -> int:
         """K slices for small-M GEMMs: double while 128 x 128 tiles cannot give every CU a workgroup and a slice keeps >= 4 K pairs"""
         rows = d.B * d.H * d.W
@@ -350,10 +384,12 @@ class HipEngine:
             return best
         if torch.cuda.is_current_stream_capturing():
             # never time inside a hipGraph capture: static heuristic (same numerics)
-            return (N.CONV_TILE_HI | (2 if d.N % 192 == 0 else 1)) if d.split_k > 1 else 0
+            return self._static_split_tile(d) if d.split_k > 1 else 0
         patch = (bool(d.wt_split) and d.KH == 3 and d.KW == 3 and d.SH == 1 and d.SW == 1 and d.PH == 1 and d.PW == 1 and
                  d.Ho == d.H and d.Wo == d.W and not d.a_scale and d.W % 16 == 0 and d.H % 8 == 0)
-        if patch:     # the patch kernel walks K as (chunk, tap): candidates stay inside one K order (bit-identical results)
+        if patch and d.split_k > 1:
+            cands = [15] + ([N.CONV_TILE_HI] if d.N > 128 else [])
+        elif patch:     # the patch kernel walks K as (chunk, tap): candidates stay inside one K order (bit-identical results)
             # 15 / TILE_HI|0 (=16): wave-specialised variants, 128 and 192 output channels per workgroup
             widths = {10: 32, 11: 64, 12: 128, 15: 128, N.CONV_TILE_HI: 192}
             cands = [t for t in widths if widths[t] < 2 * d.N + 64 or t == 10]
