@@ -209,6 +209,13 @@ int vs_aug_color(const float* src, float* dst, int F, int H, int W, int op, floa
 int vs_aug_crop_flip(const float* src, float* dst, int planes, int H, int W, int i0, int j0, int h, int w, int flip, void* stream);
 /* bilinear resize NCHW -> NCHW, align_corners=False, antialias on/off (geometric.py:62-91; augmenter.py:147-150)        */
 int vs_resize_nchw(const float* src, float* dst, int planes, int H, int W, int oh, int ow, int antialias, void* stream);
+/* Rotate / Perspective (geometric.py:28-59, 127-183 -> torchvision F.rotate (nearest) / F.perspective (bilinear)): sampling grid +
+ * grid_sample(padding zeros, align_corners=False) in one kernel, `planes` H x W planes -> oh x ow.
+ *   kind 0 (affine):      coeffs[6] (HOST) = inverse affine matrix rows divided by (0.5*W) resp. (0.5*H)  (_gen_affine_grid)
+ *   kind 1 (perspective): coeffs[8] (HOST) = the 8 coefficients of _get_perspective_coeffs(startpoints, endpoints)
+ * torchvision is not vendored by the reference: parity of this entry point is pinned only against oracle/augment.py's restatement. */
+int vs_aug_warp(const float* src, float* dst, int planes, int H, int W, int oh, int ow, int kind, const float* coeffs,
+                int bilinear, void* stream);
 /* torchvision gaussian_blur: k x k (odd), reflect padding, separable (valuemetric.py:53-71)                              */
 int vs_gaussian_blur(const float* src, float* tmp, float* dst, int planes, int H, int W, int k, float sigma, void* stream);
 /* median of the k row-medians of the zero-padded k x k window, k in {3,5,7} (utils/image.py:60-84)                        */

@@ -124,3 +124,72 @@ def jpeg(x, quality):
         u8 = x[i].mul(255).byte().permute(1, 2, 0).numpy()
         out[i] = torch.from_numpy(pil_roundtrip(np.ascontiguousarray(u8), quality).copy()).permute(2, 0, 1).float() / 255
     return out
+
+
+# ---- Rotate / Perspective (geometric.py:28-59, 127-183).  torchvision is neither installed nor vendored by the reference
+# ("parity unpinned"): this restates torchvision/_functional_tensor.py (_gen_affine_grid, _perspective_grid,
+# _compute_affine_output_size, _get_inverse_affine_matrix, _get_perspective_coeffs) with torch ops and uses the real ATen
+# F.grid_sample for the sampling itself.
+def _inverse_rotate_matrix(angle):
+    import math
+    rot = math.radians(-angle)
+    a, b, c, d = math.cos(rot), -math.sin(rot), math.sin(rot), math.cos(rot)
+    return [d, -b, 0.0, -c, a, 0.0]
+
+
+def _affine_output_size(matrix, w, h):
+    pts = torch.tensor([[-0.5 * w, -0.5 * h, 1.0], [-0.5 * w, 0.5 * h, 1.0], [0.5 * w, 0.5 * h, 1.0], [0.5 * w, -0.5 * h, 1.0]])
+    theta = torch.tensor(matrix, dtype=torch.float).view(2, 3)
+    new_pts = torch.matmul(pts, theta.T)
+    min_vals, _ = new_pts.min(dim=0)
+    max_vals, _ = new_pts.max(dim=0)
+    min_vals += torch.tensor((w * 0.5, h * 0.5))
+    max_vals += torch.tensor((w * 0.5, h * 0.5))
+    tol = 1e-4
+    cmax = torch.ceil((max_vals / tol).trunc_() * tol)
+    cmin = torch.floor((min_vals / tol).trunc_() * tol)
+    size = cmax - cmin
+    return int(size[0]), int(size[1])
+
+
+def rotate(x, angle, expand=False):
+    """F.rotate(img, angle, interpolation=NEAREST, expand=expand, center=None, fill=None)."""
+    h, w = x.shape[-2:]
+    matrix = _inverse_rotate_matrix(angle)
+    ow, oh = _affine_output_size(matrix, w, h) if expand else (w, h)
+    theta = torch.tensor(matrix, dtype=torch.float32).reshape(1, 2, 3)
+    d = 0.5
+    base = torch.empty(1, oh, ow, 3)
+    base[..., 0].copy_(torch.linspace(-ow * 0.5 + d, ow * 0.5 + d - 1, steps=ow))
+    base[..., 1].copy_(torch.linspace(-oh * 0.5 + d, oh * 0.5 + d - 1, steps=oh).unsqueeze_(-1))
+    base[..., 2].fill_(1)
+    rescaled = theta.transpose(1, 2) / torch.tensor([0.5 * w, 0.5 * h])
+    grid = base.view(1, oh * ow, 3).bmm(rescaled).view(1, oh, ow, 2)
+    return F.grid_sample(x, grid.expand(x.shape[0], oh, ow, 2), mode="nearest", padding_mode="zeros", align_corners=False)
+
+
+def perspective_coeffs(startpoints, endpoints):
+    a = torch.zeros(2 * len(startpoints), 8, dtype=torch.float64)
+    for i, (p1, p2) in enumerate(zip(endpoints, startpoints)):
+        a[2 * i, :] = torch.tensor([p1[0], p1[1], 1, 0, 0, 0, -p2[0] * p1[0], -p2[0] * p1[1]])
+        a[2 * i + 1, :] = torch.tensor([0, 0, 0, p1[0], p1[1], 1, -p2[1] * p1[0], -p2[1] * p1[1]])
+    b = torch.tensor(startpoints, dtype=torch.float64).view(8)
+    return torch.linalg.lstsq(a, b, driver="gels").solution.to(torch.float32).tolist()
+
+
+def perspective(x, startpoints, endpoints):
+    """F.perspective(img, startpoints, endpoints, interpolation=BILINEAR, fill=None)."""
+    oh, ow = x.shape[-2:]
+    c = perspective_coeffs(startpoints, endpoints)
+    theta1 = torch.tensor([[[c[0], c[1], c[2]], [c[3], c[4], c[5]]]])
+    theta2 = torch.tensor([[[c[6], c[7], 1.0], [c[6], c[7], 1.0]]])
+    d = 0.5
+    base = torch.empty(1, oh, ow, 3)
+    base[..., 0].copy_(torch.linspace(d, ow * 1.0 + d - 1.0, steps=ow))
+    base[..., 1].copy_(torch.linspace(d, oh * 1.0 + d - 1.0, steps=oh).unsqueeze_(-1))
+    base[..., 2].fill_(1)
+    rescaled1 = theta1.transpose(1, 2) / torch.tensor([0.5 * ow, 0.5 * oh])
+    g1 = base.view(1, oh * ow, 3).bmm(rescaled1)
+    g2 = base.view(1, oh * ow, 3).bmm(theta2.transpose(1, 2))
+    grid = (g1 / g2 - 1.0).view(1, oh, ow, 2)
+    return F.grid_sample(x, grid.expand(x.shape[0], oh, ow, 2), mode="bilinear", padding_mode="zeros", align_corners=False)

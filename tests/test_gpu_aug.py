@@ -59,6 +59,39 @@ def test_grayscale_flip_crop_resize(frames):
         assert (im.cpu() - A.resize(frames, size)).abs().max() < 2e-6 and (mk.cpu() - A.resize(mask, size)).abs().max() < 2e-6
 
 
+@pytest.mark.parametrize("angle", [5, 10, 30, 45, 90, -90, 100, -17])
+def test_rotate(frames, angle):
+    """geometric.py:28-59 through vs_aug_warp vs the restated torchvision grid + ATen grid_sample (nearest: a value is either equal or
+    comes from the neighbouring pixel when the source coordinate sits within an ulp of a .5 boundary)."""
+    x = frames.cuda()
+    mask = (torch.rand(3, 1, 93, 118) > 0.5).float()
+    im, mk = G.Rotate()(x, mask.cuda(), angle)
+    base = angle // 90 * 90
+    ref = A.rotate(A.rotate(frames, base, expand=True), angle - base)
+    refm = A.rotate(A.rotate(mask, base, expand=True), angle - base)
+    assert im.shape == ref.shape and mk.shape == refm.shape
+    # (odd x even frames: a 90-degree turn puts source coordinates exactly on .5 ties, so even those are not a clean permutation)
+    assert ((im.cpu() != ref).float().mean() < 2e-3) and ((mk.cpu() != refm).float().mean() < 2e-3)
+    if angle == 90:          # even x even: exact pixel permutation
+        ev = frames[..., :92, :].contiguous()
+        assert torch.equal(G.Rotate()(ev.cuda(), None, 90)[0].cpu(), torch.rot90(ev, 1, dims=(-2, -1)))
+
+
+@pytest.mark.parametrize("scale", [0.1, 0.3, 0.5, 0.8])
+def test_perspective(frames, scale):
+    """geometric.py:127-183: same corner draws as the reference (torch CPU RNG), bilinear grid_sample with zero fill."""
+    x = frames.cuda()
+    mask = torch.rand(3, 1, 93, 118)
+    torch.manual_seed(3)
+    im, mk = G.Perspective()(x, mask.cuda(), scale)
+    torch.manual_seed(3)
+    sp, ep = G.Perspective.get_perspective_params(118, 93, scale)
+    ref, refm = A.perspective(frames, sp, ep), A.perspective(mask, sp, ep)
+    # coordinates agree to a few ulp (summation order of the 3-term dot products): a bilinear sample moves by <= |grad| * 1e-4 px
+    assert (im.cpu() - ref).abs().max() < 2e-4 and (mk.cpu() - refm).abs().max() < 5e-4
+    assert (im.cpu() - ref).abs().mean() < 2e-6
+
+
 @pytest.mark.parametrize("k", [3, 5, 9, 13, 17])
 def test_gaussian_blur(frames, k):
     got, _ = G.GaussianBlur()(frames.cuda(), None, k)
@@ -80,7 +113,7 @@ def test_augmenter_picks_like_the_reference():
     out, mask, names = aug(x, x, None, is_video=False, do_resize=True)
     assert out.shape == x.shape and mask.shape == (2, 1, 64, 64) and len(names.split("+")) == 2
     with pytest.raises(NotImplementedError):
-        G.Rotate()(x, None, 10)
+        G.H264()(x, None, 23)          # external codec: loud, no fallback
 
 
 def test_config3_clip_through_the_full_chain():

@@ -4,14 +4,17 @@ Same call surface as the reference's ``videoseal.augmentation`` for the rows in 
 every op is ``op(image, mask=None, strength=None) -> (image, mask)``, ``Sequential(*ops)(image, mask, args)``,
 ``Augmenter(masks, augs, augs_params, num_augs)`` with the multinomial pick, and the validation tables.
 Random parameters are drawn exactly like the reference (torch CPU RNG: ``torch.randint`` / ``torch.rand``),
-so a seeded run picks the same strengths.  Out of scope and loud: Rotate / Perspective (grid-sample kernels,
-SURVEY 8(f)3) and the H.264/H.265/VP9/AV1 codecs (external libx264).
+so a seeded run picks the same strengths.  Out of scope and loud: the H.264/H.265/VP9/AV1 codecs (external libx264,
+SURVEY 8(f)2).  Rotate / Perspective follow torchvision's grid construction + ATen grid_sample (torchvision itself is
+not vendored by the reference: pinned against oracle/augment.py only).
 
 Forward values only: the reference wraps JPEG / MedianFilter in a straight-through estimator whose forward value
 is the codec / filter output, which is what these kernels produce; there is no autograd here.
 """
 from __future__ import annotations
 
+import ctypes as C
+import math
 from typing import Dict, List, Optional, Tuple
 
 import torch
@@ -236,12 +239,116 @@ class _NotBuilt(_Aug):
         raise NotImplementedError(f"{self.__class__.__name__}: {self.why}")
 
 
-class Rotate(_NotBuilt):
-    why = "grid-sample kernels are a 'next' row (SURVEY.md 8(f)3)"
+def _rotate_matrix(angle: float) -> List[float]:
+    """torchvision F.rotate -> _get_inverse_affine_matrix([0,0], -angle, [0,0], 1.0, [0,0]) (python floats)."""
+    rot = math.radians(-angle)
+    a, b, c, d_ = math.cos(rot), -math.sin(rot), math.sin(rot), math.cos(rot)
+    return [d_, -b, 0.0, -c, a, 0.0]
 
 
-class Perspective(_NotBuilt):
-    why = "grid-sample kernels are a 'next' row (SURVEY.md 8(f)3)"
+def _affine_out_size(m: List[float], w: int, h: int) -> Tuple[int, int]:
+    """torchvision _compute_affine_output_size (expand=True), float32 like the tensor code."""
+    import numpy as np
+    pts = np.array([[-0.5 * w, -0.5 * h, 1.0], [-0.5 * w, 0.5 * h, 1.0], [0.5 * w, 0.5 * h, 1.0], [0.5 * w, -0.5 * h, 1.0]], dtype=np.float32)
+    theta = np.array(m, dtype=np.float32).reshape(2, 3)
+    new = pts @ theta.T
+    mn, mx = new.min(0) + np.float32([w * 0.5, h * 0.5]), new.max(0) + np.float32([w * 0.5, h * 0.5])
+    tol = np.float32(1e-4)
+    cmax = np.ceil(np.trunc(mx / tol) * tol)
+    cmin = np.floor(np.trunc(mn / tol) * tol)
+    size = cmax - cmin
+    return int(size[0]), int(size[1])
+
+
+def rotate(x: torch.Tensor, angle: float, expand: bool = False) -> torch.Tensor:
+    """torchvision F.rotate(img, angle, interpolation=NEAREST, expand=expand, fill=None) on vs_aug_warp."""
+    import numpy as np
+    x = _dev(x)
+    planes, H, W = _planes(x)
+    m = _rotate_matrix(angle)
+    ow, oh = _affine_out_size(m, W, H) if expand else (W, H)
+    th = np.array(m, dtype=np.float32).reshape(2, 3)
+    resc = (th.T / np.array([0.5 * W, 0.5 * H], dtype=np.float32)).astype(np.float32)      # [3][2], as _gen_affine_grid
+    coeffs = (C.c_float * 6)(*[float(resc[k][0]) for k in range(3)], *[float(resc[k][1]) for k in range(3)])
+    out = torch.empty(x.shape[0], x.shape[1], oh, ow, device=x.device, dtype=torch.float32)
+    N.check(N.lib().vs_aug_warp(N.ptr(x), N.ptr(out), planes, H, W, oh, ow, 0, coeffs, 0, N.stream()), "vs_aug_warp")
+    return out
+
+
+def perspective_coeffs(startpoints, endpoints) -> List[float]:
+    """torchvision _get_perspective_coeffs: least squares in float64, result cast to float32."""
+    a = torch.zeros(8, 8, dtype=torch.float64)
+    for i, (p1, p2) in enumerate(zip(endpoints, startpoints)):
+        a[2 * i, :] = torch.tensor([p1[0], p1[1], 1, 0, 0, 0, -p2[0] * p1[0], -p2[0] * p1[1]])
+        a[2 * i + 1, :] = torch.tensor([0, 0, 0, p1[0], p1[1], 1, -p2[1] * p1[0], -p2[1] * p1[1]])
+    b = torch.tensor(startpoints, dtype=torch.float64).view(8)
+    res = torch.linalg.lstsq(a, b, driver="gels").solution.to(torch.float32)
+    return res.tolist()
+
+
+def perspective(x: torch.Tensor, startpoints, endpoints) -> torch.Tensor:
+    """torchvision F.perspective(img, startpoints, endpoints, interpolation=BILINEAR, fill=None) on vs_aug_warp."""
+    x = _dev(x)
+    planes, H, W = _planes(x)
+    coeffs = (C.c_float * 8)(*perspective_coeffs(startpoints, endpoints))
+    out = torch.empty_like(x)
+    N.check(N.lib().vs_aug_warp(N.ptr(x), N.ptr(out), planes, H, W, H, W, 1, coeffs, 1, N.stream()), "vs_aug_warp")
+    return out
+
+
+class Rotate(_Aug):
+    """geometric.py:28-59: multiples of 90 degrees with expand=True, the remainder with expand=False (both nearest)."""
+
+    def __init__(self, min_angle=None, max_angle=None, do90=False):
+        super().__init__()
+        self.min_angle, self.max_angle = min_angle, max_angle
+        self.base_angles = torch.tensor([-90, 0, 0, 90]) if do90 else torch.tensor([0])
+
+    def get_random_angle(self):
+        if self.min_angle is None or self.max_angle is None:
+            raise ValueError("min_angle and max_angle must be provided")
+        base_angle = self.base_angles[torch.randint(0, len(self.base_angles), size=(1,))].item()
+        return base_angle + torch.randint(self.min_angle, self.max_angle + 1, size=(1,)).item()
+
+    def forward(self, image, mask=None, angle=None):
+        angle = angle or self.get_random_angle()
+        base_angle = angle // 90 * 90
+        angle = angle - base_angle
+        image = rotate(rotate(image, base_angle, expand=True), angle)
+        mask = rotate(rotate(mask, base_angle, expand=True), angle) if mask is not None else mask
+        return image, mask
+
+
+class Perspective(_Aug):
+    """geometric.py:127-183."""
+
+    def __init__(self, min_distortion_scale=None, max_distortion_scale=None):
+        super().__init__()
+        self.min_distortion_scale, self.max_distortion_scale = min_distortion_scale, max_distortion_scale
+
+    def get_random_distortion_scale(self):
+        if self.min_distortion_scale is None or self.max_distortion_scale is None:
+            raise ValueError("min_distortion_scale and max_distortion_scale must be provided")
+        return self.min_distortion_scale + torch.rand(1).item() * (self.max_distortion_scale - self.min_distortion_scale)
+
+    def forward(self, image, mask=None, distortion_scale=None):
+        distortion_scale = distortion_scale or self.get_random_distortion_scale()
+        width, height = image.shape[-1], image.shape[-2]
+        startpoints, endpoints = self.get_perspective_params(width, height, distortion_scale)
+        image = perspective(image, startpoints, endpoints)
+        mask = perspective(mask, startpoints, endpoints) if mask is not None else mask
+        return image, mask
+
+    @staticmethod
+    def get_perspective_params(width, height, distortion_scale):
+        half_height, half_width = height // 2, width // 2
+        ri = lambda lo, hi: int(torch.randint(lo, hi, size=(1,)).item())   # noqa: E731  (same draw order as the reference)
+        topleft = [ri(0, int(distortion_scale * half_width) + 1), ri(0, int(distortion_scale * half_height) + 1)]
+        topright = [ri(width - int(distortion_scale * half_width) - 1, width), ri(0, int(distortion_scale * half_height) + 1)]
+        botright = [ri(width - int(distortion_scale * half_width) - 1, width), ri(height - int(distortion_scale * half_height) - 1, height)]
+        botleft = [ri(0, int(distortion_scale * half_width) + 1), ri(height - int(distortion_scale * half_height) - 1, height)]
+        startpoints = [[0, 0], [width - 1, 0], [width - 1, height - 1], [0, height - 1]]
+        return startpoints, [topleft, topright, botright, botleft]
 
 
 class H264(_NotBuilt):
@@ -320,17 +427,19 @@ class Augmenter(nn.Module):
 
 def get_validation_augs(is_video: bool = False, only_identity: bool = False, only_combined: bool = False) -> list:
     """The fixed-strength evaluation table of augmentation/__init__.py:58-124 restricted to the ops built here
-    (image table; codecs / Rotate / Perspective rows are dropped)."""
+    (codec rows are dropped)."""
     if only_identity:
         return [(Identity(), [0])]
     if only_combined:
         return [(Identity(), [0]), (Sequential(JPEG(), Crop(), Brightness()), [(40, 0.71, 0.5)])]
     if is_video:
-        return [(Identity(), [0]), (HorizontalFlip(), [0]), (Resize(), [0.55, 0.71]), (Crop(), [0.55, 0.71]), (Brightness(), [0.5, 1.5]),
+        return [(Identity(), [0]), (HorizontalFlip(), [0]), (Rotate(), [10, 90]), (Resize(), [0.55, 0.71]), (Crop(), [0.55, 0.71]),
+                (Perspective(), [0.5]), (Brightness(), [0.5, 1.5]),
                 (Contrast(), [0.5, 1.5]), (Saturation(), [0.5, 1.5]), (Hue(), [0.25]), (Grayscale(), [-1]), (JPEG(), [40]), (GaussianBlur(), [9])]
-    return [(Identity(), [0]), (HorizontalFlip(), [0]),
+    return [(Identity(), [0]), (HorizontalFlip(), [0]), (Rotate(), [5, 10, 30, 45, 90]),
             (Resize(), [0.32, 0.45, 0.55, 0.63, 0.71, 0.77, 0.84, 0.89, 0.95, 1.00]),
             (Crop(), [0.32, 0.45, 0.55, 0.63, 0.71, 0.77, 0.84, 0.89, 0.95, 1.00]),
+            (Perspective(), [0.1, 0.2, 0.3, 0.4, 0.5, 0.6, 0.7, 0.8]),
             (Brightness(), [0.1, 0.25, 0.5, 0.75, 1.0, 1.25, 1.5, 1.75, 2.0]), (Contrast(), [0.1, 0.25, 0.5, 0.75, 1.0, 1.25, 1.5, 1.75, 2.0]),
             (Hue(), [-0.4, -0.3, -0.2, -0.1, 0.0, 0.1, 0.2, 0.3, 0.4, 0.5]), (Grayscale(), [-1]), (JPEG(), [40, 50, 60, 70, 80, 90]),
             (GaussianBlur(), [3, 5, 9, 13, 17]),

@@ -405,7 +405,66 @@ inline unsigned gridx(int64_t n, int per = 256, int64_t cap = 4096) {
   return (unsigned)(g < 1 ? 1 : (g > cap ? cap : g));
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Rotate / Perspective (geometric.py:28-59, 127-183): torchvision builds a sampling grid and calls grid_sample(padding zeros,
+// align_corners=False).  The grid of output pixel (ox, oy), restated from torchvision/_functional_tensor.py
+//   affine (_gen_affine_grid):       base = (ox + 0.5 - ow/2, oy + 0.5 - oh/2, 1);  g = base . (theta^T / (0.5 w, 0.5 h))
+//   perspective (_perspective_grid): base = (ox + 0.5, oy + 0.5, 1);  g = base . (theta1^T / (0.5 ow, 0.5 oh)) / (base . theta2^T) - 1
+// then grid_sample (ATen GridSamplerKernel): ix = ((gx + 1) * W - 1) / 2; nearest = nearbyint (half to even); bilinear =
+// nw, ne, sw, se taps weighted by the opposite areas, taps outside the image contribute zero.
+struct WarpArgs { float t[8]; int kind, bilinear; };   // kind 0: t[0..5] = rescaled theta^T columns (see host), 1: perspective
+
+__global__ __launch_bounds__(256) void warp_kernel(const float* __restrict__ src, float* __restrict__ dst, int H, int W, int oh, int ow,
+                                                   WarpArgs a) {
+  const int ox = blockIdx.x * 32 + (threadIdx.x & 31), oy = blockIdx.y * 8 + (threadIdx.x >> 5);
+  if (ox >= ow || oy >= oh) return;
+  const float* sp = src + (int64_t)blockIdx.z * H * W;
+  float gx, gy;
+  if (a.kind == 0) {
+    const float bx = (float)ox + (0.5f - ow * 0.5f), by = (float)oy + (0.5f - oh * 0.5f);
+    gx = (bx * a.t[0] + by * a.t[1]) + a.t[2];
+    gy = (bx * a.t[3] + by * a.t[4]) + a.t[5];
+  } else {
+    const float bx = (float)ox + 0.5f, by = (float)oy + 0.5f;
+    const float n1 = (bx * (a.t[0] / (0.5f * ow)) + by * (a.t[1] / (0.5f * ow))) + a.t[2] / (0.5f * ow);
+    const float n2 = (bx * (a.t[3] / (0.5f * oh)) + by * (a.t[4] / (0.5f * oh))) + a.t[5] / (0.5f * oh);
+    const float den = (bx * a.t[6] + by * a.t[7]) + 1.0f;
+    gx = n1 / den - 1.0f;
+    gy = n2 / den - 1.0f;
+  }
+  const float ix = ((gx + 1.f) * W - 1.f) / 2.f, iy = ((gy + 1.f) * H - 1.f) / 2.f;
+  float v = 0.f;
+  if (!a.bilinear) {
+    const float rx = nearbyintf(ix), ry = nearbyintf(iy);
+    if (rx >= 0.f && rx <= (float)(W - 1) && ry >= 0.f && ry <= (float)(H - 1)) v = sp[(int64_t)(int)ry * W + (int)rx];
+  } else {
+    const float x0 = floorf(ix), y0 = floorf(iy);
+    const float x1 = x0 + 1.f, y1 = y0 + 1.f;
+    const float nw = (x1 - ix) * (y1 - iy), ne = (ix - x0) * (y1 - iy), sw = (x1 - ix) * (iy - y0), se = (ix - x0) * (iy - y0);
+    auto at = [&](float xf, float yf) -> float {
+      return (xf >= 0.f && xf <= (float)(W - 1) && yf >= 0.f && yf <= (float)(H - 1)) ? sp[(int64_t)(int)yf * W + (int)xf] : 0.f;
+    };
+    v = at(x0, y0) * nw;
+    v += at(x1, y0) * ne;
+    v += at(x0, y1) * sw;
+    v += at(x1, y1) * se;
+  }
+  dst[((int64_t)blockIdx.z * oh + oy) * ow + ox] = v;
+}
+
 }  // namespace
+
+extern "C" int vs_aug_warp(const float* src, float* dst, int planes, int H, int W, int oh, int ow, int kind, const float* coeffs,
+                           int bilinear, void* stream) {
+  VS_REQUIRE(src && dst && coeffs && planes > 0 && H > 0 && W > 0 && oh > 0 && ow > 0 && (kind == 0 || kind == 1));
+  WarpArgs a;
+  for (int i = 0; i < 8; ++i) a.t[i] = i < (kind == 0 ? 6 : 8) ? coeffs[i] : 0.f;
+  a.kind = kind; a.bilinear = bilinear;
+  hipLaunchKernelGGL(warp_kernel, dim3((ow + 31) / 32, (oh + 7) / 8, planes), dim3(256), 0, (hipStream_t)stream, src, dst, H, W, oh, ow, a);
+  return vs_launch_status();
+}
+
+
 
 extern "C" int vs_aug_color(const float* src, float* dst, int F, int H, int W, int op, float factor, float* scratch, void* stream) {
   VS_REQUIRE(src && dst && F > 0 && H > 0 && W > 0 && op >= 0 && op <= 4);

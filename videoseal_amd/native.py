@@ -23,7 +23,7 @@ VIDEO_MODES = {"repeat": 0, "alternate": 1, "interpolate": 2}
 EXPORTS = [
     "vs_version", "vs_arch", "vs_error_string", "vs_sizeof_conv_desc", "vs_sizeof_tail_desc", "vs_conv_gemm", "vs_layernorm_act", "vs_dwconv7_ln", "vs_grn_scale", "vs_grn_scale_from_partials",
     "vs_upcat2x", "vs_msg_latent", "vs_broadcast_channels", "vs_outc_tanh", "vs_pool_linear", "vs_resize_pre", "vs_resize_pre_u8",
-    "vs_jnd_heatmap", "vs_embed_tail", "vs_aug_color_scratch_floats", "vs_aug_color", "vs_aug_crop_flip", "vs_resize_nchw",
+    "vs_jnd_heatmap", "vs_embed_tail", "vs_aug_color_scratch_floats", "vs_aug_color", "vs_aug_crop_flip", "vs_aug_warp", "vs_resize_nchw",
     "vs_gaussian_blur", "vs_median_filter", "vs_jpeg_workspace_bytes", "vs_jpeg_roundtrip",
 ]
 
@@ -99,6 +99,7 @@ def lib() -> C.CDLL:
         "vs_aug_color": [P, P, I, I, I, I, F, P, P],
         "vs_aug_crop_flip": [P, P, I, I, I, I, I, I, I, I, P],
         "vs_resize_nchw": [P, P, I, I, I, I, I, I, P],
+        "vs_aug_warp": [P, P, I, I, I, I, I, I, P, I, P],
         "vs_gaussian_blur": [P, P, P, I, I, I, I, F, P],
         "vs_median_filter": [P, P, I, I, I, I, P],
         "vs_jpeg_roundtrip": [P, P, I, I, I, I, P, P],
