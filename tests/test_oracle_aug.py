@@ -38,3 +38,22 @@ def test_median_is_median_of_row_medians():
 def test_gaussian_blur_preserves_constants():
     x = torch.full((1, 3, 20, 20), 0.37)
     assert torch.allclose(A.gaussian_blur(x, 9), x, atol=1e-6)
+
+
+def test_rotate_perspective_restatement_sanity():
+    """oracle/augment.py rotate / perspective (torchvision restated; unpinned -- torchvision is not installed): closed-form cases."""
+    import torch
+    from oracle import augment as A
+    x = torch.rand(2, 3, 12, 18)
+    assert torch.equal(A.rotate(x, 90, expand=True), torch.rot90(x, 1, dims=(-2, -1)))
+    assert torch.equal(A.rotate(x, -90, expand=True), torch.rot90(x, -1, dims=(-2, -1)))
+    assert torch.equal(A.rotate(x, 0, expand=True), x) and torch.equal(A.rotate(x, 0), x)
+    r = A.rotate(x, 30)
+    assert r.shape == x.shape and (r[..., 0, 0] == 0).all()            # corners rotate out of the frame: zero fill
+    sp = [[0, 0], [17, 0], [17, 11], [0, 11]]
+    assert (A.perspective(x, sp, sp) - x).abs().max() < 1e-5            # identity homography
+    ep = [[2, 1], [15, 2], [16, 10], [1, 9]]
+    c = A.perspective_coeffs(sp, ep)
+    for (sx, sy), (ex, ey) in zip(sp, ep):                              # the homography maps end points back onto start points
+        den = c[6] * ex + c[7] * ey + 1
+        assert abs((c[0] * ex + c[1] * ey + c[2]) / den - sx) < 1e-3 and abs((c[3] * ex + c[4] * ey + c[5]) / den - sy) < 1e-3
