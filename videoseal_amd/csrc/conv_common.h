@@ -50,9 +50,8 @@ __device__ __forceinline__ void apply_act_all(f32x16 (&acc)[TM][TN], const float
       for (int j = 0; j < TN; ++j)
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
-          const float v = acc[i][j][e] + b1[j];
-          acc[i][j][e] = 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f)) + b2[j];
-          if ((e & 3) == 3) __builtin_amdgcn_sched_barrier(0);   // keep the 64 erf expansions from being interleaved (VGPR blow-up)
+          acc[i][j][e] = vs_gelu(acc[i][j][e] + b1[j]) + b2[j];
+          if ((e & 7) == 7) __builtin_amdgcn_sched_barrier(0);   // keep the expansions from being interleaved across the whole tile (VGPRs)
         }
   } else if (act == VS_ACT_TANH) {
 #pragma unroll

@@ -292,28 +292,45 @@ __global__ __launch_bounds__(512, 2) void gemm1x1_pc_kernel(const vs_conv_desc_t
 }
 
 // out = act(sum_ks ws[ks] + bias) [+ ws[split_k] + bias2 : the 1x1 second phase of the patch kernel] (+ res); columns in
-// [N, n_store) are written as zero.  One thread per (row, 4 columns).  Same epilogue order as the kernels themselves.
-__global__ __launch_bounds__(256) void splitk_epilogue_kernel(const vs_conv_desc_t d, const int M) {
+// [N, n_store) are written as zero.  One thread per (row, 4 columns), 16-byte accesses where the operands allow it.
+// Same epilogue order as the kernels themselves; the slices are added in slice order (deterministic).
+__global__ __launch_bounds__(256) void splitk_epilogue_kernel(const vs_conv_desc_t d, const int M, const int vec) {
   const int ncol4 = (d.n_store + 3) / 4;
   const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (idx >= (int64_t)M * ncol4) return;
   const int64_t m = idx / ncol4;
   const int n4 = (int)(idx % ncol4) * 4;
+  float v[4] = {0.f, 0.f, 0.f, 0.f};
+  const bool full = n4 + 4 <= d.N;
+  if (full) {            // splitk_ld % 4 == 0 and the workspace is 16-byte aligned (checked by the launcher)
+    for (int k = 0; k < d.split_k; ++k) {
+      const f32x4 t = *reinterpret_cast<const f32x4*>(d.splitk_ws + ((int64_t)k * M + m) * d.splitk_ld + n4);
+#pragma unroll
+      for (int c = 0; c < 4; ++c) v[c] += t[c];
+    }
+  } else {
+    for (int c = 0; c < 4; ++c)
+      if (n4 + c < d.N)
+        for (int k = 0; k < d.split_k; ++k) v[c] += d.splitk_ws[((int64_t)k * M + m) * d.splitk_ld + n4 + c];
+  }
 #pragma unroll
   for (int c = 0; c < 4; ++c) {
     const int n = n4 + c;
-    if (n >= d.n_store) break;
-    float v = 0.f;
-    if (n < d.N) {
-      for (int k = 0; k < d.split_k; ++k) v += d.splitk_ws[((int64_t)k * M + m) * d.splitk_ld + n];
-      v += d.bias ? d.bias[n] : 0.f;
-      if (d.act == VS_ACT_RELU) v = fmaxf(v, 0.f);
-      else if (d.act == VS_ACT_GELU) v = 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
-      else if (d.act == VS_ACT_TANH) v = tanhf(v);
-      if (d.in2) v += d.splitk_ws[((int64_t)d.split_k * M + m) * d.splitk_ld + n] + (d.bias2 ? d.bias2[n] : 0.f);
-      if (d.res) v += d.res[m * d.res_ld + n];
-    }
-    d.out[m * d.out_ld + d.out_coff + n] = v;
+    if (n >= d.N) { v[c] = 0.f; continue; }
+    float t = v[c] + (d.bias ? d.bias[n] : 0.f);
+    if (d.act == VS_ACT_RELU) t = fmaxf(t, 0.f);
+    else if (d.act == VS_ACT_GELU) t = vs_gelu(t);
+    else if (d.act == VS_ACT_TANH) t = tanhf(t);
+    if (d.in2) t += d.splitk_ws[((int64_t)d.split_k * M + m) * d.splitk_ld + n] + (d.bias2 ? d.bias2[n] : 0.f);
+    if (d.res) t += d.res[m * d.res_ld + n];
+    v[c] = t;
+  }
+  float* o = d.out + m * d.out_ld + d.out_coff + n4;
+  if (vec && n4 + 4 <= d.n_store) {
+    *reinterpret_cast<f32x4*>(o) = f32x4{v[0], v[1], v[2], v[3]};
+  } else {
+    for (int c = 0; c < 4; ++c)
+      if (n4 + c < d.n_store) o[c] = v[c];
   }
 }
 
@@ -337,7 +354,9 @@ int launch_g(const vs_conv_desc_t& d, hipStream_t st) {
 
 int vs_splitk_epilogue(const vs_conv_desc_t& d, int M, hipStream_t st) {
   const int64_t items = (int64_t)M * ((d.n_store + 3) / 4);
-  hipLaunchKernelGGL(splitk_epilogue_kernel, dim3((unsigned)cdiv64(items, 256)), dim3(256), 0, st, d, M);
+  if ((d.splitk_ld & 3) || ((uintptr_t)d.splitk_ws & 15)) return VS_ERR_BAD_ARG;
+  const int vec = ((d.out_ld & 3) == 0 && (d.out_coff & 3) == 0 && ((uintptr_t)d.out & 15) == 0) ? 1 : 0;
+  hipLaunchKernelGGL(splitk_epilogue_kernel, dim3((unsigned)cdiv64(items, 256)), dim3(256), 0, st, d, M, vec);
   return vs_launch_status();
 }
 
