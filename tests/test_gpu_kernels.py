@@ -61,6 +61,37 @@ def test_patch_pc_split_k(eng, cfg):
     assert (full[..., :4] == 7.0).all() and (full[..., 204:] == 7.0).all()
 
 
+@pytest.mark.parametrize("cx", [16, 1])
+def test_conv3x3_small_two_phase(eng, cx):
+    """thin-layer kernel with the fused 1x1 res_conv (unet.py:38-39) + residual at a channel offset; bit-identical to the patch kernel."""
+    if not eng.use_split:
+        pytest.skip("split back-end only")
+    g = torch.Generator().manual_seed(23)
+    B, Cm, H, W, Co = 3, 16, 24, 40, 16
+    t = torch.randn(B, Cm, H, W, generator=g)
+    x = torch.randn(B, cx, H, W, generator=g)
+    w1 = torch.randn(Co, Cm, 3, 3, generator=g) / math.sqrt(Cm * 9)
+    b1 = torch.randn(Co, generator=g)
+    w2 = torch.randn(Co, cx, 1, 1, generator=g) / math.sqrt(cx)
+    b2 = torch.randn(Co, generator=g)
+    ref = F.relu(F.conv2d(t, w1, b1, padding=1)) + F.conv2d(x, w2, b2)
+    ta, xa = to_nhwc(t), to_nhwc(x)
+    wt1, cp1 = pack_conv(w1.to(DEV), ta.ld)
+    wt2, cp2 = pack_conv(w2.to(DEV), xa.ld)
+    outs = []
+    for tile in (0x44, 10):
+        out = eng.new_act(f"thin{tile}", B, H, W, 24)
+        out.t.fill_(7.0)
+        eng.conv(ta, ConvW(wt1, b1.to(DEV), Co, 3, 3, cp1), out, pad=1, act=N.ACT_RELU, in2=xa, w2=ConvW(wt2, b2.to(DEV), Co, 1, 1, cp2),
+                 out_coff=4, n_store=Co, tile_hint=tile)
+        torch.cuda.synchronize()
+        full = out.t.view(B, H, W, 24).cpu()
+        assert rel_err(full[..., 4:20].permute(0, 3, 1, 2), ref) < 2e-5
+        assert (full[..., :4] == 7.0).all() and (full[..., 20:] == 7.0).all()
+        outs.append(full)
+    assert torch.equal(outs[0], outs[1])
+
+
 class Eng(HipEngine):
     """engine without a model: only the kernel wrappers + workspace."""
 
@@ -136,6 +167,11 @@ CONV_CASES = [
     (2, 384, 16, 16, 384, 3, 1, 1, 0, 1, 0x40),     # 0x40 = tile 16: 128 x 192
     (3, 48, 13, 21, 200, 3, 1, 1, 1, 2, 0x40),
     (1, 16, 8, 16, 16, 3, 1, 1, 0, 3, 0x40),
+    # persistent thin-layer kernel (tile 20 = 0x44): 16 input channels, <= 32 outputs; ragged frames, reflect, 1-channel input
+    (2, 16, 32, 48, 16, 3, 1, 1, 0, 1, 0x44),
+    (3, 16, 13, 21, 32, 3, 1, 1, 1, 2, 0x44),
+    (2, 1, 24, 32, 16, 3, 1, 1, 0, 1, 0x44),
+    (5, 12, 40, 40, 20, 3, 1, 1, 0, 3, 0x44),
     (2, 768, 16, 16, 64, 3, 1, 1, 0, 1, 0x43),      # 0x43 = tile 19: 128 x 64
     (3, 48, 13, 21, 70, 3, 1, 1, 1, 2, 0x43),
     (3, 160, 7, 9, 130, 3, 2, 1, 0, 1, 14),

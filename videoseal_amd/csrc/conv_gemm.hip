@@ -400,6 +400,7 @@ int vs_conv_gemm_pc_dispatch(const vs_conv_desc_t& d, int tile, hipStream_t st);
 int vs_conv3x3_patch_dispatch(const vs_conv_desc_t& d, int tile, hipStream_t st);  // conv3x3_patch.hip
 int vs_conv3x3_patch_pc_dispatch(const vs_conv_desc_t& d, int tile, hipStream_t st);  // conv3x3_patch_pc.hip
 int vs_gemm1x1_pc_dispatch(const vs_conv_desc_t& d, int tile, hipStream_t st);         // gemm1x1_pc.hip
+int vs_conv3x3_small_dispatch(const vs_conv_desc_t& d, hipStream_t st);                // conv3x3_small.hip
 namespace {
 
 inline bool fits_u32(int64_t bytes) { return bytes >= 0 && bytes < 0xffffffffLL; }
@@ -441,6 +442,13 @@ extern "C" int vs_conv_gemm(const vs_conv_desc_t* dp, void* stream) {
     if (d.split_k > 1) VS_REQUIRE(d.splitk_ws && d.splitk_ld >= d.N && d.split_k <= d.CinP / 16 && !d.sumsq_part);
     return vs_conv3x3_patch_pc_dispatch(d, tile, st);
   }
+  // thin full-resolution layers (16 input channels, <= 32 outputs): persistent kernel with the weights in registers
+  const bool small_ok = patch_ok && d.CinP == 16 && d.N <= 32 && d.n_store <= 32 && (!d.in2 || d.Cin2P == 16) && d.split_k <= 1 &&
+                        !d.sumsq_part;
+  if (tile == 20) {
+    VS_REQUIRE(small_ok);
+    return vs_conv3x3_small_dispatch(d, st);
+  }
   if (tile == 17 || tile == 18) {   // wave-specialised 1x1 GEMM: dense rows, whole 32-wide K pairs, no second phase
     VS_REQUIRE(can_split0 && d.wt_blk && ((uintptr_t)d.wt_blk & 15) == 0 && !(d.tile_hint & VS_CONV_FORCE_F32));
     VS_REQUIRE(d.KH == 1 && d.KW == 1 && d.SH == 1 && d.SW == 1 && d.PH == 0 && d.PW == 0 && d.Ho == d.H && d.Wo == d.W && !d.in2);
@@ -452,6 +460,7 @@ extern "C" int vs_conv_gemm(const vs_conv_desc_t* dp, void* stream) {
   }
   VS_REQUIRE(d.split_k <= 1);
   if (d.sumsq_part) VS_REQUIRE(d.KH == 1 && d.KW == 1 && !d.in2 && !d.res && !patch_ok);
+  if (tile == 0 && small_ok && !d.in2) return vs_conv3x3_small_dispatch(d, st);   // (with the fused 1x1 the patch kernel is as fast)
   if (tile == 0 && patch_ok && d.W % 16 == 0 && d.H % 8 == 0) {
     const bool blk_ok = d.wt_blk && (!d.in2 || d.wt2_blk) && ((uintptr_t)d.wt_blk & 15) == 0;
     if (blk_ok && d.N >= 128) return vs_conv3x3_patch_pc_dispatch(d, d.N % 192 == 0 ? 16 : 15, st);   // wave-specialised for wide layers

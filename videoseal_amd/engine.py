@@ -387,8 +387,13 @@ class HipEngine:
             return self._static_split_tile(d) if d.split_k > 1 else 0
         patch = (bool(d.wt_split) and d.KH == 3 and d.KW == 3 and d.SH == 1 and d.SW == 1 and d.PH == 1 and d.PW == 1 and
                  d.Ho == d.H and d.Wo == d.W and not d.a_scale and d.W % 16 == 0 and d.H % 8 == 0)
+        small = (bool(d.wt_split) and d.KH == 3 and d.KW == 3 and d.SH == 1 and d.SW == 1 and d.PH == 1 and d.PW == 1 and d.Ho == d.H
+                 and d.Wo == d.W and not d.a_scale and d.CinP == 16 and d.N <= 32 and d.n_store <= 32 and (not d.in2 or d.Cin2P == 16)
+                 and d.split_k <= 1 and not d.sumsq_part)
         if patch and d.split_k > 1:
             cands = [15] + ([N.CONV_TILE_HI] if d.N > 128 else [])
+        elif patch and small:     # + the persistent thin-layer kernel (tile 20); same K order -> bit-identical
+            cands = [10, N.CONV_TILE_HI | 4]
         elif patch:     # the patch kernel walks K as (chunk, tap): candidates stay inside one K order (bit-identical results)
             # 15 / TILE_HI|0 (=16): wave-specialised variants, 128 and 192 output channels per workgroup
             widths = {10: 32, 11: 64, 12: 128, 15: 128, N.CONV_TILE_HI: 192}
