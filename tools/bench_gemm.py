@@ -33,9 +33,15 @@ def run(name, B, HW, K, Nn, variants, grn=False, reps=30):
             for _ in range(reps): eng.conv(xa, cw, out, tile_hint=t, split_k=sk, act=N.ACT_GELU if not grn else 0, **kw)
             e1.record(); torch.cuda.synchronize()
             best[v] = min(best[v], e0.elapsed_time(e1) / reps)
-    print(name + ": " + "  ".join(f"[t{(t & 15) + (16 if t & HI else 0)} sk{sk}] {ms*1e3:6.1f}us {flops/ms/1e9:5.0f}TF" for (t, sk), ms in best.items()), flush=True)
+    print(name + ": " + "  ".join(f"[t{(t & 15) + (16 if t & HI else 0)}/{t >> 8:x} sk{sk}] {ms*1e3:6.1f}us {flops/ms/1e9:5.0f}TF" for (t, sk), ms in best.items()), flush=True)
 
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "abl":
+        for t in (HI | 1, HI | 2):
+            V = [(5, 1), (1, 1), (t, 1)]
+            run("s2 pw1 384->1536 M=8192 ", 32, 16, 384, 1536, V)
+            run("chunky s2 1472->5888 M=15376", 16, 31, 1472, 5888, V, reps=5)
+        sys.exit(0)
     G = [(1, 1), (2, 1), (5, 1), (4, 1), (13, 1), (14, 1)]
     run("s0 pw1  96->384  M=131072", 32, 64, 96, 384, G + [(HI | 1, 1), (HI | 2, 1)])
     run("s0 pw2 384->96   M=131072", 32, 64, 384, 96, G + [(HI | 1, 1)], grn=True)

@@ -30,15 +30,14 @@ __device__ __forceinline__ void dma_1k(const char* gp, unsigned char* lds_base) 
                                    (__attribute__((address_space(3))) void*)lds_base, 16, 0, 0);
 }
 
-template <int TN>
+template <int TN, bool GRN>
 __global__ __launch_bounds__(512, 2) void gemm1x1_pc_kernel(const vs_conv_desc_t d, const int M, const int mtiles, const int ntiles,
                                                             const int pairs_per_split) {
   constexpr int TM = 2;
   constexpr int BN = 64 * TN;
   constexpr int NG = BN / 32;
-  constexpr int NRING = TN >= 3 ? 5 : 6;
-  constexpr int B_STAGE = 3 * BN * 32;
-  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * A_STAGE + NRING * B_STAGE];
+  constexpr int B_STAGE = 3 * BN * 32;                   // three planes of NG pre-swizzled 1 KiB blocks
+  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * A_STAGE + 2 * B_STAGE];
   unsigned char* const Aring = smem;
   unsigned char* const Bring = smem + 2 * A_STAGE;
 
@@ -57,60 +56,27 @@ __global__ __launch_bounds__(512, 2) void gemm1x1_pc_kernel(const vs_conv_desc_t
   const int npairs = min(pairs_per_split, pairs_total - pair0);
   const int total = 2 * npairs;                 // 16-wide K steps of this workgroup, step s <-> K chunk 2*pair0 + s
 
-  if (wave >= 6) {
-    // ================================================================== weight producers: LDS-DMA only (see conv3x3_patch_pc.hip)
-    const int bw = wave - 6;
-    const char* const wblk = reinterpret_cast<const char*>(d.wt_blk);
-    const int g0 = n0 / 32;
-    const int ngroups = (d.N + 31) / 32;
-    const int nch = d.CinP / 16;
-    constexpr int NGW = NG / 2;
-    int64_t goff[NGW];
-#pragma unroll
-    for (int q = 0; q < NGW; ++q) {
-      const int gi = g0 + bw * NGW + q;
-      goff[q] = (int64_t)(gi < ngroups ? gi : ngroups - 1) * nch * 3072 + (int64_t)(2 * pair0) * 3072 + lane * 16;
-    }
-    auto dma_tile = [&, bw](const int t) __attribute__((always_inline)) {
-      unsigned char* st = Bring + (t % NRING) * B_STAGE;
-#pragma unroll
-      for (int q = 0; q < NGW; ++q) {
-        const char* gp = wblk + goff[q] + (int64_t)t * 3072;
-#pragma unroll
-        for (int p = 0; p < 3; ++p) dma_1k(gp + p * 1024, st + p * (BN * 32) + (bw * NGW + q) * 1024);
-      }
-    };
-    constexpr int ND = 3 * NGW;
-#pragma unroll
-    for (int t = 0; t < NRING - 1; ++t)
-      if (t < total) dma_tile(t);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    for (int s = 0; s < total; ++s) {
-      if (s + NRING - 1 < total) {
-        dma_tile(s + NRING - 1);
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NRING - 3) * ND) : "memory");   // tiles <= s+2 have landed
-      } else {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      }
-      __builtin_amdgcn_s_barrier();
-    }
-    return;
-  }
-
   if (wave >= 4) {
-    // ================================================================== activation producers
-    // item (row, seg): 16 bytes = 4 fp32 of row `row`, K offset seg*4 inside the 32-wide pair; 8 consecutive lanes read one
-    // 128-byte line.  seg 0-3 belong to the even step of the pair, seg 4-7 to the odd step.
-    const int pt = tid & 127;
-    constexpr int NI = BM * 8 / 128;       // 8 items per thread per pair
+    // ================================================================== producers (waves 4-7, one per SIMD)
+    // All data movement, with ordinary loads only, balanced over the four SIMDs (an earlier version had two waves splitting
+    // A and two waves DMA-ing B: the splitting waves were the bottleneck, 152 vs 230 TF-eq with them idle).
+    //   A: item (row, seg) = 16 bytes = 4 fp32 of row `row` at K offset seg*4 inside the 32-wide pair; 8 consecutive lanes read
+    //      one 128-byte line.  seg 0-3 belong to the even step of the pair, seg 4-7 to the odd step.
+    //   B: the pair's 2 * 3 * NG pre-split, pre-swizzled 1 KiB weight blocks, copied 16 bytes per thread and chunk.
+    // Operands of step t are written during step t-2 and read (prefetched by the consumers) during step t-1: two LDS
+    // stages each, stage = t & 1.  Three register sets rotate (a pair is loaded 3 pairs = 6 steps before it is stored); the
+    // loop body is straight-line so that hipcc's s_waitcnt vmcnt(N) placement is exact.
+    const int pt = tid & 255;
+    constexpr int NI = BM * 8 / 256;       // 4 A items per thread per pair
+    constexpr int NBP = 3 * TN;            // 16-byte weight chunks per thread per pair (2 steps * 3 planes * NG * 64 / 256)
+    constexpr int CPS = 3 * NG * 64;       // chunks per step
     const int seg = pt & 7;
     const int HW = d.H * d.W;
     unsigned a_off[NI];
     int l_off[NI];
 #pragma unroll
     for (int i = 0; i < NI; ++i) {
-      const int row = (pt >> 3) + i * 16;
+      const int row = (pt >> 3) + i * 32;
       int m = m0 + row;
       m = m < M ? m : M - 1;                                            // ragged last tile: re-read a valid row (discarded)
       a_off[i] = (unsigned)(((int64_t)m * d.in_sx + seg * 4) * 4);
@@ -120,15 +86,35 @@ __global__ __launch_bounds__(512, 2) void gemm1x1_pc_kernel(const vs_conv_desc_t
     // frame and rows 64-127 in one frame -> two scale vectors + one shift vector per thread and pair, loaded with the data
     const int f_lo = min(m0 / HW, d.B - 1), f_hi = min((m0 + 64) / HW, d.B - 1);
     const char* const abase = reinterpret_cast<const char*>(d.in) + (int64_t)pair0 * 128;
-    const bool grn = d.a_scale != nullptr;
+    constexpr bool grn = GRN;       // compile-time: a run-time branch around the scale loads makes hipcc's vmcnt counting pessimistic
     const char* const sbase0 = reinterpret_cast<const char*>(d.a_scale) + ((int64_t)f_lo * d.a_scale_ld + pair0 * 32 + seg * 4) * 4;
     const char* const sbase1 = reinterpret_cast<const char*>(d.a_scale) + ((int64_t)f_hi * d.a_scale_ld + pair0 * 32 + seg * 4) * 4;
     const char* const hbase = reinterpret_cast<const char*>(d.a_shift) + ((int64_t)pair0 * 32 + seg * 4) * 4;
+    // weight chunks of this thread
+    const int g0 = n0 / 32;
+    const int ngroups = (d.N + 31) / 32;
+    const int nch = d.CinP / 16;
+    unsigned b_goff[NBP];
+    int b_loff[NBP];
+    bool b_half[NBP];
+#pragma unroll
+    for (int j = 0; j < NBP; ++j) {
+      const int cid = pt + j * 256;
+      const int half = cid >= CPS ? 1 : 0;
+      const int c = cid - half * CPS;
+      const int p = c / (NG * 64), rem = c - p * (NG * 64);
+      const int gi = rem >> 6, l = rem & 63;
+      const int gsel = (g0 + gi) < ngroups ? g0 + gi : ngroups - 1;     // tile wider than N: re-read a valid group (columns discarded)
+      b_goff[j] = (unsigned)(((int64_t)gsel * nch + half) * 3072 + p * 1024 + l * 16);
+      b_loff[j] = half * B_STAGE + p * (BN * 32) + gi * 1024 + l * 16;
+      b_half[j] = half != 0;
+    }
+    const char* const wbase = reinterpret_cast<const char*>(d.wt_blk) + (int64_t)(2 * pair0) * 3072;
     const int lastp = npairs - 1;
 
-    struct ASet { f32x4 r[NI]; f32x4 s0, s1, h; };
-    ASet rs0, rs1, rs2;      // three rotating register sets
-    auto load_pair = [&](ASet& R, int j) __attribute__((always_inline)) {
+    struct PSet { f32x4 r[NI]; f32x4 s0, s1, h; u32x4 b[NBP]; };
+    PSet rs0, rs1, rs2;      // three rotating register sets
+    auto load_pair = [&](PSet& R, int j) __attribute__((always_inline)) {
       j = j < lastp ? j : lastp;                                        // past the end: harmless re-read, keeps the body branch-free
       const char* base = abase + (int64_t)j * 128;
 #pragma unroll
@@ -138,10 +124,12 @@ __global__ __launch_bounds__(512, 2) void gemm1x1_pc_kernel(const vs_conv_desc_t
         R.s1 = *reinterpret_cast<const f32x4*>(sbase1 + (int64_t)j * 128);
         R.h = *reinterpret_cast<const f32x4*>(hbase + (int64_t)j * 128);
       }
+      const char* wb = wbase + (int64_t)j * (2 * 3072);
+#pragma unroll
+      for (int q = 0; q < NBP; ++q) R.b[q] = *reinterpret_cast<const u32x4*>(wb + b_goff[q]);
     };
-    // half h of the pair in R -> stage (step parity h): seg>>2 == h for this thread's items or not at all, so each thread
-    // stores ALL its items at one of the two steps; threads with seg 0-3 store at the even step, seg 4-7 at the odd one.
-    auto store_half = [&](const ASet& R, const int h) __attribute__((always_inline)) {
+    // half h of the pair in R -> stage h: every thread stores its A items at one of the two steps (seg 0-3: even, 4-7: odd)
+    auto store_half = [&](const PSet& R, const int h) __attribute__((always_inline)) {
       if ((seg >> 2) == h) {
 #pragma unroll
         for (int i = 0; i < NI; ++i) {
@@ -155,6 +143,9 @@ __global__ __launch_bounds__(512, 2) void gemm1x1_pc_kernel(const vs_conv_desc_t
           *reinterpret_cast<u32x2*>(dst + 2 * BM * ROWB) = p3;
         }
       }
+#pragma unroll
+      for (int q = 0; q < NBP; ++q)
+        if (b_half[q] == (h != 0)) *reinterpret_cast<u32x4*>(Bring + b_loff[q]) = R.b[q];
     };
     // A(t) (step t) is written during step t-2 and read (prefetched) during step t-1: two stages, stage = t & 1.
     // prologue: pair 0 -> both stages; pairs 1, 2, 3 -> registers.
@@ -165,6 +156,7 @@ __global__ __launch_bounds__(512, 2) void gemm1x1_pc_kernel(const vs_conv_desc_t
     store_half(rs0, 1);
     load_pair(rs0, 3);
     __syncthreads();
+    __syncthreads();        // the consumers read the fragments of step 0 between these two barriers: stage 0 is rewritten in step 0
     // steps 2j, 2j+1 (consumers on pair j): store pair j+1 (set (j+1)%3), then reload that set with pair j+4
     for (int j = 0; j < npairs; j += 3) {
       store_half(rs1, 0);
@@ -203,7 +195,7 @@ __global__ __launch_bounds__(512, 2) void gemm1x1_pc_kernel(const vs_conv_desc_t
   struct Frags { bf16x8 a[TM][3]; bf16x8 b[TN][3]; };
   Frags F0, F1;
   auto load_frags = [&, a_frag, b_frag](Frags& F, const int s) __attribute__((always_inline)) {
-    const unsigned char* Bb = Bring + (s % NRING) * B_STAGE;
+    const unsigned char* Bb = Bring + (s & 1) * B_STAGE;
 #pragma unroll
     for (int j = 0; j < TN; ++j)
 #pragma unroll
@@ -229,6 +221,7 @@ __global__ __launch_bounds__(512, 2) void gemm1x1_pc_kernel(const vs_conv_desc_t
   __syncthreads();
   load_frags(F0, 0);
   __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0), see conv3x3_patch_pc.hip
+  __syncthreads();                       // step 0's operands are in registers: the producers may now overwrite stage 0 with step 2's
   int s = 0;
   for (; s + 2 < total; s += 2) {
     load_frags(F1, s + 1);
@@ -344,7 +337,10 @@ int launch_g(const vs_conv_desc_t& d, hipStream_t st) {
   const int pps = (pairs + sk - 1) / sk;
   if ((int64_t)(sk - 1) * pps >= pairs) return VS_ERR_BAD_ARG;           // an empty K slice
   if (mt * nt * sk > 0x7fffffffLL || M > 0x7fffffffLL) return VS_ERR_UNSUPPORTED;
-  hipLaunchKernelGGL((gemm1x1_pc_kernel<TN>), dim3((unsigned)(mt * nt * sk)), dim3(512), 0, st, d, (int)M, (int)mt, (int)nt, pps);
+  if (d.a_scale)
+    hipLaunchKernelGGL((gemm1x1_pc_kernel<TN, true>), dim3((unsigned)(mt * nt * sk)), dim3(512), 0, st, d, (int)M, (int)mt, (int)nt, pps);
+  else
+    hipLaunchKernelGGL((gemm1x1_pc_kernel<TN, false>), dim3((unsigned)(mt * nt * sk)), dim3(512), 0, st, d, (int)M, (int)mt, (int)nt, pps);
   int rc = vs_launch_status();
   if (rc != VS_OK || sk == 1) return rc;
   return vs_splitk_epilogue(d, (int)M, st);
