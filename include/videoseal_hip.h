@@ -127,6 +127,9 @@ int vs_dwconv7_ln(const float* x, int B, int H, int W, int C, int64_t ld, const 
  * over the activations. */
 int vs_grn_scale_from_partials(const float* partial, int B, int HW, int C, const float* gamma, float* scale, int64_t scale_ld,
                                void* stream);
+/* GRN apply as a separate in-place pass: h = h * scale[b] + beta (common.py:168 minus the residual `+ x`, which the caller's
+ * pwconv2 input convention already folds into scale = 1 + gamma*Nx).  beta must be readable up to the next multiple of 4. */
+int vs_grn_apply(float* h, int B, int HW, int C, int64_t ld, const float* scale, int64_t scale_ld, const float* beta, void* stream);
 int vs_grn_scale(const float* h, int B, int HW, int C, int64_t ld, const float* gamma, float* partial,
                  float* scale, void* stream);
 

@@ -257,3 +257,17 @@ def test_uint8_rgb24_clip_path(tiny, lowres):
         model.embed_u8(clip.cuda().float(), msgs)
     with pytest.raises(ValueError):
         model.detect_u8(clip.cuda()[..., :2])
+
+
+def test_wide_chunky_detector_vs_oracle():
+    """ChunkySeal's extractor shape at a size the CPU oracle handles: channel counts >= 128 that are not multiples of 32 (activation
+    strides padded to whole 32-channel K pairs), stride-2 stem -> 31 x 31 / 15 x 15 feature maps (frames do not align with the GEMM's
+    64-row halves -> GRN applied by vs_grn_apply), wave-specialised 1x1 GEMM + K split on the padded layers."""
+    s = tiny_spec(yuv=False, in_ch=3, out_ch=3, dims=[130, 148, 260, 300], depths=[1, 1, 2, 1], stem_stride=2, hidden=32, nbits=16)
+    sd = make_state_dict(s, seed=6)
+    model = make_model(s, sd)
+    imgs = synthetic_frames(5, 80, 72, seed=12)
+    ref = R.detect(sd, s, imgs)["preds"]
+    got = model.detect(imgs.cuda(), is_video=True)["preds"].cpu()
+    assert (got - ref).abs().max().item() < TOL_LOGIT * max(1.0, ref.abs().max().item())
+    assert ((got > 0) == (ref > 0))[ref.abs() > 1e-3].all()

@@ -363,6 +363,34 @@ extern "C" int vs_grn_scale(const float* h, int B, int HW, int C, int64_t ld, co
   return vs_launch_status();
 }
 
+// h[b, r, c] = h[b, r, c] * scale[b][c] + beta[c] in place (pad lanes untouched): the GRN apply as its own pass, for layers whose
+// frames do not align with the 64-row halves the fused GEMM transform assumes
+__global__ __launch_bounds__(256) void grn_apply_kernel(float* __restrict__ h, int64_t rows, int HW, int C, int64_t ld,
+                                                        const float* __restrict__ scale, int64_t sld, const float* __restrict__ beta) {
+  const int C4 = (C + 3) >> 2;
+  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= rows * C4) return;
+  const int64_t m = idx / C4;
+  const int c = (int)(idx - m * C4) * 4;
+  const int b = (int)(m / HW);
+  f32x4 v = *reinterpret_cast<f32x4*>(h + m * ld + c);
+  const f32x4 s = *reinterpret_cast<const f32x4*>(scale + (int64_t)b * sld + c);
+  const f32x4 sh = *reinterpret_cast<const f32x4*>(beta + c);
+  const f32x4 o = v * s + sh;                     // same expression as the GEMM's fused transform
+#pragma unroll
+  for (int e = 0; e < 4; ++e) v[e] = c + e < C ? o[e] : v[e];
+  *reinterpret_cast<f32x4*>(h + m * ld + c) = v;
+}
+
+extern "C" int vs_grn_apply(float* h, int B, int HW, int C, int64_t ld, const float* scale, int64_t scale_ld, const float* beta,
+                            void* stream) {
+  VS_REQUIRE(h && scale && beta && B > 0 && HW > 0 && C > 0 && ld >= C && (ld & 3) == 0 && (scale_ld & 3) == 0 && scale_ld >= ((C + 3) & ~3));
+  const int64_t rows = (int64_t)B * HW, items = rows * ((C + 3) >> 2);
+  hipLaunchKernelGGL(grn_apply_kernel, dim3((unsigned)cdiv64(items, 256)), dim3(256), 0, (hipStream_t)stream, h, rows, HW, C, ld, scale,
+                     scale_ld, beta);
+  return vs_launch_status();
+}
+
 extern "C" int vs_grn_scale_from_partials(const float* partial, int B, int HW, int C, const float* gamma, float* scale,
                                           int64_t scale_ld, void* stream) {
   VS_REQUIRE(partial && gamma && scale && B > 0 && HW > 0 && HW % 32 == 0 && C > 0 && scale_ld >= C);

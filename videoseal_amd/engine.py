@@ -208,6 +208,12 @@ class HipEngine:
                 raise N.NativeError(f"U-Net channel count {ch} is not a multiple of 4 (unsupported by the HIP path)")
         self.E = E
 
+    @staticmethod
+    def _xld(C_: int) -> int:
+        """channel stride of the extractor's activations: wide layers are padded to whole 32-channel K pairs (zero lanes) so that the
+        wave-specialised 1x1 GEMM applies to ChunkySeal's 362 / 724 / 1448 / 2896-channel stages as well"""
+        return rup(C_, 32) if C_ >= 128 else rup(C_, 4)
+
     def _pack_extractor(self, g):
         c = self.cfg
         cn = "detector.convnext"
@@ -218,7 +224,7 @@ class HipEngine:
         X["stem_ln"] = (g(f"{cn}.downsample_layers.0.1.weight").float().contiguous(), g(f"{cn}.downsample_layers.0.1.bias").float().contiguous())
         X["down"] = []
         for i in range(3):
-            wd, cp = pack_patch_conv(g(f"{cn}.downsample_layers.{i+1}.1.weight"), rup(d[i], 4))
+            wd, cp = pack_patch_conv(g(f"{cn}.downsample_layers.{i+1}.1.weight"), self._xld(d[i]))
             X["down"].append(dict(lnw=g(f"{cn}.downsample_layers.{i+1}.0.weight").float().contiguous(),
                                   lnb=g(f"{cn}.downsample_layers.{i+1}.0.bias").float().contiguous(),
                                   conv=ConvW(wd, g(f"{cn}.downsample_layers.{i+1}.1.bias").float().contiguous(), d[i + 1], 2, 1, cp)))
@@ -226,7 +232,7 @@ class HipEngine:
         for st in range(4):
             blocks = []
             Cc = d[st]
-            ld, ld4 = rup(Cc, 4), rup(4 * Cc, 4)
+            ld, ld4 = self._xld(Cc), self._xld(4 * Cc)
             for j in range(c.depths[st]):
                 p = f"{cn}.stages.{st}.{j}"
                 wdw = torch.zeros(49, ld, device=self.dev)
@@ -240,7 +246,7 @@ class HipEngine:
                                    pw2=ConvW(w2, g(p + ".pwconv2.bias").float().contiguous(), Cc, 1, 1, cp2)))
             X["stages"].append(blocks)
         pd = "detector.pixel_decoder"
-        wh, cph = pack_conv(g(pd + ".output_upscaling.0.upsample_block.2.weight"), rup(d[-1], 4))
+        wh, cph = pack_conv(g(pd + ".output_upscaling.0.upsample_block.2.weight"), self._xld(d[-1]))
         X["head_conv"] = ConvW(wh, None, d[-1], 3, 3, cph)
         X["head_ln"] = (g(pd + ".output_upscaling.0.upsample_block.3.weight").float().contiguous(), g(pd + ".output_upscaling.0.upsample_block.3.bias").float().contiguous())
         X["lin_w"] = g(pd + ".linear.weight").float().contiguous()
@@ -509,21 +515,21 @@ class HipEngine:
         d = c.dims
         t = self.new_act("stem.c", B, Ho, Wo, d[0])
         self.conv(x, X["stem"], t, geom=(Wo, s * 4, 16, s, 1, 0, 0))
-        cur = self.new_act("st0.x", B, Ho, Wo, d[0])
+        cur = self.new_act("st0.x", B, Ho, Wo, d[0], self._xld(d[0]))
         self.layernorm(t, X["stem_ln"][0], X["stem_ln"][1], cur)
         for sti in range(4):
             if sti > 0:
                 dn = X["down"][sti - 1]
-                ln = self.new_act(f"st{sti}.dln", B, cur.H, cur.W, cur.C)
+                ln = self.new_act(f"st{sti}.dln", B, cur.H, cur.W, cur.C, cur.ld)
                 self.layernorm(cur, dn["lnw"], dn["lnb"], ln)
                 Ho, Wo = cur.H // 2, cur.W // 2
-                nxt = self.new_act(f"st{sti}.x", B, Ho, Wo, d[sti])
+                nxt = self.new_act(f"st{sti}.x", B, Ho, Wo, d[sti], self._xld(d[sti]))
                 self.conv(ln, dn["conv"], nxt, geom=(Wo, 2 * ln.ld, 2 * ln.ld, 2, 1, 0, 0))
                 cur = nxt
             Cc = d[sti]
             HW = cur.H * cur.W
-            tn = self.new_act(f"st{sti}.n", B, cur.H, cur.W, Cc)
-            hh = self.new_act(f"st{sti}.h", B, cur.H, cur.W, 4 * Cc)
+            tn = self.new_act(f"st{sti}.n", B, cur.H, cur.W, Cc, self._xld(Cc))
+            hh = self.new_act(f"st{sti}.h", B, cur.H, cur.W, 4 * Cc, self._xld(4 * Cc))
             nchunk = (HW + 63) // 64
             part = self.buf(f"st{sti}.gp", nchunk * B * 4 * Cc)
             scale = self.buf(f"st{sti}.gs", B * hh.ld + 16)   # +16: the conv A-transform reads whole 16-float chunks
@@ -539,7 +545,11 @@ class HipEngine:
                     self.conv(tn, blk["pw1"], hh, act=N.ACT_GELU)
                     N.check(L.vs_grn_scale(N.ptr(hh.t), B, HW, 4 * Cc, hh.ld, N.ptr(blk["gamma"]), N.ptr(part), N.ptr(scale), st),
                             "vs_grn_scale")
-                self.conv(hh, blk["pw2"], cur, res=cur, a_scale=scale, a_scale_ld=hh.ld, a_shift=blk["beta"])
+                if HW % 64 == 0 or not self.use_split:
+                    self.conv(hh, blk["pw2"], cur, res=cur, a_scale=scale, a_scale_ld=hh.ld, a_shift=blk["beta"])
+                else:     # frames do not align with the GEMM's 64-row halves (ChunkySeal: 31 x 31): apply GRN in place, then a plain GEMM
+                    N.check(L.vs_grn_apply(N.ptr(hh.t), B, HW, 4 * Cc, hh.ld, N.ptr(scale), hh.ld, N.ptr(blk["beta"]), st), "vs_grn_apply")
+                    self.conv(hh, blk["pw2"], cur, res=cur)
         hc = self.new_act("head.c", B, cur.H, cur.W, d[-1])
         self.conv(cur, X["head_conv"], hc, pad=1, pad_mode=N.PAD_REFLECT)
         hl = self.new_act("head.l", B, cur.H, cur.W, d[-1])
