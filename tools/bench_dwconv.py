@@ -1,0 +1,22 @@
+#!/usr/bin/env python
+"""dwconv7 + LayerNorm of the four ConvNeXt stages (B = 32 frames at 256^2 proc): time and effective GB/s (in + out)."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from videoseal_amd import native as N
+L = N.lib()
+B = 32
+for HW, Cc in ((64, 96), (32, 192), (16, 384), (8, 768)):
+    x = torch.randn(B, HW, HW, Cc, device="cuda"); out = torch.empty_like(x)
+    wdw = torch.randn(49, Cc, device="cuda"); v = [torch.randn(Cc, device="cuda") for _ in range(3)]
+    fn = lambda: N.check(L.vs_dwconv7_ln(N.ptr(x), B, HW, HW, Cc, Cc, N.ptr(wdw), N.ptr(v[0]), N.ptr(v[1]), N.ptr(v[2]), 1e-6, N.ptr(out), Cc, N.stream()), "dw")
+    for _ in range(3): fn()
+    torch.cuda.synchronize()
+    best = 1e9
+    for _ in range(3):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(20): fn()
+        e1.record(); torch.cuda.synchronize()
+        best = min(best, e0.elapsed_time(e1) / 20)
+    print(f"dwconv7_ln {HW}x{HW} C={Cc}: {best*1e3:7.1f} us  {2*x.numel()*4/best/1e6:6.0f} GB/s  ({49*x.numel()*2/best/1e9:5.1f} TFLOP/s fp32 FMA)")
