@@ -101,6 +101,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--mode", choices=["image", "video", "stream"], default="image",
                     help="stream = BASELINE config 4: --frames frames processed as 16-frame embed(lowres_attenuation)+detect calls")
+    ap.add_argument("--u8", action="store_true", help="stream mode: uint8 RGB24 clips in and out (inference_streaming.py's data format) "
+                    "through embed_u8 / detect_u8 instead of fp32 NCHW tensors")
     ap.add_argument("--frames", type=int, default=1024, help="stream mode: total frames of the clip (sharded over the ranks)")
     ap.add_argument("--graphs", action="store_true", help="replay the per-chunk launch sequences from hipGraphs")
     ap.add_argument("--batch", type=int, default=32)
@@ -141,6 +143,7 @@ def main():
         f0, f1 = shard_range(args.frames, rank, world, 16)
         B = f1 - f0
     frames = synthetic_batch(B, S, dev, seed=1000 + rank)
+    frames_u8 = (frames * 255.0).to(torch.uint8).permute(0, 2, 3, 1).contiguous() if (stream and args.u8) else None
     gm = torch.Generator().manual_seed(5)
     is_video = args.mode in ("video", "stream")
     msgs = torch.randint(0, 2, (1 if is_video else B, cfg.nbits), generator=gm)
@@ -149,8 +152,12 @@ def main():
     def step_stream():      # inference_streaming.py:83-107,117-164: 16-frame chunks, low-res attenuation, mean of the logits
         logits = []
         for a in range(0, B, 16):
-            w = model.embed(frames[a:a + 16], msgs, is_video=True, lowres_attenuation=True)["imgs_w"]
-            logits.append(model.detect(w, is_video=True)["preds"])
+            if args.u8:
+                w = model.embed_u8(frames_u8[a:a + 16], msgs, lowres_attenuation=True)["imgs_w"]
+                logits.append(model.detect_u8(w)["preds"])
+            else:
+                w = model.embed(frames[a:a + 16], msgs, is_video=True, lowres_attenuation=True)["imgs_w"]
+                logits.append(model.detect(w, is_video=True)["preds"])
         preds = torch.cat(logits, 0)
         if dist_on:
             preds = gather_frame_logits(preds, args.frames, align=16)
@@ -250,7 +257,7 @@ def main():
                                    f"({'embedder on every frame' if not is_video else 'key frames every %d' % cfg.step_size}, "
                                    f"{'low-res' if args.lowres_attenuation else 'full-res'} JND), " + ("detect only" if args.detect_only else "embed + detect")
                                    + (", all-gather of bit logits" if dist_on else "")
-                                   + (f"; streaming: {args.frames}-frame clip as 16-frame calls, low-res JND" if stream else "")
+                                   + (f"; streaming: {args.frames}-frame clip as 16-frame calls, low-res JND" + (", uint8 RGB24 in/out" if args.u8 else "") if stream else "")
                                    + (", hipGraph replay" if args.graphs else ""),
                        "card": args.card, "weights": "random-init (seeded), no checkpoint offline", "batch_per_gpu": B,
                        "frame": [S, S], "mode": args.mode},

@@ -244,11 +244,24 @@ __global__ __launch_bounds__(256) void upcat2x_kernel(const float* __restrict__ 
 // ---------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void msg_latent_kernel(const float* __restrict__ table, const int32_t* __restrict__ msgs,
                                                          int nbits, int hidden, float* __restrict__ lat) {
+  // the row index of every bit first (LDS), so that the table loads below do not depend on a load each: 16 of them are in
+  // flight at a time instead of 2 x nbits serial round trips; the summation order (k ascending) is unchanged
+  __shared__ int rowsel[1024];
   const int b = blockIdx.y;
+  for (int k = threadIdx.x; k < nbits; k += 256) rowsel[k] = 2 * k + (msgs[(int64_t)b * nbits + k] != 0);
+  __syncthreads();
   const int c = blockIdx.x * 256 + threadIdx.x;
   if (c >= hidden) return;
   float s = 0.f;
-  for (int k = 0; k < nbits; ++k) s += table[(int64_t)(2 * k + (msgs[(int64_t)b * nbits + k] != 0)) * hidden + c];
+  int k = 0;
+  for (; k + 16 <= nbits; k += 16) {
+    float v[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) v[j] = table[(int64_t)rowsel[k + j] * hidden + c];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) s += v[j];
+  }
+  for (; k < nbits; ++k) s += table[(int64_t)rowsel[k] * hidden + c];
   lat[(int64_t)b * hidden + c] = s;
 }
 __global__ __launch_bounds__(256) void broadcast_channels_kernel(const float* __restrict__ lat, int Bm, int hidden,
@@ -410,7 +423,7 @@ extern "C" int vs_upcat2x(const float* x, int C1, int64_t ld1, const float* skip
 }
 
 extern "C" int vs_msg_latent(const float* table, const int32_t* msgs, int Bm, int nbits, int hidden, float* lat, void* stream) {
-  VS_REQUIRE(table && msgs && lat && Bm > 0 && nbits > 0 && hidden > 0);
+  VS_REQUIRE(table && msgs && lat && Bm > 0 && nbits > 0 && nbits <= 1024 && hidden > 0);
   hipLaunchKernelGGL(msg_latent_kernel, dim3((unsigned)((hidden + 255) / 256), (unsigned)Bm), dim3(256), 0, (hipStream_t)stream,
                      table, msgs, nbits, hidden, lat);
   return vs_launch_status();
