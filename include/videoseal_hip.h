@@ -89,7 +89,7 @@ typedef struct vs_conv_desc {
                             /* 6 = 256x128, 7 = 128x128, 8 = 128x64, 9 = 256x64 (producer/consumer, need wt_blk);   */
                             /* 10 = 128x32, 11 = 128x64, 12 = 128x128: 3x3 stride-1 'patch' kernel (8x16-pixel tile);  */
                             /* 13 = 64x64, 14 = 64x128 (generic kernel, small-M layers);                              */
-                            /* 15 = 128x128, 16 = 128x192, 19 = 128x64: wave-specialised patch kernel (needs wt_blk);   */
+                            /* 15 = 128x128, 16 = 128x192, 19 = 128x64, 21 = 256x64: wave-specialised patch kernel (needs wt_blk); */
                             /* 20: persistent 3x3 kernel for 16-input-channel layers with <= 32 outputs (weights in registers);          */
                             /* 17 = 128x128, 18 = 128x192: wave-specialised 1x1 GEMM (dense rows, Cin % 32 == 0, wt_blk);  */
                             /* | VS_CONV_TILE_HI: tile code + 16;                                                     */

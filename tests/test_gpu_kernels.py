@@ -173,6 +173,8 @@ CONV_CASES = [
     (2, 1, 24, 32, 16, 3, 1, 1, 0, 1, 0x44),
     (5, 12, 40, 40, 20, 3, 1, 1, 0, 3, 0x44),
     (2, 768, 16, 16, 64, 3, 1, 1, 0, 1, 0x43),      # 0x43 = tile 19: 128 x 64
+    (2, 768, 32, 16, 64, 3, 1, 1, 0, 1, 0x45),      # 0x45 = tile 21: 256 px x 64 ch
+    (3, 80, 21, 37, 50, 3, 1, 1, 1, 2, 0x45),
     (3, 48, 13, 21, 70, 3, 1, 1, 1, 2, 0x43),
     (3, 160, 7, 9, 130, 3, 2, 1, 0, 1, 14),
 ]
@@ -202,7 +204,7 @@ def test_conv_gemm_matches_conv2d(eng, case):
     assert torch.isfinite(full).all() and (full[..., Cout:] == 0).all()   # pad lanes written as zero
 
 
-@pytest.mark.parametrize("tile", [0, 7, 8, 10, 11, 1, 15, 0x40, 0x43])
+@pytest.mark.parametrize("tile", [0, 7, 8, 10, 11, 1, 15, 0x40, 0x43, 0x45])
 def test_conv_two_phase_residual_block(eng, tile):
     """ResnetBlock tail: relu(conv3x3(t)+b) + (conv1x1(x)+b2), written at a channel offset of a wider buffer."""
     if tile >= 6 and not eng.use_split:

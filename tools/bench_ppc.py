@@ -45,5 +45,5 @@ if __name__ == "__main__":
     run(32, 384, 32, 32, 384, [12, 15, 0x40], True)
     run(8, 384, 32, 32, 384, [12, 15, 0x40], False)
     run(32, 128, 32, 32, 128, [12, 15], False)
-    run(32, 768, 64, 64, 64, [11, 15, 0x43], False)
-    run(32, 64, 64, 64, 64, [11, 0x43], True)
+    run(32, 768, 64, 64, 64, [11, 0x43, 0x45], False)
+    run(32, 64, 64, 64, 64, [11, 0x43, 0x45], True)

@@ -21,11 +21,20 @@ namespace {
 
 using namespace vsconv;
 
-constexpr int TH = 8, TW = 16, PW = TW + 2, PH = TH + 2, PROWS = PW * PH;   // 180 patch pixels
-constexpr int PITEMS = PROWS * 4;
-constexpr int BMP = TH * TW;
-constexpr int NPI = (PITEMS + 127) / 128;                                    // patch float4 items per producer thread (6)
-constexpr int P_BYTES = 3 * PROWS * ROWB;                                    // one patch buffer, three bf16 planes
+constexpr int TW = 16, PW = TW + 2;
+// tile geometry: TH x 16 output pixels.  TH = 8: 128 pixels, consumers 2 x 2 (64 px x 32*TN ch each), BN = 64*TN.
+//                                        TH = 16: 256 pixels, consumers 4 x 1 (64 px x 32*TN ch each), BN = 32*TN -- for
+// 64-channel layers (768->64 @64^2): with 128-pixel tiles a wave reads 9 fragments per 12 MFMAs and the kernel is LDS-bound.
+template <int TH_>
+struct Geo {
+  static constexpr int TH = TH_, PH = TH_ + 2, PROWS = PW * PH;              // 180 / 324 patch pixels
+  static constexpr int PITEMS = PROWS * 4;
+  static constexpr int BMP = TH_ * TW;
+  static constexpr int NPI = (PITEMS + 127) / 128;                            // patch float4 items per producer thread (6 / 11)
+  static constexpr int IPT = (NPI + 5) / 6;                                   // of which per tap-step (taps 2..7)
+  static constexpr int P_BYTES = 3 * PROWS * ROWB;                            // one patch buffer, three bf16 planes
+  static constexpr int WN = TH_ == 8 ? 2 : 1, WM = 4 / WN;
+};
 
 // one wave moves a 1 KiB block global -> LDS (lane l: 16 bytes at gp, landing at lds_base + 16*l)
 __device__ __forceinline__ void dma_1k(const char* gp, unsigned char* lds_base) {
@@ -33,11 +42,13 @@ __device__ __forceinline__ void dma_1k(const char* gp, unsigned char* lds_base) 
                                    (__attribute__((address_space(3))) void*)lds_base, 16, 0, 0);
 }
 
-template <int TN>
+template <int TN, int TH_>
 __global__ __launch_bounds__(512, 2) void conv3x3_patch_pc_kernel(const vs_conv_desc_t d, const int tiles_x, const int tiles_y,
                                                                   const int mtiles, const int ntiles, const int cps) {
+  using G = Geo<TH_>;
+  constexpr int TH = G::TH, PROWS = G::PROWS, PITEMS = G::PITEMS, BMP = G::BMP, NPI = G::NPI, P_BYTES = G::P_BYTES;
   constexpr int TM = 2;
-  constexpr int BN = 64 * TN;
+  constexpr int BN = G::WN * TN * 32;
   constexpr int NG = BN / 32;                            // 32-row weight groups per tile
   constexpr int NRING = TN >= 3 ? 5 : 6;                 // weight ring depth (LDS: 2 patches + NRING tiles <= 160 KiB)
   constexpr int B_STAGE = 3 * BN * 32;                   // three planes of [BN rows][16 bf16], rows unpadded (DMA-written)
@@ -180,7 +191,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_patch_pc_kernel(const vs_conv_
       unsigned char* Ps = Pbuf + pb * P_BYTES;
 #pragma unroll
       for (int i = 0; i < NPI; ++i)
-        if (p_have[i] && (first < 0 || tap == first + i)) {
+        if (p_have[i] && (first < 0 || tap == first + i / G::IPT)) {
           u32x2 p1, p2, p3;
           split4(rp[i], p1, p2, p3);
           *reinterpret_cast<u32x2*>(Ps + p_lds[i]) = p1;
@@ -224,7 +235,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_patch_pc_kernel(const vs_conv_
     for (int s = 0; s < total; ++s) {
       if (abl & 4) {
       } else if (s < n1) {
-        if (tap >= 2 && tap < 2 + NPI && cc + 1 < spt) store_patch((cc + 1) & 1, tap, 2);   // split + stored at taps 2..7 (other buffer)
+        if (tap >= 2 && tap < 8 && cc + 1 < spt) store_patch((cc + 1) & 1, tap, 2);   // split + stored at taps 2..7 (other buffer)
         if (tap == 8 && cc + 2 < spt) load_patch(cc + 2);                 // registers are free again: request the patch after next
         if (n2 > 0 && cc == spt - 1) {
           if (tap == 1) load_rows2(0);
@@ -241,7 +252,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_patch_pc_kernel(const vs_conv_
   }
 
   // ==================================================================== consumers (2 x 2 waves, 64 px x 32*TN... each)
-  const int wm = wave >> 1, wn = wave & 1;
+  const int wm = G::WN == 2 ? wave >> 1 : wave, wn = G::WN == 2 ? wave & 1 : 0;
   f32x16 acc[TM][TN];
 #pragma unroll
   for (int i = 0; i < TM; ++i)
@@ -391,9 +402,10 @@ __global__ __launch_bounds__(512, 2) void conv3x3_patch_pc_kernel(const vs_conv_
   }
 }
 
-template <int TN>
+template <int TN, int TH_ = 8>
 int launch_ppc(const vs_conv_desc_t& d, hipStream_t st) {
-  constexpr int BN = 64 * TN;
+  constexpr int BN = Geo<TH_>::WN * TN * 32;
+  constexpr int TH = TH_;
   const int tiles_x = (d.W + TW - 1) / TW, tiles_y = (d.H + TH - 1) / TH;
   const int sk = d.split_k > 1 ? d.split_k : 1;
   const int64_t mt = (int64_t)d.B * tiles_x * tiles_y, nt = cdiv64(sk > 1 ? d.N : d.n_store, BN);
@@ -402,7 +414,7 @@ int launch_ppc(const vs_conv_desc_t& d, hipStream_t st) {
   if (sk > 1 && (int64_t)(sk - 1) * cps >= spt) return VS_ERR_BAD_ARG;       // an empty K slice
   const int slices = sk > 1 ? sk + (d.in2 ? 1 : 0) : 1;
   if (mt * nt * slices > 0x7fffffffLL) return VS_ERR_UNSUPPORTED;
-  hipLaunchKernelGGL((conv3x3_patch_pc_kernel<TN>), dim3((unsigned)(mt * nt * slices)), dim3(512), 0, st, d, tiles_x, tiles_y, (int)mt,
+  hipLaunchKernelGGL((conv3x3_patch_pc_kernel<TN, TH_>), dim3((unsigned)(mt * nt * slices)), dim3(512), 0, st, d, tiles_x, tiles_y, (int)mt,
                      (int)nt, cps);
   int rc = vs_launch_status();
   if (rc != VS_OK || sk == 1) return rc;
@@ -417,6 +429,7 @@ int vs_conv3x3_patch_pc_dispatch(const vs_conv_desc_t& d, int tile, hipStream_t 
     case 15: return launch_ppc<2>(d, st);
     case 16: return launch_ppc<3>(d, st);
     case 19: return launch_ppc<1>(d, st);
+    case 21: return launch_ppc<2, 16>(d, st);      // 256 pixels x 64 channels
     default: return VS_ERR_UNSUPPORTED;
   }
 }

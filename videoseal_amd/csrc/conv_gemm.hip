@@ -437,7 +437,7 @@ extern "C" int vs_conv_gemm(const vs_conv_desc_t* dp, void* stream) {
     VS_REQUIRE(patch_ok);
     return vs_conv3x3_patch_dispatch(d, tile, st);
   }
-  if (tile == 15 || tile == 16 || tile == 19) {   // wave-specialised patch kernel
+  if (tile == 15 || tile == 16 || tile == 19 || tile == 21) {   // wave-specialised patch kernel
     VS_REQUIRE(patch_ok && d.wt_blk && (!d.in2 || d.wt2_blk) && ((uintptr_t)d.wt_blk & 15) == 0);
     if (d.split_k > 1) VS_REQUIRE(d.splitk_ws && d.splitk_ld >= d.N && d.split_k <= d.CinP / 16 && !d.sumsq_part);
     return vs_conv3x3_patch_pc_dispatch(d, tile, st);
@@ -464,6 +464,7 @@ extern "C" int vs_conv_gemm(const vs_conv_desc_t* dp, void* stream) {
   if (tile == 0 && patch_ok && d.W % 16 == 0 && d.H % 8 == 0) {
     const bool blk_ok = d.wt_blk && (!d.in2 || d.wt2_blk) && ((uintptr_t)d.wt_blk & 15) == 0;
     if (blk_ok && d.N >= 128) return vs_conv3x3_patch_pc_dispatch(d, d.N % 192 == 0 ? 16 : 15, st);   // wave-specialised for wide layers
+    if (blk_ok && d.N > 32 && d.N <= 64 && d.H % 16 == 0 && d.CinP >= 64) return vs_conv3x3_patch_pc_dispatch(d, 21, st);   // 256 px x 64 ch
     return vs_conv3x3_patch_dispatch(d, d.N <= 32 ? 10 : (d.N <= 64 ? 11 : 12), st);
   }
   if (tile == 0) tile = d.N <= 32 ? 3 : (d.N <= 64 ? 2 : (d.N <= 96 ? 5 : ((d.N % 192 == 0 || (d.N > 128 && d.N <= 192)) ? 4 : 1)));

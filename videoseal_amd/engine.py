@@ -412,6 +412,8 @@ class HipEngine:
             # 15 / TILE_HI|0 (=16): wave-specialised variants, 128 and 192 output channels per workgroup
             widths = {10: 32, 11: 64, 12: 128, 15: 128, N.CONV_TILE_HI: 192}
             cands = [t for t in widths if widths[t] < 2 * d.N + 64 or t == 10]
+            if 32 < d.N <= 64 and d.H % 16 == 0 and d.CinP >= 64:
+                cands.append(N.CONV_TILE_HI | 5)      # tile 21: 256 pixels x 64 channels (wave-specialised)
         elif d.split_k > 1:      # K-split plan fixed by the shape rule: only the kernels that implement it
             cands = [N.CONV_TILE_HI | 1] + ([N.CONV_TILE_HI | 2] if d.N > 128 else [])
         else:
