@@ -271,3 +271,23 @@ def test_wide_chunky_detector_vs_oracle():
     got = model.detect(imgs.cuda(), is_video=True)["preds"].cpu()
     assert (got - ref).abs().max().item() < TOL_LOGIT * max(1.0, ref.abs().max().item())
     assert ((got > 0) == (ref > 0))[ref.abs() > 1e-3].all()
+
+
+def test_config2_batch_partition_invariance():
+    """BASELINE config 2 at its full size (32 x 768 x 768): frames are independent, so the whole batch in one call must equal four
+    calls of 8 frames up to fp32 summation order (different batch sizes select different tiles / K splits), in image and video mode."""
+    model = videoseal_amd.build("videoseal_1.0", seed=7).eval().to("cuda")
+    imgs = synthetic_frames(32, 768, 768, seed=21).cuda()
+    msgs = synthetic_msgs(32, 256, seed=21)
+    model.chunk_size = 32
+    full = model.embed(imgs, msgs, is_video=False)["imgs_w"]
+    parts = torch.cat([model.embed(imgs[a:a + 8], msgs[a:a + 8], is_video=False)["imgs_w"] for a in range(0, 32, 8)])
+    assert (full - parts).abs().max().item() < 2e-6
+    pf = model.detect(full, is_video=True)["preds"]
+    pp = torch.cat([model.detect(full[a:a + 8], is_video=True)["preds"] for a in range(0, 32, 8)])
+    assert (pf - pp).abs().max().item() < 2e-5
+    assert ((pf > 0) == (pp > 0))[pf.abs() > 1e-4].all()
+    vfull = model.embed(imgs, msgs[:1], is_video=True)["imgs_w"]           # key frames 0,4,..,28 in one chunk
+    model.chunk_size = 2                                                     # 8 frames per chunk
+    vparts = model.embed(imgs, msgs[:1], is_video=True)["imgs_w"]
+    assert (vfull - vparts).abs().max().item() < 2e-6
