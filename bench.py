@@ -101,6 +101,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--mode", choices=["image", "video", "stream"], default="image",
                     help="stream = BASELINE config 4: --frames frames processed as 16-frame embed(lowres_attenuation)+detect calls")
+    ap.add_argument("--capi", action="store_true", help="drive the model-level C-ABI (vs_model_embed / vs_model_detect, host code in C++, static "
+                    "tile heuristics) instead of the Python host path")
     ap.add_argument("--u8", action="store_true", help="stream mode: uint8 RGB24 clips in and out (inference_streaming.py's data format) "
                     "through embed_u8 / detect_u8 instead of fp32 NCHW tensors")
     ap.add_argument("--frames", type=int, default=1024, help="stream mode: total frames of the clip (sharded over the ranks)")
@@ -163,9 +165,17 @@ def main():
             preds = gather_frame_logits(preds, args.frames, align=16)
         return preds
 
+    cmodel = None
+    if args.capi:
+        from videoseal_amd.capi import CModel
+        cmodel = CModel(cfg, model.state_dict(), scaling_w=model.blender.scaling_w, scaling_i=model.blender.scaling_i)
+
     def step():
         if stream:
             return step_stream()
+        if cmodel is not None:
+            w = cmodel.embed(frames, msgs, step=(cfg.step_size if is_video else 1), lowres_attenuation=args.lowres_attenuation)
+            return cmodel.detect(w)
         if args.detect_only:
             preds = model.detect(frames, is_video=True)["preds"]
         else:

@@ -198,6 +198,40 @@ typedef struct vs_tail_desc {
 int vs_embed_tail(const vs_tail_desc_t* d, void* stream);
 
 /* ------------------------------------------------------------------------------------------------------------------
+ * Model-level entry points (the granularity a non-Python host would bind): an opaque model built from the card numbers
+ * (utils/cfg.py:88-154, embedder.py:243-262, extractor.py:189-208) and the reference state_dict (cfg.py:147-150:
+ * checkpoint['model'], HOST fp32 tensors by their reference names, loaded like strict=False: unknown names are ignored,
+ * required ones must be present).  vs_model_create folds eval-BatchNorm, packs / splits / blocks the weights and uploads
+ * them once; afterwards the model is immutable (thread-safe across streams) and embed / detect allocate nothing: the
+ * caller passes a 256-byte-aligned device workspace of vs_model_workspace_bytes(...) bytes.
+ *   vs_model_embed  = Wam.embed / Videoseal.embed on ONE chunk of device-resident frames (wam.py:134-204,
+ *                     videoseal.py:258-350): resize -> Y -> U-Net -> (low-res | full-res) JND -> blend -> clamp.
+ *                     imgs / imgs_w: NCHW fp32 [frames][3][H][W]; msgs: int32 0/1 [n_msgs][nbits], n_msgs = 1 (video:
+ *                     one message for the clip) or ceil(frames/step) (image mode: step = 1); preds_w optional.
+ *   vs_model_detect = Wam.detect / Videoseal.detect (wam.py:206-234): resize -> ConvNeXt-V2 -> logits [frames][1+nbits].
+ * Chunking over long clips, frame aggregation (videoseal.py:390-428) and message generation stay with the caller. */
+typedef struct vs_model vs_model_t;
+typedef struct vs_model_cfg {
+  int32_t nbits, hidden, img_size;          /* args.nbits, nbits * hidden_size_multiplier, args.img_size_proc             */
+  int32_t in_ch, out_ch, yuv;               /* embedder I/O channels; yuv = 'yuv' in the embedder name (embedder.py:281) */
+  int32_t nlev;                             /* U-Net down/up levels = len(z_channels_mults) - 1                           */
+  int32_t zc[8];                            /* z_channels * mult, nlev + 1 entries                                        */
+  int32_t num_blocks, last_tanh;            /* bottleneck ResnetBlocks; tanh on the output                                */
+  int32_t depths[4], dims[4], stem_stride;  /* ConvNeXt-V2 (dims already scaled by sqrt(nbits/128) where the card asks)   */
+  int32_t attenuate, clamp;                 /* JND attenuation present; clamp imgs_w to [0,1]                             */
+  float scaling_w, scaling_i;               /* blender (mutable by evals: pass the current values at create time)         */
+} vs_model_cfg_t;
+typedef struct vs_tensor { const char* name; const float* data; int64_t numel; } vs_tensor_t;
+int vs_model_create(const vs_model_cfg_t* cfg, const vs_tensor_t* tensors, int ntensors, vs_model_t** out);
+void vs_model_destroy(vs_model_t* m);
+int64_t vs_model_workspace_bytes(const vs_model_t* m, int frames, int H, int W, int step);
+int vs_model_embed(vs_model_t* m, const float* imgs, const int32_t* msgs, int n_msgs, int frames, int H, int W, int step,
+                   int video_mode, int lowres_attenuation, int antialias, float* imgs_w, float* preds_w, void* ws,
+                   int64_t ws_bytes, void* stream);
+int vs_model_detect(vs_model_t* m, const float* imgs, int frames, int H, int W, int antialias, float* logits, void* ws,
+                    int64_t ws_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------------------
  * Augmentations (videoseal/augmentation/valuemetric.py, geometric.py, utils/image.py).  Frames are NCHW fp32 [F][3][H][W]
  * (masks: [F][1][H][W] through the `planes` entry points).  All are forward-only (the reference's JPEG / median use a
  * straight-through estimator whose forward value is exactly the codec / filter output).

@@ -1,0 +1,541 @@
+// Model-level entry points of the C-ABI (last row): an opaque vs_model_t built from a card + the reference
+// state_dict (HOST fp32 tensors by name), immutable after creation, and whole-path calls at the granularity of
+// Wam.embed / Videoseal.embed (wam.py:134-204, videoseal.py:258-350) and detect (wam.py:206-234, videoseal.py:352-388).
+// Everything here is host code: weight preparation (eval-BatchNorm folding, [N][tap][CinP] packing, the 3 x bf16 split and the
+// LDS-image blocking of engine.py) and the launch sequences of engine.py::embedder_forward / extractor_forward, issued on the
+// caller's stream into the caller's workspace through the operator-level entry points of this same library.
+// No allocation after vs_model_create, no synchronisation, no torch.
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "vs_common.h"
+
+#pragma clang fp contract(off)      // host-side weight folding must round like the torch ops it restates (no fused multiply-add)
+
+namespace {
+
+inline int rup(int v, int m) { return (v + m - 1) / m * m; }
+
+struct HostT { const float* p; int64_t n; };
+
+struct CW {                      // one conv / linear layer on the device
+  float* wt = nullptr; float* bias = nullptr; void* split = nullptr; void* blk = nullptr;
+  int N = 0, KH = 0, KW = 0, CinP = 0;
+};
+struct RB { CW c0, c1, res; int cout = 0; };
+struct Up { CW conv; float* lnw = nullptr; float* lnb = nullptr; RB rb; };
+struct Down { float* lnw = nullptr; float* lnb = nullptr; CW conv; };
+struct Blk { float *wdw = nullptr, *bdw = nullptr, *lnw = nullptr, *lnb = nullptr, *gamma = nullptr, *beta = nullptr; CW pw1, pw2; };
+
+struct Act { float* p; int B, H, W, C, ld; int64_t rows() const { return (int64_t)B * H * W; } };
+
+}  // namespace
+
+struct vs_model {
+  vs_model_cfg_t c;
+  std::vector<void*> dev;
+  std::vector<int> zc;
+  int bott = 0;
+  // embedder
+  RB inc;
+  std::vector<CW> down_conv;
+  std::vector<RB> down_rb, bottleneck;
+  std::vector<Up> ups;
+  float *outc_w = nullptr, *outc_b = nullptr, *table = nullptr;
+  // extractor
+  CW stem, head;
+  float *stem_lnw = nullptr, *stem_lnb = nullptr, *head_lnw = nullptr, *head_lnb = nullptr, *lin_w = nullptr, *lin_b = nullptr;
+  Down down[3];
+  std::vector<Blk> stages[4];
+  float ymat[3];
+  float taps43[43];
+  bool ok = true;
+};
+
+namespace {
+
+int xld(int C) { return C >= 128 ? rup(C, 32) : rup(C, 4); }     // engine.py::_xld
+
+// ---------------------------------------------------------------- weight preparation (host) + upload
+struct Packer {
+  vs_model* m;
+  const std::map<std::string, HostT>& sd;
+  bool fail = false;
+
+  const HostT& get(const std::string& k, bool optional = false) {
+    static HostT none{nullptr, 0};
+    auto it = sd.find(k);
+    if (it == sd.end()) { if (!optional) fail = true; return none; }
+    return it->second;
+  }
+  template <typename T>
+  T* upload(const std::vector<T>& v) {
+    void* d = nullptr;
+    if (v.empty()) return nullptr;
+    if (hipMalloc(&d, v.size() * sizeof(T)) != hipSuccess) { fail = true; return nullptr; }
+    if (hipMemcpy(d, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice) != hipSuccess) fail = true;
+    m->dev.push_back(d);
+    return static_cast<T*>(d);
+  }
+  float* vec(const std::string& k, int padded = 0) {
+    const HostT& t = get(k);
+    if (!t.p) return nullptr;
+    std::vector<float> v((size_t)std::max<int64_t>(t.n, padded), 0.f);
+    std::copy(t.p, t.p + t.n, v.begin());
+    return upload(v);
+  }
+  // fp32 -> three bf16 terms by truncation (engine.py::split_bf16x3); planes [3][N][K]
+  static void split3(const std::vector<float>& w, std::vector<uint16_t>& planes) {
+    const size_t n = w.size();
+    planes.assign(3 * n, 0);
+    for (size_t i = 0; i < n; ++i) {
+      float r = w[i];
+      for (int p = 0; p < 3; ++p) {
+        uint32_t u;
+        std::memcpy(&u, &r, 4);
+        const uint32_t hi = u & 0xffff0000u;
+        planes[p * n + i] = (uint16_t)(hi >> 16);
+        float h;
+        std::memcpy(&h, &hi, 4);
+        r = r - h;
+      }
+    }
+  }
+  // engine.py::pack_blocked: [3][N][K] -> [ceil(N/32)][K/16][3][64 slots][8], chunk order (channel chunk, tap), bank swizzle
+  static void blocked(const std::vector<uint16_t>& planes, int n, int k, int ntaps, std::vector<uint16_t>& out) {
+    const int G = (n + 31) / 32, nch = k / 16, spt = nch / ntaps;
+    out.assign((size_t)G * nch * 3 * 64 * 8, 0);
+    for (int p = 0; p < 3; ++p)
+      for (int row = 0; row < n; ++row) {
+        const int g = row / 32, r = row % 32;
+        for (int tap = 0; tap < ntaps; ++tap)
+          for (int cc = 0; cc < spt; ++cc) {
+            const int blkidx = cc * ntaps + tap;                  // step order of the kernels
+            for (int h = 0; h < 2; ++h) {
+              const int slot = 2 * r + (h ^ ((r >> 3) & 1));
+              const uint16_t* src = &planes[(size_t)p * n * k + (size_t)row * k + (size_t)(tap * spt + cc) * 16 + h * 8];
+              uint16_t* dst = &out[((((size_t)g * nch + blkidx) * 3 + p) * 64 + slot) * 8];
+              std::copy(src, src + 8, dst);
+            }
+          }
+      }
+  }
+  void finish(CW& cw, const std::vector<float>& wt, const std::vector<float>& bias, bool has_bias) {
+    cw.wt = upload(wt);
+    if (has_bias) cw.bias = upload(bias);
+    std::vector<uint16_t> planes, blk;
+    split3(wt, planes);
+    cw.split = upload(planes);
+    blocked(planes, cw.N, cw.KH * cw.KW * cw.CinP, cw.KH * cw.KW, blk);
+    cw.blk = upload(blk);
+  }
+  // engine.py::pack_conv: [N,Cin,KH,KW] -> [N][tap][CinP], optional per-row scale (folded BatchNorm)
+  void conv(CW& cw, const std::string& wkey, int cin, int kh, int kw, int in_ld, const std::vector<float>* scale,
+            const std::vector<float>* bias_v, const std::string& bias_key) {
+    const HostT& w = get(wkey);
+    if (!w.p) return;
+    const int n = (int)(w.n / ((int64_t)cin * kh * kw));
+    const int cinp = rup(std::max(in_ld, cin), 16);
+    cw.N = n; cw.KH = kh; cw.KW = kw; cw.CinP = cinp;
+    std::vector<float> wt((size_t)n * kh * kw * cinp, 0.f);
+    for (int o = 0; o < n; ++o)
+      for (int c = 0; c < cin; ++c)
+        for (int t = 0; t < kh * kw; ++t) {
+          float v = w.p[((size_t)o * cin + c) * kh * kw + t];
+          if (scale) v = v * (*scale)[o];
+          wt[((size_t)o * kh * kw + t) * cinp + c] = v;
+        }
+    std::vector<float> b;
+    bool hb = false;
+    if (bias_v) { b = *bias_v; hb = true; }
+    else if (!bias_key.empty()) { const HostT& t = get(bias_key); if (t.p) { b.assign(t.p, t.p + t.n); hb = true; } }
+    finish(cw, wt, b, hb);
+  }
+  // engine.py::pack_patch_conv: kw pixels of a row are one run of kw*pix_ld floats -> KH x 1 conv with Cin' = kw*pix_ld
+  void patch_conv(CW& cw, const std::string& wkey, int cin, int k, int pix_ld, const std::string& bias_key) {
+    const HostT& w = get(wkey);
+    if (!w.p) return;
+    const int n = (int)(w.n / ((int64_t)cin * k * k));
+    const int run = k * pix_ld, cinp = rup(run, 16);
+    cw.N = n; cw.KH = k; cw.KW = 1; cw.CinP = cinp;
+    std::vector<float> wt((size_t)n * k * cinp, 0.f);
+    for (int o = 0; o < n; ++o)
+      for (int c = 0; c < cin; ++c)
+        for (int ky = 0; ky < k; ++ky)
+          for (int kx = 0; kx < k; ++kx) wt[((size_t)o * k + ky) * cinp + kx * pix_ld + c] = w.p[(((size_t)o * cin + c) * k + ky) * k + kx];
+    const HostT& bt = get(bias_key);
+    std::vector<float> b;
+    if (bt.p) b.assign(bt.p, bt.p + bt.n);
+    finish(cw, wt, b, bt.p != nullptr);
+  }
+  void bn_fold(const std::string& p, std::vector<float>& s, std::vector<float>& b) {          // engine.py::_bn_fold
+    const HostT &w = get(p + ".weight"), &bi = get(p + ".bias"), &mu = get(p + ".running_mean"), &var = get(p + ".running_var");
+    if (!w.p || !bi.p || !mu.p || !var.p) return;
+    s.resize(w.n); b.resize(w.n);
+    for (int64_t i = 0; i < w.n; ++i) {
+      s[i] = w.p[i] / std::sqrt(var.p[i] + 1e-5f);
+      b[i] = bi.p[i] - mu.p[i] * s[i];
+    }
+  }
+  void resblock(RB& rb, const std::string& p, int cin) {                                         // engine.py::_pack_resblock
+    const HostT& w0 = get(p + ".double_conv.0.weight");
+    if (!w0.p) return;
+    const int cout = (int)(w0.n / ((int64_t)cin * 9));
+    rb.cout = cout;
+    std::vector<float> s0, b0, s1, b1;
+    bn_fold(p + ".double_conv.1", s0, b0);
+    bn_fold(p + ".double_conv.4", s1, b1);
+    conv(rb.c0, p + ".double_conv.0.weight", cin, 3, 3, rup(cin, 4), &s0, &b0, "");
+    conv(rb.c1, p + ".double_conv.3.weight", cout, 3, 3, rup(cout, 4), &s1, &b1, "");
+    conv(rb.res, p + ".res_conv.weight", cin, 1, 1, rup(cin, 4), nullptr, nullptr, p + ".res_conv.bias");
+  }
+};
+
+// ---------------------------------------------------------------- launch sequences
+struct Runner {
+  vs_model* m;
+  char* ws;             // nullptr: counting pass (vs_model_workspace_bytes), no launches
+  int64_t cap, used = 0;
+  void* st;
+  int rc = VS_OK;
+
+  float* alloc(int64_t floats) {
+    const int64_t bytes = (floats * 4 + 255) & ~(int64_t)255;
+    float* p = ws ? reinterpret_cast<float*>(ws + used) : nullptr;
+    used += bytes;
+    if (ws && used > cap) rc = VS_ERR_BAD_ARG;
+    return p;
+  }
+  Act act(int B, int H, int W, int C, int ld = 0) {
+    if (!ld) ld = rup(C, 4);
+    return Act{alloc((int64_t)B * H * W * ld), B, H, W, C, ld};
+  }
+  bool live() const { return ws && rc == VS_OK; }
+  void chk(int code) { if (rc == VS_OK && code != VS_OK) rc = code; }
+
+  // engine.py::conv with tile_hint = 0 (the library's static heuristics) and the shape-only K-split rules
+  void conv(const Act& x, const CW& w, const Act& out, int stride = 1, int pad = 0, int pad_mode = VS_PAD_ZERO, int act_ = VS_ACT_NONE,
+            int out_coff = 0, int n_store = -1, const Act* res = nullptr, const Act* in2 = nullptr, const CW* w2 = nullptr,
+            const float* a_scale = nullptr, int64_t a_scale_ld = 0, const float* a_shift = nullptr, const int* geom = nullptr,
+            float* sumsq = nullptr) {
+    vs_conv_desc_t d;
+    std::memset(&d, 0, sizeof(d));
+    int sh = stride, sw = stride, ph = pad, pw = pad, H = x.H, W = x.W, cin = x.ld;
+    int64_t sx = x.ld;
+    if (geom) { W = geom[0]; sx = geom[1]; cin = geom[2]; sh = geom[3]; sw = geom[4]; ph = geom[5]; pw = geom[6]; }
+    d.in = x.p;
+    d.in_sb = (int64_t)x.H * x.W * x.ld; d.in_sy = (int64_t)x.W * x.ld; d.in_sx = sx;
+    d.B = x.B; d.H = H; d.W = W; d.Cin = cin;
+    d.KH = w.KH; d.KW = w.KW; d.SH = sh; d.SW = sw; d.PH = ph; d.PW = pw; d.pad_mode = pad_mode;
+    d.Ho = out.H; d.Wo = out.W;
+    d.wt = w.wt; d.CinP = w.CinP; d.N = w.N;
+    d.a_scale = a_scale; d.a_scale_ld = a_scale_ld; d.a_shift = a_shift;
+    d.bias = w.bias; d.act = act_;
+    d.n_store = n_store >= 0 ? n_store : (out_coff == 0 ? out.ld - out_coff : w.N);
+    if (res) { d.res = res->p; d.res_ld = res->ld; }
+    if (in2) { d.in2 = in2->p; d.in2_ld = in2->ld; d.Cin2 = in2->ld; d.Cin2P = w2->CinP; d.wt2 = w2->wt; d.bias2 = w2->bias; }
+    d.out = out.p; d.out_ld = out.ld; d.out_coff = out_coff; d.tile_hint = 0;
+    d.wt_split = w.split; d.wt_blk = w.blk;
+    if (in2) { d.wt2_split = w2->split; d.wt2_blk = w2->blk; }
+    int split_k = 1;
+    const bool dense_rows = d.in_sy == (int64_t)d.W * d.in_sx && d.in_sb == (int64_t)d.H * d.in_sy;
+    const bool gemm_pc = d.KH == 1 && d.KW == 1 && sh == 1 && sw == 1 && ph == 0 && pw == 0 && !in2 && d.Ho == d.H && d.Wo == d.W &&
+                         d.Cin % 32 == 0 && d.CinP == d.Cin && dense_rows && (!a_scale || ((d.H * d.W) % 64 == 0));
+    const bool patch_pc = d.KH == 3 && d.KW == 3 && sh == 1 && sw == 1 && ph == 1 && pw == 1 && d.Ho == d.H && d.Wo == d.W && !a_scale &&
+                          d.W % 16 == 0 && d.H % 8 == 0;
+    if (sumsq) {
+      d.sumsq_part = sumsq;
+    } else if (gemm_pc) {                                       // engine.py::_split_k_rule
+      const int64_t rows = (int64_t)d.B * d.H * d.W;
+      const int64_t blocks = ((rows + 127) / 128) * ((d.N + 127) / 128);
+      const int pairs = d.CinP / 32;
+      while (blocks * split_k < 256 && pairs % (split_k * 2) == 0 && pairs / (split_k * 2) >= 4) split_k *= 2;
+    } else if (patch_pc && d.N >= 128 && d.CinP >= 128) {      // engine.py::_split_k_rule_patch
+      const int64_t blocks = (int64_t)d.B * (d.H / 8) * (d.W / 16) * (d.N % 192 == 0 ? (d.N + 191) / 192 : (d.N + 127) / 128);
+      const int spt = d.CinP / 16;
+      const int cands[5] = {2, 3, 4, 6, 8};
+      for (int cand : cands) {
+        if (blocks * split_k >= 192) break;
+        if (spt % cand == 0 && spt / cand >= 2) split_k = cand;
+      }
+    }
+    if (split_k > 1) {
+      const int ws_ld = rup(w.N, 4);
+      const int slices = split_k + ((patch_pc && in2) ? 1 : 0);
+      d.splitk_ws = alloc((int64_t)slices * out.rows() * ws_ld);
+      d.splitk_ld = ws_ld;
+      d.split_k = split_k;
+      d.tile_hint = d.KH == 3 ? (d.N % 192 == 0 ? VS_CONV_TILE_HI | 0 : 15) : (VS_CONV_TILE_HI | (d.N % 192 == 0 ? 2 : 1));
+    }
+    if (live()) chk(vs_conv_gemm(&d, st));
+  }
+  void layernorm(const Act& x, const float* w, const float* b, const Act& out, int act_ = VS_ACT_NONE) {
+    if (live()) chk(vs_layernorm_act(x.p, x.rows(), x.C, x.ld, w, b, 1e-6f, act_, out.p, out.ld, st));
+  }
+  Act resblock(const Act& x, const RB& p, const Act* out_in = nullptr) {                      // engine.py::resblock
+    Act t = act(x.B, x.H, x.W, p.cout);
+    conv(x, p.c0, t, 1, 1, VS_PAD_ZERO, VS_ACT_RELU);
+    Act out = out_in ? *out_in : act(x.B, x.H, x.W, p.cout);
+    conv(t, p.c1, out, 1, 1, VS_PAD_ZERO, VS_ACT_RELU, 0, out.ld != rup(p.cout, 4) ? p.cout : -1, nullptr, &x, &p.res);
+    return out;
+  }
+  // engine.py::embedder_forward: key frames (NHWC, ld 4, mapped to [-1,1]) -> delta [B][out_ch][S][S]
+  float* embedder(const Act& x, const int32_t* msgs, int n_msgs, int& Sh, int& Sw) {
+    const vs_model_cfg_t& c = m->c;
+    const int B = x.B, nlev = (int)m->zc.size() - 1;
+    std::vector<Act> hid;
+    hid.push_back(resblock(x, m->inc));
+    for (int i = 0; i < nlev; ++i) {
+      const Act src = hid.back();
+      const int Ho = (src.H - 1) / 2 + 1, Wo = (src.W - 1) / 2 + 1;
+      Act dwn = act(B, Ho, Wo, m->zc[i + 1]);
+      conv(src, m->down_conv[i], dwn, 2, 1);
+      if (i == nlev - 1) {
+        Act h3 = act(B, Ho, Wo, m->bott);
+        resblock(dwn, m->down_rb[i], &h3);
+        hid.push_back(h3);
+      } else {
+        hid.push_back(resblock(dwn, m->down_rb[i]));
+      }
+    }
+    Act h3 = hid.back();
+    float* lat = alloc((int64_t)n_msgs * c.hidden);
+    if (live()) chk(vs_msg_latent(m->table, msgs, n_msgs, c.nbits, c.hidden, lat, st));
+    if (live()) chk(vs_broadcast_channels(lat, n_msgs, c.hidden, h3.p, B, h3.H * h3.W, h3.ld, m->zc.back(), st));
+    Act cur = h3;
+    for (int j = 0; j < c.num_blocks; ++j) cur = resblock(cur, m->bottleneck[j]);
+    for (int k = 0; k < nlev; ++k) {                   // skips are popped deepest first; the first one is the [latent | message] map itself
+      const Act skip = hid.back();
+      hid.pop_back();
+      const Up& up = m->ups[k];
+      Act cat = act(B, 2 * cur.H, 2 * cur.W, cur.C + skip.C);
+      if (live()) chk(vs_upcat2x(cur.p, cur.C, cur.ld, skip.p, skip.C, skip.ld, 0.70710678118654752440f, B, cur.H, cur.W, cat.p, cat.ld, st));
+      Act cv = act(B, cat.H, cat.W, up.conv.N);
+      conv(cat, up.conv, cv, 1, 1, VS_PAD_REFLECT);
+      Act ln = act(B, cat.H, cat.W, up.conv.N);
+      layernorm(cv, up.lnw, up.lnb, ln, VS_ACT_RELU);
+      cur = resblock(ln, up.rb);
+    }
+    float* delta = alloc((int64_t)B * c.out_ch * cur.H * cur.W);
+    if (live()) chk(vs_outc_tanh(cur.p, (int64_t)cur.H * cur.W, B, cur.C, cur.ld, m->outc_w, m->outc_b, c.out_ch, c.last_tanh ? 1 : 0, delta, st));
+    Sh = cur.H; Sw = cur.W;
+    return delta;
+  }
+  // engine.py::extractor_forward: frames (NHWC ld 4, mapped to [-1,1]) -> logits [B][1+nbits]
+  void extractor(const Act& x, float* logits) {
+    const vs_model_cfg_t& c = m->c;
+    const int B = x.B, s = c.stem_stride;
+    int Ho = (x.H - 4) / s + 1, Wo = (x.W - 4) / s + 1;
+    Act t = act(B, Ho, Wo, c.dims[0]);
+    { const int geom[7] = {Wo, s * 4, 16, s, 1, 0, 0}; conv(x, m->stem, t, 1, 0, VS_PAD_ZERO, VS_ACT_NONE, 0, -1, nullptr, nullptr, nullptr, nullptr, 0, nullptr, geom); }
+    Act cur = act(B, Ho, Wo, c.dims[0], xld(c.dims[0]));
+    layernorm(t, m->stem_lnw, m->stem_lnb, cur);
+    for (int sti = 0; sti < 4; ++sti) {
+      if (sti > 0) {
+        const Down& dn = m->down[sti - 1];
+        Act ln = act(B, cur.H, cur.W, cur.C, cur.ld);
+        layernorm(cur, dn.lnw, dn.lnb, ln);
+        Ho = cur.H / 2; Wo = cur.W / 2;
+        Act nxt = act(B, Ho, Wo, c.dims[sti], xld(c.dims[sti]));
+        const int geom[7] = {Wo, 2 * ln.ld, 2 * ln.ld, 2, 1, 0, 0};
+        conv(ln, dn.conv, nxt, 1, 0, VS_PAD_ZERO, VS_ACT_NONE, 0, -1, nullptr, nullptr, nullptr, nullptr, 0, nullptr, geom);
+        cur = nxt;
+      }
+      const int Cc = c.dims[sti], HW = cur.H * cur.W;
+      Act tn = act(B, cur.H, cur.W, Cc, xld(Cc));
+      Act hh = act(B, cur.H, cur.W, 4 * Cc, xld(4 * Cc));
+      float* part = alloc((int64_t)((HW + 63) / 64) * B * 4 * Cc);
+      float* part32 = alloc((int64_t)B * ((HW + 31) / 32) * 4 * Cc);
+      float* scale = alloc((int64_t)B * hh.ld + 16);
+      for (const Blk& blk : m->stages[sti]) {
+        if (live()) chk(vs_dwconv7_ln(cur.p, B, cur.H, cur.W, Cc, cur.ld, blk.wdw, blk.bdw, blk.lnw, blk.lnb, 1e-6f, tn.p, tn.ld, st));
+        if (HW % 32 == 0) {
+          conv(tn, blk.pw1, hh, 1, 0, VS_PAD_ZERO, VS_ACT_GELU, 0, -1, nullptr, nullptr, nullptr, nullptr, 0, nullptr, nullptr, part32);
+          if (live()) chk(vs_grn_scale_from_partials(part32, B, HW, 4 * Cc, blk.gamma, scale, hh.ld, st));
+        } else {
+          conv(tn, blk.pw1, hh, 1, 0, VS_PAD_ZERO, VS_ACT_GELU);
+          if (live()) chk(vs_grn_scale(hh.p, B, HW, 4 * Cc, hh.ld, blk.gamma, part, scale, st));
+        }
+        if (HW % 64 == 0) {
+          conv(hh, blk.pw2, cur, 1, 0, VS_PAD_ZERO, VS_ACT_NONE, 0, -1, &cur, nullptr, nullptr, scale, hh.ld, blk.beta);
+        } else {
+          if (live()) chk(vs_grn_apply(hh.p, B, HW, 4 * Cc, hh.ld, scale, hh.ld, blk.beta, st));
+          conv(hh, blk.pw2, cur, 1, 0, VS_PAD_ZERO, VS_ACT_NONE, 0, -1, &cur);
+        }
+      }
+    }
+    Act hc = act(B, cur.H, cur.W, c.dims[3]);
+    conv(cur, m->head, hc, 1, 1, VS_PAD_REFLECT);
+    Act hl = act(B, cur.H, cur.W, c.dims[3]);
+    layernorm(hc, m->head_lnw, m->head_lnb, hl, VS_ACT_GELU);
+    if (live()) chk(vs_pool_linear(hl.p, B, hl.H * hl.W, hl.C, hl.ld, m->lin_w, m->lin_b, c.nbits + 1, logits, st));
+  }
+  // model.py::_embed_frames_eager
+  void embed(const float* imgs, const int32_t* msgs, int n_msgs, int F, int H, int W, int step, int video_mode, int lowres, int antialias,
+             float* out, float* preds_w) {
+    const vs_model_cfg_t& c = m->c;
+    const int S = c.img_size, nk = (F + step - 1) / step;
+    const bool att = c.attenuate != 0;
+    Act rgb{nullptr, F, S, S, 3, 4}, key = act(nk, S, S, c.in_ch, 4);
+    if (att && lowres) rgb = act(F, S, S, 3, 4);
+    if (live()) chk(vs_resize_pre(imgs, F, 3, H, W, S, S, antialias, (att && lowres) ? rgb.p : nullptr, 1.0f, 0.0f, key.p, step, c.yuv ? m->ymat : nullptr, st));
+    int Sh = 0, Sw = 0;
+    float* delta = embedder(key, msgs, n_msgs, Sh, Sw);
+    float* hmap = nullptr;
+    if (att && lowres) {
+      hmap = alloc((int64_t)F * S * S);
+      if (live()) chk(vs_jnd_heatmap(rgb.p, F, S, S, (int64_t)S * S * 4, 1, (int64_t)S * 4, 4, m->taps43, hmap, st));
+    }
+    vs_tail_desc_t d;
+    std::memset(&d, 0, sizeof(d));
+    d.imgs = imgs; d.out = out; d.preds_w = preds_w; d.delta = delta; d.hmap_lowres = hmap; d.taps43 = m->taps43;
+    d.F = F; d.H = H; d.W = W; d.S_h = Sh; d.S_w = Sw; d.Cd = c.out_ch;
+    d.step = step; d.video_mode = video_mode; d.total_key = nk;
+    d.attenuate = att ? 1 : 0; d.clamp = c.clamp; d.antialias = antialias;
+    d.scaling_i = c.scaling_i; d.scaling_w = c.scaling_w;
+    if (live()) chk(vs_embed_tail(&d, st));
+  }
+  void detect(const float* imgs, int F, int H, int W, int antialias, float* logits) {
+    const int S = m->c.img_size;
+    Act rgb = act(F, S, S, 3, 4);
+    if (live()) chk(vs_resize_pre(imgs, F, 3, H, W, S, S, antialias, rgb.p, 2.0f, -1.0f, nullptr, 1, nullptr, st));
+    extractor(rgb, logits);
+  }
+};
+
+}  // namespace
+
+extern "C" int vs_model_create(const vs_model_cfg_t* cfg, const vs_tensor_t* tensors, int ntensors, vs_model_t** out) {
+  VS_REQUIRE(cfg && tensors && ntensors > 0 && out);
+  VS_REQUIRE(cfg->nlev >= 1 && cfg->nlev <= 7 && cfg->num_blocks >= 0 && (cfg->out_ch == 1 || cfg->out_ch == 3) && cfg->nbits > 0 && cfg->nbits <= 1024);
+  std::map<std::string, HostT> sd;
+  for (int i = 0; i < ntensors; ++i) {
+    VS_REQUIRE(tensors[i].name && tensors[i].data && tensors[i].numel > 0);
+    sd[tensors[i].name] = HostT{tensors[i].data, tensors[i].numel};
+  }
+  vs_model* m = new vs_model();
+  m->c = *cfg;
+  for (int i = 0; i <= cfg->nlev; ++i) {
+    m->zc.push_back(cfg->zc[i]);
+    if (cfg->zc[i] % 4) { delete m; return VS_ERR_UNSUPPORTED; }
+  }
+  m->bott = m->zc.back() + cfg->hidden;
+  Packer P{m, sd};
+  const std::string u = "embedder.unet";
+  P.resblock(m->inc, u + ".inc", cfg->in_ch);
+  const int nlev = cfg->nlev;
+  m->down_conv.resize(nlev); m->down_rb.resize(nlev); m->ups.resize(nlev); m->bottleneck.resize(cfg->num_blocks);
+  for (int i = 0; i < nlev; ++i) {
+    const std::string p = u + ".downs." + std::to_string(i);
+    P.conv(m->down_conv[i], p + ".down.weight", m->zc[i], 3, 3, rup(m->zc[i], 4), nullptr, nullptr, p + ".down.bias");
+    P.resblock(m->down_rb[i], p + ".conv", m->zc[i + 1]);
+  }
+  for (int j = 0; j < cfg->num_blocks; ++j) P.resblock(m->bottleneck[j], u + ".bottleneck.model." + std::to_string(j), m->bott);
+  std::vector<int> zz(m->zc.begin(), m->zc.end() - 1);
+  zz.push_back(m->bott);
+  for (int k = 0; k < nlev; ++k) {
+    const int i = nlev - 1 - k;
+    const int cin = 2 * zz[i + 1], cout = zz[i];
+    const std::string p = u + ".ups." + std::to_string(k);
+    P.conv(m->ups[k].conv, p + ".up.upsample_block.2.weight", cin, 3, 3, rup(cin, 4), nullptr, nullptr, "");
+    m->ups[k].lnw = P.vec(p + ".up.upsample_block.3.weight");
+    m->ups[k].lnb = P.vec(p + ".up.upsample_block.3.bias");
+    P.resblock(m->ups[k].rb, p + ".conv", cout);
+  }
+  m->outc_w = P.vec(u + ".outc.weight");
+  m->outc_b = P.vec(u + ".outc.bias");
+  m->table = P.vec(u + ".msg_processor.msg_embeddings.weight");
+  // extractor
+  const std::string cn = "detector.convnext";
+  P.patch_conv(m->stem, cn + ".downsample_layers.0.0.weight", 3, 4, 4, cn + ".downsample_layers.0.0.bias");
+  m->stem_lnw = P.vec(cn + ".downsample_layers.0.1.weight");
+  m->stem_lnb = P.vec(cn + ".downsample_layers.0.1.bias");
+  for (int i = 0; i < 3; ++i) {
+    const std::string p = cn + ".downsample_layers." + std::to_string(i + 1);
+    m->down[i].lnw = P.vec(p + ".0.weight");
+    m->down[i].lnb = P.vec(p + ".0.bias");
+    P.patch_conv(m->down[i].conv, p + ".1.weight", cfg->dims[i], 2, xld(cfg->dims[i]), p + ".1.bias");
+  }
+  for (int s = 0; s < 4; ++s) {
+    const int Cc = cfg->dims[s], ld = xld(Cc), ld4 = xld(4 * Cc);
+    m->stages[s].resize(cfg->depths[s]);
+    for (int j = 0; j < cfg->depths[s]; ++j) {
+      const std::string p = cn + ".stages." + std::to_string(s) + "." + std::to_string(j);
+      Blk& b = m->stages[s][j];
+      const HostT& dw = P.get(p + ".dwconv.weight");
+      if (dw.p) {
+        std::vector<float> wdw((size_t)49 * ld, 0.f);
+        for (int c2 = 0; c2 < Cc; ++c2)
+          for (int t = 0; t < 49; ++t) wdw[(size_t)t * ld + c2] = dw.p[(size_t)c2 * 49 + t];
+        b.wdw = P.upload(wdw);
+      }
+      b.bdw = P.vec(p + ".dwconv.bias", ld);
+      b.lnw = P.vec(p + ".norm.weight", ld);
+      b.lnb = P.vec(p + ".norm.bias", ld);
+      b.gamma = P.vec(p + ".grn.gamma");
+      b.beta = P.vec(p + ".grn.beta", rup(ld4, 16));
+      P.conv(b.pw1, p + ".pwconv1.weight", Cc, 1, 1, ld, nullptr, nullptr, p + ".pwconv1.bias");
+      P.conv(b.pw2, p + ".pwconv2.weight", 4 * Cc, 1, 1, ld4, nullptr, nullptr, p + ".pwconv2.bias");
+    }
+  }
+  const std::string pd = "detector.pixel_decoder";
+  P.conv(m->head, pd + ".output_upscaling.0.upsample_block.2.weight", cfg->dims[3], 3, 3, xld(cfg->dims[3]), nullptr, nullptr, "");
+  m->head_lnw = P.vec(pd + ".output_upscaling.0.upsample_block.3.weight");
+  m->head_lnb = P.vec(pd + ".output_upscaling.0.upsample_block.3.bias");
+  m->lin_w = P.vec(pd + ".linear.weight");
+  m->lin_b = P.vec(pd + ".linear.bias");
+  const HostT& M = P.get("rgb2yuv.M", !cfg->yuv);
+  if (M.p) for (int i = 0; i < 3; ++i) m->ymat[i] = M.p[i];
+  const bool noatt = !cfg->attenuate;
+  const HostT &tl = P.get("attenuation.conv_lum.weight", noatt), &tx = P.get("attenuation.conv_x.weight", noatt), &ty = P.get("attenuation.conv_y.weight", noatt);
+  if (tl.p && tx.p && ty.p) {
+    for (int i = 0; i < 25; ++i) m->taps43[i] = tl.p[i];
+    for (int i = 0; i < 9; ++i) { m->taps43[25 + i] = tx.p[i]; m->taps43[34 + i] = ty.p[i]; }
+  }
+  if (P.fail) {
+    for (void* d : m->dev) (void)hipFree(d);
+    delete m;
+    return VS_ERR_BAD_ARG;       // a tensor of the state_dict is missing (or the device ran out of memory)
+  }
+  *out = m;
+  return VS_OK;
+}
+
+extern "C" void vs_model_destroy(vs_model_t* m) {
+  if (!m) return;
+  for (void* d : m->dev) (void)hipFree(d);
+  delete m;
+}
+
+extern "C" int64_t vs_model_workspace_bytes(const vs_model_t* m, int frames, int H, int W, int step) {
+  if (!m || frames <= 0 || H <= 0 || W <= 0 || step < 1) return -1;
+  Runner e{const_cast<vs_model_t*>(m), nullptr, 0, 0, nullptr};
+  e.embed(nullptr, nullptr, 1, frames, H, W, step, 0, 1, 1, nullptr, nullptr);
+  Runner dt{const_cast<vs_model_t*>(m), nullptr, 0, 0, nullptr};
+  dt.detect(nullptr, frames, H, W, 1, nullptr);
+  return std::max(e.used, dt.used) + 256;
+}
+
+extern "C" int vs_model_embed(vs_model_t* m, const float* imgs, const int32_t* msgs, int n_msgs, int frames, int H, int W, int step,
+                              int video_mode, int lowres_attenuation, int antialias, float* imgs_w, float* preds_w, void* ws,
+                              int64_t ws_bytes, void* stream) {
+  VS_REQUIRE(m && imgs && msgs && imgs_w && ws && frames > 0 && H > 0 && W > 0 && step >= 1 && ((uintptr_t)ws & 255) == 0);
+  const int nk = (frames + step - 1) / step;
+  VS_REQUIRE(n_msgs == 1 || n_msgs == nk);
+  VS_REQUIRE(video_mode >= 0 && video_mode <= 2);
+  Runner r{m, static_cast<char*>(ws), ws_bytes, 0, stream};
+  r.embed(imgs, msgs, n_msgs, frames, H, W, step, video_mode, lowres_attenuation, antialias, imgs_w, preds_w);
+  return r.rc;
+}
+
+extern "C" int vs_model_detect(vs_model_t* m, const float* imgs, int frames, int H, int W, int antialias, float* logits, void* ws,
+                               int64_t ws_bytes, void* stream) {
+  VS_REQUIRE(m && imgs && logits && ws && frames > 0 && H > 0 && W > 0 && ((uintptr_t)ws & 255) == 0);
+  Runner r{m, static_cast<char*>(ws), ws_bytes, 0, stream};
+  r.detect(imgs, frames, H, W, antialias, logits);
+  return r.rc;
+}

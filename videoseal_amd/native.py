@@ -21,7 +21,8 @@ CONV_FORCE_F32, CONV_FORCE_SPLIT, CONV_TILE_HI = 0x10, 0x20, 0x40
 VIDEO_MODES = {"repeat": 0, "alternate": 1, "interpolate": 2}
 
 EXPORTS = [
-    "vs_version", "vs_arch", "vs_error_string", "vs_sizeof_conv_desc", "vs_sizeof_tail_desc", "vs_conv_gemm", "vs_layernorm_act", "vs_dwconv7_ln", "vs_grn_scale", "vs_grn_scale_from_partials", "vs_grn_apply",
+    "vs_version", "vs_arch", "vs_error_string", "vs_sizeof_conv_desc", "vs_sizeof_tail_desc",
+    "vs_model_create", "vs_model_destroy", "vs_model_workspace_bytes", "vs_model_embed", "vs_model_detect", "vs_conv_gemm", "vs_layernorm_act", "vs_dwconv7_ln", "vs_grn_scale", "vs_grn_scale_from_partials", "vs_grn_apply",
     "vs_upcat2x", "vs_msg_latent", "vs_broadcast_channels", "vs_outc_tanh", "vs_pool_linear", "vs_resize_pre", "vs_resize_pre_u8",
     "vs_jnd_heatmap", "vs_embed_tail", "vs_aug_color_scratch_floats", "vs_aug_color", "vs_aug_crop_flip", "vs_aug_warp", "vs_resize_nchw",
     "vs_gaussian_blur", "vs_median_filter", "vs_jpeg_workspace_bytes", "vs_jpeg_roundtrip",
