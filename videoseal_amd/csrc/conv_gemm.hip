@@ -467,7 +467,17 @@ extern "C" int vs_conv_gemm(const vs_conv_desc_t* dp, void* stream) {
     if (blk_ok && d.N > 32 && d.N <= 64 && d.H % 16 == 0 && d.CinP >= 64) return vs_conv3x3_patch_pc_dispatch(d, 21, st);   // 256 px x 64 ch
     return vs_conv3x3_patch_dispatch(d, d.N <= 32 ? 10 : (d.N <= 64 ? 11 : 12), st);
   }
-  if (tile == 0) tile = d.N <= 32 ? 3 : (d.N <= 64 ? 2 : (d.N <= 96 ? 5 : ((d.N % 192 == 0 || (d.N > 128 && d.N <= 192)) ? 4 : 1)));
+  if (tile == 0) {
+    // static choice (no tuner: model-level C API, hipGraph capture, VIDEOSEAL_AUTOTUNE=0), following what the tuner measures on
+    // the benchmark shapes: deep-K 1x1 GEMMs on the wave-specialised kernel, shallow-K ones on 128x128 generic tiles
+    const bool gemm_ok = can_split0 && d.wt_blk && ((uintptr_t)d.wt_blk & 15) == 0 && !(d.tile_hint & VS_CONV_FORCE_F32) && d.KH == 1 &&
+                         d.KW == 1 && d.SH == 1 && d.SW == 1 && d.PH == 0 && d.PW == 0 && d.Ho == d.H && d.Wo == d.W && !d.in2 &&
+                         d.Cin % 32 == 0 && d.CinP == d.Cin && d.in_sy == (int64_t)d.W * d.in_sx && d.in_sb == (int64_t)d.H * d.in_sy &&
+                         (!d.a_scale || (d.H * d.W) % 64 == 0) && !(d.sumsq_part && d.res);
+    if (gemm_ok && d.CinP >= 384 && d.N > 128) return vs_gemm1x1_pc_dispatch(d, 18, st);
+    if (d.KH == 1 && d.KW == 1 && d.CinP < 384 && d.N >= 256) tile = 1;
+    else tile = d.N <= 32 ? 3 : (d.N <= 64 ? 2 : (d.N <= 96 ? 5 : ((d.N % 192 == 0 || (d.N > 128 && d.N <= 192)) ? 4 : 1)));
+  }
   if (tile >= 6 && tile <= 9) {   // producer/consumer kernels
     VS_REQUIRE(d.wt_blk && (!d.in2 || d.wt2_blk) && ((uintptr_t)d.wt_blk & 15) == 0);
     return vs_conv_gemm_pc_dispatch(d, tile, st);
