@@ -477,6 +477,16 @@ extern "C" int vs_conv_gemm(const vs_conv_desc_t* dp, void* stream) {
     if (gemm_ok && d.CinP >= 384 && d.N > 128) return vs_gemm1x1_pc_dispatch(d, 18, st);
     if (d.KH == 1 && d.KW == 1 && d.CinP < 384 && d.N >= 256) tile = 1;
     else tile = d.N <= 32 ? 3 : (d.N <= 64 ? 2 : (d.N <= 96 ? 5 : ((d.N % 192 == 0 || (d.N > 128 && d.N <= 192)) ? 4 : 1)));
+    // few output tiles (down-sampling convs, the 8x8 head conv): smaller tiles until the 256 CUs have work
+    auto blocks_of = [&](int t) -> int64_t {
+      const int bm = (t == 13 || t == 14) ? 64 : (t == 3 ? 256 : 128);
+      const int bn = t == 1 ? 128 : t == 2 ? 64 : t == 3 ? 32 : t == 4 ? 192 : t == 5 ? 96 : t == 13 ? 64 : 128;
+      return cdiv64(M, bm) * cdiv64(d.n_store, bn);
+    };
+    if (d.N > 32 && blocks_of(tile) < 384) {
+      if (tile == 4 || tile == 1) tile = blocks_of(2) >= 384 ? 2 : 13;
+      else if (tile == 5 || tile == 2) tile = 13;
+    }
   }
   if (tile >= 6 && tile <= 9) {   // producer/consumer kernels
     VS_REQUIRE(d.wt_blk && (!d.in2 || d.wt2_blk) && ((uintptr_t)d.wt_blk & 15) == 0);
