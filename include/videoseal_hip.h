@@ -209,6 +209,7 @@ int vs_embed_tail(const vs_tail_desc_t* d, void* stream);
  *                     imgs / imgs_w: NCHW fp32 [frames][3][H][W]; msgs: int32 0/1 [n_msgs][nbits], n_msgs = 1 (video:
  *                     one message for the clip) or ceil(frames/step) (image mode: step = 1); preds_w optional.
  *   vs_model_detect = Wam.detect / Videoseal.detect (wam.py:206-234): resize -> ConvNeXt-V2 -> logits [frames][1+nbits].
+ * io_u8 = 1: imgs / imgs_w are uint8 RGB24 [frames][H][W][3] (inference_streaming.py:26,31), conversions fused.
  * Chunking over long clips, frame aggregation (videoseal.py:390-428) and message generation stay with the caller. */
 typedef struct vs_model vs_model_t;
 typedef struct vs_model_cfg {
@@ -225,10 +226,10 @@ typedef struct vs_tensor { const char* name; const float* data; int64_t numel; }
 int vs_model_create(const vs_model_cfg_t* cfg, const vs_tensor_t* tensors, int ntensors, vs_model_t** out);
 void vs_model_destroy(vs_model_t* m);
 int64_t vs_model_workspace_bytes(const vs_model_t* m, int frames, int H, int W, int step);
-int vs_model_embed(vs_model_t* m, const float* imgs, const int32_t* msgs, int n_msgs, int frames, int H, int W, int step,
-                   int video_mode, int lowres_attenuation, int antialias, float* imgs_w, float* preds_w, void* ws,
+int vs_model_embed(vs_model_t* m, const void* imgs, const int32_t* msgs, int n_msgs, int frames, int H, int W, int step,
+                   int video_mode, int lowres_attenuation, int antialias, int io_u8, void* imgs_w, float* preds_w, void* ws,
                    int64_t ws_bytes, void* stream);
-int vs_model_detect(vs_model_t* m, const float* imgs, int frames, int H, int W, int antialias, float* logits, void* ws,
+int vs_model_detect(vs_model_t* m, const void* imgs, int frames, int H, int W, int antialias, int io_u8, float* logits, void* ws,
                     int64_t ws_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------------------------------

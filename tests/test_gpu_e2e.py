@@ -314,6 +314,13 @@ def test_model_level_c_api(which, tiny, tinyc):
     pref = R.detect(sd, spec, ref)["preds"]
     assert (lg - pref).abs().max().item() < TOL_LOGIT
     assert ((lg > 0) == (pref > 0))[pref.abs() > 2e-3].all()
+    # uint8 RGB24 clip in / out == the Python host's embed_u8 / detect_u8
+    clip = (imgs * 255).to(torch.uint8).permute(0, 2, 3, 1).contiguous().cuda()
+    model.chunk_size, model.step_size = 3, 2
+    u_py = model.embed_u8(clip, msgs, lowres_attenuation=True)["imgs_w"]
+    u_c = cm.embed(clip, msgs, step=2, lowres_attenuation=True)
+    assert u_c.dtype == torch.uint8 and (u_c.int() - u_py.int()).abs().max().item() <= 1 and (u_c != u_py).float().mean().item() < 1e-3
+    assert (cm.detect(u_py) - model.detect_u8(u_py)["preds"]).abs().max().item() < 1e-4
     # image mode: one message per frame, preds_w returned
     m6 = synthetic_msgs(6, spec.nbits, seed=34)
     out, pw = cm.embed(imgs.cuda(), m6, step=1, want_preds_w=True)

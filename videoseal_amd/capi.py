@@ -37,9 +37,9 @@ def _bind(L):
     L.vs_model_destroy.restype = None
     L.vs_model_workspace_bytes.argtypes = [P, I, I, I, I]
     L.vs_model_workspace_bytes.restype = I64
-    L.vs_model_embed.argtypes = [P, P, P, I, I, I, I, I, I, I, I, P, P, P, I64, P]
+    L.vs_model_embed.argtypes = [P, P, P, I, I, I, I, I, I, I, I, I, P, P, P, I64, P]
     L.vs_model_embed.restype = I
-    L.vs_model_detect.argtypes = [P, P, I, I, I, I, P, P, I64, P]
+    L.vs_model_detect.argtypes = [P, P, I, I, I, I, I, P, P, I64, P]
     L.vs_model_detect.restype = I
     L._model_api_bound = True
 
@@ -91,21 +91,23 @@ class CModel:
 
     def embed(self, imgs: torch.Tensor, msgs: torch.Tensor, *, step: int = 1, video_mode: int = 0, lowres_attenuation: bool = False,
               antialias: bool = True, want_preds_w: bool = False):
-        x = N.f32c(imgs)
-        F_, _, H, W = x.shape
+        u8 = imgs.dtype == torch.uint8                 # RGB24 [F,H,W,3] in and out
+        x = imgs.contiguous() if u8 else N.f32c(imgs)
+        F_, H, W = (x.shape[0], x.shape[1], x.shape[2]) if u8 else (x.shape[0], x.shape[2], x.shape[3])
         m = msgs.to(device=x.device, dtype=torch.int32).contiguous()
         out = torch.empty_like(x)
         pw = torch.empty(F_, self.cfg.out_ch, H, W, device=x.device) if want_preds_w else None
         ws = self._workspace(F_, H, W, step)
         N.check(self._L.vs_model_embed(self._h, N.ptr(x), N.ptr(m), m.shape[0], F_, H, W, step, video_mode, int(lowres_attenuation),
-                                       int(antialias), N.ptr(out), N.ptr(pw), N.ptr(ws), ws.numel(), N.stream()), "vs_model_embed")
+                                       int(antialias), int(u8), N.ptr(out), N.ptr(pw), N.ptr(ws), ws.numel(), N.stream()), "vs_model_embed")
         return (out, pw) if want_preds_w else out
 
     def detect(self, imgs: torch.Tensor, antialias: bool = True) -> torch.Tensor:
-        x = N.f32c(imgs)
-        F_, _, H, W = x.shape
+        u8 = imgs.dtype == torch.uint8
+        x = imgs.contiguous() if u8 else N.f32c(imgs)
+        F_, H, W = (x.shape[0], x.shape[1], x.shape[2]) if u8 else (x.shape[0], x.shape[2], x.shape[3])
         logits = torch.empty(F_, self.cfg.nbits + 1, device=x.device)
         ws = self._workspace(F_, H, W, 1)
-        N.check(self._L.vs_model_detect(self._h, N.ptr(x), F_, H, W, int(antialias), N.ptr(logits), N.ptr(ws), ws.numel(), N.stream()),
+        N.check(self._L.vs_model_detect(self._h, N.ptr(x), F_, H, W, int(antialias), int(u8), N.ptr(logits), N.ptr(ws), ws.numel(), N.stream()),
                 "vs_model_detect")
         return logits

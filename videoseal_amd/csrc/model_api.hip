@@ -375,14 +375,20 @@ struct Runner {
     if (live()) chk(vs_pool_linear(hl.p, B, hl.H * hl.W, hl.C, hl.ld, m->lin_w, m->lin_b, c.nbits + 1, logits, st));
   }
   // model.py::_embed_frames_eager
-  void embed(const float* imgs, const int32_t* msgs, int n_msgs, int F, int H, int W, int step, int video_mode, int lowres, int antialias,
-             float* out, float* preds_w) {
+  void resize(const void* imgs, bool u8, int F, int H, int W, int S, int antialias, float* rgb, float mul, float add, float* key, int step,
+              const float* ymat) {
+    if (!live()) return;
+    if (u8) chk(vs_resize_pre_u8(static_cast<const unsigned char*>(imgs), F, H, W, S, S, antialias, rgb, mul, add, key, step, ymat, st));
+    else chk(vs_resize_pre(static_cast<const float*>(imgs), F, 3, H, W, S, S, antialias, rgb, mul, add, key, step, ymat, st));
+  }
+  void embed(const void* imgs, bool u8, const int32_t* msgs, int n_msgs, int F, int H, int W, int step, int video_mode, int lowres, int antialias,
+             void* out, float* preds_w) {
     const vs_model_cfg_t& c = m->c;
     const int S = c.img_size, nk = (F + step - 1) / step;
     const bool att = c.attenuate != 0;
     Act rgb{nullptr, F, S, S, 3, 4}, key = act(nk, S, S, c.in_ch, 4);
     if (att && lowres) rgb = act(F, S, S, 3, 4);
-    if (live()) chk(vs_resize_pre(imgs, F, 3, H, W, S, S, antialias, (att && lowres) ? rgb.p : nullptr, 1.0f, 0.0f, key.p, step, c.yuv ? m->ymat : nullptr, st));
+    resize(imgs, u8, F, H, W, S, antialias, (att && lowres) ? rgb.p : nullptr, 1.0f, 0.0f, key.p, step, c.yuv ? m->ymat : nullptr);
     int Sh = 0, Sw = 0;
     float* delta = embedder(key, msgs, n_msgs, Sh, Sw);
     float* hmap = nullptr;
@@ -397,12 +403,13 @@ struct Runner {
     d.step = step; d.video_mode = video_mode; d.total_key = nk;
     d.attenuate = att ? 1 : 0; d.clamp = c.clamp; d.antialias = antialias;
     d.scaling_i = c.scaling_i; d.scaling_w = c.scaling_w;
+    d.io_u8 = u8 ? 1 : 0;
     if (live()) chk(vs_embed_tail(&d, st));
   }
-  void detect(const float* imgs, int F, int H, int W, int antialias, float* logits) {
+  void detect(const void* imgs, bool u8, int F, int H, int W, int antialias, float* logits) {
     const int S = m->c.img_size;
     Act rgb = act(F, S, S, 3, 4);
-    if (live()) chk(vs_resize_pre(imgs, F, 3, H, W, S, S, antialias, rgb.p, 2.0f, -1.0f, nullptr, 1, nullptr, st));
+    resize(imgs, u8, F, H, W, S, antialias, rgb.p, 2.0f, -1.0f, nullptr, 1, nullptr);
     extractor(rgb, logits);
   }
 };
@@ -514,28 +521,29 @@ extern "C" void vs_model_destroy(vs_model_t* m) {
 extern "C" int64_t vs_model_workspace_bytes(const vs_model_t* m, int frames, int H, int W, int step) {
   if (!m || frames <= 0 || H <= 0 || W <= 0 || step < 1) return -1;
   Runner e{const_cast<vs_model_t*>(m), nullptr, 0, 0, nullptr};
-  e.embed(nullptr, nullptr, 1, frames, H, W, step, 0, 1, 1, nullptr, nullptr);
+  e.embed(nullptr, false, nullptr, 1, frames, H, W, step, 0, 1, 1, nullptr, nullptr);
   Runner dt{const_cast<vs_model_t*>(m), nullptr, 0, 0, nullptr};
-  dt.detect(nullptr, frames, H, W, 1, nullptr);
+  dt.detect(nullptr, false, frames, H, W, 1, nullptr);
   return std::max(e.used, dt.used) + 256;
 }
 
-extern "C" int vs_model_embed(vs_model_t* m, const float* imgs, const int32_t* msgs, int n_msgs, int frames, int H, int W, int step,
-                              int video_mode, int lowres_attenuation, int antialias, float* imgs_w, float* preds_w, void* ws,
+extern "C" int vs_model_embed(vs_model_t* m, const void* imgs, const int32_t* msgs, int n_msgs, int frames, int H, int W, int step,
+                              int video_mode, int lowres_attenuation, int antialias, int io_u8, void* imgs_w, float* preds_w, void* ws,
                               int64_t ws_bytes, void* stream) {
   VS_REQUIRE(m && imgs && msgs && imgs_w && ws && frames > 0 && H > 0 && W > 0 && step >= 1 && ((uintptr_t)ws & 255) == 0);
   const int nk = (frames + step - 1) / step;
   VS_REQUIRE(n_msgs == 1 || n_msgs == nk);
   VS_REQUIRE(video_mode >= 0 && video_mode <= 2);
   Runner r{m, static_cast<char*>(ws), ws_bytes, 0, stream};
-  r.embed(imgs, msgs, n_msgs, frames, H, W, step, video_mode, lowres_attenuation, antialias, imgs_w, preds_w);
+  if (io_u8) VS_REQUIRE(m->c.clamp);
+  r.embed(imgs, io_u8 != 0, msgs, n_msgs, frames, H, W, step, video_mode, lowres_attenuation, antialias, imgs_w, preds_w);
   return r.rc;
 }
 
-extern "C" int vs_model_detect(vs_model_t* m, const float* imgs, int frames, int H, int W, int antialias, float* logits, void* ws,
+extern "C" int vs_model_detect(vs_model_t* m, const void* imgs, int frames, int H, int W, int antialias, int io_u8, float* logits, void* ws,
                                int64_t ws_bytes, void* stream) {
   VS_REQUIRE(m && imgs && logits && ws && frames > 0 && H > 0 && W > 0 && ((uintptr_t)ws & 255) == 0);
   Runner r{m, static_cast<char*>(ws), ws_bytes, 0, stream};
-  r.detect(imgs, frames, H, W, antialias, logits);
+  r.detect(imgs, io_u8 != 0, frames, H, W, antialias, logits);
   return r.rc;
 }
