@@ -103,6 +103,8 @@ def main():
                     help="stream = BASELINE config 4: --frames frames processed as 16-frame embed(lowres_attenuation)+detect calls")
     ap.add_argument("--capi", action="store_true", help="drive the model-level C-ABI (vs_model_embed / vs_model_detect, host code in C++, static "
                     "tile heuristics) instead of the Python host path")
+    ap.add_argument("--no-overlap", dest="overlap", action="store_false", help="stream mode: strictly sequential calls on one stream "
+                    "(default: detect(chunk i) on a second HIP stream while embed(chunk i+1) is issued, videoseal_amd/streaming.py)")
     ap.add_argument("--u8", action="store_true", help="stream mode: uint8 RGB24 clips in and out (inference_streaming.py's data format) "
                     "through embed_u8 / detect_u8 instead of fp32 NCHW tensors")
     ap.add_argument("--frames", type=int, default=1024, help="stream mode: total frames of the clip (sharded over the ranks)")
@@ -151,7 +153,18 @@ def main():
     msgs = torch.randint(0, 2, (1 if is_video else B, cfg.nbits), generator=gm)
     model.chunk_size = max(model.chunk_size, B)
 
+    two_streams = stream and args.overlap
+
+    def step_stream_overlapped():     # videoseal_amd/streaming.py: detect(chunk i) on a second HIP stream while embed(chunk i+1) is issued
+        from videoseal_amd.streaming import embed_detect_chunks
+        preds = embed_detect_chunks(model, frames_u8 if args.u8 else frames, msgs, chunk=16, lowres_attenuation=True, overlap=True)
+        if dist_on:
+            preds = gather_frame_logits(preds, args.frames, align=16)
+        return preds
+
     def step_stream():      # inference_streaming.py:83-107,117-164: 16-frame chunks, low-res attenuation, mean of the logits
+        if two_streams:
+            return step_stream_overlapped()
         logits = []
         for a in range(0, B, 16):
             if args.u8:
@@ -267,7 +280,7 @@ def main():
                                    f"({'embedder on every frame' if not is_video else 'key frames every %d' % cfg.step_size}, "
                                    f"{'low-res' if args.lowres_attenuation else 'full-res'} JND), " + ("detect only" if args.detect_only else "embed + detect")
                                    + (", all-gather of bit logits" if dist_on else "")
-                                   + (f"; streaming: {args.frames}-frame clip as 16-frame calls, low-res JND" + (", uint8 RGB24 in/out" if args.u8 else "") if stream else "")
+                                   + (f"; streaming: {args.frames}-frame clip as 16-frame calls, low-res JND" + (", uint8 RGB24 in/out" if args.u8 else "") + (", detect overlapped with the next embed on a second stream" if args.overlap else "") if stream else "")
                                    + (", hipGraph replay" if args.graphs else ""),
                        "card": args.card, "weights": "random-init (seeded), no checkpoint offline", "batch_per_gpu": B,
                        "frame": [S, S], "mode": args.mode},

@@ -340,3 +340,25 @@ def test_model_level_c_api_vs10(vs10):
     got = cm.embed(imgs, msgs, step=2, lowres_attenuation=True)
     assert (got - py).abs().max().item() < 1e-6
     assert (cm.detect(got) - model.detect(py, is_video=True)["preds"]).abs().max().item() < 1e-4
+
+
+def test_streaming_overlap_equals_sequential(tiny):
+    """videoseal_amd/streaming.py: detect(chunk i) overlapped with embed(chunk i+1) on two HIP streams returns exactly what the
+    sequential 16-frame calls return (fp32 and uint8 clips), chunk after chunk."""
+    from videoseal_amd.streaming import embed_detect_chunks
+    spec, sd, model = tiny
+    model.chunk_size, model.step_size, model.video_mode = 4, 4, "repeat"
+    frames = synthetic_frames(40, 96, 80, seed=51).cuda()
+    msgs = synthetic_msgs(1, spec.nbits, seed=51)
+    seq_w, ovl_w = [], []
+    a = embed_detect_chunks(model, frames, msgs, chunk=16, overlap=False, sink=lambda i, w: seq_w.append(w.clone()))
+    for _ in range(3):          # repeated: a stream race would not be deterministic
+        ovl_w.clear()
+        b = embed_detect_chunks(model, frames, msgs, chunk=16, overlap=True, sink=lambda i, w: ovl_w.append(w.clone()))
+        torch.cuda.synchronize()
+        assert torch.equal(a, b)
+        assert all(torch.equal(x, y) for x, y in zip(seq_w, ovl_w))
+    clip = (frames * 255).to(torch.uint8).permute(0, 2, 3, 1).contiguous()
+    assert torch.equal(embed_detect_chunks(model, clip, msgs, overlap=False), embed_detect_chunks(model, clip, msgs, overlap=True))
+    ref = R.detect(sd, spec, R.embed_video(sd, spec, frames[:16].cpu(), msgs, chunk_size=4, step_size=4, lowres_attenuation=True)["imgs_w"])["preds"]
+    assert (a[:16].cpu() - ref).abs().max().item() < TOL_LOGIT

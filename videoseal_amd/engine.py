@@ -325,7 +325,7 @@ class HipEngine:
         if split_k > 1:
             ws_ld = rup(w.N, 4)
             slices = split_k + (1 if (patch_pc and in2 is not None) else 0)     # + the slice of the 1x1 second phase
-            d.splitk_ws, d.splitk_ld, d.split_k = N.ptr(self.buf("splitk.ws", slices * out.rows * ws_ld)), ws_ld, split_k
+            d.splitk_ws, d.splitk_ld, d.split_k = N.ptr(self.buf(f"splitk.ws@{N.stream()}", slices * out.rows * ws_ld)), ws_ld, split_k
             if tile_hint == 0 and not self.autotune:
                 d.tile_hint = self._static_split_tile(d)
         if tile_hint == 0 and self.autotune:
