@@ -103,6 +103,7 @@ def main():
                     help="stream = BASELINE config 4: --frames frames processed as 16-frame embed(lowres_attenuation)+detect calls")
     ap.add_argument("--capi", action="store_true", help="drive the model-level C-ABI (vs_model_embed / vs_model_detect, host code in C++, static "
                     "tile heuristics) instead of the Python host path")
+    ap.add_argument("--pipeline", action="store_true", help="image / video mode: overlap detect(batch i) with embed(batch i+1) on two HIP streams")
     ap.add_argument("--no-overlap", dest="overlap", action="store_false", help="stream mode: strictly sequential calls on one stream "
                     "(default: detect(chunk i) on a second HIP stream while embed(chunk i+1) is issued, videoseal_amd/streaming.py)")
     ap.add_argument("--u8", action="store_true", help="stream mode: uint8 RGB24 clips in and out (inference_streaming.py's data format) "
@@ -191,6 +192,18 @@ def main():
             return cmodel.detect(w)
         if args.detect_only:
             preds = model.detect(frames, is_video=True)["preds"]
+        elif args.pipeline and not dist_on:
+            # consecutive steps are independent batches: detect(batch i) runs on a second HIP stream while embed(batch i+1) is issued
+            # (same calls, same results: videoseal_amd/streaming.py).  The timed region ends with a device-wide synchronize.
+            from videoseal_amd.streaming import _streams
+            s_emb, s_det = _streams(dev)
+            s_emb.wait_stream(torch.cuda.current_stream()); s_det.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(s_emb):
+                w = model.embed(frames, msgs, is_video=is_video, lowres_attenuation=args.lowres_attenuation)["imgs_w"]
+                ev = torch.cuda.Event(); ev.record(s_emb)
+            with torch.cuda.stream(s_det):
+                s_det.wait_event(ev); w.record_stream(s_det)
+                preds = model.detect(w, is_video=True)["preds"]
         else:
             out = model.embed(frames, msgs, is_video=is_video, lowres_attenuation=args.lowres_attenuation)
             preds = model.detect(out["imgs_w"], is_video=True)["preds"]
