@@ -273,9 +273,12 @@ def main():
         pmc = pmcs[-1] if pmcs else ""
         if os.path.exists(pmc) and B == 32 and S == 768 and split:     # counters were collected on this exact workload
             pj = json.load(open(pmc))
-            roof["traffic"] = {"hbm_read_MB": pj["fetch_mb_per_launch"], "hbm_write_MB": pj["write_mb_per_launch"],
-                               "algorithmic_MB": pj["algorithmic_mb_per_launch"], "mfma_busy_pct_pmc": pj["mfma_busy_pct"],
-                               "source": pj["source"]}
+            # HBM bytes per launch of the dominant kernel from the PMC passes (read + write), then the break-down
+            roof["traffic"] = round((pj["fetch_mb_per_launch"] + pj["write_mb_per_launch"]) * 1e6)
+            roof["traffic_unit"] = "bytes per launch (rocprofv3 --pmc FETCH_SIZE x2 gfx950 correction + WRITE_SIZE)"
+            roof["traffic_detail"] = {"hbm_read_MB": pj["fetch_mb_per_launch"], "hbm_write_MB": pj["write_mb_per_launch"],
+                                      "algorithmic_MB": pj["algorithmic_mb_per_launch"], "mfma_busy_pct_pmc": pj["mfma_busy_pct"],
+                                      "source": pj["source"]}
 
     if rank == 0:
         total_frames = (args.frames if stream else B * world) * args.steps
