@@ -386,7 +386,7 @@ def test_layernorm_act(eng, C_, act):
     assert (from_nhwc(out) - ref).abs().max() < 2e-5
 
 
-@pytest.mark.parametrize("C_,H,W", [(96, 16, 16), (24, 9, 13), (362, 7, 7), (768, 8, 8)])
+@pytest.mark.parametrize("C_,H,W", [(96, 16, 16), (24, 9, 13), (362, 7, 7), (768, 8, 8), (192, 40, 36), (96, 33, 19), (20, 64, 64), (130, 17, 50)])
 def test_dwconv7_ln(eng, C_, H, W):
     g = torch.Generator().manual_seed(C_ + H)
     B = 2
