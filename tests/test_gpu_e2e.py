@@ -362,3 +362,18 @@ def test_streaming_overlap_equals_sequential(tiny):
     assert torch.equal(embed_detect_chunks(model, clip, msgs, overlap=False), embed_detect_chunks(model, clip, msgs, overlap=True))
     ref = R.detect(sd, spec, R.embed_video(sd, spec, frames[:16].cpu(), msgs, chunk_size=4, step_size=4, lowres_attenuation=True)["imgs_w"])["preds"]
     assert (a[:16].cpu() - ref).abs().max().item() < TOL_LOGIT
+
+
+def test_chunkyseal_released_size_detector_vs_oracle():
+    """BASELINE config 5 architecture at its released size (ConvNeXt dims 362/724/1448/2896, depths 3/3/27/3, 774 M extractor
+    parameters, 1024 bits, stride-2 stem -> 127/63/31/15 feature maps): HIP detect vs the CPU oracle on two frames."""
+    spec = spec_from_card(os.path.join(CARDS, "chunkyseal.yaml"))
+    sd = make_state_dict(spec, seed=2)
+    model = make_model(spec, sd)
+    imgs = synthetic_frames(2, 512, 480, seed=7)
+    ref = R.detect(sd, spec, imgs)["preds"]
+    got = model.detect(imgs.cuda(), is_video=True)["preds"].cpu()
+    assert (got - ref).abs().max().item() < 1e-4
+    assert ((got > 0) == (ref > 0))[ref.abs() > 1e-4].all()
+    del model
+    torch.cuda.empty_cache()
