@@ -377,3 +377,20 @@ def test_chunkyseal_released_size_detector_vs_oracle():
     assert ((got > 0) == (ref > 0))[ref.abs() > 1e-4].all()
     del model
     torch.cuda.empty_cache()
+
+
+def test_vs10_768_vs_oracle(vs10):
+    """BASELINE config 2 frame size (768 x 768) directly against the CPU oracle: image mode (full-res JND) and video mode (key frames
+    every 2, low-res JND), watermarked frames, PSNR and logits."""
+    spec, sd, model = vs10
+    imgs = synthetic_frames(4, 768, 768, seed=61)
+    m4, m1 = synthetic_msgs(4, spec.nbits, seed=61), synthetic_msgs(1, spec.nbits, seed=62)
+    model.chunk_size, model.step_size, model.video_mode = 8, 2, "repeat"
+    for got, ref in ((model.embed(imgs.cuda(), m4, is_video=False)["imgs_w"].cpu(), R.embed_image(sd, spec, imgs, m4)["imgs_w"]),
+                     (model.embed(imgs.cuda(), m1, is_video=True, lowres_attenuation=True)["imgs_w"].cpu(),
+                      R.embed_video(sd, spec, imgs, m1, chunk_size=8, step_size=2, lowres_attenuation=True)["imgs_w"])):
+        assert (got - ref).abs().max().item() < TOL_IMG
+        assert abs(R.psnr(got, imgs).mean().item() - R.psnr(ref, imgs).mean().item()) < 1e-3
+        p, pr = model.detect(got.cuda(), is_video=True)["preds"].cpu(), R.detect(sd, spec, ref)["preds"]
+        assert (p - pr).abs().max().item() < TOL_LOGIT
+        assert ((p > 0) == (pr > 0))[pr.abs() > 1e-4].all()
