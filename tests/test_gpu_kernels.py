@@ -291,6 +291,8 @@ GEMM_PC_CASES = [
     (1, 8, 8, 3072, 768, 0, True, True, 2, 8),
     (5, 8, 8, 64, 40, 3, False, False, 1, 2),         # one K pair per slice, tanh
     (2, 16, 24, 32, 130, 2, False, True, 2, 1),       # single pair, three N tiles of which one ragged
+    (3, 15, 15, 160, 96, 0, True, True, 1, 1),        # 225-row frames: tiles straddle frame boundaries at arbitrary rows (ChunkySeal)
+    (2, 31, 31, 96, 200, 0, True, True, 2, 1),
 ]
 
 

@@ -453,7 +453,7 @@ extern "C" int vs_conv_gemm(const vs_conv_desc_t* dp, void* stream) {
     VS_REQUIRE(can_split0 && d.wt_blk && ((uintptr_t)d.wt_blk & 15) == 0 && !(d.tile_hint & VS_CONV_FORCE_F32));
     VS_REQUIRE(d.KH == 1 && d.KW == 1 && d.SH == 1 && d.SW == 1 && d.PH == 0 && d.PW == 0 && d.Ho == d.H && d.Wo == d.W && !d.in2);
     VS_REQUIRE(d.Cin % 32 == 0 && d.CinP == d.Cin && d.in_sy == (int64_t)d.W * d.in_sx && d.in_sb == (int64_t)d.H * d.in_sy);
-    if (d.a_scale) VS_REQUIRE((d.H * d.W) % 64 == 0);
+    if (d.a_scale) VS_REQUIRE(d.H * d.W >= 128 || d.H * d.W == 64);   // a 128-row tile touches at most two frames
     if (d.sumsq_part) VS_REQUIRE(d.split_k <= 1 && !d.res);
     if (d.split_k > 1) VS_REQUIRE(d.splitk_ws && d.splitk_ld >= d.N && d.split_k <= d.CinP / 32);
     return vs_gemm1x1_pc_dispatch(d, tile, st);
@@ -473,7 +473,7 @@ extern "C" int vs_conv_gemm(const vs_conv_desc_t* dp, void* stream) {
     const bool gemm_ok = can_split0 && d.wt_blk && ((uintptr_t)d.wt_blk & 15) == 0 && !(d.tile_hint & VS_CONV_FORCE_F32) && d.KH == 1 &&
                          d.KW == 1 && d.SH == 1 && d.SW == 1 && d.PH == 0 && d.PW == 0 && d.Ho == d.H && d.Wo == d.W && !d.in2 &&
                          d.Cin % 32 == 0 && d.CinP == d.Cin && d.in_sy == (int64_t)d.W * d.in_sx && d.in_sb == (int64_t)d.H * d.in_sy &&
-                         (!d.a_scale || (d.H * d.W) % 64 == 0) && !(d.sumsq_part && d.res);
+                         (!d.a_scale || d.H * d.W >= 128 || d.H * d.W == 64) && !(d.sumsq_part && d.res);
     if (gemm_ok && d.CinP >= 384 && d.N > 128) return vs_gemm1x1_pc_dispatch(d, 18, st);
     if (d.KH == 1 && d.KW == 1 && d.CinP < 384 && d.N >= 256) tile = 1;
     else tile = d.N <= 32 ? 3 : (d.N <= 64 ? 2 : (d.N <= 96 ? 5 : ((d.N % 192 == 0 || (d.N > 128 && d.N <= 192)) ? 4 : 1)));

@@ -82,9 +82,14 @@ __global__ __launch_bounds__(512, 2) void gemm1x1_pc_kernel(const vs_conv_desc_t
       a_off[i] = (unsigned)(((int64_t)m * d.in_sx + seg * 4) * 4);
       l_off[i] = ((seg >> 2) * A_STAGE) + row * ROWB + (seg & 3) * 8;   // stage parity of the step + position inside it
     }
-    // GRN scale is per (frame, channel): H*W % 64 == 0 (checked by the dispatcher), so rows 0-63 of the tile lie in one
+    // GRN scale is per (frame, channel).  A 128-row tile touches at most two frames (H*W >= 128, or H*W == 64 with aligned tiles:
+    // checked by the dispatcher): frame f_lo up to the row `rb` where the next frame starts, f_hi from there on.  (was: rows 0-63 one
     // frame and rows 64-127 in one frame -> two scale vectors + one shift vector per thread and pair, loaded with the data
-    const int f_lo = min(m0 / HW, d.B - 1), f_hi = min((m0 + 64) / HW, d.B - 1);
+    const int f_lo = min(m0 / HW, d.B - 1), f_hi = min(f_lo + 1, d.B - 1);
+    const int rb = (f_lo + 1) * HW - m0;              // first tile row of frame f_lo + 1 (>= 128: the tile lies in one frame)
+    bool hi_sel[NI];
+#pragma unroll
+    for (int i = 0; i < NI; ++i) hi_sel[i] = ((pt >> 3) + i * 32) >= rb;
     const char* const abase = reinterpret_cast<const char*>(d.in) + (int64_t)pair0 * 128;
     constexpr bool grn = GRN;       // compile-time: a run-time branch around the scale loads makes hipcc's vmcnt counting pessimistic
     const char* const sbase0 = reinterpret_cast<const char*>(d.a_scale) + ((int64_t)f_lo * d.a_scale_ld + pair0 * 32 + seg * 4) * 4;
@@ -134,7 +139,7 @@ __global__ __launch_bounds__(512, 2) void gemm1x1_pc_kernel(const vs_conv_desc_t
 #pragma unroll
         for (int i = 0; i < NI; ++i) {
           f32x4 v = R.r[i];
-          if (grn) v = v * (i < NI / 2 ? R.s0 : R.s1) + R.h;            // GRN apply (same expression as conv_gemm_kernel)
+          if (grn) v = v * (hi_sel[i] ? R.s1 : R.s0) + R.h;            // GRN apply (same expression as conv_gemm_kernel)
           u32x2 p1, p2, p3;
           split4(v, p1, p2, p3);
           unsigned char* dst = Aring + l_off[i];

@@ -244,7 +244,7 @@ struct Runner {
     int split_k = 1;
     const bool dense_rows = d.in_sy == (int64_t)d.W * d.in_sx && d.in_sb == (int64_t)d.H * d.in_sy;
     const bool gemm_pc = d.KH == 1 && d.KW == 1 && sh == 1 && sw == 1 && ph == 0 && pw == 0 && !in2 && d.Ho == d.H && d.Wo == d.W &&
-                         d.Cin % 32 == 0 && d.CinP == d.Cin && dense_rows && (!a_scale || ((d.H * d.W) % 64 == 0));
+                         d.Cin % 32 == 0 && d.CinP == d.Cin && dense_rows && (!a_scale || d.H * d.W >= 128 || d.H * d.W == 64);
     const bool patch_pc = d.KH == 3 && d.KW == 3 && sh == 1 && sw == 1 && ph == 1 && pw == 1 && d.Ho == d.H && d.Wo == d.W && !a_scale &&
                           d.W % 16 == 0 && d.H % 8 == 0;
     if (sumsq) {
