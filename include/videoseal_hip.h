@@ -133,6 +133,20 @@ int vs_grn_apply(float* h, int B, int HW, int C, int64_t ld, const float* scale,
 int vs_grn_scale(const float* h, int B, int HW, int C, int64_t ld, const float* gamma, float* partial,
                  float* scale, void* stream);
 
+/* BatchNorm2d with BATCH statistics over the rows of an NHWC tensor -- the U-Net's ResnetBlocks under model.train()
+ * (unet.py:26,30; nn.BatchNorm2d training branch: biased variance for the normalisation, running statistics updated in place
+ * with `momentum` and the UNBIASED variance; either running pointer may be NULL).  Outputs the folded per-channel
+ * scale = gamma / sqrt(var + eps) and shift = beta - mean * scale, to be applied with vs_scale_shift_act.  Deterministic
+ * (fp64 partial sums in a fixed order).  `partial` is workspace of vs_bn_partial_doubles(rows, ld) doubles. */
+int64_t vs_bn_partial_doubles(int64_t rows, int64_t ld);
+int vs_bn_batch_stats(const float* x, int64_t rows, int C, int64_t ld, const float* gamma, const float* beta, float eps,
+                      float momentum, float* running_mean, float* running_var, double* partial, float* scale, float* shift,
+                      void* stream);
+/* out = act(x * scale[c] + shift[c]) (+ add): the normalisation + ReLU (+ res_conv branch, unet.py:38-39) of a train-mode ResnetBlock.
+ * C % 4 == 0. */
+int vs_scale_shift_act(const float* x, int64_t rows, int C, int64_t ld, const float* scale, const float* shift, int act,
+                       const float* add, int64_t add_ld, float* out, int64_t out_ld, void* stream);
+
 /* Bilinear x2 (align_corners=False) of cat(x, skip*skip_scale) along channels.  unet.py:186-191 + common.py:46. */
 int vs_upcat2x(const float* x, int C1, int64_t ld1, const float* skip, int C2, int64_t ld2, float skip_scale,
                int B, int H, int W, float* out, int64_t out_ld, void* stream);
@@ -182,6 +196,8 @@ int vs_jnd_heatmap(const float* img, int B, int H, int W, int64_t sb, int64_t sc
  *   d     *= hmap_lowres (before the resize) or JND(imgs) (after it)       (hmap_lowres may be NULL,
  *                                                                           attenuate=0 disables JND)
  *   out    = clamp(scaling_i*imgs + scaling_w*d, 0, 1)
+ * attenuate = 2 (full-resolution JND only) is the training forward's order of operations (wam.py:103-113, jnd.py:110-114):
+ *   v = scaling_i*imgs + scaling_w*d;  out = clamp(imgs + JND(imgs) * (v - imgs), 0, 1);  preds_w = the UN-attenuated d.
  * imgs/out: NCHW [F][3][H][W]; preds_w (optional) [F][Cd][H][W].
  * io_u8 = 1: imgs and out are uint8 RGB24 [F][H][W][3]; read as float(u)/255.0f, written as (unsigned char)(v*255.0f)
  * = `(imgs_w * 255.0).byte().permute(0,2,3,1)` of inference_streaming.py:31 (needs clamp = 1).
@@ -244,6 +260,12 @@ int vs_model_detect(vs_model_t* m, const void* imgs, int frames, int H, int W, i
 #define VS_COLOR_GRAYSCALE 4    /* valuemetric.py:196-208 0.299 R + 0.587 G + 0.114 B broadcast to 3 channels            */
 int64_t vs_aug_color_scratch_floats(int F, int H, int W);
 int vs_aug_color(const float* src, float* dst, int F, int H, int W, int op, float factor, float* scratch, void* stream);
+/* watermark masking of the training forward (augmenter.py:171-176): dst = imgs_w * m + imgs * (1 - m), m [F][1][H][W]          */
+int vs_aug_mask_blend(const float* imgs_w, const float* imgs, const float* mask, float* dst, int F, int C, int H, int W, void* stream);
+/* GaussianNoise (valuemetric.py:176-194): dst = x + noise * std over n floats; `noise` is the caller's torch.randn_like draw    */
+int vs_aug_add_scaled(const float* x, const float* noise, float std, float* dst, int64_t n, void* stream);
+/* DropFrame / SpeedChange (augmentation/video.py:491-526, 263-313): dst[f] = src[idx[f]] for n_out whole frames; idx int32 on device */
+int vs_aug_gather_frames(const float* src, const int32_t* idx, float* dst, int n_out, int64_t frame_floats, void* stream);
 /* crop (geometric.py:94-124, zero fill outside) and/or horizontal flip (geometric.py:186-196) of `planes` H x W planes   */
 int vs_aug_crop_flip(const float* src, float* dst, int planes, int H, int W, int i0, int j0, int h, int w, int flip, void* stream);
 /* bilinear resize NCHW -> NCHW, align_corners=False, antialias on/off (geometric.py:62-91; augmenter.py:147-150)        */

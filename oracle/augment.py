@@ -193,3 +193,56 @@ def perspective(x, startpoints, endpoints):
     g2 = base.view(1, oh * ow, 3).bmm(theta2.transpose(1, 2))
     grid = (g1 / g2 - 1.0).view(1, oh, ow, 2)
     return F.grid_sample(x, grid.expand(x.shape[0], oh, ow, 2), mode="bilinear", padding_mode="zeros", align_corners=False)
+
+
+# ---- Augmenter (augmentation/augmenter.py:60-194) with the ops the golden forward cases use.  RNG draws in the reference's order:
+# torch.multinomial(probs, 1) for the pick, then the op's own draws (Crop: randint h, randint w, then RandomCrop.get_params'
+# randint i, randint j unless the size is unchanged).
+class Augmenter:
+    OPS = {"identity": "Identity", "crop": "Crop", "hflip": "HorizontalFlip", "resize": "Resize"}
+
+    def __init__(self, augs: dict, augs_params: dict, num_augs: int = 1):
+        self.names = list(augs.keys())
+        tot = sum(float(v) for v in augs.values())
+        self.probs = torch.tensor([float(augs[k]) / tot for k in self.names])
+        self.params = augs_params
+        self.num_augs = num_augs
+
+    def _size(self, name, h, w):
+        p = self.params[name]
+        return (torch.randint(int(p["min_size"] * h), int(p["max_size"] * h) + 1, size=(1,)).item(),
+                torch.randint(int(p["min_size"] * w), int(p["max_size"] * w) + 1, size=(1,)).item())
+
+    def _apply(self, name, image, mask):
+        h, w = image.shape[-2:]
+        if name == "identity":
+            return image, mask
+        if name == "hflip":
+            return hflip(image), (hflip(mask) if mask is not None else mask)
+        if name == "resize":
+            out = self._size(name, h, w)
+            return resize(image, out), (resize(mask, out) if mask is not None else mask)
+        if name == "crop":
+            th, tw = self._size(name, h, w)
+            if (th, tw) == (h, w):
+                i = j = 0
+            else:
+                i = torch.randint(0, h - th + 1, size=(1,)).item()
+                j = torch.randint(0, w - tw + 1, size=(1,)).item()
+            return crop(image, i, j, th, tw), (crop(mask, i, j, th, tw) if mask is not None else mask)
+        raise ValueError(name)
+
+    def __call__(self, imgs_w, imgs, masks, is_video=True, do_resize=True):
+        """training branch with the full mask (NoMaskEmbedder): mask_targets = 1, imgs_aug = imgs_w * 1 + imgs * 0."""
+        mask_targets = torch.ones_like(imgs_w[:, 0:1])
+        imgs_aug = imgs_w * mask_targets + imgs * (1 - mask_targets)
+        names = []
+        for _ in range(self.num_augs):
+            name = self.names[torch.multinomial(self.probs, 1).item()]
+            h, w = imgs_aug.shape[-2:]
+            imgs_aug, mask_targets = self._apply(name, imgs_aug, mask_targets)
+            if do_resize and tuple(imgs_aug.shape[-2:]) != (h, w):
+                imgs_aug = resize(imgs_aug, (h, w))
+                mask_targets = resize(mask_targets, (h, w))
+            names.append(self.OPS[name])
+        return imgs_aug, mask_targets, "+".join(names)

@@ -20,16 +20,24 @@ AA = {"mode": "bilinear", "align_corners": False, "antialias": True}
 
 
 # --------------------------------------------------------------------------- layers
-def _bn_eval(sd: SD, p: str, x):
-    # nn.BatchNorm2d in eval mode (unet.py:26,30 via common.py:182-184), eps = 1e-5
-    return F.batch_norm(x, sd[p + ".running_mean"], sd[p + ".running_var"], sd[p + ".weight"], sd[p + ".bias"],
-                        training=False, eps=1e-5)
+def _bn(sd: SD, p: str, x, bn: Optional[dict] = None):
+    """nn.BatchNorm2d (unet.py:26,30 via common.py:182-184), eps = 1e-5.  bn=None: eval mode (running statistics).
+    bn = {}: TRAIN mode -- batch statistics, and the updated running_mean / running_var / num_batches_tracked
+    (momentum 0.1, unbiased variance) are written into `bn` under their state_dict names (sd itself is not modified)."""
+    if bn is None:
+        return F.batch_norm(x, sd[p + ".running_mean"], sd[p + ".running_var"], sd[p + ".weight"], sd[p + ".bias"],
+                            training=False, eps=1e-5)
+    rm, rv = sd[p + ".running_mean"].clone(), sd[p + ".running_var"].clone()
+    y = F.batch_norm(x, rm, rv, sd[p + ".weight"], sd[p + ".bias"], training=True, momentum=0.1, eps=1e-5)
+    bn[p + ".running_mean"], bn[p + ".running_var"] = rm, rv
+    bn[p + ".num_batches_tracked"] = sd[p + ".num_batches_tracked"] + 1
+    return y
 
 
-def resnet_block(sd: SD, p: str, x):
+def resnet_block(sd: SD, p: str, x, bn: Optional[dict] = None):
     """unet.py:17-39  relu(bn(conv3(relu(bn(conv3(x)))))) + conv1x1(x)."""
-    h = F.relu(_bn_eval(sd, p + ".double_conv.1", F.conv2d(x, sd[p + ".double_conv.0.weight"], padding=1)))
-    h = F.relu(_bn_eval(sd, p + ".double_conv.4", F.conv2d(h, sd[p + ".double_conv.3.weight"], padding=1)))
+    h = F.relu(_bn(sd, p + ".double_conv.1", F.conv2d(x, sd[p + ".double_conv.0.weight"], padding=1), bn))
+    h = F.relu(_bn(sd, p + ".double_conv.4", F.conv2d(h, sd[p + ".double_conv.3.weight"], padding=1), bn))
     return h + F.conv2d(x, sd[p + ".res_conv.weight"], sd[p + ".res_conv.bias"])
 
 
@@ -62,30 +70,30 @@ def msg_latent(sd: SD, msgs):
     return F.embedding(idx, table).sum(dim=-2)
 
 
-def unet_forward(sd: SD, s: ModelSpec, x, msgs):
-    """unet.py:170-197 (x already in [-1,1])."""
+def unet_forward(sd: SD, s: ModelSpec, x, msgs, bn: Optional[dict] = None):
+    """unet.py:170-197 (x already in [-1,1]).  bn: see _bn (None = eval, dict = train mode)."""
     u = "embedder.unet"
-    hid = [resnet_block(sd, u + ".inc", x)]
+    hid = [resnet_block(sd, u + ".inc", x, bn)]
     for i in range(len(s.mults) - 1):
         d = F.conv2d(hid[-1], sd[f"{u}.downs.{i}.down.weight"], sd[f"{u}.downs.{i}.down.bias"], stride=2, padding=1)
-        hid.append(resnet_block(sd, f"{u}.downs.{i}.conv", d))
+        hid.append(resnet_block(sd, f"{u}.downs.{i}.conv", d, bn))
     lat = hid.pop()
     m = msg_latent(sd, msgs)[:, :, None, None].expand(-1, -1, lat.shape[-2], lat.shape[-1])
     hid.append(torch.cat([lat, m], dim=1))          # msg_processor.py:111-115 (concat, msg_mult = 1)
     x = hid[-1]
     for j in range(s.num_blocks):
-        x = resnet_block(sd, f"{u}.bottleneck.model.{j}", x)
+        x = resnet_block(sd, f"{u}.bottleneck.model.{j}", x, bn)
     for k in range(len(s.mults) - 1):
         x = torch.cat((x, hid.pop() * (2 ** -0.5)), dim=1)     # unet.py:186-187
         x = upsample_block(sd, f"{u}.ups.{k}.up", x, 2, F.relu)
-        x = resnet_block(sd, f"{u}.ups.{k}.conv", x)
+        x = resnet_block(sd, f"{u}.ups.{k}.conv", x, bn)
     x = F.conv2d(x, sd[u + ".outc.weight"], sd[u + ".outc.bias"])
     return torch.tanh(x) if s.last_tanh else x
 
 
-def embedder_forward(sd: SD, s: ModelSpec, imgs01, msgs):
+def embedder_forward(sd: SD, s: ModelSpec, imgs01, msgs, bn: Optional[dict] = None):
     """embedder.py:151-165  x*2-1 -> UNetMsg."""
-    return unet_forward(sd, s, imgs01 * 2 - 1, msgs)
+    return unet_forward(sd, s, imgs01 * 2 - 1, msgs, bn)
 
 
 def convnext_block(sd: SD, p: str, x):
@@ -222,6 +230,62 @@ def embed_video(sd: SD, s: ModelSpec, imgs, msgs, interp=AA, lowres_attenuation=
     if clamp:
         out = torch.clamp(out, 0, 1)
     return {"imgs_w": out, "msgs": msgs[0:1].repeat(len(imgs), 1)}
+
+
+def forward_image(sd: SD, s: ModelSpec, imgs, masks, msgs, augment, interp=AA, bn: Optional[dict] = None, attenuate=True,
+                  clamp=True, scaling_i=None, scaling_w=None):
+    """wam.py:68-132, the training forward.  `augment(imgs_w, imgs, masks, is_video, do_resize) -> (imgs_aug, masks, name)` is the
+    augmenter (oracle/augment.py:Augmenter).  bn: see _bn."""
+    si = s.scaling_i if scaling_i is None else scaling_i
+    sw = s.scaling_w if scaling_w is None else scaling_w
+    P = (s.img_size, s.img_size)
+    res = _resize(imgs, P, interp)
+    x = rgb2y(sd, res) if s.yuv else res
+    preds_w = embedder_forward(sd, s, x, msgs, bn)
+    if tuple(imgs.shape[-2:]) != P:
+        preds_w = F.interpolate(preds_w, size=imgs.shape[-2:], **interp)
+    imgs_w = si * imgs + sw * preds_w                               # blender.py:61-68
+    if attenuate:
+        imgs_w = imgs + jnd_heatmaps(sd, s, imgs) * (imgs_w - imgs)      # jnd.py:110-114
+    if clamp:
+        imgs_w = torch.clamp(imgs_w, 0, 1)
+    imgs_aug, masks, selected = augment(imgs_w, imgs, masks, False, False)
+    if tuple(imgs_aug.shape[-2:]) != P:
+        imgs_aug = F.interpolate(imgs_aug, size=P, **interp)
+    preds = extractor_forward(sd, s, imgs_aug)
+    return {"msgs": msgs, "masks": masks, "preds_w": preds_w, "imgs_w": imgs_w, "imgs_aug": imgs_aug, "preds": preds,
+            "selected_aug": selected}
+
+
+def forward_video(sd: SD, s: ModelSpec, imgs, masks, msgs, augment, interp=AA, bn: Optional[dict] = None, step_size=None,
+                  video_mode="repeat", lowres_attenuation=False, attenuate=True, clamp=True):
+    """videoseal.py:163-256 (`video_forward`)."""
+    assert msgs.shape[0] == 1, "Message should be unique"
+    st = step_size or s.step_size
+    P = (s.img_size, s.img_size)
+    m = msgs.expand(len(imgs), -1)
+    res = _resize(imgs, P, interp)
+    key = res[::st]
+    x = rgb2y(sd, key) if s.yuv else key
+    preds_w = apply_video_mode(embedder_forward(sd, s, x, m[::st], bn), len(res), st, video_mode)
+    if lowres_attenuation and attenuate:
+        preds_w = jnd_heatmaps(sd, s, res) * preds_w
+        if tuple(imgs.shape[-2:]) != P:
+            preds_w = F.interpolate(preds_w, size=imgs.shape[-2:], **interp)
+        imgs_w = s.scaling_i * imgs + s.scaling_w * preds_w
+    else:
+        if tuple(imgs.shape[-2:]) != P:
+            preds_w = F.interpolate(preds_w, size=imgs.shape[-2:], **interp)
+        imgs_w = s.scaling_i * imgs + s.scaling_w * preds_w
+        if attenuate:
+            imgs_w = imgs + jnd_heatmaps(sd, s, imgs) * (imgs_w - imgs)
+    if clamp:
+        imgs_w = torch.clamp(imgs_w, 0, 1)
+    imgs_aug, masks, selected = augment(imgs_w, imgs, masks, True, False)
+    if tuple(imgs.shape[-2:]) != P:
+        imgs_aug = F.interpolate(imgs_aug, size=P, **interp)
+    preds = extractor_forward(sd, s, imgs_aug)
+    return {"msgs": m, "masks": masks, "imgs_w": imgs_w, "imgs_aug": imgs_aug, "preds": preds, "selected_aug": selected}
 
 
 def detect(sd: SD, s: ModelSpec, imgs, interp=AA):

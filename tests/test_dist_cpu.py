@@ -59,3 +59,15 @@ def test_gather_frame_logits_world2(n_frames):
     for rank, ok, msg in res:
         assert ok, f"rank {rank}: gathered logits differ from the single-process matrix"
         assert msg == want                                   # every rank decodes the same message
+
+
+def test_shard_alignment_rules():
+    """shard starts must be key frames; interpolate mode additionally needs chunk-aligned shards"""
+    from types import SimpleNamespace
+    from videoseal_amd.dist import check_alignment
+    check_alignment(SimpleNamespace(step_size=4, chunk_size=32, video_mode="repeat"), 16)
+    check_alignment(SimpleNamespace(step_size=4, chunk_size=4, video_mode="interpolate"), 16)
+    with pytest.raises(ValueError, match="step_size"):
+        check_alignment(SimpleNamespace(step_size=3, chunk_size=8, video_mode="repeat"), 16)
+    with pytest.raises(ValueError, match="interpolate"):
+        check_alignment(SimpleNamespace(step_size=4, chunk_size=32, video_mode="interpolate"), 16)

@@ -104,16 +104,39 @@ def test_median_filter(frames, k):
     assert torch.equal(got.cpu(), A.median_filter(frames, k))      # selection only: exact
 
 
-def test_augmenter_picks_like_the_reference():
-    aug = G.Augmenter(masks={"kind": None}, augs={"identity": 1, "crop": 1, "brightness": 1, "jpeg": 1, "hflip": 1},
-                      augs_params={"crop": {"min_size": 0.5, "max_size": 1.0}, "brightness": {"min_factor": 0.5, "max_factor": 2},
-                                   "jpeg": {"min_quality": 40, "max_quality": 80}}, num_augs=2)
-    x = synthetic_frames(2, 64, 64, seed=3).cuda()
-    torch.manual_seed(11)
-    out, mask, names = aug(x, x, None, is_video=False, do_resize=True)
-    assert out.shape == x.shape and mask.shape == (2, 1, 64, 64) and len(names.split("+")) == 2
+def test_augmenter_draws_strengths_in_the_reference_order():
+    """augmenter.py:137-152 with value ops: the multinomial pick, then each op's own draw (valuemetric.py:27-31, 104-108), replayed
+    here draw by draw.  (Names + crop draws against the REFERENCE Augmenter itself: tests/test_gpu_fwd.py, augmenter_picks.json.)"""
+    augs = {"identity": 1, "crop": 1, "brightness": 1, "jpeg": 1, "hflip": 1}
+    params = {"crop": {"min_size": 0.5, "max_size": 1.0}, "brightness": {"min_factor": 0.5, "max_factor": 2},
+              "jpeg": {"min_quality": 40, "max_quality": 80}}
+    aug = G.Augmenter(masks={"kind": "none"}, augs=augs, augs_params=params, num_augs=3).train()
+    names = list(augs)
+    cls = {"identity": "Identity", "crop": "Crop", "brightness": "Brightness", "jpeg": "JPEG", "hflip": "HorizontalFlip"}
+    x = synthetic_frames(2, 64, 64, seed=3)
+    for seed in range(8):
+        torch.manual_seed(seed)
+        out, mask, picked = aug(x.cuda(), x.cuda(), None, is_video=False, do_resize=True)
+        torch.manual_seed(seed)
+        ref, want = x, []
+        for _ in range(3):
+            n = names[torch.multinomial(torch.full((5,), 0.2), 1).item()]
+            want.append(cls[n])
+            if n == "crop":
+                th = torch.randint(32, 65, size=(1,)).item(); tw = torch.randint(32, 65, size=(1,)).item()
+                i, j = (0, 0) if (th, tw) == (64, 64) else (torch.randint(0, 64 - th + 1, size=(1,)).item(), torch.randint(0, 64 - tw + 1, size=(1,)).item())
+                ref = A.resize(A.crop(ref, i, j, th, tw), (64, 64))
+            elif n == "brightness":
+                ref = A.brightness(ref, torch.rand(1).item() * 1.5 + 0.5)
+            elif n == "jpeg":
+                ref = A.jpeg(ref, torch.randint(40, 81, size=(1,)).item())
+            elif n == "hflip":
+                ref = A.hflip(ref)
+        assert picked == "+".join(want), seed
+        assert out.shape == x.shape and mask.shape == (2, 1, 64, 64)
+        assert (out.cpu() - ref).abs().max() < (1e-5 if "JPEG" not in picked else 3e-2), (seed, picked)
     with pytest.raises(NotImplementedError):
-        G.H264()(x, None, 23)          # external codec: loud, no fallback
+        G.H264()(x.cuda(), None, 23)          # external codec: loud, no fallback
 
 
 def test_config3_clip_through_the_full_chain():

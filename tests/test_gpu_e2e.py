@@ -144,10 +144,31 @@ def test_errors_are_loud(tiny):
         model.embed(imgs, synthetic_msgs(2, spec.nbits), is_video=True)
     with pytest.raises(NotImplementedError):
         model.detect(imgs, interpolation={"mode": "bicubic", "align_corners": False})
-    model.train()
-    with pytest.raises(NotImplementedError, match="eval"):
-        model.embed(imgs, is_video=True)
-    model.eval()
+    with pytest.raises(NotImplementedError, match="mixed"):         # OpenCV mask embedder: loud, not silently the full mask
+        from videoseal_amd.augmentation import Augmenter
+        Augmenter(masks={"kind": None}, augs={"identity": 1}, augs_params={}).train()(imgs, imgs, None)
+
+
+def test_embed_in_train_mode_uses_batch_statistics():
+    """README.md:61-71 never calls .eval(): load() returns a train-mode module whose BatchNorm runs on batch statistics and updates
+    its running statistics (SURVEY 8(b) 'Train/eval flag').  Same here (fresh module: the call mutates the buffers)."""
+    spec = tiny_spec()
+    sd = make_state_dict(spec, seed=3)
+    model = make_model(spec, sd).train()
+    imgs = synthetic_frames(3, 64, 64, seed=1)
+    msgs = synthetic_msgs(3, spec.nbits, seed=1)
+    out = model.embed(imgs.cuda(), msgs, is_video=False)["imgs_w"].cpu()
+    P = (spec.img_size, spec.img_size)
+    bn = {}
+    with torch.no_grad():
+        y = R.rgb2y(sd, imgs)
+        delta = R.embedder_forward(sd, spec, y, msgs, bn)
+        ref = torch.clamp(spec.scaling_i * imgs + spec.scaling_w * R.jnd_heatmaps(sd, spec, imgs) * delta, 0, 1)
+    assert P == tuple(imgs.shape[-2:]) and (out - ref).abs().max() < 1e-4
+    new = model.state_dict()
+    for k, v in bn.items():
+        assert (new[k].cpu().float() - v.float()).abs().max() < 2e-5 * max(1.0, float(v.float().abs().max())), k
+    assert (out - R.embed_image(sd, spec, imgs, msgs)["imgs_w"]).abs().max() > 1e-5        # not the eval-mode result
 
 
 def test_full_size_properties():

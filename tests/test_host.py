@@ -127,3 +127,24 @@ def test_metrics_match_oracle():
     assert torch.equal(bit_accuracy(p, t), R.bit_accuracy(p, t))
     pix = torch.randn(2, 8, 5, 5)
     assert bit_accuracy(pix, torch.randint(0, 2, (2, 8))).shape == (2,)
+
+
+def test_videoseal_import_shim_resolves_the_reference_paths():
+    """inference_streaming.py:18-20, inference_av.py:20: `import videoseal` / `videoseal.models` / `videoseal.evals.metrics` / `utils.cfg`"""
+    import videoseal
+    import videoseal_amd
+    from videoseal.augmentation import Identity, JPEG, get_validation_augs  # noqa: F401
+    from videoseal.augmentation.augmenter import Augmenter, get_dummy_augmenter  # noqa: F401
+    from videoseal.augmentation.sequential import Sequential  # noqa: F401
+    from videoseal.evals.metrics import bit_accuracy, psnr
+    from videoseal.models import Videoseal, Wam
+    from videoseal.models.videoseal import Videoseal as V2
+    from videoseal.modules.jnd import JND  # noqa: F401
+    from videoseal.utils.cfg import setup_model_from_model_card
+    assert videoseal.load is videoseal_amd.load and setup_model_from_model_card is videoseal_amd.load
+    assert Videoseal is videoseal_amd.Videoseal and V2 is Videoseal and issubclass(Videoseal, Wam)
+    assert bit_accuracy is videoseal_amd.metrics.bit_accuracy and psnr is videoseal_amd.metrics.psnr
+    m = videoseal_amd.build("videoseal_1.0")
+    assert isinstance(m, Videoseal) and m.training and type(m.augmenter).__name__ == "Augmenter"
+    with pytest.raises(FileNotFoundError):
+        videoseal.load("videoseal")          # card found, checkpoint absent (no network): the reference's error type

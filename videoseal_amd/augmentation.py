@@ -229,6 +229,93 @@ class JPEG(_Aug):
         return (out[0] if squeeze else out), mask
 
 
+class GaussianNoise(_Aug):
+    """valuemetric.py:176-194: image + randn_like(image) * std.  The normal draw is torch's own generator on the image's device,
+    exactly as in the reference; the scale-and-add is the HIP kernel."""
+
+    def __init__(self, min_std=None, max_std=None):
+        super().__init__()
+        self.min_std, self.max_std = min_std, max_std
+
+    def get_random_std(self):
+        if self.min_std is None or self.max_std is None:
+            raise ValueError("Standard deviation range must be specified")
+        return torch.rand(1).item() * (self.max_std - self.min_std) + self.min_std
+
+    def forward(self, image, mask=None, std=None):
+        std = self.get_random_std() if std is None else std
+        x = _dev(image)
+        noise = torch.randn_like(x)
+        out = torch.empty_like(x)
+        N.check(N.lib().vs_aug_add_scaled(N.ptr(x), N.ptr(noise), float(std), N.ptr(out), x.numel(), N.stream()), "vs_aug_add_scaled")
+        return out, mask
+
+
+def gather_frames(x: torch.Tensor, indices) -> torch.Tensor:
+    """frames[indices] for whole frames (any trailing shape) on the HIP gather kernel."""
+    x = _dev(x)
+    idx = torch.as_tensor(indices, dtype=torch.int32).to(x.device)
+    out = torch.empty((idx.numel(),) + tuple(x.shape[1:]), device=x.device, dtype=torch.float32)
+    if idx.numel():
+        N.check(N.lib().vs_aug_gather_frames(N.ptr(x), N.ptr(idx), N.ptr(out), idx.numel(), x[0].numel(), N.stream()), "vs_aug_gather_frames")
+    return out
+
+
+class DropFrame(_Aug):
+    """augmentation/video.py:491-529: every frame is replaced by a neighbour with probability drop_frame_prob (python `random`,
+    same draw order as the reference)."""
+
+    def __init__(self, drop_frame_prob=0.125):
+        super().__init__()
+        self.drop_frame_prob = drop_frame_prob
+
+    def get_random_drop_prob(self):
+        return self.drop_frame_prob
+
+    def forward(self, frames, mask=None, drop_prob=None, *args, **kwargs):
+        import random
+        drop_prob = drop_prob if drop_prob is not None else self.drop_frame_prob
+        n = len(frames)
+        idx = list(range(n))
+        for i in range(n):
+            if random.random() >= drop_prob:
+                continue
+            diff_ = -1 if random.random() < 0.5 else 1
+            idx[i] = (i + diff_) % n
+        return gather_frames(frames, idx), mask
+
+    def __repr__(self):
+        return f"DropFrame(prob={self.drop_frame_prob})"
+
+
+class SpeedChange(_Aug):
+    """augmentation/video.py:263-316: frames duplicated (speed < 1) or skipped (speed > 1) by rounded linspace indices."""
+
+    def __init__(self, min_speed=0.5, max_speed=1.5):
+        super().__init__()
+        self.min_speed, self.max_speed = min_speed, max_speed
+
+    def get_random_speed(self):
+        import random
+        if self.min_speed is None or self.max_speed is None:
+            raise ValueError("min_speed and max_speed must be provided")
+        return random.uniform(self.min_speed, self.max_speed)
+
+    def forward(self, frames, mask=None, speed_factor=None, *args, **kwargs):
+        n = frames.shape[0]
+        speed_factor = speed_factor if speed_factor is not None else self.get_random_speed()
+        if speed_factor == 1.0:
+            return frames, mask
+        if speed_factor < 1.0:
+            indices = torch.linspace(0, n - 1, int(n / speed_factor)).round().long().clamp(0, n - 1)
+        else:
+            indices = torch.linspace(0, n - 1, int(n * speed_factor))[:n].round().long().clamp(0, n - 1)
+        return gather_frames(frames, indices), (gather_frames(mask, indices) if mask is not None else None)
+
+    def __repr__(self):
+        return f"SpeedChange(min_speed={self.min_speed}, max_speed={self.max_speed})"
+
+
 class _NotBuilt(_Aug):
     why = ""
 
@@ -374,18 +461,69 @@ class Sequential(nn.Module):
 
 name2aug = {"resize": Resize, "crop": Crop, "hflip": HorizontalFlip, "identity": Identity, "jpeg": JPEG, "gaussian_blur": GaussianBlur,
             "median_filter": MedianFilter, "brightness": Brightness, "contrast": Contrast, "saturation": Saturation, "hue": Hue,
-            "rotate": Rotate, "perspective": Perspective, "h264": H264, "h264rgb": H264, "h265": H264, "video_compression": H264}
+            "rotate": Rotate, "perspective": Perspective, "h264": H264, "h264rgb": H264, "h265": H264, "video_compression": H264,
+            "drop_frame": DropFrame, "gaussian_noise": GaussianNoise, "grayscale": Grayscale, "speed_change": SpeedChange}
 video_augs = ["video_compression", "h264", "h264rgb", "h265"]
 
 
+class NoMaskEmbedder:
+    """augmentation/masks.py:305-314: the whole frame is watermarked (configs/all_augs.yaml:2-3 `kind: none`)."""
+
+    def __call__(self, imgs, iter_i=None, raw_image=None, **kwargs):
+        return torch.ones_like(imgs[:, 0:1, ...])
+
+    def sample_representative_masks(self, img):
+        return torch.ones((1, 1, img.shape[-2], img.shape[-1]))
+
+
+class GivenMaskEmbedder:
+    """The `masks` the caller passes to forward() are the mask targets (the CocoSegmentation branch of masks.py:395-396)."""
+
+    def __call__(self, imgs, masks=None, **kwargs):
+        if masks is None:
+            raise ValueError("GivenMaskEmbedder needs the masks argument of forward()")
+        return masks
+
+
+class _MixedMaskEmbedder:
+    why = ("the 'mixed' mask embedder (masks.py:317-424) draws irregular strokes / boxes with OpenCV + numpy on the host and is out of "
+           "scope (SURVEY.md section 2); use masks={'kind': 'none'} (the training config) or assign any callable "
+           "`augmenter.mask_embedder = fn(imgs_w, masks=...) -> [F,1,H,W]`")
+
+    def __call__(self, *a, **k):
+        raise NotImplementedError(self.why)
+
+
+def get_mask_embedder(kind=None, **kwargs):
+    """augmentation/masks.py:426-438."""
+    if kind is None:
+        kind = "mixed"
+    if kind == "none":
+        return NoMaskEmbedder()
+    if kind == "given":
+        return GivenMaskEmbedder()
+    if kind == "mixed":
+        return _MixedMaskEmbedder()
+    raise NotImplementedError(f"No such embedder kind = {kind}")
+
+
+def mask_blend(imgs_w: torch.Tensor, imgs: torch.Tensor, mask: torch.Tensor) -> torch.Tensor:
+    """augmenter.py:175  imgs_w * m + imgs * (1 - m), m [F,1,H,W]."""
+    a, b, m = _dev(imgs_w), _dev(imgs), _dev(mask)
+    F_, Cc, H, W = a.shape
+    if b.shape != a.shape or tuple(m.shape) != (F_, 1, H, W):
+        raise ValueError(f"mask blend: shapes {tuple(a.shape)}, {tuple(b.shape)}, {tuple(m.shape)}")
+    out = torch.empty_like(a)
+    N.check(N.lib().vs_aug_mask_blend(N.ptr(a), N.ptr(b), N.ptr(m), N.ptr(out), F_, Cc, H, W, N.stream()), "vs_aug_mask_blend")
+    return out
+
+
 class Augmenter(nn.Module):
-    """augmentation/augmenter.py:60-199 (train branch; masks kind None/'none' = full masks, all_augs.yaml:2-3)."""
+    """augmentation/augmenter.py:60-199."""
 
     def __init__(self, masks: dict, augs: dict, augs_params: dict, num_augs: int = 1, **kwargs) -> None:
         super().__init__()
-        kind = (masks or {}).get("kind", None)
-        if kind not in (None, "none", "None"):
-            raise NotImplementedError("mask embedders other than the full mask are out of scope (SURVEY.md section 2, row 23)")
+        self.mask_embedder = get_mask_embedder(**(masks or {}))
         self.augs, self.aug_probs = self.parse_augmentations(augs, augs_params)
         self.augs_video, self.aug_probs_video = self.parse_augmentations(augs, augs_params, is_video=True)
         self.num_augs = num_augs
@@ -415,14 +553,25 @@ class Augmenter(nn.Module):
         return image, mask, aug.__class__.__name__
 
     def forward(self, imgs_w, imgs, masks, is_video=True, do_resize=True):
-        # full mask: mask_targets = 1, imgs_aug = imgs_w (augmenter.py:171-176 with NoMaskEmbedder)
-        mask_targets = torch.ones_like(imgs_w)[:, 0:1]
-        imgs_aug = imgs_w
+        """augmenter.py:154-194.  Training: mask targets from the mask embedder, imgs_w * m + imgs * (1 - m), then num_augs picks.
+        Eval: the reference's branch references an unassigned variable (augmenter.py:185-194 cannot run); here it is the
+        full-mask case, i.e. the picks applied to imgs_w."""
+        if self.training and not isinstance(self.mask_embedder, NoMaskEmbedder):
+            mask_targets = self.mask_embedder(imgs_w, masks=masks).to(imgs_w.device)
+            imgs_aug = mask_blend(imgs_w, imgs, mask_targets.float().expand(imgs_w.shape[0], 1, *imgs_w.shape[-2:]).contiguous())
+        else:           # m = 1: imgs_w * 1 + imgs * 0 is imgs_w itself, no pass over the frames
+            mask_targets = torch.ones_like(imgs_w)[:, 0:1]
+            imgs_aug = imgs_w
         names: List[str] = []
         for _ in range(self.num_augs):
             imgs_aug, mask_targets, nm = self.augment(imgs_aug, mask_targets, is_video, do_resize)
             names.append(nm)
         return imgs_aug, mask_targets, "+".join(names)
+
+
+def get_dummy_augmenter():
+    """augmenter.py:48-57 (full mask instead of the OpenCV 'mixed' embedder, see model.get_dummy_augmenter)."""
+    return Augmenter(augs={"identity": 1}, augs_params={}, masks={"kind": "none"})
 
 
 def get_validation_augs(is_video: bool = False, only_identity: bool = False, only_combined: bool = False) -> list:

@@ -96,6 +96,33 @@ __global__ void gray_finish_kernel(const float* __restrict__ partial, int nblk, 
   means[f] = s / (float)plane;
 }
 
+// ------------------------------------------------------------------------------------------------ mask blend / additive noise
+// augmenter.py:175: imgs_aug = imgs_w * m + imgs * (1 - m), m = [F][1][H][W] broadcast over the C planes of a frame
+__global__ __launch_bounds__(256) void mask_blend_kernel(const float* __restrict__ iw, const float* __restrict__ im,
+                                                         const float* __restrict__ m, float* __restrict__ dst, int Cc, int64_t plane) {
+  const int64_t pl = blockIdx.y;                 // frame * Cc + channel
+  const float* mk = m + (pl / Cc) * plane;
+  const int64_t o = pl * plane;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < plane; i += (int64_t)gridDim.x * 256) {
+    const float w = mk[i];
+    dst[o + i] = __fadd_rn(__fmul_rn(iw[o + i], w), __fmul_rn(im[o + i], __fsub_rn(1.f, w)));   // no fma contraction: ATen rounds each product
+  }
+}
+// valuemetric.py:188-191: image + noise * std (the noise itself is the caller's torch.randn_like draw)
+__global__ __launch_bounds__(256) void add_scaled_kernel(const float* __restrict__ x, const float* __restrict__ nz, float std,
+                                                         float* __restrict__ dst, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) dst[i] = __fadd_rn(x[i], __fmul_rn(nz[i], std));
+}
+
+// video.py:507-526 (DropFrame) / 283-313 (SpeedChange): dst[f] = src[idx[f]], whole frames of `fsz` floats (fsz % 4 == 0 fast path)
+__global__ __launch_bounds__(256) void gather_frames_kernel(const float* __restrict__ src, const int32_t* __restrict__ idx,
+                                                            float* __restrict__ dst, int64_t fsz) {
+  const int64_t f = blockIdx.y;
+  const float* s = src + (int64_t)idx[f] * fsz;
+  float* d = dst + f * fsz;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < fsz; i += (int64_t)gridDim.x * 256) d[i] = s[i];
+}
+
 // ------------------------------------------------------------------------------------------------ geometric
 __global__ __launch_bounds__(256) void crop_flip_kernel(const float* __restrict__ src, float* __restrict__ dst, int H, int W, int i0,
                                                         int j0, int h, int w, int flip) {
@@ -551,5 +578,25 @@ extern "C" int vs_jpeg_roundtrip(const float* src, float* dst, int F, int H, int
   hipLaunchKernelGGL(jpeg_block_kernel, dim3((unsigned)cdiv64(nbc * (Wp / 16), 64)), dim3(64), 0, st, Cb, Wp / 2, Wp / 16, nbc * (Wp / 16), qc);
   hipLaunchKernelGGL(jpeg_block_kernel, dim3((unsigned)cdiv64(nbc * (Wp / 16), 64)), dim3(64), 0, st, Cr, Wp / 2, Wp / 16, nbc * (Wp / 16), qc);
   hipLaunchKernelGGL(jpeg_rgb_kernel, dim3((W + 31) / 32, (H + 7) / 8, F), dim3(256), 0, st, Y, Cb, Cr, H, W, Hp, Wp, dst);
+  return vs_launch_status();
+}
+
+extern "C" int vs_aug_mask_blend(const float* imgs_w, const float* imgs, const float* mask, float* dst, int F, int C, int H, int W,
+                                 void* stream) {
+  VS_REQUIRE(imgs_w && imgs && mask && dst && F > 0 && C > 0 && H > 0 && W > 0);
+  const int64_t plane = (int64_t)H * W;
+  hipLaunchKernelGGL(mask_blend_kernel, dim3(gridx(plane), F * C), dim3(256), 0, (hipStream_t)stream, imgs_w, imgs, mask, dst, C, plane);
+  return vs_launch_status();
+}
+
+extern "C" int vs_aug_add_scaled(const float* x, const float* noise, float std, float* dst, int64_t n, void* stream) {
+  VS_REQUIRE(x && noise && dst && n > 0);
+  hipLaunchKernelGGL(add_scaled_kernel, dim3(gridx(n, 256, 1 << 16)), dim3(256), 0, (hipStream_t)stream, x, noise, std, dst, n);
+  return vs_launch_status();
+}
+
+extern "C" int vs_aug_gather_frames(const float* src, const int32_t* idx, float* dst, int n_out, int64_t frame_floats, void* stream) {
+  VS_REQUIRE(src && idx && dst && n_out > 0 && frame_floats > 0);
+  hipLaunchKernelGGL(gather_frames_kernel, dim3(gridx(frame_floats), n_out), dim3(256), 0, (hipStream_t)stream, src, idx, dst, frame_floats);
   return vs_launch_status();
 }

@@ -325,6 +325,83 @@ __global__ __launch_bounds__(256) void pool_linear_kernel(const float* __restric
   }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// BatchNorm2d with BATCH statistics (the U-Net's ResnetBlocks under model.train(): unet.py:26,30 -> nn.BatchNorm2d).
+// Two deterministic stages over an NHWC tensor [rows][ld]:
+//   bn_partial_kernel : every block sums x and x^2 of BN_ROWS rows per channel (fp64 accumulators, fixed order)
+//   bn_finish_kernel  : mean / biased variance -> scale = gamma/sqrt(var+eps), shift = beta - mean*scale, and the
+//                       running-statistics update of nn.BatchNorm2d (momentum m, UNBIASED variance) in place.
+constexpr int BN_ROWS = 2048;
+__global__ __launch_bounds__(256) void bn_partial_kernel(const float* __restrict__ x, int64_t rows, int64_t ld,
+                                                         double* __restrict__ partial) {
+  __shared__ double red[2][256][4];
+  const int C4 = (int)(ld >> 2);
+  const int RL = 256 / C4 > 0 ? 256 / C4 : 1;          // row lanes per channel group
+  const int g = threadIdx.x % C4, rl = threadIdx.x / C4;
+  const int64_t r0 = (int64_t)blockIdx.x * BN_ROWS, r1 = r0 + BN_ROWS < rows ? r0 + BN_ROWS : rows;
+  for (int gb = 0; gb < C4; gb += 256) {                // C4 > 256 only for very wide tensors
+    const int gg = gb + g;
+    double s[4] = {0, 0, 0, 0}, q[4] = {0, 0, 0, 0};
+    if (rl < RL && gg < C4)
+      for (int64_t r = r0 + rl; r < r1; r += RL) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(x + r * ld + 4 * gg);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { s[e] += (double)v[e]; q[e] += (double)v[e] * (double)v[e]; }
+      }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { red[0][threadIdx.x][e] = s[e]; red[1][threadIdx.x][e] = q[e]; }
+    __syncthreads();
+    if (rl == 0 && gg < C4) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        double ss = 0, qq = 0;
+        for (int j = 0; j < RL && j * C4 + g < 256; ++j) { ss += red[0][j * C4 + g][e]; qq += red[1][j * C4 + g][e]; }
+        partial[((int64_t)blockIdx.x * 2 + 0) * ld + 4 * gg + e] = ss;
+        partial[((int64_t)blockIdx.x * 2 + 1) * ld + 4 * gg + e] = qq;
+      }
+    }
+    __syncthreads();
+  }
+}
+__global__ __launch_bounds__(256) void bn_finish_kernel(const double* __restrict__ partial, int nchunk, int64_t rows, int C, int64_t ld,
+                                                        const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
+                                                        float momentum, float* __restrict__ running_mean,
+                                                        float* __restrict__ running_var, float* __restrict__ scale,
+                                                        float* __restrict__ shift) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= C) return;
+  double s = 0, q = 0;
+  for (int k = 0; k < nchunk; ++k) { s += partial[((int64_t)k * 2 + 0) * ld + c]; q += partial[((int64_t)k * 2 + 1) * ld + c]; }
+  const double n = (double)rows;
+  const double mean = s / n;
+  double var = q / n - mean * mean;
+  if (var < 0) var = 0;
+  const float sc = gamma[c] * (float)(1.0 / sqrt(var + (double)eps));
+  scale[c] = sc;
+  shift[c] = beta[c] - (float)mean * sc;
+  if (running_mean) running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mean;
+  if (running_var) running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)(n > 1 ? var * n / (n - 1) : var);
+}
+// out[r][c] = act(x[r][c] * scale[c] + shift[c]) (+ add[r][c]);  C % 4 == 0
+__global__ __launch_bounds__(256) void scale_shift_act_kernel(const float* __restrict__ x, int64_t rows, int C, int64_t ld,
+                                                              const float* __restrict__ scale, const float* __restrict__ shift, int act,
+                                                              const float* __restrict__ add, int64_t add_ld, float* __restrict__ out,
+                                                              int64_t out_ld) {
+  const int C4 = C >> 2;
+  const int64_t total = rows * C4;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int64_t r = i / C4;
+    const int c = (int)(i - r * C4) * 4;
+    const f32x4 v = *reinterpret_cast<const f32x4*>(x + r * ld + c);
+    const f32x4 sc = *reinterpret_cast<const f32x4*>(scale + c), sh = *reinterpret_cast<const f32x4*>(shift + c);
+    f32x4 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) o[e] = vs_apply_act(v[e] * sc[e] + sh[e], act);
+    if (add) o += *reinterpret_cast<const f32x4*>(add + r * add_ld + c);
+    *reinterpret_cast<f32x4*>(out + r * out_ld + c) = o;
+  }
+}
+
 inline unsigned grid_for(int64_t total, int per_block = 256, int64_t cap = 256 * 32) {
   int64_t g = cdiv64(total, per_block);
   return (unsigned)(g < 1 ? 1 : (g > cap ? cap : g));
@@ -453,5 +530,28 @@ extern "C" int vs_pool_linear(const float* x, int B, int HW, int C, int64_t ld, 
   const size_t smem = (size_t)C * sizeof(float);
   if (smem > 64 * 1024) return VS_ERR_UNSUPPORTED;
   hipLaunchKernelGGL(pool_linear_kernel, dim3((unsigned)B, 16), dim3(256), smem, (hipStream_t)stream, x, HW, C, ld, w, bias, N, out);
+  return vs_launch_status();
+}
+
+extern "C" int64_t vs_bn_partial_doubles(int64_t rows, int64_t ld) { return cdiv64(rows, BN_ROWS) * 2 * ld; }
+
+extern "C" int vs_bn_batch_stats(const float* x, int64_t rows, int C, int64_t ld, const float* gamma, const float* beta, float eps,
+                                 float momentum, float* running_mean, float* running_var, double* partial, float* scale, float* shift,
+                                 void* stream) {
+  VS_REQUIRE(x && gamma && beta && partial && scale && shift && rows > 0 && C > 0 && ld >= C && (ld & 3) == 0);
+  VS_REQUIRE((((uintptr_t)x) & 15) == 0);
+  const int nchunk = (int)cdiv64(rows, BN_ROWS);
+  hipLaunchKernelGGL(bn_partial_kernel, dim3((unsigned)nchunk), dim3(256), 0, (hipStream_t)stream, x, rows, ld, partial);
+  hipLaunchKernelGGL(bn_finish_kernel, dim3((unsigned)((C + 255) / 256)), dim3(256), 0, (hipStream_t)stream, partial, nchunk, rows, C, ld,
+                     gamma, beta, eps, momentum, running_mean, running_var, scale, shift);
+  return vs_launch_status();
+}
+
+extern "C" int vs_scale_shift_act(const float* x, int64_t rows, int C, int64_t ld, const float* scale, const float* shift, int act,
+                                  const float* add, int64_t add_ld, float* out, int64_t out_ld, void* stream) {
+  VS_REQUIRE(x && scale && shift && out && rows > 0 && C > 0 && (C & 3) == 0 && ld >= C && out_ld >= C && (ld & 3) == 0 && (out_ld & 3) == 0);
+  VS_REQUIRE(!add || (add_ld >= C && (add_ld & 3) == 0));
+  hipLaunchKernelGGL(scale_shift_act_kernel, dim3(grid_for(rows * (C >> 2), 256, 1 << 16)), dim3(256), 0, (hipStream_t)stream, x, rows, C,
+                     ld, scale, shift, act, add, add_ld, out, out_ld);
   return vs_launch_status();
 }

@@ -489,9 +489,14 @@ __global__ __launch_bounds__(256) void embed_tail_kernel(TailArgs a, JndTaps k) 
           for (int c = 0; c < a.Cd; ++c) d[c] += wy * r[c];
         }
       }
+      // attenuate == 2: the training forward's order of operations (wam.py:103-113): blend first, then
+      // imgs + hmaps * (imgs_w - imgs) (jnd.py:110-114); preds_w stays the un-attenuated resized delta
+      const bool fwd_order = full_jnd && a.attenuate == 2;
+      float hm = 1.f;
       if (full_jnd) {
-        const float hm = jnd_at(L, TLW, lx + HALO, ly + HALO, k);
-        for (int c = 0; c < a.Cd; ++c) d[c] = hm * d[c];
+        hm = jnd_at(L, TLW, lx + HALO, ly + HALO, k);
+        if (!fwd_order)
+          for (int c = 0; c < a.Cd; ++c) d[c] = hm * d[c];
       }
       const int64_t pix = (int64_t)y * a.W + x;
       if (a.preds_w)
@@ -499,6 +504,7 @@ __global__ __launch_bounds__(256) void embed_tail_kernel(TailArgs a, JndTaps k) 
 #pragma unroll
       for (int c = 0; c < 3; ++c) {
         float v = a.scaling_i * px[q][c] + a.scaling_w * d[a.Cd == 1 ? 0 : c];
+        if (fwd_order) v = px[q][c] + hm * (v - px[q][c]);
         if (a.clamp) v = fminf(fmaxf(v, 0.f), 1.f);
         Px<T>::st(outf, plane, c, pix, v);
       }

@@ -45,9 +45,11 @@ def gather_frame_logits(local: torch.Tensor, n_frames: int, align: int = 16, gro
     k = local.shape[1]
     pad = torch.zeros(biggest, k, device=local.device, dtype=local.dtype)
     pad[: b - a] = local
-    out = [torch.empty_like(pad) for _ in range(world)]
-    dist.all_gather(out, pad, group=group)
-    return torch.cat([out[r][: e - s] for r, (s, e) in enumerate(shards)], dim=0)
+    out = torch.empty(world * biggest, k, device=local.device, dtype=local.dtype)
+    dist.all_gather_into_tensor(out, pad, group=group)        # ONE fixed-size collective (RCCL ring over xGMI: 128 KiB per rank)
+    if all(e - s == biggest for s, e in shards):
+        return out
+    return torch.cat([out[r * biggest: r * biggest + e - s] for r, (s, e) in enumerate(shards)], dim=0)
 
 
 def extract_message_sharded(model, local_frames: torch.Tensor, n_frames: int, aggregation: str = "avg", align: int = 16,
@@ -63,7 +65,20 @@ def extract_message_sharded(model, local_frames: torch.Tensor, n_frames: int, ag
     return (aggregate_bits(full[:, 1:], aggregation) > 0).squeeze().unsqueeze(0)
 
 
-def embed_sharded(model, local_frames: torch.Tensor, msgs: torch.Tensor, **kw) -> torch.Tensor:
-    """Embedding of the local shard; shard starts are multiples of step_size so key frames match the
-    single-process run.  No collective: outputs stay sharded (or are written to disjoint file ranges)."""
+def check_alignment(model, align: int = 16) -> None:
+    """Shard boundaries must not move key frames: every shard has to start on a key frame of the single-process run
+    (align % step_size == 0), and in video_mode='interpolate' additionally on a chunk boundary, because the last key frame
+    of a chunk is held instead of interpolated (videoseal.py:101-117) -- chunk_size*step_size frames per chunk."""
+    step, chunk = int(model.step_size), int(model.chunk_size)
+    if align % step != 0:
+        raise ValueError(f"shard alignment {align} is not a multiple of step_size {step}: key frames would move")
+    if getattr(model, "video_mode", "repeat") == "interpolate" and align % (step * chunk) != 0:
+        raise ValueError(f"video_mode='interpolate' needs shards aligned to chunk_size*step_size = {step * chunk} frames (got {align})")
+
+
+def embed_sharded(model, local_frames: torch.Tensor, msgs: torch.Tensor, align: int = 16, **kw) -> torch.Tensor:
+    """Embedding of the local shard of a clip split with shard_range(..., align).  The result equals the corresponding slice of
+    the single-process run (check_alignment enforces the conditions).  No collective: outputs stay sharded (or are written to
+    disjoint file ranges)."""
+    check_alignment(model, align)
     return model.embed(local_frames, msgs, is_video=True, **kw)["imgs_w"]

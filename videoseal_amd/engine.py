@@ -162,44 +162,77 @@ class HipEngine:
             if path and os.path.exists(path):
                 with open(path) as f:
                     self._tile_cache.update({tuple(json.loads(k)): v for k, v in json.load(f).items()})
-        g = lambda k: sd[k].detach().to(device)   # noqa: E731
-        self._g = g
+        # `sd` is the reference-format state_dict, or a callable returning the owner's live state_dict (model.py): tensors are
+        # fetched when a weight group is (re)packed, so `invalidate()` after an optimiser step / load_state_dict re-reads them
+        self._sd_src = sd if callable(sd) else (lambda: sd)
+        self._sd_now = None
+        self._g = self._fetch
         self.E = None          # packed embedder / extractor weights, built on first use (ChunkySeal: 1.0 G + 0.77 G parameters)
+        self.Et = None         # embedder weights with BatchNorm NOT folded (batch-statistics forward under model.train())
         self.X = None
+        self.ymat = self.taps43 = None
+        self._pack_misc()
+
+    def _fetch(self, k: str) -> torch.Tensor:
+        if self._sd_now is None:
+            self._sd_now = self._sd_src()
+        return self._sd_now[k].detach().to(self.dev)
+
+    def _pack_misc(self):
+        g = self._g
         m = g("rgb2yuv.M").float().cpu()
         self.ymat = (C.c_float * 3)(*[float(v) for v in m[0]])
-        taps = torch.cat([g("attenuation.conv_lum.weight")[0, 0].reshape(-1), g("attenuation.conv_x.weight")[0, 0].reshape(-1),
-                          g("attenuation.conv_y.weight")[0, 0].reshape(-1)]).float().cpu()
-        self.taps43 = (C.c_float * 43)(*[float(v) for v in taps])
+        if "attenuation.conv_lum.weight" in self._sd_now:
+            taps = torch.cat([g("attenuation.conv_lum.weight")[0, 0].reshape(-1), g("attenuation.conv_x.weight")[0, 0].reshape(-1),
+                              g("attenuation.conv_y.weight")[0, 0].reshape(-1)]).float().cpu()
+            self.taps43 = (C.c_float * 43)(*[float(v) for v in taps])
+        self._sd_now = None
+
+    def invalidate(self, *groups: str):
+        """drop packed weights: 'E' (folded embedder), 'Et' (train-mode embedder), 'X' (extractor), 'misc' (Y row, JND taps)"""
+        self._sd_now = None
+        for gname in (groups or ("E", "Et", "X", "misc")):
+            if gname == "misc":
+                self._pack_misc()
+            else:
+                setattr(self, gname, None)
 
     # ------------------------------------------------------------------ packing
     def _bn_fold(self, g, p):
         s = g(p + ".weight").float() / torch.sqrt(g(p + ".running_var").float() + 1e-5)
         return s, g(p + ".bias").float() - g(p + ".running_mean").float() * s
 
-    def _pack_resblock(self, g, p, cin):
+    def _pack_resblock(self, g, p, cin, train=False):
         w0 = g(p + ".double_conv.0.weight")
         cout = w0.shape[0]
+        wr, cpr = pack_conv(g(p + ".res_conv.weight"), rup(cin, 4))
+        res = ConvW(wr, g(p + ".res_conv.bias").float().contiguous(), cout, 1, 1, cpr)
+        if train:      # batch-statistics BatchNorm: raw convolutions + the live BN tensors (running stats are updated in place)
+            wt0, cp0 = pack_conv(w0, rup(cin, 4))
+            wt1, cp1 = pack_conv(g(p + ".double_conv.3.weight"), rup(cout, 4))
+            bn = [dict(w=g(f"{p}.double_conv.{i}.weight").float().contiguous(), b=g(f"{p}.double_conv.{i}.bias").float().contiguous(),
+                       rm=g(f"{p}.double_conv.{i}.running_mean"), rv=g(f"{p}.double_conv.{i}.running_var"),
+                       nbt=g(f"{p}.double_conv.{i}.num_batches_tracked")) for i in (1, 4)]
+            return dict(c0=ConvW(wt0, None, cout, 3, 3, cp0), c1=ConvW(wt1, None, cout, 3, 3, cp1), res=res, cout=cout, bn=bn)
         s0, b0 = self._bn_fold(g, p + ".double_conv.1")
         s1, b1 = self._bn_fold(g, p + ".double_conv.4")
         wt0, cp0 = pack_conv(w0, rup(cin, 4), s0)
         wt1, cp1 = pack_conv(g(p + ".double_conv.3.weight"), rup(cout, 4), s1)
-        wr, cpr = pack_conv(g(p + ".res_conv.weight"), rup(cin, 4))
         return dict(c0=ConvW(wt0, b0.contiguous(), cout, 3, 3, cp0), c1=ConvW(wt1, b1.contiguous(), cout, 3, 3, cp1),
-                    res=ConvW(wr, g(p + ".res_conv.bias").float().contiguous(), cout, 1, 1, cpr), cout=cout)
+                    res=res, cout=cout)
 
-    def _pack_embedder(self, g):
+    def _pack_embedder(self, g, train=False):
         c = self.cfg
         u = "embedder.unet"
         zc = c.zc
         E = {}
-        E["inc"] = self._pack_resblock(g, u + ".inc", c.in_ch)
+        E["inc"] = self._pack_resblock(g, u + ".inc", c.in_ch, train)
         E["downs"] = []
         for i in range(len(zc) - 1):
             wd, cp = pack_conv(g(f"{u}.downs.{i}.down.weight"), rup(zc[i], 4))
             E["downs"].append(dict(down=ConvW(wd, g(f"{u}.downs.{i}.down.bias").float().contiguous(), zc[i + 1], 3, 3, cp),
-                                   rb=self._pack_resblock(g, f"{u}.downs.{i}.conv", zc[i + 1])))
-        E["bott"] = [self._pack_resblock(g, f"{u}.bottleneck.model.{j}", c.bott) for j in range(c.num_blocks)]
+                                   rb=self._pack_resblock(g, f"{u}.downs.{i}.conv", zc[i + 1], train)))
+        E["bott"] = [self._pack_resblock(g, f"{u}.bottleneck.model.{j}", c.bott, train) for j in range(c.num_blocks)]
         zz = zc[:-1] + [c.bott]
         E["ups"] = []
         for k, i in enumerate(reversed(range(len(zz) - 1))):
@@ -207,14 +240,18 @@ class HipEngine:
             wu, cp = pack_conv(g(f"{u}.ups.{k}.up.upsample_block.2.weight"), rup(cin, 4))
             E["ups"].append(dict(conv=ConvW(wu, None, cout, 3, 3, cp), lnw=g(f"{u}.ups.{k}.up.upsample_block.3.weight").float().contiguous(),
                                  lnb=g(f"{u}.ups.{k}.up.upsample_block.3.bias").float().contiguous(),
-                                 rb=self._pack_resblock(g, f"{u}.ups.{k}.conv", cout)))
+                                 rb=self._pack_resblock(g, f"{u}.ups.{k}.conv", cout, train)))
         E["outc_w"] = g(u + ".outc.weight").float().reshape(c.out_ch, zc[0]).contiguous()
         E["outc_b"] = g(u + ".outc.bias").float().contiguous()
         E["table"] = g(u + ".msg_processor.msg_embeddings.weight").float().contiguous()
         for ch in zc + [c.bott]:
             if ch % 4:
                 raise N.NativeError(f"U-Net channel count {ch} is not a multiple of 4 (unsupported by the HIP path)")
-        self.E = E
+        if train:
+            self.Et = E
+        else:
+            self.E = E
+        self._sd_now = None
 
     @staticmethod
     def _xld(C_: int) -> int:
@@ -260,6 +297,7 @@ class HipEngine:
         X["lin_w"] = g(pd + ".linear.weight").float().contiguous()
         X["lin_b"] = g(pd + ".linear.bias").float().contiguous()
         self.X = X
+        self._sd_now = None
 
     # ------------------------------------------------------------------ workspace
     def buf(self, tag: str, numel: int, zero: bool = False) -> torch.Tensor:
@@ -455,8 +493,40 @@ class HipEngine:
                                           N.stream()), "vs_layernorm_act")
         return out
 
+    def _bn_batch(self, raw: Act, bn: dict, act: int, out: Act, add: Optional[Act] = None):
+        """nn.BatchNorm2d training branch on an NHWC tensor + activation (+ the res_conv branch): batch statistics, running
+        statistics updated in place (momentum 0.1, unbiased variance), num_batches_tracked += 1."""
+        L, st = self.lib, N.stream()
+        part = self.buf("bn.part", 2 * int(L.vs_bn_partial_doubles(raw.rows, raw.ld)))       # doubles = 2 floats each
+        ss = self.buf("bn.ss", 2 * raw.ld)
+        scale, shift = ss[: raw.ld], ss[raw.ld:]
+        N.check(L.vs_bn_batch_stats(N.ptr(raw.t), raw.rows, raw.C, raw.ld, N.ptr(bn["w"]), N.ptr(bn["b"]), 1e-5, 0.1, N.ptr(bn["rm"]),
+                                    N.ptr(bn["rv"]), N.ptr(part), N.ptr(scale), N.ptr(shift), st), "vs_bn_batch_stats")
+        bn["nbt"].add_(1)
+        N.check(L.vs_scale_shift_act(N.ptr(raw.t), raw.rows, raw.C, raw.ld, N.ptr(scale), N.ptr(shift), act,
+                                     N.ptr(add.t) if add is not None else None, add.ld if add is not None else 0, N.ptr(out.t), out.ld, st),
+                "vs_scale_shift_act")
+        return out
+
+    def resblock_train(self, x: Act, p, tag: str, out: Optional[Act] = None) -> Act:
+        """unet.py:17-39 under model.train(): conv -> BN(batch stats) -> ReLU twice, + res_conv(x)."""
+        cout = p["cout"]
+        raw = self.new_act(tag + ".raw", x.B, x.H, x.W, cout)
+        t = self.new_act(tag + ".t", x.B, x.H, x.W, cout)
+        self.conv(x, p["c0"], raw, pad=1)
+        self._bn_batch(raw, p["bn"][0], N.ACT_RELU, t)
+        self.conv(t, p["c1"], raw, pad=1)
+        rs = self.new_act(tag + ".res", x.B, x.H, x.W, cout)
+        self.conv(x, p["res"], rs)
+        if out is None:
+            out = self.new_act(tag + ".o", x.B, x.H, x.W, cout)
+        return self._bn_batch(raw, p["bn"][1], N.ACT_RELU, out, add=rs)
+
     def resblock(self, x: Act, p, tag: str, out: Optional[Act] = None, out_coff=0) -> Act:
         """unet.py:38-39  relu(bn(conv(relu(bn(conv(x)))))) + res_conv(x); the 1x1 rides in the 2nd conv's K loop."""
+        if "bn" in p:
+            assert out_coff == 0
+            return self.resblock_train(x, p, tag, out)
         cout = p["cout"]
         t = self.new_act(tag + ".t", x.B, x.H, x.W, cout)
         self.conv(x, p["c0"], t, pad=1, act=N.ACT_RELU, prof=("bott.conv3x3" if tag.startswith("bott") else None))
@@ -467,11 +537,15 @@ class HipEngine:
         return out
 
     # ------------------------------------------------------------------ embedder
-    def embedder_forward(self, x: Act, msgs_i32: torch.Tensor) -> torch.Tensor:
-        """x: key frames, NHWC(ld 4), already mapped to [-1,1]. Returns delta [B][out_ch][S_h][S_w] (planar)."""
-        if self.E is None:
+    def embedder_forward(self, x: Act, msgs_i32: torch.Tensor, bn_train: bool = False) -> torch.Tensor:
+        """x: key frames, NHWC(ld 4), already mapped to [-1,1]. Returns delta [B][out_ch][S_h][S_w] (planar).
+        bn_train: BatchNorm on batch statistics (module in .train() mode), running statistics updated in place."""
+        if bn_train:
+            if self.Et is None:
+                self._pack_embedder(self._g, train=True)
+        elif self.E is None:
             self._pack_embedder(self._g)
-        c, E, L = self.cfg, self.E, self.lib
+        c, E, L = self.cfg, (self.Et if bn_train else self.E), self.lib
         B = x.B
         st = N.stream()
         hid: List[Act] = [self.resblock(x, E["inc"], "inc")]

@@ -6,8 +6,9 @@ models/wam.py:18-234) for the inference path ``embed / detect / extract_message`
 ``forward``; all arithmetic runs in hand-written gfx950 kernels (engine.py -> native.py -> csrc/).
 
 Deliberate differences, each loud rather than silent:
-  * no CPU / ATen execution path: the model must live on a ROCm device (``.to('cuda')``) and in ``.eval()``
-    mode (batch-statistics BatchNorm and autograd are the training row, SURVEY.md 8(f)1);
+  * no CPU / ATen execution path: the model must live on a ROCm device (``.to('cuda')``);
+  * forward values only: under ``model.train()`` the U-Net's BatchNorm runs on batch statistics and updates its running
+    statistics exactly like nn.BatchNorm2d, but there is no autograd graph (backward kernels are SURVEY.md 8(f)1);
   * frames handed over on the CPU are copied to the model's device, processed there end to end and the
     results are copied back to ``imgs.device`` (the reference keeps the full-resolution shell on the CPU).
 """
@@ -68,17 +69,18 @@ class Embedder(nn.Module):
     def forward(self, imgs: torch.Tensor, msgs: torch.Tensor) -> torch.Tensor:
         root = self._root[0]
         eng = root._engine()
-        x = N.f32c(imgs.to(eng.dev))
-        B, Cc, H, W = x.shape
-        if Cc != self.cfg.in_ch:
-            raise ValueError(f"embedder expects {self.cfg.in_ch} input channel(s), got {Cc}")
-        ident = (1.0, 0.0, 0.0)
-        import ctypes as C
-        key = eng.new_act("emb.in", B, H, W, Cc, 4)
-        ymat = (C.c_float * 3)(*ident) if Cc == 1 else None
-        N.check(eng.lib.vs_resize_pre(N.ptr(x), B, Cc, H, W, H, W, 0, None, 1.0, 0.0, N.ptr(key.t), 1, ymat, N.stream()), "vs_resize_pre")
-        delta = eng.embedder_forward(key, _msgs_i32(msgs, eng.dev))
-        return delta.clone().to(imgs.device)
+        with torch.cuda.device(eng.dev):
+            x = N.f32c(imgs.to(eng.dev))
+            B, Cc, H, W = x.shape
+            if Cc != self.cfg.in_ch:
+                raise ValueError(f"embedder expects {self.cfg.in_ch} input channel(s), got {Cc}")
+            ident = (1.0, 0.0, 0.0)
+            import ctypes as C
+            key = eng.new_act("emb.in", B, H, W, Cc, 4)
+            ymat = (C.c_float * 3)(*ident) if Cc == 1 else None
+            N.check(eng.lib.vs_resize_pre(N.ptr(x), B, Cc, H, W, H, W, 0, None, 1.0, 0.0, N.ptr(key.t), 1, ymat, N.stream()), "vs_resize_pre")
+            delta = eng.embedder_forward(key, _msgs_i32(msgs, eng.dev), bn_train=self.training)
+            return delta.clone().to(imgs.device)
 
 
 class Extractor(nn.Module):
@@ -95,9 +97,10 @@ class Extractor(nn.Module):
     def forward(self, imgs: torch.Tensor) -> torch.Tensor:
         root = self._root[0]
         eng = root._engine()
-        x = N.f32c(imgs.to(eng.dev))
-        rgb, _ = eng.resize_pre(x, (x.shape[-2], x.shape[-1]), False, want_rgb=True, mul=2.0, add=-1.0, tag="det.in")
-        return eng.extractor_forward(rgb).clone().to(imgs.device)
+        with torch.cuda.device(eng.dev):
+            x = N.f32c(imgs.to(eng.dev))
+            rgb, _ = eng.resize_pre(x, (x.shape[-2], x.shape[-1]), False, want_rgb=True, mul=2.0, add=-1.0, tag="det.in")
+            return eng.extractor_forward(rgb).clone().to(imgs.device)
 
 
 class Blender(nn.Module):
@@ -145,14 +148,16 @@ class JND(nn.Module):
         if clc != 0.3:
             raise NotImplementedError("clc != 0.3")
         eng = self._root[0]._engine()
-        return eng.jnd_full(N.f32c(imgs.to(eng.dev))).to(imgs.device)
+        with torch.cuda.device(eng.dev):
+            return eng.jnd_full(N.f32c(imgs.to(eng.dev))).to(imgs.device)
 
 
-class IdentityAugmenter(nn.Module):
-    """augmentation/augmenter.py get_dummy_augmenter(): returns the watermarked frames unchanged."""
-
-    def forward(self, imgs_w, imgs, masks, is_video=True, do_resize=True):
-        return imgs_w, masks, "identity"
+def get_dummy_augmenter() -> nn.Module:
+    """augmentation/augmenter.py:48-57 ``get_dummy_augmenter()``: an Augmenter whose only op is Identity.  The reference builds it
+    with masks={'kind': None}, i.e. its OpenCV-drawn MixedMaskEmbedder; here the mask embedder is the full mask of the training
+    config (configs/all_augs.yaml:2-3 `kind: none`) -- assign ``augmenter.mask_embedder`` to plug any other callable."""
+    from .augmentation import Augmenter
+    return Augmenter(augs={"identity": 1}, augs_params={}, masks={"kind": "none"})
 
 
 def _msgs_i32(msgs: torch.Tensor, dev) -> torch.Tensor:
@@ -176,7 +181,9 @@ class Wam(nn.Module):
         self.attenuation = attenuation
         self.clamp = clamp
         self._eng: Optional[HipEngine] = None
-        self._eng_key = None
+        self._wkeys: Dict[str, tuple] = {}
+        self._wgroups: Optional[Dict[str, list]] = None
+        self._msg_cache: Optional[tuple] = None
         # hipGraph replay of the per-chunk launch sequences (fixed chunk shapes, e.g. streaming callers): the ~300 kernel
         # launches of an embed / detect chunk are captured once per (shape, flags) and replayed with one launch
         self.use_graphs = os.environ.get("VIDEOSEAL_GRAPHS", "0") == "1"
@@ -186,6 +193,13 @@ class Wam(nn.Module):
         if attenuation is not None:
             attenuation._root = holder
 
+    def __setattr__(self, name, value):
+        if name == "attenuation" and isinstance(value, JND):       # evals swap the attenuation module (evals/full.py:317-336)
+            value._root = [self]
+        if name in ("attenuation", "embedder", "detector", "rgb2yuv") and "_wgroups" in self.__dict__:
+            self.__dict__["_wgroups"] = None
+        super().__setattr__(name, value)
+
     # ---- plumbing
     @property
     def device(self):
@@ -194,26 +208,65 @@ class Wam(nn.Module):
     def get_random_msg(self, bsz: int = 1, nb_repetitions=1) -> torch.Tensor:
         return self.embedder.get_random_msg(bsz, nb_repetitions)
 
+    def _apply(self, fn, *a, **k):                 # .to() / .cuda() / .float(): tensors are replaced -> regroup
+        self._wgroups = None
+        return super()._apply(fn, *a, **k)
+
+    def load_state_dict(self, *a, **k):
+        self._wgroups = None
+        return super().load_state_dict(*a, **k)
+
+    def _weight_groups(self) -> Dict[str, list]:
+        """the tensors each packed weight group is built from (cached: walking the module tree costs 0.6 ms per call)"""
+        if self._wgroups is None:
+            emb_p = list(self.embedder.parameters())
+            emb_b = list(self.embedder.buffers())
+            det = list(self.detector.parameters()) + list(self.detector.buffers())
+            misc = list(self.rgb2yuv.buffers()) + (list(self.attenuation.parameters()) if self.attenuation is not None else [])
+            self._wgroups = {"Et": emb_p, "E": emb_p + emb_b, "X": det, "misc": misc}
+        return self._wgroups
+
     def _engine(self) -> HipEngine:
         dev = self.device
         if dev.type != "cuda":
             raise N.NativeError("Videoseal (MI355X build) has no CPU execution path: move the model to a ROCm device "
                                 "with .to('cuda') before embed()/detect().")
-        if self.training:
-            raise NotImplementedError("the HIP path implements inference (folded BatchNorm): call model.eval() first; "
-                                      "batch-statistics BatchNorm / backward are not implemented yet")
-        key = (str(dev), sum(p._version for p in self.parameters()) + sum(b._version for b in self.buffers()),
-               tuple(id(p) for p in list(self.parameters())[:4]))
-        if self._eng is None or self._eng_key != key:
-            self._eng = HipEngine(self.embedder.cfg, self.state_dict(), dev)
-            self._eng_key = key
+        if self._eng is None or self._eng.dev != dev:
+            self._eng = HipEngine(self.embedder.cfg, self.state_dict, dev)
+            self._wkeys = {}
+            self._graphs.clear()
+        # packed weights go stale when any source tensor is replaced (data_ptr) or written in place (_version): every tensor of
+        # the group is part of the key
+        stale = []
+        for name, ts in self._weight_groups().items():
+            key = tuple((t.data_ptr(), t._version) for t in ts)
+            if self._wkeys.get(name) != key:
+                if name in self._wkeys:
+                    stale.append(name)
+                self._wkeys[name] = key
+        if stale:
+            self._eng.invalidate(*stale)
             self._graphs.clear()
         return self._eng
 
     def repack(self) -> None:
-        """Force re-packing of the weights (after in-place edits that bypass tensor versioning)."""
-        self._eng = None
+        """Force re-packing of the weights (after edits that bypass tensor versioning, e.g. writes through raw pointers)."""
+        self._wgroups = None
+        if self._eng is not None:
+            self._eng.invalidate()
         self._graphs.clear()
+
+    def _msgs_dev(self, msgs: torch.Tensor, dev) -> torch.Tensor:
+        """int32 device copy of the message; a CPU message that has not changed since the last call is not copied again
+        (streaming callers pass the same [1, k] tensor for every chunk: one pageable H2D sync per call otherwise)."""
+        if msgs.device == dev:
+            return _msgs_i32(msgs, dev)
+        c = self._msg_cache
+        if c is not None and c[0] is msgs and c[1] == msgs._version and c[2].device == dev:
+            return c[2]
+        mi = _msgs_i32(msgs, dev)
+        self._msg_cache = (msgs, msgs._version, mi)
+        return mi
 
     def _graphed(self, key: tuple, ins: Dict[str, torch.Tensor], run):
         """Replay `run(static_inputs) -> dict of output tensors` from a hipGraph captured once per key.
@@ -245,10 +298,12 @@ class Wam(nn.Module):
 
     # ---- core of embed: one chunk of frames on the device
     def _embed_frames(self, eng: HipEngine, fr: torch.Tensor, msgs_i32: torch.Tensor, out: torch.Tensor, *, step: int,
-                      video_mode: int, antialias: bool, lowres: bool, preds_w: Optional[torch.Tensor] = None) -> None:
-        if self.use_graphs and not torch.cuda.is_current_stream_capturing():
+                      video_mode: int, antialias: bool, lowres: bool, preds_w: Optional[torch.Tensor] = None,
+                      fwd_order: bool = False) -> None:
+        bn_train = self.embedder.training
+        if self.use_graphs and not bn_train and not torch.cuda.is_current_stream_capturing():
             key = ("emb", fr.dtype, tuple(fr.shape), tuple(msgs_i32.shape), step, video_mode, antialias, lowres, preds_w is not None, self.img_size,
-                   self.clamp, float(self.blender.scaling_i), float(self.blender.scaling_w), self.attenuation is not None, id(eng))
+                   self.clamp, float(self.blender.scaling_i), float(self.blender.scaling_w), self.attenuation is not None, fwd_order, id(eng))
             ent = self._graphs.get(key)
             if ent is None:
                 sin = {"fr": fr.clone(), "msgs": msgs_i32.clone()}
@@ -256,12 +311,12 @@ class Wam(nn.Module):
                 spw = torch.empty_like(preds_w) if preds_w is not None else None
                 for _ in range(2):
                     self._embed_frames_eager(eng, sin["fr"], sin["msgs"], sout, step=step, video_mode=video_mode, antialias=antialias,
-                                             lowres=lowres, preds_w=spw)
+                                             lowres=lowres, preds_w=spw, fwd_order=fwd_order)
                 torch.cuda.synchronize()
                 g = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(g):
                     self._embed_frames_eager(eng, sin["fr"], sin["msgs"], sout, step=step, video_mode=video_mode, antialias=antialias,
-                                             lowres=lowres, preds_w=spw)
+                                             lowres=lowres, preds_w=spw, fwd_order=fwd_order)
                 ent = {"g": g, "in": sin, "out": sout, "pw": spw}
                 self._graphs[key] = ent
             ent["in"]["fr"].copy_(fr)
@@ -272,17 +327,43 @@ class Wam(nn.Module):
                 preds_w.copy_(ent["pw"])
             return
         self._embed_frames_eager(eng, fr, msgs_i32, out, step=step, video_mode=video_mode, antialias=antialias, lowres=lowres,
-                                 preds_w=preds_w)
+                                 preds_w=preds_w, fwd_order=fwd_order)
 
     def _embed_frames_eager(self, eng: HipEngine, fr: torch.Tensor, msgs_i32: torch.Tensor, out: torch.Tensor, *, step: int,
-                            video_mode: int, antialias: bool, lowres: bool, preds_w: Optional[torch.Tensor] = None) -> None:
+                            video_mode: int, antialias: bool, lowres: bool, preds_w: Optional[torch.Tensor] = None,
+                            fwd_order: bool = False) -> None:
         S = (self.img_size, self.img_size)
         att = self.attenuation is not None
         rgb, key = eng.resize_pre(fr, S, antialias, want_rgb=(att and lowres), want_key=True, key_step=step)
-        delta = eng.embedder_forward(key, msgs_i32)
+        delta = eng.embedder_forward(key, msgs_i32, bn_train=self.embedder.training)
         hmap = eng.jnd_lowres(rgb) if (att and lowres) else None
-        eng.embed_tail(fr, out, delta, step=step, video_mode=video_mode, hmap_low=hmap, attenuate=att, clamp=self.clamp,
+        eng.embed_tail(fr, out, delta, step=step, video_mode=video_mode, hmap_low=hmap,
+                       attenuate=(2 if (att and fwd_order and not lowres) else int(att)), clamp=self.clamp,
                        antialias=antialias, scaling_i=self.blender.scaling_i, scaling_w=self.blender.scaling_w, preds_w=preds_w)
+
+    def _run_chunks(self, eng: HipEngine, imgs: torch.Tensor, span: int, fn, *, want_out: bool = True, extra=None):
+        """Drive `fn(chunk_on_device, out_chunk_on_device, a, b)` over [a, b) frame ranges of `span` frames.  Frames that are not
+        on the model's device move one chunk at a time (videoseal.py:286-297 keeps the full clip where the caller put it);
+        the result comes back on imgs.device."""
+        on_dev = imgs.device == eng.dev
+        if on_dev:
+            src = imgs if imgs.dtype == torch.uint8 else N.f32c(imgs)
+            out = torch.empty_like(src) if want_out else None
+        else:
+            src = imgs
+            out = torch.empty(imgs.shape, dtype=(imgs.dtype if imgs.dtype == torch.uint8 else torch.float32), device=imgs.device) if want_out else None
+        for a in range(0, imgs.shape[0], span):
+            b = min(imgs.shape[0], a + span)
+            if on_dev:
+                fn(src[a:b], out[a:b] if want_out else None, a, b)
+            else:
+                ch = src[a:b].to(eng.dev)
+                ch = ch.contiguous() if ch.dtype == torch.uint8 else N.f32c(ch)
+                oc = torch.empty_like(ch) if want_out else None
+                fn(ch, oc, a, b)
+                if want_out:
+                    out[a:b].copy_(oc)
+        return out
 
     @torch.no_grad()
     def embed(self, imgs: torch.Tensor, msgs: torch.Tensor = None, interpolation: dict = None,
@@ -292,45 +373,68 @@ class Wam(nn.Module):
             msgs = self.get_random_msg(imgs.shape[0])
         eng = self._engine()
         aa = _antialias_flag(interpolation)
-        x = N.f32c(imgs.to(eng.dev))
-        B = x.shape[0]
+        B = imgs.shape[0]
+        cd = self.embedder.cfg.out_ch
         if B == 0:
-            return {"msgs": msgs, "preds_w": imgs.new_zeros((0, self.embedder.cfg.out_ch) + tuple(imgs.shape[-2:])), "imgs_w": imgs.clone()}
+            return {"msgs": msgs, "preds_w": imgs.new_zeros((0, cd) + tuple(imgs.shape[-2:])), "imgs_w": imgs.clone()}
         if msgs.shape[0] != B:
             raise ValueError(f"msgs has {msgs.shape[0]} rows for {B} images")
-        out = torch.empty_like(x)
-        cd = self.embedder.cfg.out_ch
-        preds_w = torch.empty(B, cd, x.shape[-2], x.shape[-1], device=eng.dev, dtype=torch.float32)
-        mi = _msgs_i32(msgs, eng.dev)
-        ck = max(1, int(getattr(self, "chunk_size", 32)))
-        for a in range(0, B, ck):
-            b = min(B, a + ck)
-            self._embed_frames(eng, x[a:b], mi[a:b], out[a:b], step=1, video_mode=0, antialias=aa, lowres=lowres_attenuation,
-                               preds_w=preds_w[a:b])
-        return {"msgs": msgs, "preds_w": preds_w.to(imgs.device), "imgs_w": out.to(imgs.device)}
+        with torch.cuda.device(eng.dev):
+            mi = self._msgs_dev(msgs, eng.dev)
+            preds_w = torch.empty(B, cd, imgs.shape[-2], imgs.shape[-1], device=imgs.device, dtype=torch.float32)
+            on_dev = imgs.device == eng.dev
+
+            def one(fr, oc, a, b):
+                pw = preds_w[a:b] if on_dev else torch.empty(b - a, cd, fr.shape[-2], fr.shape[-1], device=eng.dev, dtype=torch.float32)
+                self._embed_frames(eng, fr, mi[a:b], oc, step=1, video_mode=0, antialias=aa, lowres=lowres_attenuation, preds_w=pw)
+                if not on_dev:
+                    preds_w[a:b].copy_(pw)
+            out = self._run_chunks(eng, imgs, max(1, int(getattr(self, "chunk_size", 32))), one)
+        return {"msgs": msgs, "preds_w": preds_w, "imgs_w": out}
 
     @torch.no_grad()
     def detect(self, imgs: torch.Tensor, interpolation: dict = None) -> dict:
         """wam.py:206-234."""
         eng = self._engine()
         aa = _antialias_flag(interpolation)
-        x = N.f32c(imgs.to(eng.dev))
-        if x.shape[0] == 0:
+        if imgs.shape[0] == 0:
             return {"preds": imgs.new_zeros((0, self.embedder.cfg.nbits + 1))}
-        return {"preds": self._detect_frames(eng, x, (self.img_size, self.img_size), aa).to(imgs.device)}
+        with torch.cuda.device(eng.dev):
+            x = N.f32c(imgs.to(eng.dev))
+            return {"preds": self._detect_frames(eng, x, (self.img_size, self.img_size), aa).to(imgs.device)}
+
+    def _augment_detect(self, eng: HipEngine, imgs_w: torch.Tensor, imgs: torch.Tensor, masks, is_video: bool, aa: bool):
+        """wam.py:115-125 / videoseal.py:231-243: augment -> resize to the processing size -> detector (device tensors)."""
+        from . import augmentation as A
+        imgs_aug, masks, selected = self.augmenter(imgs_w, imgs, masks.to(eng.dev) if torch.is_tensor(masks) else masks,
+                                                   is_video=is_video, do_resize=False)
+        S = (self.img_size, self.img_size)
+        if tuple(imgs_aug.shape[-2:]) != S:
+            imgs_aug = A.resize(imgs_aug, S, aa)
+        rgb, _ = eng.resize_pre(N.f32c(imgs_aug), S, False, want_rgb=True, mul=2.0, add=-1.0, tag="det.in")
+        return imgs_aug, masks, selected, eng.extractor_forward(rgb).clone()
 
     @torch.no_grad()
     def forward(self, imgs: torch.Tensor, masks: torch.Tensor, msgs: torch.Tensor = None, interpolation: dict = None) -> dict:
-        """wam.py:68-132, forward-only (no autograd): embed (full-res attenuation) -> augment -> detect."""
+        """wam.py:68-132 (forward values only): embed (blend, then full-resolution attenuation(imgs, imgs_w), clamp) -> augmenter ->
+        resize to img_size -> detector.  `preds_w` is the UN-attenuated resized delta and `imgs_aug` the resized augmented batch,
+        like the reference.  BatchNorm follows ``self.embedder.training``."""
         if msgs is None:
             msgs = self.get_random_msg(imgs.shape[0]).to(imgs.device)
-        if self.blender.scaling_i != 1.0 and self.attenuation is not None:
-            raise NotImplementedError("forward() with scaling_i != 1 and JND attenuation")
-        emb = self.embed(imgs, msgs, interpolation, lowres_attenuation=False)
-        imgs_aug, masks, selected = self.augmenter(emb["imgs_w"], imgs, masks, is_video=False, do_resize=False)
-        preds = self.detect(imgs_aug, interpolation)["preds"]
-        return {"msgs": msgs, "masks": masks, "preds_w": emb["preds_w"], "imgs_w": emb["imgs_w"], "imgs_aug": imgs_aug,
-                "preds": preds, "selected_aug": selected}
+        eng = self._engine()
+        aa = _antialias_flag(_DEFAULT_INTERP if interpolation is None else interpolation)
+        back = imgs.device
+        with torch.cuda.device(eng.dev):
+            x = N.f32c(imgs.to(eng.dev))
+            B = x.shape[0]
+            out = torch.empty_like(x)
+            preds_w = torch.empty(B, self.embedder.cfg.out_ch, x.shape[-2], x.shape[-1], device=eng.dev, dtype=torch.float32)
+            self._embed_frames(eng, x, self._msgs_dev(msgs, eng.dev), out, step=1, video_mode=0, antialias=aa, lowres=False,
+                               preds_w=preds_w, fwd_order=True)
+            imgs_aug, masks, selected, preds = self._augment_detect(eng, out, x, masks, False, aa)
+        to = (lambda t: t.to(back) if torch.is_tensor(t) else t)     # noqa: E731
+        return {"msgs": msgs, "masks": to(masks), "preds_w": to(preds_w), "imgs_w": to(out), "imgs_aug": to(imgs_aug),
+                "preds": to(preds), "selected_aug": selected}
 
 
 class Videoseal(Wam):
@@ -344,6 +448,19 @@ class Videoseal(Wam):
         self.video_mode = video_mode
         self.lowres_attenuation = lowres_attenuation
 
+    def _embed_clip(self, imgs: torch.Tensor, msgs: torch.Tensor, interpolation, lowres_attenuation: bool) -> torch.Tensor:
+        if self.video_mode not in N.VIDEO_MODES:
+            raise ValueError(f"unknown video_mode {self.video_mode}")
+        eng = self._engine()
+        aa = _antialias_flag(interpolation)
+        step, ck = int(self.step_size), int(self.chunk_size)
+        with torch.cuda.device(eng.dev):
+            mi = self._msgs_dev(msgs, eng.dev)
+            vm = N.VIDEO_MODES[self.video_mode]
+            return self._run_chunks(eng, imgs, ck * step,       # frames per chunk (videoseal.py:292-297)
+                                    lambda fr, oc, a, b: self._embed_frames(eng, fr, mi, oc, step=step, video_mode=vm, antialias=aa,
+                                                                            lowres=lowres_attenuation))
+
     @torch.no_grad()
     def embed(self, imgs: torch.Tensor, msgs: torch.Tensor = None, is_video: bool = True, interpolation: dict = None,
               lowres_attenuation: bool = False) -> dict:
@@ -354,37 +471,28 @@ class Videoseal(Wam):
             msgs = self.get_random_msg()
         else:
             assert msgs.shape[0] == 1, "Message should be unique"
-        if self.video_mode not in N.VIDEO_MODES:
-            raise ValueError(f"unknown video_mode {self.video_mode}")
+        out = self._embed_clip(imgs, msgs, interpolation, lowres_attenuation)
+        return {"imgs_w": out, "msgs": msgs[0:1].repeat(len(imgs), 1)}
+
+    def _detect_clip(self, imgs: torch.Tensor, interpolation) -> torch.Tensor:
         eng = self._engine()
         aa = _antialias_flag(interpolation)
-        x = N.f32c(imgs.to(eng.dev))
-        out = torch.empty_like(x)
-        mi = _msgs_i32(msgs, eng.dev)
-        step, ck = int(self.step_size), int(self.chunk_size)
-        span = ck * step                      # frames per chunk (videoseal.py:292-297)
-        for a in range(0, x.shape[0], span):
-            b = min(x.shape[0], a + span)
-            self._embed_frames(eng, x[a:b], mi, out[a:b], step=step, video_mode=N.VIDEO_MODES[self.video_mode], antialias=aa,
-                               lowres=lowres_attenuation)
-        return {"imgs_w": out.to(imgs.device), "msgs": msgs[0:1].repeat(len(imgs), 1)}
+        S = (self.img_size, self.img_size)
+        preds = []
+        with torch.cuda.device(eng.dev):
+            self._run_chunks(eng, imgs, max(1, int(self.chunk_size)),
+                             lambda fr, oc, a, b: preds.append(self._detect_frames(eng, fr, S, aa)), want_out=False)
+            return torch.cat(preds, dim=0).to(imgs.device)
 
     @torch.no_grad()
     def detect(self, imgs: torch.Tensor, is_video: bool = True, interpolation: dict = None) -> dict:
         """videoseal.py:352-388."""
         if not is_video:
             return super().detect(imgs) if interpolation is None else super().detect(imgs, interpolation)
-        eng = self._engine()
-        aa = _antialias_flag(interpolation)
-        x = N.f32c(imgs.to(eng.dev))
-        if x.shape[0] == 0:
+        if imgs.shape[0] == 0:
+            self._engine()
             return {"preds": imgs.new_zeros((0, self.embedder.cfg.nbits + 1))}
-        S = (self.img_size, self.img_size)
-        preds = []
-        ck = max(1, int(self.chunk_size))
-        for a in range(0, x.shape[0], ck):
-            preds.append(self._detect_frames(eng, x[a:a + ck], S, aa))
-        return {"preds": torch.cat(preds, dim=0).to(imgs.device)}
+        return {"preds": self._detect_clip(imgs, interpolation)}
 
     # ---- uint8 RGB24 clips, the data format on either side of the path in inference_streaming.py
     @torch.no_grad()
@@ -402,35 +510,18 @@ class Videoseal(Wam):
             msgs = self.get_random_msg()
         else:
             assert msgs.shape[0] == 1, "Message should be unique"
-        if self.video_mode not in N.VIDEO_MODES:
-            raise ValueError(f"unknown video_mode {self.video_mode}")
-        eng = self._engine()
-        aa = _antialias_flag(interpolation)
-        x = clip.to(eng.dev).contiguous()
-        out = torch.empty_like(x)
-        mi = _msgs_i32(msgs, eng.dev)
-        step, ck = int(self.step_size), int(self.chunk_size)
-        span = ck * step
-        for a in range(0, x.shape[0], span):
-            b = min(x.shape[0], a + span)
-            self._embed_frames(eng, x[a:b], mi, out[a:b], step=step, video_mode=N.VIDEO_MODES[self.video_mode], antialias=aa,
-                               lowres=lowres_attenuation)
-        return {"imgs_w": out.to(clip.device), "msgs": msgs[0:1].repeat(len(clip), 1)}
+        out = self._embed_clip(clip.contiguous(), msgs, interpolation, lowres_attenuation)
+        return {"imgs_w": out, "msgs": msgs[0:1].repeat(len(clip), 1)}
 
     @torch.no_grad()
     def detect_u8(self, clip: torch.Tensor, interpolation: dict = None) -> dict:
         """inference_streaming.py:119-125 (`detect_video_clip`): uint8 [F,H,W,3] -> {'preds': [F, 1+nbits]}."""
         if clip.dtype != torch.uint8 or clip.dim() != 4 or clip.shape[-1] != 3:
             raise ValueError("detect_u8 wants a uint8 RGB24 clip [F, H, W, 3]")
-        eng = self._engine()
-        aa = _antialias_flag(interpolation)
-        x = clip.to(eng.dev).contiguous()
-        if x.shape[0] == 0:
+        if clip.shape[0] == 0:
+            self._engine()
             return {"preds": torch.zeros((0, self.embedder.cfg.nbits + 1), device=clip.device)}
-        S = (self.img_size, self.img_size)
-        ck = max(1, int(self.chunk_size))
-        preds = [self._detect_frames(eng, x[a:a + ck], S, aa) for a in range(0, x.shape[0], ck)]
-        return {"preds": torch.cat(preds, dim=0).to(clip.device)}
+        return {"preds": self._detect_clip(clip.contiguous(), interpolation)}
 
     def extract_message(self, imgs: torch.Tensor, aggregation: str = "avg",
                         interpolation: dict = {"mode": "bilinear", "align_corners": False, "antialias": False}) -> torch.Tensor:
@@ -442,7 +533,7 @@ class Videoseal(Wam):
 
     @torch.no_grad()
     def forward(self, imgs: torch.Tensor, masks: torch.Tensor, msgs: torch.Tensor = None, is_video: bool = True):
-        """videoseal.py:120-256, forward-only."""
+        """videoseal.py:120-161 (forward values only)."""
         assert not (is_video and len(imgs.shape) not in [4, 5]), \
             "If is_video is True, input shape should be [b, frames, c, h, w] or [frames, c, h, w]"
         assert not (not is_video and len(imgs.shape) != 4), "If is_video is False, input shape should be [b, c, h, w]"
@@ -455,24 +546,26 @@ class Videoseal(Wam):
 
     @torch.no_grad()
     def video_forward(self, imgs, masks, msgs=None, interpolation: dict = None) -> dict:
-        """videoseal.py:163-256: whole clip in one chunk, key frames every step_size."""
+        """videoseal.py:163-256: the whole clip as one chunk, key frames every step_size, video_mode expansion, attenuation at low
+        resolution (self.lowres_attenuation) or as attenuation(imgs, imgs_w) at full resolution, clamp, augment, resize, detect."""
         if msgs is None:
             msgs = self.get_random_msg()
         else:
             assert msgs.shape[0] == 1, "Message should be unique"
         msgs = msgs.to(imgs.device)
+        if self.video_mode not in N.VIDEO_MODES:
+            raise ValueError(f"unknown video_mode {self.video_mode}")
         eng = self._engine()
-        aa = _antialias_flag(interpolation)
-        x = N.f32c(imgs.to(eng.dev))
-        out = torch.empty_like(x)
-        self._embed_frames(eng, x, _msgs_i32(msgs, eng.dev), out, step=int(self.step_size),
-                           video_mode=N.VIDEO_MODES[self.video_mode], antialias=aa, lowres=bool(self.lowres_attenuation))
-        imgs_w = out.to(imgs.device)
-        imgs_aug, masks, selected = self.augmenter(imgs_w, imgs, masks, is_video=True, do_resize=False)
-        rgb, _ = eng.resize_pre(N.f32c(imgs_aug.to(eng.dev)), (self.img_size, self.img_size), aa, want_rgb=True, mul=2.0, add=-1.0,
-                                tag="det.in")
-        preds = eng.extractor_forward(rgb).clone().to(imgs.device)
-        return {"msgs": msgs.expand(imgs.shape[0], -1), "masks": masks, "imgs_w": imgs_w, "imgs_aug": imgs_aug, "preds": preds,
+        aa = _antialias_flag(_DEFAULT_INTERP if interpolation is None else interpolation)
+        back = imgs.device
+        with torch.cuda.device(eng.dev):
+            x = N.f32c(imgs.to(eng.dev))
+            out = torch.empty_like(x)
+            self._embed_frames(eng, x, self._msgs_dev(msgs, eng.dev), out, step=int(self.step_size),
+                               video_mode=N.VIDEO_MODES[self.video_mode], antialias=aa, lowres=bool(self.lowres_attenuation), fwd_order=True)
+            imgs_aug, masks, selected, preds = self._augment_detect(eng, out, x, masks, True, aa)
+        to = (lambda t: t.to(back) if torch.is_tensor(t) else t)     # noqa: E731
+        return {"msgs": msgs.expand(imgs.shape[0], -1), "masks": to(masks), "imgs_w": to(out), "imgs_aug": to(imgs_aug), "preds": to(preds),
                 "selected_aug": selected}
 
 
@@ -493,7 +586,7 @@ def aggregate_bits(bit_preds: torch.Tensor, aggregation: Optional[str]) -> torch
 
 def build_model(cfg: ModelCfg, seed: int = 0) -> Videoseal:
     """cfg.py:120-144: embedder + extractor + identity augmenter + JND -> Videoseal (train mode, CPU, like the reference)."""
-    return Videoseal(Embedder(cfg, seed), Extractor(cfg, seed), IdentityAugmenter(),
+    return Videoseal(Embedder(cfg, seed), Extractor(cfg, seed), get_dummy_augmenter(),
                      attenuation=JND(in_channels=cfg.jnd_in, out_channels=cfg.jnd_out), scaling_w=cfg.scaling_w,
                      scaling_i=cfg.scaling_i, img_size=cfg.img_size, chunk_size=cfg.chunk_size, step_size=cfg.step_size,
                      blending_method=cfg.blending_method)

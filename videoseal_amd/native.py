@@ -26,6 +26,7 @@ EXPORTS = [
     "vs_upcat2x", "vs_msg_latent", "vs_broadcast_channels", "vs_outc_tanh", "vs_pool_linear", "vs_resize_pre", "vs_resize_pre_u8",
     "vs_jnd_heatmap", "vs_embed_tail", "vs_aug_color_scratch_floats", "vs_aug_color", "vs_aug_crop_flip", "vs_aug_warp", "vs_resize_nchw",
     "vs_gaussian_blur", "vs_median_filter", "vs_jpeg_workspace_bytes", "vs_jpeg_roundtrip",
+    "vs_bn_partial_doubles", "vs_bn_batch_stats", "vs_scale_shift_act", "vs_aug_mask_blend", "vs_aug_add_scaled", "vs_aug_gather_frames",
 ]
 
 
@@ -105,6 +106,11 @@ def lib() -> C.CDLL:
         "vs_gaussian_blur": [P, P, P, I, I, I, I, F, P],
         "vs_median_filter": [P, P, I, I, I, I, P],
         "vs_jpeg_roundtrip": [P, P, I, I, I, I, P, P],
+        "vs_bn_batch_stats": [P, I64, I, I64, P, P, F, F, P, P, P, P, P, P],
+        "vs_scale_shift_act": [P, I64, I, I64, P, P, I, P, I64, P, I64, P],
+        "vs_aug_mask_blend": [P, P, P, P, I, I, I, I, P],
+        "vs_aug_add_scaled": [P, P, F, P, I64, P],
+        "vs_aug_gather_frames": [P, P, P, I, I64, P],
     }
     for name, args in sig.items():
         fn = getattr(L, name)
@@ -114,6 +120,8 @@ def lib() -> C.CDLL:
     L.vs_aug_color_scratch_floats.argtypes = [I, I, I]
     L.vs_jpeg_workspace_bytes.restype = C.c_int64
     L.vs_jpeg_workspace_bytes.argtypes = [I, I, I]
+    L.vs_bn_partial_doubles.restype = C.c_int64
+    L.vs_bn_partial_doubles.argtypes = [I64, I64]
     L.vs_sizeof_conv_desc.restype = C.c_int
     L.vs_sizeof_tail_desc.restype = C.c_int
     if L.vs_sizeof_conv_desc() != C.sizeof(ConvDesc) or L.vs_sizeof_tail_desc() != C.sizeof(TailDesc):
