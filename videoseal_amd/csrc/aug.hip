@@ -111,7 +111,11 @@ __global__ __launch_bounds__(256) void mask_blend_kernel(const float* __restrict
 // valuemetric.py:188-191: image + noise * std (the noise itself is the caller's torch.randn_like draw)
 __global__ __launch_bounds__(256) void add_scaled_kernel(const float* __restrict__ x, const float* __restrict__ nz, float std,
                                                          float* __restrict__ dst, int64_t n) {
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) dst[i] = __fadd_rn(x[i], __fmul_rn(nz[i], std));
+#pragma clang fp contract(off)      // torch rounds the product before the add; HIP's __fmul_rn is a plain '*' that hipcc would contract into an fma
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const float t = nz[i] * std;
+    dst[i] = x[i] + t;
+  }
 }
 
 // video.py:507-526 (DropFrame) / 283-313 (SpeedChange): dst[f] = src[idx[f]], whole frames of `fsz` floats (fsz % 4 == 0 fast path)
