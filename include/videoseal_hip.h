@@ -151,6 +151,20 @@ int vs_scale_shift_act(const float* x, int64_t rows, int C, int64_t ld, const fl
 int vs_upcat2x(const float* x, int C1, int64_t ld1, const float* skip, int C2, int64_t ld2, float skip_scale,
                int B, int H, int W, float* out, int64_t out_ld, void* stream);
 
+/* The Upsample group of the U-Net (common.py:45-52: bilinear x2 -> ReflectionPad2d(1) -> Conv3x3 (no bias) -> LayerNorm(C) -> act) WITHOUT
+ * the up-sampled tensor.  Interpolation, padding and the tap shift are linear over space and commute with the conv's channel mixing:
+ *   conv3x3(pad(up(v)))[Y,X,c] = sum_t up(z_t)[refl(Y+ky-1), refl(X+kx-1), c],   z[b][y][x][t*Co + c] = sum_ci W[c][ci][t] v[b][y][x][ci]
+ * z is one vs_conv_gemm launch on the LOW-resolution map (1x1, N = 9*Co rows ordered (tap, channel): a quarter of the conv's MACs);
+ * vs_upconv_gather_ln does the 9-tap x 4-neighbour gather, the LayerNorm over Co (biased variance, eps) and the activation, and writes
+ * [B][2H][2W][out_ld].  vs_upconv_supported(Co): Co % 16 == 0 and Co / min(16, Co/4) a power of two (every released card).
+ * vs_cat2_scale: out[r] = [x[r][0:C1] | skip[r][0:C2] * skip_scale] -- unet.py:186-187 at the low resolution; x == NULL when the
+ * producer of x already wrote columns [0, C1) of `out`. */
+int vs_upconv_supported(int Co);
+int vs_upconv_gather_ln(const float* z, int64_t z_ld, int B, int H, int W, int Co, const float* lnw, const float* lnb, float eps,
+                        int act, float* out, int64_t out_ld, void* stream);
+int vs_cat2_scale(const float* x, int C1, int64_t ld1, const float* skip, int C2, int64_t ld2, float skip_scale, int64_t rows,
+                  float* out, int64_t out_ld, void* stream);
+
 /* Message latent: lat[b][c] = sum_k table[2k + msg[b][k]][c].  msg_processor.py:88-98.  msgs are int32 0/1. */
 int vs_msg_latent(const float* table, const int32_t* msgs, int Bm, int nbits, int hidden, float* lat, void* stream);
 /* Broadcast lat[b or 0][0:hidden] over H*W pixels into channels [coff, coff+hidden) of dst.  msg_processor.py:96-115. */

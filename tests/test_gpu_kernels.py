@@ -439,6 +439,41 @@ def test_upcat2x(eng):
     assert (from_nhwc(out) - ref).abs().max() < 1e-6
 
 
+@pytest.mark.parametrize("shape", [(2, 24, 8, 7, 9, 16), (1, 64, 64, 8, 16, 32), (2, 40, 24, 5, 6, 64), (1, 32, 32, 3, 3, 128),
+                                   (2, 16, 16, 1, 2, 16)])
+def test_upconv_lowres_gemm_gather_ln(eng, shape):
+    """Upsample group (common.py:45-52) as cat2 -> 1x1 GEMM of the nine taps at the LOW resolution -> gather + LayerNorm + ReLU,
+    against bilinear x2 -> ReflectionPad2d(1) -> Conv3x3 -> LayerNorm(channels_first) -> ReLU in torch fp32."""
+    B, C1, C2, H, W, Co = shape
+    g = torch.Generator().manual_seed(31)
+    x, sk = torch.randn(B, C1, H, W, generator=g), torch.randn(B, C2, H, W, generator=g)
+    w = torch.randn(Co, C1 + C2, 3, 3, generator=g) / math.sqrt(9 * (C1 + C2))
+    lw, lb = torch.rand(Co, generator=g) + 0.5, torch.randn(Co, generator=g)
+    up = F.interpolate(torch.cat((x, sk * 2 ** -0.5), 1), scale_factor=2, mode="bilinear", align_corners=False)
+    cv = F.conv2d(F.pad(up, (1, 1, 1, 1), mode="reflect"), w)
+    u = cv.mean(1, keepdim=True)
+    sdev = (cv - u).pow(2).mean(1, keepdim=True)
+    ref = F.relu(lw[None, :, None, None] * ((cv - u) / torch.sqrt(sdev + 1e-6)) + lb[None, :, None, None])
+    assert eng.lib.vs_upconv_supported(Co) == 1
+    xa, sa = to_nhwc(x), to_nhwc(sk)
+    lc = eng.new_act("t.lcat", B, H, W, C1 + C2)
+    N.check(eng.lib.vs_cat2_scale(N.ptr(xa.t), C1, xa.ld, N.ptr(sa.t), C2, sa.ld, 2 ** -0.5, lc.rows, N.ptr(lc.t), lc.ld, N.stream()), "cat2")
+    wz, cpz = pack_conv(w.to(DEV).permute(2, 3, 0, 1).reshape(9 * Co, C1 + C2)[:, :, None, None], lc.ld)
+    z = eng.new_act("t.z", B, H, W, 9 * Co)
+    eng.conv(lc, ConvW(wz, None, 9 * Co, 1, 1, cpz), z)
+    out = eng.new_act("t.upln", B, 2 * H, 2 * W, Co)
+    N.check(eng.lib.vs_upconv_gather_ln(N.ptr(z.t), z.ld, B, H, W, Co, N.ptr(dv(lw)), N.ptr(dv(lb)), 1e-6, N.ACT_RELU, N.ptr(out.t),
+                                        out.ld, N.stream()), "upconv_gather_ln")
+    torch.cuda.synchronize()
+    assert (from_nhwc(out) - ref).abs().max() < 2e-5          # LayerNorm output is O(1); fp32 re-association only
+    # x == NULL: the producer already wrote columns [0, C1)
+    lc.t.view(B, H, W, lc.ld)[..., C1:] = -5.0
+    N.check(eng.lib.vs_cat2_scale(None, C1, 0, N.ptr(sa.t), C2, sa.ld, 2 ** -0.5, lc.rows, N.ptr(lc.t), lc.ld, N.stream()), "cat2")
+    torch.cuda.synchronize()
+    got = lc.t.view(B, H, W, lc.ld).cpu()
+    assert torch.equal(got[..., :C1], x.permute(0, 2, 3, 1)) and torch.equal(got[..., C1:], (sk * 2 ** -0.5).permute(0, 2, 3, 1))
+
+
 def test_msg_latent_and_broadcast(eng):
     g = torch.Generator().manual_seed(10)
     B, k, hid = 3, 40, 24

@@ -1,11 +1,13 @@
 #!/usr/bin/env python
-"""dwconv7 + LayerNorm of the four ConvNeXt stages (B = 32 frames at 256^2 proc): time and effective GB/s (in + out)."""
+"""dwconv7 + LayerNorm of the four ConvNeXt stages (B = 32 frames at 256^2 proc): time and effective GB/s (in + out).
+VS_DWCONV=<n> picks the kernel (unset: the library's rule; 0: one-row kernel; 1..4: LDS-tiled configurations) -- one process per value."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from videoseal_amd import native as N
 L = N.lib()
 B = 32
+print("VS_DWCONV =", os.environ.get("VS_DWCONV", "auto"))
 for HW, Cc in ((64, 96), (32, 192), (16, 384), (8, 768)):
     x = torch.randn(B, HW, HW, Cc, device="cuda"); out = torch.empty_like(x)
     wdw = torch.randn(49, Cc, device="cuda"); v = [torch.randn(Cc, device="cuda") for _ in range(3)]

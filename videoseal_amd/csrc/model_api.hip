@@ -27,7 +27,7 @@ struct CW {                      // one conv / linear layer on the device
   int N = 0, KH = 0, KW = 0, CinP = 0;
 };
 struct RB { CW c0, c1, res; int cout = 0; };
-struct Up { CW conv; float* lnw = nullptr; float* lnb = nullptr; RB rb; };
+struct Up { CW conv; CW gemm; bool lowres = false; float* lnw = nullptr; float* lnb = nullptr; RB rb; };   // gemm: nine taps at the low resolution (vs_upconv_gather_ln)
 struct Down { float* lnw = nullptr; float* lnb = nullptr; CW conv; };
 struct Blk { float *wdw = nullptr, *bdw = nullptr, *lnw = nullptr, *lnb = nullptr, *gamma = nullptr, *beta = nullptr; CW pw1, pw2; };
 
@@ -154,6 +154,18 @@ struct Packer {
     if (bias_v) { b = *bias_v; hb = true; }
     else if (!bias_key.empty()) { const HostT& t = get(bias_key); if (t.p) { b.assign(t.p, t.p + t.n); hb = true; } }
     finish(cw, wt, b, hb);
+  }
+  // engine.py::_pack_embedder (Upsample groups): [Co,Cin,3,3] -> rows (tap, channel) of a 1x1 GEMM on the low-resolution [x | skip] map
+  void upconv9(CW& cw, const std::string& wkey, int cin, int cout) {
+    const HostT& w = get(wkey);
+    if (!w.p) return;
+    const int cinp = rup(cin, 16);
+    cw.N = 9 * cout; cw.KH = 1; cw.KW = 1; cw.CinP = cinp;
+    std::vector<float> wt((size_t)9 * cout * cinp, 0.f);
+    for (int o = 0; o < cout; ++o)
+      for (int c = 0; c < cin; ++c)
+        for (int t = 0; t < 9; ++t) wt[((size_t)t * cout + o) * cinp + c] = w.p[((size_t)o * cin + c) * 9 + t];
+    finish(cw, wt, {}, false);
   }
   // engine.py::pack_patch_conv: kw pixels of a row are one run of kw*pix_ld floats -> KH x 1 conv with Cin' = kw*pix_ld
   void patch_conv(CW& cw, const std::string& wkey, int cin, int k, int pix_ld, const std::string& bias_key) {
@@ -307,18 +319,45 @@ struct Runner {
     if (live()) chk(vs_msg_latent(m->table, msgs, n_msgs, c.nbits, c.hidden, lat, st));
     if (live()) chk(vs_broadcast_channels(lat, n_msgs, c.hidden, h3.p, B, h3.H * h3.W, h3.ld, m->zc.back(), st));
     Act cur = h3;
-    for (int j = 0; j < c.num_blocks; ++j) cur = resblock(cur, m->bottleneck[j]);
+    // Upsample group k on the low-resolution map: its [x | skip] concat buffer is allocated before x's producer runs, so that the
+    // producer (last bottleneck block / previous up block) writes columns [0, C) itself (engine.py::embedder_forward)
+    auto lowres_cat = [&](int k, const Act& like, Act& view) -> bool {
+      if (k >= nlev || !m->ups[k].lowres) return false;
+      const Act& skip = hid[nlev - k];
+      Act lc = act(B, like.H, like.W, like.C + skip.C);
+      view = Act{lc.p, B, like.H, like.W, like.C, lc.ld};
+      return true;
+    };
+    for (int j = 0; j < c.num_blocks; ++j) {
+      Act view{};
+      const bool direct = j == c.num_blocks - 1 && lowres_cat(0, cur, view);
+      cur = resblock(cur, m->bottleneck[j], direct ? &view : nullptr);
+    }
     for (int k = 0; k < nlev; ++k) {                   // skips are popped deepest first; the first one is the [latent | message] map itself
       const Act skip = hid.back();
       hid.pop_back();
       const Up& up = m->ups[k];
-      Act cat = act(B, 2 * cur.H, 2 * cur.W, cur.C + skip.C);
-      if (live()) chk(vs_upcat2x(cur.p, cur.C, cur.ld, skip.p, skip.C, skip.ld, 0.70710678118654752440f, B, cur.H, cur.W, cat.p, cat.ld, st));
-      Act cv = act(B, cat.H, cat.W, up.conv.N);
-      conv(cat, up.conv, cv, 1, 1, VS_PAD_REFLECT);
-      Act ln = act(B, cat.H, cat.W, up.conv.N);
-      layernorm(cv, up.lnw, up.lnb, ln, VS_ACT_RELU);
-      cur = resblock(ln, up.rb);
+      Act ln{};
+      if (up.lowres) {
+        const int co = up.gemm.N / 9;
+        const bool direct = cur.ld == cur.C + skip.C;
+        Act lc = direct ? Act{cur.p, B, cur.H, cur.W, cur.C + skip.C, cur.ld} : act(B, cur.H, cur.W, cur.C + skip.C);
+        if (live()) chk(vs_cat2_scale(direct ? nullptr : cur.p, cur.C, cur.ld, skip.p, skip.C, skip.ld, 0.70710678118654752440f, lc.rows(), lc.p, lc.ld, st));
+        Act z = act(B, lc.H, lc.W, 9 * co);
+        conv(lc, up.gemm, z);
+        ln = act(B, 2 * lc.H, 2 * lc.W, co);
+        if (live()) chk(vs_upconv_gather_ln(z.p, z.ld, B, lc.H, lc.W, co, up.lnw, up.lnb, 1e-6f, VS_ACT_RELU, ln.p, ln.ld, st));
+      } else {
+        Act cat = act(B, 2 * cur.H, 2 * cur.W, cur.C + skip.C);
+        if (live()) chk(vs_upcat2x(cur.p, cur.C, cur.ld, skip.p, skip.C, skip.ld, 0.70710678118654752440f, B, cur.H, cur.W, cat.p, cat.ld, st));
+        Act cv = act(B, cat.H, cat.W, up.conv.N);
+        conv(cat, up.conv, cv, 1, 1, VS_PAD_REFLECT);
+        ln = act(B, cat.H, cat.W, up.conv.N);
+        layernorm(cv, up.lnw, up.lnb, ln, VS_ACT_RELU);
+      }
+      Act view{};
+      const bool direct = lowres_cat(k + 1, Act{nullptr, B, ln.H, ln.W, up.rb.cout, 0}, view);
+      cur = resblock(ln, up.rb, direct ? &view : nullptr);
     }
     float* delta = alloc((int64_t)B * c.out_ch * cur.H * cur.W);
     if (live()) chk(vs_outc_tanh(cur.p, (int64_t)cur.H * cur.W, B, cur.C, cur.ld, m->outc_w, m->outc_b, c.out_ch, c.last_tanh ? 1 : 0, delta, st));
@@ -448,7 +487,9 @@ extern "C" int vs_model_create(const vs_model_cfg_t* cfg, const vs_tensor_t* ten
     const int i = nlev - 1 - k;
     const int cin = 2 * zz[i + 1], cout = zz[i];
     const std::string p = u + ".ups." + std::to_string(k);
-    P.conv(m->ups[k].conv, p + ".up.upsample_block.2.weight", cin, 3, 3, rup(cin, 4), nullptr, nullptr, "");
+    m->ups[k].lowres = vs_upconv_supported(cout) != 0;
+    if (m->ups[k].lowres) P.upconv9(m->ups[k].gemm, p + ".up.upsample_block.2.weight", cin, cout);
+    else P.conv(m->ups[k].conv, p + ".up.upsample_block.2.weight", cin, 3, 3, rup(cin, 4), nullptr, nullptr, "");
     m->ups[k].lnw = P.vec(p + ".up.upsample_block.3.weight");
     m->ups[k].lnb = P.vec(p + ".up.upsample_block.3.bias");
     P.resblock(m->ups[k].rb, p + ".conv", cout);

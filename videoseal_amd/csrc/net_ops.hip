@@ -2,6 +2,9 @@
 // LayerNorm(+act), depthwise 7x7 fused with LayerNorm, GRN statistics, bilinear x2 of the skip concat,
 // message latent + broadcast, the final 1x1+tanh, and the pooled linear head.
 // All activations are NHWC fp32 with a channel stride `ld` (multiple of 4, pad lanes kept at zero).
+#include <algorithm>
+#include <cstdlib>
+
 #include "vs_common.h"
 
 namespace {
@@ -78,6 +81,64 @@ __global__ __launch_bounds__(256) void layernorm_act_small_kernel(const float* _
     }
 }
 
+// LayerNorm over the C channels of pixels whose conv results sit in LDS rows of `stride` floats (stride/4 odd: conflict-free
+// 16-byte reads).  Four adjacent lanes share a pixel (interleaved float4 columns) and combine with two quad shuffles: a wave
+// normalises 16 pixels at a time instead of one pixel per wave with two 6-step butterflies (which left the one-row kernel
+// latency-bound: 2 x 6 dependent cross-lane steps per pixel, one pixel in flight per wave).
+template <int NT, int LPP, typename RowPtr>
+__device__ __forceinline__ void ln_rows_from_lds_impl(const float* __restrict__ s, int stride, int npx, int C, const float* __restrict__ lnw,
+                                                      const float* __restrict__ lnb, float eps, int out_ld, RowPtr rowptr) {
+  const int q = threadIdx.x & (LPP - 1);
+  const int C4 = (C + 3) >> 2, O4 = out_ld >> 2;
+  const float invC = 1.0f / (float)C;
+  for (int p = threadIdx.x / LPP; p < npx; p += NT / LPP) {
+    float* orow = rowptr(p);
+    if (!orow) continue;                                  // the LPP lanes of a pixel skip together
+    const float* r = s + (int64_t)p * stride;
+    float sum = 0.f;
+    for (int c4 = q; c4 < C4; c4 += LPP) {
+      const f32x4 v = *reinterpret_cast<const f32x4*>(r + 4 * c4);
+      sum += (v[0] + v[1]) + (v[2] + v[3]);               // channels >= C hold exact zeros (zero taps, zero bias)
+    }
+#pragma unroll
+    for (int o = 1; o < LPP; o <<= 1) sum += __shfl_xor(sum, o, 64);
+    const float mean = sum * invC;
+    float var = 0.f;
+    for (int c4 = q; c4 < C4; c4 += LPP) {
+      const f32x4 v = *reinterpret_cast<const f32x4*>(r + 4 * c4);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float dl = (4 * c4 + e < C) ? v[e] - mean : 0.f;
+        var += dl * dl;
+      }
+    }
+#pragma unroll
+    for (int o = 1; o < LPP; o <<= 1) var += __shfl_xor(var, o, 64);
+    const float rden = 1.0f / sqrtf(var * invC + eps);
+    for (int c4 = q; c4 < O4; c4 += LPP) {
+      f32x4 o = {0.f, 0.f, 0.f, 0.f};
+      if (c4 < C4) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(r + 4 * c4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          if (4 * c4 + e < C) o[e] = lnw[4 * c4 + e] * ((v[e] - mean) * rden) + lnb[4 * c4 + e];
+      }
+      *reinterpret_cast<f32x4*>(orow + 4 * c4) = o;
+    }
+  }
+}
+// lanes per pixel: as few as keep the whole workgroup busy (many pixels of few channels: 4 lanes and two quad shuffles; a
+// handful of pixels of many channels: up to a wave per pixel)
+template <int NT, typename RowPtr>
+__device__ __forceinline__ void ln_rows_from_lds(const float* __restrict__ s, int stride, int npx, int C, const float* __restrict__ lnw,
+                                                 const float* __restrict__ lnb, float eps, int out_ld, RowPtr rowptr) {
+  if (npx * 8 > NT) ln_rows_from_lds_impl<NT, 4>(s, stride, npx, C, lnw, lnb, eps, out_ld, rowptr);
+  else if (npx * 16 > NT) ln_rows_from_lds_impl<NT, 8>(s, stride, npx, C, lnw, lnb, eps, out_ld, rowptr);
+  else if (npx * 32 > NT) ln_rows_from_lds_impl<NT, 16>(s, stride, npx, C, lnw, lnb, eps, out_ld, rowptr);
+  else if (npx * 64 > NT) ln_rows_from_lds_impl<NT, 32>(s, stride, npx, C, lnw, lnb, eps, out_ld, rowptr);
+  else ln_rows_from_lds_impl<NT, 64>(s, stride, npx, C, lnw, lnb, eps, out_ld, rowptr);
+}
+
 // ---------------------------------------------------------------------------------------------------
 // Depthwise 7x7 (pad 3) + bias, then LayerNorm over C, per pixel (convnext.py:43-46).
 // A work item = (strip of 4 consecutive x, group of 4 channels): 70 float4 loads feed 16 outputs x 4 channels,
@@ -87,7 +148,7 @@ __global__ __launch_bounds__(256) void dwconv7_ln_kernel(const float* __restrict
                                                          const float* __restrict__ lnw, const float* __restrict__ lnb,
                                                          float eps, float* __restrict__ out, int64_t out_ld, int NS,
                                                          int spr, int64_t nstrips) {
-  extern __shared__ __attribute__((aligned(16))) float conv[];   // [NS*4][ld]
+  extern __shared__ __attribute__((aligned(16))) float conv[];   // [NS*4][ld + 4]
   const int C4 = (int)(ld >> 2);
   const int64_t s0 = (int64_t)blockIdx.x * NS;
   const int items = NS * C4;
@@ -124,30 +185,135 @@ __global__ __launch_bounds__(256) void dwconv7_ln_kernel(const float* __restrict
       }
     }
 #pragma unroll
-    for (int p = 0; p < 4; ++p) *reinterpret_cast<f32x4*>(conv + (int64_t)(sl * 4 + p) * ld + c) = acc[p];
+    for (int p = 0; p < 4; ++p) *reinterpret_cast<f32x4*>(conv + (int64_t)(sl * 4 + p) * (ld + 4) + c) = acc[p];
   }
   __syncthreads();
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nw = blockDim.x >> 6;
-  for (int p = wv; p < NS * 4; p += nw) {
+  ln_rows_from_lds<256>(conv, (int)ld + 4, NS * 4, C, lnw, lnb, eps, (int)out_ld, [&](int p) -> float* {
     const int64_t sidx = s0 + (p >> 2);
-    if (sidx >= nstrips) break;
-    const int xs = (int)(sidx % spr);
-    const int64_t t = sidx / spr;
-    const int px = xs * 4 + (p & 3);
-    if (px >= W) continue;
-    const float* cr = conv + (int64_t)p * ld;
-    float s = 0.f;
-    for (int c = lane; c < C; c += 64) s += cr[c];
-    const float mean = wave_sum(s) / (float)C;
-    float v = 0.f;
-    for (int c = lane; c < C; c += 64) {
-      const float dlt = cr[c] - mean;
-      v += dlt * dlt;
-    }
-    const float den = sqrtf(wave_sum(v) / (float)C + eps);
-    float* orow = out + (t * W + px) * out_ld;
-    for (int c = lane; c < (int)out_ld; c += 64) orow[c] = c < C ? lnw[c] * ((cr[c] - mean) / den) + lnb[c] : 0.f;
+    if (sidx >= nstrips) return nullptr;
+    const int px = (int)(sidx % spr) * 4 + (p & 3);
+    return px < W ? out + ((sidx / spr) * W + px) * out_ld : nullptr;
+  });
+}
+
+// LDS-tiled flavour of the same op (same FMA order per output => bit-identical to dwconv7_ln_kernel): a workgroup owns a TH x TW
+// pixel tile of one frame and ALL channels.  Channels are walked in chunks of CCH: the zero-padded (TH+6) x (TW+6) halo tile of the
+// chunk and its 49 taps + bias are staged in LDS once (coalesced 16-byte loads, no per-tap bounds checks or address arithmetic in
+// the inner loop), a work item = 4 consecutive pixels x 4 channels reads 7 x 10 float4 from LDS for 784 FMAs, and the conv results
+// are parked in an LDS [pixel][channel] buffer until the per-pixel LayerNorm (one wave per pixel, as in the one-row kernel).
+// The one-row kernel re-read every input 30x through L1 with 4.5 VALU instructions per FMA (rocprofv3).
+template <int TH, int TW, int CCH, int NT>
+__global__ __launch_bounds__(NT) void dwconv7_ln_tiled_kernel(const float* __restrict__ x, int H, int W, int C, int64_t ld,
+                                                              const float* __restrict__ wdw, const float* __restrict__ bdw,
+                                                              const float* __restrict__ lnw, const float* __restrict__ lnb,
+                                                              float eps, float* __restrict__ out, int64_t out_ld, int tiles_x,
+                                                              int tiles_y, int nblk) {
+  constexpr int IH = TH + 6, IW = TW + 6, CP = CCH + 4, SPR = TW / 4, N4 = CCH / 4;
+  constexpr int NIN = IH * IW * N4, NWT = 50 * N4;            // float4 slots of a chunk: halo tile, taps + bias
+  constexpr int LIN = (NIN + NT - 1) / NT, LWT = (NWT + NT - 1) / NT;
+  constexpr int ITEMS = TH * SPR * N4;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* const s_in = smem;                       // [IH][IW][CP]
+  float* const s_w = s_in + IH * IW * CP;         // [50][CCH]: 49 taps + bias
+  float* const s_out = s_w + 50 * CCH;            // [TH*TW][ld + 4]
+  const int tid = threadIdx.x;
+  const int per = (nblk + 7) >> 3;                // XCD-aware order: neighbouring tiles (shared halos) on one XCD's L2
+  const int vb = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
+  if (vb >= nblk) return;
+  const int tx = vb % tiles_x;
+  const int t1 = vb / tiles_x;
+  const int ty = t1 % tiles_y;
+  const int b = t1 / tiles_y;
+  const int y0 = ty * TH, x0 = tx * TW;
+  const float* xb = x + (int64_t)b * H * W * ld;
+  // per-thread slots of the halo tile are the same for every chunk: global offset (or -1 outside the image) + LDS offset
+  int g_off[LIN], l_off[LIN];
+#pragma unroll
+  for (int k = 0; k < LIN; ++k) {
+    const int i = tid + k * NT;
+    const int cg = i % N4, pp = i / N4;
+    const int px = pp % IW, py = pp / IW;
+    const int gy = y0 + py - 3, gx = x0 + px - 3;
+    const bool ok = i < NIN && gy >= 0 && gy < H && gx >= 0 && gx < W;
+    g_off[k] = ok ? (int)(((int64_t)gy * W + gx) * ld) + cg * 4 : -1;
+    l_off[k] = i < NIN ? (py * IW + px) * CP + cg * 4 : -1;
   }
+  f32x4 rin[LIN], rwt[LWT];
+  auto fetch = [&](int c0) __attribute__((always_inline)) {
+#pragma unroll
+    for (int k = 0; k < LIN; ++k) {
+      rin[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (g_off[k] >= 0) rin[k] = *reinterpret_cast<const f32x4*>(xb + g_off[k] + c0);
+    }
+#pragma unroll
+    for (int k = 0; k < LWT; ++k) {
+      const int i = tid + k * NT;
+      const int cg = i % N4, t = i / N4;
+      if (i < NWT) rwt[k] = *reinterpret_cast<const f32x4*>((t < 49 ? wdw + (int64_t)t * ld : bdw) + c0 + cg * 4);
+    }
+  };
+  const int nch = (int)ld / CCH;                   // the launcher guarantees ld % CCH == 0
+  fetch(0);
+  for (int ch = 0; ch < nch; ++ch) {
+    const int c0 = ch * CCH;
+#pragma unroll
+    for (int k = 0; k < LIN; ++k)
+      if (l_off[k] >= 0) *reinterpret_cast<f32x4*>(s_in + l_off[k]) = rin[k];
+#pragma unroll
+    for (int k = 0; k < LWT; ++k) {
+      const int i = tid + k * NT;
+      if (i < NWT) *reinterpret_cast<f32x4*>(s_w + (i / N4) * CCH + (i % N4) * 4) = rwt[k];
+    }
+    __syncthreads();
+    if (ch + 1 < nch) fetch(c0 + CCH);             // next chunk's global loads fly during this chunk's FMAs
+    for (int it = tid; it < ITEMS; it += NT) {
+      const int cg = it % N4, rs = it / N4;
+      const int sx = rs % SPR, r = rs / SPR;
+      f32x4 acc[4];
+      const f32x4 bv = *reinterpret_cast<const f32x4*>(s_w + 49 * CCH + cg * 4);
+#pragma unroll
+      for (int p = 0; p < 4; ++p) acc[p] = bv;
+#pragma unroll
+      for (int ky = 0; ky < 7; ++ky) {
+        const float* row = s_in + ((r + ky) * IW + sx * 4) * CP + cg * 4;
+        f32x4 in[10];
+#pragma unroll
+        for (int j = 0; j < 10; ++j) in[j] = *reinterpret_cast<const f32x4*>(row + j * CP);
+#pragma unroll
+        for (int kx = 0; kx < 7; ++kx) {
+          const f32x4 wv = *reinterpret_cast<const f32x4*>(s_w + (ky * 7 + kx) * CCH + cg * 4);
+#pragma unroll
+          for (int p = 0; p < 4; ++p) acc[p] += in[p + kx] * wv;
+        }
+      }
+#pragma unroll
+      for (int p = 0; p < 4; ++p) *reinterpret_cast<f32x4*>(s_out + (int64_t)(r * TW + sx * 4 + p) * (ld + 4) + c0 + cg * 4) = acc[p];
+    }
+    __syncthreads();
+  }
+  ln_rows_from_lds<NT>(s_out, (int)ld + 4, TH * TW, C, lnw, lnb, eps, (int)out_ld, [&](int p) -> float* {
+    const int gy = y0 + p / TW, gx = x0 + p % TW;
+    return (gy < H && gx < W) ? out + (((int64_t)b * H + gy) * W + gx) * out_ld : nullptr;
+  });
+}
+
+template <int TH, int TW, int CCH, int NT>
+static int launch_dwconv_tiled(const float* x, int B, int H, int W, int C, int64_t ld, const float* wdw, const float* bdw, const float* lnw,
+                               const float* lnb, float eps, float* out, int64_t out_ld, hipStream_t st) {
+  const size_t smem = sizeof(float) * ((size_t)(TH + 6) * (TW + 6) * (CCH + 4) + 50 * CCH + (size_t)TH * TW * (ld + 4));
+  if (smem > 160 * 1024 || ld % CCH != 0 || (int64_t)H * W * ld >= (1ll << 31)) return VS_ERR_UNSUPPORTED;
+  auto kern = dwconv7_ln_tiled_kernel<TH, TW, CCH, NT>;
+  static size_t attr_set = 0;            // raise the dynamic-LDS limit once per size class (a cheap host-side call otherwise)
+  if (smem > 64 * 1024 && smem > attr_set) {
+    (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr_set = 160 * 1024;
+  }
+  const int tiles_x = (W + TW - 1) / TW, tiles_y = (H + TH - 1) / TH;
+  const int64_t nblk = (int64_t)B * tiles_x * tiles_y;
+  if (nblk >= (1 << 30)) return VS_ERR_UNSUPPORTED;
+  hipLaunchKernelGGL(kern, dim3((unsigned)((nblk + 7) / 8 * 8)), dim3(NT), smem, st, x, H, W, C, ld, wdw, bdw, lnw, lnb, eps, out, out_ld,
+                     tiles_x, tiles_y, (int)nblk);
+  return vs_launch_status();
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -238,6 +404,112 @@ __global__ __launch_bounds__(256) void upcat2x_kernel(const float* __restrict__ 
       v = (ly0 * (lx0 * (p00 * mul) + lx1 * (p01 * mul)) + ly1 * (lx0 * (p10 * mul) + lx1 * (p11 * mul)));
     }
     *reinterpret_cast<f32x4*>(out + (((int64_t)b * 2 * H + Y) * 2 * W + X) * old + c) = v;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Upsample group without the up-sampled tensor (common.py:45-52: bilinear x2 -> ReflectionPad2d(1) -> Conv3x3 (no bias) -> LayerNorm
+// over C -> act).  Bilinear interpolation, the reflect padding and the tap shift are linear maps over space and commute with the
+// channel mixing of the conv, so
+//     conv3x3(pad(up(v)))[Y,X,c] = sum_t  up(z_t)[refl(Y+ky-1), refl(X+kx-1), c],     z_t[y,x,c] = sum_ci W[c,ci,t] v[y,x,ci]
+// z (all nine taps: a plain [rows] x [9*Co] x [Cin] GEMM on the LOW-resolution map, a quarter of the conv's MACs) comes from
+// vs_conv_gemm; this kernel does the 9-tap x 4-neighbour gather, the per-pixel LayerNorm and the activation.  The x2 up-sampled
+// concat (384 MB per launch at 64^2 x 768 channels x 32 frames) is never materialised.
+// Thread = (output pixel, group of CG channels); the TPP = Co / CG lanes of a pixel are adjacent and reduce with xor shuffles.
+template <int CG>
+__global__ __launch_bounds__(256) void upconv_gather_ln_kernel(const float* __restrict__ z, int64_t zld, int H, int W, int Co,
+                                                               int tpp_log2, const float* __restrict__ lnw,
+                                                               const float* __restrict__ lnb, float eps, int act,
+                                                               float* __restrict__ out, int64_t old, int64_t npix, int nblk) {
+  // XCD-aware order: workgroup b runs on XCD b % 8 (MI355X_MICROARCH.md); give every XCD one contiguous range of rows so that
+  // the low-resolution z rows shared by neighbouring output rows stay in that XCD's L2
+  const int per = (nblk + 7) >> 3;
+  const int64_t vb = (int64_t)(blockIdx.x & 7) * per + (blockIdx.x >> 3);
+  const int64_t gid = vb * 256 + threadIdx.x;
+  const int64_t pq = gid >> tpp_log2;
+  const int g = (int)(gid & ((1 << tpp_log2) - 1));
+  const bool live = pq < npix && vb < nblk;
+  const int64_t p = live ? pq : 0;           // dead lanes still take part in the shuffles
+  const int W2 = 2 * W, H2 = 2 * H;
+  const int X = (int)(p % W2);
+  const int64_t t0 = p / W2;
+  const int Y = (int)(t0 % H2);
+  const int64_t b = t0 / H2;
+  int ys[3][2], xs[3][2];
+  float wy[3][2], wx[3][2];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    int yr = Y + k - 1, xr = X + k - 1;
+    yr = yr < 0 ? -yr : (yr >= H2 ? 2 * H2 - 2 - yr : yr);            // ReflectionPad2d(1) on the up-sampled grid
+    xr = xr < 0 ? -xr : (xr >= W2 ? 2 * W2 - 2 - xr : xr);
+    const float sy = fmaxf((yr + 0.5f) * 0.5f - 0.5f, 0.f), sx = fmaxf((xr + 0.5f) * 0.5f - 0.5f, 0.f);   // align_corners=False
+    const int y0 = (int)sy, x0 = (int)sx;
+    ys[k][0] = y0; ys[k][1] = y0 + (y0 < H - 1);
+    xs[k][0] = x0; xs[k][1] = x0 + (x0 < W - 1);
+    wy[k][1] = sy - y0; wy[k][0] = 1.f - wy[k][1];
+    wx[k][1] = sx - x0; wx[k][0] = 1.f - wx[k][1];
+  }
+  constexpr int NV = CG / 4;
+  f32x4 acc[NV];
+#pragma unroll
+  for (int j = 0; j < NV; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const float* zb = z + b * H * W * zld + g * CG;
+#pragma unroll
+  for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {
+      const float* zr = zb + (int64_t)ys[ky][a] * W * zld + ky * 3 * Co;
+#pragma unroll
+      for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+          const float w = wy[ky][a] * wx[kx][c];
+          const float* q = zr + (int64_t)xs[kx][c] * zld + kx * Co;
+#pragma unroll
+          for (int j = 0; j < NV; ++j) acc[j] += w * *reinterpret_cast<const f32x4*>(q + 4 * j);
+        }
+    }
+  float s = 0.f;
+#pragma unroll
+  for (int j = 0; j < NV; ++j) s += (acc[j][0] + acc[j][1]) + (acc[j][2] + acc[j][3]);
+  for (int o = 1; o < (1 << tpp_log2); o <<= 1) s += __shfl_xor(s, o, 64);
+  const float mean = s / (float)Co;
+  float v = 0.f;
+#pragma unroll
+  for (int j = 0; j < NV; ++j)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { const float dl = acc[j][e] - mean; v += dl * dl; }
+  for (int o = 1; o < (1 << tpp_log2); o <<= 1) v += __shfl_xor(v, o, 64);
+  const float den = sqrtf(v / (float)Co + eps);
+  if (!live) return;
+  float* orow = out + p * old + g * CG;
+  const float* lw = lnw + g * CG;
+  const float* lb = lnb + g * CG;
+#pragma unroll
+  for (int j = 0; j < NV; ++j) {
+    const f32x4 wv = *reinterpret_cast<const f32x4*>(lw + 4 * j), bv = *reinterpret_cast<const f32x4*>(lb + 4 * j);
+    f32x4 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) o[e] = vs_apply_act(wv[e] * ((acc[j][e] - mean) / den) + bv[e], act);
+    *reinterpret_cast<f32x4*>(orow + 4 * j) = o;
+  }
+}
+
+// channel concat of two NHWC maps of the same pixels, the second one scaled: out[r] = [x[r] | skip[r] * s]  (unet.py:186-187 at the
+// LOW resolution).  x may be NULL when its producer already wrote columns [0, C1) of `out`.
+__global__ __launch_bounds__(256) void cat2_scale_kernel(const float* __restrict__ x, int C1, int64_t ld1, const float* __restrict__ skip,
+                                                         int C2, int64_t ld2, float s, int64_t rows, float* __restrict__ out,
+                                                         int64_t old) {
+  const int g1 = x ? C1 >> 2 : 0, G = g1 + (C2 >> 2);
+  const int64_t total = rows * G;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int cg = (int)(i % G);
+    const int64_t r = i / G;
+    f32x4 v;
+    int c;
+    if (cg < g1) { c = cg * 4; v = *reinterpret_cast<const f32x4*>(x + r * ld1 + c); }
+    else { const int c2 = (cg - g1) * 4; c = C1 + c2; v = *reinterpret_cast<const f32x4*>(skip + r * ld2 + c2) * s; }
+    *reinterpret_cast<f32x4*>(out + r * old + c) = v;
   }
 }
 
@@ -427,13 +699,36 @@ extern "C" int vs_layernorm_act(const float* x, int64_t rows, int C, int64_t ld,
 extern "C" int vs_dwconv7_ln(const float* x, int B, int H, int W, int C, int64_t ld, const float* wdw, const float* bdw,
                              const float* lnw, const float* lnb, float eps, float* out, int64_t out_ld, void* stream) {
   VS_REQUIRE(x && wdw && bdw && lnw && lnb && out && B > 0 && H > 0 && W > 0 && C > 0);
-  VS_REQUIRE(ld % 4 == 0 && ld >= C && out_ld >= C);
+  VS_REQUIRE(ld % 4 == 0 && ld >= C && out_ld >= C && out_ld % 4 == 0);
+  // LDS-tiled kernels where the tile + the [pixel][channel] LayerNorm buffer fit the 160 KB of a CU and the map is large enough to
+  // give every CU a tile; every variant produces bit-identical values (same FMA order), so the choice is purely a speed matter.
+  // VS_DWCONV=0 forces the one-row kernel, 1 / 2 a tiled configuration (tools/bench_dwconv.py).
+  static const int force = [] { const char* e = getenv("VS_DWCONV"); return e ? atoi(e) : -1; }();
+  {
+    const int64_t hw = (int64_t)H * W;
+    int cfg = 0;
+    if (force >= 0) cfg = force;
+    else if (hw >= 4096) cfg = 5;              // measured on MI355X, B = 32 (tools/bench_dwconv.py): 64^2 x 96: 117 -> 60 us,
+    else if (hw >= 1024) cfg = 3;              // 32^2 x 192: 65 -> 38 us; 16^2 x 384: 32 -> 23 us (128-channel chunks: 256 work items
+    else if (hw >= 256) cfg = 6;               // per 4 x 8 tile); 8^2 x 768: the one-row kernel stays ahead (24 us)
+    int rc = VS_ERR_UNSUPPORTED;
+    if (cfg == 1) rc = launch_dwconv_tiled<8, 8, 48, 256>(x, B, H, W, C, ld, wdw, bdw, lnw, lnb, eps, out, out_ld, (hipStream_t)stream);
+    else if (cfg == 2) rc = launch_dwconv_tiled<4, 8, 64, 128>(x, B, H, W, C, ld, wdw, bdw, lnw, lnb, eps, out, out_ld, (hipStream_t)stream);
+    else if (cfg == 3) rc = launch_dwconv_tiled<8, 16, 32, 256>(x, B, H, W, C, ld, wdw, bdw, lnw, lnb, eps, out, out_ld, (hipStream_t)stream);
+    else if (cfg == 4) rc = launch_dwconv_tiled<4, 16, 64, 256>(x, B, H, W, C, ld, wdw, bdw, lnw, lnb, eps, out, out_ld, (hipStream_t)stream);
+    else if (cfg == 5) rc = launch_dwconv_tiled<4, 16, 48, 256>(x, B, H, W, C, ld, wdw, bdw, lnw, lnb, eps, out, out_ld, (hipStream_t)stream);
+    else if (cfg == 6) rc = launch_dwconv_tiled<4, 8, 128, 256>(x, B, H, W, C, ld, wdw, bdw, lnw, lnb, eps, out, out_ld, (hipStream_t)stream);
+    else if (cfg == 7) rc = launch_dwconv_tiled<4, 4, 128, 128>(x, B, H, W, C, ld, wdw, bdw, lnw, lnb, eps, out, out_ld, (hipStream_t)stream);
+    if (rc == VS_ERR_UNSUPPORTED && force < 0 && cfg == 3)      // tile does not fit / ld % 32: the other tiled shape
+      rc = launch_dwconv_tiled<4, 16, 48, 256>(x, B, H, W, C, ld, wdw, bdw, lnw, lnb, eps, out, out_ld, (hipStream_t)stream);
+    if (rc != VS_ERR_UNSUPPORTED) return rc;
+  }
   const int C4 = (int)(ld / 4);
   int NS = 256 / C4;
   if (NS < 1) NS = 1;
   const int spr = (W + 3) / 4;
   const int64_t nstrips = (int64_t)B * H * spr;
-  const size_t smem = (size_t)NS * 4 * ld * sizeof(float);
+  const size_t smem = (size_t)NS * 4 * (ld + 4) * sizeof(float);
   if (smem > 160 * 1024) return VS_ERR_UNSUPPORTED;
   if (smem > 64 * 1024)
     (void)hipFuncSetAttribute((const void*)dwconv7_ln_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
@@ -496,6 +791,44 @@ extern "C" int vs_upcat2x(const float* x, int C1, int64_t ld1, const float* skip
   const int64_t total = (int64_t)B * 2 * H * 2 * W * (out_ld / 4);
   hipLaunchKernelGGL(upcat2x_kernel, dim3(grid_for(total, 256, 1 << 20)), dim3(256), 0, (hipStream_t)stream, x, C1, ld1, skip,
                      C2, ld2, skip_scale, B, H, W, out, out_ld, total);
+  return vs_launch_status();
+}
+
+extern "C" int vs_cat2_scale(const float* x, int C1, int64_t ld1, const float* skip, int C2, int64_t ld2, float skip_scale,
+                             int64_t rows, float* out, int64_t out_ld, void* stream) {
+  VS_REQUIRE(skip && out && rows > 0 && C1 >= 0 && C2 > 0 && C1 % 4 == 0 && C2 % 4 == 0 && ld2 % 4 == 0 && out_ld % 4 == 0 &&
+             out_ld >= C1 + C2 && (!x || (ld1 % 4 == 0 && ld1 >= C1)));
+  const int64_t total = rows * ((x ? C1 : 0) + C2) / 4;
+  hipLaunchKernelGGL(cat2_scale_kernel, dim3((unsigned)std::min<int64_t>(cdiv64(total, 256), 1 << 16)), dim3(256), 0, (hipStream_t)stream,
+                     x, C1, ld1, skip, C2, ld2, skip_scale, rows, out, out_ld);
+  return vs_launch_status();
+}
+
+extern "C" int vs_upconv_supported(int Co) {
+  if (Co < 16 || Co % 16) return 0;
+  const int cg = Co >= 64 ? 16 : Co / 4;
+  const int tpp = Co / cg;
+  return (cg == 4 || cg == 8 || cg == 16) && tpp <= 64 && (tpp & (tpp - 1)) == 0;
+}
+
+extern "C" int vs_upconv_gather_ln(const float* z, int64_t z_ld, int B, int H, int W, int Co, const float* lnw, const float* lnb,
+                                   float eps, int act, float* out, int64_t out_ld, void* stream) {
+  VS_REQUIRE(z && lnw && lnb && out && B > 0 && H > 0 && W > 0 && vs_upconv_supported(Co) && z_ld >= 9 * (int64_t)Co && z_ld % 4 == 0 &&
+             out_ld >= Co && out_ld % 4 == 0);
+  const int cg = Co >= 64 ? 16 : Co / 4;
+  int tl = 0;
+  while ((cg << tl) < Co) ++tl;
+  const int64_t npix = (int64_t)B * 4 * H * W;
+  const int64_t nblk64 = cdiv64(npix << tl, 256);
+  VS_REQUIRE(nblk64 < (1 << 30));
+  const int nblk = (int)nblk64;
+  const int grid = ((nblk + 7) / 8) * 8;
+  hipStream_t st = (hipStream_t)stream;
+#define VS_UPG(CG_) hipLaunchKernelGGL(upconv_gather_ln_kernel<CG_>, dim3(grid), dim3(256), 0, st, z, z_ld, H, W, Co, tl, lnw, lnb, eps, act, out, out_ld, npix, nblk)
+  if (cg == 4) VS_UPG(4);
+  else if (cg == 8) VS_UPG(8);
+  else VS_UPG(16);
+#undef VS_UPG
   return vs_launch_status();
 }
 

@@ -146,6 +146,9 @@ class HipEngine:
         self.kernel_timers = None        # list of (name, start_event, end_event, flops) when bench.py enables it
         self.time_all_convs = False
         self.use_split = os.environ.get("VIDEOSEAL_CONV", "split") != "f32"   # arithmetic back-end of vs_conv_gemm
+        # Upsample groups as a low-resolution 9-tap GEMM + gather (a quarter of the MACs, no up-sampled concat); 0 = the literal
+        # bilinear x2 -> reflect-pad conv3x3 -> LayerNorm sequence (kept for A/B checks)
+        self.upconv_lowres = os.environ.get("VIDEOSEAL_UPCONV", "lowres") != "direct"
         # per-shape tile selection: every candidate walks K in the same order, so the result is bit-identical whatever
         # tile wins -- only speed changes (measure, don't guess).  VIDEOSEAL_AUTOTUNE=0 keeps the static heuristic.
         self.autotune = os.environ.get("VIDEOSEAL_AUTOTUNE", "1") != "0"
@@ -237,10 +240,18 @@ class HipEngine:
         E["ups"] = []
         for k, i in enumerate(reversed(range(len(zz) - 1))):
             cin, cout = 2 * zz[i + 1], zz[i]
-            wu, cp = pack_conv(g(f"{u}.ups.{k}.up.upsample_block.2.weight"), rup(cin, 4))
-            E["ups"].append(dict(conv=ConvW(wu, None, cout, 3, 3, cp), lnw=g(f"{u}.ups.{k}.up.upsample_block.3.weight").float().contiguous(),
-                                 lnb=g(f"{u}.ups.{k}.up.upsample_block.3.bias").float().contiguous(),
-                                 rb=self._pack_resblock(g, f"{u}.ups.{k}.conv", cout, train)))
+            wup = g(f"{u}.ups.{k}.up.upsample_block.2.weight")
+            upd = dict(lnw=g(f"{u}.ups.{k}.up.upsample_block.3.weight").float().contiguous(),
+                       lnb=g(f"{u}.ups.{k}.up.upsample_block.3.bias").float().contiguous(),
+                       rb=self._pack_resblock(g, f"{u}.ups.{k}.conv", cout, train))
+            if self.upconv_lowres and self.lib.vs_upconv_supported(cout):
+                # per-tap products on the LOW-resolution map (vs_upconv_gather_ln): rows ordered (tap, channel), K = [x | skip]
+                wz, cpz = pack_conv(wup.float().permute(2, 3, 0, 1).reshape(9 * cout, cin)[:, :, None, None], rup(cin, 4))
+                upd["gemm"] = ConvW(wz, None, 9 * cout, 1, 1, cpz)
+            else:
+                wu, cp = pack_conv(wup, rup(cin, 4))
+                upd["conv"] = ConvW(wu, None, cout, 3, 3, cp)
+            E["ups"].append(upd)
         E["outc_w"] = g(u + ".outc.weight").float().reshape(c.out_ch, zc[0]).contiguous()
         E["outc_b"] = g(u + ".outc.bias").float().contiguous()
         E["table"] = g(u + ".msg_processor.msg_embeddings.weight").float().contiguous()
@@ -568,19 +579,40 @@ class HipEngine:
         N.check(L.vs_broadcast_channels(N.ptr(lat), Bm, c.hidden, N.ptr(h3.t), B, h3.H * h3.W, h3.ld, c.zc[-1], st),
                 "vs_broadcast_channels")
         xcur = h3
+        def lowres_cat(k: int, like: Act) -> Optional[Act]:
+            """[x | skip] of Upsample group k at the LOW resolution; the producer of x writes columns [0, C) itself (eval mode)"""
+            if k >= nlev or "gemm" not in E["ups"][k] or bn_train:
+                return None
+            return self.new_act(f"up{k}.lcat", B, like.H, like.W, like.C + hid[nlev - k].C)
+
         for j in range(c.num_blocks):
-            xcur = self.resblock(xcur, E["bott"][j], f"bott{j & 1}")
+            lc = lowres_cat(0, xcur) if j == c.num_blocks - 1 else None
+            xcur = self.resblock(xcur, E["bott"][j], f"bott{j & 1}", out=(Act(lc.t, B, lc.H, lc.W, xcur.C, lc.ld) if lc else None))
         for k in range(nlev):
             skip = hid.pop()
             up = E["ups"][k]
-            cat = self.new_act(f"up{k}.cat", B, 2 * xcur.H, 2 * xcur.W, xcur.C + skip.C)
-            N.check(L.vs_upcat2x(N.ptr(xcur.t), xcur.C, xcur.ld, N.ptr(skip.t), skip.C, skip.ld, 2 ** -0.5, B, xcur.H, xcur.W,
-                                 N.ptr(cat.t), cat.ld, st), "vs_upcat2x")
-            cv = self.new_act(f"up{k}.conv", B, cat.H, cat.W, up["conv"].N)
-            self.conv(cat, up["conv"], cv, pad=1, pad_mode=N.PAD_REFLECT)
-            ln = self.new_act(f"up{k}.ln", B, cat.H, cat.W, up["conv"].N)
-            self.layernorm(cv, up["lnw"], up["lnb"], ln, act=N.ACT_RELU)
-            xcur = self.resblock(ln, up["rb"], f"up{k}")
+            if "gemm" in up:       # low-resolution 9-tap GEMM + gather / LayerNorm / ReLU (see vs_upconv_gather_ln)
+                co = up["gemm"].N // 9
+                direct = xcur.ld == xcur.C + skip.C      # x already sits in columns [0, C) of the concat buffer
+                lc = Act(xcur.t, B, xcur.H, xcur.W, xcur.C + skip.C, xcur.ld) if direct else \
+                    self.new_act(f"up{k}.lcat", B, xcur.H, xcur.W, xcur.C + skip.C)
+                N.check(L.vs_cat2_scale(None if direct else N.ptr(xcur.t), xcur.C, xcur.ld, N.ptr(skip.t), skip.C, skip.ld, 2 ** -0.5,
+                                        lc.rows, N.ptr(lc.t), lc.ld, st), "vs_cat2_scale")
+                z = self.new_act(f"up{k}.z", B, lc.H, lc.W, 9 * co)
+                self.conv(lc, up["gemm"], z, prof=(f"up{k}.gemm9" if self.time_all_convs else None))
+                ln = self.new_act(f"up{k}.ln", B, 2 * lc.H, 2 * lc.W, co)
+                N.check(L.vs_upconv_gather_ln(N.ptr(z.t), z.ld, B, lc.H, lc.W, co, N.ptr(up["lnw"]), N.ptr(up["lnb"]), 1e-6, N.ACT_RELU,
+                                              N.ptr(ln.t), ln.ld, st), "vs_upconv_gather_ln")
+            else:
+                cat = self.new_act(f"up{k}.cat", B, 2 * xcur.H, 2 * xcur.W, xcur.C + skip.C)
+                N.check(L.vs_upcat2x(N.ptr(xcur.t), xcur.C, xcur.ld, N.ptr(skip.t), skip.C, skip.ld, 2 ** -0.5, B, xcur.H, xcur.W,
+                                     N.ptr(cat.t), cat.ld, st), "vs_upcat2x")
+                cv = self.new_act(f"up{k}.conv", B, cat.H, cat.W, up["conv"].N)
+                self.conv(cat, up["conv"], cv, pad=1, pad_mode=N.PAD_REFLECT)
+                ln = self.new_act(f"up{k}.ln", B, cat.H, cat.W, up["conv"].N)
+                self.layernorm(cv, up["lnw"], up["lnb"], ln, act=N.ACT_RELU)
+            lc = lowres_cat(k + 1, ln)
+            xcur = self.resblock(ln, up["rb"], f"up{k}", out=(Act(lc.t, B, lc.H, lc.W, up["rb"]["cout"], lc.ld) if lc else None))
         delta = self.buf("delta", B * c.out_ch * xcur.H * xcur.W)
         N.check(L.vs_outc_tanh(N.ptr(xcur.t), xcur.H * xcur.W, B, xcur.C, xcur.ld, N.ptr(E["outc_w"]), N.ptr(E["outc_b"]), c.out_ch,
                                1 if c.last_tanh else 0, N.ptr(delta), st), "vs_outc_tanh")
