@@ -165,6 +165,19 @@ int vs_upconv_gather_ln(const float* z, int64_t z_ld, int B, int H, int W, int C
 int vs_cat2_scale(const float* x, int C1, int64_t ld1, const float* skip, int C2, int64_t ld2, float skip_scale, int64_t rows,
                   float* out, int64_t out_ld, void* stream);
 
+/* The same Upsample group in ONE kernel for the thin levels (Co = 16 or 32, C1 % 16 == 0, C2 % 16 == 0, C1 + C2 <= 256): the nine-tap
+ * GEMM of an 8 x 8-cell tile (+ halo) runs on the matrix cores inside the workgroup and z stays in LDS; inputs are x and skip
+ * themselves (no concat buffer).  wt_split = the [3][9*Co][C1+C2] bf16 planes of the (tap, channel)-ordered weight (exact 3-term split). */
+int vs_upconv_fused_supported(int C1, int C2, int Co);
+int vs_upconv_fused(const float* x, int C1, int64_t ld1, const float* skip, int C2, int64_t ld2, float skip_scale, const void* wt_split,
+                    int B, int H, int W, int Co, const float* lnw, const float* lnb, float eps, int act, float* out, int64_t out_ld,
+                    void* stream);
+
+/* Patch matrix of a 3x3 / stride 1 / pad 1 conv (zero or reflect padding) on a small NHWC map: out[m][t*ld + c], m = (b, y, x),
+ * t = ky*3 + kx -- the K order of the packed conv weights, so the conv becomes vs_conv_gemm with KH = KW = 1, Cin = 9*ld on `out`
+ * (used for the pixel decoder's conv on the 8x8 map, pixel_decoder.py:44-48, whose 2048 rows cannot fill the chip as an implicit GEMM). */
+int vs_im2col3x3(const float* x, int B, int H, int W, int64_t ld, int pad_mode, float* out, void* stream);
+
 /* Message latent: lat[b][c] = sum_k table[2k + msg[b][k]][c].  msg_processor.py:88-98.  msgs are int32 0/1. */
 int vs_msg_latent(const float* table, const int32_t* msgs, int Bm, int nbits, int hidden, float* lat, void* stream);
 /* Broadcast lat[b or 0][0:hidden] over H*W pixels into channels [coff, coff+hidden) of dst.  msg_processor.py:96-115. */

@@ -440,7 +440,7 @@ def test_upcat2x(eng):
 
 
 @pytest.mark.parametrize("shape", [(2, 24, 8, 7, 9, 16), (1, 64, 64, 8, 16, 32), (2, 40, 24, 5, 6, 64), (1, 32, 32, 3, 3, 128),
-                                   (2, 16, 16, 1, 2, 16)])
+                                   (2, 16, 16, 1, 2, 16), (2, 32, 32, 19, 13, 16), (1, 48, 16, 9, 17, 32)])
 def test_upconv_lowres_gemm_gather_ln(eng, shape):
     """Upsample group (common.py:45-52) as cat2 -> 1x1 GEMM of the nine taps at the LOW resolution -> gather + LayerNorm + ReLU,
     against bilinear x2 -> ReflectionPad2d(1) -> Conv3x3 -> LayerNorm(channels_first) -> ReLU in torch fp32."""
@@ -466,6 +466,14 @@ def test_upconv_lowres_gemm_gather_ln(eng, shape):
                                         out.ld, N.stream()), "upconv_gather_ln")
     torch.cuda.synchronize()
     assert (from_nhwc(out) - ref).abs().max() < 2e-5          # LayerNorm output is O(1); fp32 re-association only
+    if eng.use_split and eng.lib.vs_upconv_fused_supported(C1, C2, Co):      # one-kernel form (z stays in LDS), same maths
+        out2 = eng.new_act("t.upln2", B, 2 * H, 2 * W, Co)
+        out2.t.fill_(-3.0)
+        cw = ConvW(wz, None, 9 * Co, 1, 1, cpz).with_split()
+        N.check(eng.lib.vs_upconv_fused(N.ptr(xa.t), C1, xa.ld, N.ptr(sa.t), C2, sa.ld, 2 ** -0.5, N.ptr(cw.split), B, H, W, Co,
+                                        N.ptr(dv(lw)), N.ptr(dv(lb)), 1e-6, N.ACT_RELU, N.ptr(out2.t), out2.ld, N.stream()), "upconv_fused")
+        torch.cuda.synchronize()
+        assert (from_nhwc(out2) - ref).abs().max() < 2e-5
     # x == NULL: the producer already wrote columns [0, C1)
     lc.t.view(B, H, W, lc.ld)[..., C1:] = -5.0
     N.check(eng.lib.vs_cat2_scale(None, C1, 0, N.ptr(sa.t), C2, sa.ld, 2 ** -0.5, lc.rows, N.ptr(lc.t), lc.ld, N.stream()), "cat2")

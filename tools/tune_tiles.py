@@ -32,6 +32,7 @@ def run(card, B, S, video, lowres, detect_only=False, rounds=8):
 run("videoseal_1.0", 32, 768, False, False)
 run("videoseal_1.0", 32, 768, True, False)
 run("videoseal_1.0", 16, 768, True, True)
+run("videoseal_1.0", 16, 768, True, False)      # chain mode (BASELINE configs[2]): 16-frame clip, full-resolution JND
 run("videoseal_1.0", 1, 256, False, False)
 if "--chunky" in sys.argv:
     run("chunkyseal", 16, 1024, False, False, detect_only=True, rounds=3)

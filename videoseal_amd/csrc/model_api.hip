@@ -47,7 +47,7 @@ struct vs_model {
   std::vector<Up> ups;
   float *outc_w = nullptr, *outc_b = nullptr, *table = nullptr;
   // extractor
-  CW stem, head;
+  CW stem, head, head_gemm;      // head_gemm: the same 3x3 weights seen as a 1x1 GEMM on the patch matrix (vs_im2col3x3)
   float *stem_lnw = nullptr, *stem_lnb = nullptr, *head_lnw = nullptr, *head_lnb = nullptr, *lin_w = nullptr, *lin_b = nullptr;
   Down down[3];
   std::vector<Blk> stages[4];
@@ -124,7 +124,7 @@ struct Packer {
           }
       }
   }
-  void finish(CW& cw, const std::vector<float>& wt, const std::vector<float>& bias, bool has_bias) {
+  void finish(CW& cw, const std::vector<float>& wt, const std::vector<float>& bias, bool has_bias, CW* as_gemm = nullptr) {
     cw.wt = upload(wt);
     if (has_bias) cw.bias = upload(bias);
     std::vector<uint16_t> planes, blk;
@@ -132,10 +132,17 @@ struct Packer {
     cw.split = upload(planes);
     blocked(planes, cw.N, cw.KH * cw.KW * cw.CinP, cw.KH * cw.KW, blk);
     cw.blk = upload(blk);
+    if (as_gemm) {                 // same rows read as one K run of KH*KW*CinP (K order (tap, channel)): blocked image in plain K order
+      *as_gemm = cw;
+      as_gemm->CinP = cw.KH * cw.KW * cw.CinP;
+      as_gemm->KH = as_gemm->KW = 1;
+      blocked(planes, cw.N, as_gemm->CinP, 1, blk);
+      as_gemm->blk = upload(blk);
+    }
   }
   // engine.py::pack_conv: [N,Cin,KH,KW] -> [N][tap][CinP], optional per-row scale (folded BatchNorm)
   void conv(CW& cw, const std::string& wkey, int cin, int kh, int kw, int in_ld, const std::vector<float>* scale,
-            const std::vector<float>* bias_v, const std::string& bias_key) {
+            const std::vector<float>* bias_v, const std::string& bias_key, CW* as_gemm = nullptr) {
     const HostT& w = get(wkey);
     if (!w.p) return;
     const int n = (int)(w.n / ((int64_t)cin * kh * kw));
@@ -153,7 +160,7 @@ struct Packer {
     bool hb = false;
     if (bias_v) { b = *bias_v; hb = true; }
     else if (!bias_key.empty()) { const HostT& t = get(bias_key); if (t.p) { b.assign(t.p, t.p + t.n); hb = true; } }
-    finish(cw, wt, b, hb);
+    finish(cw, wt, b, hb, as_gemm);
   }
   // engine.py::_pack_embedder (Upsample groups): [Co,Cin,3,3] -> rows (tap, channel) of a 1x1 GEMM on the low-resolution [x | skip] map
   void upconv9(CW& cw, const std::string& wkey, int cin, int cout) {
@@ -321,9 +328,13 @@ struct Runner {
     Act cur = h3;
     // Upsample group k on the low-resolution map: its [x | skip] concat buffer is allocated before x's producer runs, so that the
     // producer (last bottleneck block / previous up block) writes columns [0, C) itself (engine.py::embedder_forward)
+    auto fused_ok = [&](int k, int c1, int c2) -> bool {
+      return m->ups[k].lowres && vs_upconv_fused_supported(c1, c2, m->ups[k].gemm.N / 9) && m->ups[k].gemm.CinP == c1 + c2;
+    };
     auto lowres_cat = [&](int k, const Act& like, Act& view) -> bool {
       if (k >= nlev || !m->ups[k].lowres) return false;
       const Act& skip = hid[nlev - k];
+      if (fused_ok(k, like.C, skip.C)) return false;       // the one-kernel form reads x and skip themselves
       Act lc = act(B, like.H, like.W, like.C + skip.C);
       view = Act{lc.p, B, like.H, like.W, like.C, lc.ld};
       return true;
@@ -338,7 +349,12 @@ struct Runner {
       hid.pop_back();
       const Up& up = m->ups[k];
       Act ln{};
-      if (up.lowres) {
+      if (up.lowres && cur.ld == cur.C && fused_ok(k, cur.C, skip.C)) {
+        const int co = up.gemm.N / 9;
+        ln = act(B, 2 * cur.H, 2 * cur.W, co);
+        if (live()) chk(vs_upconv_fused(cur.p, cur.C, cur.ld, skip.p, skip.C, skip.ld, 0.70710678118654752440f, up.gemm.split, B, cur.H, cur.W, co,
+                                        up.lnw, up.lnb, 1e-6f, VS_ACT_RELU, ln.p, ln.ld, st));
+      } else if (up.lowres) {
         const int co = up.gemm.N / 9;
         const bool direct = cur.ld == cur.C + skip.C;
         Act lc = direct ? Act{cur.p, B, cur.H, cur.W, cur.C + skip.C, cur.ld} : act(B, cur.H, cur.W, cur.C + skip.C);
@@ -408,7 +424,13 @@ struct Runner {
       }
     }
     Act hc = act(B, cur.H, cur.W, c.dims[3]);
-    conv(cur, m->head, hc, 1, 1, VS_PAD_REFLECT);
+    if (cur.rows() <= 4096 && cur.H > 1 && cur.W > 1 && m->head.CinP == cur.ld) {       // engine.py::extractor_forward
+      Act cols{alloc(cur.rows() * 9 * cur.ld), B, cur.H, cur.W, 9 * cur.ld, 9 * cur.ld};
+      if (live()) chk(vs_im2col3x3(cur.p, B, cur.H, cur.W, cur.ld, VS_PAD_REFLECT, cols.p, st));
+      conv(cols, m->head_gemm, hc);
+    } else {
+      conv(cur, m->head, hc, 1, 1, VS_PAD_REFLECT);
+    }
     Act hl = act(B, cur.H, cur.W, c.dims[3]);
     layernorm(hc, m->head_lnw, m->head_lnb, hl, VS_ACT_GELU);
     if (live()) chk(vs_pool_linear(hl.p, B, hl.H * hl.W, hl.C, hl.ld, m->lin_w, m->lin_b, c.nbits + 1, logits, st));
@@ -531,7 +553,7 @@ extern "C" int vs_model_create(const vs_model_cfg_t* cfg, const vs_tensor_t* ten
     }
   }
   const std::string pd = "detector.pixel_decoder";
-  P.conv(m->head, pd + ".output_upscaling.0.upsample_block.2.weight", cfg->dims[3], 3, 3, xld(cfg->dims[3]), nullptr, nullptr, "");
+  P.conv(m->head, pd + ".output_upscaling.0.upsample_block.2.weight", cfg->dims[3], 3, 3, xld(cfg->dims[3]), nullptr, nullptr, "", &m->head_gemm);
   m->head_lnw = P.vec(pd + ".output_upscaling.0.upsample_block.3.weight");
   m->head_lnb = P.vec(pd + ".output_upscaling.0.upsample_block.3.bias");
   m->lin_w = P.vec(pd + ".linear.weight");

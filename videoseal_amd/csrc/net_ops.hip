@@ -495,6 +495,34 @@ __global__ __launch_bounds__(256) void upconv_gather_ln_kernel(const float* __re
   }
 }
 
+// 3x3 / stride 1 / pad 1 patch matrix of a SMALL map: out[m][t*ld + c] = in[b][p(y+ky-1)][p(x+kx-1)][c], p = reflect or zero padding.
+// Turns the pixel decoder's 3x3 conv on the 8x8 map (pixel_decoder.py:44-48: 2048 rows at 32 frames, K = 6912) into a dense 1x1 GEMM
+// that the wave-specialised split-K kernel can spread over all CUs (the implicit-GEMM conv had 96 workgroups for 256 CUs).
+__global__ __launch_bounds__(256) void im2col3x3_kernel(const float* __restrict__ x, int H, int W, int64_t ld, int reflect,
+                                                        float* __restrict__ out, int64_t total) {
+  const int G = (int)(ld >> 2);
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int cg = (int)(i % G);
+    int64_t r = i / G;
+    const int t = (int)(r % 9);
+    r /= 9;                                   // output row m = (b, y, x)
+    const int xx = (int)(r % W);
+    const int yy = (int)((r / W) % H);
+    const int64_t b = r / ((int64_t)W * H);
+    int sy = yy + t / 3 - 1, sx = xx + t % 3 - 1;
+    bool ok = true;
+    if (reflect) {
+      sy = sy < 0 ? -sy : (sy >= H ? 2 * H - 2 - sy : sy);
+      sx = sx < 0 ? -sx : (sx >= W ? 2 * W - 2 - sx : sx);
+    } else {
+      ok = sy >= 0 && sy < H && sx >= 0 && sx < W;
+    }
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (ok) v = *reinterpret_cast<const f32x4*>(x + ((b * H + sy) * W + sx) * ld + cg * 4);
+    *reinterpret_cast<f32x4*>(out + (r * 9 + t) * ld + cg * 4) = v;
+  }
+}
+
 // channel concat of two NHWC maps of the same pixels, the second one scaled: out[r] = [x[r] | skip[r] * s]  (unet.py:186-187 at the
 // LOW resolution).  x may be NULL when its producer already wrote columns [0, C1) of `out`.
 __global__ __launch_bounds__(256) void cat2_scale_kernel(const float* __restrict__ x, int C1, int64_t ld1, const float* __restrict__ skip,
@@ -801,6 +829,14 @@ extern "C" int vs_cat2_scale(const float* x, int C1, int64_t ld1, const float* s
   const int64_t total = rows * ((x ? C1 : 0) + C2) / 4;
   hipLaunchKernelGGL(cat2_scale_kernel, dim3((unsigned)std::min<int64_t>(cdiv64(total, 256), 1 << 16)), dim3(256), 0, (hipStream_t)stream,
                      x, C1, ld1, skip, C2, ld2, skip_scale, rows, out, out_ld);
+  return vs_launch_status();
+}
+
+extern "C" int vs_im2col3x3(const float* x, int B, int H, int W, int64_t ld, int pad_mode, float* out, void* stream) {
+  VS_REQUIRE(x && out && B > 0 && H > 1 && W > 1 && ld > 0 && ld % 4 == 0);
+  const int64_t total = (int64_t)B * H * W * 9 * (ld / 4);
+  hipLaunchKernelGGL(im2col3x3_kernel, dim3((unsigned)std::min<int64_t>(cdiv64(total, 256), 1 << 16)), dim3(256), 0, (hipStream_t)stream, x, H,
+                     W, ld, pad_mode == VS_PAD_REFLECT ? 1 : 0, out, total);
   return vs_launch_status();
 }
 

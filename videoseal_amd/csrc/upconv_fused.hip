@@ -1,0 +1,242 @@
+// Upsample group of the U-Net in ONE kernel for the thin full-resolution levels (common.py:45-52 after unet.py:186-187):
+//   cat(x, skip * 2^-1/2) -> bilinear x2 -> ReflectionPad2d(1) -> Conv3x3 (no bias) -> LayerNorm(C) -> ReLU
+// computed as in vs_upconv_gather_ln (net_ops.hip): the nine per-tap products z_t = W_t [x | skip] are taken on the LOW-resolution
+// map (a quarter of the conv's MACs) and the interpolation / padding / tap shift become a 36-term gather.  Here the GEMM runs
+// inside the workgroup on the matrix cores (3 x bf16 split, six v_mfma_f32_32x32x16_bf16 per product like vs_conv_gemm) and z
+// lives only in LDS: at 128^2 x 64 -> 16 channels x 32 frames the two-kernel form writes and re-reads 302 MB of z for 134 MB of
+// input and 134 MB of output; this kernel touches the 268 MB only.
+//
+// Workgroup = 8 x 8 low-resolution cells (16 x 16 output pixels) of one frame, 4 waves:
+//   1. K loop over 16-channel chunks of [x | skip]: the 10 x 10 halo pixels (rows padded to 128) are loaded, scaled, split into
+//      three bf16 planes and stored to LDS next to the chunk of the pre-split weights ([3][9*Co][K] bf16); wave w multiplies
+//      row block w by all NB column blocks;
+//   2. accumulators -> z tile in LDS [100][9*Co (+4)] (the staging buffers are dead by then and are reused);
+//   3. gather + LayerNorm + activation: 4 lanes per output pixel, Co/4 channels each, two quad shuffles, 16-byte stores.
+#include <algorithm>
+
+#include "conv_common.h"
+
+namespace {
+
+using namespace vsconv;
+
+constexpr int UT = 8;                 // low-resolution cells per tile edge
+constexpr int UH = UT + 2;            // with halo
+constexpr int UROWS = 128;            // UH*UH = 100 halo pixels padded to 4 MFMA row blocks
+
+template <int NB, int CG>
+__global__ __launch_bounds__(256) void upconv_fused_kernel(const float* __restrict__ x, int C1, int64_t ld1, const float* __restrict__ skip,
+                                                           int C2, int64_t ld2, float sscale, const unsigned short* __restrict__ wsplit,
+                                                           int H, int W, int Co, const float* __restrict__ lnw,
+                                                           const float* __restrict__ lnb, float eps, int act, float* __restrict__ out,
+                                                           int64_t old, int tiles_x, int tiles_y, int nblk) {
+  constexpr int BN = NB * 32;
+  constexpr int A_BYTES = 3 * UROWS * ROWB, B_BYTES = 3 * BN * ROWB;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_u[];
+  unsigned char* const As = smem_u;
+  unsigned char* const Bs = smem_u + A_BYTES;
+  float* const Z = reinterpret_cast<float*>(smem_u);      // reused after the K loop
+  const int N = 9 * Co, K = C1 + C2, ZS = N + 4;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 31, g = lane >> 5;
+  const int per = (nblk + 7) >> 3;                        // XCD-aware order (block b runs on XCD b % 8): neighbouring tiles share halos in L2
+  const int vb = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
+  if (vb >= nblk) return;
+  const int tx = vb % tiles_x;
+  const int t1 = vb / tiles_x;
+  const int ty = t1 % tiles_y;
+  const int b = t1 / tiles_y;
+  const int y0 = ty * UT - 1, x0 = tx * UT - 1;           // low-resolution origin of the halo tile
+
+  // ---- A rows of this thread: 2 float4 slots per chunk (128 rows x 4)
+  int64_t a_pix[2];
+  int a_lds[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int s = tid + i * 256;
+    const int row = s >> 2;
+    const int hy = row < UH * UH ? row / UH : 0, hx = row < UH * UH ? row % UH : 0;
+    const int py = min(max(y0 + hy, 0), H - 1), px = min(max(x0 + hx, 0), W - 1);   // clamped: rows outside the image are never gathered
+    a_pix[i] = ((int64_t)b * H + py) * W + px;
+    a_lds[i] = row * ROWB + (s & 3) * 8;
+  }
+  const int k4 = (tid & 3) * 4;
+  constexpr int BSLOT = BN * 2;                           // 16-byte slots per plane per chunk
+  constexpr int NBL = (BSLOT + 255) / 256;
+
+  f32x16 acc[NB];
+#pragma unroll
+  for (int j = 0; j < NB; ++j)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[j][e] = 0.f;
+
+  for (int kc = 0; kc < K; kc += BK) {
+    // global -> registers
+    f32x4 ra[2];
+    const bool from_x = kc < C1;                          // C1 % 16 == 0: a chunk never straddles the concat boundary
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      if (from_x) ra[i] = *reinterpret_cast<const f32x4*>(x + a_pix[i] * ld1 + kc + k4);
+      else ra[i] = *reinterpret_cast<const f32x4*>(skip + a_pix[i] * ld2 + (kc - C1) + k4) * sscale;
+    }
+    u32x4 rb[NBL][3];
+#pragma unroll
+    for (int i = 0; i < NBL; ++i) {
+      const int s = tid + i * 256;
+      const int row = s >> 1, sub = s & 1;
+#pragma unroll
+      for (int p = 0; p < 3; ++p) {
+        rb[i][p] = u32x4{0u, 0u, 0u, 0u};
+        if (s < BSLOT && row < N) rb[i][p] = *reinterpret_cast<const u32x4*>(wsplit + ((int64_t)p * N + row) * K + kc + sub * 8);
+      }
+    }
+    if (kc) __syncthreads();                              // the previous chunk's fragments have been read
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      u32x2 p1, p2, p3;
+      split4(ra[i], p1, p2, p3);
+      *reinterpret_cast<u32x2*>(As + a_lds[i]) = p1;
+      *reinterpret_cast<u32x2*>(As + UROWS * ROWB + a_lds[i]) = p2;
+      *reinterpret_cast<u32x2*>(As + 2 * UROWS * ROWB + a_lds[i]) = p3;
+    }
+#pragma unroll
+    for (int i = 0; i < NBL; ++i) {
+      const int s = tid + i * 256;
+      if (s < BSLOT) {
+#pragma unroll
+        for (int p = 0; p < 3; ++p) *reinterpret_cast<u32x4*>(Bs + p * BN * ROWB + (s >> 1) * ROWB + (s & 1) * 16) = rb[i][p];
+      }
+    }
+    __syncthreads();
+    bf16x8 af[3], bf[NB][3];
+#pragma unroll
+    for (int p = 0; p < 3; ++p) af[p] = *reinterpret_cast<const bf16x8*>(As + p * UROWS * ROWB + (wave * 32 + r) * ROWB + g * 16);
+#pragma unroll
+    for (int j = 0; j < NB; ++j)
+#pragma unroll
+      for (int p = 0; p < 3; ++p) bf[j][p] = *reinterpret_cast<const bf16x8*>(Bs + p * BN * ROWB + (j * 32 + r) * ROWB + g * 16);
+#pragma unroll
+    for (int q = 0; q < 6; ++q) {                         // smallest partial products first, as in conv_gemm.hip
+      constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};
+#pragma unroll
+      for (int j = 0; j < NB; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[PA[q]], bf[j][PB[q]], acc[j], 0, 0, 0);
+    }
+  }
+  __syncthreads();                                        // all fragment reads done: the staging area becomes the z tile
+  // C/D layout of the 32x32 MFMA: column = lane & 31, row = (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5)
+#pragma unroll
+  for (int j = 0; j < NB; ++j) {
+    const int n = j * 32 + r;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int m = wave * 32 + (e & 3) + 8 * (e >> 2) + 4 * g;
+      if (m < UH * UH && n < N) Z[m * ZS + n] = acc[j][e];
+    }
+  }
+  __syncthreads();
+
+  // ---- gather + LayerNorm + activation: 16 x 16 output pixels, 4 lanes per pixel
+  constexpr int NV = CG / 4;
+  const int q4 = tid & 3;
+  const int H2 = 2 * H, W2 = 2 * W;
+  const float invC = 1.0f / (float)Co;
+  for (int it = tid >> 2; it < 4 * UT * UT; it += 64) {
+    const int oy = it / (2 * UT), ox = it % (2 * UT);
+    const int Y = (y0 + 1) * 2 + oy, X = (x0 + 1) * 2 + ox;
+    const bool live = Y < H2 && X < W2;
+    const int Yc = min(Y, H2 - 1), Xc = min(X, W2 - 1);
+    int ys[3][2], xs[3][2];
+    float wy[3][2], wx[3][2];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      int yr = Yc + k - 1, xr = Xc + k - 1;
+      yr = yr < 0 ? -yr : (yr >= H2 ? 2 * H2 - 2 - yr : yr);
+      xr = xr < 0 ? -xr : (xr >= W2 ? 2 * W2 - 2 - xr : xr);
+      const float sy = fmaxf((yr + 0.5f) * 0.5f - 0.5f, 0.f), sx = fmaxf((xr + 0.5f) * 0.5f - 0.5f, 0.f);
+      const int yl = (int)sy, xl = (int)sx;
+      ys[k][0] = yl - y0; ys[k][1] = yl + (yl < H - 1) - y0;          // tile-relative low-resolution coordinates
+      xs[k][0] = xl - x0; xs[k][1] = xl + (xl < W - 1) - x0;
+      wy[k][1] = sy - yl; wy[k][0] = 1.f - wy[k][1];
+      wx[k][1] = sx - xl; wx[k][0] = 1.f - wx[k][1];
+    }
+    f32x4 v[NV];
+#pragma unroll
+    for (int j = 0; j < NV; ++j) v[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const float* zb = Z + q4 * CG;
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+      for (int a = 0; a < 2; ++a) {
+        const float* zr = zb + ys[ky][a] * UH * ZS + ky * 3 * Co;
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+          for (int c = 0; c < 2; ++c) {
+            const float w = wy[ky][a] * wx[kx][c];
+            const float* qz = zr + xs[kx][c] * ZS + kx * Co;
+#pragma unroll
+            for (int j = 0; j < NV; ++j) v[j] += w * *reinterpret_cast<const f32x4*>(qz + 4 * j);
+          }
+      }
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < NV; ++j) s += (v[j][0] + v[j][1]) + (v[j][2] + v[j][3]);
+    s += __shfl_xor(s, 1, 64);
+    s += __shfl_xor(s, 2, 64);
+    const float mean = s * invC;
+    float var = 0.f;
+#pragma unroll
+    for (int j = 0; j < NV; ++j)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { const float dl = v[j][e] - mean; var += dl * dl; }
+    var += __shfl_xor(var, 1, 64);
+    var += __shfl_xor(var, 2, 64);
+    const float den = sqrtf(var * invC + eps);
+    if (!live) continue;
+    float* orow = out + (((int64_t)b * H2 + Y) * W2 + X) * old + q4 * CG;
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+      const f32x4 wv = *reinterpret_cast<const f32x4*>(lnw + q4 * CG + 4 * j), bv = *reinterpret_cast<const f32x4*>(lnb + q4 * CG + 4 * j);
+      f32x4 o;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) o[e] = vs_apply_act(wv[e] * ((v[j][e] - mean) / den) + bv[e], act);
+      *reinterpret_cast<f32x4*>(orow + 4 * j) = o;
+    }
+  }
+}
+
+template <int NB, int CG>
+int launch_fused(const float* x, int C1, int64_t ld1, const float* skip, int C2, int64_t ld2, float s, const void* wsplit, int B, int H, int W,
+                 int Co, const float* lnw, const float* lnb, float eps, int act, float* out, int64_t old, hipStream_t st) {
+  const size_t stage = 3 * (size_t)(UROWS + NB * 32) * ROWB, ztile = (size_t)UH * UH * (9 * Co + 4) * sizeof(float);
+  const size_t smem = std::max(stage, ztile);
+  if (smem > 160 * 1024) return VS_ERR_UNSUPPORTED;
+  auto kern = upconv_fused_kernel<NB, CG>;
+  static bool attr = false;
+  if (smem > 64 * 1024 && !attr) {
+    (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr = true;
+  }
+  const int tiles_x = (W + UT - 1) / UT, tiles_y = (H + UT - 1) / UT;
+  const int64_t nblk = (int64_t)B * tiles_x * tiles_y;
+  if (nblk >= (1 << 30)) return VS_ERR_UNSUPPORTED;
+  hipLaunchKernelGGL(kern, dim3((unsigned)((nblk + 7) / 8 * 8)), dim3(256), smem, st, x, C1, ld1, skip, C2, ld2, s,
+                     static_cast<const unsigned short*>(wsplit), H, W, Co, lnw, lnb, eps, act, out, old, tiles_x, tiles_y, (int)nblk);
+  return vs_launch_status();
+}
+
+}  // namespace
+
+extern "C" int vs_upconv_fused_supported(int C1, int C2, int Co) {
+  return (Co == 16 || Co == 32) && C1 > 0 && C2 > 0 && C1 % 16 == 0 && C2 % 16 == 0 && C1 + C2 <= 256;
+}
+
+extern "C" int vs_upconv_fused(const float* x, int C1, int64_t ld1, const float* skip, int C2, int64_t ld2, float skip_scale,
+                               const void* wt_split, int B, int H, int W, int Co, const float* lnw, const float* lnb, float eps, int act,
+                               float* out, int64_t out_ld, void* stream) {
+  VS_REQUIRE(x && skip && wt_split && lnw && lnb && out && B > 0 && H > 0 && W > 0 && vs_upconv_fused_supported(C1, C2, Co));
+  VS_REQUIRE(ld1 % 4 == 0 && ld2 % 4 == 0 && ld1 >= C1 && ld2 >= C2 && out_ld % 4 == 0 && out_ld >= Co && ((uintptr_t)wt_split & 15) == 0);
+  hipStream_t st = (hipStream_t)stream;
+  if (Co == 16) return launch_fused<5, 4>(x, C1, ld1, skip, C2, ld2, skip_scale, wt_split, B, H, W, Co, lnw, lnb, eps, act, out, out_ld, st);
+  return launch_fused<9, 8>(x, C1, ld1, skip, C2, ld2, skip_scale, wt_split, B, H, W, Co, lnw, lnb, eps, act, out, out_ld, st);
+}

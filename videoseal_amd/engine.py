@@ -149,6 +149,7 @@ class HipEngine:
         # Upsample groups as a low-resolution 9-tap GEMM + gather (a quarter of the MACs, no up-sampled concat); 0 = the literal
         # bilinear x2 -> reflect-pad conv3x3 -> LayerNorm sequence (kept for A/B checks)
         self.upconv_lowres = os.environ.get("VIDEOSEAL_UPCONV", "lowres") != "direct"
+        self.upconv_fused = os.environ.get("VIDEOSEAL_UPCONV", "lowres") != "unfused"    # thin levels: GEMM + gather in one kernel
         # per-shape tile selection: every candidate walks K in the same order, so the result is bit-identical whatever
         # tile wins -- only speed changes (measure, don't guess).  VIDEOSEAL_AUTOTUNE=0 keeps the static heuristic.
         self.autotune = os.environ.get("VIDEOSEAL_AUTOTUNE", "1") != "0"
@@ -579,9 +580,14 @@ class HipEngine:
         N.check(L.vs_broadcast_channels(N.ptr(lat), Bm, c.hidden, N.ptr(h3.t), B, h3.H * h3.W, h3.ld, c.zc[-1], st),
                 "vs_broadcast_channels")
         xcur = h3
+        def fused_ok(k: int, c1: int, c2: int) -> bool:
+            up_ = E["ups"][k]
+            return bool(self.upconv_fused and self.use_split and "gemm" in up_ and L.vs_upconv_fused_supported(c1, c2, up_["gemm"].N // 9)
+                        and up_["gemm"].CinP == c1 + c2)
+
         def lowres_cat(k: int, like: Act) -> Optional[Act]:
             """[x | skip] of Upsample group k at the LOW resolution; the producer of x writes columns [0, C) itself (eval mode)"""
-            if k >= nlev or "gemm" not in E["ups"][k] or bn_train:
+            if k >= nlev or "gemm" not in E["ups"][k] or bn_train or fused_ok(k, like.C, hid[nlev - k].C):
                 return None
             return self.new_act(f"up{k}.lcat", B, like.H, like.W, like.C + hid[nlev - k].C)
 
@@ -591,7 +597,13 @@ class HipEngine:
         for k in range(nlev):
             skip = hid.pop()
             up = E["ups"][k]
-            if "gemm" in up:       # low-resolution 9-tap GEMM + gather / LayerNorm / ReLU (see vs_upconv_gather_ln)
+            if "gemm" in up and xcur.ld == xcur.C and fused_ok(k, xcur.C, skip.C):     # thin levels: one kernel, z stays in LDS
+                co = up["gemm"].N // 9
+                ln = self.new_act(f"up{k}.ln", B, 2 * xcur.H, 2 * xcur.W, co)
+                N.check(L.vs_upconv_fused(N.ptr(xcur.t), xcur.C, xcur.ld, N.ptr(skip.t), skip.C, skip.ld, 2 ** -0.5,
+                                          N.ptr(up["gemm"].with_split().split), B, xcur.H, xcur.W, co, N.ptr(up["lnw"]), N.ptr(up["lnb"]),
+                                          1e-6, N.ACT_RELU, N.ptr(ln.t), ln.ld, st), "vs_upconv_fused")
+            elif "gemm" in up:     # low-resolution 9-tap GEMM + gather / LayerNorm / ReLU (see vs_upconv_gather_ln)
                 co = up["gemm"].N // 9
                 direct = xcur.ld == xcur.C + skip.C      # x already sits in columns [0, C) of the concat buffer
                 lc = Act(xcur.t, B, xcur.H, xcur.W, xcur.C + skip.C, xcur.ld) if direct else \
@@ -668,7 +680,16 @@ class HipEngine:
                     N.check(L.vs_grn_apply(N.ptr(hh.t), B, HW, 4 * Cc, hh.ld, N.ptr(scale), hh.ld, N.ptr(blk["beta"]), st), "vs_grn_apply")
                     self.conv(hh, blk["pw2"], cur, res=cur)
         hc = self.new_act("head.c", B, cur.H, cur.W, d[-1])
-        self.conv(cur, X["head_conv"], hc, pad=1, pad_mode=N.PAD_REFLECT)
+        hw = X["head_conv"]
+        if cur.rows <= 4096 and cur.H > 1 and cur.W > 1 and hw.CinP == cur.ld and self.use_split:
+            # few rows, long K (VideoSeal: 2048 x 6912): patch matrix + dense split-K GEMM instead of 96 implicit-GEMM workgroups
+            if "head_gemm" not in X:
+                X["head_gemm"] = ConvW(hw.wt, None, hw.N, 1, 1, 9 * hw.CinP)
+            cols = Act(self.buf("head.cols", cur.rows * 9 * cur.ld), B, cur.H, cur.W, 9 * cur.ld, 9 * cur.ld)
+            N.check(L.vs_im2col3x3(N.ptr(cur.t), B, cur.H, cur.W, cur.ld, N.PAD_REFLECT, N.ptr(cols.t), st), "vs_im2col3x3")
+            self.conv(cols, X["head_gemm"], hc)
+        else:
+            self.conv(cur, hw, hc, pad=1, pad_mode=N.PAD_REFLECT)
         hl = self.new_act("head.l", B, cur.H, cur.W, d[-1])
         self.layernorm(hc, X["head_ln"][0], X["head_ln"][1], hl, act=N.ACT_GELU)
         out = self.buf("logits", B * (c.nbits + 1)).view(B, c.nbits + 1)
