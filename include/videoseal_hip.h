@@ -169,6 +169,7 @@ int vs_cat2_scale(const float* x, int C1, int64_t ld1, const float* skip, int C2
  * GEMM of an 8 x 8-cell tile (+ halo) runs on the matrix cores inside the workgroup and z stays in LDS; inputs are x and skip
  * themselves (no concat buffer).  wt_split = the [3][9*Co][C1+C2] bf16 planes of the (tap, channel)-ordered weight (exact 3-term split). */
 int vs_upconv_fused_supported(int C1, int C2, int Co);
+int vs_upconv_fused_preferred(int C1, int C2, int Co);   /* supported AND measured faster than GEMM + gather (Co = 16 levels) */
 int vs_upconv_fused(const float* x, int C1, int64_t ld1, const float* skip, int C2, int64_t ld2, float skip_scale, const void* wt_split,
                     int B, int H, int W, int Co, const float* lnw, const float* lnb, float eps, int act, float* out, int64_t out_ld,
                     void* stream);

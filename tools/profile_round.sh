@@ -7,6 +7,7 @@ O=$R/gpurun_out/$TAG; mkdir -p $O
 python bench.py --steps 30 --warmup 3 > $O/bench_image.json 2> $O/bench_image.err
 python bench.py --mode video --steps 30 --warmup 3 --no-cpu-baseline > $O/bench_video.json 2> $O/bench_video.err
 python bench.py --mode stream --no-cpu-baseline > $O/bench_stream.json 2> $O/bench_stream.err
+python bench.py --mode chain --steps 30 --warmup 3 --no-cpu-baseline > $O/bench_chain.json 2> $O/bench_chain.err
 cd /tmp
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O -o img -- python $R/bench.py --no-cpu-baseline --no-kernel-timers --steps 10 --warmup 2 > $O/img.log 2>&1
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O -o vid -- python $R/bench.py --mode video --no-cpu-baseline --no-kernel-timers --steps 10 --warmup 2 > $O/vid.log 2>&1

@@ -329,7 +329,7 @@ struct Runner {
     // Upsample group k on the low-resolution map: its [x | skip] concat buffer is allocated before x's producer runs, so that the
     // producer (last bottleneck block / previous up block) writes columns [0, C) itself (engine.py::embedder_forward)
     auto fused_ok = [&](int k, int c1, int c2) -> bool {
-      return m->ups[k].lowres && vs_upconv_fused_supported(c1, c2, m->ups[k].gemm.N / 9) && m->ups[k].gemm.CinP == c1 + c2;
+      return m->ups[k].lowres && vs_upconv_fused_preferred(c1, c2, m->ups[k].gemm.N / 9) && m->ups[k].gemm.CinP == c1 + c2;
     };
     auto lowres_cat = [&](int k, const Act& like, Act& view) -> bool {
       if (k >= nlev || !m->ups[k].lowres) return false;

@@ -13,6 +13,7 @@
 //   2. accumulators -> z tile in LDS [100][9*Co (+4)] (the staging buffers are dead by then and are reused);
 //   3. gather + LayerNorm + activation: 4 lanes per output pixel, Co/4 channels each, two quad shuffles, 16-byte stores.
 #include <algorithm>
+#include <cstdlib>
 
 #include "conv_common.h"
 
@@ -29,9 +30,9 @@ __global__ __launch_bounds__(256) void upconv_fused_kernel(const float* __restri
                                                            int C2, int64_t ld2, float sscale, const unsigned short* __restrict__ wsplit,
                                                            int H, int W, int Co, const float* __restrict__ lnw,
                                                            const float* __restrict__ lnb, float eps, int act, float* __restrict__ out,
-                                                           int64_t old, int tiles_x, int tiles_y, int nblk) {
+                                                           int64_t old, int tiles_x, int tiles_y, int nblk, int abl) {
   constexpr int BN = NB * 32;
-  constexpr int A_BYTES = 3 * UROWS * ROWB, B_BYTES = 3 * BN * ROWB;
+  constexpr int A_BYTES = 3 * UROWS * ROWB;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_u[];
   unsigned char* const As = smem_u;
   unsigned char* const Bs = smem_u + A_BYTES;
@@ -70,16 +71,12 @@ __global__ __launch_bounds__(256) void upconv_fused_kernel(const float* __restri
 #pragma unroll
     for (int e = 0; e < 16; ++e) acc[j][e] = 0.f;
 
-  for (int kc = 0; kc < K; kc += BK) {
-    // global -> registers
-    f32x4 ra[2];
-    const bool from_x = kc < C1;                          // C1 % 16 == 0: a chunk never straddles the concat boundary
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      if (from_x) ra[i] = *reinterpret_cast<const f32x4*>(x + a_pix[i] * ld1 + kc + k4);
-      else ra[i] = *reinterpret_cast<const f32x4*>(skip + a_pix[i] * ld2 + (kc - C1) + k4) * sscale;
-    }
-    u32x4 rb[NBL][3];
+  // The activation rows of up to KG chunks (128 channels) are requested in ONE burst per group -- with one chunk (8 KB per workgroup)
+  // in flight the kernel paid the full HBM latency once per chunk and ran at a quarter of the bandwidth; the weight chunk of step
+  // c+1 (L2-resident) is fetched while step c multiplies.
+  constexpr int KG = 8;
+  u32x4 rb[NBL][3];
+  auto fetch_b = [&](const int kc) __attribute__((always_inline)) {
 #pragma unroll
     for (int i = 0; i < NBL; ++i) {
       const int s = tid + i * 256;
@@ -90,36 +87,59 @@ __global__ __launch_bounds__(256) void upconv_fused_kernel(const float* __restri
         if (s < BSLOT && row < N) rb[i][p] = *reinterpret_cast<const u32x4*>(wsplit + ((int64_t)p * N + row) * K + kc + sub * 8);
       }
     }
-    if (kc) __syncthreads();                              // the previous chunk's fragments have been read
+  };
+  fetch_b(0);
+  for (int kg = 0; kg < ((abl & 1) ? 0 : K); kg += KG * BK) {      // abl: tools/bench_upconv.py ablations (1: no GEMM, 2: no gather)
+    f32x4 ra[KG][2];
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      u32x2 p1, p2, p3;
-      split4(ra[i], p1, p2, p3);
-      *reinterpret_cast<u32x2*>(As + a_lds[i]) = p1;
-      *reinterpret_cast<u32x2*>(As + UROWS * ROWB + a_lds[i]) = p2;
-      *reinterpret_cast<u32x2*>(As + 2 * UROWS * ROWB + a_lds[i]) = p3;
-    }
+    for (int c = 0; c < KG; ++c) {
+      const int kc = kg + c * BK;
+      if (kc < K) {
+        const bool from_x = kc < C1;                      // C1 % 16 == 0: a chunk never straddles the concat boundary
 #pragma unroll
-    for (int i = 0; i < NBL; ++i) {
-      const int s = tid + i * 256;
-      if (s < BSLOT) {
-#pragma unroll
-        for (int p = 0; p < 3; ++p) *reinterpret_cast<u32x4*>(Bs + p * BN * ROWB + (s >> 1) * ROWB + (s & 1) * 16) = rb[i][p];
+        for (int i = 0; i < 2; ++i) {
+          if (from_x) ra[c][i] = *reinterpret_cast<const f32x4*>(x + a_pix[i] * ld1 + kc + k4);
+          else ra[c][i] = *reinterpret_cast<const f32x4*>(skip + a_pix[i] * ld2 + (kc - C1) + k4) * sscale;
+        }
       }
     }
-    __syncthreads();
-    bf16x8 af[3], bf[NB][3];
 #pragma unroll
-    for (int p = 0; p < 3; ++p) af[p] = *reinterpret_cast<const bf16x8*>(As + p * UROWS * ROWB + (wave * 32 + r) * ROWB + g * 16);
+    for (int c = 0; c < KG; ++c) {
+      const int kc = kg + c * BK;
+      if (kc < K) {
+        if (kc) __syncthreads();                          // the previous chunk's fragments have been read
 #pragma unroll
-    for (int j = 0; j < NB; ++j)
+        for (int i = 0; i < 2; ++i) {
+          u32x2 p1, p2, p3;
+          split4(ra[c][i], p1, p2, p3);
+          *reinterpret_cast<u32x2*>(As + a_lds[i]) = p1;
+          *reinterpret_cast<u32x2*>(As + UROWS * ROWB + a_lds[i]) = p2;
+          *reinterpret_cast<u32x2*>(As + 2 * UROWS * ROWB + a_lds[i]) = p3;
+        }
 #pragma unroll
-      for (int p = 0; p < 3; ++p) bf[j][p] = *reinterpret_cast<const bf16x8*>(Bs + p * BN * ROWB + (j * 32 + r) * ROWB + g * 16);
+        for (int i = 0; i < NBL; ++i) {
+          const int s = tid + i * 256;
+          if (s < BSLOT) {
 #pragma unroll
-    for (int q = 0; q < 6; ++q) {                         // smallest partial products first, as in conv_gemm.hip
-      constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};
+            for (int p = 0; p < 3; ++p) *reinterpret_cast<u32x4*>(Bs + p * BN * ROWB + (s >> 1) * ROWB + (s & 1) * 16) = rb[i][p];
+          }
+        }
+        __syncthreads();
+        if (kc + BK < K) fetch_b(kc + BK);
+        bf16x8 af[3], bf[NB][3];
 #pragma unroll
-      for (int j = 0; j < NB; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[PA[q]], bf[j][PB[q]], acc[j], 0, 0, 0);
+        for (int p = 0; p < 3; ++p) af[p] = *reinterpret_cast<const bf16x8*>(As + p * UROWS * ROWB + (wave * 32 + r) * ROWB + g * 16);
+#pragma unroll
+        for (int j = 0; j < NB; ++j)
+#pragma unroll
+          for (int p = 0; p < 3; ++p) bf[j][p] = *reinterpret_cast<const bf16x8*>(Bs + p * BN * ROWB + (j * 32 + r) * ROWB + g * 16);
+#pragma unroll
+        for (int q = 0; q < 6; ++q) {                     // smallest partial products first, as in conv_gemm.hip
+          constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};
+#pragma unroll
+          for (int j = 0; j < NB; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[PA[q]], bf[j][PB[q]], acc[j], 0, 0, 0);
+        }
+      }
     }
   }
   __syncthreads();                                        // all fragment reads done: the staging area becomes the z tile
@@ -140,7 +160,7 @@ __global__ __launch_bounds__(256) void upconv_fused_kernel(const float* __restri
   const int q4 = tid & 3;
   const int H2 = 2 * H, W2 = 2 * W;
   const float invC = 1.0f / (float)Co;
-  for (int it = tid >> 2; it < 4 * UT * UT; it += 64) {
+  for (int it = tid >> 2; it < ((abl & 2) ? 0 : 4 * UT * UT); it += 64) {
     const int oy = it / (2 * UT), ox = it % (2 * UT);
     const int Y = (y0 + 1) * 2 + oy, X = (x0 + 1) * 2 + ox;
     const bool live = Y < H2 && X < W2;
@@ -220,8 +240,9 @@ int launch_fused(const float* x, int C1, int64_t ld1, const float* skip, int C2,
   const int tiles_x = (W + UT - 1) / UT, tiles_y = (H + UT - 1) / UT;
   const int64_t nblk = (int64_t)B * tiles_x * tiles_y;
   if (nblk >= (1 << 30)) return VS_ERR_UNSUPPORTED;
+  static const int abl = [] { const char* e = getenv("VS_UPCONV_ABL"); return e ? atoi(e) : 0; }();
   hipLaunchKernelGGL(kern, dim3((unsigned)((nblk + 7) / 8 * 8)), dim3(256), smem, st, x, C1, ld1, skip, C2, ld2, s,
-                     static_cast<const unsigned short*>(wsplit), H, W, Co, lnw, lnb, eps, act, out, old, tiles_x, tiles_y, (int)nblk);
+                     static_cast<const unsigned short*>(wsplit), H, W, Co, lnw, lnb, eps, act, out, old, tiles_x, tiles_y, (int)nblk, abl);
   return vs_launch_status();
 }
 
@@ -230,6 +251,10 @@ int launch_fused(const float* x, int C1, int64_t ld1, const float* skip, int C2,
 extern "C" int vs_upconv_fused_supported(int C1, int C2, int Co) {
   return (Co == 16 || Co == 32) && C1 > 0 && C2 > 0 && C1 % 16 == 0 && C2 % 16 == 0 && C1 + C2 <= 256;
 }
+// Measured on MI355X at 32 frames (tools/bench_upconv.py): 128^2 x (32+32) -> 16: 253 us fused vs 441 us as cat + GEMM + gather (z is
+// 302 MB there); 64^2 x (64+64) -> 32: 218 us fused vs 204 us -- the in-kernel GEMM pays for the halo rows (100 of 64) and the row /
+// column padding (128 x 288) and its phases do not overlap (ablations: GEMM 110 us, gather 75-107 us, rest 30-39 us).
+extern "C" int vs_upconv_fused_preferred(int C1, int C2, int Co) { return vs_upconv_fused_supported(C1, C2, Co) && Co == 16; }
 
 extern "C" int vs_upconv_fused(const float* x, int C1, int64_t ld1, const float* skip, int C2, int64_t ld2, float skip_scale,
                                const void* wt_split, int B, int H, int W, int Co, const float* lnw, const float* lnb, float eps, int act,

@@ -582,7 +582,7 @@ class HipEngine:
         xcur = h3
         def fused_ok(k: int, c1: int, c2: int) -> bool:
             up_ = E["ups"][k]
-            return bool(self.upconv_fused and self.use_split and "gemm" in up_ and L.vs_upconv_fused_supported(c1, c2, up_["gemm"].N // 9)
+            return bool(self.upconv_fused and self.use_split and "gemm" in up_ and L.vs_upconv_fused_preferred(c1, c2, up_["gemm"].N // 9)
                         and up_["gemm"].CinP == c1 + c2)
 
         def lowres_cat(k: int, like: Act) -> Optional[Act]:
