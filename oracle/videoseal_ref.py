@@ -34,8 +34,18 @@ def _bn(sd: SD, p: str, x, bn: Optional[dict] = None):
     return y
 
 
+def _chan_rms(sd: SD, p: str, x):
+    """common.py:172-179  ChanRMSNorm: F.normalize(x, dim=1) * sqrt(C) * gamma   (F.normalize: x / max(||x||_2, 1e-12))."""
+    return F.normalize(x, dim=1) * (x.shape[1] ** 0.5) * sd[p + ".gamma"]
+
+
 def resnet_block(sd: SD, p: str, x, bn: Optional[dict] = None):
-    """unet.py:17-39  relu(bn(conv3(relu(bn(conv3(x)))))) + conv1x1(x)."""
+    """unet.py:17-39  act(norm(conv3(act(norm(conv3(x)))))) + conv1x1(x); norm/act = BatchNorm/ReLU (released cards) or
+    ChanRMSNorm/SiLU (legacy videoseal_0.0 card) -- told apart by the tensors present."""
+    if p + ".double_conv.1.gamma" in sd:
+        h = F.silu(_chan_rms(sd, p + ".double_conv.1", F.conv2d(x, sd[p + ".double_conv.0.weight"], padding=1)))
+        h = F.silu(_chan_rms(sd, p + ".double_conv.4", F.conv2d(h, sd[p + ".double_conv.3.weight"], padding=1)))
+        return h + F.conv2d(x, sd[p + ".res_conv.weight"], sd[p + ".res_conv.bias"])
     h = F.relu(_bn(sd, p + ".double_conv.1", F.conv2d(x, sd[p + ".double_conv.0.weight"], padding=1), bn))
     h = F.relu(_bn(sd, p + ".double_conv.4", F.conv2d(h, sd[p + ".double_conv.3.weight"], padding=1), bn))
     return h + F.conv2d(x, sd[p + ".res_conv.weight"], sd[p + ".res_conv.bias"])
@@ -85,7 +95,7 @@ def unet_forward(sd: SD, s: ModelSpec, x, msgs, bn: Optional[dict] = None):
         x = resnet_block(sd, f"{u}.bottleneck.model.{j}", x, bn)
     for k in range(len(s.mults) - 1):
         x = torch.cat((x, hid.pop() * (2 ** -0.5)), dim=1)     # unet.py:186-187
-        x = upsample_block(sd, f"{u}.ups.{k}.up", x, 2, F.relu)
+        x = upsample_block(sd, f"{u}.ups.{k}.up", x, 2, F.silu if s.unet_act == "silu" else F.relu)      # unet.py:61-62: the U-Net's act_layer
         x = resnet_block(sd, f"{u}.ups.{k}.conv", x, bn)
     x = F.conv2d(x, sd[u + ".outc.weight"], sd[u + ".outc.bias"])
     return torch.tanh(x) if s.last_tanh else x
@@ -110,8 +120,69 @@ def convnext_block(sd: SD, p: str, x):
     return x + h.permute(0, 3, 1, 2)
 
 
+def _rel_pos(q_size: int, k_size: int, rel_pos):
+    """vit.py:405-433 get_rel_pos for q_size == k_size and a table of 2*size-1 rows (the only case the encoder produces):
+    R[i, j] = rel_pos[i - j + size - 1]."""
+    assert q_size == k_size and rel_pos.shape[0] == 2 * q_size - 1
+    idx = torch.arange(q_size)[:, None] - torch.arange(k_size)[None, :] + (k_size - 1)
+    return rel_pos[idx]
+
+
+def vit_attention(sd: SD, p: str, x, heads: int, rel_pos: bool):
+    """vit.py:302-360 Attention.forward on [B, H, W, C] tokens (B = frames * windows), decomposed relative positions vit.py:436-470."""
+    B, H, W, C = x.shape
+    hd = C // heads
+    qkv = F.linear(x, sd[p + ".qkv.weight"], sd[p + ".qkv.bias"]).reshape(B, H * W, 3, heads, hd).permute(2, 0, 3, 1, 4)
+    q, k, v = qkv.reshape(3, B * heads, H * W, hd).unbind(0)
+    attn = (q * hd ** -0.5) @ k.transpose(-2, -1)
+    if rel_pos:
+        Rh, Rw = _rel_pos(H, H, sd[p + ".rel_pos_h"]), _rel_pos(W, W, sd[p + ".rel_pos_w"])
+        rq = q.reshape(B * heads, H, W, hd)
+        rel_h = torch.einsum("bhwc,hkc->bhwk", rq, Rh)
+        rel_w = torch.einsum("bhwc,wkc->bhwk", rq, Rw)
+        attn = (attn.view(B * heads, H, W, H, W) + rel_h[:, :, :, :, None] + rel_w[:, :, :, None, :]).view(B * heads, H * W, H * W)
+    attn = attn.softmax(dim=-1)
+    x = (attn @ v).view(B, heads, H, W, hd).permute(0, 2, 3, 1, 4).reshape(B, H, W, C)
+    return F.linear(x, sd[p + ".proj.weight"], sd[p + ".proj.bias"])
+
+
+def vit_block(sd: SD, p: str, x, heads: int, window: int, rel_pos: bool):
+    """vit.py:146-209 Block.forward: x + attn(norm1(x)) (windowed when window > 0, vit.py:363-402), then x + mlp(norm2(x))."""
+    B, H, W, C = x.shape
+    h = F.layer_norm(x, (C,), sd[p + ".norm1.weight"], sd[p + ".norm1.bias"], 1e-5)      # nn.LayerNorm default eps
+    if window > 0:
+        ph, pw = (window - H % window) % window, (window - W % window) % window
+        h = F.pad(h, (0, 0, 0, pw, 0, ph))
+        Hp, Wp = H + ph, W + pw
+        h = h.view(B, Hp // window, window, Wp // window, window, C).permute(0, 1, 3, 2, 4, 5).reshape(-1, window, window, C)
+    h = vit_attention(sd, p + ".attn", h, heads, rel_pos)
+    if window > 0:
+        h = h.view(B, Hp // window, Wp // window, window, window, C).permute(0, 1, 3, 2, 4, 5).reshape(B, Hp, Wp, C)[:, :H, :W]
+    x = x + h
+    h = F.layer_norm(x, (C,), sd[p + ".norm2.weight"], sd[p + ".norm2.bias"], 1e-5)
+    h = F.linear(F.gelu(F.linear(h, sd[p + ".mlp.lin1.weight"], sd[p + ".mlp.lin1.bias"])), sd[p + ".mlp.lin2.weight"], sd[p + ".mlp.lin2.bias"])
+    return x + h
+
+
+def vit_extractor_forward(sd: SD, s: ModelSpec, imgs01):
+    """extractor.py:45-75 SegmentationExtractor.forward: x*2-1 -> ImageEncoderViT (vit.py:129-144) -> PixelDecoder."""
+    ie = "detector.image_encoder"
+    x = F.conv2d(imgs01 * 2 - 1, sd[ie + ".patch_embed.proj.weight"], sd[ie + ".patch_embed.proj.bias"], stride=s.vit_patch)
+    x = x.permute(0, 2, 3, 1) + sd[ie + ".pos_embed"]
+    for i in range(s.vit_depth):
+        x = vit_block(sd, f"{ie}.blocks.{i}", x, s.vit_heads, 0 if i in s.vit_global else s.vit_window, s.vit_rel_pos)
+    x = x.permute(0, 3, 1, 2)
+    x = layernorm_cf(F.conv2d(x, sd[ie + ".neck.0.weight"]), sd[ie + ".neck.1.weight"], sd[ie + ".neck.1.bias"])
+    x = layernorm_cf(F.conv2d(x, sd[ie + ".neck.2.weight"], padding=1), sd[ie + ".neck.3.weight"], sd[ie + ".neck.3.bias"])
+    x = upsample_block(sd, "detector.pixel_decoder.output_upscaling.0", x, 1, F.gelu)
+    x = x.mean(dim=[-2, -1])
+    return F.linear(x, sd["detector.pixel_decoder.linear.weight"], sd["detector.pixel_decoder.linear.bias"])
+
+
 def extractor_forward(sd: SD, s: ModelSpec, imgs01):
     """extractor.py:154-167, convnext.py:146-156, pixel_decoder.py:61-83."""
+    if s.extractor == "sam":
+        return vit_extractor_forward(sd, s, imgs01)
     c = "detector.convnext"
     x = imgs01 * 2 - 1
     x = F.conv2d(x, sd[f"{c}.downsample_layers.0.0.weight"], sd[f"{c}.downsample_layers.0.0.bias"], stride=s.stem_stride)
@@ -162,6 +233,7 @@ def _resize(x, size, interp):
 # --------------------------------------------------------------------------- embed / detect
 def embed_image(sd: SD, s: ModelSpec, imgs, msgs, interp=AA, lowres_attenuation=False, attenuate=True, clamp=True):
     """wam.py:134-204."""
+    attenuate = attenuate and s.jnd_in > 0          # cards without a JND module (cfg.py:126-131)
     P = (s.img_size, s.img_size)
     res = _resize(imgs, P, interp)
     x = rgb2y(sd, res) if s.yuv else res
@@ -203,6 +275,7 @@ def embed_video(sd: SD, s: ModelSpec, imgs, msgs, interp=AA, lowres_attenuation=
                 chunk_size: Optional[int] = None, step_size: Optional[int] = None, video_mode="repeat",
                 attenuate=True, clamp=True):
     """videoseal.py:258-350 (msgs is [1,k])."""
+    attenuate = attenuate and s.jnd_in > 0          # cards without a JND module (cfg.py:126-131)
     assert msgs.shape[0] == 1, "Message should be unique"
     ck = chunk_size or s.chunk_size
     st = step_size or s.step_size
@@ -236,6 +309,7 @@ def forward_image(sd: SD, s: ModelSpec, imgs, masks, msgs, augment, interp=AA, b
                   clamp=True, scaling_i=None, scaling_w=None):
     """wam.py:68-132, the training forward.  `augment(imgs_w, imgs, masks, is_video, do_resize) -> (imgs_aug, masks, name)` is the
     augmenter (oracle/augment.py:Augmenter).  bn: see _bn."""
+    attenuate = attenuate and s.jnd_in > 0          # cards without a JND module (cfg.py:126-131)
     si = s.scaling_i if scaling_i is None else scaling_i
     sw = s.scaling_w if scaling_w is None else scaling_w
     P = (s.img_size, s.img_size)
@@ -260,6 +334,7 @@ def forward_image(sd: SD, s: ModelSpec, imgs, masks, msgs, augment, interp=AA, b
 def forward_video(sd: SD, s: ModelSpec, imgs, masks, msgs, augment, interp=AA, bn: Optional[dict] = None, step_size=None,
                   video_mode="repeat", lowres_attenuation=False, attenuate=True, clamp=True):
     """videoseal.py:163-256 (`video_forward`)."""
+    attenuate = attenuate and s.jnd_in > 0          # cards without a JND module (cfg.py:126-131)
     assert msgs.shape[0] == 1, "Message should be unique"
     st = step_size or s.step_size
     P = (s.img_size, s.img_size)

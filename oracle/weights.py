@@ -42,9 +42,23 @@ class ModelSpec:
     depths: List[int] = field(default_factory=lambda: [3, 3, 9, 3])
     dims: List[int] = field(default_factory=lambda: [96, 192, 384, 768])
     stem_stride: int = 4
-    # JND (attenuation.yaml jnd_1_1)
+    # JND (attenuation.yaml jnd_1_1); jnd_in = 0: the card has no attenuation (videoseal_0.0: `attenuation: None`, cfg.py:126-131)
     jnd_in: int = 1
     jnd_out: int = 1
+    # U-Net flavour (common.py:110-127, 182-194): 'relu' + 'batch' (released 1.0 / PixelSeal / ChunkySeal) or 'silu' + 'rms' (legacy 0.0)
+    unet_act: str = "relu"
+    unet_norm: str = "batch"
+    # extractor family (extractor.py:170-213): 'convnext' or 'sam' (ImageEncoderViT, vit.py:14-144)
+    extractor: str = "convnext"
+    vit_dim: int = 384
+    vit_depth: int = 12
+    vit_heads: int = 6
+    vit_patch: int = 16
+    vit_window: int = 8
+    vit_global: List[int] = field(default_factory=lambda: [2, 5, 8, 11])
+    vit_out: int = 384
+    vit_mlp_ratio: float = 4.0
+    vit_rel_pos: bool = True
 
     @property
     def zc(self) -> List[int]:
@@ -63,13 +77,22 @@ def spec_from_card(path: str) -> ModelSpec:
     e = card["extractor"]["params"]
     nbits = int(a["nbits"])
     mult = a.get("hidden_size_multiplier", 2)
-    dims = list(e["encoder"]["dims"])
+    dims = list(e["encoder"].get("dims", [0, 0, 0, 0]))
     if e.get("proportional_dim", False):          # extractor.py:193-198
         m = math.sqrt(nbits / 128)
         dims = [int(d * m) for d in dims]
-    att = {"jnd_1_1": (1, 1), "jnd_3_3": (3, 3), "jnd_1_3": (1, 3), "jnd_3_1": (3, 1)}[a["attenuation"]]
+    att = {"jnd_1_1": (1, 1), "jnd_3_3": (3, 3), "jnd_1_3": (1, 3), "jnd_3_1": (3, 1)}.get(str(a["attenuation"]).lower(), (0, 0))
+    extra = {}
+    if str(card["extractor"]["model"]).startswith("sam"):
+        v = e["encoder"]
+        extra = dict(extractor="sam", vit_dim=int(v["embed_dim"]), vit_depth=int(v["depth"]), vit_heads=int(v["num_heads"]),
+                     vit_patch=int(v["patch_size"]), vit_window=int(v["window_size"]), vit_global=list(v["global_attn_indexes"]),
+                     vit_out=int(v["out_chans"]), vit_mlp_ratio=float(v["mlp_ratio"]), vit_rel_pos=bool(v["use_rel_pos"]))
+        dims = [0, 0, 0, int(v["out_chans"])]
     return ModelSpec(
-        nbits=nbits, hidden=int(nbits * mult), img_size=int(a["img_size_proc"]),
+        unet_act=str(u.get("activation", "relu")), unet_norm=("rms" if str(u.get("normalization", "batch")).startswith("rms") else "batch"),
+        **extra,
+        nbits=nbits, hidden=int(nbits * mult), img_size=int(a.get("img_size_proc", a.get("img_size_extractor", 256))),
         scaling_w=float(a["scaling_w"]), scaling_i=float(a["scaling_i"]),
         chunk_size=int(a.get("videoseal_chunk_size", a.get("videowam_chunk_size"))),
         step_size=int(a.get("videoseal_step_size", a.get("videowam_step_size"))),
@@ -77,7 +100,7 @@ def spec_from_card(path: str) -> ModelSpec:
         in_ch=int(u["in_channels"]), out_ch=int(u["out_channels"]), z=int(u["z_channels"]),
         mults=list(u["z_channels_mults"]), num_blocks=int(u["num_blocks"]),
         last_tanh=bool(u.get("last_tanh", True)),
-        depths=list(e["encoder"]["depths"]), dims=dims,
+        depths=list(e["encoder"].get("depths", [0, 0, 0, 0])), dims=dims,
         stem_stride=int(e["encoder"].get("stem_stride", 4)),
         jnd_in=att[0], jnd_out=att[1],
     )
@@ -92,6 +115,17 @@ def tiny_spec(**kw) -> ModelSpec:
     return ModelSpec(**d)
 
 
+def legacy_tiny_spec(**kw) -> ModelSpec:
+    """Small architecture of the videoseal_0.0 family: RMSNorm/SiLU RGB U-Net, ViT extractor on an 8 x 8 token grid with
+    4 x 4 windows and two global blocks, no JND."""
+    d = dict(nbits=16, hidden=32, img_size=64, chunk_size=4, step_size=2, z=8, mults=[1, 2, 4, 8], num_blocks=2, yuv=False,
+             in_ch=3, out_ch=3, unet_act="silu", unet_norm="rms", extractor="sam", vit_dim=32, vit_depth=4, vit_heads=2,
+             vit_patch=8, vit_window=4, vit_global=[1, 3], vit_out=24, depths=[0, 0, 0, 0], dims=[0, 0, 0, 24],
+             jnd_in=0, jnd_out=0, scaling_w=1.0)
+    d.update(kw)
+    return ModelSpec(**d)
+
+
 def state_dict_layout(s: ModelSpec) -> Dict[str, tuple]:
     """name -> shape for every tensor of Videoseal.state_dict()."""
     L: Dict[str, tuple] = {}
@@ -101,9 +135,15 @@ def state_dict_layout(s: ModelSpec) -> Dict[str, tuple]:
         L[p + ".running_mean"] = (c,); L[p + ".running_var"] = (c,)
         L[p + ".num_batches_tracked"] = ()
 
+    def norm(p, c):                                  # common.py:182-194: BatchNorm2d or ChanRMSNorm (gamma [C,1,1])
+        if s.unet_norm == "rms":
+            L[p + ".gamma"] = (c, 1, 1)
+        else:
+            bn(p, c)
+
     def resblock(p, cin, cout):                      # unet.py:20-36
-        L[p + ".double_conv.0.weight"] = (cout, cin, 3, 3); bn(p + ".double_conv.1", cout)
-        L[p + ".double_conv.3.weight"] = (cout, cout, 3, 3); bn(p + ".double_conv.4", cout)
+        L[p + ".double_conv.0.weight"] = (cout, cin, 3, 3); norm(p + ".double_conv.1", cout)
+        L[p + ".double_conv.3.weight"] = (cout, cout, 3, 3); norm(p + ".double_conv.4", cout)
         L[p + ".res_conv.weight"] = (cout, cin, 1, 1); L[p + ".res_conv.bias"] = (cout,)
 
     zc = s.zc
@@ -125,21 +165,45 @@ def state_dict_layout(s: ModelSpec) -> Dict[str, tuple]:
     L[u + ".outc.weight"] = (s.out_ch, zc[0], 1, 1); L[u + ".outc.bias"] = (s.out_ch,)
     L["embedder.msg_processor.msg_embeddings.weight"] = emb      # same tensor, registered twice (embedder.py:141-142)
 
+    if s.extractor == "sam":                         # vit.py:55-127, 302-339; extractor.py:171-177
+        ie = "detector.image_encoder"
+        D_, g = s.vit_dim, s.img_size // s.vit_patch
+        hd = D_ // s.vit_heads
+        L[ie + ".pos_embed"] = (1, g, g, D_)
+        L[ie + ".patch_embed.proj.weight"] = (D_, 3, s.vit_patch, s.vit_patch); L[ie + ".patch_embed.proj.bias"] = (D_,)
+        for i in range(s.vit_depth):
+            p = f"{ie}.blocks.{i}"
+            t = g if (i in s.vit_global or s.vit_window == 0) else s.vit_window      # vit.py:89-90, 185
+            L[p + ".norm1.weight"] = (D_,); L[p + ".norm1.bias"] = (D_,)
+            if s.vit_rel_pos:
+                L[p + ".attn.rel_pos_h"] = (2 * t - 1, hd); L[p + ".attn.rel_pos_w"] = (2 * t - 1, hd)
+            L[p + ".attn.qkv.weight"] = (3 * D_, D_); L[p + ".attn.qkv.bias"] = (3 * D_,)
+            L[p + ".attn.proj.weight"] = (D_, D_); L[p + ".attn.proj.bias"] = (D_,)
+            L[p + ".norm2.weight"] = (D_,); L[p + ".norm2.bias"] = (D_,)
+            hid = int(D_ * s.vit_mlp_ratio)
+            L[p + ".mlp.lin1.weight"] = (hid, D_); L[p + ".mlp.lin1.bias"] = (hid,)
+            L[p + ".mlp.lin2.weight"] = (D_, hid); L[p + ".mlp.lin2.bias"] = (D_,)
+        O_ = s.vit_out
+        L[ie + ".neck.0.weight"] = (O_, D_, 1, 1)
+        L[ie + ".neck.1.weight"] = (O_,); L[ie + ".neck.1.bias"] = (O_,)
+        L[ie + ".neck.2.weight"] = (O_, O_, 3, 3)
+        L[ie + ".neck.3.weight"] = (O_,); L[ie + ".neck.3.bias"] = (O_,)
     c = "detector.convnext"
-    d = s.dims
-    L[f"{c}.downsample_layers.0.0.weight"] = (d[0], 3, 4, 4); L[f"{c}.downsample_layers.0.0.bias"] = (d[0],)
-    L[f"{c}.downsample_layers.0.1.weight"] = (d[0],); L[f"{c}.downsample_layers.0.1.bias"] = (d[0],)
-    for i in range(3):
-        L[f"{c}.downsample_layers.{i+1}.0.weight"] = (d[i],); L[f"{c}.downsample_layers.{i+1}.0.bias"] = (d[i],)
-        L[f"{c}.downsample_layers.{i+1}.1.weight"] = (d[i + 1], d[i], 2, 2); L[f"{c}.downsample_layers.{i+1}.1.bias"] = (d[i + 1],)
-    for st in range(4):
-        for j in range(s.depths[st]):
-            p = f"{c}.stages.{st}.{j}"; C = d[st]
-            L[p + ".dwconv.weight"] = (C, 1, 7, 7); L[p + ".dwconv.bias"] = (C,)
-            L[p + ".norm.weight"] = (C,); L[p + ".norm.bias"] = (C,)
-            L[p + ".pwconv1.weight"] = (4 * C, C); L[p + ".pwconv1.bias"] = (4 * C,)
-            L[p + ".grn.gamma"] = (1, 1, 1, 4 * C); L[p + ".grn.beta"] = (1, 1, 1, 4 * C)
-            L[p + ".pwconv2.weight"] = (C, 4 * C); L[p + ".pwconv2.bias"] = (C,)
+    d = s.dims if s.extractor == "convnext" else [0, 0, 0, s.vit_out]
+    if s.extractor == "convnext":
+        L[f"{c}.downsample_layers.0.0.weight"] = (d[0], 3, 4, 4); L[f"{c}.downsample_layers.0.0.bias"] = (d[0],)
+        L[f"{c}.downsample_layers.0.1.weight"] = (d[0],); L[f"{c}.downsample_layers.0.1.bias"] = (d[0],)
+        for i in range(3):
+            L[f"{c}.downsample_layers.{i+1}.0.weight"] = (d[i],); L[f"{c}.downsample_layers.{i+1}.0.bias"] = (d[i],)
+            L[f"{c}.downsample_layers.{i+1}.1.weight"] = (d[i + 1], d[i], 2, 2); L[f"{c}.downsample_layers.{i+1}.1.bias"] = (d[i + 1],)
+        for st in range(4):
+            for j in range(s.depths[st]):
+                p = f"{c}.stages.{st}.{j}"; C = d[st]
+                L[p + ".dwconv.weight"] = (C, 1, 7, 7); L[p + ".dwconv.bias"] = (C,)
+                L[p + ".norm.weight"] = (C,); L[p + ".norm.bias"] = (C,)
+                L[p + ".pwconv1.weight"] = (4 * C, C); L[p + ".pwconv1.bias"] = (4 * C,)
+                L[p + ".grn.gamma"] = (1, 1, 1, 4 * C); L[p + ".grn.beta"] = (1, 1, 1, 4 * C)
+                L[p + ".pwconv2.weight"] = (C, 4 * C); L[p + ".pwconv2.bias"] = (C,)
     pd = "detector.pixel_decoder"
     E = d[-1]
     L[pd + ".output_upscaling.0.upsample_block.2.weight"] = (E, E, 3, 3)
@@ -147,8 +211,9 @@ def state_dict_layout(s: ModelSpec) -> Dict[str, tuple]:
     L[pd + ".linear.weight"] = (s.nbits + 1, E); L[pd + ".linear.bias"] = (s.nbits + 1,)
     L["rgb2yuv.M"] = (3, 3)
     g = s.jnd_in
-    L["attenuation.conv_x.weight"] = (g, 1, 3, 3); L["attenuation.conv_y.weight"] = (g, 1, 3, 3)
-    L["attenuation.conv_lum.weight"] = (g, 1, 5, 5)
+    if g > 0:                                        # no JND module in the card (cfg.py:131) -> no attenuation.* tensors
+        L["attenuation.conv_x.weight"] = (g, 1, 3, 3); L["attenuation.conv_y.weight"] = (g, 1, 3, 3)
+        L["attenuation.conv_lum.weight"] = (g, 1, 5, 5)
     return L
 
 
@@ -185,6 +250,12 @@ def make_state_dict(s: ModelSpec, seed: int = 0) -> Dict[str, torch.Tensor]:
             t = 0.1 * rnd(name, shape, "normal")
         elif leaf == "running_var":
             t = 0.5 + rnd(name, shape, "uniform")
+        elif leaf == "gamma" and len(shape) == 3:    # ChanRMSNorm scale (default ones)
+            t = 0.5 + rnd(name, shape, "uniform")
+        elif leaf == "pos_embed":
+            t = 0.2 * rnd(name, shape, "normal")
+        elif leaf in ("rel_pos_h", "rel_pos_w"):     # zero-initialised in the reference: randomised here or the term would go untested
+            t = 0.3 * rnd(name, shape, "normal")
         elif leaf == "gamma":
             t = 0.5 * rnd(name, shape, "normal")
         elif leaf == "beta":
@@ -201,7 +272,7 @@ def make_state_dict(s: ModelSpec, seed: int = 0) -> Dict[str, torch.Tensor]:
             gain = math.sqrt(2.0)
             if ".outc." in name:
                 gain = 0.25
-            elif "res_conv" in name or "pwconv2" in name or ".linear." in name:
+            elif "res_conv" in name or "pwconv2" in name or ".linear." in name or ".attn." in name or ".mlp.lin2" in name or ".neck." in name:
                 gain = 1.0
             t = rnd(name, shape, "normal") * (gain / math.sqrt(fan_in))
         sd[name] = t.to(torch.int64 if leaf == "num_batches_tracked" else torch.float32).contiguous()

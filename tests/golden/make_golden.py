@@ -27,7 +27,7 @@ sys.path.insert(0, ROOT)
 REF = "/root/reference"
 
 from oracle.inputs import synthetic_frames, synthetic_msgs          # noqa: E402
-from oracle.weights import make_state_dict, spec_from_card, tiny_spec, state_dict_layout   # noqa: E402
+from oracle.weights import make_state_dict, spec_from_card, tiny_spec, legacy_tiny_spec, state_dict_layout   # noqa: E402
 
 
 def import_reference():
@@ -75,20 +75,31 @@ def build_reference(spec, card_like, device="cpu"):
     c = toD(card_like)
     emb = be(c.embedder.model, c.embedder.params, spec.nbits, spec.hidden / spec.nbits)
     ext = bx(c.extractor.model, c.extractor.params, spec.img_size, spec.nbits)
-    return Videoseal(emb, ext, dummy_aug(), attenuation=JND(in_channels=spec.jnd_in, out_channels=spec.jnd_out),
+    return Videoseal(emb, ext, dummy_aug(), attenuation=(JND(in_channels=spec.jnd_in, out_channels=spec.jnd_out) if spec.jnd_in > 0 else None),
                      scaling_w=spec.scaling_w, scaling_i=spec.scaling_i, img_size=spec.img_size,
                      chunk_size=spec.chunk_size, step_size=spec.step_size)
 
 
 def card_for_spec(s):
     """A card-shaped dict that makes the reference builders produce architecture ``s``."""
+    pdec = {"pixelwise": False, "upscale_stages": [1], "embed_dim": s.dims[-1], "nbits": 16, "sigmoid_output": False}
+    if s.extractor == "sam":
+        ext = {"model": "sam_small",
+               "params": {"encoder": {"img_size": s.img_size, "embed_dim": s.vit_dim, "out_chans": s.vit_out, "depth": s.vit_depth,
+                                      "num_heads": s.vit_heads, "patch_size": s.vit_patch, "global_attn_indexes": list(s.vit_global),
+                                      "window_size": s.vit_window, "mlp_ratio": s.vit_mlp_ratio, "qkv_bias": True,
+                                      "use_rel_pos": s.vit_rel_pos},
+                          "pixel_decoder": dict(pdec, embed_dim=s.vit_out, upscale_type="bilinear")}}
+    else:
+        ext = None
     return {
         "embedder": {"model": "unet_small2_yuv_quant" if s.yuv else "unet_rgb",
                      "params": {"msg_processor": {"nbits": 16, "hidden_size": 32, "msg_processor_type": "binary+concat"},
                                 "unet": {"in_channels": s.in_ch, "out_channels": s.out_ch, "z_channels": s.z,
-                                         "num_blocks": s.num_blocks, "activation": "relu", "normalization": "batch",
+                                         "num_blocks": s.num_blocks, "activation": s.unet_act,
+                                         "normalization": "rms" if s.unet_norm == "rms" else "batch",
                                          "z_channels_mults": list(s.mults), "last_tanh": s.last_tanh}}},
-        "extractor": {"model": "convnext_tiny",
+        "extractor": ext or {"model": "convnext_tiny",
                       "params": {"encoder": {"depths": list(s.depths), "dims": list(s.dims), "stem_stride": s.stem_stride},
                                  "pixel_decoder": {"pixelwise": False, "upscale_stages": [1], "embed_dim": s.dims[-1],
                                                    "nbits": 16, "sigmoid_output": False}}},
@@ -138,7 +149,8 @@ def run_case(model, spec, name, *, n, h, w, seed, is_video, lowres, chunk=None, 
         x = imgs
         y = model.rgb2yuv(x)[:, 0:1] if model.embedder.yuv else x
         pack(d, "delta", model.embedder(y, msgs))
-        pack(d, "hmaps", model.attenuation.heatmaps(x))
+        if model.attenuation is not None:
+            pack(d, "hmaps", model.attenuation.heatmaps(x))
     np.savez_compressed(os.path.join(HERE, name + ".npz"), **d)
     print(f"{name}: psnr={psnr:.3f} dB  bit_acc={( (det['preds'][:,1:]>0) == (msgs>0.5)).float().mean():.3f}"
           f"  |logit| median={det['preds'][:,1:].abs().median():.4f} min={det['preds'][:,1:].abs().min():.2e}")
@@ -149,7 +161,7 @@ def main():
     torch.set_num_threads(8)
     # ---- key/shape lists of the real reference for every released card (meta device: no allocation)
     keys = {}
-    for card in ("videoseal_1.0", "pixelseal", "chunkyseal"):
+    for card in ("videoseal_1.0", "pixelseal", "chunkyseal", "videoseal_0.0"):
         path = f"{REF}/videoseal/cards/{card}.yaml"
         spec = spec_from_card(path)
         _ls = torch.linspace                      # convnext.py:122 calls .item() on a linspace: keep that one on cpu
@@ -167,6 +179,8 @@ def main():
         print(card, len(ref_keys), "tensors,", sum(int(np.prod(v)) for v in ref_keys.values()) / 1e6, "M elements")
     json.dump(keys, open(os.path.join(HERE, "state_dict_keys.json"), "w"), indent=0)
 
+    if "--legacy-only" in sys.argv:
+        return legacy_cases()
     # ---- VideoSeal 1.0 (full size), seed 0
     path = f"{REF}/videoseal/cards/videoseal_1.0.yaml"
     spec = spec_from_card(path)
@@ -202,5 +216,24 @@ def main():
     run_case(tcm, tc, "tinyc_vid", n=7, h=96, w=80, seed=22, is_video=True, lowres=True, chunk=2, step=2)
 
 
+def legacy_cases():
+    """videoseal_0.0 card: RMSNorm/SiLU RGB U-Net, SAM-style ViT extractor with windowed + global attention and
+    decomposed relative positions, no JND, scaling_w = 1."""
+    path = f"{REF}/videoseal/cards/videoseal_0.0.yaml"
+    spec = spec_from_card(path)
+    model = build_reference(spec, yaml.safe_load(open(path))).eval()
+    print("strict load:", model.load_state_dict(make_state_dict(spec, seed=5), strict=True))
+    run_case(model, spec, "vs00_img256", n=2, h=256, w=256, seed=31, is_video=False, lowres=False)
+    run_case(model, spec, "vs00_vid", n=6, h=144, w=176, seed=32, is_video=True, lowres=False, chunk=2, step=2)
+    tv = legacy_tiny_spec()
+    tm = build_reference(tv, card_for_spec(tv)).eval()
+    tm.load_state_dict(make_state_dict(tv, seed=6), strict=True)
+    run_case(tm, tv, "tinyv_img", n=3, h=64, w=64, seed=41, is_video=False, lowres=False)
+    run_case(tm, tv, "tinyv_img_resize", n=2, h=90, w=130, seed=42, is_video=False, lowres=False)
+    run_case(tm, tv, "tinyv_vid", n=7, h=80, w=72, seed=43, is_video=True, lowres=False, chunk=2, step=2)
+
+
 if __name__ == "__main__":
     main()
+    if "--legacy-only" not in sys.argv:
+        legacy_cases()
