@@ -34,6 +34,7 @@ extern "C" {
 #define VS_ACT_RELU 1
 #define VS_ACT_GELU 2            /* exact erf GELU (nn.GELU default)                          */
 #define VS_ACT_TANH 3
+#define VS_ACT_SILU 4            /* x * sigmoid(x) (legacy videoseal_0.0 U-Net, common.py:118-119)  */
 
 #define VS_PAD_ZERO 0
 #define VS_PAD_REFLECT 1
@@ -115,6 +116,22 @@ int vs_conv_gemm(const vs_conv_desc_t* d, void* stream);
 /* LayerNorm over the channel dim of [rows][ld] (+ optional activation).  common.py:131-155 (both data formats). */
 int vs_layernorm_act(const float* x, int64_t rows, int C, int64_t ld, const float* w, const float* b, float eps,
                      int act, float* out, int64_t out_ld, void* stream);
+
+/* ChanRMSNorm over the channel dim of [rows][ld] (common.py:172-179: F.normalize(x, dim=1) * sqrt(C) * gamma, i.e.
+ * x / max(||x||_2, 1e-12) * sqrt(C) * gamma[c]) + activation (+ add[row][c]: the ResnetBlock's res_conv branch, unet.py:38-39).
+ * The U-Net norm of the legacy videoseal_0.0 card.  C % 4 == 0. */
+int vs_rmsnorm_act(const float* x, int64_t rows, int C, int64_t ld, const float* gamma, int act, const float* add, int64_t add_ld,
+                   float* out, int64_t out_ld, void* stream);
+
+/* Multi-head self-attention of the SAM-style ViT extractor (vit.py:302-360 + 436-470), fp32:
+ *   qkv  [frames*H*W][3*heads*hd]   rows = tokens (frame, y, x); columns [q | k | v], each [head][hd]   (vit.py:345-347)
+ *   out  [frames*H*W][heads*hd]     column = head*hd + c                                               (vit.py:357)
+ *   S[i][j] = (q_i * hd^-1/2) . k_j + q_i . rel_h[y_i - y_j + T_h - 1] + q_i . rel_w[x_i - x_j + T_w - 1];  out_i = softmax_j(S) v
+ * window = 0: global attention over the H x W grid of a frame (T_h = H, T_w = W); window > 0: non-overlapping window x window
+ * token windows (vit.py:363-402; H and W must be multiples of window), T_h = T_w = window.  rel_h / rel_w: [2*T-1][hd] or NULL.
+ * hd in {16, 32, 64}; tokens per attention group <= 256. */
+int vs_vit_attention(const float* qkv, int frames, int H, int W, int heads, int hd, int window, const float* rel_h, const float* rel_w,
+                     float* out, void* stream);
 
 /* ConvNeXt-V2 block front: depthwise 7x7 (pad 3, bias) fused with LayerNorm(C).  convnext.py:43-46.
  * wdw is packed [49][C]. */

@@ -11,7 +11,7 @@ pytestmark = pytest.mark.gpu
 
 from oracle import videoseal_ref as R  # noqa: E402
 from oracle.inputs import synthetic_frames, synthetic_msgs  # noqa: E402
-from oracle.weights import make_state_dict, spec_from_card, tiny_spec  # noqa: E402
+from oracle.weights import legacy_tiny_spec, make_state_dict, spec_from_card, tiny_spec  # noqa: E402
 from tests._util import check_sub, load_golden, psnr_np  # noqa: E402
 from tests.test_oracle_golden import CARDS, FULL, TINY, TINYC  # noqa: E402
 
@@ -27,7 +27,10 @@ def cfg_of(spec) -> ModelCfg:
     return ModelCfg(nbits=spec.nbits, hidden=spec.hidden, img_size=spec.img_size, scaling_w=spec.scaling_w, scaling_i=spec.scaling_i,
                     chunk_size=spec.chunk_size, step_size=spec.step_size, yuv=spec.yuv, in_ch=spec.in_ch, out_ch=spec.out_ch, z=spec.z,
                     mults=list(spec.mults), num_blocks=spec.num_blocks, last_tanh=spec.last_tanh, depths=list(spec.depths),
-                    dims=list(spec.dims), stem_stride=spec.stem_stride, jnd_in=spec.jnd_in, jnd_out=spec.jnd_out)
+                    dims=list(spec.dims), stem_stride=spec.stem_stride, jnd_in=spec.jnd_in, jnd_out=spec.jnd_out,
+                    unet_act=spec.unet_act, unet_norm=spec.unet_norm, extractor=spec.extractor, vit_dim=spec.vit_dim,
+                    vit_depth=spec.vit_depth, vit_heads=spec.vit_heads, vit_patch=spec.vit_patch, vit_window=spec.vit_window,
+                    vit_global=list(spec.vit_global), vit_out=spec.vit_out, vit_mlp_ratio=spec.vit_mlp_ratio, vit_rel_pos=spec.vit_rel_pos)
 
 
 def make_model(spec, sd):
@@ -104,6 +107,32 @@ def tinyc():
 def test_tiny_chunky_matches_reference_golden(tinyc, name):
     """ChunkySeal-shaped architecture: RGB embedder, stride-2 stem, channel counts not multiple of 4, odd feature maps."""
     _run_case(*tinyc, name)
+
+
+@pytest.fixture(scope="module")
+def tinyv():
+    s = legacy_tiny_spec()
+    sd = make_state_dict(s, seed=6)
+    return s, sd, make_model(s, sd)
+
+
+@pytest.mark.parametrize("name", ["tinyv_img", "tinyv_img_resize", "tinyv_vid"])
+def test_tiny_legacy_matches_reference_golden(tinyv, name):
+    """videoseal_0.0 family: ChanRMSNorm/SiLU RGB U-Net, ViT extractor (windowed + global attention with decomposed
+    relative positions), no JND -- HIP path vs fixtures of the unmodified reference"""
+    _run_case(*tinyv, name)
+
+
+@pytest.mark.parametrize("name", ["vs00_img256", "vs00_vid"])
+def test_vs00_matches_reference_golden(name):
+    """the released legacy card itself (96 bits, 12-block ViT-S/16 extractor) through videoseal_amd.build"""
+    s = spec_from_card(os.path.join(CARDS, "videoseal_0.0.yaml"))
+    sd = make_state_dict(s, seed=5)
+    m = videoseal_amd.build("videoseal_0.0")
+    assert m.attenuation is None and m.embedder.cfg.extractor == "sam"
+    msg = m.load_state_dict(sd, strict=True)
+    assert not msg.missing_keys and not msg.unexpected_keys
+    _run_case(s, sd, m.eval().to("cuda"), name)
 
 
 @pytest.mark.parametrize("name", FULL)

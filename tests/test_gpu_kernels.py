@@ -482,6 +482,50 @@ def test_upconv_lowres_gemm_gather_ln(eng, shape):
     assert torch.equal(got[..., :C1], x.permute(0, 2, 3, 1)) and torch.equal(got[..., C1:], (sk * 2 ** -0.5).permute(0, 2, 3, 1))
 
 
+@pytest.mark.parametrize("shape", [(37, 16), (130, 64), (9, 320)])
+def test_rmsnorm_act(eng, shape):
+    """ChanRMSNorm (common.py:172-179) + SiLU (+ residual branch) against F.normalize * sqrt(C) * gamma in torch fp32"""
+    rows, Cc = shape
+    g = torch.Generator().manual_seed(41)
+    x, add = torch.randn(rows, Cc, generator=g), torch.randn(rows, Cc, generator=g)
+    gamma = torch.rand(Cc, generator=g) + 0.5
+    ref = F.silu(F.normalize(x, dim=1) * Cc ** 0.5 * gamma) + add
+    out = torch.full((rows, Cc + 4), -7.0, device=DEV)
+    N.check(eng.lib.vs_rmsnorm_act(N.ptr(dv(x)), rows, Cc, Cc, N.ptr(dv(gamma)), N.ACT_SILU, N.ptr(dv(add)), Cc, N.ptr(out), Cc + 4, N.stream()), "rms")
+    torch.cuda.synchronize()
+    assert (out.cpu()[:, :Cc] - ref).abs().max() < 2e-6 and (out.cpu()[:, Cc:] == 0).all()
+
+
+@pytest.mark.parametrize("cfg", [(2, 16, 16, 6, 64, 0), (2, 16, 16, 6, 64, 8), (3, 8, 8, 2, 16, 4), (1, 8, 12, 3, 32, 0), (2, 8, 8, 2, 16, 0)])
+def test_vit_attention(eng, cfg):
+    """vit.py:302-360 Attention.forward core (scaled q.k^T + decomposed relative positions, softmax, @v) incl. the window partition
+    of vit.py:363-402, against the same maths in torch fp32"""
+    B, H, W, heads, hd, win = cfg
+    D = heads * hd
+    g = torch.Generator().manual_seed(43)
+    qkv = torch.randn(B, H, W, 3 * D, generator=g)
+    Th, Tw = (win, win) if win else (H, W)
+    rel_h, rel_w = 0.3 * torch.randn(2 * Th - 1, hd, generator=g), 0.3 * torch.randn(2 * Tw - 1, hd, generator=g)
+    x = qkv
+    if win:
+        x = x.view(B, H // win, win, W // win, win, 3 * D).permute(0, 1, 3, 2, 4, 5).reshape(-1, win, win, 3 * D)
+    Bw = x.shape[0]
+    q, k, v = x.reshape(Bw, Th * Tw, 3, heads, hd).permute(2, 0, 3, 1, 4).reshape(3, Bw * heads, Th * Tw, hd).unbind(0)
+    attn = (q * hd ** -0.5) @ k.transpose(-2, -1)
+    Rh = rel_h[torch.arange(Th)[:, None] - torch.arange(Th)[None, :] + Th - 1]
+    Rw = rel_w[torch.arange(Tw)[:, None] - torch.arange(Tw)[None, :] + Tw - 1]
+    rq = q.reshape(Bw * heads, Th, Tw, hd)
+    attn = (attn.view(Bw * heads, Th, Tw, Th, Tw) + torch.einsum("bhwc,hkc->bhwk", rq, Rh)[:, :, :, :, None]
+            + torch.einsum("bhwc,wkc->bhwk", rq, Rw)[:, :, :, None, :]).view(Bw * heads, Th * Tw, Th * Tw)
+    o = (attn.softmax(-1) @ v).view(Bw, heads, Th, Tw, hd).permute(0, 2, 3, 1, 4).reshape(Bw, Th, Tw, D)
+    if win:
+        o = o.view(B, H // win, W // win, win, win, D).permute(0, 1, 3, 2, 4, 5).reshape(B, H, W, D)
+    out = torch.empty(B, H, W, D, device=DEV)
+    N.check(eng.lib.vs_vit_attention(N.ptr(dv(qkv)), B, H, W, heads, hd, win, N.ptr(dv(rel_h)), N.ptr(dv(rel_w)), N.ptr(out), N.stream()), "attn")
+    torch.cuda.synchronize()
+    assert (out.cpu() - o).abs().max() < 1e-5
+
+
 def test_msg_latent_and_broadcast(eng):
     g = torch.Generator().manual_seed(10)
     B, k, hid = 3, 40, 24

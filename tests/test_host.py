@@ -17,7 +17,7 @@ from tests._util import GOLDEN
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-@pytest.mark.parametrize("card", ["videoseal_1.0", "pixelseal"])
+@pytest.mark.parametrize("card", ["videoseal_1.0", "pixelseal", "videoseal_0.0"])
 def test_state_dict_contract(card):
     """keys, ORDER and shapes equal the reference's state_dict (dumped by tests/golden/make_golden.py)."""
     ref = json.load(open(os.path.join(GOLDEN, "state_dict_keys.json")))[card]

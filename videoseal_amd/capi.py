@@ -51,6 +51,9 @@ class CModel:
                  scaling_w: Optional[float] = None, scaling_i: Optional[float] = None):
         L = N.lib()
         _bind(L)
+        if cfg.extractor != "convnext" or cfg.unet_norm != "batch":
+            raise NotImplementedError("the model-level C-ABI covers the released cards (BatchNorm/ReLU U-Net + ConvNeXt-V2 extractor); "
+                                      "the legacy videoseal_0.0 family runs through the operator-level entry points (videoseal_amd.engine)")
         self.cfg = cfg
         c = ModelCfgC()
         c.nbits, c.hidden, c.img_size, c.in_ch, c.out_ch, c.yuv = cfg.nbits, cfg.hidden, cfg.img_size, cfg.in_ch, cfg.out_ch, int(cfg.yuv)

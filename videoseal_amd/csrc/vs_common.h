@@ -43,6 +43,7 @@ __device__ __forceinline__ float vs_apply_act(float v, int act) {
     case VS_ACT_RELU: return v > 0.f ? v : 0.f;
     case VS_ACT_GELU: return vs_gelu(v);
     case VS_ACT_TANH: return tanhf(v);
+    case VS_ACT_SILU: return v / (1.0f + __expf(-v));       // nn.SiLU: x * sigmoid(x)
     default: return v;
   }
 }

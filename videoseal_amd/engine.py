@@ -211,6 +211,11 @@ class HipEngine:
         cout = w0.shape[0]
         wr, cpr = pack_conv(g(p + ".res_conv.weight"), rup(cin, 4))
         res = ConvW(wr, g(p + ".res_conv.bias").float().contiguous(), cout, 1, 1, cpr)
+        if self.cfg.unet_norm == "rms":     # ChanRMSNorm + SiLU (legacy 0.0 card): nothing folds into the convs
+            wt0, cp0 = pack_conv(w0, rup(cin, 4))
+            wt1, cp1 = pack_conv(g(p + ".double_conv.3.weight"), rup(cout, 4))
+            gm = [g(f"{p}.double_conv.{i}.gamma").float().reshape(-1).contiguous() for i in (1, 4)]
+            return dict(c0=ConvW(wt0, None, cout, 3, 3, cp0), c1=ConvW(wt1, None, cout, 3, 3, cp1), res=res, cout=cout, rms=gm)
         if train:      # batch-statistics BatchNorm: raw convolutions + the live BN tensors (running stats are updated in place)
             wt0, cp0 = pack_conv(w0, rup(cin, 4))
             wt1, cp1 = pack_conv(g(p + ".double_conv.3.weight"), rup(cout, 4))
@@ -500,8 +505,8 @@ class HipEngine:
         bn = {1: 128, 2: 64, 3: 32, 4: 192, 5: 96, 13: 64, 14: 128}[tile]
         return bn < 2 * n + 64 or tile == 3     # skip tiles that would be mostly padding
 
-    def layernorm(self, x: Act, w, b, out: Act, act=N.ACT_NONE):
-        N.check(self.lib.vs_layernorm_act(N.ptr(x.t), x.rows, x.C, x.ld, N.ptr(w), N.ptr(b), 1e-6, act, N.ptr(out.t), out.ld,
+    def layernorm(self, x: Act, w, b, out: Act, act=N.ACT_NONE, eps=1e-6):
+        N.check(self.lib.vs_layernorm_act(N.ptr(x.t), x.rows, x.C, x.ld, N.ptr(w), N.ptr(b), eps, act, N.ptr(out.t), out.ld,
                                           N.stream()), "vs_layernorm_act")
         return out
 
@@ -534,8 +539,29 @@ class HipEngine:
             out = self.new_act(tag + ".o", x.B, x.H, x.W, cout)
         return self._bn_batch(raw, p["bn"][1], N.ACT_RELU, out, add=rs)
 
+    def resblock_rms(self, x: Act, p, tag: str, out: Optional[Act] = None) -> Act:
+        """unet.py:17-39 with ChanRMSNorm + SiLU (common.py:118-119, 172-179): silu(rms(conv(silu(rms(conv(x)))))) + res_conv(x)."""
+        cout, L, st = p["cout"], self.lib, N.stream()
+        raw = self.new_act(tag + ".raw", x.B, x.H, x.W, cout)
+        t = self.new_act(tag + ".t", x.B, x.H, x.W, cout)
+        self.conv(x, p["c0"], raw, pad=1)
+        N.check(L.vs_rmsnorm_act(N.ptr(raw.t), raw.rows, cout, raw.ld, N.ptr(p["rms"][0]), N.ACT_SILU, None, 0, N.ptr(t.t), t.ld, st), "vs_rmsnorm_act")
+        self.conv(t, p["c1"], raw, pad=1)
+        rs = self.new_act(tag + ".res", x.B, x.H, x.W, cout)
+        self.conv(x, p["res"], rs)
+        if out is None:
+            out = self.new_act(tag + ".o", x.B, x.H, x.W, cout)
+        if out.ld != rup(cout, 4):
+            raise N.NativeError("resblock_rms writes whole rows")
+        N.check(L.vs_rmsnorm_act(N.ptr(raw.t), raw.rows, cout, raw.ld, N.ptr(p["rms"][1]), N.ACT_SILU, N.ptr(rs.t), rs.ld, N.ptr(out.t), out.ld, st),
+                "vs_rmsnorm_act")
+        return out
+
     def resblock(self, x: Act, p, tag: str, out: Optional[Act] = None, out_coff=0) -> Act:
         """unet.py:38-39  relu(bn(conv(relu(bn(conv(x)))))) + res_conv(x); the 1x1 rides in the 2nd conv's K loop."""
+        if "rms" in p:
+            assert out_coff == 0
+            return self.resblock_rms(x, p, tag, out)
         if "bn" in p:
             assert out_coff == 0
             return self.resblock_train(x, p, tag, out)
@@ -552,6 +578,8 @@ class HipEngine:
     def embedder_forward(self, x: Act, msgs_i32: torch.Tensor, bn_train: bool = False) -> torch.Tensor:
         """x: key frames, NHWC(ld 4), already mapped to [-1,1]. Returns delta [B][out_ch][S_h][S_w] (planar).
         bn_train: BatchNorm on batch statistics (module in .train() mode), running statistics updated in place."""
+        if self.cfg.unet_norm == "rms":
+            bn_train = False              # no BatchNorm in the net: train and eval forwards coincide
         if bn_train:
             if self.Et is None:
                 self._pack_embedder(self._g, train=True)
@@ -560,6 +588,8 @@ class HipEngine:
         c, E, L = self.cfg, (self.Et if bn_train else self.E), self.lib
         B = x.B
         st = N.stream()
+        rms = c.unet_norm == "rms"
+        up_act = N.ACT_SILU if c.unet_act == "silu" else N.ACT_RELU        # unet.py:61-62: Upsample gets the U-Net's act_layer
         hid: List[Act] = [self.resblock(x, E["inc"], "inc")]
         nlev = len(c.zc) - 1
         for i in range(nlev):
@@ -569,7 +599,11 @@ class HipEngine:
             self.conv(src, E["downs"][i]["down"], dwn, stride=2, pad=1)
             if i == nlev - 1:     # last level lands in the message-augmented latent [lat | msg]
                 h3 = self.new_act("h3", B, Ho, Wo, c.bott)
-                self.resblock(dwn, E["downs"][i]["rb"], f"down{i}", out=h3)
+                if rms:           # the RMSNorm epilogue writes whole rows: land in a dense map, then copy into columns [0, zc[-1])
+                    lat_ = self.resblock(dwn, E["downs"][i]["rb"], f"down{i}")
+                    N.check(L.vs_cat2_scale(None, 0, 0, N.ptr(lat_.t), lat_.C, lat_.ld, 1.0, lat_.rows, N.ptr(h3.t), h3.ld, st), "vs_cat2_scale")
+                else:
+                    self.resblock(dwn, E["downs"][i]["rb"], f"down{i}", out=h3)
                 hid.append(h3)
             else:
                 hid.append(self.resblock(dwn, E["downs"][i]["rb"], f"down{i}"))
@@ -587,7 +621,7 @@ class HipEngine:
 
         def lowres_cat(k: int, like: Act) -> Optional[Act]:
             """[x | skip] of Upsample group k at the LOW resolution; the producer of x writes columns [0, C) itself (eval mode)"""
-            if k >= nlev or "gemm" not in E["ups"][k] or bn_train or fused_ok(k, like.C, hid[nlev - k].C):
+            if k >= nlev or "gemm" not in E["ups"][k] or bn_train or rms or fused_ok(k, like.C, hid[nlev - k].C):
                 return None
             return self.new_act(f"up{k}.lcat", B, like.H, like.W, like.C + hid[nlev - k].C)
 
@@ -602,7 +636,7 @@ class HipEngine:
                 ln = self.new_act(f"up{k}.ln", B, 2 * xcur.H, 2 * xcur.W, co)
                 N.check(L.vs_upconv_fused(N.ptr(xcur.t), xcur.C, xcur.ld, N.ptr(skip.t), skip.C, skip.ld, 2 ** -0.5,
                                           N.ptr(up["gemm"].with_split().split), B, xcur.H, xcur.W, co, N.ptr(up["lnw"]), N.ptr(up["lnb"]),
-                                          1e-6, N.ACT_RELU, N.ptr(ln.t), ln.ld, st), "vs_upconv_fused")
+                                          1e-6, up_act, N.ptr(ln.t), ln.ld, st), "vs_upconv_fused")
             elif "gemm" in up:     # low-resolution 9-tap GEMM + gather / LayerNorm / ReLU (see vs_upconv_gather_ln)
                 co = up["gemm"].N // 9
                 direct = xcur.ld == xcur.C + skip.C      # x already sits in columns [0, C) of the concat buffer
@@ -613,7 +647,7 @@ class HipEngine:
                 z = self.new_act(f"up{k}.z", B, lc.H, lc.W, 9 * co)
                 self.conv(lc, up["gemm"], z, prof=(f"up{k}.gemm9" if self.time_all_convs else None))
                 ln = self.new_act(f"up{k}.ln", B, 2 * lc.H, 2 * lc.W, co)
-                N.check(L.vs_upconv_gather_ln(N.ptr(z.t), z.ld, B, lc.H, lc.W, co, N.ptr(up["lnw"]), N.ptr(up["lnb"]), 1e-6, N.ACT_RELU,
+                N.check(L.vs_upconv_gather_ln(N.ptr(z.t), z.ld, B, lc.H, lc.W, co, N.ptr(up["lnw"]), N.ptr(up["lnb"]), 1e-6, up_act,
                                               N.ptr(ln.t), ln.ld, st), "vs_upconv_gather_ln")
             else:
                 cat = self.new_act(f"up{k}.cat", B, 2 * xcur.H, 2 * xcur.W, xcur.C + skip.C)
@@ -622,7 +656,7 @@ class HipEngine:
                 cv = self.new_act(f"up{k}.conv", B, cat.H, cat.W, up["conv"].N)
                 self.conv(cat, up["conv"], cv, pad=1, pad_mode=N.PAD_REFLECT)
                 ln = self.new_act(f"up{k}.ln", B, cat.H, cat.W, up["conv"].N)
-                self.layernorm(cv, up["lnw"], up["lnb"], ln, act=N.ACT_RELU)
+                self.layernorm(cv, up["lnw"], up["lnb"], ln, act=up_act)
             lc = lowres_cat(k + 1, ln)
             xcur = self.resblock(ln, up["rb"], f"up{k}", out=(Act(lc.t, B, lc.H, lc.W, up["rb"]["cout"], lc.ld) if lc else None))
         delta = self.buf("delta", B * c.out_ch * xcur.H * xcur.W)
@@ -633,6 +667,8 @@ class HipEngine:
     # ------------------------------------------------------------------ extractor
     def extractor_forward(self, x: Act) -> torch.Tensor:
         """x: NHWC(ld 4) RGB already mapped to [-1,1]. Returns logits [B][1+nbits]."""
+        if self.cfg.extractor == "sam":
+            return self.vit_extractor_forward(x)
         if self.X is None:
             self._pack_extractor(self._g)
         c, X, L = self.cfg, self.X, self.lib
@@ -679,6 +715,12 @@ class HipEngine:
                           # than the GEMM with the fused transform, whose frame-boundary select costs registers
                     N.check(L.vs_grn_apply(N.ptr(hh.t), B, HW, 4 * Cc, hh.ld, N.ptr(scale), hh.ld, N.ptr(blk["beta"]), st), "vs_grn_apply")
                     self.conv(hh, blk["pw2"], cur, res=cur)
+        return self._pixel_decoder(cur, X)
+
+    def _pixel_decoder(self, cur: Act, X) -> torch.Tensor:
+        """pixel_decoder.py:61-83 with upscale_stages [1]: reflect-pad conv3x3 -> LayerNorm(cf) -> GELU -> mean(H, W) -> Linear."""
+        c, L, st, B = self.cfg, self.lib, N.stream(), cur.B
+        d = [cur.C]
         hc = self.new_act("head.c", B, cur.H, cur.W, d[-1])
         hw = X["head_conv"]
         if cur.rows <= 4096 and cur.H > 1 and cur.W > 1 and hw.CinP == cur.ld and self.use_split:
@@ -696,6 +738,88 @@ class HipEngine:
         N.check(L.vs_pool_linear(N.ptr(hl.t), B, hl.H * hl.W, hl.C, hl.ld, N.ptr(X["lin_w"]), N.ptr(X["lin_b"]), c.nbits + 1, N.ptr(out), st),
                 "vs_pool_linear")
         return out
+
+    # ------------------------------------------------------------------ ViT extractor (legacy videoseal_0.0 card)
+    def _pack_vit(self, g):
+        c = self.cfg
+        ie = "detector.image_encoder"
+        D_ = c.vit_dim
+        V = {}
+
+        def lin(key, in_ld):
+            w, cp = pack_conv(g(key + ".weight").float()[:, :, None, None], in_ld)
+            return ConvW(w, g(key + ".bias").float().contiguous(), w.shape[0], 1, 1, cp)
+
+        wp, cpp = pack_patch_conv(g(ie + ".patch_embed.proj.weight"), 4)
+        V["patch"] = ConvW(wp, g(ie + ".patch_embed.proj.bias").float().contiguous(), D_, c.vit_patch, 1, cpp)
+        V["pos"] = g(ie + ".pos_embed").float().reshape(-1, D_).contiguous()          # [g*g][D]
+        V["blocks"] = []
+        for i in range(c.vit_depth):
+            p = f"{ie}.blocks.{i}"
+            V["blocks"].append(dict(
+                n1=(g(p + ".norm1.weight").float().contiguous(), g(p + ".norm1.bias").float().contiguous()),
+                n2=(g(p + ".norm2.weight").float().contiguous(), g(p + ".norm2.bias").float().contiguous()),
+                qkv=lin(p + ".attn.qkv", D_), proj=lin(p + ".attn.proj", D_),
+                lin1=lin(p + ".mlp.lin1", D_), lin2=lin(p + ".mlp.lin2", int(D_ * c.vit_mlp_ratio)),
+                rel_h=g(p + ".attn.rel_pos_h").float().contiguous() if c.vit_rel_pos else None,
+                rel_w=g(p + ".attn.rel_pos_w").float().contiguous() if c.vit_rel_pos else None,
+                window=0 if i in c.vit_global else c.vit_window))
+        wn0, cp0 = pack_conv(g(ie + ".neck.0.weight"), rup(D_, 4))
+        V["neck0"] = ConvW(wn0, None, c.vit_out, 1, 1, cp0)
+        V["neck1"] = (g(ie + ".neck.1.weight").float().contiguous(), g(ie + ".neck.1.bias").float().contiguous())
+        wn2, cp2 = pack_conv(g(ie + ".neck.2.weight"), self._xld(c.vit_out))
+        V["neck2"] = ConvW(wn2, None, c.vit_out, 3, 3, cp2)
+        V["neck3"] = (g(ie + ".neck.3.weight").float().contiguous(), g(ie + ".neck.3.bias").float().contiguous())
+        pd = "detector.pixel_decoder"
+        wh, cph = pack_conv(g(pd + ".output_upscaling.0.upsample_block.2.weight"), self._xld(c.vit_out))
+        V["head_conv"] = ConvW(wh, None, c.vit_out, 3, 3, cph)
+        V["head_ln"] = (g(pd + ".output_upscaling.0.upsample_block.3.weight").float().contiguous(), g(pd + ".output_upscaling.0.upsample_block.3.bias").float().contiguous())
+        V["lin_w"] = g(pd + ".linear.weight").float().contiguous()
+        V["lin_b"] = g(pd + ".linear.bias").float().contiguous()
+        self.X = V
+        self._sd_now = None
+
+    def vit_extractor_forward(self, x: Act) -> torch.Tensor:
+        """extractor.py:45-75 + vit.py:129-144: x (NHWC ld 4, already x*2-1) -> patch embedding + absolute positions -> blocks
+        (LayerNorm -> windowed / global attention with decomposed relative positions -> +x -> LayerNorm -> MLP -> +x) -> neck ->
+        pixel decoder -> logits [B][1+nbits].  Linears and convs: vs_conv_gemm; attention: vs_vit_attention."""
+        if self.X is None:
+            self._pack_vit(self._g)
+        c, V, L, st, B = self.cfg, self.X, self.lib, N.stream(), x.B
+        P, D_ = c.vit_patch, c.vit_dim
+        gh, gw = x.H // P, x.W // P
+        if gh * gw * D_ != V["pos"].numel():
+            raise N.NativeError(f"ViT extractor: {x.H}x{x.W} input does not match the {int(math.isqrt(V['pos'].shape[0])) * P}^2 position table")
+        pos = self._ws.get(("vit.pos", B))
+        if pos is None:                      # absolute positions as the patch conv's residual operand: one row per token of every frame
+            pos = V["pos"].repeat(B, 1).contiguous()
+            self._ws[("vit.pos", B)] = pos
+        tok = self.new_act("vit.x", B, gh, gw, D_)
+        self.conv(x, V["patch"], tok, geom=(gw, P * 4, P * 4, P, 1, 0, 0), res=Act(pos, B, gh, gw, D_, D_))
+        hd = D_ // c.vit_heads
+        hid = int(D_ * c.vit_mlp_ratio)
+        nrm = self.new_act("vit.n", B, gh, gw, D_)
+        qkv = self.new_act("vit.qkv", B, gh, gw, 3 * D_)
+        att = self.new_act("vit.att", B, gh, gw, D_)
+        mid = self.new_act("vit.mid", B, gh, gw, hid)
+        for blk in V["blocks"]:
+            self.layernorm(tok, blk["n1"][0], blk["n1"][1], nrm, eps=1e-5)           # nn.LayerNorm default eps
+            self.conv(nrm, blk["qkv"], qkv)
+            N.check(L.vs_vit_attention(N.ptr(qkv.t), B, gh, gw, c.vit_heads, hd, blk["window"], N.ptr(blk["rel_h"]), N.ptr(blk["rel_w"]),
+                                       N.ptr(att.t), st), "vs_vit_attention")
+            self.conv(att, blk["proj"], tok, res=tok)                                # x = shortcut + proj(attn)
+            self.layernorm(tok, blk["n2"][0], blk["n2"][1], nrm, eps=1e-5)
+            self.conv(nrm, blk["lin1"], mid, act=N.ACT_GELU)
+            self.conv(mid, blk["lin2"], tok, res=tok)                                # x = x + mlp(norm2(x))
+        n0 = self.new_act("vit.neck0", B, gh, gw, c.vit_out)
+        self.conv(tok, V["neck0"], n0)
+        n1 = self.new_act("vit.neck1", B, gh, gw, c.vit_out, self._xld(c.vit_out))
+        self.layernorm(n0, V["neck1"][0], V["neck1"][1], n1)
+        n2 = self.new_act("vit.neck2", B, gh, gw, c.vit_out)
+        self.conv(n1, V["neck2"], n2, pad=1)
+        n3 = self.new_act("vit.neck3", B, gh, gw, c.vit_out, self._xld(c.vit_out))
+        self.layernorm(n2, V["neck3"][0], V["neck3"][1], n3)
+        return self._pixel_decoder(n3, V)
 
     # ------------------------------------------------------------------ shell
     def resize_pre(self, imgs: torch.Tensor, S: Tuple[int, int], antialias: bool, *, want_rgb: bool, mul=1.0, add=0.0,

@@ -89,7 +89,10 @@ class Extractor(nn.Module):
     def __init__(self, cfg: ModelCfg, seed: int = 0):
         super().__init__()
         tree = build_tree(detector_entries(cfg), seed + 1)
-        self.convnext = tree.convnext
+        if cfg.extractor == "sam":            # SegmentationExtractor (extractor.py:40-75): image_encoder + pixel_decoder
+            self.image_encoder = tree.image_encoder
+        else:
+            self.convnext = tree.convnext
         self.pixel_decoder = tree.pixel_decoder
         self.cfg = cfg
         self._root = None
@@ -587,6 +590,6 @@ def aggregate_bits(bit_preds: torch.Tensor, aggregation: Optional[str]) -> torch
 def build_model(cfg: ModelCfg, seed: int = 0) -> Videoseal:
     """cfg.py:120-144: embedder + extractor + identity augmenter + JND -> Videoseal (train mode, CPU, like the reference)."""
     return Videoseal(Embedder(cfg, seed), Extractor(cfg, seed), get_dummy_augmenter(),
-                     attenuation=JND(in_channels=cfg.jnd_in, out_channels=cfg.jnd_out), scaling_w=cfg.scaling_w,
+                     attenuation=(JND(in_channels=cfg.jnd_in, out_channels=cfg.jnd_out) if cfg.jnd_in > 0 else None), scaling_w=cfg.scaling_w,
                      scaling_i=cfg.scaling_i, img_size=cfg.img_size, chunk_size=cfg.chunk_size, step_size=cfg.step_size,
                      blending_method=cfg.blending_method)
