@@ -331,6 +331,15 @@ int vs_median_filter(const float* src, float* dst, int planes, int H, int W, int
 int64_t vs_jpeg_workspace_bytes(int F, int H, int W);
 int vs_jpeg_roundtrip(const float* src, float* dst, int F, int H, int W, int quality, void* workspace, void* stream);
 
+/* H.264-style transform-coding PROXY for VideoCompression / H264 / H264rgb / H265 (augmentation/video.py:20-205).  The reference
+ * round-trips the clip through libx264 / libx265 via PyAV on the CPU; that codec has no in-repo arithmetic and is not available
+ * offline, so this entry point is a DEFINED stand-in, not a bit-stream model: clamp -> uint8 -> [integer BT.601
+ * YCbCr, 4:2:0] -> per 4x4 block H.264 core transform + quantisation / de-quantisation at qp (flat 128 prediction, no deblocking) ->
+ * back to RGB / 255.  qp in [0, 51] (the wrappers pass clamp(crf)); rgb_mode = 1 codes the R, G, B planes directly (libx264rgb).
+ * Bit-exact with oracle/h264_proxy.py.  workspace: vs_h264_proxy_workspace_bytes(F, H, W) bytes. */
+int64_t vs_h264_proxy_workspace_bytes(int F, int H, int W);
+int vs_h264_proxy_roundtrip(const float* src, float* dst, int F, int H, int W, int qp, int rgb_mode, void* workspace, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

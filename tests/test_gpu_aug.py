@@ -11,6 +11,7 @@ from oracle.inputs import synthetic_frames, synthetic_msgs  # noqa: E402
 from oracle.weights import make_state_dict, tiny_spec  # noqa: E402
 from tests.test_gpu_e2e import make_model  # noqa: E402
 from videoseal_amd import augmentation as G  # noqa: E402
+from videoseal_amd import native as N  # noqa: E402
 
 
 @pytest.fixture(scope="module")
@@ -135,8 +136,49 @@ def test_augmenter_draws_strengths_in_the_reference_order():
         assert picked == "+".join(want), seed
         assert out.shape == x.shape and mask.shape == (2, 1, 64, 64)
         assert (out.cpu() - ref).abs().max() < (1e-5 if "JPEG" not in picked else 3e-2), (seed, picked)
-    with pytest.raises(NotImplementedError):
-        G.H264()(x.cuda(), None, 23)          # external codec: loud, no fallback
+
+
+@pytest.mark.parametrize("shape", [(3, 64, 64), (2, 70, 90), (1, 33, 47), (4, 144, 176)])
+@pytest.mark.parametrize("crf", [0, 23, 28, 40, 51])
+def test_h264_proxy_bit_exact_with_its_definition(shape, crf):
+    """csrc/h264_proxy.hip vs oracle/h264_proxy.py (integer arithmetic: bit-exact), yuv420 and rgb planes.  The proxy stands in for
+    the reference's libx264 round trip (augmentation/video.py:20-119), which cannot be pinned offline -- see the oracle header."""
+    from oracle import h264_proxy as HP
+    x = synthetic_frames(*shape, seed=9)
+    for rgb in (False, True):
+        got = G.h264_proxy(x.cuda(), crf, rgb_mode=rgb).cpu()
+        ref = torch.from_numpy(HP.roundtrip(x.numpy(), crf, rgb))
+        assert torch.equal(got, ref), (shape, crf, rgb, (got - ref).abs().max().item())
+
+
+def test_h264_classes_follow_the_reference_interface():
+    """video.py:147-205: crf drawn with torch.randint from [min_crf, max_crf]; odd sizes zero-padded to even; masks pass through;
+    name2aug wiring; the pyav side path is loud when PyAV is missing"""
+    x = synthetic_frames(5, 45, 63, seed=3).cuda()
+    m = torch.ones(5, 1, 45, 63).cuda()
+    torch.manual_seed(11)
+    out, mo = G.H264(min_crf=28, max_crf=40)(x, m)
+    torch.manual_seed(11)
+    crf = torch.randint(28, 41, size=(1,)).item()
+    xp = torch.nn.functional.pad(x, (0, 1, 0, 1))
+    assert out.shape == (5, 3, 46, 64) and mo.shape == (5, 1, 46, 64)
+    assert torch.equal(out, G.h264_proxy(xp, crf))
+    assert torch.equal(G.H264rgb(20, 20)(xp)[0], G.h264_proxy(xp, 20, rgb_mode=True))
+    assert torch.equal(G.H265(30, 30)(xp)[0], G.h264_proxy(xp, 30))
+    assert torch.equal(G.VideoCompression(crf=34)(xp)[0], G.h264_proxy(xp, 34))
+    assert G.name2aug["h264"] is G.H264 and G.name2aug["video_compression"] is G.VideoCompression
+    with pytest.raises(ValueError):
+        G.H264()(xp)
+    vc = G.VideoCompression()
+    vc.backend = "pyav"
+    try:
+        import av  # noqa: F401
+    except ImportError:
+        with pytest.raises(N.NativeError):
+            vc(xp)
+    # distortion grows with crf
+    ps = [float(((G.h264_proxy(xp, q) - xp) ** 2).mean()) for q in (10, 23, 34, 46)]
+    assert ps == sorted(ps)
 
 
 def test_config3_clip_through_the_full_chain():

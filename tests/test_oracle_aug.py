@@ -57,3 +57,20 @@ def test_rotate_perspective_restatement_sanity():
     for (sx, sy), (ex, ey) in zip(sp, ep):                              # the homography maps end points back onto start points
         den = c[6] * ex + c[7] * ey + 1
         assert abs((c[0] * ex + c[1] * ey + c[2]) / den - sx) < 1e-3 and abs((c[3] * ex + c[4] * ey + c[5]) / den - sy) < 1e-3
+
+
+def test_h264_proxy_definition_is_well_behaved():
+    """oracle/h264_proxy.py (the DEFINITION of the codec stand-in; libx264 itself cannot be pinned offline): a flat frame survives any
+    QP exactly up to the colour conversion, distortion grows with crf, padding is cropped, rgb mode codes planes directly."""
+    import numpy as np
+    from oracle import h264_proxy as HP
+    from oracle.inputs import synthetic_frames
+    x = synthetic_frames(2, 37, 50, seed=5).numpy()
+    mse = [float(((HP.roundtrip(x, q) - x) ** 2).mean()) for q in (0, 12, 23, 34, 45, 51)]
+    assert mse == sorted(mse) and mse[0] < 4e-4 and mse[-1] > 10 * mse[0]
+    assert HP.roundtrip(x, 28).shape == x.shape
+    flat = np.full((1, 3, 16, 16), 128 / 255, dtype=np.float32)
+    assert np.abs(HP.roundtrip(flat, 51, True) - flat).max() < 1e-6          # a flat 128 block has a zero residual
+    assert np.abs(HP.roundtrip(flat, 51) - flat).max() <= 2 / 255            # + limited-range YCbCr rounding
+    # the 4x4 transform pair is exact at QP 0 up to the quantiser's rounding: |error| <= 1 grey level in rgb mode
+    assert np.abs(HP.roundtrip(x, 0, True) - np.floor(np.clip(x, 0, 1) * 255) / 255).max() <= 1 / 255 + 1e-7

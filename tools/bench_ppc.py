@@ -40,6 +40,10 @@ def run(B, C, H, W, Co, tiles, two_phase, reps=40):
         print(f"B{B} {C}->{Co} {H}x{W} two_phase={two_phase} tile {(t & 15) + (16 if t & 0x40 else 0):2d} abl {t >> 8:x}: {ms:7.3f} ms {flops/ms/1e9:7.1f} TF-eq{same}", flush=True)
 
 if __name__ == "__main__":
+    if "--prio" in sys.argv:
+        run(32, 384, 32, 32, 384, [0x40, 0x40 | 0x1000, 15, 15 | 0x1000], False)
+        run(32, 384, 32, 32, 384, [0x40, 0x40 | 0x1000], True)
+        sys.exit(0)
     run(32, 384, 32, 32, 384, [12, 15, 0x40], False)
     run(32, 384, 32, 32, 384, [15, 15 | 0x100, 15 | 0x400, 15 | 0x500, 0x40, 0x40 | 0x100, 0x40 | 0x400, 0x40 | 0x500], False)
     run(32, 384, 32, 32, 384, [12, 15, 0x40], True)

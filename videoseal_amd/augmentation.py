@@ -15,10 +15,12 @@ from __future__ import annotations
 
 import ctypes as C
 import math
+import os
 from typing import Dict, List, Optional, Tuple
 
 import torch
 import torch.nn as nn
+import torch.nn.functional as F
 
 from . import native as N
 
@@ -438,8 +440,101 @@ class Perspective(_Aug):
         return startpoints, [topleft, topright, botright, botleft]
 
 
-class H264(_NotBuilt):
-    why = "external libx264 codec (PyAV) -- no in-repo arithmetic to restate (SURVEY.md 8(f)2)"
+def h264_proxy(frames: torch.Tensor, crf: int, rgb_mode: bool = False) -> torch.Tensor:
+    """[F,3,H,W] -> H.264-style transform-coding proxy at QP = clamp(crf, 0, 51) (csrc/h264_proxy.hip, oracle/h264_proxy.py)."""
+    x = _dev(frames)
+    F_, _, H, W = x.shape
+    out = torch.empty_like(x)
+    L = N.lib()
+    ws = torch.empty(int(L.vs_h264_proxy_workspace_bytes(F_, H, W)), dtype=torch.uint8, device=x.device)
+    N.check(L.vs_h264_proxy_roundtrip(N.ptr(x), N.ptr(out), F_, H, W, int(min(max(int(crf), 0), 51)), int(rgb_mode), N.ptr(ws), N.stream()),
+            "vs_h264_proxy_roundtrip")
+    return out
+
+
+class VideoCompression(_Aug):
+    """augmentation/video.py:20-119.  The reference encodes + decodes the clip with libx264 / libx265 through PyAV on the CPU and
+    returns it behind a straight-through estimator.  Two back-ends here:
+      * 'proxy' (default): the on-GPU transform-coding proxy of csrc/h264_proxy.hip -- H.264 4x4 core transform + quantisation at
+        QP = crf, 4:2:0, no prediction / deblocking / rate control.  A documented stand-in (SURVEY.md 8(f)2), NOT libx264 parity.
+      * 'pyav' (VIDEOSEAL_CODEC=pyav, needs the `av` package): the reference's own CPU round trip, kept at the boundary as a side
+        path (frames leave the device exactly as in video.py:106-116).
+    Forward-only, like every augmentation here (the reference's STE forward value is the codec output)."""
+
+    def __init__(self, codec="libx264", crf=28, fps=24):
+        super().__init__()
+        self.codec, self.crf, self.fps = codec, crf, fps
+        self.pix_fmt = "yuv420p" if codec != "libx264rgb" else "rgb24"
+        self.backend = os.environ.get("VIDEOSEAL_CODEC", "proxy")
+
+    def _pyav_roundtrip(self, frames: torch.Tensor, crf: int) -> torch.Tensor:
+        try:
+            import av
+        except ImportError as e:       # loud, never a silent fall-back to the proxy
+            raise N.NativeError("VIDEOSEAL_CODEC=pyav needs the PyAV package (`av`); unset it to use the on-GPU proxy") from e
+        import io
+        import numpy as np
+        arr = (frames.clamp(0, 1).permute(0, 2, 3, 1) * 255).to(torch.uint8).cpu().numpy()
+        buf = io.BytesIO()
+        with av.open(buf, mode="w", format="mp4") as box:
+            st = box.add_stream(self.codec, rate=self.fps)
+            st.width, st.height, st.pix_fmt = arr.shape[2], arr.shape[1], self.pix_fmt
+            st.options = {"crf": str(crf), "threads": "10", "x265-params": "log_level=none"}
+            for fr in arr:
+                for pkt in st.encode(av.VideoFrame.from_ndarray(fr, format="rgb24")):
+                    box.mux(pkt)
+            for pkt in st.encode():
+                box.mux(pkt)
+        buf.seek(0)
+        with av.open(buf, mode="r") as box:
+            dec = [f.to_ndarray(format="rgb24") for f in box.decode(video=0)]
+        return (torch.tensor(np.stack(dec) / 255, dtype=torch.float32).permute(0, 3, 1, 2)).to(frames.device)
+
+    def forward(self, frames, mask=None, crf=None):
+        self.crf = crf or self.crf
+        if frames.shape[2] % 2 or frames.shape[3] % 2:          # video.py:98-102: pad odd sizes with zeros to even
+            frames = F.pad(frames, (0, frames.shape[3] % 2, 0, frames.shape[2] % 2))
+            if mask is not None:
+                mask = F.pad(mask, (0, mask.shape[3] % 2, 0, mask.shape[2] % 2))
+        if self.backend == "pyav":
+            return self._pyav_roundtrip(frames, self.crf), mask
+        return h264_proxy(frames, self.crf, rgb_mode=(self.pix_fmt == "rgb24")), mask
+
+    def __repr__(self):
+        return f"Compressor(codec={self.codec}, crf={self.crf}, fps={self.fps})"
+
+
+class _CrfCodec(VideoCompression):
+    """video.py:147-205: H264 / H264rgb / H265 draw an integer crf in [min_crf, max_crf] from torch's global generator."""
+    CODEC = "libx264"
+
+    def __init__(self, min_crf=None, max_crf=None, fps=24):
+        super().__init__(codec=self.CODEC, fps=fps)
+        self.min_crf, self.max_crf = min_crf, max_crf
+
+    def get_random_crf(self):
+        if self.min_crf is None or self.max_crf is None:
+            raise ValueError("min_crf and max_crf must be provided")
+        return torch.randint(self.min_crf, self.max_crf + 1, size=(1,)).item()
+
+    def forward(self, frames, mask=None, crf=None):
+        return super().forward(frames, mask, crf or self.get_random_crf())
+
+    def __repr__(self):
+        return self.__class__.__name__
+
+
+class H264(_CrfCodec):
+    CODEC = "libx264"
+
+
+class H264rgb(_CrfCodec):
+    CODEC = "libx264rgb"
+
+
+class H265(_CrfCodec):
+    """the proxy has one transform size: at equal crf it produces the same distortion as H264's (HEVC's larger transforms are not modelled)"""
+    CODEC = "libx265"
 
 
 class Sequential(nn.Module):
@@ -461,7 +556,7 @@ class Sequential(nn.Module):
 
 name2aug = {"resize": Resize, "crop": Crop, "hflip": HorizontalFlip, "identity": Identity, "jpeg": JPEG, "gaussian_blur": GaussianBlur,
             "median_filter": MedianFilter, "brightness": Brightness, "contrast": Contrast, "saturation": Saturation, "hue": Hue,
-            "rotate": Rotate, "perspective": Perspective, "h264": H264, "h264rgb": H264, "h265": H264, "video_compression": H264,
+            "rotate": Rotate, "perspective": Perspective, "h264": H264, "h264rgb": H264rgb, "h265": H265, "video_compression": VideoCompression,
             "drop_frame": DropFrame, "gaussian_noise": GaussianNoise, "grayscale": Grayscale, "speed_change": SpeedChange}
 video_augs = ["video_compression", "h264", "h264rgb", "h265"]
 

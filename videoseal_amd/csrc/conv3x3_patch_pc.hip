@@ -318,6 +318,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_patch_pc_kernel(const vs_conv_
   };
 
   __syncthreads();                 // prologue of the producers
+  if (abl & 16) __builtin_amdgcn_s_setprio(3);      // experiment (tools/bench_ppc.py): consumers win every issue arbitration against the producer waves
   int s = 0;
   if (n1 > 0) {
     load_frags(F0, 0);

@@ -25,7 +25,7 @@ EXPORTS = [
     "vs_model_create", "vs_model_destroy", "vs_model_workspace_bytes", "vs_model_embed", "vs_model_detect", "vs_conv_gemm", "vs_layernorm_act", "vs_rmsnorm_act", "vs_vit_attention", "vs_dwconv7_ln", "vs_grn_scale", "vs_grn_scale_from_partials", "vs_grn_apply",
     "vs_upcat2x", "vs_upconv_supported", "vs_upconv_gather_ln", "vs_cat2_scale", "vs_upconv_fused_supported", "vs_upconv_fused_preferred", "vs_upconv_fused", "vs_im2col3x3", "vs_msg_latent", "vs_broadcast_channels", "vs_outc_tanh", "vs_pool_linear", "vs_resize_pre", "vs_resize_pre_u8",
     "vs_jnd_heatmap", "vs_embed_tail", "vs_aug_color_scratch_floats", "vs_aug_color", "vs_aug_crop_flip", "vs_aug_warp", "vs_resize_nchw",
-    "vs_gaussian_blur", "vs_median_filter", "vs_jpeg_workspace_bytes", "vs_jpeg_roundtrip",
+    "vs_gaussian_blur", "vs_median_filter", "vs_jpeg_workspace_bytes", "vs_jpeg_roundtrip", "vs_h264_proxy_workspace_bytes", "vs_h264_proxy_roundtrip",
     "vs_bn_partial_doubles", "vs_bn_batch_stats", "vs_scale_shift_act", "vs_aug_mask_blend", "vs_aug_add_scaled", "vs_aug_gather_frames",
 ]
 
@@ -115,6 +115,7 @@ def lib() -> C.CDLL:
         "vs_gaussian_blur": [P, P, P, I, I, I, I, F, P],
         "vs_median_filter": [P, P, I, I, I, I, P],
         "vs_jpeg_roundtrip": [P, P, I, I, I, I, P, P],
+        "vs_h264_proxy_roundtrip": [P, P, I, I, I, I, I, P, P],
         "vs_bn_batch_stats": [P, I64, I, I64, P, P, F, F, P, P, P, P, P, P],
         "vs_scale_shift_act": [P, I64, I, I64, P, P, I, P, I64, P, I64, P],
         "vs_aug_mask_blend": [P, P, P, P, I, I, I, I, P],
@@ -129,6 +130,8 @@ def lib() -> C.CDLL:
     L.vs_aug_color_scratch_floats.argtypes = [I, I, I]
     L.vs_jpeg_workspace_bytes.restype = C.c_int64
     L.vs_jpeg_workspace_bytes.argtypes = [I, I, I]
+    L.vs_h264_proxy_workspace_bytes.restype = C.c_int64
+    L.vs_h264_proxy_workspace_bytes.argtypes = [I, I, I]
     L.vs_bn_partial_doubles.restype = C.c_int64
     L.vs_bn_partial_doubles.argtypes = [I64, I64]
     L.vs_sizeof_conv_desc.restype = C.c_int
