@@ -111,6 +111,8 @@ typedef struct vs_conv_desc {
 #define VS_CONV_FORCE_F32 0x10
 #define VS_CONV_FORCE_SPLIT 0x20
 #define VS_CONV_TILE_HI 0x40
+#define VS_CONV_PRE 0x80          /* wave-specialised 3x3 kernel (tile codes 15 / 16) only: a_scale is a border-class table [frames][9][N]     */
+                                  /*   (frame stride a_scale_ld, 0 = shared): v = act(acc + table[frame][class(y,x)][n] + bias), see vs_msg_pre */
 int vs_conv_gemm(const vs_conv_desc_t* d, void* stream);
 
 /* LayerNorm over the channel dim of [rows][ld] (+ optional activation).  common.py:131-155 (both data formats). */
@@ -201,6 +203,14 @@ int vs_msg_latent(const float* table, const int32_t* msgs, int Bm, int nbits, in
 /* Broadcast lat[b or 0][0:hidden] over H*W pixels into channels [coff, coff+hidden) of dst.  msg_processor.py:96-115. */
 int vs_broadcast_channels(const float* lat, int Bm, int hidden, float* dst, int B, int HW, int64_t ld, int coff,
                           void* stream);
+
+/* First bottleneck block of the U-Net (unet.py:183-185): its input is [latent | message], and the message channels are CONSTANT over
+ * space (msg_processor.py:96-115), so conv3x3 over them is a per-frame table of NINE border classes (zero padding: first / last rows
+ * and columns miss taps).  P[bm][tap*N + n] = sum_c W[n][tap][msg c] * latent[bm][c] comes from one small vs_conv_gemm; vs_msg_pre
+ * reduces it to table[bm][cy*3 + cx][n] = sum_{valid ky, kx} P[bm][(ky*3+kx)*N + n]  (cy / cx: 0 first, 1 interior, 2 last row / column).
+ * The 3x3 conv over the latent channels alone then adds table[frame][class(y, x)][n] before bias + activation (VS_CONV_PRE with
+ * a_scale = table, a_scale_ld = 9*N, or 0 when one message serves every frame): K shrinks from 9*(lat+msg) to 9*lat. */
+int vs_msg_pre(const float* P, int Bm, int N, float* table, void* stream);
 
 /* 1x1 conv C -> Cout (Cout <= 4) + bias + optional tanh, NHWC in, planar [B][Cout][HW] out.  unet.py:166,194-196. */
 int vs_outc_tanh(const float* x, int64_t rows_per_frame, int B, int C, int64_t ld, const float* w, const float* bias,

@@ -104,6 +104,7 @@ class Eng(HipEngine):
         self.autotune = False
         self.time_all_convs = False
         self._tile_cache = {}
+        self.msg_table_conv = True
 
 
 @pytest.fixture(scope="module", params=["split", "f32"])
@@ -524,6 +525,36 @@ def test_vit_attention(eng, cfg):
     N.check(eng.lib.vs_vit_attention(N.ptr(dv(qkv)), B, H, W, heads, hd, win, N.ptr(dv(rel_h)), N.ptr(dv(rel_w)), N.ptr(out), N.stream()), "attn")
     torch.cuda.synchronize()
     assert (out.cpu() - o).abs().max() < 1e-5
+
+
+@pytest.mark.parametrize("Bm", [1, 4])
+def test_first_bottleneck_block_message_table(eng, Bm):
+    """unet.py:183-185 first bottleneck ResnetBlock on [latent | spatially constant message]: the table form (vs_msg_pre + VS_CONV_PRE,
+    K over the latent channels only) against the plain block on the materialised 384-channel map, and against torch fp32"""
+    if not eng.use_split:
+        pytest.skip("split back-end only")
+    B, nlat, hid, H, W, Co = 4, 128, 256, 16, 32, 384
+    g = torch.Generator().manual_seed(51)
+    latent = torch.randn(B, nlat, H, W, generator=g)
+    msg = torch.randn(Bm, hid, generator=g)
+    x = torch.cat([latent, msg[:, :, None, None].expand(Bm, hid, H, W).expand(B, hid, H, W) if Bm == 1 else msg[:, :, None, None].expand(B, hid, H, W)], 1)
+    w0 = torch.randn(Co, nlat + hid, 3, 3, generator=g) / math.sqrt(9 * (nlat + hid))
+    w1 = torch.randn(Co, Co, 3, 3, generator=g) / math.sqrt(9 * Co)
+    wr = torch.randn(Co, nlat + hid, 1, 1, generator=g) / math.sqrt(nlat + hid)
+    b0, b1, br = (torch.randn(Co, generator=g) * 0.1 for _ in range(3))
+    ref = F.relu(F.conv2d(F.relu(F.conv2d(x, w0, b0, padding=1)), w1, b1, padding=1)) + F.conv2d(x, wr, br)
+    xa = to_nhwc(x)
+    p = {}
+    for k, (w, b) in dict(c0=(w0, b0), c1=(w1, b1), res=(wr, br)).items():
+        wt, cp = pack_conv(w.to(DEV), rup(w.shape[1], 4))
+        p[k] = ConvW(wt, b.to(DEV), Co, w.shape[2], w.shape[3], cp)
+    p["cout"] = Co
+    plain = from_nhwc(eng.resblock(xa, p, "tb")).clone()
+    lat_dev = dv(msg)
+    out = from_nhwc(eng.resblock_msg0(xa, p, "tm", lat_dev, Bm, nlat))
+    torch.cuda.synchronize()
+    assert rel_err(plain, ref) < 2e-5
+    assert rel_err(out, ref) < 2e-5 and (out - plain).abs().max() < 2e-5
 
 
 def test_msg_latent_and_broadcast(eng):

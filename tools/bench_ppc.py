@@ -40,6 +40,11 @@ def run(B, C, H, W, Co, tiles, two_phase, reps=40):
         print(f"B{B} {C}->{Co} {H}x{W} two_phase={two_phase} tile {(t & 15) + (16 if t & 0x40 else 0):2d} abl {t >> 8:x}: {ms:7.3f} ms {flops/ms/1e9:7.1f} TF-eq{same}", flush=True)
 
 if __name__ == "__main__":
+    if "--overhead" in sys.argv:       # fixed cost per launch: K = 9*16 .. 9*384, with / without the output stores
+        for C in (16, 64, 128, 384):
+            run(32, C, 32, 32, 384, [0x40, 0x40 | 0x2000], False)
+        run(16, 384, 32, 32, 384, [0x40, 0x40 | 0x2000], False)
+        sys.exit(0)
     if "--prio" in sys.argv:
         run(32, 384, 32, 32, 384, [0x40, 0x40 | 0x1000, 15, 15 | 0x1000], False)
         run(32, 384, 32, 32, 384, [0x40, 0x40 | 0x1000], True)

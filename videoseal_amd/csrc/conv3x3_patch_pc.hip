@@ -325,6 +325,9 @@ __global__ __launch_bounds__(512, 2) void conv3x3_patch_pc_kernel(const vs_conv_
     __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0): otherwise hipcc drains the PREFETCH below before the first MFMA of every iteration
     // phase 1: the fragment reads of step s+1 are in flight while the MFMAs of step s issue (straight-line body, no
     // conditionals: the compiler's waitcnt placement is exact only then)
+    // (measured, round 2: raw s_barrier + sched_barrier-pinned prefetch instead of __syncthreads() -- hipcc then issues all 15 fragment
+    // reads of step s+1 ahead of the MFMAs of step s instead of draining 13 of them with lgkmcnt(0) in front of the barrier -- left
+    // the per-step time at 0.80 us = 36 MFMAs + ~1/3 bubbles: the LDS round trip in front of the barrier is not what the loop waits for)
     for (; s + 2 < n1; s += 2) {
       load_frags(F1, s + 1);
       mfma_all(F0);
@@ -366,6 +369,20 @@ __global__ __launch_bounds__(512, 2) void conv3x3_patch_pc_kernel(const vs_conv_
       }
     return;
   }
+  if (d.tile_hint & VS_CONV_PRE) {      // border-class table [frames][9][N] (first bottleneck block: the conv over the message channels)
+    const float* tb = d.a_scale + (int64_t)fb * d.a_scale_ld;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int p = (wm * TM + i) * 32 + (e & 3) + 8 * (e >> 2) + 4 * g;
+        const int y = y0 + (p >> 4), x = x0 + (p & 15);
+        const int cls = (y == 0 ? 0 : (y >= d.H - 1 ? 2 : 1)) * 3 + (x == 0 ? 0 : (x >= d.W - 1 ? 2 : 1));
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          if (col[j] < d.N) acc[i][j][e] += tb[cls * d.N + col[j]];
+      }
+  }
   if (n2 > 0) {
     apply_act_all<TM, TN>(acc, bias1, bias2, d.act);
     for (s = n1; s < total; ++s) {       // short: no prefetch across these steps (the rows are published one barrier before)
@@ -380,6 +397,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_patch_pc_kernel(const vs_conv_
     apply_act_all<TM, TN>(acc, bias1, zero, d.act);
   }
 
+  if (abl & 32) return;             // ablation (tools/bench_ppc.py): no output stores
 #pragma unroll
   for (int i = 0; i < TM; ++i) {
 #pragma unroll

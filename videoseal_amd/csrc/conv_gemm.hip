@@ -417,7 +417,9 @@ extern "C" int vs_conv_gemm(const vs_conv_desc_t* dp, void* stream) {
   VS_REQUIRE(d.n_store >= d.N && d.out_coff >= 0 && d.out_coff + d.n_store <= d.out_ld);
   VS_REQUIRE(((uintptr_t)d.in & 15) == 0 && ((uintptr_t)d.wt & 15) == 0);
   if (d.pad_mode == VS_PAD_REFLECT) VS_REQUIRE(d.PH < d.H && d.PW < d.W);
-  if (d.a_scale) VS_REQUIRE(d.a_shift && d.KH == 1 && d.KW == 1 && d.a_scale_ld % 4 == 0);
+  const bool pre_add = (d.tile_hint & VS_CONV_PRE) != 0;      // a_scale = pre-activation addend of the wave-specialised 3x3 kernel
+  if (pre_add) VS_REQUIRE(d.a_scale && (d.a_scale_ld == 0 || d.a_scale_ld >= 9 * (int64_t)d.N) && d.split_k <= 1 && d.H > 1 && d.W > 1);
+  else if (d.a_scale) VS_REQUIRE(d.a_shift && d.KH == 1 && d.KW == 1 && d.a_scale_ld % 4 == 0);
   if (d.in2) VS_REQUIRE(d.wt2 && d.Cin2 > 0 && d.Cin2 % 4 == 0 && d.Cin2P % BK == 0 && d.Cin2P >= d.Cin2 && d.in2_ld % 4 == 0);
   if (d.res) VS_REQUIRE(d.res_ld >= d.N);
   // the kernels address every operand as base + 32-bit byte offset
@@ -425,14 +427,15 @@ extern "C" int vs_conv_gemm(const vs_conv_desc_t* dp, void* stream) {
   const int64_t Ktot = (int64_t)d.KH * d.KW * d.CinP;
   if (!fits_u32(((int64_t)d.B * d.in_sb + (int64_t)(d.H + d.PH) * d.in_sy + (int64_t)d.W * d.in_sx) * 4) ||
       !fits_u32((int64_t)d.N * Ktot * 4) || (d.in2 && !fits_u32(M * d.in2_ld * 4)) ||
-      (d.a_scale && !fits_u32((int64_t)d.B * d.a_scale_ld * 4)))
+      (d.a_scale && !pre_add && !fits_u32((int64_t)d.B * d.a_scale_ld * 4)))
     return VS_ERR_UNSUPPORTED;   // > 4 GiB operand: the caller chunks the batch
   hipStream_t st = (hipStream_t)stream;
   int tile = (d.tile_hint & 0xf) + ((d.tile_hint & VS_CONV_TILE_HI) ? 16 : 0);
   const bool can_split0 = d.wt_split && (!d.in2 || d.wt2_split) && ((uintptr_t)d.wt_split & 15) == 0;
   // 3x3 / stride 1 / "same" convs on tile-aligned frames go to the patch kernel (input patch staged once per channel chunk)
   const bool patch_ok = can_split0 && d.KH == 3 && d.KW == 3 && d.SH == 1 && d.SW == 1 && d.PH == 1 && d.PW == 1 && d.Ho == d.H &&
-                        d.Wo == d.W && !d.a_scale && !(d.tile_hint & VS_CONV_FORCE_F32);
+                        d.Wo == d.W && (!d.a_scale || pre_add) && !(d.tile_hint & VS_CONV_FORCE_F32);
+  if (pre_add) VS_REQUIRE(patch_ok && (tile == 15 || tile == 16));
   if (tile >= 10 && tile <= 12) {
     VS_REQUIRE(patch_ok);
     return vs_conv3x3_patch_dispatch(d, tile, st);

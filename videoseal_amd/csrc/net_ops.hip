@@ -523,6 +523,22 @@ __global__ __launch_bounds__(256) void im2col3x3_kernel(const float* __restrict_
   }
 }
 
+// unet.py:183-185 first bottleneck conv over the spatially constant message channels: border-class table from the per-tap table P
+// (see header).  class = cy*3 + cx, cy / cx = 0 first row / column (tap 0 falls outside), 1 interior, 2 last (tap 2 outside).
+__global__ __launch_bounds__(256) void msg_pre_kernel(const float* __restrict__ P, int N, float* __restrict__ T, int64_t total) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int n = (int)(i % N);
+    const int cls = (int)((i / N) % 9);
+    const int64_t bm = i / ((int64_t)9 * N);
+    const int cy = cls / 3, cx = cls % 3;
+    const float* pb = P + bm * 9 * N + n;
+    float v = 0.f;
+    for (int ky = (cy == 0 ? 1 : 0); ky <= (cy == 2 ? 1 : 2); ++ky)
+      for (int kx = (cx == 0 ? 1 : 0); kx <= (cx == 2 ? 1 : 2); ++kx) v += pb[(ky * 3 + kx) * N];
+    T[i] = v;
+  }
+}
+
 // channel concat of two NHWC maps of the same pixels, the second one scaled: out[r] = [x[r] | skip[r] * s]  (unet.py:186-187 at the
 // LOW resolution).  x may be NULL when its producer already wrote columns [0, C1) of `out`.
 __global__ __launch_bounds__(256) void cat2_scale_kernel(const float* __restrict__ x, int C1, int64_t ld1, const float* __restrict__ skip,
@@ -837,6 +853,14 @@ extern "C" int vs_im2col3x3(const float* x, int B, int H, int W, int64_t ld, int
   const int64_t total = (int64_t)B * H * W * 9 * (ld / 4);
   hipLaunchKernelGGL(im2col3x3_kernel, dim3((unsigned)std::min<int64_t>(cdiv64(total, 256), 1 << 16)), dim3(256), 0, (hipStream_t)stream, x, H,
                      W, ld, pad_mode == VS_PAD_REFLECT ? 1 : 0, out, total);
+  return vs_launch_status();
+}
+
+extern "C" int vs_msg_pre(const float* P, int Bm, int N, float* table, void* stream) {
+  VS_REQUIRE(P && table && Bm > 0 && N > 0);
+  const int64_t total = (int64_t)Bm * 9 * N;
+  hipLaunchKernelGGL(msg_pre_kernel, dim3((unsigned)std::min<int64_t>(cdiv64(total, 256), 1 << 16)), dim3(256), 0, (hipStream_t)stream, P, N, table,
+                     total);
   return vs_launch_status();
 }
 

@@ -150,6 +150,7 @@ class HipEngine:
         # bilinear x2 -> reflect-pad conv3x3 -> LayerNorm sequence (kept for A/B checks)
         self.upconv_lowres = os.environ.get("VIDEOSEAL_UPCONV", "lowres") != "direct"
         self.upconv_fused = os.environ.get("VIDEOSEAL_UPCONV", "lowres") != "unfused"    # thin levels: GEMM + gather in one kernel
+        self.msg_table_conv = os.environ.get("VIDEOSEAL_MSG_TABLE", "1") != "0"         # first bottleneck block: message channels as a table
         # per-shape tile selection: every candidate walks K in the same order, so the result is bit-identical whatever
         # tile wins -- only speed changes (measure, don't guess).  VIDEOSEAL_AUTOTUNE=0 keeps the static heuristic.
         self.autotune = os.environ.get("VIDEOSEAL_AUTOTUNE", "1") != "0"
@@ -336,13 +337,14 @@ class HipEngine:
     def conv(self, x: Act, w: ConvW, out: Act, *, stride=1, pad=0, pad_mode=N.PAD_ZERO, act=N.ACT_NONE, out_coff=0,
              n_store=None, res: Optional[Act] = None, in2: Optional[Act] = None, w2: Optional[ConvW] = None,
              a_scale=None, a_scale_ld=0, a_shift=None, geom=None, tile_hint=0, prof: Optional[str] = None,
-             split_k: Optional[int] = None, sumsq: Optional[torch.Tensor] = None):
+             split_k: Optional[int] = None, sumsq: Optional[torch.Tensor] = None, cin: Optional[int] = None, flops: Optional[float] = None):
+        """cin: read only the first `cin` channels of every pixel (pixel stride stays x.ld)"""
         d = N.ConvDesc()
         if geom is None:
             sh = sw = stride
             ph = pw = pad
             H, W, sx = x.H, x.W, x.ld
-            cin = x.ld
+            cin = x.ld if cin is None else cin
         else:           # patch conv: (W', sx, cin, sh, sw, ph, pw)
             W, sx, cin, sh, sw, ph, pw = geom
             H = x.H
@@ -395,7 +397,7 @@ class HipEngine:
         if timed:
             ev1.record()
             k_total = w.KH * w.KW * w.CinP + (w2.CinP if w2 is not None else 0)
-            self.kernel_timers.append((prof, ev0, ev1, 2.0 * out.rows * w.N * k_total))
+            self.kernel_timers.append((prof, ev0, ev1, 2.0 * out.rows * w.N * k_total if flops is None else flops))
         return out
 
     @staticmethod
@@ -557,6 +559,35 @@ class HipEngine:
                 "vs_rmsnorm_act")
         return out
 
+    def resblock_msg0(self, h3: Act, p, tag: str, lat: torch.Tensor, Bm: int, nlat: int) -> Act:
+        """First bottleneck block (unet.py:183-185) on h3 = [latent (nlat channels) | message (spatially constant)]: the 3x3 conv over
+        the message channels is a per-frame table of nine border classes (vs_msg_pre), so the conv's K loop covers the latent channels
+        only (9*128 instead of 9*384 for VideoSeal 1.0) and the table is added before bias + activation (VS_CONV_PRE)."""
+        cout, c0 = p["cout"], p["c0"]
+        hidden = h3.C - nlat
+        if "c0_lat" not in p:          # sliced once from the BN-folded packed weight [N][9][CinP]
+            w3 = c0.wt.view(cout, 9, c0.CinP)
+            p["c0_lat"] = ConvW(w3[:, :, :nlat].reshape(cout, 9 * nlat).contiguous(), c0.bias, cout, 3, 3, nlat)
+            wm = w3[:, :, nlat:nlat + hidden].permute(1, 0, 2).reshape(9 * cout, hidden).contiguous()      # rows (tap, n)
+            p["c0_msg"] = ConvW(wm, None, 9 * cout, 1, 1, hidden)
+        P = Act(self.buf(tag + ".P", Bm * 9 * cout), Bm, 1, 1, 9 * cout, 9 * cout)
+        self.conv(Act(lat, Bm, 1, 1, hidden, hidden), p["c0_msg"], P)
+        pre = self.buf(tag + ".pre", Bm * 9 * cout)          # border-class table [Bm][9][N]
+        N.check(self.lib.vs_msg_pre(N.ptr(P.t), Bm, cout, N.ptr(pre), N.stream()), "vs_msg_pre")
+        t = self.new_act(tag + ".t", h3.B, h3.H, h3.W, cout)
+        tile = (N.CONV_TILE_HI | 0) if cout % 192 == 0 else 15
+        self.conv(h3, p["c0_lat"], t, pad=1, act=N.ACT_RELU, cin=nlat, a_scale=pre, a_scale_ld=(0 if Bm == 1 else 9 * cout), tile_hint=tile | N.CONV_PRE,
+                  prof=("bott.conv3x3.lat" if self.time_all_convs else None))
+        out = self.new_act(tag + ".o", h3.B, h3.H, h3.W, cout)
+        self.conv(t, p["c1"], out, pad=1, act=N.ACT_RELU, in2=h3, w2=p["res"])
+        return out
+
+    def _msg0_ok(self, h3: Act, p, nlat: int) -> bool:
+        hidden = h3.C - nlat
+        return (self.use_split and self.msg_table_conv and "bn" not in p and "rms" not in p and nlat % 16 == 0 and hidden % 32 == 0 and
+                h3.ld == h3.C and p["c0"].CinP == h3.C and h3.W % 16 == 0 and h3.H % 8 == 0 and p["cout"] >= 128 and
+                h3.B * (h3.H // 8) * (h3.W // 16) >= 128)
+
     def resblock(self, x: Act, p, tag: str, out: Optional[Act] = None, out_coff=0) -> Act:
         """unet.py:38-39  relu(bn(conv(relu(bn(conv(x)))))) + res_conv(x); the 1x1 rides in the 2nd conv's K loop."""
         if "rms" in p:
@@ -627,6 +658,9 @@ class HipEngine:
 
         for j in range(c.num_blocks):
             lc = lowres_cat(0, xcur) if j == c.num_blocks - 1 else None
+            if j == 0 and lc is None and self._msg0_ok(h3, E["bott"][0], c.zc[-1]):
+                xcur = self.resblock_msg0(h3, E["bott"][0], "bott0", lat, Bm, c.zc[-1])
+                continue
             xcur = self.resblock(xcur, E["bott"][j], f"bott{j & 1}", out=(Act(lc.t, B, lc.H, lc.W, xcur.C, lc.ld) if lc else None))
         for k in range(nlev):
             skip = hid.pop()

@@ -17,13 +17,13 @@ LIB_PATH = os.path.join(_HERE, "csrc", "libvideoseal_hip.so")
 
 ACT_NONE, ACT_RELU, ACT_GELU, ACT_TANH, ACT_SILU = 0, 1, 2, 3, 4
 PAD_ZERO, PAD_REFLECT = 0, 1
-CONV_FORCE_F32, CONV_FORCE_SPLIT, CONV_TILE_HI = 0x10, 0x20, 0x40
+CONV_FORCE_F32, CONV_FORCE_SPLIT, CONV_TILE_HI, CONV_PRE = 0x10, 0x20, 0x40, 0x80
 VIDEO_MODES = {"repeat": 0, "alternate": 1, "interpolate": 2}
 
 EXPORTS = [
     "vs_version", "vs_arch", "vs_error_string", "vs_sizeof_conv_desc", "vs_sizeof_tail_desc",
     "vs_model_create", "vs_model_destroy", "vs_model_workspace_bytes", "vs_model_embed", "vs_model_detect", "vs_conv_gemm", "vs_layernorm_act", "vs_rmsnorm_act", "vs_vit_attention", "vs_dwconv7_ln", "vs_grn_scale", "vs_grn_scale_from_partials", "vs_grn_apply",
-    "vs_upcat2x", "vs_upconv_supported", "vs_upconv_gather_ln", "vs_cat2_scale", "vs_upconv_fused_supported", "vs_upconv_fused_preferred", "vs_upconv_fused", "vs_im2col3x3", "vs_msg_latent", "vs_broadcast_channels", "vs_outc_tanh", "vs_pool_linear", "vs_resize_pre", "vs_resize_pre_u8",
+    "vs_upcat2x", "vs_upconv_supported", "vs_upconv_gather_ln", "vs_cat2_scale", "vs_msg_pre", "vs_upconv_fused_supported", "vs_upconv_fused_preferred", "vs_upconv_fused", "vs_im2col3x3", "vs_msg_latent", "vs_broadcast_channels", "vs_outc_tanh", "vs_pool_linear", "vs_resize_pre", "vs_resize_pre_u8",
     "vs_jnd_heatmap", "vs_embed_tail", "vs_aug_color_scratch_floats", "vs_aug_color", "vs_aug_crop_flip", "vs_aug_warp", "vs_resize_nchw",
     "vs_gaussian_blur", "vs_median_filter", "vs_jpeg_workspace_bytes", "vs_jpeg_roundtrip", "vs_h264_proxy_workspace_bytes", "vs_h264_proxy_roundtrip",
     "vs_bn_partial_doubles", "vs_bn_batch_stats", "vs_scale_shift_act", "vs_aug_mask_blend", "vs_aug_add_scaled", "vs_aug_gather_frames",
@@ -96,6 +96,7 @@ def lib() -> C.CDLL:
         "vs_upconv_supported": [I],
         "vs_upconv_gather_ln": [P, I64, I, I, I, I, P, P, F, I, P, I64, P],
         "vs_cat2_scale": [P, I, I64, P, I, I64, F, I64, P, I64, P],
+        "vs_msg_pre": [P, I, I, P, P],
         "vs_upconv_fused_supported": [I, I, I],
         "vs_upconv_fused_preferred": [I, I, I],
         "vs_upconv_fused": [P, I, I64, P, I, I64, F, P, I, I, I, I, P, P, F, I, P, I64, P],
