@@ -260,15 +260,64 @@ __global__ __launch_bounds__(512, 2) void conv3x3_patch_pc_kernel(const vs_conv_
     for (int j = 0; j < TN; ++j)
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
-  int col[TN];
-  float bias1[TN], bias2[TN];
+  // Operands are SWAPPED in the MFMA (weights first), so the accumulator holds C^T: element e of acc[i][j] is
+  //   channel  cbase[j] + (e & 3) + 8 * (e >> 2)      (cbase already contains the half-wave's 4 * g)
+  //   pixel    (wm * TM + i) * 32 + r
+  // i.e. a lane owns 4 x 4 CONSECUTIVE channels of one pixel per 32 x 32 block and the epilogue works on float4 groups: 24 16-byte
+  // stores per lane instead of 96 4-byte ones, one validity test per pixel.  (The scalar epilogue was 20 k instructions with 700
+  // bytes of scratch per lane; stores alone were 16 us of a 386 us launch.)  Same products, same K order: bit-identical values.
+  int cbase[TN];
 #pragma unroll
-  for (int j = 0; j < TN; ++j) {
-    col[j] = n0 + (wn * TN + j) * 32 + r;
-    const bool ok = col[j] < d.N;
-    bias1[j] = (ok && d.bias) ? d.bias[col[j]] : 0.f;
-    bias2[j] = (ok && d.bias2) ? d.bias2[col[j]] : 0.f;
+  for (int j = 0; j < TN; ++j) cbase[j] = n0 + (wn * TN + j) * 32 + 4 * g;
+  auto ld4 = [](const float* p, int n, int N) __attribute__((always_inline)) -> f32x4 {      // p[n .. n+3], zero past N
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (p) {
+      if (n + 4 <= N) v = *reinterpret_cast<const f32x4*>(p + n);
+      else
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          if (n + e < N) v[e] = p[n + e];
+    }
+    return v;
+  };
+  auto grp = [&](int i, int j, int q) __attribute__((always_inline)) -> f32x4 {
+    return f32x4{acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]};
+  };
+  auto put = [&](int i, int j, int q, const f32x4& v) __attribute__((always_inline)) {
+    acc[i][j][4 * q] = v[0]; acc[i][j][4 * q + 1] = v[1]; acc[i][j][4 * q + 2] = v[2]; acc[i][j][4 * q + 3] = v[3];
+  };
+  // pixel of this lane in block i, its row in the output and whether it lies inside the image
+  int64_t mrow[TM];
+  bool pin[TM];
+  int pcls[TM];
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+    const int p = (wm * TM + i) * 32 + r;
+    const int y = y0 + (p >> 4), x = x0 + (p & 15);
+    pin[i] = y < d.H && x < d.W;
+    mrow[i] = ((int64_t)fb * d.H + (pin[i] ? y : 0)) * d.W + (pin[i] ? x : 0);
+    pcls[i] = (y == 0 ? 0 : (y >= d.H - 1 ? 2 : 1)) * 3 + (x == 0 ? 0 : (x >= d.W - 1 ? 2 : 1));
   }
+  // v = act(acc (+ table) + bias1) + bias2 on every float4 group (the activation sits between the two K phases)
+  auto finish_phase1 = [&](const bool with_b2) __attribute__((always_inline)) {
+    const float* tb = (d.tile_hint & VS_CONV_PRE) ? d.a_scale + (int64_t)fb * d.a_scale_ld : nullptr;
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int n = cbase[j] + 8 * q;
+        const f32x4 b1 = ld4(d.bias, n, d.N);
+        const f32x4 b2 = with_b2 ? ld4(d.bias2, n, d.N) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+          f32x4 v = grp(i, j, q) + b1;
+          if (tb) v += ld4(tb + pcls[i] * d.N, n, d.N);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = vs_apply_act(v[e], d.act);
+          put(i, j, q, v + b2);
+        }
+      }
+  };
   int a_patch[TM], a_plain[TM];
 #pragma unroll
   for (int i = 0; i < TM; ++i) {
@@ -313,7 +362,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_patch_pc_kernel(const vs_conv_
       for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(F.a[i][PA[q]], F.b[j][PB[q]], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(F.b[j][PB[q]], F.a[i][PA[q]], acc[i][j], 0, 0, 0);   // C^T: see the epilogue
     }
   };
 
@@ -356,68 +405,51 @@ __global__ __launch_bounds__(512, 2) void conv3x3_patch_pc_kernel(const vs_conv_
     const int64_t Mrows = (int64_t)d.B * d.H * d.W;
     float* ws = d.splitk_ws + (int64_t)ks * Mrows * d.splitk_ld;
 #pragma unroll
-    for (int i = 0; i < TM; ++i)
+    for (int i = 0; i < TM; ++i) {
+      if (!pin[i]) continue;
 #pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        const int p = (wm * TM + i) * 32 + (e & 3) + 8 * (e >> 2) + 4 * g;
-        const int y = y0 + (p >> 4), x = x0 + (p & 15);
-        if (y >= d.H || x >= d.W) continue;
-        const int64_t m = ((int64_t)fb * d.H + y) * d.W + x;
+      for (int j = 0; j < TN; ++j)
 #pragma unroll
-        for (int j = 0; j < TN; ++j)
-          if (col[j] < d.N) ws[m * d.splitk_ld + col[j]] = acc[i][j][e];
-      }
+        for (int q = 0; q < 4; ++q) {
+          const int n = cbase[j] + 8 * q;
+          if (n < d.N) *reinterpret_cast<f32x4*>(ws + mrow[i] * d.splitk_ld + n) = grp(i, j, q);
+        }
+    }
     return;
   }
-  if (d.tile_hint & VS_CONV_PRE) {      // border-class table [frames][9][N] (first bottleneck block: the conv over the message channels)
-    const float* tb = d.a_scale + (int64_t)fb * d.a_scale_ld;
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        const int p = (wm * TM + i) * 32 + (e & 3) + 8 * (e >> 2) + 4 * g;
-        const int y = y0 + (p >> 4), x = x0 + (p & 15);
-        const int cls = (y == 0 ? 0 : (y >= d.H - 1 ? 2 : 1)) * 3 + (x == 0 ? 0 : (x >= d.W - 1 ? 2 : 1));
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-          if (col[j] < d.N) acc[i][j][e] += tb[cls * d.N + col[j]];
-      }
-  }
   if (n2 > 0) {
-    apply_act_all<TM, TN>(acc, bias1, bias2, d.act);
+    finish_phase1(true);
     for (s = n1; s < total; ++s) {       // short: no prefetch across these steps (the rows are published one barrier before)
       load_frags(F0, s);
       mfma_all(F0);
       __syncthreads();
     }
   } else {
-    float zero[TN];
-#pragma unroll
-    for (int j = 0; j < TN; ++j) zero[j] = 0.f;
-    apply_act_all<TM, TN>(acc, bias1, zero, d.act);
+    finish_phase1(false);
   }
-
   if (abl & 32) return;             // ablation (tools/bench_ppc.py): no output stores
 #pragma unroll
   for (int i = 0; i < TM; ++i) {
+    if (!pin[i]) continue;
+    float* orow = d.out + mrow[i] * d.out_ld + d.out_coff;
+    const float* rrow = d.res ? d.res + mrow[i] * d.res_ld : nullptr;
 #pragma unroll
-    for (int e = 0; e < 16; ++e) {
-      const int p = (wm * TM + i) * 32 + (e & 3) + 8 * (e >> 2) + 4 * g;
-      const int y = y0 + (p >> 4), x = x0 + (p & 15);
-      if (y >= d.H || x >= d.W) continue;
-      const int64_t m = ((int64_t)fb * d.H + y) * d.W + x;
+    for (int j = 0; j < TN; ++j)
 #pragma unroll
-      for (int j = 0; j < TN; ++j) {
-        const int n = col[j];
+      for (int q = 0; q < 4; ++q) {
+        const int n = cbase[j] + 8 * q;
         if (n >= d.n_store) continue;
-        float v = 0.f;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};          // columns in [N, n_store) are written as zeros
         if (n < d.N) {
-          v = acc[i][j][e];
-          if (d.res) v += d.res[m * d.res_ld + n];
+          v = grp(i, j, q);
+          if (rrow) v += *reinterpret_cast<const f32x4*>(rrow + n);
+          if (n + 4 > d.N)           // N % 4 != 0: the tail of the last group is padding
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+              if (n + e >= d.N) v[e] = 0.f;
         }
-        d.out[m * d.out_ld + d.out_coff + n] = v;
+        *reinterpret_cast<f32x4*>(orow + n) = v;
       }
-    }
   }
 }
 

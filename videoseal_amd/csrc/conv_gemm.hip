@@ -405,6 +405,14 @@ namespace {
 
 inline bool fits_u32(int64_t bytes) { return bytes >= 0 && bytes < 0xffffffffLL; }
 
+// the wave-specialised 3x3 kernel reads / writes the epilogue operands in float4 channel groups
+inline bool pc_vec_ok(const vs_conv_desc_t& d) {
+  auto al16 = [](const void* p) { return ((uintptr_t)p & 15) == 0; };
+  return d.n_store % 4 == 0 && d.n_store >= ((d.N + 3) & ~3) && d.out_ld % 4 == 0 && d.out_coff % 4 == 0 && al16(d.out) && al16(d.bias) && al16(d.bias2) &&
+         (!d.res || (d.res_ld % 4 == 0 && al16(d.res))) && (d.split_k <= 1 || (d.splitk_ld % 4 == 0 && al16(d.splitk_ws))) &&
+         (!(d.tile_hint & VS_CONV_PRE) || (d.a_scale_ld % 4 == 0 && al16(d.a_scale)));
+}
+
 }  // namespace
 
 extern "C" int vs_conv_gemm(const vs_conv_desc_t* dp, void* stream) {
@@ -443,6 +451,7 @@ extern "C" int vs_conv_gemm(const vs_conv_desc_t* dp, void* stream) {
   if (tile == 15 || tile == 16 || tile == 19 || tile == 21) {   // wave-specialised patch kernel
     VS_REQUIRE(patch_ok && d.wt_blk && (!d.in2 || d.wt2_blk) && ((uintptr_t)d.wt_blk & 15) == 0);
     if (d.split_k > 1) VS_REQUIRE(d.splitk_ws && d.splitk_ld >= d.N && d.split_k <= d.CinP / 16 && !d.sumsq_part);
+    if (!pc_vec_ok(d)) return VS_ERR_UNSUPPORTED;
     return vs_conv3x3_patch_pc_dispatch(d, tile, st);
   }
   // thin full-resolution layers (16 input channels, <= 32 outputs): persistent kernel with the weights in registers
@@ -466,8 +475,8 @@ extern "C" int vs_conv_gemm(const vs_conv_desc_t* dp, void* stream) {
   if (tile == 0 && small_ok && !d.in2) return vs_conv3x3_small_dispatch(d, st);   // (with the fused 1x1 the patch kernel is as fast)
   if (tile == 0 && patch_ok && d.W % 16 == 0 && d.H % 8 == 0) {
     const bool blk_ok = d.wt_blk && (!d.in2 || d.wt2_blk) && ((uintptr_t)d.wt_blk & 15) == 0;
-    if (blk_ok && d.N >= 128) return vs_conv3x3_patch_pc_dispatch(d, d.N % 192 == 0 ? 16 : 15, st);   // wave-specialised for wide layers
-    if (blk_ok && d.N > 32 && d.N <= 64 && d.H % 16 == 0 && d.CinP >= 64) return vs_conv3x3_patch_pc_dispatch(d, 21, st);   // 256 px x 64 ch
+    if (blk_ok && pc_vec_ok(d) && d.N >= 128) return vs_conv3x3_patch_pc_dispatch(d, d.N % 192 == 0 ? 16 : 15, st);   // wave-specialised for wide layers
+    if (blk_ok && pc_vec_ok(d) && d.N > 32 && d.N <= 64 && d.H % 16 == 0 && d.CinP >= 64) return vs_conv3x3_patch_pc_dispatch(d, 21, st);   // 256 px x 64 ch
     return vs_conv3x3_patch_dispatch(d, d.N <= 32 ? 10 : (d.N <= 64 ? 11 : 12), st);
   }
   if (tile == 0) {
