@@ -44,6 +44,8 @@ struct vs_model {
   RB inc;
   std::vector<CW> down_conv;
   std::vector<RB> down_rb, bottleneck;
+  CW b0_lat, b0_msg;             // first bottleneck block with the message channels as a border-class table (engine.py::resblock_msg0)
+  bool b0_table = false;
   std::vector<Up> ups;
   float *outc_w = nullptr, *outc_b = nullptr, *table = nullptr;
   // extractor
@@ -142,7 +144,7 @@ struct Packer {
   }
   // engine.py::pack_conv: [N,Cin,KH,KW] -> [N][tap][CinP], optional per-row scale (folded BatchNorm)
   void conv(CW& cw, const std::string& wkey, int cin, int kh, int kw, int in_ld, const std::vector<float>* scale,
-            const std::vector<float>* bias_v, const std::string& bias_key, CW* as_gemm = nullptr) {
+            const std::vector<float>* bias_v, const std::string& bias_key, CW* as_gemm = nullptr, std::vector<float>* keep_wt = nullptr) {
     const HostT& w = get(wkey);
     if (!w.p) return;
     const int n = (int)(w.n / ((int64_t)cin * kh * kw));
@@ -161,6 +163,7 @@ struct Packer {
     if (bias_v) { b = *bias_v; hb = true; }
     else if (!bias_key.empty()) { const HostT& t = get(bias_key); if (t.p) { b.assign(t.p, t.p + t.n); hb = true; } }
     finish(cw, wt, b, hb, as_gemm);
+    if (keep_wt) *keep_wt = std::move(wt);
   }
   // engine.py::_pack_embedder (Upsample groups): [Co,Cin,3,3] -> rows (tap, channel) of a 1x1 GEMM on the low-resolution [x | skip] map
   void upconv9(CW& cw, const std::string& wkey, int cin, int cout) {
@@ -200,7 +203,22 @@ struct Packer {
       b[i] = bi.p[i] - mu.p[i] * s[i];
     }
   }
-  void resblock(RB& rb, const std::string& p, int cin) {                                         // engine.py::_pack_resblock
+  // engine.py::resblock_msg0: c0 of the first bottleneck block split into its latent columns (3x3, K = 9*nlat) and the per-tap
+  // message columns (rows (tap, n), K = hidden) from the BN-folded packed weight [N][9][cinp]
+  void msg_table_convs(CW& lat, CW& msg, const std::vector<float>& wt, const std::vector<float>& bias, int n, int cinp, int nlat, int hidden) {
+    std::vector<float> wl((size_t)n * 9 * nlat), wm((size_t)9 * n * hidden);
+    for (int o = 0; o < n; ++o)
+      for (int t = 0; t < 9; ++t) {
+        const float* src = &wt[((size_t)o * 9 + t) * cinp];
+        std::copy(src, src + nlat, &wl[((size_t)o * 9 + t) * nlat]);
+        std::copy(src + nlat, src + nlat + hidden, &wm[((size_t)t * n + o) * hidden]);
+      }
+    lat.N = n; lat.KH = 3; lat.KW = 3; lat.CinP = nlat;
+    finish(lat, wl, bias, true);
+    msg.N = 9 * n; msg.KH = 1; msg.KW = 1; msg.CinP = hidden;
+    finish(msg, wm, {}, false);
+  }
+  void resblock(RB& rb, const std::string& p, int cin, std::vector<float>* keep_c0 = nullptr, std::vector<float>* keep_b0 = nullptr) {   // engine.py::_pack_resblock
     const HostT& w0 = get(p + ".double_conv.0.weight");
     if (!w0.p) return;
     const int cout = (int)(w0.n / ((int64_t)cin * 9));
@@ -208,7 +226,8 @@ struct Packer {
     std::vector<float> s0, b0, s1, b1;
     bn_fold(p + ".double_conv.1", s0, b0);
     bn_fold(p + ".double_conv.4", s1, b1);
-    conv(rb.c0, p + ".double_conv.0.weight", cin, 3, 3, rup(cin, 4), &s0, &b0, "");
+    conv(rb.c0, p + ".double_conv.0.weight", cin, 3, 3, rup(cin, 4), &s0, &b0, "", nullptr, keep_c0);
+    if (keep_b0) *keep_b0 = b0;
     conv(rb.c1, p + ".double_conv.3.weight", cout, 3, 3, rup(cout, 4), &s1, &b1, "");
     conv(rb.res, p + ".res_conv.weight", cin, 1, 1, rup(cin, 4), nullptr, nullptr, p + ".res_conv.bias");
   }
@@ -240,12 +259,13 @@ struct Runner {
   void conv(const Act& x, const CW& w, const Act& out, int stride = 1, int pad = 0, int pad_mode = VS_PAD_ZERO, int act_ = VS_ACT_NONE,
             int out_coff = 0, int n_store = -1, const Act* res = nullptr, const Act* in2 = nullptr, const CW* w2 = nullptr,
             const float* a_scale = nullptr, int64_t a_scale_ld = 0, const float* a_shift = nullptr, const int* geom = nullptr,
-            float* sumsq = nullptr) {
+            float* sumsq = nullptr, int cin_first = 0, bool pre_table = false) {
     vs_conv_desc_t d;
     std::memset(&d, 0, sizeof(d));
     int sh = stride, sw = stride, ph = pad, pw = pad, H = x.H, W = x.W, cin = x.ld;
     int64_t sx = x.ld;
     if (geom) { W = geom[0]; sx = geom[1]; cin = geom[2]; sh = geom[3]; sw = geom[4]; ph = geom[5]; pw = geom[6]; }
+    if (cin_first) cin = cin_first;             // only the first channels of every pixel (pixel stride stays x.ld)
     d.in = x.p;
     d.in_sb = (int64_t)x.H * x.W * x.ld; d.in_sy = (int64_t)x.W * x.ld; d.in_sx = sx;
     d.B = x.B; d.H = H; d.W = W; d.Cin = cin;
@@ -266,7 +286,9 @@ struct Runner {
                          d.Cin % 32 == 0 && d.CinP == d.Cin && dense_rows && (!a_scale || d.H * d.W >= 128 || d.H * d.W == 64);
     const bool patch_pc = d.KH == 3 && d.KW == 3 && sh == 1 && sw == 1 && ph == 1 && pw == 1 && d.Ho == d.H && d.Wo == d.W && !a_scale &&
                           d.W % 16 == 0 && d.H % 8 == 0;
-    if (sumsq) {
+    if (pre_table) {                            // border-class table added before bias + activation (engine.py::resblock_msg0)
+      d.tile_hint = (d.N % 192 == 0 ? (VS_CONV_TILE_HI | 0) : 15) | VS_CONV_PRE;
+    } else if (sumsq) {
       d.sumsq_part = sumsq;
     } else if (gemm_pc) {                                       // engine.py::_split_k_rule
       const int64_t rows = (int64_t)d.B * d.H * d.W;
@@ -342,7 +364,23 @@ struct Runner {
     for (int j = 0; j < c.num_blocks; ++j) {
       Act view{};
       const bool direct = j == c.num_blocks - 1 && lowres_cat(0, cur, view);
-      cur = resblock(cur, m->bottleneck[j], direct ? &view : nullptr);
+      const RB& rb = m->bottleneck[j];
+      if (j == 0 && !direct && m->b0_table && h3.ld == h3.C && rb.c0.CinP == h3.C && h3.W % 16 == 0 && h3.H % 8 == 0 &&
+          (int64_t)B * (h3.H / 8) * (h3.W / 16) >= 128) {                        // engine.py::resblock_msg0
+        const int N9 = m->b0_msg.N, N = rb.cout;
+        Act P = act(n_msgs, 1, 1, N9);
+        conv(Act{lat, n_msgs, 1, 1, c.hidden, c.hidden}, m->b0_msg, P);
+        float* table = alloc((int64_t)n_msgs * 9 * N);
+        if (live()) chk(vs_msg_pre(P.p, n_msgs, N, table, st));
+        Act t = act(B, h3.H, h3.W, N);
+        conv(h3, m->b0_lat, t, 1, 1, VS_PAD_ZERO, VS_ACT_RELU, 0, -1, nullptr, nullptr, nullptr, table, n_msgs == 1 ? 0 : 9 * (int64_t)N, nullptr,
+             nullptr, nullptr, m->zc.back(), true);
+        Act out = act(B, h3.H, h3.W, N);
+        conv(t, rb.c1, out, 1, 1, VS_PAD_ZERO, VS_ACT_RELU, 0, -1, nullptr, &h3, &rb.res);
+        cur = out;
+        continue;
+      }
+      cur = resblock(cur, rb, direct ? &view : nullptr);
     }
     for (int k = 0; k < nlev; ++k) {                   // skips are popped deepest first; the first one is the [latent | message] map itself
       const Act skip = hid.back();
@@ -502,7 +540,16 @@ extern "C" int vs_model_create(const vs_model_cfg_t* cfg, const vs_tensor_t* ten
     P.conv(m->down_conv[i], p + ".down.weight", m->zc[i], 3, 3, rup(m->zc[i], 4), nullptr, nullptr, p + ".down.bias");
     P.resblock(m->down_rb[i], p + ".conv", m->zc[i + 1]);
   }
-  for (int j = 0; j < cfg->num_blocks; ++j) P.resblock(m->bottleneck[j], u + ".bottleneck.model." + std::to_string(j), m->bott);
+  for (int j = 0; j < cfg->num_blocks; ++j) {
+    std::vector<float> w0, b0;
+    const int nlat = m->zc.back(), hidden = cfg->hidden;
+    const bool table = j == 0 && nlat % 16 == 0 && hidden % 32 == 0 && m->bott % 16 == 0;
+    P.resblock(m->bottleneck[j], u + ".bottleneck.model." + std::to_string(j), m->bott, table ? &w0 : nullptr, table ? &b0 : nullptr);
+    if (table && !w0.empty() && m->bottleneck[0].cout >= 128) {
+      P.msg_table_convs(m->b0_lat, m->b0_msg, w0, b0, m->bottleneck[0].cout, m->bottleneck[0].c0.CinP, nlat, hidden);
+      m->b0_table = true;
+    }
+  }
   std::vector<int> zz(m->zc.begin(), m->zc.end() - 1);
   zz.push_back(m->bott);
   for (int k = 0; k < nlev; ++k) {
