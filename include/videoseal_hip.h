@@ -87,7 +87,7 @@ typedef struct vs_conv_desc {
   int64_t out_ld;
   int32_t out_coff;
   int32_t tile_hint;        /* low nibble: 0 = auto, 1 = 128x128, 2 = 128x64, 3 = 256x32, 4 = 128x192, 5 = 128x96,   */
-                            /* 6 = 256x128, 7 = 128x128, 8 = 128x64, 9 = 256x64 (producer/consumer, need wt_blk);   */
+                            /* (6..9: retired);                                                                      */
                             /* 10 = 128x32, 11 = 128x64, 12 = 128x128: 3x3 stride-1 'patch' kernel (8x16-pixel tile);  */
                             /* 13 = 64x64, 14 = 64x128 (generic kernel, small-M layers);                              */
                             /* 15 = 128x128, 16 = 128x192, 19 = 128x64, 21 = 256x64: wave-specialised patch kernel (needs wt_blk); */

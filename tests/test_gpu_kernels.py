@@ -142,12 +142,12 @@ CONV_CASES = [
     (2, 24, 12, 12, 20, 3, 1, 1, 1, 3, 3),
     (2, 64, 33, 31, 96, 3, 1, 1, 0, 1, 2),
     # producer/consumer kernels (tile codes 6..9), incl. ragged M / N, reflect, stride 2, tiny K
-    (2, 384, 16, 16, 384, 3, 1, 1, 0, 1, 6),
-    (3, 64, 19, 23, 136, 3, 1, 1, 1, 2, 7),
-    (2, 32, 20, 20, 64, 3, 2, 1, 0, 0, 8),
-    (1, 16, 40, 24, 40, 1, 1, 0, 0, 3, 9),
-    (2, 1, 32, 32, 16, 3, 1, 1, 0, 1, 8),
-    (2, 96, 9, 9, 200, 3, 1, 1, 0, 1, 6),
+    (2, 384, 16, 16, 384, 3, 1, 1, 0, 1, 1),
+    (3, 64, 19, 23, 136, 3, 1, 1, 1, 2, 1),
+    (2, 32, 20, 20, 64, 3, 2, 1, 0, 0, 2),
+    (1, 16, 40, 24, 40, 1, 1, 0, 0, 3, 2),
+    (2, 1, 32, 32, 16, 3, 1, 1, 0, 1, 2),
+    (2, 96, 9, 9, 200, 3, 1, 1, 0, 1, 1),
     (2, 128, 16, 16, 96, 1, 1, 0, 0, 2, 5),
     (2, 128, 16, 16, 192, 3, 1, 1, 0, 1, 4),
     # 3x3 patch kernel (tile codes 10..12): aligned and ragged frames, zero / reflect padding, small and large channel counts
@@ -184,8 +184,8 @@ CONV_CASES = [
 @pytest.mark.parametrize("case", CONV_CASES)
 def test_conv_gemm_matches_conv2d(eng, case):
     B, Cin, H, W, Cout, k, s, p, pm, act, tile = case
-    if tile >= 6 and not eng.use_split:
-        pytest.skip("producer/consumer kernels exist for the split back-end only")
+    if tile >= 10 and not eng.use_split:
+        pytest.skip("patch / wave-specialised kernels exist for the split back-end only")
     g = torch.Generator().manual_seed(hash(case) % 1000)
     x = torch.randn(B, Cin, H, W, generator=g)
     w = torch.randn(Cout, Cin, k, k, generator=g) / math.sqrt(Cin * k * k)
@@ -205,10 +205,10 @@ def test_conv_gemm_matches_conv2d(eng, case):
     assert torch.isfinite(full).all() and (full[..., Cout:] == 0).all()   # pad lanes written as zero
 
 
-@pytest.mark.parametrize("tile", [0, 7, 8, 10, 11, 1, 15, 0x40, 0x43, 0x45])
+@pytest.mark.parametrize("tile", [0, 2, 10, 11, 1, 15, 0x40, 0x43, 0x45])
 def test_conv_two_phase_residual_block(eng, tile):
     """ResnetBlock tail: relu(conv3x3(t)+b) + (conv1x1(x)+b2), written at a channel offset of a wider buffer."""
-    if tile >= 6 and not eng.use_split:
+    if tile >= 10 and not eng.use_split:
         pytest.skip("split back-end only")
     g = torch.Generator().manual_seed(5)
     B, Cm, Cx, H, W, Co = 2, 32, 16, 14, 18, 32
@@ -232,10 +232,10 @@ def test_conv_two_phase_residual_block(eng, tile):
     assert (full[..., :8] == 7.0).all() and (full[..., 40:] == 7.0).all()   # neighbours untouched
 
 
-@pytest.mark.parametrize("tile", [0, 8])
+@pytest.mark.parametrize("tile", [0, 2])
 def test_conv_grn_transform_and_residual(eng, tile):
     """pwconv2 with the GRN apply folded into the A load and the block residual (convnext.py:50-56)."""
-    if tile >= 6 and not eng.use_split:
+    if tile >= 10 and not eng.use_split:
         pytest.skip("split back-end only")
     g = torch.Generator().manual_seed(6)
     B, HW, K, Nn = 3, 50, 72, 20
@@ -258,7 +258,7 @@ def test_conv_grn_transform_and_residual(eng, tile):
 @pytest.mark.parametrize("tile", [0, 1, 3, 5, 13, 0x41, 0x42])
 def test_conv_epilogue_grn_partials(eng, tile):
     """pwconv1 + GELU with the GRN sum-of-squares partials written by the epilogue, then vs_grn_scale_from_partials == common.py:166-168."""
-    if tile >= 6 and not eng.use_split:
+    if tile >= 10 and not eng.use_split:
         pytest.skip("split back-end only")
     g = torch.Generator().manual_seed(9)
     B, H, W, K, Nn = 3, 8, 12, 64, 200         # HW = 96 = 3 groups of 32 rows per frame

@@ -106,7 +106,8 @@ __global__ __launch_bounds__(512, 2) void conv3x3_patch_pc_kernel(const vs_conv_
     }
     auto dma_tile = [&, n1, n2, n1_all, c_off, bw, lane](const int t) __attribute__((always_inline)) {
       unsigned char* st = Bring + (t % NRING) * B_STAGE;
-      // (never select between two captured variables here: see conv_gemm_pc.hip)
+      // NB: never select between two captured variables here (ph2 ? n2 : n1_all): LLVM turns select-of-loads into a load of a
+      // selected closure address, which pins the whole closure (and every uniform in it) in scratch memory
       const int ph2 = t >= n1 ? 1 : 0;
       const int nsel = n1_all + ph2 * (__builtin_amdgcn_readfirstlane(n2) - n1_all);     // blocks per group in this phase
       const int64_t off = (int64_t)ph2 * w2delta + (int64_t)(t - ph2 * n1 + (1 - ph2) * c_off * 9) * 3072 + lane * 16;

@@ -396,7 +396,6 @@ int dispatch(const vs_conv_desc_t& d, int tile, hipStream_t st) {
 }
 
 }  // namespace
-int vs_conv_gemm_pc_dispatch(const vs_conv_desc_t& d, int tile, hipStream_t st);   // conv_gemm_pc.hip
 int vs_conv3x3_patch_dispatch(const vs_conv_desc_t& d, int tile, hipStream_t st);  // conv3x3_patch.hip
 int vs_conv3x3_patch_pc_dispatch(const vs_conv_desc_t& d, int tile, hipStream_t st);  // conv3x3_patch_pc.hip
 int vs_gemm1x1_pc_dispatch(const vs_conv_desc_t& d, int tile, hipStream_t st);         // gemm1x1_pc.hip
@@ -500,10 +499,7 @@ extern "C" int vs_conv_gemm(const vs_conv_desc_t* dp, void* stream) {
       else if (tile == 5 || tile == 2) tile = 13;
     }
   }
-  if (tile >= 6 && tile <= 9) {   // producer/consumer kernels
-    VS_REQUIRE(d.wt_blk && (!d.in2 || d.wt2_blk) && ((uintptr_t)d.wt_blk & 15) == 0);
-    return vs_conv_gemm_pc_dispatch(d, tile, st);
-  }
+  if (tile >= 6 && tile <= 9) return VS_ERR_UNSUPPORTED;   // (codes of a retired generic producer/consumer kernel)
   const bool can_split = d.wt_split && (!d.in2 || d.wt2_split) && ((uintptr_t)d.wt_split & 15) == 0;
   if (d.tile_hint & VS_CONV_FORCE_SPLIT) VS_REQUIRE(can_split);
   if (can_split && !(d.tile_hint & VS_CONV_FORCE_F32)) return dispatch<true>(d, tile, st);
