@@ -42,6 +42,12 @@ if __name__ == "__main__":
             run("s2 pw1 384->1536 M=8192 ", 32, 16, 384, 1536, V)
             run("chunky s2 1472->5888 M=15376", 16, 31, 1472, 5888, V, reps=5)
         sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "ksweep":      # fixed cost per launch of the wave-specialised GEMM: time vs K at M = 8192, N = 1536
+        for K in (64, 128, 256, 384, 768, 1536):
+            run(f"M=8192 N=1536 K={K:4d}", 32, 16, K, 1536, [(HI | 2, 1), (HI | 1, 1), (1, 1)])
+        for K in (64, 384):
+            run(f"M=8192 N=1536 K={K:4d} no act", 32, 16, K, 1536, [(HI | 2, 1)], grn=True)
+        sys.exit(0)
     G = [(1, 1), (2, 1), (5, 1), (4, 1), (13, 1), (14, 1)]
     run("s0 pw1  96->384  M=131072", 32, 64, 96, 384, G + [(HI | 1, 1), (HI | 2, 1)])
     run("s0 pw2 384->96   M=131072", 32, 64, 384, 96, G + [(HI | 1, 1)], grn=True)
