@@ -46,7 +46,8 @@ if __name__ == "__main__":
         for K in (64, 128, 256, 384, 768, 1536):
             run(f"M=8192 N=1536 K={K:4d}", 32, 16, K, 1536, [(HI | 2, 1), (HI | 1, 1), (1, 1)])
         for K in (64, 384):
-            run(f"M=8192 N=1536 K={K:4d} no act", 32, 16, K, 1536, [(HI | 2, 1)], grn=True)
+            run(f"M=8192 N=1536 K={K:4d} ablations (none / no act / no stores / neither)", 32, 16, K, 1536,
+                [(HI | 2, 1), (HI | 2 | 0x4000, 1), (HI | 2 | 0x2000, 1), (HI | 2 | 0x6000, 1)])
         sys.exit(0)
     G = [(1, 1), (2, 1), (5, 1), (4, 1), (13, 1), (14, 1)]
     run("s0 pw1  96->384  M=131072", 32, 64, 96, 384, G + [(HI | 1, 1), (HI | 2, 1)])

@@ -14,6 +14,9 @@
 //                            (engine.pack_blocked) into a ring of 6 (TN=2) / 5 (TN=3) tiles, counted s_waitcnt.
 // split_k > 1 (small-M layers: 2048 / 8192 rows cannot fill 256 CUs with 128-row tiles): every K slice writes its raw
 // partial sums to the workspace, vs_conv_gemm then runs splitk_epilogue_kernel (fixed summation order -> deterministic).
+#include <algorithm>
+#include <cstdlib>
+
 #include "conv_common.h"
 
 int vs_splitk_epilogue(const vs_conv_desc_t& d, int M, hipStream_t st);
@@ -30,14 +33,19 @@ __device__ __forceinline__ void dma_1k(const char* gp, unsigned char* lds_base) 
                                    (__attribute__((address_space(3))) void*)lds_base, 16, 0, 0);
 }
 
+// One output tile (tile id -> (row tile, column tile, K slice)).  The kernel below is PERSISTENT: a workgroup walks tiles
+// blockIdx.x, blockIdx.x + gridDim.x, ...  Both roles execute the same number of barriers per tile, all LDS fragment reads of a
+// tile are retired before its last barrier, and the consumers' output stores are not waited for -- so the producers fetch the next
+// tile's first operands while the consumers are in the epilogue, and the 50 MB of output of a 128 x 192-tile round drain under the
+// next tile's MFMAs instead of in a stores-only phase at the end of every round (measured: stores 16.6 us + activation 6 us of a
+// 75.7 us K = 384 launch, tools/bench_gemm.py ksweep).
 template <int TN, bool GRN>
-__global__ __launch_bounds__(512, 2) void gemm1x1_pc_kernel(const vs_conv_desc_t d, const int M, const int mtiles, const int ntiles,
-                                                            const int pairs_per_split) {
+__device__ __forceinline__ void gemm1x1_pc_tile(const vs_conv_desc_t& d, const int M, const int mtiles, const int ntiles,
+                                                const int pairs_per_split, const int tile, unsigned char* const smem) {
   constexpr int TM = 2;
   constexpr int BN = 64 * TN;
   constexpr int NG = BN / 32;
   constexpr int B_STAGE = 3 * BN * 32;                   // three planes of NG pre-swizzled 1 KiB blocks
-  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * A_STAGE + 2 * B_STAGE];
   unsigned char* const Aring = smem;
   unsigned char* const Bring = smem + 2 * A_STAGE;
 
@@ -46,9 +54,9 @@ __global__ __launch_bounds__(512, 2) void gemm1x1_pc_kernel(const vs_conv_desc_t
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int r = lane & 31, g = lane >> 5;
 
-  const int bm = blockIdx.x % mtiles;
-  const int bn = (blockIdx.x / mtiles) % ntiles;
-  const int ks = blockIdx.x / (mtiles * ntiles);
+  const int bm = tile % mtiles;
+  const int bn = (tile / mtiles) % ntiles;
+  const int ks = tile / (mtiles * ntiles);
   const int m0 = bm * BM;
   const int n0 = bn * BN;
   const int pairs_total = d.CinP / 32;
@@ -187,6 +195,12 @@ __global__ __launch_bounds__(512, 2) void gemm1x1_pc_kernel(const vs_conv_desc_t
 
   // ==================================================================== consumers
   const int wm = wave >> 1, wn = wave & 1;
+  // consumer-side barrier: LDS reads retired, but NOT vmcnt(0) -- __syncthreads() would wait for the previous tile's output stores
+  // (persistent kernel) before the first barrier of the next tile; the consumers exchange nothing through global memory
+  auto cbar = []() __attribute__((always_inline)) {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+  };
   f32x16 acc[TM][TN];
 #pragma unroll
   for (int i = 0; i < TM; ++i)
@@ -223,24 +237,24 @@ __global__ __launch_bounds__(512, 2) void gemm1x1_pc_kernel(const vs_conv_desc_t
     }
   };
 
-  __syncthreads();
+  cbar();
   load_frags(F0, 0);
   __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0), see conv3x3_patch_pc.hip
-  __syncthreads();                       // step 0's operands are in registers: the producers may now overwrite stage 0 with step 2's
+  cbar();                       // step 0's operands are in registers: the producers may now overwrite stage 0 with step 2's
   int s = 0;
   for (; s + 2 < total; s += 2) {
     load_frags(F1, s + 1);
     mfma_all(F0);
-    __syncthreads();
+    cbar();
     load_frags(F0, s + 2);
     mfma_all(F1);
-    __syncthreads();
+    cbar();
   }
   load_frags(F1, s + 1);              // total is even: two steps left
   mfma_all(F0);
-  __syncthreads();
+  cbar();
   mfma_all(F1);
-  __syncthreads();
+  cbar();
 
   // ---- epilogue.  C/D layout of the 32x32 MFMA: col = lane&31, row = (e&3) + 8*(e>>2) + 4*(lane>>5)
   int col[TN];
@@ -266,8 +280,10 @@ __global__ __launch_bounds__(512, 2) void gemm1x1_pc_kernel(const vs_conv_desc_t
     bias1[j] = (col[j] < d.N && d.bias) ? d.bias[col[j]] : 0.f;
     zero[j] = 0.f;
   }
-  apply_act_all<TM, TN>(acc, bias1, zero, d.act);
+  const int abl = d.tile_hint >> 8;       // ablations (tools/bench_gemm.py ksweep): 64 no activation, 32 no output stores
+  if (!(abl & 64)) apply_act_all<TM, TN>(acc, bias1, zero, d.act);
   if (d.sumsq_part) write_sumsq<TM, TN>(acc, d.sumsq_part, d.N, m0 + (int64_t)wm * TM * 32, M, col, g);
+  if (abl & 32) return;
 #pragma unroll
   for (int i = 0; i < TM; ++i) {
 #pragma unroll
@@ -287,6 +303,14 @@ __global__ __launch_bounds__(512, 2) void gemm1x1_pc_kernel(const vs_conv_desc_t
       }
     }
   }
+}
+
+template <int TN, bool GRN>
+__global__ __launch_bounds__(512, 2) void gemm1x1_pc_kernel(const vs_conv_desc_t d, const int M, const int mtiles, const int ntiles,
+                                                            const int pairs_per_split, const int ntot) {
+  constexpr int B_STAGE = 3 * (64 * TN) * 32;
+  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * A_STAGE + 2 * B_STAGE];
+  for (int tile = blockIdx.x; tile < ntot; tile += gridDim.x) gemm1x1_pc_tile<TN, GRN>(d, M, mtiles, ntiles, pairs_per_split, tile, smem);
 }
 
 // out = act(sum_ks ws[ks] + bias) [+ ws[split_k] + bias2 : the 1x1 second phase of the patch kernel] (+ res); columns in
@@ -342,10 +366,13 @@ int launch_g(const vs_conv_desc_t& d, hipStream_t st) {
   const int pps = (pairs + sk - 1) / sk;
   if ((int64_t)(sk - 1) * pps >= pairs) return VS_ERR_BAD_ARG;           // an empty K slice
   if (mt * nt * sk > 0x7fffffffLL || M > 0x7fffffffLL) return VS_ERR_UNSUPPORTED;
+  const int ntot = (int)(mt * nt * sk);
+  static const int force_grid = [] { const char* e = getenv("VS_GEMM_GRID"); return e ? atoi(e) : 0; }();      // experiments: 0 = one workgroup per CU
+  const int grid = std::min(ntot, force_grid > 0 ? force_grid : vs_num_cus());
   if (d.a_scale)
-    hipLaunchKernelGGL((gemm1x1_pc_kernel<TN, true>), dim3((unsigned)(mt * nt * sk)), dim3(512), 0, st, d, (int)M, (int)mt, (int)nt, pps);
+    hipLaunchKernelGGL((gemm1x1_pc_kernel<TN, true>), dim3(grid), dim3(512), 0, st, d, (int)M, (int)mt, (int)nt, pps, ntot);
   else
-    hipLaunchKernelGGL((gemm1x1_pc_kernel<TN, false>), dim3((unsigned)(mt * nt * sk)), dim3(512), 0, st, d, (int)M, (int)mt, (int)nt, pps);
+    hipLaunchKernelGGL((gemm1x1_pc_kernel<TN, false>), dim3(grid), dim3(512), 0, st, d, (int)M, (int)mt, (int)nt, pps, ntot);
   int rc = vs_launch_status();
   if (rc != VS_OK || sk == 1) return rc;
   return vs_splitk_epilogue(d, (int)M, st);

@@ -17,6 +17,16 @@ static inline int vs_launch_status() { return hipGetLastError() == hipSuccess ? 
 
 static inline int64_t cdiv64(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
+// compute units of the current device (256 on MI355X): grid size of the persistent kernels
+static inline int vs_num_cus() {
+  static const int n = [] {
+    int dev = 0, v = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
+    return v;
+  }();
+  return n;
+}
+
 // Exact-erf GELU (nn.GELU default, convnext.py:49) in ~16 VALU instructions, branch-free (ocml's erff is two divergent
 // branches, ~40 instructions, and made the pwconv1 epilogues VALU-bound):
 //   gelu(v) = max(v, 0) - 0.5 |v| erfc(|v|/sqrt2),   erfc(t) = exp(-P(t)),  P(t) = t * Q8(t) fitted to -ln erfc on [0, 4]
