@@ -362,11 +362,11 @@ def main():
         if roof is not None:
             roof["e2e_frac"] = round(fps * gmac * 2e9 / 1e12 / world / (PEAK_SPLIT_TFLOPS if eng.use_split else PEAK_F32_MFMA_TFLOPS), 4)
             roof["e2e_note"] = "whole-step dense conv/GEMM FLOP/s (SURVEY 8(d) per-frame GMAC x frames/s) over the same MFMA ceiling"
-        metric = "frames/sec embed+extract 256-bit @768x768"
+        metric = f"frames/sec embed+extract {cfg.nbits}-bit @{S}x{S}"
         if args.detect_only:
             metric = f"frames/sec extract ({args.card}) @{S}x{S}"
         elif chain:
-            metric = f"frames/sec embed+augment+extract 256-bit @{S}x{S} (BASELINE configs[2])"
+            metric = f"frames/sec embed+augment+extract {cfg.nbits}-bit @{S}x{S} (BASELINE configs[2])"
         line = {
             "metric": metric, "value": round(fps, 2), "unit": "frames/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 3),
