@@ -95,18 +95,23 @@ typedef struct vs_conv_desc {
                             /* 17 = 128x128, 18 = 128x192: wave-specialised 1x1 GEMM (dense rows, Cin % 32 == 0, wt_blk);  */
                             /* | VS_CONV_TILE_HI: tile code + 16;                                                     */
                             /* | VS_CONV_FORCE_F32: v_mfma_f32_32x32x2_f32 path; | VS_CONV_FORCE_SPLIT */
-  const void* wt_split;     /* optional [3][N][Ktot] bf16: wt split exactly into 3 bf16 terms; when set */
-  const void* wt2_split;    /*   (and wt2_split for phase 2) the 6-product bf16-MFMA path is used       */
-  const void* wt_blk;       /* optional: the same split weights in LDS-image order [ceil(N/32)][Ktot/16][3][1 KiB]  */
+  const void* wt_split;     /* optional [P][N][Ktot] 16-bit planes (P = 3 bf16 / 2 f16, see arith): wt split into P terms; when set */
+  const void* wt2_split;    /*   (and wt2_split for phase 2) the split MFMA path is used                  */
+  const void* wt_blk;       /* optional: the same split weights in LDS-image order [ceil(N/32)][Ktot/16][P][1 KiB]  */
   const void* wt2_blk;      /*   (slot of (row r, k-half h) inside a block = 2r + (h ^ ((r>>3)&1)), rows >= N zero);  */
                             /*   enables the producer/consumer kernels, tile codes 6..9, 15..18                        */
   float* splitk_ws;         /* split_k > 1 (tile codes 17, 18 only): workspace [split_k][M][splitk_ld] floats for the */
   int64_t splitk_ld;        /*   partial sums of the K slices; splitk_ld >= N.  Summed in slice order (deterministic)  */
   int32_t split_k;          /*   0 / 1 = no K split                                                                    */
-  int32_t reserved_;
+  int32_t arith;            /* arithmetic of the split path: 0 / 3 = "3 x bf16" (wt_split / wt_blk hold 3 bf16 planes, 6 products),   */
+                            /*   2 = "2 x f16" (2 f16 planes of wt * w_mul, 3 products; a_mul / acc_mul / acc_mul2 below)          */
   float* sumsq_part;        /* optional (1x1, no phase 2 / residual / K split): [ceil(M/32)][N] sums of squares of the stored  */
                             /*   values per 32-row group and column = GRN's ||x||^2 partials (common.py:166), see              */
                             /*   vs_grn_scale_from_partials                                                                    */
+  float a_mul;              /* arith = 2: power of two the activations (in and in2) are multiplied with before the f16 split       */
+  float acc_mul;            /*   = 1 / (a_mul * w_mul): the accumulator of phase 1 is multiplied with it before bias / activation  */
+  float acc_mul2;           /*   = 1 / (a_mul * w2_mul): the same for the products of the second phase (in2 x wt2)                 */
+  int32_t reserved_;
 } vs_conv_desc_t;
 #define VS_CONV_FORCE_F32 0x10
 #define VS_CONV_FORCE_SPLIT 0x20
@@ -186,12 +191,13 @@ int vs_cat2_scale(const float* x, int C1, int64_t ld1, const float* skip, int C2
 
 /* The same Upsample group in ONE kernel for the thin levels (Co = 16 or 32, C1 % 16 == 0, C2 % 16 == 0, C1 + C2 <= 256): the nine-tap
  * GEMM of an 8 x 8-cell tile (+ halo) runs on the matrix cores inside the workgroup and z stays in LDS; inputs are x and skip
- * themselves (no concat buffer).  wt_split = the [3][9*Co][C1+C2] bf16 planes of the (tap, channel)-ordered weight (exact 3-term split). */
+ * themselves (no concat buffer).  wt_split = the [P][9*Co][C1+C2] 16-bit planes of the (tap, channel)-ordered weight; arith / a_mul / acc_mul
+ * as in vs_conv_desc_t -- arith 0 or 3: three bf16 planes, exact; arith 2: two f16 planes of wt * w_mul, acc_mul = 1 / (a_mul * w_mul). */
 int vs_upconv_fused_supported(int C1, int C2, int Co);
 int vs_upconv_fused_preferred(int C1, int C2, int Co);   /* supported AND measured faster than GEMM + gather (Co = 16 levels) */
 int vs_upconv_fused(const float* x, int C1, int64_t ld1, const float* skip, int C2, int64_t ld2, float skip_scale, const void* wt_split,
                     int B, int H, int W, int Co, const float* lnw, const float* lnb, float eps, int act, float* out, int64_t out_ld,
-                    void* stream);
+                    int arith, float a_mul, float acc_mul, void* stream);
 
 /* Patch matrix of a 3x3 / stride 1 / pad 1 conv (zero or reflect padding) on a small NHWC map: out[m][t*ld + c], m = (b, y, x),
  * t = ky*3 + kx -- the K order of the packed conv weights, so the conv becomes vs_conv_gemm with KH = KW = 1, Cin = 9*ld on `out`
@@ -292,6 +298,8 @@ typedef struct vs_model_cfg {
   int32_t depths[4], dims[4], stem_stride;  /* ConvNeXt-V2 (dims already scaled by sqrt(nbits/128) where the card asks)   */
   int32_t attenuate, clamp;                 /* JND attenuation present; clamp imgs_w to [0,1]                             */
   float scaling_w, scaling_i;               /* blender (mutable by evals: pass the current values at create time)         */
+  int32_t arith, reserved_;                 /* arithmetic of the dense layers (vs_conv_desc_t::arith): 2 = 2 x f16, 3 = 3 x bf16,   */
+                                            /*   0 = the library default (VS_DEFAULT_ARITH, overridable with VIDEOSEAL_CONV=f16x2|bf16x3) */
 } vs_model_cfg_t;
 typedef struct vs_tensor { const char* name; const float* data; int64_t numel; } vs_tensor_t;
 int vs_model_create(const vs_model_cfg_t* cfg, const vs_tensor_t* tensors, int ntensors, vs_model_t** out);

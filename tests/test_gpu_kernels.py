@@ -95,7 +95,8 @@ def test_conv3x3_small_two_phase(eng, cx):
 class Eng(HipEngine):
     """engine without a model: only the kernel wrappers + workspace."""
 
-    def __init__(self, use_split=True):
+    def __init__(self, use_split=True, arith=3):
+        self.arith = arith
         self.dev = torch.device(DEV)
         self.lib = N.lib()
         self._ws = {}
@@ -107,10 +108,10 @@ class Eng(HipEngine):
         self.msg_table_conv = True
 
 
-@pytest.fixture(scope="module", params=["split", "f32"])
+@pytest.fixture(scope="module", params=["split", "h2", "f32"])
 def eng(request):
-    """both arithmetic back-ends of vs_conv_gemm: 3 x bf16 split (default) and the fp32-input MFMA"""
-    return Eng(use_split=(request.param == "split"))
+    """the arithmetic back-ends of vs_conv_gemm: 3 x bf16 split (exact), 2 x f16 split (3 products) and the fp32-input MFMA"""
+    return Eng(use_split=(request.param != "f32"), arith=2 if request.param == "h2" else 3)
 
 
 _KEEP = []
@@ -470,9 +471,10 @@ def test_upconv_lowres_gemm_gather_ln(eng, shape):
     if eng.use_split and eng.lib.vs_upconv_fused_supported(C1, C2, Co):      # one-kernel form (z stays in LDS), same maths
         out2 = eng.new_act("t.upln2", B, 2 * H, 2 * W, Co)
         out2.t.fill_(-3.0)
-        cw = ConvW(wz, None, 9 * Co, 1, 1, cpz).with_split()
+        cw = ConvW(wz, None, 9 * Co, 1, 1, cpz).with_split(eng.arith)
         N.check(eng.lib.vs_upconv_fused(N.ptr(xa.t), C1, xa.ld, N.ptr(sa.t), C2, sa.ld, 2 ** -0.5, N.ptr(cw.split), B, H, W, Co,
-                                        N.ptr(dv(lw)), N.ptr(dv(lb)), 1e-6, N.ACT_RELU, N.ptr(out2.t), out2.ld, N.stream()), "upconv_fused")
+                                        N.ptr(dv(lw)), N.ptr(dv(lb)), 1e-6, N.ACT_RELU, N.ptr(out2.t), out2.ld, eng.arith, 16.0,
+                                        1.0 / (16.0 * cw.w_mul), N.stream()), "upconv_fused")
         torch.cuda.synchronize()
         assert (from_nhwc(out2) - ref).abs().max() < 2e-5
     # x == NULL: the producer already wrote columns [0, C1)

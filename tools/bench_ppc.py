@@ -7,8 +7,10 @@ from videoseal_amd import native as N
 from videoseal_amd.engine import Act, ConvW, pack_conv
 from tools.bench_conv import Eng
 
-def run(B, C, H, W, Co, tiles, two_phase, reps=40):
+def run(B, C, H, W, Co, tiles, two_phase, reps=40, ariths=(3,)):
+    """tiles: tile hints; with ariths = (3, 2) every tile is run with the 3 x bf16 and the 2 x f16 arithmetic (key (tile, arith))"""
     eng = Eng()
+    eng.arith = 3
     g = torch.Generator().manual_seed(1)
     x = torch.randn(B, H, W, C, generator=g).cuda(); x2 = torch.randn(B, H, W, C, generator=g).cuda()
     w = (torch.randn(Co, C, 3, 3, generator=g) / math.sqrt(C * 9)).cuda(); w2 = (torch.randn(Co, C, 1, 1, generator=g) / math.sqrt(C)).cuda()
@@ -18,11 +20,18 @@ def run(B, C, H, W, Co, tiles, two_phase, reps=40):
     out = eng.new_act("o", B, H, W, Co)
     flops = 2.0 * B * H * W * Co * C * (10 if two_phase else 9)
     ref = None
+    ref64 = F.conv2d(x[:2].permute(0, 3, 1, 2).double(), w.double(), padding=1)
+    if two_phase: ref64 = torch.relu(ref64) + F.conv2d(x2[:2].permute(0, 3, 1, 2).double(), w2.double())
+    else: ref64 = torch.relu(ref64)
+    ref64 = ref64.permute(0, 2, 3, 1)
+    tiles = [(t, a) for t in tiles for a in ariths]
     best = {t: 1e9 for t in tiles}
     outs = {}
     for rnd in range(5):            # interleave the variants, keep the best round of each: clocks wander by +-10 % on this box
         for t in tiles:
-            kw = dict(pad=1, act=N.ACT_RELU, tile_hint=t)
+            t, ar = t
+            kw = dict(pad=1, act=N.ACT_RELU, tile_hint=t, arith=ar)
+            t = (t, ar)
             if two_phase: kw.update(in2=xa2, w2=cw2)
             for _ in range(3): eng.conv(xa, cw, out, **kw)
             torch.cuda.synchronize()
@@ -37,13 +46,23 @@ def run(B, C, H, W, Co, tiles, two_phase, reps=40):
         same = "" if ref is None else f" bit-identical to first: {bool((got == ref).all())}  maxdiff {(got-ref).abs().max().item():.2e}"
         if ref is None: ref = got
         ms = best[t]
-        print(f"B{B} {C}->{Co} {H}x{W} two_phase={two_phase} tile {(t & 15) + (16 if t & 0x40 else 0):2d} abl {t >> 8:x}: {ms:7.3f} ms {flops/ms/1e9:7.1f} TF-eq{same}", flush=True)
+        e64 = (got.view(B, H, W, -1)[:2, ..., :Co].double() - ref64).abs()
+        t, ar = t
+        print(f"B{B} {C}->{Co} {H}x{W} two_phase={two_phase} tile {(t & 15) + (16 if t & 0x40 else 0):2d} abl {t >> 8:x} arith {ar}: {ms:7.3f} ms {flops/ms/1e9:7.1f} TF-eq"
+              f"  err vs fp64 max {e64.max().item():.2e} rms {e64.pow(2).mean().sqrt().item():.2e} (|ref|max {ref64.abs().max().item():.2f}){same}", flush=True)
 
 if __name__ == "__main__":
     if "--overhead" in sys.argv:       # fixed cost per launch: K = 9*16 .. 9*384, with / without the output stores
         for C in (16, 64, 128, 384):
             run(32, C, 32, 32, 384, [0x40, 0x40 | 0x2000], False)
         run(16, 384, 32, 32, 384, [0x40, 0x40 | 0x2000], False)
+        sys.exit(0)
+    if "--arith" in sys.argv:          # 3 x bf16 (6 products) against 2 x f16 (3 products): time and error against fp64
+        run(32, 384, 32, 32, 384, [0x40, 15, 0x40 | 0x400, 0x40 | 0x100], False, ariths=(3, 2))
+        run(32, 384, 32, 32, 384, [0x40, 15], True, ariths=(3, 2))
+        run(32, 128, 32, 32, 128, [15], True, ariths=(3, 2))
+        run(32, 768, 64, 64, 64, [0x45], False, ariths=(3, 2))
+        run(4, 384, 32, 32, 384, [0x40], True, ariths=(3, 2))
         sys.exit(0)
     if "--prio" in sys.argv:
         run(32, 384, 32, 32, 384, [0x40, 0x40 | 0x1000, 15, 15 | 0x1000], False)

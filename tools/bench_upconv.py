@@ -42,7 +42,7 @@ for (H, C1, C2, Co) in ((32, 384, 384, 64), (64, 64, 64, 32), (128, 32, 32, 16))
     line = f"{H}^2 {C1}+{C2}->{Co}: cat {t[0]:6.1f}  gemm9 {t[1]:6.1f}  gather+LN {t[2]:6.1f}  = {sum(t):6.1f} us"
     if L.vs_upconv_fused_supported(C1, C2, Co):
         fu = lambda: N.check(L.vs_upconv_fused(N.ptr(xa.t), C1, xa.ld, N.ptr(sa.t), C2, sa.ld, 2 ** -0.5, N.ptr(cw.split), B, H, H, Co,
-                                               N.ptr(lw), N.ptr(lb), 1e-6, 1, N.ptr(out.t), out.ld, st), "f")
+                                               N.ptr(lw), N.ptr(lb), 1e-6, 1, N.ptr(out.t), out.ld, cw.arith, 16.0, 1.0 / (16.0 * cw.w_mul), st), "f")
         tf = timeit(fu)
         io = (x.numel() + sk.numel() + out.rows * Co) * 4
         line += f" | fused {tf:6.1f} us ({io / tf / 1e6:5.0f} GB/s of in+out)"

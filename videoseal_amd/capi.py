@@ -19,7 +19,7 @@ class ModelCfgC(C.Structure):
     _fields_ = [("nbits", C.c_int32), ("hidden", C.c_int32), ("img_size", C.c_int32), ("in_ch", C.c_int32), ("out_ch", C.c_int32),
                 ("yuv", C.c_int32), ("nlev", C.c_int32), ("zc", C.c_int32 * 8), ("num_blocks", C.c_int32), ("last_tanh", C.c_int32),
                 ("depths", C.c_int32 * 4), ("dims", C.c_int32 * 4), ("stem_stride", C.c_int32), ("attenuate", C.c_int32),
-                ("clamp", C.c_int32), ("scaling_w", C.c_float), ("scaling_i", C.c_float)]
+                ("clamp", C.c_int32), ("scaling_w", C.c_float), ("scaling_i", C.c_float), ("arith", C.c_int32), ("reserved_", C.c_int32)]
 
 
 class TensorC(C.Structure):

@@ -21,15 +21,16 @@ constexpr int NTH = 256;
 constexpr int PITEMS = PROWS * 4;                                            // float4 items of a patch chunk
 constexpr int NPI = (PITEMS + NTH - 1) / NTH;                                // per thread: 3
 
-template <int WM, int WN, int TM, int TN>
+template <int WM, int WN, int TM, int TN, int NP>
 __global__ __launch_bounds__(NTH, 2) void conv3x3_patch_kernel(const vs_conv_desc_t d, const int tiles_x, const int tiles_y,
                                                                const int mtiles) {
   constexpr int BN = WN * TN * 32;
   static_assert(WM * WN == 4 && WM * TM * 32 == BM, "4 waves cover the 128-pixel tile");
   constexpr int BSLOTS = BN * 2;                        // 16-byte B slots per plane per step
   constexpr int NB = (BSLOTS + NTH - 1) / NTH;
-  constexpr int P_BYTES = 3 * PROWS * ROWB;             // patch, three planes
-  constexpr int B_BYTES = 3 * BN * ROWB;
+  using AR = Arith<NP>;
+  constexpr int P_BYTES = NP * PROWS * ROWB;            // patch, NP 16-bit planes
+  constexpr int B_BYTES = NP * BN * ROWB;
   __shared__ __attribute__((aligned(16))) unsigned char smem[P_BYTES + 2 * B_BYTES];
   unsigned char* const Ps = smem;
   unsigned char* const Bs0 = smem + P_BYTES;
@@ -110,8 +111,9 @@ __global__ __launch_bounds__(NTH, 2) void conv3x3_patch_kernel(const vs_conv_des
   const char* const wbase = reinterpret_cast<const char*>(d.wt_split);
   const char* const wbase2 = reinterpret_cast<const char*>(d.wt2_split);
 
+  const float amul = NP == 2 ? d.a_mul : 1.f;
   f32x4 rp[NPI];
-  u32x4 rb[NB][3];
+  u32x4 rb[NB][NP];
 
   auto load_patch = [&, tid](const int cc) __attribute__((always_inline)) {      // channel chunk cc -> registers
     const char* base = reinterpret_cast<const char*>(d.in) + (int64_t)cc * (BK * 4);
@@ -128,11 +130,10 @@ __global__ __launch_bounds__(NTH, 2) void conv3x3_patch_kernel(const vs_conv_des
 #pragma unroll
     for (int i = 0; i < NPI; ++i)
       if (p_have[i]) {
-        u32x2 p1, p2, p3;
-        split4(rp[i], p1, p2, p3);
-        *reinterpret_cast<u32x2*>(Ps + p_lds[i]) = p1;
-        *reinterpret_cast<u32x2*>(Ps + PROWS * ROWB + p_lds[i]) = p2;
-        *reinterpret_cast<u32x2*>(Ps + 2 * PROWS * ROWB + p_lds[i]) = p3;
+        u32x2 pl[NP];
+        split4n<NP>(rp[i], amul, pl);
+#pragma unroll
+        for (int p = 0; p < NP; ++p) *reinterpret_cast<u32x2*>(Ps + p * PROWS * ROWB + p_lds[i]) = pl[p];
       }
   };
   auto load_b = [&](const int cc, const int tap) __attribute__((always_inline)) {
@@ -141,7 +142,7 @@ __global__ __launch_bounds__(NTH, 2) void conv3x3_patch_kernel(const vs_conv_des
     for (int i = 0; i < NB; ++i)
       if (b_have[i]) {
 #pragma unroll
-        for (int p = 0; p < 3; ++p) rb[i][p] = *reinterpret_cast<const u32x4*>(bbase + p * plane1 + b_off[i]);
+        for (int p = 0; p < NP; ++p) rb[i][p] = *reinterpret_cast<const u32x4*>(bbase + p * plane1 + b_off[i]);
       }
   };
   auto load_b2 = [&](const int c2) __attribute__((always_inline)) {
@@ -150,7 +151,7 @@ __global__ __launch_bounds__(NTH, 2) void conv3x3_patch_kernel(const vs_conv_des
     for (int i = 0; i < NB; ++i)
       if (b_have[i]) {
 #pragma unroll
-        for (int p = 0; p < 3; ++p) rb[i][p] = *reinterpret_cast<const u32x4*>(bbase + p * plane2 + b_off2[i]);
+        for (int p = 0; p < NP; ++p) rb[i][p] = *reinterpret_cast<const u32x4*>(bbase + p * plane2 + b_off2[i]);
       }
   };
   auto store_b = [&](const int buf) __attribute__((always_inline)) {
@@ -159,7 +160,7 @@ __global__ __launch_bounds__(NTH, 2) void conv3x3_patch_kernel(const vs_conv_des
     for (int i = 0; i < NB; ++i)
       if (b_have[i]) {
 #pragma unroll
-        for (int p = 0; p < 3; ++p) *reinterpret_cast<u32x4*>(Bb + p * BN * ROWB + b_lds[i]) = rb[i][p];
+        for (int p = 0; p < NP; ++p) *reinterpret_cast<u32x4*>(Bb + p * BN * ROWB + b_lds[i]) = rb[i][p];
       }
   };
 
@@ -190,25 +191,23 @@ __global__ __launch_bounds__(NTH, 2) void conv3x3_patch_kernel(const vs_conv_des
 
   auto mfma_step = [&](const int buf, const int a_tap_off) __attribute__((always_inline)) {
     const unsigned char* Bb = Bs0 + buf * B_BYTES;
-    bf16x8 af[TM][3], bf[TN][3];
+    bf16x8 af[TM][NP], bf[TN][NP];
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
-      for (int p = 0; p < 3; ++p) af[i][p] = *reinterpret_cast<const bf16x8*>(Ps + p * PROWS * ROWB + a_frag[i] + a_tap_off);
+      for (int p = 0; p < NP; ++p) af[i][p] = *reinterpret_cast<const bf16x8*>(Ps + p * PROWS * ROWB + a_frag[i] + a_tap_off);
 #pragma unroll
     for (int j = 0; j < TN; ++j)
 #pragma unroll
-      for (int p = 0; p < 3; ++p) bf[j][p] = *reinterpret_cast<const bf16x8*>(Bb + p * BN * ROWB + b_frag + j * 32 * ROWB);
+      for (int p = 0; p < NP; ++p) bf[j][p] = *reinterpret_cast<const bf16x8*>(Bb + p * BN * ROWB + b_frag + j * 32 * ROWB);
       // product term outermost, tiles innermost: consecutive MFMAs hit different accumulators (no dependent-issue stall);
       // smallest terms first
 #pragma unroll
-      for (int q = 0; q < 6; ++q) {
-        constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};
+      for (int q = 0; q < AR::NPROD; ++q) {
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
-          for (int j = 0; j < TN; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][PA[q]], bf[j][PB[q]], acc[i][j], 0, 0, 0);
+          for (int j = 0; j < TN; ++j) acc[i][j] = AR::mfma(af[i][AR::PA[q]], bf[j][AR::PB[q]], acc[i][j]);
       }
   };
 
@@ -241,8 +240,10 @@ __global__ __launch_bounds__(NTH, 2) void conv3x3_patch_kernel(const vs_conv_des
     }
   }
   // ---- phase 2: the ResnetBlock's 1x1 res_conv on the block input, accumulated on top of relu(bn(conv3x3))
+  if constexpr (NP == 2) scale_all<TM, TN>(acc, d.acc_mul);      // back to real units (exact: a power of two)
   if (n2 > 0) {
     apply_act_all<TM, TN>(acc, bias1, bias2, d.act);
+    if constexpr (NP == 2) scale_all<TM, TN>(acc, 1.f / d.acc_mul2);   // into the units of the phase-2 products
     int a2_frag[TM];
 #pragma unroll
     for (int i = 0; i < TM; ++i) a2_frag[i] = ((wm * TM + i) * 32 + r) * ROWB + g * 16 - a_frag[i];   // rows are plain pixels
@@ -260,39 +261,37 @@ __global__ __launch_bounds__(NTH, 2) void conv3x3_patch_kernel(const vs_conv_des
       __syncthreads();                                    // previous readers of the patch rows are done
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
-        u32x2 p1, p2, p3;
-        split4(qa[i], p1, p2, p3);
+        u32x2 pl[NP];
+        split4n<NP>(qa[i], amul, pl);
         const int off = ((tid + i * NTH) >> 2) * ROWB + qk4 * 2;
-        *reinterpret_cast<u32x2*>(Ps + off) = p1;
-        *reinterpret_cast<u32x2*>(Ps + PROWS * ROWB + off) = p2;
-        *reinterpret_cast<u32x2*>(Ps + 2 * PROWS * ROWB + off) = p3;
+#pragma unroll
+        for (int p = 0; p < NP; ++p) *reinterpret_cast<u32x2*>(Ps + p * PROWS * ROWB + off) = pl[p];
       }
       __syncthreads();
       {
         const unsigned char* Bb = Bs0 + (step & 1) * B_BYTES;
-        bf16x8 af[TM][3], bf[TN][3];
+        bf16x8 af[TM][NP], bf[TN][NP];
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
-          for (int p = 0; p < 3; ++p) af[i][p] = *reinterpret_cast<const bf16x8*>(Ps + p * PROWS * ROWB + a_frag[i] + a2_frag[i]);
+          for (int p = 0; p < NP; ++p) af[i][p] = *reinterpret_cast<const bf16x8*>(Ps + p * PROWS * ROWB + a_frag[i] + a2_frag[i]);
 #pragma unroll
         for (int j = 0; j < TN; ++j)
 #pragma unroll
-          for (int p = 0; p < 3; ++p) bf[j][p] = *reinterpret_cast<const bf16x8*>(Bb + p * BN * ROWB + b_frag + j * 32 * ROWB);
+          for (int p = 0; p < NP; ++p) bf[j][p] = *reinterpret_cast<const bf16x8*>(Bb + p * BN * ROWB + b_frag + j * 32 * ROWB);
       // product term outermost, tiles innermost: consecutive MFMAs hit different accumulators (no dependent-issue stall);
       // smallest terms first
 #pragma unroll
-      for (int q = 0; q < 6; ++q) {
-        constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};
+      for (int q = 0; q < AR::NPROD; ++q) {
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
-          for (int j = 0; j < TN; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][PA[q]], bf[j][PB[q]], acc[i][j], 0, 0, 0);
+          for (int j = 0; j < TN; ++j) acc[i][j] = AR::mfma(af[i][AR::PA[q]], bf[j][AR::PB[q]], acc[i][j]);
       }
       }
       if (c2 + 1 < n2) store_b((step + 1) & 1);
     }
+    if constexpr (NP == 2) scale_all<TM, TN>(acc, d.acc_mul2);
   } else {
     float zero[TN];
 #pragma unroll
@@ -326,11 +325,13 @@ __global__ __launch_bounds__(NTH, 2) void conv3x3_patch_kernel(const vs_conv_des
 
 template <int WM, int WN, int TM, int TN>
 int launch_patch(const vs_conv_desc_t& d, hipStream_t st) {
+  const bool h2 = d.arith == 2;
   constexpr int BN = WN * TN * 32;
   const int tiles_x = (d.W + TW - 1) / TW, tiles_y = (d.H + TH - 1) / TH;
   const int64_t mt = (int64_t)d.B * tiles_x * tiles_y, nt = cdiv64(d.n_store, BN);
   if (mt * nt > 0x7fffffffLL) return VS_ERR_UNSUPPORTED;
-  hipLaunchKernelGGL((conv3x3_patch_kernel<WM, WN, TM, TN>), dim3((unsigned)(mt * nt)), dim3(NTH), 0, st, d, tiles_x, tiles_y, (int)mt);
+  if (h2) hipLaunchKernelGGL((conv3x3_patch_kernel<WM, WN, TM, TN, 2>), dim3((unsigned)(mt * nt)), dim3(NTH), 0, st, d, tiles_x, tiles_y, (int)mt);
+  else hipLaunchKernelGGL((conv3x3_patch_kernel<WM, WN, TM, TN, 3>), dim3((unsigned)(mt * nt)), dim3(NTH), 0, st, d, tiles_x, tiles_y, (int)mt);
   return vs_launch_status();
 }
 

@@ -32,7 +32,7 @@ struct Geo {
   static constexpr int BMP = TH_ * TW;
   static constexpr int NPI = (PITEMS + 127) / 128;                            // patch float4 items per producer thread (6 / 11)
   static constexpr int IPT = (NPI + 5) / 6;                                   // of which per tap-step (taps 2..7)
-  static constexpr int P_BYTES = 3 * PROWS * ROWB;                            // one patch buffer, three bf16 planes
+  template <int NP> static constexpr int p_bytes() { return NP * PROWS * ROWB; }   // one patch buffer, NP 16-bit planes
   static constexpr int WN = TH_ == 8 ? 2 : 1, WM = 4 / WN;
 };
 
@@ -42,16 +42,18 @@ __device__ __forceinline__ void dma_1k(const char* gp, unsigned char* lds_base) 
                                    (__attribute__((address_space(3))) void*)lds_base, 16, 0, 0);
 }
 
-template <int TN, int TH_>
+template <int TN, int TH_, int NP>
 __global__ __launch_bounds__(512, 2) void conv3x3_patch_pc_kernel(const vs_conv_desc_t d, const int tiles_x, const int tiles_y,
                                                                   const int mtiles, const int ntiles, const int cps) {
   using G = Geo<TH_>;
-  constexpr int TH = G::TH, PROWS = G::PROWS, PITEMS = G::PITEMS, BMP = G::BMP, NPI = G::NPI, P_BYTES = G::P_BYTES;
+  using AR = Arith<NP>;
+  constexpr int TH = G::TH, PROWS = G::PROWS, PITEMS = G::PITEMS, BMP = G::BMP, NPI = G::NPI, P_BYTES = G::template p_bytes<NP>();
+  constexpr int WBLK = NP * 1024;                        // bytes of one (32 rows x 16 k) weight block, all planes
   constexpr int TM = 2;
   constexpr int BN = G::WN * TN * 32;
   constexpr int NG = BN / 32;                            // 32-row weight groups per tile
   constexpr int NRING = TN >= 3 ? 5 : 6;                 // weight ring depth (LDS: 2 patches + NRING tiles <= 160 KiB)
-  constexpr int B_STAGE = 3 * BN * 32;                   // three planes of [BN rows][16 bf16], rows unpadded (DMA-written)
+  constexpr int B_STAGE = NP * BN * 32;                  // NP planes of [BN rows][16 halves], rows unpadded (DMA-written)
   __shared__ __attribute__((aligned(16))) unsigned char smem[2 * P_BYTES + NRING * B_STAGE];
   unsigned char* const Pbuf = smem;
   unsigned char* const Bring = smem + 2 * P_BYTES;
@@ -110,15 +112,15 @@ __global__ __launch_bounds__(512, 2) void conv3x3_patch_pc_kernel(const vs_conv_
       // selected closure address, which pins the whole closure (and every uniform in it) in scratch memory
       const int ph2 = t >= n1 ? 1 : 0;
       const int nsel = n1_all + ph2 * (__builtin_amdgcn_readfirstlane(n2) - n1_all);     // blocks per group in this phase
-      const int64_t off = (int64_t)ph2 * w2delta + (int64_t)(t - ph2 * n1 + (1 - ph2) * c_off * 9) * 3072 + lane * 16;
+      const int64_t off = (int64_t)ph2 * w2delta + (int64_t)(t - ph2 * n1 + (1 - ph2) * c_off * 9) * WBLK + lane * 16;
 #pragma unroll
       for (int q = 0; q < NGW; ++q) {
-        const char* gp = wblk + off + (int64_t)gsel[q] * nsel * 3072;
+        const char* gp = wblk + off + (int64_t)gsel[q] * nsel * WBLK;
 #pragma unroll
-        for (int p = 0; p < 3; ++p) dma_1k(gp + p * 1024, st + p * (BN * 32) + (bw * NGW + q) * 1024);
+        for (int p = 0; p < NP; ++p) dma_1k(gp + p * 1024, st + p * (BN * 32) + (bw * NGW + q) * 1024);
       }
     };
-    constexpr int ND = 3 * NGW;                          // DMA instructions per wave per tile
+    constexpr int ND = NP * NGW;                         // DMA instructions per wave per tile
 #pragma unroll
     for (int t = 0; t < NRING - 1; ++t)
       if (t < total) dma_tile(t);
@@ -171,6 +173,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_patch_pc_kernel(const vs_conv_
       const int64_t m = ((int64_t)fb * d.H + (q_ok[i] ? y : 0)) * d.W + (q_ok[i] ? x : 0);
       q_off[i] = (unsigned)((m * d.in2_ld + qk4) * 4);
     }
+    const float amul = NP == 2 ? d.a_mul : 1.f;
     f32x4 rp[NPI];          // patch registers
     f32x4 rq[NQ];           // in2 rows
 
@@ -193,11 +196,10 @@ __global__ __launch_bounds__(512, 2) void conv3x3_patch_pc_kernel(const vs_conv_
 #pragma unroll
       for (int i = 0; i < NPI; ++i)
         if (p_have[i] && (first < 0 || tap == first + i / G::IPT)) {
-          u32x2 p1, p2, p3;
-          split4(rp[i], p1, p2, p3);
-          *reinterpret_cast<u32x2*>(Ps + p_lds[i]) = p1;
-          *reinterpret_cast<u32x2*>(Ps + PROWS * ROWB + p_lds[i]) = p2;
-          *reinterpret_cast<u32x2*>(Ps + 2 * PROWS * ROWB + p_lds[i]) = p3;
+          u32x2 pl[NP];
+          split4n<NP>(rp[i], amul, pl);
+#pragma unroll
+          for (int p = 0; p < NP; ++p) *reinterpret_cast<u32x2*>(Ps + p * PROWS * ROWB + p_lds[i]) = pl[p];
         }
     };
     auto load_rows2 = [&, qk4](const int c2) __attribute__((always_inline)) {      // in2 chunk c2 -> registers
@@ -213,12 +215,11 @@ __global__ __launch_bounds__(512, 2) void conv3x3_patch_pc_kernel(const vs_conv_
       unsigned char* Ps = Pbuf + pb * P_BYTES;
 #pragma unroll
       for (int i = 0; i < NQ; ++i) {
-        u32x2 p1, p2, p3;
-        split4(rq[i], p1, p2, p3);
+        u32x2 pl[NP];
+        split4n<NP>(rq[i], amul, pl);
         const int off = ((pt + i * 128) >> 2) * ROWB + qk4 * 2;
-        *reinterpret_cast<u32x2*>(Ps + off) = p1;
-        *reinterpret_cast<u32x2*>(Ps + PROWS * ROWB + off) = p2;
-        *reinterpret_cast<u32x2*>(Ps + 2 * PROWS * ROWB + off) = p3;
+#pragma unroll
+        for (int p = 0; p < NP; ++p) *reinterpret_cast<u32x2*>(Ps + p * PROWS * ROWB + off) = pl[p];
       }
     };
 
@@ -328,14 +329,14 @@ __global__ __launch_bounds__(512, 2) void conv3x3_patch_pc_kernel(const vs_conv_
   }
   const int b_frag = (wn * TN) * 1024 + (2 * r + (g ^ ((r >> 3) & 1))) * 16;   // pack_blocked's bank swizzle
 
-  struct Frags { bf16x8 a[TM][3]; bf16x8 b[TN][3]; };
+  struct Frags { bf16x8 a[TM][NP]; bf16x8 b[TN][NP]; };
   Frags F0, F1;
   auto load_frags = [&, n1, spt, b_frag](Frags& F, const int s) __attribute__((always_inline)) {
     const unsigned char* Bb = Bring + (s % NRING) * B_STAGE;
 #pragma unroll
     for (int j = 0; j < TN; ++j)
 #pragma unroll
-      for (int p = 0; p < 3; ++p) F.b[j][p] = *reinterpret_cast<const bf16x8*>(Bb + p * (BN * 32) + b_frag + j * 1024);
+      for (int p = 0; p < NP; ++p) F.b[j][p] = *reinterpret_cast<const bf16x8*>(Bb + p * (BN * 32) + b_frag + j * 1024);
     int pb, toff;
     if (s < n1) {
       const int cc = s / 9, tap = s - cc * 9;
@@ -352,18 +353,16 @@ __global__ __launch_bounds__(512, 2) void conv3x3_patch_pc_kernel(const vs_conv_
     for (int i = 0; i < TM; ++i) {
       const int ao = ph2 ? a_plain[i] : a_patch[i];
 #pragma unroll
-      for (int p = 0; p < 3; ++p) F.a[i][p] = *reinterpret_cast<const bf16x8*>(Ps + p * PROWS * ROWB + ao);
+      for (int p = 0; p < NP; ++p) F.a[i][p] = *reinterpret_cast<const bf16x8*>(Ps + p * PROWS * ROWB + ao);
     }
   };
   auto mfma_all = [&](const Frags& F) __attribute__((always_inline)) {
 #pragma unroll
-    for (int q = 0; q < 6; ++q) {   // smallest partial products first; consecutive MFMAs hit different accumulators
-      constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};
+    for (int q = 0; q < AR::NPROD; ++q) {   // smallest partial products first; consecutive MFMAs hit different accumulators
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int j = 0; j < TN; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(F.b[j][PB[q]], F.a[i][PA[q]], acc[i][j], 0, 0, 0);   // C^T: see the epilogue
+        for (int j = 0; j < TN; ++j) acc[i][j] = AR::mfma(F.b[j][AR::PB[q]], F.a[i][AR::PA[q]], acc[i][j]);   // C^T: see the epilogue
     }
   };
 
@@ -403,6 +402,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_patch_pc_kernel(const vs_conv_
       mfma_all(F0);
       __syncthreads();
     }
+    if constexpr (NP == 2) scale_all<TM, TN>(acc, p2_slice ? d.acc_mul2 : d.acc_mul);     // exact (power of two): the slices add up in real units
     const int64_t Mrows = (int64_t)d.B * d.H * d.W;
     float* ws = d.splitk_ws + (int64_t)ks * Mrows * d.splitk_ld;
 #pragma unroll
@@ -418,13 +418,16 @@ __global__ __launch_bounds__(512, 2) void conv3x3_patch_pc_kernel(const vs_conv_
     }
     return;
   }
+  if constexpr (NP == 2) scale_all<TM, TN>(acc, d.acc_mul);
   if (n2 > 0) {
     finish_phase1(true);
+    if constexpr (NP == 2) scale_all<TM, TN>(acc, 1.f / d.acc_mul2);     // into the units of the phase-2 products (exact: powers of two)
     for (s = n1; s < total; ++s) {       // short: no prefetch across these steps (the rows are published one barrier before)
       load_frags(F0, s);
       mfma_all(F0);
       __syncthreads();
     }
+    if constexpr (NP == 2) scale_all<TM, TN>(acc, d.acc_mul2);
   } else {
     finish_phase1(false);
   }
@@ -454,8 +457,8 @@ __global__ __launch_bounds__(512, 2) void conv3x3_patch_pc_kernel(const vs_conv_
   }
 }
 
-template <int TN, int TH_ = 8>
-int launch_ppc(const vs_conv_desc_t& d, hipStream_t st) {
+template <int TN, int TH_, int NP>
+int launch_ppc_np(const vs_conv_desc_t& d, hipStream_t st) {
   constexpr int BN = Geo<TH_>::WN * TN * 32;
   constexpr int TH = TH_;
   const int tiles_x = (d.W + TW - 1) / TW, tiles_y = (d.H + TH - 1) / TH;
@@ -466,11 +469,16 @@ int launch_ppc(const vs_conv_desc_t& d, hipStream_t st) {
   if (sk > 1 && (int64_t)(sk - 1) * cps >= spt) return VS_ERR_BAD_ARG;       // an empty K slice
   const int slices = sk > 1 ? sk + (d.in2 ? 1 : 0) : 1;
   if (mt * nt * slices > 0x7fffffffLL) return VS_ERR_UNSUPPORTED;
-  hipLaunchKernelGGL((conv3x3_patch_pc_kernel<TN, TH_>), dim3((unsigned)(mt * nt * slices)), dim3(512), 0, st, d, tiles_x, tiles_y, (int)mt,
+  hipLaunchKernelGGL((conv3x3_patch_pc_kernel<TN, TH_, NP>), dim3((unsigned)(mt * nt * slices)), dim3(512), 0, st, d, tiles_x, tiles_y, (int)mt,
                      (int)nt, cps);
   int rc = vs_launch_status();
   if (rc != VS_OK || sk == 1) return rc;
   return vs_splitk_epilogue(d, (int)((int64_t)d.B * d.H * d.W), st);
+}
+
+template <int TN, int TH_ = 8>
+int launch_ppc(const vs_conv_desc_t& d, hipStream_t st) {
+  return d.arith == 2 ? launch_ppc_np<TN, TH_, 2>(d, st) : launch_ppc_np<TN, TH_, 3>(d, st);
 }
 
 }  // namespace

@@ -19,12 +19,13 @@ constexpr int TH = 8, TW = 16, PW = TW + 2, PH = TH + 2, PROWS = PW * PH;   // 1
 constexpr int BMP = TH * TW;                                                 // 128 output pixels per tile
 constexpr int PITEMS = PROWS * 4;
 constexpr int NPI = (PITEMS + 255) / 256;                                    // 3 patch float4 items per thread
-constexpr int P_BYTES = 3 * PROWS * ROWB;                                    // one patch buffer (three bf16 planes)
-constexpr int Q_BYTES = 3 * BMP * ROWB;                                      // in2 rows of a tile
 
-template <bool IN2>
+template <bool IN2, int NP>
 __global__ __launch_bounds__(256, 2) void conv3x3_small_kernel(const vs_conv_desc_t d, const int tiles_x, const int tiles_y,
                                                                const int ntiles_total, const int tiles_per_wg) {
+  using AR = Arith<NP>;
+  constexpr int P_BYTES = NP * PROWS * ROWB;                                   // one patch buffer (NP 16-bit planes)
+  constexpr int Q_BYTES = NP * BMP * ROWB;                                     // in2 rows of a tile
   __shared__ __attribute__((aligned(16))) unsigned char smem[2 * P_BYTES + (IN2 ? Q_BYTES : 0)];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -37,16 +38,16 @@ __global__ __launch_bounds__(256, 2) void conv3x3_small_kernel(const vs_conv_des
   const int nrow = r < d.N ? r : d.N - 1;                 // N < 32: lanes beyond N re-read a valid row (columns discarded)
   const int64_t plane1 = (int64_t)d.N * 144 * 2;
   const char* wb = reinterpret_cast<const char*>(d.wt_split) + ((int64_t)nrow * 144 + g * 8) * 2;
-  bf16x8 bw[9][3];
+  bf16x8 bw[9][NP];
 #pragma unroll
   for (int t = 0; t < 9; ++t)
 #pragma unroll
-    for (int p = 0; p < 3; ++p) bw[t][p] = *reinterpret_cast<const bf16x8*>(wb + p * plane1 + t * 32);
-  bf16x8 bw2[3];
+    for (int p = 0; p < NP; ++p) bw[t][p] = *reinterpret_cast<const bf16x8*>(wb + p * plane1 + t * 32);
+  bf16x8 bw2[NP];
   if (IN2) {
     const char* wb2 = reinterpret_cast<const char*>(d.wt2_split) + ((int64_t)nrow * 16 + g * 8) * 2;
 #pragma unroll
-    for (int p = 0; p < 3; ++p) bw2[p] = *reinterpret_cast<const bf16x8*>(wb2 + p * ((int64_t)d.N * 16 * 2));
+    for (int p = 0; p < NP; ++p) bw2[p] = *reinterpret_cast<const bf16x8*>(wb2 + p * ((int64_t)d.N * 16 * 2));
   }
   // MFMA operands are swapped (weights = A operand, pixels = B operand): the accumulator is C[channel][pixel], i.e. lane =
   // pixel (lane & 31) and element e = channel (e&3) + 8*(e>>2) + 4*g.  Every lane then owns runs of 4 consecutive
@@ -85,6 +86,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_small_kernel(const vs_conv_des
   const bool vec_io = (d.out_ld & 3) == 0 && (d.out_coff & 3) == 0 && ((uintptr_t)d.out & 15) == 0 &&
                       (!d.res || ((d.res_ld & 3) == 0 && ((uintptr_t)d.res & 15) == 0));
 
+  const float amul = NP == 2 ? d.a_mul : 1.f;
+  const float acc_mul = NP == 2 ? d.acc_mul : 1.f, acc_mul2 = (NP == 2 && IN2) ? d.acc_mul2 : 1.f, inv_mul2 = 1.f / acc_mul2;
   f32x4 rp[NPI], rq[2];
   auto load_tile = [&](const int fb, const int y0, const int x0) __attribute__((always_inline)) {   // patch (+ in2 rows) -> registers
     const bool interior = y0 >= 1 && x0 >= 1 && y0 + TH + 1 <= d.H && x0 + TW + 1 <= d.W;           // workgroup-uniform
@@ -126,22 +129,20 @@ __global__ __launch_bounds__(256, 2) void conv3x3_small_kernel(const vs_conv_des
 #pragma unroll
     for (int i = 0; i < NPI; ++i)
       if (p_have[i]) {
-        u32x2 p1, p2, p3;
-        split4(rp[i], p1, p2, p3);
-        *reinterpret_cast<u32x2*>(Ps + p_lds[i]) = p1;
-        *reinterpret_cast<u32x2*>(Ps + PROWS * ROWB + p_lds[i]) = p2;
-        *reinterpret_cast<u32x2*>(Ps + 2 * PROWS * ROWB + p_lds[i]) = p3;
+        u32x2 pl[NP];
+        split4n<NP>(rp[i], amul, pl);
+#pragma unroll
+        for (int p = 0; p < NP; ++p) *reinterpret_cast<u32x2*>(Ps + p * PROWS * ROWB + p_lds[i]) = pl[p];
       }
     if (IN2) {
       unsigned char* Qs = smem + 2 * P_BYTES;              // single buffer (LDS: two workgroups per CU), see the barrier below
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
-        u32x2 p1, p2, p3;
-        split4(rq[i], p1, p2, p3);
+        u32x2 pl[NP];
+        split4n<NP>(rq[i], amul, pl);
         const int off = ((tid + i * 256) >> 2) * ROWB + k4 * 2;
-        *reinterpret_cast<u32x2*>(Qs + off) = p1;
-        *reinterpret_cast<u32x2*>(Qs + BMP * ROWB + off) = p2;
-        *reinterpret_cast<u32x2*>(Qs + 2 * BMP * ROWB + off) = p3;
+#pragma unroll
+        for (int p = 0; p < NP; ++p) *reinterpret_cast<u32x2*>(Qs + p * BMP * ROWB + off) = pl[p];
       }
     }
   };
@@ -166,32 +167,36 @@ __global__ __launch_bounds__(256, 2) void conv3x3_small_kernel(const vs_conv_des
 #pragma unroll
     for (int tap = 0; tap < 9; ++tap) {
       const int toff = ((tap / 3) * PW + (tap % 3)) * ROWB;
-      bf16x8 af[3];
+      bf16x8 af[NP];
 #pragma unroll
-      for (int p = 0; p < 3; ++p) af[p] = *reinterpret_cast<const bf16x8*>(Ps + p * PROWS * ROWB + toff);
-      if (abl & 1) { acc[tap] += (float)af[0][0] + (float)af[1][1] + (float)af[2][2]; continue; }
+      for (int p = 0; p < NP; ++p) af[p] = *reinterpret_cast<const bf16x8*>(Ps + p * PROWS * ROWB + toff);
+      if (abl & 1) { acc[tap] += (float)af[0][0] + (float)af[1][1]; continue; }
       // smallest partial products first (same order as every other split kernel); weights are the A operand
-      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bw[tap][0], af[2], acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bw[tap][2], af[0], acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bw[tap][1], af[1], acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bw[tap][0], af[1], acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bw[tap][1], af[0], acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bw[tap][0], af[0], acc, 0, 0, 0);
+#pragma unroll
+      for (int q = 0; q < AR::NPROD; ++q) acc = AR::mfma(bw[tap][AR::PB[q]], af[AR::PA[q]], acc);
+    }
+    if constexpr (NP == 2) {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[e] *= acc_mul;       // back to real units (exact: a power of two)
     }
     // epilogue order of vs_conv_gemm: v = act(acc + bias); [phase 2: v += in2 (1x1) wt2 + bias2]; v += res
 #pragma unroll
     for (int e = 0; e < 16; ++e) acc[e] = vs_apply_act(acc[e] + bias1[e], d.act) + bias2[e];
     if (IN2) {
       const unsigned char* Qs = smem + 2 * P_BYTES + a2_frag;
-      bf16x8 af[3];
+      bf16x8 af[NP];
 #pragma unroll
-      for (int p = 0; p < 3; ++p) af[p] = *reinterpret_cast<const bf16x8*>(Qs + p * BMP * ROWB);
-      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bw2[0], af[2], acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bw2[2], af[0], acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bw2[1], af[1], acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bw2[0], af[1], acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bw2[1], af[0], acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bw2[0], af[0], acc, 0, 0, 0);
+      for (int p = 0; p < NP; ++p) af[p] = *reinterpret_cast<const bf16x8*>(Qs + p * BMP * ROWB);
+      if constexpr (NP == 2) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[e] *= inv_mul2;    // into the units of the phase-2 products
+      }
+#pragma unroll
+      for (int q = 0; q < AR::NPROD; ++q) acc = AR::mfma(bw2[AR::PB[q]], af[AR::PA[q]], acc);
+      if constexpr (NP == 2) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[e] *= acc_mul2;
+      }
     }
     const int y = ty * TH + py, x = tx * TW + px;
     if (y < d.H && x < d.W && !((abl & 2) && acc[0] != 123.25f)) {
@@ -247,9 +252,12 @@ int vs_conv3x3_small_dispatch(const vs_conv_desc_t& d, hipStream_t st) {
   const int per = (int)((nt + want - 1) / want);
   const int tpw = per < 1 ? 1 : per;
   const unsigned grid = (unsigned)((nt + tpw - 1) / tpw);
-  if (d.in2)
-    hipLaunchKernelGGL((conv3x3_small_kernel<true>), dim3(grid), dim3(256), 0, st, d, tiles_x, tiles_y, (int)nt, tpw);
+  if (d.arith == 2) {
+    if (d.in2) hipLaunchKernelGGL((conv3x3_small_kernel<true, 2>), dim3(grid), dim3(256), 0, st, d, tiles_x, tiles_y, (int)nt, tpw);
+    else hipLaunchKernelGGL((conv3x3_small_kernel<false, 2>), dim3(grid), dim3(256), 0, st, d, tiles_x, tiles_y, (int)nt, tpw);
+  } else if (d.in2)
+    hipLaunchKernelGGL((conv3x3_small_kernel<true, 3>), dim3(grid), dim3(256), 0, st, d, tiles_x, tiles_y, (int)nt, tpw);
   else
-    hipLaunchKernelGGL((conv3x3_small_kernel<false>), dim3(grid), dim3(256), 0, st, d, tiles_x, tiles_y, (int)nt, tpw);
+    hipLaunchKernelGGL((conv3x3_small_kernel<false, 3>), dim3(grid), dim3(256), 0, st, d, tiles_x, tiles_y, (int)nt, tpw);
   return vs_launch_status();
 }

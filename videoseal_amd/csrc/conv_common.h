@@ -33,6 +33,67 @@ __device__ __forceinline__ void split4(const f32x4& v, u32x2& p1, u32x2& p2, u32
   p3 = u32x2{pack_hi(l[0], l[1]), pack_hi(l[2], l[3])};
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------------
+// Arithmetic of the split back-ends (vs_conv_desc_t::arith).  NP = number of 16-bit planes an fp32 operand is split into.
+//   NP = 3  "3 x bf16": truncation split, exact (8+8+8 mantissa bits), six partial products of weight >= 2^-16.
+//   NP = 2  "2 x f16" : a*a_mul = h + l with h = RN_f16(a*a_mul), l = RN_f16(a*a_mul - h)  (|a*a_mul - h - l| <= 2^-24 |a*a_mul|, the size
+//           of the fp32 rounding of a itself, as long as l is a normal f16, i.e. |a*a_mul| >= 2^-2; below that the absolute error is
+//           <= 2^-25: f16 denormals are honoured by the matrix cores -- measured, tools/micro/f16x2_probe.hip), three partial products
+//           h_a h_b + h_a l_b + l_a h_b (dropped: l_a l_b <= 2^-24 |ab|).  Half the MFMA work of NP = 3 at the accuracy of an fp32 fmaf
+//           chain (probe: rms error 1.9e-7 of |y|max at K = 3456, against 3.0e-7 for NP = 3 and 3.2e-7 for fmaf).  The f16 exponent
+//           range is handled by power-of-two scales that cancel exactly: the weights are pre-scaled per layer so that max|w| lands in
+//           [2^13, 2^14) (engine.split_f16x2 / model_api), the activations by the descriptor's a_mul (default 2^4: |a| < 4094), and the
+//           epilogue multiplies the accumulator by acc_mul = 1 / (a_mul * w_mul) before the bias.  |a| * a_mul >= 65520 overflows to
+//           inf -> NaN in the output (loud, not silent); VIDEOSEAL_CONV=bf16x3 selects the range-free NP = 3 path.
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+
+template <int NP> struct Arith;
+template <> struct Arith<3> {
+  static constexpr int NPROD = 6;
+  // smallest partial products first; (plane of the first operand, plane of the second operand)
+  static constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};
+  static __device__ __forceinline__ f32x16 mfma(const bf16x8& a, const bf16x8& b, const f32x16& c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+  }
+};
+template <> struct Arith<2> {
+  static constexpr int NPROD = 3;
+  static constexpr int PA[3] = {1, 0, 0}, PB[3] = {0, 1, 0};
+  // fragments travel as 16-byte bf16x8 containers in every kernel; here they hold eight f16
+  static __device__ __forceinline__ f32x16 mfma(const bf16x8& a, const bf16x8& b, const f32x16& c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+  }
+};
+
+// 4 floats -> 2 planes of 4 f16 (round-to-nearest split of v * amul; the residual is exact in fp32: one fma)
+__device__ __forceinline__ void split4h(const f32x4& v, const float amul, u32x2& p1, u32x2& p2) {
+  f16x4 hi, lo;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) hi[i] = (_Float16)(v[i] * amul);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) lo[i] = (_Float16)__builtin_fmaf(v[i], amul, -(float)hi[i]);
+  p1 = __builtin_bit_cast(u32x2, hi);
+  p2 = __builtin_bit_cast(u32x2, lo);
+}
+
+// 4 floats -> NP planes (p[0] = most significant)
+template <int NP>
+__device__ __forceinline__ void split4n(const f32x4& v, const float amul, u32x2 (&p)[NP]) {
+  if constexpr (NP == 3) split4(v, p[0], p[1], p[2]);
+  else split4h(v, amul, p[0], p[1]);
+}
+
+template <int TM, int TN>
+__device__ __forceinline__ void scale_all(f32x16 (&acc)[TM][TN], const float mul) {
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] *= mul;
+}
+
 template <int TM, int TN>
 __device__ __forceinline__ void apply_act_all(f32x16 (&acc)[TM][TN], const float (&b1)[TN], const float (&b2)[TN], int act) {
   // act is wave-uniform: one branch around the whole register tile instead of a switch per element

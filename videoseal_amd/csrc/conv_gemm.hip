@@ -30,18 +30,21 @@ namespace {
 
 using namespace vsconv;
 
-template <int WM, int WN, int TM, int TN, bool SPLIT>
+// NPL: 0 = f32 MFMA, 3 = "3 x bf16", 2 = "2 x f16" (conv_common.h, Arith<NP>)
+template <int WM, int WN, int TM, int TN, int NPL>
 __global__ __launch_bounds__(NT, (TM * TN > 4 ? 1 : 2)) void conv_gemm_kernel(const vs_conv_desc_t d, const int M, const int mtiles) {
+  constexpr bool SPLIT = NPL != 0;
+  using AR = Arith<SPLIT ? NPL : 3>;
   constexpr int BM = WM * TM * 32;
   constexpr int BN = WN * TN * 32;
   constexpr int NA = BM * 4 / NT;                       // float4 A loads per thread per chunk
   constexpr int BSLOTS = SPLIT ? BN * 2 : BN * 4;       // 16-byte B slots per plane per chunk
   constexpr int NB = (BSLOTS + NT - 1) / NT;
-  constexpr int NP = SPLIT ? 3 : 1;                     // weight planes
+  constexpr int NP = SPLIT ? NPL : 1;                   // weight planes
   static_assert(WM * WN == 4 && (BM * 4) % NT == 0, "4 waves, whole A tile per pass");
 
-  constexpr int A_BYTES = SPLIT ? 3 * BM * ROWB : BM * LDKF * 4;
-  constexpr int B_BYTES = SPLIT ? 3 * BN * ROWB : BN * LDKF * 4;
+  constexpr int A_BYTES = SPLIT ? NP * BM * ROWB : BM * LDKF * 4;
+  constexpr int B_BYTES = SPLIT ? NP * BN * ROWB : BN * LDKF * 4;
   __shared__ __attribute__((aligned(16))) unsigned char smem[2 * (A_BYTES + B_BYTES)];
   unsigned char* const As0 = smem;
   unsigned char* const Bs0 = smem + 2 * A_BYTES;
@@ -122,6 +125,7 @@ __global__ __launch_bounds__(NT, (TM * TN > 4 ? 1 : 2)) void conv_gemm_kernel(co
   const char* const wbase2 = SPLIT ? reinterpret_cast<const char*>(d.wt2_split) : reinterpret_cast<const char*>(d.wt2);
   constexpr int WELT = SPLIT ? 2 : 4;                    // bytes per weight element
 
+  const float amul = NPL == 2 ? d.a_mul : 1.f;
   int ld_ky = 0, ld_kx = 0, ld_cc = 0, ld_step = 0;
   // two register sets: global loads run two chunks ahead of the MFMAs (chunk c lives in set c&1, LDS buffer c&1)
   struct Regs { f32x4 a[NA]; u32x4 b[NB][NP]; };
@@ -221,13 +225,12 @@ __global__ __launch_bounds__(NT, (TM * TN > 4 ? 1 : 2)) void conv_gemm_kernel(co
 #pragma unroll
     for (int i = 0; i < NA; ++i) {
       const int row = (tid + i * NT) >> 2;
-      if (SPLIT) {
-        u32x2 p1, p2, p3;
-        split4(ra[i], p1, p2, p3);
+      if constexpr (SPLIT) {
+        u32x2 pl[NP];
+        split4n<NP>(ra[i], amul, pl);
         const int off = row * ROWB + k4 * 2;
-        *reinterpret_cast<u32x2*>(Ab + off) = p1;
-        *reinterpret_cast<u32x2*>(Ab + BM * ROWB + off) = p2;
-        *reinterpret_cast<u32x2*>(Ab + 2 * BM * ROWB + off) = p3;
+#pragma unroll
+        for (int p = 0; p < NP; ++p) *reinterpret_cast<u32x2*>(Ab + p * BM * ROWB + off) = pl[p];
       } else {
         *reinterpret_cast<f32x4*>(Ab + (row * LDKF + k4) * 4) = ra[i];
       }
@@ -262,28 +265,26 @@ __global__ __launch_bounds__(NT, (TM * TN > 4 ? 1 : 2)) void conv_gemm_kernel(co
     const unsigned char* Ab = As0 + buf * A_BYTES;
     const unsigned char* Bb = Bs0 + buf * B_BYTES;
     if (abl & 2) {
-    } else if (SPLIT) {
-      bf16x8 af[TM][3], bf[TN][3];
+    } else if constexpr (SPLIT) {
+      bf16x8 af[TM][NP], bf[TN][NP];
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int p = 0; p < 3; ++p)
+        for (int p = 0; p < NP; ++p)
           af[i][p] = *reinterpret_cast<const bf16x8*>(Ab + p * BM * ROWB + ((wm * TM + i) * 32 + r) * ROWB + g * 16);
 #pragma unroll
       for (int j = 0; j < TN; ++j)
 #pragma unroll
-        for (int p = 0; p < 3; ++p)
+        for (int p = 0; p < NP; ++p)
           bf[j][p] = *reinterpret_cast<const bf16x8*>(Bb + p * BN * ROWB + ((wn * TN + j) * 32 + r) * ROWB + g * 16);
       // product term outermost, tiles innermost: consecutive MFMAs hit different accumulators (no dependent-issue stall);
       // smallest terms first
 #pragma unroll
-      for (int q = 0; q < 6; ++q) {
-        constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};
+      for (int q = 0; q < AR::NPROD; ++q) {
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
-          for (int j = 0; j < TN; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][PA[q]], bf[j][PB[q]], acc[i][j], 0, 0, 0);
+          for (int j = 0; j < TN; ++j) acc[i][j] = AR::mfma(af[i][AR::PA[q]], bf[j][AR::PB[q]], acc[i][j]);
       }
     } else {
       // lanes 0-31 hold k 0..7, lanes 32-63 k 8..15 of the chunk; MFMA q multiplies the k pair (q, 8+q)
@@ -337,9 +338,12 @@ __global__ __launch_bounds__(NT, (TM * TN > 4 ? 1 : 2)) void conv_gemm_kernel(co
     }
   };
   k_loop(0, n1e);
+  if constexpr (NPL == 2) scale_all<TM, TN>(acc, d.acc_mul);     // back to real units (exact: a power of two)
   if (n2 > 0) {   // phase 2: finish phase 1 in registers (bias, activation) and keep accumulating the 1x1 conv on top
     apply_act_all<TM, TN>(acc, bias1, bias2, d.act);
+    if constexpr (NPL == 2) scale_all<TM, TN>(acc, 1.f / d.acc_mul2);   // into the units of the phase-2 products
     k_loop(n1e, total);
+    if constexpr (NPL == 2) scale_all<TM, TN>(acc, d.acc_mul2);
   }
 
   // ---- epilogue.  C/D layout of the 32x32 MFMA: col = lane&31, row = (e&3) + 8*(e>>2) + 4*(lane>>5)
@@ -371,7 +375,7 @@ __global__ __launch_bounds__(NT, (TM * TN > 4 ? 1 : 2)) void conv_gemm_kernel(co
   }
 }
 
-template <int WM, int WN, int TM, int TN, bool SPLIT>
+template <int WM, int WN, int TM, int TN, int SPLIT>
 int launch(const vs_conv_desc_t& d, hipStream_t st) {
   constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
   const int64_t M = (int64_t)d.B * d.Ho * d.Wo;
@@ -381,7 +385,7 @@ int launch(const vs_conv_desc_t& d, hipStream_t st) {
   return vs_launch_status();
 }
 
-template <bool SPLIT>
+template <int SPLIT>
 int dispatch(const vs_conv_desc_t& d, int tile, hipStream_t st) {
   switch (tile) {
     case 1: return launch<2, 2, 2, 2, SPLIT>(d, st);   // 128 x 128
@@ -447,6 +451,8 @@ extern "C" int vs_conv_gemm(const vs_conv_desc_t* dp, void* stream) {
     VS_REQUIRE(patch_ok);
     return vs_conv3x3_patch_dispatch(d, tile, st);
   }
+  VS_REQUIRE(d.arith == 0 || d.arith == 2 || d.arith == 3);
+  if (d.arith == 2) VS_REQUIRE(d.a_mul > 0.f && d.acc_mul > 0.f && (!d.in2 || d.acc_mul2 > 0.f));
   if (tile == 15 || tile == 16 || tile == 19 || tile == 21) {   // wave-specialised patch kernel
     VS_REQUIRE(patch_ok && d.wt_blk && (!d.in2 || d.wt2_blk) && ((uintptr_t)d.wt_blk & 15) == 0);
     if (d.split_k > 1) VS_REQUIRE(d.splitk_ws && d.splitk_ld >= d.N && d.split_k <= d.CinP / 16 && !d.sumsq_part);
@@ -502,6 +508,6 @@ extern "C" int vs_conv_gemm(const vs_conv_desc_t* dp, void* stream) {
   if (tile >= 6 && tile <= 9) return VS_ERR_UNSUPPORTED;   // (codes of a retired generic producer/consumer kernel)
   const bool can_split = d.wt_split && (!d.in2 || d.wt2_split) && ((uintptr_t)d.wt_split & 15) == 0;
   if (d.tile_hint & VS_CONV_FORCE_SPLIT) VS_REQUIRE(can_split);
-  if (can_split && !(d.tile_hint & VS_CONV_FORCE_F32)) return dispatch<true>(d, tile, st);
-  return dispatch<false>(d, tile, st);
+  if (can_split && !(d.tile_hint & VS_CONV_FORCE_F32)) return d.arith == 2 ? dispatch<2>(d, tile, st) : dispatch<3>(d, tile, st);
+  return dispatch<0>(d, tile, st);
 }

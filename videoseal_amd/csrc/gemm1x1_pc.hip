@@ -26,7 +26,7 @@ namespace {
 using namespace vsconv;
 
 constexpr int BM = 128;
-constexpr int A_STAGE = 3 * BM * ROWB;     // three bf16 planes of [128 rows][16 k], 48-byte rows (conflict-free b128 reads)
+template <int NP> constexpr int a_stage() { return NP * BM * ROWB; }     // NP 16-bit planes of [128 rows][16 k], 48-byte rows (conflict-free b128 reads)
 
 __device__ __forceinline__ void dma_1k(const char* gp, unsigned char* lds_base) {
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gp,
@@ -39,13 +39,16 @@ __device__ __forceinline__ void dma_1k(const char* gp, unsigned char* lds_base) 
 // tile's first operands while the consumers are in the epilogue, and the 50 MB of output of a 128 x 192-tile round drain under the
 // next tile's MFMAs instead of in a stores-only phase at the end of every round (measured: stores 16.6 us + activation 6 us of a
 // 75.7 us K = 384 launch, tools/bench_gemm.py ksweep).
-template <int TN, bool GRN>
+template <int TN, bool GRN, int NP>
 __device__ __forceinline__ void gemm1x1_pc_tile(const vs_conv_desc_t& d, const int M, const int mtiles, const int ntiles,
                                                 const int pairs_per_split, const int tile, unsigned char* const smem) {
   constexpr int TM = 2;
   constexpr int BN = 64 * TN;
   constexpr int NG = BN / 32;
-  constexpr int B_STAGE = 3 * BN * 32;                   // three planes of NG pre-swizzled 1 KiB blocks
+  using AR = Arith<NP>;
+  constexpr int A_STAGE = a_stage<NP>();
+  constexpr int WBLK = NP * 1024;                        // one (32 rows x 16 k) weight block, all planes
+  constexpr int B_STAGE = NP * BN * 32;                  // NP planes of NG pre-swizzled 1 KiB blocks
   unsigned char* const Aring = smem;
   unsigned char* const Bring = smem + 2 * A_STAGE;
 
@@ -76,8 +79,8 @@ __device__ __forceinline__ void gemm1x1_pc_tile(const vs_conv_desc_t& d, const i
     // loop body is straight-line so that hipcc's s_waitcnt vmcnt(N) placement is exact.
     const int pt = tid & 255;
     constexpr int NI = BM * 8 / 256;       // 4 A items per thread per pair
-    constexpr int NBP = 3 * TN;            // 16-byte weight chunks per thread per pair (2 steps * 3 planes * NG * 64 / 256)
-    constexpr int CPS = 3 * NG * 64;       // chunks per step
+    constexpr int NBP = NP * TN;           // 16-byte weight chunks per thread per pair (2 steps * NP planes * NG * 64 / 256)
+    constexpr int CPS = NP * NG * 64;      // chunks per step
     const int seg = pt & 7;
     const int HW = d.H * d.W;
     unsigned a_off[NI];
@@ -118,11 +121,12 @@ __device__ __forceinline__ void gemm1x1_pc_tile(const vs_conv_desc_t& d, const i
       const int p = c / (NG * 64), rem = c - p * (NG * 64);
       const int gi = rem >> 6, l = rem & 63;
       const int gsel = (g0 + gi) < ngroups ? g0 + gi : ngroups - 1;     // tile wider than N: re-read a valid group (columns discarded)
-      b_goff[j] = (unsigned)(((int64_t)gsel * nch + half) * 3072 + p * 1024 + l * 16);
+      b_goff[j] = (unsigned)(((int64_t)gsel * nch + half) * WBLK + p * 1024 + l * 16);
       b_loff[j] = half * B_STAGE + p * (BN * 32) + gi * 1024 + l * 16;
       b_half[j] = half != 0;
     }
-    const char* const wbase = reinterpret_cast<const char*>(d.wt_blk) + (int64_t)(2 * pair0) * 3072;
+    const char* const wbase = reinterpret_cast<const char*>(d.wt_blk) + (int64_t)(2 * pair0) * WBLK;
+    const float amul = NP == 2 ? d.a_mul : 1.f;
     const int lastp = npairs - 1;
 
     struct PSet { f32x4 r[NI]; f32x4 s0, s1, h; u32x4 b[NBP]; };
@@ -137,7 +141,7 @@ __device__ __forceinline__ void gemm1x1_pc_tile(const vs_conv_desc_t& d, const i
         R.s1 = *reinterpret_cast<const f32x4*>(sbase1 + (int64_t)j * 128);
         R.h = *reinterpret_cast<const f32x4*>(hbase + (int64_t)j * 128);
       }
-      const char* wb = wbase + (int64_t)j * (2 * 3072);
+      const char* wb = wbase + (int64_t)j * (2 * WBLK);
 #pragma unroll
       for (int q = 0; q < NBP; ++q) R.b[q] = *reinterpret_cast<const u32x4*>(wb + b_goff[q]);
     };
@@ -148,12 +152,11 @@ __device__ __forceinline__ void gemm1x1_pc_tile(const vs_conv_desc_t& d, const i
         for (int i = 0; i < NI; ++i) {
           f32x4 v = R.r[i];
           if (grn) v = v * (hi_sel[i] ? R.s1 : R.s0) + R.h;            // GRN apply (same expression as conv_gemm_kernel)
-          u32x2 p1, p2, p3;
-          split4(v, p1, p2, p3);
+          u32x2 pl[NP];
+          split4n<NP>(v, amul, pl);
           unsigned char* dst = Aring + l_off[i];
-          *reinterpret_cast<u32x2*>(dst) = p1;
-          *reinterpret_cast<u32x2*>(dst + BM * ROWB) = p2;
-          *reinterpret_cast<u32x2*>(dst + 2 * BM * ROWB) = p3;
+#pragma unroll
+          for (int p = 0; p < NP; ++p) *reinterpret_cast<u32x2*>(dst + p * BM * ROWB) = pl[p];
         }
       }
 #pragma unroll
@@ -211,29 +214,27 @@ __device__ __forceinline__ void gemm1x1_pc_tile(const vs_conv_desc_t& d, const i
   const int a_frag = (wm * TM * 32 + r) * ROWB + g * 16;
   const int b_frag = (wn * TN) * 1024 + (2 * r + (g ^ ((r >> 3) & 1))) * 16;   // pack_blocked's bank swizzle
 
-  struct Frags { bf16x8 a[TM][3]; bf16x8 b[TN][3]; };
+  struct Frags { bf16x8 a[TM][NP]; bf16x8 b[TN][NP]; };
   Frags F0, F1;
   auto load_frags = [&, a_frag, b_frag](Frags& F, const int s) __attribute__((always_inline)) {
     const unsigned char* Bb = Bring + (s & 1) * B_STAGE;
 #pragma unroll
     for (int j = 0; j < TN; ++j)
 #pragma unroll
-      for (int p = 0; p < 3; ++p) F.b[j][p] = *reinterpret_cast<const bf16x8*>(Bb + p * (BN * 32) + b_frag + j * 1024);
+      for (int p = 0; p < NP; ++p) F.b[j][p] = *reinterpret_cast<const bf16x8*>(Bb + p * (BN * 32) + b_frag + j * 1024);
     const unsigned char* Ab = Aring + (s & 1) * A_STAGE;
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
-      for (int p = 0; p < 3; ++p) F.a[i][p] = *reinterpret_cast<const bf16x8*>(Ab + p * BM * ROWB + a_frag + i * 32 * ROWB);
+      for (int p = 0; p < NP; ++p) F.a[i][p] = *reinterpret_cast<const bf16x8*>(Ab + p * BM * ROWB + a_frag + i * 32 * ROWB);
   };
   auto mfma_all = [&](const Frags& F) __attribute__((always_inline)) {
 #pragma unroll
-    for (int q = 0; q < 6; ++q) {   // smallest partial products first; consecutive MFMAs hit different accumulators
-      constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};
+    for (int q = 0; q < AR::NPROD; ++q) {   // smallest partial products first; consecutive MFMAs hit different accumulators
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int j = 0; j < TN; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(F.a[i][PA[q]], F.b[j][PB[q]], acc[i][j], 0, 0, 0);
+        for (int j = 0; j < TN; ++j) acc[i][j] = AR::mfma(F.a[i][AR::PA[q]], F.b[j][AR::PB[q]], acc[i][j]);
     }
   };
 
@@ -260,6 +261,7 @@ __device__ __forceinline__ void gemm1x1_pc_tile(const vs_conv_desc_t& d, const i
   int col[TN];
 #pragma unroll
   for (int j = 0; j < TN; ++j) col[j] = n0 + (wn * TN + j) * 32 + r;
+  if constexpr (NP == 2) scale_all<TM, TN>(acc, d.acc_mul);       // back to real units (exact: a power of two), also for the K-slice partial sums
   if (d.split_k > 1) {                // raw partial sums -> workspace [ks][M][ws_ld]
     float* ws = d.splitk_ws + (int64_t)ks * M * d.splitk_ld;
 #pragma unroll
@@ -305,12 +307,12 @@ __device__ __forceinline__ void gemm1x1_pc_tile(const vs_conv_desc_t& d, const i
   }
 }
 
-template <int TN, bool GRN>
+template <int TN, bool GRN, int NP>
 __global__ __launch_bounds__(512, 2) void gemm1x1_pc_kernel(const vs_conv_desc_t d, const int M, const int mtiles, const int ntiles,
                                                             const int pairs_per_split, const int ntot) {
-  constexpr int B_STAGE = 3 * (64 * TN) * 32;
-  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * A_STAGE + 2 * B_STAGE];
-  for (int tile = blockIdx.x; tile < ntot; tile += gridDim.x) gemm1x1_pc_tile<TN, GRN>(d, M, mtiles, ntiles, pairs_per_split, tile, smem);
+  constexpr int B_STAGE = NP * (64 * TN) * 32;
+  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * a_stage<NP>() + 2 * B_STAGE];
+  for (int tile = blockIdx.x; tile < ntot; tile += gridDim.x) gemm1x1_pc_tile<TN, GRN, NP>(d, M, mtiles, ntiles, pairs_per_split, tile, smem);
 }
 
 // out = act(sum_ks ws[ks] + bias) [+ ws[split_k] + bias2 : the 1x1 second phase of the patch kernel] (+ res); columns in
@@ -369,10 +371,15 @@ int launch_g(const vs_conv_desc_t& d, hipStream_t st) {
   const int ntot = (int)(mt * nt * sk);
   static const int force_grid = [] { const char* e = getenv("VS_GEMM_GRID"); return e ? atoi(e) : 0; }();      // experiments: 0 = one workgroup per CU
   const int grid = std::min(ntot, force_grid > 0 ? force_grid : vs_num_cus());
-  if (d.a_scale)
-    hipLaunchKernelGGL((gemm1x1_pc_kernel<TN, true>), dim3(grid), dim3(512), 0, st, d, (int)M, (int)mt, (int)nt, pps, ntot);
+  if (d.arith == 2) {
+    if (d.a_scale)
+      hipLaunchKernelGGL((gemm1x1_pc_kernel<TN, true, 2>), dim3(grid), dim3(512), 0, st, d, (int)M, (int)mt, (int)nt, pps, ntot);
+    else
+      hipLaunchKernelGGL((gemm1x1_pc_kernel<TN, false, 2>), dim3(grid), dim3(512), 0, st, d, (int)M, (int)mt, (int)nt, pps, ntot);
+  } else if (d.a_scale)
+    hipLaunchKernelGGL((gemm1x1_pc_kernel<TN, true, 3>), dim3(grid), dim3(512), 0, st, d, (int)M, (int)mt, (int)nt, pps, ntot);
   else
-    hipLaunchKernelGGL((gemm1x1_pc_kernel<TN, false>), dim3(grid), dim3(512), 0, st, d, (int)M, (int)mt, (int)nt, pps, ntot);
+    hipLaunchKernelGGL((gemm1x1_pc_kernel<TN, false, 3>), dim3(grid), dim3(512), 0, st, d, (int)M, (int)mt, (int)nt, pps, ntot);
   int rc = vs_launch_status();
   if (rc != VS_OK || sk == 1) return rc;
   return vs_splitk_epilogue(d, (int)M, st);

@@ -25,6 +25,7 @@ struct HostT { const float* p; int64_t n; };
 struct CW {                      // one conv / linear layer on the device
   float* wt = nullptr; float* bias = nullptr; void* split = nullptr; void* blk = nullptr;
   int N = 0, KH = 0, KW = 0, CinP = 0;
+  float w_mul = 1.f;             // power of two the weights were multiplied with before the 2 x f16 split (arith 2)
 };
 struct RB { CW c0, c1, res; int cout = 0; };
 struct Up { CW conv; CW gemm; bool lowres = false; float* lnw = nullptr; float* lnb = nullptr; RB rb; };   // gemm: nine taps at the low resolution (vs_upconv_gather_ln)
@@ -55,8 +56,11 @@ struct vs_model {
   std::vector<Blk> stages[4];
   float ymat[3];
   float taps43[43];
+  int arith = 3;                 // arithmetic of the split planes (vs_conv_desc_t::arith)
   bool ok = true;
 };
+
+static constexpr float A_MUL = 16.f;      // engine.py::A_MUL
 
 namespace {
 
@@ -107,11 +111,29 @@ struct Packer {
       }
     }
   }
-  // engine.py::pack_blocked: [3][N][K] -> [ceil(N/32)][K/16][3][64 slots][8], chunk order (channel chunk, tap), bank swizzle
+  // engine.py::split_f16x2: w * w_mul = hi + lo in round-to-nearest f16, w_mul = the power of two that puts max|w| into [2^13, 2^14)
+  static float split2(const std::vector<float>& w, std::vector<uint16_t>& planes) {
+    const size_t n = w.size();
+    planes.assign(2 * n, 0);
+    float amax = 0.f;
+    for (float v : w) amax = std::max(amax, std::fabs(v));
+    int kw = 0;
+    if (amax > 0.f && std::isfinite(amax)) { int e; (void)std::frexp(amax, &e); kw = std::max(-100, std::min(100, 14 - e)); }
+    for (size_t i = 0; i < n; ++i) {
+      const float ws = std::ldexp(w[i], kw);
+      const _Float16 hi = (_Float16)ws;
+      const _Float16 lo = (_Float16)(ws - (float)hi);
+      std::memcpy(&planes[i], &hi, 2);
+      std::memcpy(&planes[n + i], &lo, 2);
+    }
+    return std::ldexp(1.f, kw);
+  }
+  // engine.py::pack_blocked: [P][N][K] -> [ceil(N/32)][K/16][P][64 slots][8], chunk order (channel chunk, tap), bank swizzle
   static void blocked(const std::vector<uint16_t>& planes, int n, int k, int ntaps, std::vector<uint16_t>& out) {
+    const int NPL = (int)(planes.size() / ((size_t)n * k));
     const int G = (n + 31) / 32, nch = k / 16, spt = nch / ntaps;
-    out.assign((size_t)G * nch * 3 * 64 * 8, 0);
-    for (int p = 0; p < 3; ++p)
+    out.assign((size_t)G * nch * NPL * 64 * 8, 0);
+    for (int p = 0; p < NPL; ++p)
       for (int row = 0; row < n; ++row) {
         const int g = row / 32, r = row % 32;
         for (int tap = 0; tap < ntaps; ++tap)
@@ -120,7 +142,7 @@ struct Packer {
             for (int h = 0; h < 2; ++h) {
               const int slot = 2 * r + (h ^ ((r >> 3) & 1));
               const uint16_t* src = &planes[(size_t)p * n * k + (size_t)row * k + (size_t)(tap * spt + cc) * 16 + h * 8];
-              uint16_t* dst = &out[((((size_t)g * nch + blkidx) * 3 + p) * 64 + slot) * 8];
+              uint16_t* dst = &out[((((size_t)g * nch + blkidx) * NPL + p) * 64 + slot) * 8];
               std::copy(src, src + 8, dst);
             }
           }
@@ -130,7 +152,8 @@ struct Packer {
     cw.wt = upload(wt);
     if (has_bias) cw.bias = upload(bias);
     std::vector<uint16_t> planes, blk;
-    split3(wt, planes);
+    if (m->arith == 2) cw.w_mul = split2(wt, planes);
+    else split3(wt, planes);
     cw.split = upload(planes);
     blocked(planes, cw.N, cw.KH * cw.KW * cw.CinP, cw.KH * cw.KW, blk);
     cw.blk = upload(blk);
@@ -279,7 +302,8 @@ struct Runner {
     if (in2) { d.in2 = in2->p; d.in2_ld = in2->ld; d.Cin2 = in2->ld; d.Cin2P = w2->CinP; d.wt2 = w2->wt; d.bias2 = w2->bias; }
     d.out = out.p; d.out_ld = out.ld; d.out_coff = out_coff; d.tile_hint = 0;
     d.wt_split = w.split; d.wt_blk = w.blk;
-    if (in2) { d.wt2_split = w2->split; d.wt2_blk = w2->blk; }
+    d.arith = m->arith; d.a_mul = A_MUL; d.acc_mul = 1.f / (A_MUL * w.w_mul);
+    if (in2) { d.wt2_split = w2->split; d.wt2_blk = w2->blk; d.acc_mul2 = 1.f / (A_MUL * w2->w_mul); }
     int split_k = 1;
     const bool dense_rows = d.in_sy == (int64_t)d.W * d.in_sx && d.in_sb == (int64_t)d.H * d.in_sy;
     const bool gemm_pc = d.KH == 1 && d.KW == 1 && sh == 1 && sw == 1 && ph == 0 && pw == 0 && !in2 && d.Ho == d.H && d.Wo == d.W &&
@@ -391,7 +415,7 @@ struct Runner {
         const int co = up.gemm.N / 9;
         ln = act(B, 2 * cur.H, 2 * cur.W, co);
         if (live()) chk(vs_upconv_fused(cur.p, cur.C, cur.ld, skip.p, skip.C, skip.ld, 0.70710678118654752440f, up.gemm.split, B, cur.H, cur.W, co,
-                                        up.lnw, up.lnb, 1e-6f, VS_ACT_RELU, ln.p, ln.ld, st));
+                                        up.lnw, up.lnb, 1e-6f, VS_ACT_RELU, ln.p, ln.ld, m->arith, A_MUL, 1.f / (A_MUL * up.gemm.w_mul), st));
       } else if (up.lowres) {
         const int co = up.gemm.N / 9;
         const bool direct = cur.ld == cur.C + skip.C;
@@ -525,6 +549,7 @@ extern "C" int vs_model_create(const vs_model_cfg_t* cfg, const vs_tensor_t* ten
   }
   vs_model* m = new vs_model();
   m->c = *cfg;
+  m->arith = cfg->arith == 2 || cfg->arith == 3 ? cfg->arith : vs_default_arith();
   for (int i = 0; i <= cfg->nlev; ++i) {
     m->zc.push_back(cfg->zc[i]);
     if (cfg->zc[i] % 4) { delete m; return VS_ERR_UNSUPPORTED; }

@@ -25,14 +25,15 @@ constexpr int UT = 8;                 // low-resolution cells per tile edge
 constexpr int UH = UT + 2;            // with halo
 constexpr int UROWS = 128;            // UH*UH = 100 halo pixels padded to 4 MFMA row blocks
 
-template <int NB, int CG>
+template <int NB, int CG, int NP>
 __global__ __launch_bounds__(256) void upconv_fused_kernel(const float* __restrict__ x, int C1, int64_t ld1, const float* __restrict__ skip,
                                                            int C2, int64_t ld2, float sscale, const unsigned short* __restrict__ wsplit,
                                                            int H, int W, int Co, const float* __restrict__ lnw,
                                                            const float* __restrict__ lnb, float eps, int act, float* __restrict__ out,
-                                                           int64_t old, int tiles_x, int tiles_y, int nblk, int abl) {
+                                                           int64_t old, int tiles_x, int tiles_y, int nblk, int abl, float a_mul, float acc_mul) {
+  using AR = Arith<NP>;
   constexpr int BN = NB * 32;
-  constexpr int A_BYTES = 3 * UROWS * ROWB;
+  constexpr int A_BYTES = NP * UROWS * ROWB;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_u[];
   unsigned char* const As = smem_u;
   unsigned char* const Bs = smem_u + A_BYTES;
@@ -75,14 +76,14 @@ __global__ __launch_bounds__(256) void upconv_fused_kernel(const float* __restri
   // in flight the kernel paid the full HBM latency once per chunk and ran at a quarter of the bandwidth; the weight chunk of step
   // c+1 (L2-resident) is fetched while step c multiplies.
   constexpr int KG = 8;
-  u32x4 rb[NBL][3];
+  u32x4 rb[NBL][NP];
   auto fetch_b = [&](const int kc) __attribute__((always_inline)) {
 #pragma unroll
     for (int i = 0; i < NBL; ++i) {
       const int s = tid + i * 256;
       const int row = s >> 1, sub = s & 1;
 #pragma unroll
-      for (int p = 0; p < 3; ++p) {
+      for (int p = 0; p < NP; ++p) {
         rb[i][p] = u32x4{0u, 0u, 0u, 0u};
         if (s < BSLOT && row < N) rb[i][p] = *reinterpret_cast<const u32x4*>(wsplit + ((int64_t)p * N + row) * K + kc + sub * 8);
       }
@@ -110,34 +111,32 @@ __global__ __launch_bounds__(256) void upconv_fused_kernel(const float* __restri
         if (kc) __syncthreads();                          // the previous chunk's fragments have been read
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
-          u32x2 p1, p2, p3;
-          split4(ra[c][i], p1, p2, p3);
-          *reinterpret_cast<u32x2*>(As + a_lds[i]) = p1;
-          *reinterpret_cast<u32x2*>(As + UROWS * ROWB + a_lds[i]) = p2;
-          *reinterpret_cast<u32x2*>(As + 2 * UROWS * ROWB + a_lds[i]) = p3;
+          u32x2 pl[NP];
+          split4n<NP>(ra[c][i], a_mul, pl);
+#pragma unroll
+          for (int p = 0; p < NP; ++p) *reinterpret_cast<u32x2*>(As + p * UROWS * ROWB + a_lds[i]) = pl[p];
         }
 #pragma unroll
         for (int i = 0; i < NBL; ++i) {
           const int s = tid + i * 256;
           if (s < BSLOT) {
 #pragma unroll
-            for (int p = 0; p < 3; ++p) *reinterpret_cast<u32x4*>(Bs + p * BN * ROWB + (s >> 1) * ROWB + (s & 1) * 16) = rb[i][p];
+            for (int p = 0; p < NP; ++p) *reinterpret_cast<u32x4*>(Bs + p * BN * ROWB + (s >> 1) * ROWB + (s & 1) * 16) = rb[i][p];
           }
         }
         __syncthreads();
         if (kc + BK < K) fetch_b(kc + BK);
-        bf16x8 af[3], bf[NB][3];
+        bf16x8 af[NP], bf[NB][NP];
 #pragma unroll
-        for (int p = 0; p < 3; ++p) af[p] = *reinterpret_cast<const bf16x8*>(As + p * UROWS * ROWB + (wave * 32 + r) * ROWB + g * 16);
+        for (int p = 0; p < NP; ++p) af[p] = *reinterpret_cast<const bf16x8*>(As + p * UROWS * ROWB + (wave * 32 + r) * ROWB + g * 16);
 #pragma unroll
         for (int j = 0; j < NB; ++j)
 #pragma unroll
-          for (int p = 0; p < 3; ++p) bf[j][p] = *reinterpret_cast<const bf16x8*>(Bs + p * BN * ROWB + (j * 32 + r) * ROWB + g * 16);
+          for (int p = 0; p < NP; ++p) bf[j][p] = *reinterpret_cast<const bf16x8*>(Bs + p * BN * ROWB + (j * 32 + r) * ROWB + g * 16);
 #pragma unroll
-        for (int q = 0; q < 6; ++q) {                     // smallest partial products first, as in conv_gemm.hip
-          constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};
+        for (int q = 0; q < AR::NPROD; ++q) {             // smallest partial products first, as in conv_gemm.hip
 #pragma unroll
-          for (int j = 0; j < NB; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[PA[q]], bf[j][PB[q]], acc[j], 0, 0, 0);
+          for (int j = 0; j < NB; ++j) acc[j] = AR::mfma(af[AR::PA[q]], bf[j][AR::PB[q]], acc[j]);
         }
       }
     }
@@ -150,7 +149,7 @@ __global__ __launch_bounds__(256) void upconv_fused_kernel(const float* __restri
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
       const int m = wave * 32 + (e & 3) + 8 * (e >> 2) + 4 * g;
-      if (m < UH * UH && n < N) Z[m * ZS + n] = acc[j][e];
+      if (m < UH * UH && n < N) Z[m * ZS + n] = NP == 2 ? acc[j][e] * acc_mul : acc[j][e];     // back to real units (exact: a power of two)
     }
   }
   __syncthreads();
@@ -227,22 +226,23 @@ __global__ __launch_bounds__(256) void upconv_fused_kernel(const float* __restri
 
 template <int NB, int CG>
 int launch_fused(const float* x, int C1, int64_t ld1, const float* skip, int C2, int64_t ld2, float s, const void* wsplit, int B, int H, int W,
-                 int Co, const float* lnw, const float* lnb, float eps, int act, float* out, int64_t old, hipStream_t st) {
+                 int Co, const float* lnw, const float* lnb, float eps, int act, float* out, int64_t old, int arith, float a_mul, float acc_mul,
+                 hipStream_t st) {
   const size_t stage = 3 * (size_t)(UROWS + NB * 32) * ROWB, ztile = (size_t)UH * UH * (9 * Co + 4) * sizeof(float);
   const size_t smem = std::max(stage, ztile);
   if (smem > 160 * 1024) return VS_ERR_UNSUPPORTED;
-  auto kern = upconv_fused_kernel<NB, CG>;
-  static bool attr = false;
-  if (smem > 64 * 1024 && !attr) {
+  auto kern = arith == 2 ? upconv_fused_kernel<NB, CG, 2> : upconv_fused_kernel<NB, CG, 3>;
+  static bool attr[2] = {false, false};
+  if (smem > 64 * 1024 && !attr[arith == 2]) {
     (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    attr = true;
+    attr[arith == 2] = true;
   }
   const int tiles_x = (W + UT - 1) / UT, tiles_y = (H + UT - 1) / UT;
   const int64_t nblk = (int64_t)B * tiles_x * tiles_y;
   if (nblk >= (1 << 30)) return VS_ERR_UNSUPPORTED;
   static const int abl = [] { const char* e = getenv("VS_UPCONV_ABL"); return e ? atoi(e) : 0; }();
   hipLaunchKernelGGL(kern, dim3((unsigned)((nblk + 7) / 8 * 8)), dim3(256), smem, st, x, C1, ld1, skip, C2, ld2, s,
-                     static_cast<const unsigned short*>(wsplit), H, W, Co, lnw, lnb, eps, act, out, old, tiles_x, tiles_y, (int)nblk, abl);
+                     static_cast<const unsigned short*>(wsplit), H, W, Co, lnw, lnb, eps, act, out, old, tiles_x, tiles_y, (int)nblk, abl, a_mul, acc_mul);
   return vs_launch_status();
 }
 
@@ -258,10 +258,11 @@ extern "C" int vs_upconv_fused_preferred(int C1, int C2, int Co) { return vs_upc
 
 extern "C" int vs_upconv_fused(const float* x, int C1, int64_t ld1, const float* skip, int C2, int64_t ld2, float skip_scale,
                                const void* wt_split, int B, int H, int W, int Co, const float* lnw, const float* lnb, float eps, int act,
-                               float* out, int64_t out_ld, void* stream) {
+                               float* out, int64_t out_ld, int arith, float a_mul, float acc_mul, void* stream) {
+  VS_REQUIRE((arith == 0 || arith == 3) || (arith == 2 && a_mul > 0.f && acc_mul > 0.f));
   VS_REQUIRE(x && skip && wt_split && lnw && lnb && out && B > 0 && H > 0 && W > 0 && vs_upconv_fused_supported(C1, C2, Co));
   VS_REQUIRE(ld1 % 4 == 0 && ld2 % 4 == 0 && ld1 >= C1 && ld2 >= C2 && out_ld % 4 == 0 && out_ld >= Co && ((uintptr_t)wt_split & 15) == 0);
   hipStream_t st = (hipStream_t)stream;
-  if (Co == 16) return launch_fused<5, 4>(x, C1, ld1, skip, C2, ld2, skip_scale, wt_split, B, H, W, Co, lnw, lnb, eps, act, out, out_ld, st);
-  return launch_fused<9, 8>(x, C1, ld1, skip, C2, ld2, skip_scale, wt_split, B, H, W, Co, lnw, lnb, eps, act, out, out_ld, st);
+  if (Co == 16) return launch_fused<5, 4>(x, C1, ld1, skip, C2, ld2, skip_scale, wt_split, B, H, W, Co, lnw, lnb, eps, act, out, out_ld, arith, a_mul, acc_mul, st);
+  return launch_fused<9, 8>(x, C1, ld1, skip, C2, ld2, skip_scale, wt_split, B, H, W, Co, lnw, lnb, eps, act, out, out_ld, arith, a_mul, acc_mul, st);
 }

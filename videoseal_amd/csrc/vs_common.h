@@ -2,6 +2,8 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
 
 #include "videoseal_hip.h"
 
@@ -16,6 +18,20 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 static inline int vs_launch_status() { return hipGetLastError() == hipSuccess ? VS_OK : VS_ERR_LAUNCH; }
 
 static inline int64_t cdiv64(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+// Default arithmetic of the split conv / GEMM path (vs_conv_desc_t::arith): 3 = "3 x bf16" (exact operand split, 6 products),
+// 2 = "2 x f16" (round-to-nearest split with power-of-two range scaling, 3 products; conv_common.h).  VIDEOSEAL_CONV=f16x2 | bf16x3
+// overrides it for the model-level entry points (the operator level takes it from the descriptor).
+#define VS_DEFAULT_ARITH 3
+static inline int vs_default_arith() {
+  static const int a = [] {
+    const char* e = getenv("VIDEOSEAL_CONV");
+    if (e && !strcmp(e, "f16x2")) return 2;
+    if (e && !strcmp(e, "bf16x3")) return 3;
+    return VS_DEFAULT_ARITH;
+  }();
+  return a;
+}
 
 // compute units of the current device (256 on MI355X): grid size of the persistent kernels
 static inline int vs_num_cus() {

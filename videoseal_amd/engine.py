@@ -54,38 +54,44 @@ class ConvW:
     KH: int
     KW: int
     CinP: int
-    split: Optional[torch.Tensor] = None   # [3][N][Ktot] bf16 bit patterns (int16): exact 3-term split of wt
-
+    split: Optional[torch.Tensor] = None   # [P][N][Ktot] 16-bit patterns (int16): P = 3 exact bf16 terms / P = 2 f16 terms of wt * w_mul
     blk: Optional[torch.Tensor] = None     # split weights in LDS-image order (producer/consumer kernels)
+    arith: int = 3                         # arithmetic the planes were made for (vs_conv_desc_t::arith)
+    w_mul: float = 1.0                     # power of two the weights were multiplied with before the split (arith 2)
 
-    def with_split(self) -> "ConvW":
-        if self.split is None:
-            self.split = split_bf16x3(self.wt)
+    def with_split(self, arith: int = 3) -> "ConvW":
+        if self.split is None or self.arith != arith:
+            self.arith, self.blk = arith, None
+            if arith == 2:
+                self.split, self.w_mul = split_f16x2(self.wt)
+            else:
+                self.split, self.w_mul = split_bf16x3(self.wt), 1.0
         return self
 
-    def with_blk(self) -> "ConvW":
-        if self.blk is None:
-            self.blk = pack_blocked(self.with_split().split, self.KH * self.KW)
+    def with_blk(self, arith: int = 3) -> "ConvW":
+        if self.blk is None or self.arith != arith:
+            self.with_split(arith)
+            self.blk = pack_blocked(self.split, self.KH * self.KW)
         return self
 
 
 def pack_blocked(planes: torch.Tensor, ntaps: int = 1) -> torch.Tensor:
-    """[3][N][Ktot] bf16 patterns -> [ceil(N/32)][Ktot/16][3][64 slots][8]: every (32 rows x 16 k) block is 1 KiB in
+    """[P][N][Ktot] 16-bit patterns -> [ceil(N/32)][Ktot/16][P][64 slots][8]: every (32 rows x 16 k) block is 1 KiB in
     the order the kernel wants it in LDS; slot of (row r, k-half h) = 2r + (h ^ ((r>>3)&1)) (bank swizzle).
     Chunk order is (channel chunk, tap) -- the producer/consumer kernel walks all taps of a 16-channel chunk back to
     back so that the shifted re-reads of the same activation rows hit L1/L2 -- while Ktot is laid out (tap, channel)."""
-    _, n, k = planes.shape
+    P, n, k = planes.shape
     G, nch = (n + 31) // 32, k // 16
     spt = nch // ntaps
-    pad = torch.zeros(3, G * 32, k, dtype=planes.dtype, device=planes.device)
+    pad = torch.zeros(P, G * 32, k, dtype=planes.dtype, device=planes.device)
     pad[:, :n] = planes
-    pad = pad.view(3, G * 32, ntaps, spt, 16).permute(0, 1, 3, 2, 4).reshape(3, G * 32, k)   # k order -> (chunk, tap, 16)
-    x = pad.view(3, G, 32, nch, 2, 8).permute(1, 3, 0, 2, 4, 5).contiguous()       # [G][nch][3][r][h][8]
+    pad = pad.view(P, G * 32, ntaps, spt, 16).permute(0, 1, 3, 2, 4).reshape(P, G * 32, k)   # k order -> (chunk, tap, 16)
+    x = pad.view(P, G, 32, nch, 2, 8).permute(1, 3, 0, 2, 4, 5).contiguous()       # [G][nch][P][r][h][8]
     r = torch.arange(32, device=planes.device)[:, None]
     h = torch.arange(2, device=planes.device)[None, :]
     slot = (2 * r + (h ^ ((r >> 3) & 1))).reshape(-1)                               # [(r,h)] -> slot
-    out = torch.empty(G, nch, 3, 64, 8, dtype=planes.dtype, device=planes.device)
-    out[:, :, :, slot] = x.view(G, nch, 3, 64, 8)
+    out = torch.empty(G, nch, P, 64, 8, dtype=planes.dtype, device=planes.device)
+    out[:, :, :, slot] = x.view(G, nch, P, 64, 8)
     return out.contiguous()
 
 
@@ -100,6 +106,23 @@ def split_bf16x3(w: torch.Tensor) -> torch.Tensor:
         planes.append((hi.view(torch.int32) >> 16).to(torch.int16))
         r = r - hi
     return torch.stack(planes, 0).contiguous()
+
+
+A_MUL = 16.0        # power of two the activations are multiplied with before the f16 split (vs_conv_desc_t::a_mul): |a| < 4094
+
+
+def split_f16x2(w: torch.Tensor) -> Tuple[torch.Tensor, float]:
+    """fp32 -> two f16 terms of w * w_mul by round-to-nearest (hi = f16(w'), lo = f16(w' - hi)); w_mul is the power of two that puts
+    max|w| into [2^13, 2^14) so that the low term of every weight >= 2^-16 max|w| is a normal f16 (conv_common.h, Arith<2>).
+    Returned as int16 bit patterns [2, *w.shape] and w_mul."""
+    w = w.float().contiguous()
+    amax = float(w.abs().max()) if w.numel() else 0.0
+    kw = 14 - math.frexp(amax)[1] if amax > 0.0 and math.isfinite(amax) else 0
+    kw = max(-100, min(100, kw))
+    ws = torch.ldexp(w, torch.tensor(kw, device=w.device))                     # exact
+    hi = ws.to(torch.float16)
+    lo = (ws - hi.float()).to(torch.float16)
+    return torch.stack([hi.view(torch.int16), lo.view(torch.int16)], 0).contiguous(), 2.0 ** kw
 
 
 def pack_conv(w: torch.Tensor, in_ld: int, scale: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, int]:
@@ -137,6 +160,7 @@ def padvec(v: torch.Tensor, n: int) -> torch.Tensor:
 
 class HipEngine:
     """Packed weights + launch sequences for one architecture (ModelCfg) on one device."""
+    arith = 3          # arithmetic of the split back-end (vs_conv_desc_t::arith); set per instance from VIDEOSEAL_CONV
 
     def __init__(self, cfg, sd: Dict[str, torch.Tensor], device: torch.device):
         self.cfg = cfg
@@ -145,7 +169,13 @@ class HipEngine:
         self._ws: Dict[tuple, torch.Tensor] = {}
         self.kernel_timers = None        # list of (name, start_event, end_event, flops) when bench.py enables it
         self.time_all_convs = False
-        self.use_split = os.environ.get("VIDEOSEAL_CONV", "split") != "f32"   # arithmetic back-end of vs_conv_gemm
+        # arithmetic back-end of vs_conv_gemm: "f16x2" (2 x f16 split, 3 products), "bf16x3" (exact 3 x bf16 split, 6 products),
+        # "f32" (v_mfma_f32_32x32x2_f32); "split" = the default split back-end
+        conv_mode = os.environ.get("VIDEOSEAL_CONV", "split")
+        if conv_mode not in ("split", "f32", "bf16x3", "f16x2"):
+            raise N.NativeError(f"VIDEOSEAL_CONV={conv_mode!r}: expected split, f16x2, bf16x3 or f32")
+        self.use_split = conv_mode != "f32"
+        self.arith = 2 if conv_mode == "f16x2" else 3
         # Upsample groups as a low-resolution 9-tap GEMM + gather (a quarter of the MACs, no up-sampled concat); 0 = the literal
         # bilinear x2 -> reflect-pad conv3x3 -> LayerNorm sequence (kept for A/B checks)
         self.upconv_lowres = os.environ.get("VIDEOSEAL_UPCONV", "lowres") != "direct"
@@ -337,7 +367,8 @@ class HipEngine:
     def conv(self, x: Act, w: ConvW, out: Act, *, stride=1, pad=0, pad_mode=N.PAD_ZERO, act=N.ACT_NONE, out_coff=0,
              n_store=None, res: Optional[Act] = None, in2: Optional[Act] = None, w2: Optional[ConvW] = None,
              a_scale=None, a_scale_ld=0, a_shift=None, geom=None, tile_hint=0, prof: Optional[str] = None,
-             split_k: Optional[int] = None, sumsq: Optional[torch.Tensor] = None, cin: Optional[int] = None, flops: Optional[float] = None):
+             split_k: Optional[int] = None, sumsq: Optional[torch.Tensor] = None, cin: Optional[int] = None, flops: Optional[float] = None,
+             arith: Optional[int] = None):
         """cin: read only the first `cin` channels of every pixel (pixel stride stays x.ld)"""
         d = N.ConvDesc()
         if geom is None:
@@ -364,11 +395,14 @@ class HipEngine:
             d.wt2, d.bias2 = N.ptr(w2.wt), N.ptr(w2.bias)
         d.out, d.out_ld, d.out_coff, d.tile_hint = N.ptr(out.t), out.ld, out_coff, tile_hint
         if self.use_split and not (tile_hint & N.CONV_FORCE_F32):
-            d.wt_split = N.ptr(w.with_split().split)
-            d.wt_blk = N.ptr(w.with_blk().blk)
+            ar = self.arith if arith is None else arith
+            d.wt_split = N.ptr(w.with_blk(ar).split)
+            d.wt_blk = N.ptr(w.blk)
+            d.arith, d.a_mul, d.acc_mul = ar, A_MUL, 1.0 / (A_MUL * w.w_mul)
             if in2 is not None:
-                d.wt2_split = N.ptr(w2.with_split().split)
-                d.wt2_blk = N.ptr(w2.with_blk().blk)
+                d.wt2_split = N.ptr(w2.with_blk(ar).split)
+                d.wt2_blk = N.ptr(w2.blk)
+                d.acc_mul2 = 1.0 / (A_MUL * w2.w_mul)
         if sumsq is not None:       # GRN partial sums of squares from the epilogue ([rows/32][N])
             d.sumsq_part = N.ptr(sumsq)
             split_k = 1
@@ -668,9 +702,10 @@ class HipEngine:
             if "gemm" in up and xcur.ld == xcur.C and fused_ok(k, xcur.C, skip.C):     # thin levels: one kernel, z stays in LDS
                 co = up["gemm"].N // 9
                 ln = self.new_act(f"up{k}.ln", B, 2 * xcur.H, 2 * xcur.W, co)
+                gw = up["gemm"].with_split(self.arith)
                 N.check(L.vs_upconv_fused(N.ptr(xcur.t), xcur.C, xcur.ld, N.ptr(skip.t), skip.C, skip.ld, 2 ** -0.5,
-                                          N.ptr(up["gemm"].with_split().split), B, xcur.H, xcur.W, co, N.ptr(up["lnw"]), N.ptr(up["lnb"]),
-                                          1e-6, up_act, N.ptr(ln.t), ln.ld, st), "vs_upconv_fused")
+                                          N.ptr(gw.split), B, xcur.H, xcur.W, co, N.ptr(up["lnw"]), N.ptr(up["lnb"]),
+                                          1e-6, up_act, N.ptr(ln.t), ln.ld, self.arith, A_MUL, 1.0 / (A_MUL * gw.w_mul), st), "vs_upconv_fused")
             elif "gemm" in up:     # low-resolution 9-tap GEMM + gather / LayerNorm / ReLU (see vs_upconv_gather_ln)
                 co = up["gemm"].N // 9
                 direct = xcur.ld == xcur.C + skip.C      # x already sits in columns [0, C) of the concat buffer

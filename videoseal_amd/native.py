@@ -49,8 +49,8 @@ class ConvDesc(C.Structure):
         ("wt2", C.c_void_p), ("bias2", C.c_void_p),
         ("out", C.c_void_p), ("out_ld", C.c_int64), ("out_coff", C.c_int32), ("tile_hint", C.c_int32),
         ("wt_split", C.c_void_p), ("wt2_split", C.c_void_p), ("wt_blk", C.c_void_p), ("wt2_blk", C.c_void_p),
-        ("splitk_ws", C.c_void_p), ("splitk_ld", C.c_int64), ("split_k", C.c_int32), ("reserved_", C.c_int32),
-        ("sumsq_part", C.c_void_p),
+        ("splitk_ws", C.c_void_p), ("splitk_ld", C.c_int64), ("split_k", C.c_int32), ("arith", C.c_int32),
+        ("sumsq_part", C.c_void_p), ("a_mul", C.c_float), ("acc_mul", C.c_float), ("acc_mul2", C.c_float), ("reserved_", C.c_int32),
     ]
 
 
@@ -99,7 +99,7 @@ def lib() -> C.CDLL:
         "vs_msg_pre": [P, I, I, P, P],
         "vs_upconv_fused_supported": [I, I, I],
         "vs_upconv_fused_preferred": [I, I, I],
-        "vs_upconv_fused": [P, I, I64, P, I, I64, F, P, I, I, I, I, P, P, F, I, P, I64, P],
+        "vs_upconv_fused": [P, I, I64, P, I, I64, F, P, I, I, I, I, P, P, F, I, P, I64, I, F, F, P],
         "vs_im2col3x3": [P, I, I, I, I64, I, P, P],
         "vs_msg_latent": [P, P, I, I, I, P, P],
         "vs_broadcast_channels": [P, I, I, P, I, I, I64, I, P],
