@@ -13,8 +13,8 @@ no data-path collective for embedding and one RCCL all-gather of the [32, 257] l
 Prints ONE JSON line (rank 0) with the driver's contract plus
   roofline     -- dominant kernel = the U-Net bottleneck 3x3 conv (384->384 @32x32, 81 % of the embed FLOPs):
                   algorithmic FLOPs per launch / average launch duration measured live with HIP events on the
-                  launch stream, against 2500/6 = 416.7 TFLOP/s (dense bf16 MFMA peak / 6 partial products of the
-                  exact 3 x bf16 operand split); `frac` from the live events, `frac_rocprof` from the tracked
+                  launch stream, against 2500/3 = 833.3 TFLOP/s (dense f16 MFMA peak / 3 partial products of the default
+                  2 x f16 operand split; 2500/6 with VIDEOSEAL_CONV=bf16x3); `frac` from the live events, `frac_rocprof` from the tracked
                   rocprofv3 kernel-trace average of the same command (profiles/), `e2e_frac` = whole-step model
                   FLOP/s over the same ceiling; `shell` = the HBM-bound kernels against 8 TB/s
   cpu_baseline -- the CPU oracle (torch fp32 restatement of the reference path, pinned to the reference by
@@ -35,9 +35,19 @@ sys.path.insert(0, ROOT)
 
 PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 64 FLOP/clk/SIMD
 PEAK_BF16_MFMA_TFLOPS = 2500.0    # MI355X_MICROARCH.md: dense bf16 MFMA
-# default arithmetic: every fp32 product = 6 bf16 MFMA partial products (3 x bf16 exact split, fp32 accumulate), so the
-# ceiling for *algorithmic* (fp32-equivalent) FLOP/s is the bf16 peak / 6
-PEAK_SPLIT_TFLOPS = PEAK_BF16_MFMA_TFLOPS / 6.0
+# split arithmetic: every fp32 product = 3 f16 MFMA partial products (2 x f16 split, the default) or 6 bf16 ones (3 x bf16 exact
+# split), fp32 accumulate; f16 and bf16 MFMA have the same dense peak, so the ceiling for *algorithmic* (fp32-equivalent) FLOP/s
+# is that peak / 3 resp. / 6
+def products(eng):
+    return 3 if eng.arith == 2 else 6
+
+
+def peak_split(eng):
+    return PEAK_BF16_MFMA_TFLOPS / products(eng)
+
+
+def arith_name(eng):
+    return "2 x f16 operand split, 3 products on v_mfma_f32_32x32x16_f16" if eng.arith == 2 else "3 x bf16 exact operand split, 6 products on v_mfma_f32_32x32x16_bf16"
 
 
 def synthetic_batch(n, size, device, seed):
@@ -305,15 +315,16 @@ def main():
         avg = sum(dur) / len(dur)
         ach = flops / avg / 1e12
         split = eng.use_split
-        peak = PEAK_SPLIT_TFLOPS if split else PEAK_F32_MFMA_TFLOPS
+        nprod = products(eng)
+        peak = peak_split(eng) if split else PEAK_F32_MFMA_TFLOPS
         roof = {"bound": "mfma",
                 "kernel": ("conv3x3_patch_pc_kernel" if split else "conv_gemm_kernel") + " (U-Net bottleneck 3x3 conv 384->384 @32x32, " +
-                          ("3 x bf16 split on v_mfma_f32_32x32x16_bf16, fp32 accumulate)" if split else "v_mfma_f32_32x32x2_f32)"),
+                          (arith_name(eng) + ", fp32 accumulate)" if split else "v_mfma_f32_32x32x2_f32)"),
                 "achieved": round(ach, 2), "peak": round(peak, 1), "unit": "TFLOP/s", "frac": round(ach / peak, 4),
-                "peak_note": ("2500 TF dense bf16 MFMA / 6 partial products per fp32-accurate product" if split
+                "peak_note": (f"2500 TF dense 16-bit MFMA / {nprod} partial products per fp32-accurate product" if split
                               else "f32-input MFMA, 64 FLOP/clk/SIMD"),
                 "achieved_vs_f32_mfma_peak": round(ach / PEAK_F32_MFMA_TFLOPS, 4),
-                "mfma_issue_tflops_bf16": round(ach * 6, 1) if split else None,
+                "mfma_issue_tflops_16bit": round(ach * nprod, 1) if split else None,
                 "flops_per_launch": flops, "avg_launch_ms": round(avg * 1e3, 4), "launches_timed": len(dur), "traffic": None}
         eng.kernel_timers = None
         # per-stage roofline of the HBM-bound shell: algorithmic bytes / HIP-event duration vs 8 TB/s
@@ -330,20 +341,20 @@ def main():
             # register-only v_mfma_f32_32x32x16_bf16 loop, 8 waves/CU, measured right here (tools/micro/mfma_peak.hip)
             sus = measure_sustained_mfma()
             if sus:
-                roof["mfma_sustained_measured"] = {"bf16_tflops": round(sus, 1), "split_equiv_tflops": round(sus / 6, 1),
-                                                   "frac_of_sustained": round(ach / (sus / 6), 4),
+                roof["mfma_sustained_measured"] = {"bf16_tflops": round(sus, 1), "split_equiv_tflops": round(sus / nprod, 1),
+                                                   "frac_of_sustained": round(ach / (sus / nprod), 4),
                                                    "how": "tools/micro/mfma_peak.hip: register-only MFMA loop, random operands, 8 waves/CU x 4 blocks"}
         import glob
         # the same kernel's average duration in the tracked rocprofv3 --kernel-trace --stats run of this command (profiles/):
         # both fractions are printed so that the bench line and the profile can be compared directly
         rp = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_rocprof_dominant.json")))
-        if rp and B == 32 and S == 768 and split and args.mode == "image":
+        if rp and B == 32 and S == 768 and split and args.mode == "image" and json.load(open(rp[-1])).get("arith", 3) == eng.arith:
             rj = json.load(open(rp[-1]))
             roof["frac_rocprof"] = round(flops / (rj["avg_ms"] * 1e-3) / 1e12 / peak, 4)
             roof["rocprof"] = {"avg_launch_ms": rj["avg_ms"], "launches": rj["calls"], "source": rj["source"]}
         pmcs = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_dominant.json")))
         pmc = pmcs[-1] if pmcs else ""
-        if os.path.exists(pmc) and B == 32 and S == 768 and split:     # counters were collected on this exact workload
+        if os.path.exists(pmc) and B == 32 and S == 768 and split and json.load(open(pmc)).get("arith", 3) == eng.arith:     # counters were collected on this exact workload
             pj = json.load(open(pmc))
             # HBM bytes per launch of the dominant kernel from the PMC passes (read + write), then the break-down
             roof["traffic"] = round((pj["fetch_mb_per_launch"] + pj["write_mb_per_launch"]) * 1e6)
@@ -360,7 +371,7 @@ def main():
         if args.detect_only:
             gmac = 613.6 if args.card == "chunkyseal" else 6.16
         if roof is not None:
-            roof["e2e_frac"] = round(fps * gmac * 2e9 / 1e12 / world / (PEAK_SPLIT_TFLOPS if eng.use_split else PEAK_F32_MFMA_TFLOPS), 4)
+            roof["e2e_frac"] = round(fps * gmac * 2e9 / 1e12 / world / (peak_split(eng) if eng.use_split else PEAK_F32_MFMA_TFLOPS), 4)
             roof["e2e_note"] = "whole-step dense conv/GEMM FLOP/s (SURVEY 8(d) per-frame GMAC x frames/s) over the same MFMA ceiling"
         metric = f"frames/sec embed+extract {cfg.nbits}-bit @{S}x{S}"
         if args.detect_only:
@@ -371,7 +382,7 @@ def main():
             "metric": metric, "value": round(fps, 2), "unit": "frames/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 3),
             "higher_is_better": True, "scaling": "strong" if stream else "weak", "vs_baseline": None,
-            "dtype": "f32 (3 x bf16 exact operand split on the bf16 matrix cores, fp32 accumulate)" if eng.use_split else "f32", "data": "synthetic",
+            "dtype": f"f32 ({arith_name(eng)}, fp32 accumulate)" if eng.use_split else "f32", "data": "synthetic",
             "config": {"workload": f"{args.card} {cfg.nbits}-bit, {B} frames {S}x{S} per GPU, {args.mode} mode "
                                    f"({'embedder on every frame' if not is_video else 'key frames every %d' % cfg.step_size}, "
                                    f"{'low-res' if args.lowres_attenuation else 'full-res'} JND), " + ("detect only" if args.detect_only else "embed + detect")

@@ -140,6 +140,19 @@ def test_vs10_matches_reference_golden(vs10, name):
     _run_case(*vs10, name)
 
 
+@pytest.mark.parametrize("mode,name", [("bf16x3", "vs10_img256"), ("bf16x3", "vs10_vid"), ("f32", "vs10_img256"), ("f16x2", "vs10_img_odd")])
+def test_vs10_every_arithmetic_matches_reference_golden(monkeypatch, mode, name):
+    """the three arithmetic back-ends of the dense layers (VIDEOSEAL_CONV: 2 x f16 split = default, exact 3 x bf16 split, f32 MFMA)
+    against the same goldens of the unmodified reference, same tolerances, bit decisions identical on identical inputs."""
+    monkeypatch.setenv("VIDEOSEAL_CONV", mode)
+    s = spec_from_card(os.path.join(CARDS, "videoseal_1.0.yaml"))
+    sd = make_state_dict(s, seed=0)
+    m = make_model(s, sd)
+    eng = m._engine()
+    assert (eng.use_split, eng.arith if eng.use_split else 0) == {"bf16x3": (True, 3), "f16x2": (True, 2), "f32": (False, 0)}[mode]
+    _run_case(s, sd, m, name)
+
+
 def test_submodules_match_golden(vs10):
     """model.embedder(y, msgs) / model.detector(x) / model.attenuation.heatmaps(x) (SURVEY 8(b) method surface)."""
     spec, sd, model = vs10

@@ -9,7 +9,16 @@ os.environ["VIDEOSEAL_TUNED_TILES"] = "0"
 import torch
 import videoseal_amd
 
-cache = {}
+# start from the packaged table: the signatures of the other arithmetic (VIDEOSEAL_CONV=bf16x3 / f16x2: the key ends in 2 for
+# 2 x f16) are kept, the ones of the arithmetic in use are re-measured
+from videoseal_amd.engine import TUNED_TILES
+cache, kept = {}, {}
+if os.path.exists(TUNED_TILES) and "--fresh" not in sys.argv:
+    h2 = os.environ.get("VIDEOSEAL_CONV", "split") != "bf16x3"
+    for k, v in json.load(open(TUNED_TILES)).items():
+        kt = tuple(json.loads(k))
+        if (len(kt) == 22) != h2:
+            kept[kt] = v
 def run(card, B, S, video, lowres, detect_only=False, rounds=8):
     model = videoseal_amd.build(card, seed=0).eval().cuda()
     model.chunk_size = max(model.chunk_size, B)
@@ -39,5 +48,6 @@ if "--chunky" in sys.argv:
 out = os.path.join(ROOT, "gpurun_out", "tuned_tiles_gfx950.json")
 os.makedirs(os.path.dirname(out), exist_ok=True)
 with open(out, "w") as f:
-    json.dump({json.dumps(list(k)): v for k, v in sorted(cache.items())}, f, indent=0)
+    cache.update(kept)
+    json.dump({json.dumps(list(k)): v for k, v in sorted(cache.items(), key=lambda kv: (len(kv[0]), kv[0]))}, f, indent=0)
 print("wrote", out)

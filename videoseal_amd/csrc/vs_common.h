@@ -22,7 +22,7 @@ static inline int64_t cdiv64(int64_t a, int64_t b) { return (a + b - 1) / b; }
 // Default arithmetic of the split conv / GEMM path (vs_conv_desc_t::arith): 3 = "3 x bf16" (exact operand split, 6 products),
 // 2 = "2 x f16" (round-to-nearest split with power-of-two range scaling, 3 products; conv_common.h).  VIDEOSEAL_CONV=f16x2 | bf16x3
 // overrides it for the model-level entry points (the operator level takes it from the descriptor).
-#define VS_DEFAULT_ARITH 3
+#define VS_DEFAULT_ARITH 2
 static inline int vs_default_arith() {
   static const int a = [] {
     const char* e = getenv("VIDEOSEAL_CONV");

@@ -160,7 +160,7 @@ def padvec(v: torch.Tensor, n: int) -> torch.Tensor:
 
 class HipEngine:
     """Packed weights + launch sequences for one architecture (ModelCfg) on one device."""
-    arith = 3          # arithmetic of the split back-end (vs_conv_desc_t::arith); set per instance from VIDEOSEAL_CONV
+    arith = 2          # arithmetic of the split back-end (vs_conv_desc_t::arith); set per instance from VIDEOSEAL_CONV
 
     def __init__(self, cfg, sd: Dict[str, torch.Tensor], device: torch.device):
         self.cfg = cfg
@@ -175,7 +175,7 @@ class HipEngine:
         if conv_mode not in ("split", "f32", "bf16x3", "f16x2"):
             raise N.NativeError(f"VIDEOSEAL_CONV={conv_mode!r}: expected split, f16x2, bf16x3 or f32")
         self.use_split = conv_mode != "f32"
-        self.arith = 2 if conv_mode == "f16x2" else 3
+        self.arith = 3 if conv_mode == "bf16x3" else 2
         # Upsample groups as a low-resolution 9-tap GEMM + gather (a quarter of the MACs, no up-sampled concat); 0 = the literal
         # bilinear x2 -> reflect-pad conv3x3 -> LayerNorm sequence (kept for A/B checks)
         self.upconv_lowres = os.environ.get("VIDEOSEAL_UPCONV", "lowres") != "direct"
@@ -484,6 +484,8 @@ class HipEngine:
         """time the 4-wave tile shapes once per conv signature (on a scratch output) and remember the fastest."""
         key = (d.B, d.H, d.W, d.Cin, d.KH, d.KW, d.SH, d.SW, d.pad_mode, d.Ho, d.Wo, d.N, d.CinP, bool(d.in2), d.Cin2P,
                bool(d.a_scale), bool(d.res), d.act, bool(d.wt_split), d.split_k, bool(d.sumsq_part))
+        if d.wt_split and d.arith == 2:
+            key += (2,)          # the 2 x f16 arithmetic has its own timings (half the MFMA work per tile)
         best = self._tile_cache.get(key)
         if best is not None:
             return best
