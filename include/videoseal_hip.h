@@ -93,6 +93,7 @@ typedef struct vs_conv_desc {
                             /* 15 = 128x128, 16 = 128x192, 19 = 128x64, 21 = 256x64: wave-specialised patch kernel (needs wt_blk); */
                             /* 20: persistent 3x3 kernel for 16-input-channel layers with <= 32 outputs (weights in registers);          */
                             /* 17 = 128x128, 18 = 128x192: wave-specialised 1x1 GEMM (dense rows, Cin % 32 == 0, wt_blk);  */
+                            /* 22 = 256x192, 23 = 256x128: all-DMA 3x3 kernel on pre-split planes (arith 2, in_pl, H % 16 == W % 16 == 0);  */
                             /* | VS_CONV_TILE_HI: tile code + 16;                                                     */
                             /* | VS_CONV_FORCE_F32: v_mfma_f32_32x32x2_f32 path; | VS_CONV_FORCE_SPLIT */
   const void* wt_split;     /* optional [P][N][Ktot] 16-bit planes (P = 3 bf16 / 2 f16, see arith): wt split into P terms; when set */
@@ -108,6 +109,9 @@ typedef struct vs_conv_desc {
   float* sumsq_part;        /* optional (1x1, no phase 2 / residual / K split): [ceil(M/32)][N] sums of squares of the stored  */
                             /*   values per 32-row group and column = GRN's ||x||^2 partials (common.py:166), see              */
                             /*   vs_grn_scale_from_partials                                                                    */
+  const void* in_pl;        /* tile codes 22 / 23 (arith 2): the operands as PRE-SPLIT planes, f16 hi / lo of value * a_mul, layout        */
+  const void* in2_pl;       /*   [2 planes][C/16][B*H*W][16] (vs_to_planes, or a previous launch's out_pl); `in` / `in2` may then be NULL  */
+  void* out_pl;             /*   optional: the result written as planes for the next launch (N % 16 == 0); `out` may then be NULL          */
   float a_mul;              /* arith = 2: power of two the activations (in and in2) are multiplied with before the f16 split       */
   float acc_mul;            /*   = 1 / (a_mul * w_mul): the accumulator of phase 1 is multiplied with it before bias / activation  */
   float acc_mul2;           /*   = 1 / (a_mul * w2_mul): the same for the products of the second phase (in2 x wt2)                 */
@@ -119,6 +123,9 @@ typedef struct vs_conv_desc {
 #define VS_CONV_PRE 0x80          /* wave-specialised 3x3 kernel (tile codes 15 / 16) only: a_scale is a border-class table [frames][9][N]     */
                                   /*   (frame stride a_scale_ld, 0 = shared): v = act(acc + table[frame][class(y,x)][n] + bias), see vs_msg_pre */
 int vs_conv_gemm(const vs_conv_desc_t* d, void* stream);
+/* fp32 NHWC rows [rows][ld] -> the operand planes of tile codes 22 / 23: [2][C/16][rows][16] f16, hi = f16(x * a_mul), lo = f16(x * a_mul - hi).
+ * C % 16 == 0; `planes` holds 2 * rows * C f16 values. */
+int vs_to_planes(const float* x, int64_t rows, int C, int64_t ld, float a_mul, void* planes, void* stream);
 
 /* LayerNorm over the channel dim of [rows][ld] (+ optional activation).  common.py:131-155 (both data formats). */
 int vs_layernorm_act(const float* x, int64_t rows, int C, int64_t ld, const float* w, const float* b, float eps,

@@ -153,6 +153,31 @@ def test_vs10_every_arithmetic_matches_reference_golden(monkeypatch, mode, name)
     _run_case(s, sd, m, name)
 
 
+def test_bottleneck_planes_chain_is_bit_identical(vs10):
+    """26 frames at the processing size give the all-DMA planes kernel a workgroup per CU, so the engine runs the bottleneck chain on
+    pre-split operand planes (engine.bottleneck_planes); same products, same K order, same scaling as the per-conv path: bit-identical."""
+    spec, sd, model = vs10
+    imgs = synthetic_frames(26, 256, 256, seed=41).cuda()
+    msgs = synthetic_msgs(26, spec.nbits, seed=41)
+    eng = model._engine()
+    if eng.arith != 2:
+        pytest.skip("2 x f16 arithmetic only")
+    used = []
+    orig = eng.bottleneck_planes
+    eng.bottleneck_planes = lambda *a, **k: (used.append(1), orig(*a, **k))[1]
+    try:
+        a = model.embed(imgs, msgs, is_video=False)["imgs_w"].clone()
+        assert used, "the planes chain did not run"
+        eng.planes_chain = False
+        b = model.embed(imgs, msgs, is_video=False)["imgs_w"].clone()
+    finally:
+        eng.planes_chain = True
+        eng.bottleneck_planes = orig
+    assert torch.equal(a, b)
+    ref = R.embed_image(sd, spec, imgs[:2].cpu(), msgs[:2])["imgs_w"]
+    assert (a[:2].cpu() - ref).abs().max() < TOL_IMG
+
+
 def test_submodules_match_golden(vs10):
     """model.embedder(y, msgs) / model.detector(x) / model.attenuation.heatmaps(x) (SURVEY 8(b) method surface)."""
     spec, sd, model = vs10

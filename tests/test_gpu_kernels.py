@@ -61,6 +61,50 @@ def test_patch_pc_split_k(eng, cfg):
     assert (full[..., :4] == 7.0).all() and (full[..., 204:] == 7.0).all()
 
 
+@pytest.mark.parametrize("cfg", [(2, 32, 16, 16, 192, False), (2, 48, 32, 16, 384, True), (3, 64, 16, 48, 200, True), (1, 16, 16, 16, 64, False)])
+def test_conv3x3_planes_kernel(cfg):
+    """all-DMA 3x3 kernel on pre-split operand planes (tile codes 22 / 23, conv3x3_pl.hip): fp32 output bit-identical to the
+    wave-specialised kernel in the same 2 x f16 arithmetic (same products, same K order), planes output == vs_to_planes of it,
+    and both against torch."""
+    B, C, H, W, Co, two = cfg
+    eng = Eng(arith=2)
+    g = torch.Generator().manual_seed(29)
+    x = torch.randn(B, C, H, W, generator=g)
+    x2 = torch.randn(B, C, H, W, generator=g)
+    w1 = torch.randn(Co, C, 3, 3, generator=g) / math.sqrt(C * 9)
+    b1 = torch.randn(Co, generator=g)
+    w2 = torch.randn(Co, C, 1, 1, generator=g) / math.sqrt(C)
+    b2 = torch.randn(Co, generator=g)
+    ref = F.relu(F.conv2d(x, w1, b1, padding=1))
+    if two:
+        ref = ref + F.conv2d(x2, w2, b2)
+    xa, xa2 = to_nhwc(x), to_nhwc(x2)
+    wt1, cp1 = pack_conv(w1.to(DEV), xa.ld)
+    wt2, cp2 = pack_conv(w2.to(DEV), xa2.ld)
+    cw1, cw2 = ConvW(wt1, b1.to(DEV), Co, 3, 3, cp1), ConvW(wt2, b2.to(DEV), Co, 1, 1, cp2)
+    xpl, x2pl = eng.to_planes(xa, "t.xpl"), eng.to_planes(xa2, "t.x2pl")
+    # planes layout [2][C/16][rows][16]: hi + lo == x * 16 up to the f16 split's 2^-24 relative error
+    pl = xpl.view(torch.float16).float().view(2, C // 16, B * H * W, 16).sum(0).permute(1, 0, 2).reshape(B, H, W, C).cpu() / 16.0
+    assert (pl - x.permute(0, 2, 3, 1)).abs().max() < 1e-6
+    outs = []
+    opl = eng.buf("t.opl", B * H * W * rup(Co, 16)).view(torch.int16)
+    for tile in (N.CONV_TILE_HI | 6, N.CONV_TILE_HI | 7, 15):
+        out = eng.new_act(f"t.plo{tile}", B, H, W, Co)
+        out.t.fill_(3.0)
+        kw = dict(in2=xa2, w2=cw2) if two else {}
+        if tile != 15:
+            kw.update(in_pl=xpl, in2_pl=(x2pl if two else None), out_pl=(opl if Co % 16 == 0 else None))
+        eng.conv(xa, cw1, out, pad=1, act=N.ACT_RELU, tile_hint=tile, arith=2, **kw)
+        torch.cuda.synchronize()
+        outs.append(out.t.clone())
+        assert rel_err(from_nhwc(out), ref) < 2e-5
+        if tile != 15 and Co % 16 == 0:
+            want = eng.to_planes(Act(out.t, B, H, W, Co, out.ld), "t.wpl")
+            torch.cuda.synchronize()
+            assert torch.equal(opl[: want.numel()], want)
+    assert torch.equal(outs[0], outs[2]) and torch.equal(outs[1], outs[2])
+
+
 @pytest.mark.parametrize("cx", [16, 1])
 def test_conv3x3_small_two_phase(eng, cx):
     """thin-layer kernel with the fused 1x1 res_conv (unet.py:38-39) + residual at a channel offset; bit-identical to the patch kernel."""

@@ -51,7 +51,57 @@ def run(B, C, H, W, Co, tiles, two_phase, reps=40, ariths=(3,)):
         print(f"B{B} {C}->{Co} {H}x{W} two_phase={two_phase} tile {(t & 15) + (16 if t & 0x40 else 0):2d} abl {t >> 8:x} arith {ar}: {ms:7.3f} ms {flops/ms/1e9:7.1f} TF-eq"
               f"  err vs fp64 max {e64.max().item():.2e} rms {e64.pow(2).mean().sqrt().item():.2e} (|ref|max {ref64.abs().max().item():.2f}){same}", flush=True)
 
+def run_pl(B, C, H, W, Co, two_phase, reps=40, tiles=(0x46, 0x40), bias=True):
+    """all-DMA kernel on pre-split planes (tile 22 = 0x46) against the wave-specialised kernel (tile 16 = 0x40), arith 2: time, bit-identity of
+    the fp32 output, and the planes output against a vs_to_planes of the fp32 output."""
+    eng = Eng(); eng.arith = 2
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(B, H, W, C, generator=g).cuda(); x2 = torch.randn(B, H, W, C, generator=g).cuda()
+    w = (torch.randn(Co, C, 3, 3, generator=g) / math.sqrt(C * 9)).cuda(); w2 = (torch.randn(Co, C, 1, 1, generator=g) / math.sqrt(C)).cuda()
+    b1 = torch.randn(Co, generator=g).cuda() if bias else None; b2 = torch.randn(Co, generator=g).cuda() if bias else None
+    xa, xa2 = Act(x, B, H, W, C, C), Act(x2, B, H, W, C, C)
+    wt, cp = pack_conv(w, C); wt2, cp2 = pack_conv(w2, C)
+    cw, cw2 = ConvW(wt, b1, Co, 3, 3, cp), ConvW(wt2, b2, Co, 1, 1, cp2)
+    out = eng.new_act("o", B, H, W, Co)
+    xpl, x2pl = eng.to_planes(xa, "xpl"), eng.to_planes(xa2, "x2pl")
+    opl = eng.buf("opl", B * H * W * Co).view(torch.int16)
+    flops = 2.0 * B * H * W * Co * C * (10 if two_phase else 9)
+    best, outs = {t: 1e9 for t in tiles}, {}
+    for rnd in range(5):
+        for t in tiles:
+            kw = dict(pad=1, act=N.ACT_RELU, tile_hint=t, arith=2)
+            if two_phase: kw.update(in2=xa2, w2=cw2)
+            if (t & 0x4f) in (0x46, 0x47):
+                kw.update(in_pl=xpl, in2_pl=x2pl if two_phase else None, out_pl=opl)
+            for _ in range(3): eng.conv(xa, cw, out, **kw)
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(reps): eng.conv(xa, cw, out, **kw)
+            e1.record(); torch.cuda.synchronize()
+            best[t] = min(best[t], e0.elapsed_time(e1) / reps)
+            if rnd == 0: outs[t] = out.t.clone()
+    ref = outs[tiles[-1]]
+    for t in tiles:
+        msg = f"B{B} {C}->{Co} {H}x{W} two_phase={two_phase} tile {(t & 15) + (16 if t & 0x40 else 0):2d} abl {t >> 8:x}: {best[t]:7.3f} ms {flops/best[t]/1e9:7.1f} TF-eq"
+        if t != tiles[-1]:
+            msg += f"  bit-identical to tile {(tiles[-1] & 15) + 16}: {bool((outs[t] == ref).all())} maxdiff {(outs[t]-ref).abs().max().item():.2e}"
+        print(msg, flush=True)
+    # planes output of the last tile-22 launch == planes of its fp32 output
+    want = eng.to_planes(Act(outs[tiles[0]], B, H, W, Co, Co), "wpl")
+    torch.cuda.synchronize()
+    print("   out_pl == to_planes(out):", bool((opl[: want.numel()] == want).all()), flush=True)
+
+
 if __name__ == "__main__":
+    if "--pl" in sys.argv:
+        run_pl(2, 32, 16, 16, 192, False, reps=3)
+        run_pl(2, 48, 32, 16, 384, True, reps=3)
+        run_pl(32, 384, 32, 32, 384, False)
+        run_pl(32, 384, 32, 32, 384, True)
+        run_pl(32, 384, 32, 32, 384, False, tiles=(0x46, 0x46 | 0x100, 0x46 | 0x400, 0x46 | 0x500, 0x46 | 0x2000, 0x40))
+        run_pl(32, 128, 32, 32, 384, False)
+        sys.exit(0)
     if "--overhead" in sys.argv:       # fixed cost per launch: K = 9*16 .. 9*384, with / without the output stores
         for C in (16, 64, 128, 384):
             run(32, C, 32, 32, 384, [0x40, 0x40 | 0x2000], False)

@@ -404,6 +404,7 @@ int vs_conv3x3_patch_dispatch(const vs_conv_desc_t& d, int tile, hipStream_t st)
 int vs_conv3x3_patch_pc_dispatch(const vs_conv_desc_t& d, int tile, hipStream_t st);  // conv3x3_patch_pc.hip
 int vs_gemm1x1_pc_dispatch(const vs_conv_desc_t& d, int tile, hipStream_t st);         // gemm1x1_pc.hip
 int vs_conv3x3_small_dispatch(const vs_conv_desc_t& d, hipStream_t st);                // conv3x3_small.hip
+int vs_conv3x3_pl_dispatch(const vs_conv_desc_t& d, int tile, hipStream_t st);          // conv3x3_pl.hip
 namespace {
 
 inline bool fits_u32(int64_t bytes) { return bytes >= 0 && bytes < 0xffffffffLL; }
@@ -418,8 +419,32 @@ inline bool pc_vec_ok(const vs_conv_desc_t& d) {
 
 }  // namespace
 
+// tile codes 22 / 23: every operand as pre-split planes (conv3x3_pl.hip)
+static int conv_planes(const vs_conv_desc_t& d, int tile, hipStream_t st) {
+  auto al16 = [](const void* p) { return ((uintptr_t)p & 15) == 0; };
+  VS_REQUIRE(d.arith == 2 && d.a_mul > 0.f && d.acc_mul > 0.f && d.in_pl && d.wt_blk && (d.out || d.out_pl));
+  VS_REQUIRE(d.B > 0 && d.H > 0 && d.W > 0 && d.N > 0 && d.KH == 3 && d.KW == 3 && d.SH == 1 && d.SW == 1 && d.PH == 1 && d.PW == 1);
+  VS_REQUIRE(d.Ho == d.H && d.Wo == d.W && d.pad_mode == VS_PAD_ZERO && d.CinP >= BK && d.CinP % BK == 0);
+  VS_REQUIRE(al16(d.in_pl) && al16(d.wt_blk) && al16(d.bias) && al16(d.bias2) && d.split_k <= 1 && !d.sumsq_part);
+  if (d.H % 16 || d.W % 16) return VS_ERR_UNSUPPORTED;
+  if (d.in2_pl) VS_REQUIRE(d.wt2_blk && al16(d.in2_pl) && al16(d.wt2_blk) && d.Cin2P >= BK && d.Cin2P % BK == 0 && d.acc_mul2 > 0.f);
+  if (d.out) VS_REQUIRE(al16(d.out) && d.out_ld % 4 == 0 && d.out_coff % 4 == 0 && d.n_store % 4 == 0 && d.n_store >= ((d.N + 3) & ~3) &&
+                        d.out_coff >= 0 && d.out_coff + d.n_store <= d.out_ld);
+  else VS_REQUIRE(d.n_store >= d.N);
+  if (d.out_pl) VS_REQUIRE(al16(d.out_pl) && d.N % 16 == 0);
+  if (d.res) VS_REQUIRE(d.res_ld >= d.N && d.res_ld % 4 == 0 && al16(d.res));
+  if (d.tile_hint & VS_CONV_PRE) VS_REQUIRE(d.a_scale && (d.a_scale_ld == 0 || d.a_scale_ld >= 9 * (int64_t)d.N) && d.a_scale_ld % 4 == 0 && al16(d.a_scale));
+  else VS_REQUIRE(!d.a_scale);
+  return vs_conv3x3_pl_dispatch(d, tile, st);
+}
+
 extern "C" int vs_conv_gemm(const vs_conv_desc_t* dp, void* stream) {
-  VS_REQUIRE(dp && dp->in && dp->wt && dp->out);
+  VS_REQUIRE(dp);
+  {
+    const int t = (dp->tile_hint & 0xf) + ((dp->tile_hint & VS_CONV_TILE_HI) ? 16 : 0);
+    if (t == 22 || t == 23) return conv_planes(*dp, t, (hipStream_t)stream);
+  }
+  VS_REQUIRE(dp->in && dp->wt && dp->out);
   const vs_conv_desc_t& d = *dp;
   VS_REQUIRE(d.B > 0 && d.H > 0 && d.W > 0 && d.Ho > 0 && d.Wo > 0 && d.N > 0 && d.Cin > 0);
   VS_REQUIRE(d.KH > 0 && d.KW > 0 && d.SH > 0 && d.SW > 0 && d.PH >= 0 && d.PW >= 0);

@@ -161,6 +161,7 @@ def padvec(v: torch.Tensor, n: int) -> torch.Tensor:
 class HipEngine:
     """Packed weights + launch sequences for one architecture (ModelCfg) on one device."""
     arith = 2          # arithmetic of the split back-end (vs_conv_desc_t::arith); set per instance from VIDEOSEAL_CONV
+    planes_chain = True
 
     def __init__(self, cfg, sd: Dict[str, torch.Tensor], device: torch.device):
         self.cfg = cfg
@@ -181,6 +182,7 @@ class HipEngine:
         self.upconv_lowres = os.environ.get("VIDEOSEAL_UPCONV", "lowres") != "direct"
         self.upconv_fused = os.environ.get("VIDEOSEAL_UPCONV", "lowres") != "unfused"    # thin levels: GEMM + gather in one kernel
         self.msg_table_conv = os.environ.get("VIDEOSEAL_MSG_TABLE", "1") != "0"         # first bottleneck block: message channels as a table
+        self.planes_chain = os.environ.get("VIDEOSEAL_PLANES", "1") != "0"              # bottleneck chain on pre-split operand planes
         # per-shape tile selection: every candidate walks K in the same order, so the result is bit-identical whatever
         # tile wins -- only speed changes (measure, don't guess).  VIDEOSEAL_AUTOTUNE=0 keeps the static heuristic.
         self.autotune = os.environ.get("VIDEOSEAL_AUTOTUNE", "1") != "0"
@@ -368,7 +370,8 @@ class HipEngine:
              n_store=None, res: Optional[Act] = None, in2: Optional[Act] = None, w2: Optional[ConvW] = None,
              a_scale=None, a_scale_ld=0, a_shift=None, geom=None, tile_hint=0, prof: Optional[str] = None,
              split_k: Optional[int] = None, sumsq: Optional[torch.Tensor] = None, cin: Optional[int] = None, flops: Optional[float] = None,
-             arith: Optional[int] = None):
+             arith: Optional[int] = None, in_pl: Optional[torch.Tensor] = None, in2_pl: Optional[torch.Tensor] = None,
+             out_pl: Optional[torch.Tensor] = None):
         """cin: read only the first `cin` channels of every pixel (pixel stride stays x.ld)"""
         d = N.ConvDesc()
         if geom is None:
@@ -379,7 +382,7 @@ class HipEngine:
         else:           # patch conv: (W', sx, cin, sh, sw, ph, pw)
             W, sx, cin, sh, sw, ph, pw = geom
             H = x.H
-        d.inp = N.ptr(x.t)
+        d.inp = N.ptr(x.t) if x.t is not None else None          # (None: the operand exists as planes only, see in_pl)
         d.in_sb, d.in_sy, d.in_sx = x.H * x.W * x.ld, x.W * x.ld, sx
         d.B, d.H, d.W, d.Cin = x.B, H, W, cin
         d.KH, d.KW, d.SH, d.SW, d.PH, d.PW, d.pad_mode = w.KH, w.KW, sh, sw, ph, pw, pad_mode
@@ -391,9 +394,9 @@ class HipEngine:
         if res is not None:
             d.res, d.res_ld = N.ptr(res.t), res.ld
         if in2 is not None:
-            d.in2, d.in2_ld, d.Cin2, d.Cin2P = N.ptr(in2.t), in2.ld, in2.ld, w2.CinP
+            d.in2, d.in2_ld, d.Cin2, d.Cin2P = (N.ptr(in2.t) if in2.t is not None else None), in2.ld, in2.ld, w2.CinP
             d.wt2, d.bias2 = N.ptr(w2.wt), N.ptr(w2.bias)
-        d.out, d.out_ld, d.out_coff, d.tile_hint = N.ptr(out.t), out.ld, out_coff, tile_hint
+        d.out, d.out_ld, d.out_coff, d.tile_hint = (N.ptr(out.t) if out.t is not None else None), out.ld, out_coff, tile_hint
         if self.use_split and not (tile_hint & N.CONV_FORCE_F32):
             ar = self.arith if arith is None else arith
             d.wt_split = N.ptr(w.with_blk(ar).split)
@@ -403,6 +406,10 @@ class HipEngine:
                 d.wt2_split = N.ptr(w2.with_blk(ar).split)
                 d.wt2_blk = N.ptr(w2.blk)
                 d.acc_mul2 = 1.0 / (A_MUL * w2.w_mul)
+        if in_pl is not None:       # operands as pre-split planes (tile codes 22 / 23, conv3x3_pl.hip)
+            d.in_pl, d.in2_pl, d.out_pl = N.ptr(in_pl), N.ptr(in2_pl), N.ptr(out_pl)
+            if out.t is None:
+                d.n_store = w.N
         if sumsq is not None:       # GRN partial sums of squares from the epilogue ([rows/32][N])
             d.sumsq_part = N.ptr(sumsq)
             split_k = 1
@@ -543,6 +550,14 @@ class HipEngine:
         bn = {1: 128, 2: 64, 3: 32, 4: 192, 5: 96, 13: 64, 14: 128}[tile]
         return bn < 2 * n + 64 or tile == 3     # skip tiles that would be mostly padding
 
+    def to_planes(self, x: Act, tag: str) -> torch.Tensor:
+        """fp32 NHWC activation -> the operand planes of the all-DMA 3x3 kernel: int16 [2][C/16][rows][16] (f16 hi / lo of x * A_MUL)"""
+        if x.C % 16:
+            raise N.NativeError("planes need a channel count that is a multiple of 16")
+        pl = self.buf(tag, x.rows * x.C).view(torch.int16)[: 2 * x.rows * x.C]
+        N.check(self.lib.vs_to_planes(N.ptr(x.t), x.rows, x.C, x.ld, A_MUL, N.ptr(pl), N.stream()), "vs_to_planes")
+        return pl
+
     def layernorm(self, x: Act, w, b, out: Act, act=N.ACT_NONE, eps=1e-6):
         N.check(self.lib.vs_layernorm_act(N.ptr(x.t), x.rows, x.C, x.ld, N.ptr(w), N.ptr(b), eps, act, N.ptr(out.t), out.ld,
                                           N.stream()), "vs_layernorm_act")
@@ -641,6 +656,37 @@ class HipEngine:
                   n_store=(cout if out.ld != rup(cout, 4) else None))
         return out
 
+    def _planes_ok(self, x: Act, blocks) -> bool:
+        """the bottleneck chain on pre-split operand planes (conv3x3_pl.hip): 2 x f16 arithmetic, eval BatchNorm folded, whole
+        16 x 16-pixel tiles, 192-channel column tiles, and enough 256-pixel tiles to give (nearly) every CU a workgroup"""
+        return (self.planes_chain and self.use_split and self.arith == 2 and len(blocks) > 0 and x.ld == x.C and x.C % 192 == 0 and
+                x.H % 16 == 0 and x.W % 16 == 0 and x.B * (x.H // 16) * (x.W // 16) * (x.C // 192) >= 200 and
+                all("bn" not in p and "rms" not in p and p["cout"] == x.C and p["c0"].CinP == x.C and p["res"].CinP == x.C for p in blocks))
+
+    def bottleneck_planes(self, x: Act, blocks, last_out: Optional[Act]) -> Act:
+        """ResnetBlocks `blocks` (unet.py:24-39) from the fp32 activation x, every intermediate tensor as f16 operand planes: the
+        activations are split once by the epilogue that produces them instead of by every consumer, and every conv runs on the all-DMA
+        kernel (tile code 22).  Only the last block writes fp32 (into last_out's columns [0, C) if given)."""
+        B, H, W, C = x.B, x.H, x.W, x.C
+        tile = N.CONV_TILE_HI | 6
+        ghost = Act(None, B, H, W, C, C)                  # geometry only: the tensor exists as planes
+        xpl = self.to_planes(x, "bott.pl0")
+        tpl = self.buf("bott.plt", x.rows * C).view(torch.int16)
+        ypl = self.buf("bott.pl1", x.rows * C).view(torch.int16)
+        out = None
+        for j, p in enumerate(blocks):
+            last = j == len(blocks) - 1
+            self.conv(ghost, p["c0"], ghost, pad=1, act=N.ACT_RELU, tile_hint=tile, in_pl=xpl, out_pl=tpl, prof="bott.conv3x3")
+            if last:
+                out = last_out if last_out is not None else self.new_act("bott.o", B, H, W, C)
+                self.conv(ghost, p["c1"], out, pad=1, act=N.ACT_RELU, in2=ghost, w2=p["res"], tile_hint=tile, in_pl=tpl, in2_pl=xpl,
+                          n_store=(C if out.ld != rup(C, 4) else None))
+            else:
+                self.conv(ghost, p["c1"], ghost, pad=1, act=N.ACT_RELU, in2=ghost, w2=p["res"], tile_hint=tile, in_pl=tpl, in2_pl=xpl,
+                          out_pl=ypl)
+                xpl, ypl = ypl, xpl
+        return out
+
     # ------------------------------------------------------------------ embedder
     def embedder_forward(self, x: Act, msgs_i32: torch.Tensor, bn_train: bool = False) -> torch.Tensor:
         """x: key frames, NHWC(ld 4), already mapped to [-1,1]. Returns delta [B][out_ch][S_h][S_w] (planar).
@@ -697,6 +743,10 @@ class HipEngine:
             if j == 0 and lc is None and self._msg0_ok(h3, E["bott"][0], c.zc[-1]):
                 xcur = self.resblock_msg0(h3, E["bott"][0], "bott0", lat, Bm, c.zc[-1])
                 continue
+            if j >= 1 and not bn_train and self._planes_ok(xcur, E["bott"][j:]):      # the rest of the chain on operand planes
+                lc = lowres_cat(0, xcur)
+                xcur = self.bottleneck_planes(xcur, E["bott"][j:], Act(lc.t, B, lc.H, lc.W, xcur.C, lc.ld) if lc else None)
+                break
             xcur = self.resblock(xcur, E["bott"][j], f"bott{j & 1}", out=(Act(lc.t, B, lc.H, lc.W, xcur.C, lc.ld) if lc else None))
         for k in range(nlev):
             skip = hid.pop()

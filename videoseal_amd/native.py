@@ -22,7 +22,7 @@ VIDEO_MODES = {"repeat": 0, "alternate": 1, "interpolate": 2}
 
 EXPORTS = [
     "vs_version", "vs_arch", "vs_error_string", "vs_sizeof_conv_desc", "vs_sizeof_tail_desc",
-    "vs_model_create", "vs_model_destroy", "vs_model_workspace_bytes", "vs_model_embed", "vs_model_detect", "vs_conv_gemm", "vs_layernorm_act", "vs_rmsnorm_act", "vs_vit_attention", "vs_dwconv7_ln", "vs_grn_scale", "vs_grn_scale_from_partials", "vs_grn_apply",
+    "vs_model_create", "vs_model_destroy", "vs_model_workspace_bytes", "vs_model_embed", "vs_model_detect", "vs_conv_gemm", "vs_to_planes", "vs_layernorm_act", "vs_rmsnorm_act", "vs_vit_attention", "vs_dwconv7_ln", "vs_grn_scale", "vs_grn_scale_from_partials", "vs_grn_apply",
     "vs_upcat2x", "vs_upconv_supported", "vs_upconv_gather_ln", "vs_cat2_scale", "vs_msg_pre", "vs_upconv_fused_supported", "vs_upconv_fused_preferred", "vs_upconv_fused", "vs_im2col3x3", "vs_msg_latent", "vs_broadcast_channels", "vs_outc_tanh", "vs_pool_linear", "vs_resize_pre", "vs_resize_pre_u8",
     "vs_jnd_heatmap", "vs_embed_tail", "vs_aug_color_scratch_floats", "vs_aug_color", "vs_aug_crop_flip", "vs_aug_warp", "vs_resize_nchw",
     "vs_gaussian_blur", "vs_median_filter", "vs_jpeg_workspace_bytes", "vs_jpeg_roundtrip", "vs_h264_proxy_workspace_bytes", "vs_h264_proxy_roundtrip",
@@ -50,7 +50,7 @@ class ConvDesc(C.Structure):
         ("out", C.c_void_p), ("out_ld", C.c_int64), ("out_coff", C.c_int32), ("tile_hint", C.c_int32),
         ("wt_split", C.c_void_p), ("wt2_split", C.c_void_p), ("wt_blk", C.c_void_p), ("wt2_blk", C.c_void_p),
         ("splitk_ws", C.c_void_p), ("splitk_ld", C.c_int64), ("split_k", C.c_int32), ("arith", C.c_int32),
-        ("sumsq_part", C.c_void_p), ("a_mul", C.c_float), ("acc_mul", C.c_float), ("acc_mul2", C.c_float), ("reserved_", C.c_int32),
+        ("sumsq_part", C.c_void_p), ("in_pl", C.c_void_p), ("in2_pl", C.c_void_p), ("out_pl", C.c_void_p), ("a_mul", C.c_float), ("acc_mul", C.c_float), ("acc_mul2", C.c_float), ("reserved_", C.c_int32),
     ]
 
 
@@ -85,6 +85,7 @@ def lib() -> C.CDLL:
     P, I, I64, F = C.c_void_p, C.c_int, C.c_int64, C.c_float
     sig = {
         "vs_conv_gemm": [C.POINTER(ConvDesc), P],
+        "vs_to_planes": [P, I64, I, I64, F, P, P],
         "vs_layernorm_act": [P, I64, I, I64, P, P, F, I, P, I64, P],
         "vs_rmsnorm_act": [P, I64, I, I64, P, I, P, I64, P, I64, P],
         "vs_vit_attention": [P, I, I, I, I, I, I, P, P, P, P],
