@@ -8,6 +8,8 @@ python bench.py --steps 30 --warmup 3 > $O/bench_image.json 2> $O/bench_image.er
 python bench.py --mode video --steps 30 --warmup 3 --no-cpu-baseline > $O/bench_video.json 2> $O/bench_video.err
 python bench.py --mode stream --no-cpu-baseline > $O/bench_stream.json 2> $O/bench_stream.err
 python bench.py --mode chain --steps 30 --warmup 3 --no-cpu-baseline > $O/bench_chain.json 2> $O/bench_chain.err
+python bench.py --capi --steps 30 --warmup 3 --no-cpu-baseline > $O/bench_capi.json 2> $O/bench_capi.err
+python bench.py --detect-only --card chunkyseal --size 1024 --batch 16 --steps 10 --warmup 2 --no-cpu-baseline > $O/bench_chunkyseal.json 2> $O/bench_chunkyseal.err
 cd /tmp
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O -o img -- python $R/bench.py --no-cpu-baseline --no-kernel-timers --steps 10 --warmup 2 > $O/img.log 2>&1
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O -o vid -- python $R/bench.py --mode video --no-cpu-baseline --no-kernel-timers --steps 10 --warmup 2 > $O/vid.log 2>&1

@@ -348,6 +348,55 @@ struct Runner {
     conv(t, p.c1, out, 1, 1, VS_PAD_ZERO, VS_ACT_RELU, 0, out.ld != rup(p.cout, 4) ? p.cout : -1, nullptr, &x, &p.res);
     return out;
   }
+  // one launch of the all-DMA 3x3 kernel on operand planes (tile code 22, conv3x3_pl.hip); out == nullptr: planes only
+  void conv_pl(int B, int H, int W, const CW& w, const void* in_pl, void* out_pl, const Act* out, const CW* w2 = nullptr,
+               const void* in2_pl = nullptr) {
+    vs_conv_desc_t d;
+    std::memset(&d, 0, sizeof(d));
+    d.B = B; d.H = H; d.W = W; d.Cin = w.CinP; d.KH = d.KW = 3; d.SH = d.SW = 1; d.PH = d.PW = 1; d.pad_mode = VS_PAD_ZERO; d.Ho = H; d.Wo = W;
+    d.wt = w.wt; d.CinP = w.CinP; d.N = w.N; d.bias = w.bias; d.act = VS_ACT_RELU;
+    d.wt_split = w.split; d.wt_blk = w.blk; d.arith = 2; d.a_mul = A_MUL; d.acc_mul = 1.f / (A_MUL * w.w_mul);
+    d.in_pl = in_pl; d.out_pl = out_pl;
+    if (w2) {
+      d.in2_pl = in2_pl; d.Cin2 = d.Cin2P = w2->CinP; d.wt2 = w2->wt; d.bias2 = w2->bias; d.wt2_split = w2->split; d.wt2_blk = w2->blk;
+      d.acc_mul2 = 1.f / (A_MUL * w2->w_mul);
+    }
+    d.n_store = w.N;
+    if (out) { d.out = out->p; d.out_ld = out->ld; d.n_store = out->ld != rup(w.N, 4) ? w.N : out->ld; }
+    d.tile_hint = VS_CONV_TILE_HI | 6;
+    if (live()) chk(vs_conv_gemm(&d, st));
+  }
+  // engine.py::bottleneck_planes: ResnetBlocks j0.. from the fp32 activation x with every intermediate tensor as f16 operand planes
+  Act bottleneck_planes(const Act& x, int j0, const Act* last_out) {
+    const int B = x.B, H = x.H, W = x.W, C = x.C;
+    const int64_t pl_floats = x.rows() * C;               // 2 planes x rows x C f16
+    void* xpl = alloc(pl_floats);
+    void* tpl = alloc(pl_floats);
+    void* ypl = alloc(pl_floats);
+    if (live()) chk(vs_to_planes(x.p, x.rows(), C, x.ld, A_MUL, xpl, st));
+    Act out{};
+    const int nb = (int)m->bottleneck.size();
+    for (int j = j0; j < nb; ++j) {
+      const RB& p = m->bottleneck[j];
+      conv_pl(B, H, W, p.c0, xpl, tpl, nullptr);
+      if (j == nb - 1) {
+        out = last_out ? *last_out : act(B, H, W, C);
+        conv_pl(B, H, W, p.c1, tpl, nullptr, &out, &p.res, xpl);
+      } else {
+        conv_pl(B, H, W, p.c1, tpl, ypl, nullptr, &p.res, xpl);
+        std::swap(xpl, ypl);
+      }
+    }
+    return out;
+  }
+  bool planes_ok(const Act& x, int j0) const {            // engine.py::_planes_ok
+    if (m->arith != 2 || x.ld != x.C || x.C % 192 || x.H % 16 || x.W % 16 || (int64_t)x.B * (x.H / 16) * (x.W / 16) * (x.C / 192) < 200) return false;
+    for (size_t j = j0; j < m->bottleneck.size(); ++j) {
+      const RB& p = m->bottleneck[j];
+      if (p.cout != x.C || p.c0.CinP != x.C || p.res.CinP != x.C) return false;
+    }
+    return j0 < (int)m->bottleneck.size();
+  }
   // engine.py::embedder_forward: key frames (NHWC, ld 4, mapped to [-1,1]) -> delta [B][out_ch][S][S]
   float* embedder(const Act& x, const int32_t* msgs, int n_msgs, int& Sh, int& Sw) {
     const vs_model_cfg_t& c = m->c;
@@ -403,6 +452,12 @@ struct Runner {
         conv(t, rb.c1, out, 1, 1, VS_PAD_ZERO, VS_ACT_RELU, 0, -1, nullptr, &h3, &rb.res);
         cur = out;
         continue;
+      }
+      if (j >= 1 && planes_ok(cur, j)) {                 // the rest of the chain on operand planes
+        Act v2 = view;
+        const bool d2 = j == c.num_blocks - 1 ? direct : lowres_cat(0, cur, v2);
+        cur = bottleneck_planes(cur, j, d2 ? &v2 : nullptr);
+        break;
       }
       cur = resblock(cur, rb, direct ? &view : nullptr);
     }
