@@ -94,6 +94,7 @@ typedef struct vs_conv_desc {
                             /* 20: persistent 3x3 kernel for 16-input-channel layers with <= 32 outputs (weights in registers);          */
                             /* 17 = 128x128, 18 = 128x192: wave-specialised 1x1 GEMM (dense rows, Cin % 32 == 0, wt_blk);  */
                             /* 22 = 256x192, 23 = 256x128: all-DMA 3x3 kernel on pre-split planes (arith 2, in_pl, H % 16 == W % 16 == 0);  */
+                            /* 24 = 256x192, 25 = 256x128: all-DMA 1x1 GEMM on pre-split planes (arith 2, in_pl; split_k, sumsq_part, res);  */
                             /* | VS_CONV_TILE_HI: tile code + 16;                                                     */
                             /* | VS_CONV_FORCE_F32: v_mfma_f32_32x32x2_f32 path; | VS_CONV_FORCE_SPLIT */
   const void* wt_split;     /* optional [P][N][Ktot] 16-bit planes (P = 3 bf16 / 2 f16, see arith): wt split into P terms; when set */
@@ -126,6 +127,10 @@ int vs_conv_gemm(const vs_conv_desc_t* d, void* stream);
 /* fp32 NHWC rows [rows][ld] -> the operand planes of tile codes 22 / 23: [2][C/16][rows][16] f16, hi = f16(x * a_mul), lo = f16(x * a_mul - hi).
  * C % 16 == 0; `planes` holds 2 * rows * C f16 values. */
 int vs_to_planes(const float* x, int64_t rows, int C, int64_t ld, float a_mul, void* planes, void* stream);
+/* The same with the GRN apply of common.py:166-169 in front of the split: x[r][c] * scale[r / rows_per_frame][c] + shift[c] (scale == NULL:
+ * plain conversion).  scale / shift must be readable up to C entries per row. */
+int vs_to_planes_affine(const float* x, int64_t rows, int C, int64_t ld, float a_mul, const float* scale, int64_t scale_ld,
+                        const float* shift, int rows_per_frame, void* planes, void* stream);
 
 /* LayerNorm over the channel dim of [rows][ld] (+ optional activation).  common.py:131-155 (both data formats). */
 int vs_layernorm_act(const float* x, int64_t rows, int C, int64_t ld, const float* w, const float* b, float eps,
@@ -151,6 +156,10 @@ int vs_vit_attention(const float* qkv, int frames, int H, int W, int heads, int 
  * wdw is packed [49][C]. */
 int vs_dwconv7_ln(const float* x, int B, int H, int W, int C, int64_t ld, const float* wdw, const float* bdw,
                   const float* lnw, const float* lnb, float eps, float* out, int64_t out_ld, void* stream);
+/* The same with the LayerNorm output written as the operand planes of vs_conv_gemm tile codes 24 / 25 (pwconv1 then reads them by
+ * LDS-DMA): [2][planes_C/16][B*H*W][16] f16, hi / lo of value * a_mul; planes_C >= C is the consumer's padded K (CinP), channels >= C zero. */
+int vs_dwconv7_ln_planes(const float* x, int B, int H, int W, int C, int64_t ld, const float* wdw, const float* bdw,
+                         const float* lnw, const float* lnb, float eps, float a_mul, int planes_C, void* planes, void* stream);
 
 /* GRN statistics: scale[b][c] = 1 + gamma[c] * Gx[b][c] / (mean_c Gx[b][.] + 1e-6), Gx = ||h[b,:,c]||_2.
  * common.py:166-168.  `partial` is workspace of nchunk*B*C floats, nchunk = ceil(HW/64). */

@@ -328,6 +328,69 @@ def test_conv_epilogue_grn_partials(eng, tile):
     assert torch.isnan(guard[part.numel():]).all()          # nothing written past the [M/32][N] partials
 
 
+GEMM_PL_CASES = [
+    # B, H, W, K, N, act, grn, res, tile (24 / 25), split_k, sumsq
+    (2, 16, 16, 96, 384, 2, False, False, 24, 1, True),      # pwconv1-like: GELU + GRN partials
+    (2, 16, 16, 384, 96, 0, True, True, 25, 1, False),       # pwconv2-like: GRN apply in the planes conversion + residual
+    (3, 8, 8, 768, 200, 0, True, True, 24, 1, False),        # ragged M (192 rows) and N
+    (3, 8, 8, 768, 200, 1, True, True, 24, 4, False),        # K split in 4 slices + epilogue kernel
+    (1, 8, 8, 3072, 768, 0, True, True, 24, 8, False),
+    (5, 8, 8, 64, 40, 3, False, False, 25, 2, False),        # two K16 steps per slice, tanh
+    (2, 16, 24, 16, 130, 2, False, True, 24, 1, False),      # a single K step
+    (3, 15, 15, 160, 96, 0, True, True, 25, 1, False),       # 225-row frames (ChunkySeal)
+    (2, 31, 31, 96, 200, 2, False, False, 24, 1, True),      # 1922 rows: ragged last tile with GRN partials
+]
+
+
+@pytest.mark.parametrize("case", GEMM_PL_CASES)
+def test_gemm_planes_kernel(case):
+    """all-DMA 1x1 GEMM on pre-split operand planes (tile codes 24 / 25, gemm_pl.hip) against torch, and bit-identical to the generic
+    kernel in the same 2 x f16 arithmetic when K is not split (same products, same K order).  The GRN apply runs in the planes
+    conversion (vs_to_planes_affine) instead of on the A load."""
+    B, H, W, K, Nn, act, grn, res, tile, sk, sumsq = case
+    eng = Eng(arith=2)
+    g = torch.Generator().manual_seed(31)
+    HW = H * W
+    x = torch.randn(B, HW, K, generator=g)
+    w = torch.randn(Nn, K, generator=g) / math.sqrt(K)
+    bias = torch.randn(Nn, generator=g)
+    scale = 1 + 0.5 * torch.randn(B, K, generator=g)
+    shift = torch.randn(K, generator=g)
+    r = torch.randn(B, HW, Nn, generator=g)
+    a = x * scale[:, None, :] + shift if grn else x
+    ref = F.linear(a, w, bias)
+    ref = {0: ref, 1: F.relu(ref), 2: F.gelu(ref), 3: torch.tanh(ref)}[act]
+    if res:
+        ref = ref + r
+    xa = Act(x.to(DEV).contiguous(), B, H, W, K, K)
+    wt, cp = pack_conv(w[:, :, None, None].to(DEV), K)
+    cw = ConvW(wt, bias.to(DEV), Nn, 1, 1, cp)
+    ra = Act(r.to(DEV).contiguous(), B, H, W, Nn, Nn)
+    pl = eng.buf("t.gpl", B * HW * K).view(torch.int16)
+    N.check(eng.lib.vs_to_planes_affine(N.ptr(xa.t), xa.rows, K, xa.ld, 16.0, N.ptr(dv(scale)) if grn else None, K,
+                                        N.ptr(dv(shift)) if grn else None, HW, N.ptr(pl), N.stream()), "to_planes_affine")
+    outs = []
+    for t in (N.CONV_TILE_HI | (tile - 16), 1):
+        out = eng.new_act(f"t.gplo{t}", B, H, W, Nn)
+        out.t.fill_(5.0)
+        part = torch.full((((B * HW + 31) // 32) * Nn,), float("nan"), device=DEV) if sumsq else None
+        kw = dict(act=act, res=(ra if res else None), tile_hint=t, arith=2)
+        if t != 1:
+            kw.update(in_pl=pl, split_k=sk, sumsq=part)
+        else:
+            kw.update(a_scale=(dv(scale) if grn else None), a_scale_ld=K, a_shift=(dv(shift) if grn else None), sumsq=part)
+        eng.conv(xa, cw, out, **kw)
+        torch.cuda.synchronize()
+        got = out.t.view(B, HW, out.ld)
+        assert rel_err(got[..., :Nn].cpu(), ref) < 2e-5
+        assert (got[..., Nn:] == 0).all()
+        outs.append((out.t.clone(), part))
+    if sk == 1:
+        assert torch.equal(outs[0][0], outs[1][0])
+        if sumsq:
+            assert torch.equal(outs[0][1], outs[1][1])
+
+
 GEMM_PC_CASES = [
     # B, H, W, K, N, act, grn, res, tile, split_k
     (2, 16, 16, 96, 384, 2, False, False, 1, 1),      # pwconv1-like: GELU epilogue
@@ -453,6 +516,17 @@ def test_dwconv7_ln(eng, C_, H, W):
                                   N.ptr(out.t), out.ld, N.stream()), "dw")
     torch.cuda.synchronize()
     assert (from_nhwc(out) - ref).abs().max() < 3e-5
+    # planes output (the operand of the all-DMA pwconv1 GEMM) == vs_to_planes of the fp32 output, padded to the consumer's K
+    Cp = rup(C_, 32)
+    pl = torch.full((2 * B * H * W * Cp,), 77, dtype=torch.int16, device=DEV)
+    N.check(eng.lib.vs_dwconv7_ln_planes(N.ptr(xa.t), B, H, W, C_, ld, N.ptr(dv(wp)), N.ptr(pad(bd)), N.ptr(pad(lw)), N.ptr(pad(lb)), 1e-6,
+                                         16.0, Cp, N.ptr(pl), N.stream()), "dw planes")
+    wide = torch.zeros(B * H * W, Cp, device=DEV)
+    wide[:, :C_] = out.t.view(B * H * W, out.ld)[:, :C_]
+    want = torch.empty_like(pl)
+    N.check(eng.lib.vs_to_planes(N.ptr(wide), B * H * W, Cp, Cp, 16.0, N.ptr(want), N.stream()), "to_planes")
+    torch.cuda.synchronize()
+    assert torch.equal(pl, want)
 
 
 @pytest.mark.parametrize("C_,HW", [(384, 4096), (100, 37), (1448, 225)])

@@ -24,6 +24,8 @@
 //     group hit 16 distinct 4-bank slots;
 //   * epilogue in registers: bias, ReLU/GELU/tanh, optional second K phase (the ResnetBlock's 1x1 res_conv on the
 //     block input accumulated on top of relu(bn(conv))), optional residual, coalesced 128-byte row stores.
+#include <algorithm>
+
 #include "conv_common.h"
 
 namespace {
@@ -405,6 +407,7 @@ int vs_conv3x3_patch_pc_dispatch(const vs_conv_desc_t& d, int tile, hipStream_t 
 int vs_gemm1x1_pc_dispatch(const vs_conv_desc_t& d, int tile, hipStream_t st);         // gemm1x1_pc.hip
 int vs_conv3x3_small_dispatch(const vs_conv_desc_t& d, hipStream_t st);                // conv3x3_small.hip
 int vs_conv3x3_pl_dispatch(const vs_conv_desc_t& d, int tile, hipStream_t st);          // conv3x3_pl.hip
+int vs_gemm_pl_dispatch(const vs_conv_desc_t& d, int tile, hipStream_t st);             // gemm_pl.hip
 namespace {
 
 inline bool fits_u32(int64_t bytes) { return bytes >= 0 && bytes < 0xffffffffLL; }
@@ -427,6 +430,7 @@ static int conv_planes(const vs_conv_desc_t& d, int tile, hipStream_t st) {
   VS_REQUIRE(d.Ho == d.H && d.Wo == d.W && d.pad_mode == VS_PAD_ZERO && d.CinP >= BK && d.CinP % BK == 0);
   VS_REQUIRE(al16(d.in_pl) && al16(d.wt_blk) && al16(d.bias) && al16(d.bias2) && d.split_k <= 1 && !d.sumsq_part);
   if (d.H % 16 || d.W % 16) return VS_ERR_UNSUPPORTED;
+  if (2 * (int64_t)d.B * d.H * d.W * std::max(d.CinP, d.in2_pl ? d.Cin2P : 0) * 2 >= 0xffffffffLL) return VS_ERR_UNSUPPORTED;   // 32-bit DMA offsets
   if (d.in2_pl) VS_REQUIRE(d.wt2_blk && al16(d.in2_pl) && al16(d.wt2_blk) && d.Cin2P >= BK && d.Cin2P % BK == 0 && d.acc_mul2 > 0.f);
   if (d.out) VS_REQUIRE(al16(d.out) && d.out_ld % 4 == 0 && d.out_coff % 4 == 0 && d.n_store % 4 == 0 && d.n_store >= ((d.N + 3) & ~3) &&
                         d.out_coff >= 0 && d.out_coff + d.n_store <= d.out_ld);
@@ -438,11 +442,27 @@ static int conv_planes(const vs_conv_desc_t& d, int tile, hipStream_t st) {
   return vs_conv3x3_pl_dispatch(d, tile, st);
 }
 
+// tile codes 24 / 25: 1x1 GEMM with the activations as pre-split planes (gemm_pl.hip)
+static int gemm_planes(const vs_conv_desc_t& d, int tile, hipStream_t st) {
+  auto al16 = [](const void* p) { return ((uintptr_t)p & 15) == 0; };
+  VS_REQUIRE(d.arith == 2 && d.a_mul > 0.f && d.acc_mul > 0.f && d.in_pl && d.wt_blk && d.out && !d.in2 && !d.in2_pl && !d.out_pl && !d.a_scale);
+  VS_REQUIRE(d.B > 0 && d.H > 0 && d.W > 0 && d.N > 0 && d.KH == 1 && d.KW == 1 && d.SH == 1 && d.SW == 1 && d.PH == 0 && d.PW == 0);
+  VS_REQUIRE(d.Ho == d.H && d.Wo == d.W && d.CinP >= BK && d.CinP % BK == 0 && al16(d.in_pl) && al16(d.wt_blk));
+  VS_REQUIRE(d.n_store >= d.N && d.out_coff >= 0 && d.out_coff + d.n_store <= d.out_ld);
+  if (d.res) VS_REQUIRE(d.res_ld >= d.N);
+  if (d.sumsq_part) VS_REQUIRE(d.split_k <= 1 && !d.res);
+  if (d.split_k > 1) VS_REQUIRE(d.splitk_ws && d.splitk_ld >= d.N && d.split_k <= d.CinP / BK);
+  const int64_t M = (int64_t)d.B * d.H * d.W;
+  if (2 * M * d.CinP * 2 >= 0xffffffffLL) return VS_ERR_UNSUPPORTED;          // 32-bit DMA offsets
+  return vs_gemm_pl_dispatch(d, tile, st);
+}
+
 extern "C" int vs_conv_gemm(const vs_conv_desc_t* dp, void* stream) {
   VS_REQUIRE(dp);
   {
     const int t = (dp->tile_hint & 0xf) + ((dp->tile_hint & VS_CONV_TILE_HI) ? 16 : 0);
     if (t == 22 || t == 23) return conv_planes(*dp, t, (hipStream_t)stream);
+    if (t == 24 || t == 25) return gemm_planes(*dp, t, (hipStream_t)stream);
   }
   VS_REQUIRE(dp->in && dp->wt && dp->out);
   const vs_conv_desc_t& d = *dp;

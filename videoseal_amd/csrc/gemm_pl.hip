@@ -1,0 +1,346 @@
+// 1x1 convolution / linear layer on PRE-SPLIT operand planes (arith 2, "2 x f16"): the ConvNeXt pwconv1 / pwconv2 GEMMs of the
+// extractor (convnext.py:47-51) and ChunkySeal's wide layers, in the structure of conv3x3_pl.hip:
+//   out[m][n] = epilogue( sum_k A[m][k] * W[n][k] ),   A as two f16 planes [plane][K/16][M][16] of value * a_mul (vs_to_planes), W as the
+//   blocked f16 image of engine.pack_blocked -- every operand moves global -> LDS by LDS-DMA, all EIGHT waves multiply (4 x 2 waves of
+//   64 rows x 32*TN columns on a 256-row x 64*TN-column tile), waves 0-3 issue the weight DMAs (TN per K16 step), waves 4-7 the
+//   activation DMAs (four 1 KiB pieces per step: a 256-row x 16-k chunk is 8 KiB of contiguous memory per plane).
+// Rings: five 16 KiB A stages (two steps ahead of the reads stay in flight), six weight stages (three tiles in flight).  Fragment
+// registers as in conv3x3_pl.hip (hi fragments double-buffered, lo fragments re-read in place).  Same products and K order as
+// conv_gemm_kernel / gemm1x1_pc_kernel in the 2 x f16 arithmetic: bit-identical to them when K is not split.
+// Epilogue as gemm1x1_pc_kernel: bias, activation, residual, GRN sum-of-squares partials (common.py:166), or raw K-slice partial sums
+// for the shared split-K epilogue (small-M layers).
+#include <type_traits>
+
+#include "conv_common.h"
+
+int vs_splitk_epilogue(const vs_conv_desc_t& d, int M, hipStream_t st);   // gemm1x1_pc.hip
+
+namespace {
+
+using namespace vsconv;
+
+constexpr int GBM = 256;                       // rows per tile
+constexpr int A_STAGE = GBM * 2 * 2 * 16;      // 256 rows x 2 halves x 2 planes x 16 bytes
+constexpr int NRA = 5, NRB = 6;
+
+__device__ __forceinline__ void gdma16(const char* gp, unsigned char* lds_base) {      // lane l: 16 bytes at gp -> lds_base + 16 * l
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gp, (__attribute__((address_space(3))) void*)lds_base,
+                                   16, 0, 0);
+}
+// a wave-uniform pointer the compiler has lost track of (loop-carried through uniform branches): back into SGPRs, so that the DMA uses the
+// scalar-base + 32-bit-VGPR-offset form instead of 64-bit per-lane addresses
+__device__ __forceinline__ const char* uniform_ptr(const char* p) {
+  const unsigned long long v = reinterpret_cast<unsigned long long>(p);
+  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+  return reinterpret_cast<const char*>(((unsigned long long)hi << 32) | lo);
+}
+template <int N>
+__device__ __forceinline__ void gwait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+template <int TN>
+__global__ __launch_bounds__(512, 2) void gemm_pl_kernel(const vs_conv_desc_t d, const int M, const int mtiles, const int ntiles, const int sps) {
+  using AR = Arith<2>;
+  constexpr int TM = 2;
+  constexpr int BN = 2 * TN * 32;
+  constexpr int NG = BN / 32;
+  constexpr int WBLK = 2048;                  // one (32 rows x 16 k) weight block, both planes
+  constexpr int B_STAGE = NG * WBLK;
+  __shared__ __attribute__((aligned(16))) unsigned char smem[NRA * A_STAGE + NRB * B_STAGE];
+  unsigned char* const Bring = smem + NRA * A_STAGE;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r = lane & 31, g = lane >> 5;
+
+  const int bm = blockIdx.x % mtiles;
+  const int bn = (blockIdx.x / mtiles) % ntiles;
+  const int ks = blockIdx.x / (mtiles * ntiles);        // K slice (split_k > 1)
+  const int m0 = bm * GBM;
+  const int n0 = bn * BN;
+  const int nsteps_all = d.CinP / BK;
+  const int step0 = ks * sps;
+  const int nsteps = min(sps, nsteps_all - step0);      // K16 steps of this workgroup
+
+  // ------------------------------------------------------------------ DMA issue: per-lane 32-bit offsets, wave-uniform bases
+  const int64_t cstride = (int64_t)M * 32;              // bytes between 16-channel chunks of a plane
+  const int pw = wave & 3;
+  unsigned doff[4];
+  int wdst[TN];
+  // (bases and ring stages are recomputed from the step index: loop-carried pointers / counters updated inside the wave-role branches
+  // ended up in VGPRs -- and from there in scratch, whose re-loads are VGPR-destination loads: vmcnt(0) in the K loop)
+  const char* const wbase = reinterpret_cast<const char*>(d.wt_blk) + (int64_t)step0 * WBLK;
+  const char* const abase = reinterpret_cast<const char*>(d.in_pl) + (int64_t)step0 * cstride;
+  if (wave < 4) {
+    const int g0 = n0 / 32, ngroups = (d.N + 31) / 32;
+#pragma unroll
+    for (int jj = 0; jj < TN; ++jj) {
+      const int idx = pw * TN + jj;
+      const int p = idx / NG, gi = idx - p * NG;
+      const int gs = (g0 + gi) < ngroups ? g0 + gi : ngroups - 1;       // tile wider than N: re-read a valid group (columns discarded)
+      doff[jj] = (unsigned)(gs * nsteps_all) * WBLK + p * 1024 + lane * 16;
+      wdst[jj] = __builtin_amdgcn_readfirstlane(p * (BN * 32) + gi * 1024);
+    }
+  } else {
+    const unsigned pstride = (unsigned)(nsteps_all * cstride);          // bytes between the two planes (< 4 GiB: checked by the launcher)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {             // unit U = 64 (pw + 4j) + lane of [plane][256 rows][2 halves]
+      const int U = (pw + 4 * j) * 64 + lane;
+      const int plane = U >> 9;
+      const int u = U & 511;
+      const int p = u >> 1;
+      const int hs = (u & 1) ^ ((p >> 3) & 1);
+      const int m = min(m0 + p, M - 1);       // ragged last tile: re-read a valid row (masked in the epilogue)
+      doff[j] = plane * pstride + (unsigned)m * 32u + hs * 16;
+    }
+#pragma unroll
+    for (int jj = 0; jj < TN; ++jj) wdst[jj] = 0;
+  }
+  auto dma_w = [&](const int t) __attribute__((always_inline)) {          // weight tile of step t
+    unsigned char* st = Bring + (t % NRB) * B_STAGE;
+    const char* wb = wbase + (int64_t)t * WBLK;
+#pragma unroll
+    for (int jj = 0; jj < TN; ++jj) gdma16(wb + doff[jj], st + wdst[jj]);
+  };
+  auto dma_a = [&](const int t) __attribute__((always_inline)) {          // activation chunk of step t
+    unsigned char* st = smem + (t % NRA) * A_STAGE + pw * 1024;
+    const char* ab = abase + t * cstride;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) gdma16(ab + doff[j], st + j * 4096);
+  };
+
+  // ------------------------------------------------------------------ consumers: 4 (rows) x 2 (columns) waves
+  const int wm = wave >> 1, wn = wave & 1;
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+  int a_frag[TM];
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+    const int p = (wm * TM + i) * 32 + r;
+    a_frag[i] = (2 * p + (g ^ ((p >> 3) & 1))) * 16;
+  }
+  const int b_frag = (wn * TN) * 1024 + (2 * r + (g ^ ((r >> 3) & 1))) * 16;   // pack_blocked's bank swizzle
+
+  struct Hi { bf16x8 a[TM]; bf16x8 b[TN]; };
+  Hi H0, H1;
+  bf16x8 lo_a[TM], lo_b[TN];
+  auto b_ptr = [&](const int s) __attribute__((always_inline)) -> const unsigned char* { return Bring + (s % NRB) * B_STAGE + b_frag; };
+  auto a_ptr = [&](const int s) __attribute__((always_inline)) -> const unsigned char* { return smem + (s % NRA) * A_STAGE; };
+  auto load_hi = [&](Hi& H, const int s) __attribute__((always_inline)) {
+    const unsigned char* Bb = b_ptr(s);
+#pragma unroll
+    for (int j = 0; j < TN; ++j) H.b[j] = *reinterpret_cast<const bf16x8*>(Bb + j * 1024);
+    const unsigned char* Ab = a_ptr(s);
+#pragma unroll
+    for (int i = 0; i < TM; ++i) H.a[i] = *reinterpret_cast<const bf16x8*>(Ab + a_frag[i]);
+  };
+  auto load_alo = [&](const int s) __attribute__((always_inline)) {
+    const unsigned char* Ab = a_ptr(s) + 512 * 16;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) lo_a[i] = *reinterpret_cast<const bf16x8*>(Ab + a_frag[i]);
+  };
+  auto load_blo = [&](const int s) __attribute__((always_inline)) {
+    const unsigned char* Bb = b_ptr(s) + BN * 32;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) lo_b[j] = *reinterpret_cast<const bf16x8*>(Bb + j * 1024);
+  };
+  // accumulator = C[row][column] (activations first): column = lane & 31, row = (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5)
+  auto mfma_q0 = [&](const Hi& H) __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j) acc[i][j] = AR::mfma(lo_a[i], H.b[j], acc[i][j]);
+  };
+  auto mfma_q1 = [&](const Hi& H) __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j) acc[i][j] = AR::mfma(H.a[i], lo_b[j], acc[i][j]);
+  };
+  auto mfma_q2 = [&](const Hi& H) __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j) acc[i][j] = AR::mfma(H.a[i], H.b[j], acc[i][j]);
+  };
+  // Weights: tile t issued at step t - (NRB-1); at the end of step s everything up to tile s + 2 has landed: NRB - 3 tiles stay in flight.
+  // Activations: chunk t issued at step t - (NRA-1) into the stage chunk t - NRA left two barriers ago; at the end of step s chunk
+  // s + 2 has landed: NRA - 3 chunks (4 instructions each) stay in flight.
+  auto issue = [&](const int s) __attribute__((always_inline)) {
+    if (wave < 4) {
+      if (s + NRB - 1 < nsteps) dma_w(s + NRB - 1);
+    } else if (s + NRA - 1 < nsteps) {
+      dma_a(s + NRA - 1);
+    }
+  };
+  auto finish = [&](const int s) __attribute__((always_inline)) {
+    if (wave < 4) {
+      if (s + NRB - 1 < nsteps) gwait_vm<(NRB - 3) * TN>();
+      else gwait_vm<0>();
+    } else {
+      if (s + NRA - 1 < nsteps) gwait_vm<(NRA - 3) * 4>();
+      else gwait_vm<0>();
+    }
+    __builtin_amdgcn_s_waitcnt(0xC07F);       // lgkmcnt(0) (the builtin: hipcc's waitcnt bookkeeping must see it, see conv3x3_pl.hip)
+    __builtin_amdgcn_s_barrier();
+  };
+
+  if (wave < 4) {
+    for (int t = 0; t < NRB - 1 && t < nsteps; ++t) dma_w(t);
+  } else {
+    for (int t = 0; t < NRA - 1 && t < nsteps; ++t) dma_a(t);
+  }
+  gwait_vm<0>();
+  __builtin_amdgcn_s_barrier();
+
+  int s = 0;
+  load_hi(H0, 0);
+  load_alo(0);
+  load_blo(0);
+  __builtin_amdgcn_s_waitcnt(0xC07F);
+  auto step = [&](const Hi& Hc, Hi& Hn, const int s, auto more) __attribute__((always_inline)) {
+    constexpr bool MORE = decltype(more)::value;
+    mfma_q0(Hc);                              // (first: the DMA issue and the next fragments' addresses run in its shadow)
+    __builtin_amdgcn_sched_barrier(0);
+    issue(s);
+    if constexpr (MORE) {
+      load_hi(Hn, s + 1);
+      load_alo(s + 1);
+    }
+    mfma_q1(Hc);
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (MORE) load_blo(s + 1);
+    mfma_q2(Hc);
+    finish(s);
+  };
+  for (; s + 2 < nsteps; s += 2) {
+    step(H0, H1, s, std::true_type{});
+    step(H1, H0, s + 1, std::true_type{});
+  }
+  if (s + 1 < nsteps) {
+    step(H0, H1, s, std::true_type{});
+    step(H1, H0, s + 1, std::false_type{});
+  } else {
+    step(H0, H1, s, std::false_type{});
+  }
+
+  // ---- epilogue (as gemm1x1_pc_kernel)
+  scale_all<TM, TN>(acc, d.acc_mul);          // back to real units (exact: a power of two), also for the K-slice partial sums
+  int lane_e = lane;
+  asm volatile("" : "+v"(lane_e));            // (nothing of the epilogue's addressing stays alive across the K loop)
+  const int r_e = lane_e & 31, g_e = lane_e >> 5;
+  int col[TN];
+#pragma unroll
+  for (int j = 0; j < TN; ++j) col[j] = n0 + (wn * TN + j) * 32 + r_e;
+  if (d.split_k > 1) {
+    float* ws = d.splitk_ws + (int64_t)ks * M * d.splitk_ld;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int m = m0 + (wm * TM + i) * 32 + (e & 3) + 8 * (e >> 2) + 4 * g_e;
+        if (m >= M) continue;
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          if (col[j] < d.N) ws[(int64_t)m * d.splitk_ld + col[j]] = acc[i][j][e];
+      }
+    return;
+  }
+  float bias1[TN], zero[TN];
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    bias1[j] = (col[j] < d.N && d.bias) ? d.bias[col[j]] : 0.f;
+    zero[j] = 0.f;
+  }
+  apply_act_all<TM, TN>(acc, bias1, zero, d.act);
+  if (d.sumsq_part) write_sumsq<TM, TN>(acc, d.sumsq_part, d.N, (int64_t)m0 + (int64_t)wm * TM * 32, M, col, g_e);
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int64_t m = (int64_t)m0 + (wm * TM + i) * 32 + (e & 3) + 8 * (e >> 2) + 4 * g_e;
+      if (m >= M) continue;
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const int n = col[j];
+        if (n >= d.n_store) continue;
+        float v = 0.f;                        // columns in [N, n_store) are padding lanes: always zero
+        if (n < d.N) {
+          v = acc[i][j][e];
+          if (d.res) v += d.res[m * d.res_ld + n];
+        }
+        d.out[m * d.out_ld + d.out_coff + n] = v;
+      }
+    }
+  }
+}
+
+// fp32 rows [rows][ld] (optionally x * scale[frame][c] + shift[c]: GRN apply, common.py:166-169) -> operand planes [2][C/16][rows][16]
+__global__ __launch_bounds__(256) void to_planes_affine_kernel(const float* __restrict__ x, const int64_t rows, const int C, const int64_t ld,
+                                                               const float a_mul, const float* __restrict__ scale, const int64_t scale_ld,
+                                                               const float* __restrict__ shift, const int rows_per_frame,
+                                                               char* __restrict__ pl) {
+  // thread = (row, 16-channel chunk pair member): idx -> (row, c8) with c8 fastest so that a wave reads 2 KiB of contiguous row memory
+  const int c8n = C / 8;
+  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= rows * c8n) return;
+  const int64_t row = idx / c8n;
+  const int c8 = (int)(idx - row * c8n);
+  const float* src = x + row * ld + c8 * 8;
+  f32x4 a = *reinterpret_cast<const f32x4*>(src), b = *reinterpret_cast<const f32x4*>(src + 4);
+  if (scale) {
+    const float* sp = scale + (row / rows_per_frame) * scale_ld + c8 * 8;
+    const float* hp = shift + c8 * 8;
+    a = a * *reinterpret_cast<const f32x4*>(sp) + *reinterpret_cast<const f32x4*>(hp);
+    b = b * *reinterpret_cast<const f32x4*>(sp + 4) + *reinterpret_cast<const f32x4*>(hp + 4);
+  }
+  u32x2 ah, al, bh, bl;
+  split4h(a, a_mul, ah, al);
+  split4h(b, a_mul, bh, bl);
+  char* dst = pl + ((int64_t)(c8 >> 1) * rows + row) * 32 + (c8 & 1) * 16;
+  *reinterpret_cast<u32x4*>(dst) = u32x4{ah[0], ah[1], bh[0], bh[1]};
+  *reinterpret_cast<u32x4*>(dst + (int64_t)(C / 16) * rows * 32) = u32x4{al[0], al[1], bl[0], bl[1]};
+}
+
+template <int TN>
+int launch_gpl(const vs_conv_desc_t& d, hipStream_t st) {
+  constexpr int BN = 2 * TN * 32;
+  const int64_t M = (int64_t)d.B * d.H * d.W;
+  const int sk = d.split_k > 1 ? d.split_k : 1;
+  const int64_t mt = cdiv64(M, GBM), nt = cdiv64(sk > 1 ? d.N : d.n_store, BN);
+  const int nsteps = d.CinP / BK;
+  const int sps = (nsteps + sk - 1) / sk;
+  if (sk > 1 && (int64_t)(sk - 1) * sps >= nsteps) return VS_ERR_BAD_ARG;       // an empty K slice
+  if (mt * nt * sk > 0x7fffffffLL || M > 0x7fffffffLL) return VS_ERR_UNSUPPORTED;
+  hipLaunchKernelGGL((gemm_pl_kernel<TN>), dim3((unsigned)(mt * nt * sk)), dim3(512), 0, st, d, (int)M, (int)mt, (int)nt, sps);
+  int rc = vs_launch_status();
+  if (rc != VS_OK || sk == 1) return rc;
+  return vs_splitk_epilogue(d, (int)M, st);
+}
+
+}  // namespace
+
+// tile 24 = 256 rows x 192 columns, tile 25 = 256 rows x 128 columns.  Preconditions are checked by vs_conv_gemm.
+int vs_gemm_pl_dispatch(const vs_conv_desc_t& d, int tile, hipStream_t st) {
+  switch (tile) {
+    case 24: return launch_gpl<3>(d, st);
+    case 25: return launch_gpl<2>(d, st);
+    default: return VS_ERR_UNSUPPORTED;
+  }
+}
+
+extern "C" int vs_to_planes_affine(const float* x, int64_t rows, int C, int64_t ld, float a_mul, const float* scale, int64_t scale_ld,
+                                   const float* shift, int rows_per_frame, void* planes, void* stream) {
+  VS_REQUIRE(x && planes && rows > 0 && C > 0 && C % 16 == 0 && ld >= C && ld % 4 == 0 && a_mul > 0.f);
+  VS_REQUIRE(((uintptr_t)x & 15) == 0 && ((uintptr_t)planes & 15) == 0);
+  if (scale) VS_REQUIRE(shift && rows_per_frame > 0 && scale_ld % 4 == 0 && ((uintptr_t)scale & 15) == 0 && ((uintptr_t)shift & 15) == 0);
+  const int64_t items = rows * (C / 8);
+  hipLaunchKernelGGL(to_planes_affine_kernel, dim3((unsigned)cdiv64(items, 256)), dim3(256), 0, (hipStream_t)stream, x, rows, C, ld, a_mul,
+                     scale, scale_ld, shift, rows_per_frame, static_cast<char*>(planes));
+  return vs_launch_status();
+}

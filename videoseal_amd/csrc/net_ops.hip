@@ -5,7 +5,7 @@
 #include <algorithm>
 #include <cstdlib>
 
-#include "vs_common.h"
+#include "conv_common.h"
 
 namespace {
 
@@ -85,11 +85,15 @@ __global__ __launch_bounds__(256) void layernorm_act_small_kernel(const float* _
 // 16-byte reads).  Four adjacent lanes share a pixel (interleaved float4 columns) and combine with two quad shuffles: a wave
 // normalises 16 pixels at a time instead of one pixel per wave with two 6-step butterflies (which left the one-row kernel
 // latency-bound: 2 x 6 dependent cross-lane steps per pixel, one pixel in flight per wave).
+// Planes output (pl.cstride != 0): the rows go out as the f16 operand planes of the all-DMA GEMM (gemm_pl.hip) instead of fp32 --
+// [plane][c / 16][row][16] of value * a_mul; rowptr then returns planes + row * 32 bytes (out_ld = 8 floats) and the channel range is
+// padded with zeros to a multiple of 16.
+struct PlanesOut { int64_t cstride, pstride; float a_mul; int Cp; };      // bytes between 16-channel chunks / between the two planes; channels incl. padding
 template <int NT, int LPP, typename RowPtr>
 __device__ __forceinline__ void ln_rows_from_lds_impl(const float* __restrict__ s, int stride, int npx, int C, const float* __restrict__ lnw,
-                                                      const float* __restrict__ lnb, float eps, int out_ld, RowPtr rowptr) {
+                                                      const float* __restrict__ lnb, float eps, int out_ld, RowPtr rowptr, const PlanesOut pl) {
   const int q = threadIdx.x & (LPP - 1);
-  const int C4 = (C + 3) >> 2, O4 = out_ld >> 2;
+  const int C4 = (C + 3) >> 2, O4 = pl.cstride ? pl.Cp >> 2 : out_ld >> 2;
   const float invC = 1.0f / (float)C;
   for (int p = threadIdx.x / LPP; p < npx; p += NT / LPP) {
     float* orow = rowptr(p);
@@ -123,7 +127,15 @@ __device__ __forceinline__ void ln_rows_from_lds_impl(const float* __restrict__ 
         for (int e = 0; e < 4; ++e)
           if (4 * c4 + e < C) o[e] = lnw[4 * c4 + e] * ((v[e] - mean) * rden) + lnb[4 * c4 + e];
       }
-      *reinterpret_cast<f32x4*>(orow + 4 * c4) = o;
+      if (pl.cstride) {
+        vsconv::u32x2 hi, lo;
+        vsconv::split4h(o, pl.a_mul, hi, lo);
+        char* dst = reinterpret_cast<char*>(orow) + (int64_t)(c4 >> 2) * pl.cstride + (c4 & 3) * 8;
+        *reinterpret_cast<vsconv::u32x2*>(dst) = hi;
+        *reinterpret_cast<vsconv::u32x2*>(dst + pl.pstride) = lo;
+      } else {
+        *reinterpret_cast<f32x4*>(orow + 4 * c4) = o;
+      }
     }
   }
 }
@@ -131,12 +143,13 @@ __device__ __forceinline__ void ln_rows_from_lds_impl(const float* __restrict__ 
 // handful of pixels of many channels: up to a wave per pixel)
 template <int NT, typename RowPtr>
 __device__ __forceinline__ void ln_rows_from_lds(const float* __restrict__ s, int stride, int npx, int C, const float* __restrict__ lnw,
-                                                 const float* __restrict__ lnb, float eps, int out_ld, RowPtr rowptr) {
-  if (npx * 8 > NT) ln_rows_from_lds_impl<NT, 4>(s, stride, npx, C, lnw, lnb, eps, out_ld, rowptr);
-  else if (npx * 16 > NT) ln_rows_from_lds_impl<NT, 8>(s, stride, npx, C, lnw, lnb, eps, out_ld, rowptr);
-  else if (npx * 32 > NT) ln_rows_from_lds_impl<NT, 16>(s, stride, npx, C, lnw, lnb, eps, out_ld, rowptr);
-  else if (npx * 64 > NT) ln_rows_from_lds_impl<NT, 32>(s, stride, npx, C, lnw, lnb, eps, out_ld, rowptr);
-  else ln_rows_from_lds_impl<NT, 64>(s, stride, npx, C, lnw, lnb, eps, out_ld, rowptr);
+                                                 const float* __restrict__ lnb, float eps, int out_ld, RowPtr rowptr,
+                                                 const PlanesOut pl = PlanesOut{0, 0, 1.f, 0}) {
+  if (npx * 8 > NT) ln_rows_from_lds_impl<NT, 4>(s, stride, npx, C, lnw, lnb, eps, out_ld, rowptr, pl);
+  else if (npx * 16 > NT) ln_rows_from_lds_impl<NT, 8>(s, stride, npx, C, lnw, lnb, eps, out_ld, rowptr, pl);
+  else if (npx * 32 > NT) ln_rows_from_lds_impl<NT, 16>(s, stride, npx, C, lnw, lnb, eps, out_ld, rowptr, pl);
+  else if (npx * 64 > NT) ln_rows_from_lds_impl<NT, 32>(s, stride, npx, C, lnw, lnb, eps, out_ld, rowptr, pl);
+  else ln_rows_from_lds_impl<NT, 64>(s, stride, npx, C, lnw, lnb, eps, out_ld, rowptr, pl);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -147,7 +160,7 @@ __global__ __launch_bounds__(256) void dwconv7_ln_kernel(const float* __restrict
                                                          const float* __restrict__ wdw, const float* __restrict__ bdw,
                                                          const float* __restrict__ lnw, const float* __restrict__ lnb,
                                                          float eps, float* __restrict__ out, int64_t out_ld, int NS,
-                                                         int spr, int64_t nstrips) {
+                                                         int spr, int64_t nstrips, PlanesOut pl) {
   extern __shared__ __attribute__((aligned(16))) float conv[];   // [NS*4][ld + 4]
   const int C4 = (int)(ld >> 2);
   const int64_t s0 = (int64_t)blockIdx.x * NS;
@@ -193,7 +206,7 @@ __global__ __launch_bounds__(256) void dwconv7_ln_kernel(const float* __restrict
     if (sidx >= nstrips) return nullptr;
     const int px = (int)(sidx % spr) * 4 + (p & 3);
     return px < W ? out + ((sidx / spr) * W + px) * out_ld : nullptr;
-  });
+  }, pl);
 }
 
 // LDS-tiled flavour of the same op (same FMA order per output => bit-identical to dwconv7_ln_kernel): a workgroup owns a TH x TW
@@ -207,7 +220,7 @@ __global__ __launch_bounds__(NT) void dwconv7_ln_tiled_kernel(const float* __res
                                                               const float* __restrict__ wdw, const float* __restrict__ bdw,
                                                               const float* __restrict__ lnw, const float* __restrict__ lnb,
                                                               float eps, float* __restrict__ out, int64_t out_ld, int tiles_x,
-                                                              int tiles_y, int nblk) {
+                                                              int tiles_y, int nblk, PlanesOut pl) {
   constexpr int IH = TH + 6, IW = TW + 6, CP = CCH + 4, SPR = TW / 4, N4 = CCH / 4;
   constexpr int NIN = IH * IW * N4, NWT = 50 * N4;            // float4 slots of a chunk: halo tile, taps + bias
   constexpr int LIN = (NIN + NT - 1) / NT, LWT = (NWT + NT - 1) / NT;
@@ -294,12 +307,12 @@ __global__ __launch_bounds__(NT) void dwconv7_ln_tiled_kernel(const float* __res
   ln_rows_from_lds<NT>(s_out, (int)ld + 4, TH * TW, C, lnw, lnb, eps, (int)out_ld, [&](int p) -> float* {
     const int gy = y0 + p / TW, gx = x0 + p % TW;
     return (gy < H && gx < W) ? out + (((int64_t)b * H + gy) * W + gx) * out_ld : nullptr;
-  });
+  }, pl);
 }
 
 template <int TH, int TW, int CCH, int NT>
 static int launch_dwconv_tiled(const float* x, int B, int H, int W, int C, int64_t ld, const float* wdw, const float* bdw, const float* lnw,
-                               const float* lnb, float eps, float* out, int64_t out_ld, hipStream_t st) {
+                               const float* lnb, float eps, float* out, int64_t out_ld, hipStream_t st, PlanesOut pl = PlanesOut{0, 0, 1.f, 0}) {
   const size_t smem = sizeof(float) * ((size_t)(TH + 6) * (TW + 6) * (CCH + 4) + 50 * CCH + (size_t)TH * TW * (ld + 4));
   if (smem > 160 * 1024 || ld % CCH != 0 || (int64_t)H * W * ld >= (1ll << 31)) return VS_ERR_UNSUPPORTED;
   auto kern = dwconv7_ln_tiled_kernel<TH, TW, CCH, NT>;
@@ -312,7 +325,7 @@ static int launch_dwconv_tiled(const float* x, int B, int H, int W, int C, int64
   const int64_t nblk = (int64_t)B * tiles_x * tiles_y;
   if (nblk >= (1 << 30)) return VS_ERR_UNSUPPORTED;
   hipLaunchKernelGGL(kern, dim3((unsigned)((nblk + 7) / 8 * 8)), dim3(NT), smem, st, x, H, W, C, ld, wdw, bdw, lnw, lnb, eps, out, out_ld,
-                     tiles_x, tiles_y, (int)nblk);
+                     tiles_x, tiles_y, (int)nblk, pl);
   return vs_launch_status();
 }
 
@@ -740,10 +753,10 @@ extern "C" int vs_layernorm_act(const float* x, int64_t rows, int C, int64_t ld,
   return vs_launch_status();
 }
 
-extern "C" int vs_dwconv7_ln(const float* x, int B, int H, int W, int C, int64_t ld, const float* wdw, const float* bdw,
-                             const float* lnw, const float* lnb, float eps, float* out, int64_t out_ld, void* stream) {
+static int dwconv7_ln_any(const float* x, int B, int H, int W, int C, int64_t ld, const float* wdw, const float* bdw,
+                          const float* lnw, const float* lnb, float eps, float* out, int64_t out_ld, void* stream, PlanesOut pl) {
   VS_REQUIRE(x && wdw && bdw && lnw && lnb && out && B > 0 && H > 0 && W > 0 && C > 0);
-  VS_REQUIRE(ld % 4 == 0 && ld >= C && out_ld >= C && out_ld % 4 == 0);
+  VS_REQUIRE(ld % 4 == 0 && ld >= C && (pl.cstride || (out_ld >= C && out_ld % 4 == 0)));
   // LDS-tiled kernels where the tile + the [pixel][channel] LayerNorm buffer fit the 160 KB of a CU and the map is large enough to
   // give every CU a tile; every variant produces bit-identical values (same FMA order), so the choice is purely a speed matter.
   // VS_DWCONV=0 forces the one-row kernel, 1 / 2 a tiled configuration (tools/bench_dwconv.py).
@@ -756,15 +769,15 @@ extern "C" int vs_dwconv7_ln(const float* x, int B, int H, int W, int C, int64_t
     else if (hw >= 1024) cfg = 3;              // 32^2 x 192: 65 -> 38 us; 16^2 x 384: 32 -> 23 us (128-channel chunks: 256 work items
     else if (hw >= 256) cfg = 6;               // per 4 x 8 tile); 8^2 x 768: the one-row kernel stays ahead (24 us)
     int rc = VS_ERR_UNSUPPORTED;
-    if (cfg == 1) rc = launch_dwconv_tiled<8, 8, 48, 256>(x, B, H, W, C, ld, wdw, bdw, lnw, lnb, eps, out, out_ld, (hipStream_t)stream);
-    else if (cfg == 2) rc = launch_dwconv_tiled<4, 8, 64, 128>(x, B, H, W, C, ld, wdw, bdw, lnw, lnb, eps, out, out_ld, (hipStream_t)stream);
-    else if (cfg == 3) rc = launch_dwconv_tiled<8, 16, 32, 256>(x, B, H, W, C, ld, wdw, bdw, lnw, lnb, eps, out, out_ld, (hipStream_t)stream);
-    else if (cfg == 4) rc = launch_dwconv_tiled<4, 16, 64, 256>(x, B, H, W, C, ld, wdw, bdw, lnw, lnb, eps, out, out_ld, (hipStream_t)stream);
-    else if (cfg == 5) rc = launch_dwconv_tiled<4, 16, 48, 256>(x, B, H, W, C, ld, wdw, bdw, lnw, lnb, eps, out, out_ld, (hipStream_t)stream);
-    else if (cfg == 6) rc = launch_dwconv_tiled<4, 8, 128, 256>(x, B, H, W, C, ld, wdw, bdw, lnw, lnb, eps, out, out_ld, (hipStream_t)stream);
-    else if (cfg == 7) rc = launch_dwconv_tiled<4, 4, 128, 128>(x, B, H, W, C, ld, wdw, bdw, lnw, lnb, eps, out, out_ld, (hipStream_t)stream);
+    if (cfg == 1) rc = launch_dwconv_tiled<8, 8, 48, 256>(x, B, H, W, C, ld, wdw, bdw, lnw, lnb, eps, out, out_ld, (hipStream_t)stream, pl);
+    else if (cfg == 2) rc = launch_dwconv_tiled<4, 8, 64, 128>(x, B, H, W, C, ld, wdw, bdw, lnw, lnb, eps, out, out_ld, (hipStream_t)stream, pl);
+    else if (cfg == 3) rc = launch_dwconv_tiled<8, 16, 32, 256>(x, B, H, W, C, ld, wdw, bdw, lnw, lnb, eps, out, out_ld, (hipStream_t)stream, pl);
+    else if (cfg == 4) rc = launch_dwconv_tiled<4, 16, 64, 256>(x, B, H, W, C, ld, wdw, bdw, lnw, lnb, eps, out, out_ld, (hipStream_t)stream, pl);
+    else if (cfg == 5) rc = launch_dwconv_tiled<4, 16, 48, 256>(x, B, H, W, C, ld, wdw, bdw, lnw, lnb, eps, out, out_ld, (hipStream_t)stream, pl);
+    else if (cfg == 6) rc = launch_dwconv_tiled<4, 8, 128, 256>(x, B, H, W, C, ld, wdw, bdw, lnw, lnb, eps, out, out_ld, (hipStream_t)stream, pl);
+    else if (cfg == 7) rc = launch_dwconv_tiled<4, 4, 128, 128>(x, B, H, W, C, ld, wdw, bdw, lnw, lnb, eps, out, out_ld, (hipStream_t)stream, pl);
     if (rc == VS_ERR_UNSUPPORTED && force < 0 && cfg == 3)      // tile does not fit / ld % 32: the other tiled shape
-      rc = launch_dwconv_tiled<4, 16, 48, 256>(x, B, H, W, C, ld, wdw, bdw, lnw, lnb, eps, out, out_ld, (hipStream_t)stream);
+      rc = launch_dwconv_tiled<4, 16, 48, 256>(x, B, H, W, C, ld, wdw, bdw, lnw, lnb, eps, out, out_ld, (hipStream_t)stream, pl);
     if (rc != VS_ERR_UNSUPPORTED) return rc;
   }
   const int C4 = (int)(ld / 4);
@@ -777,8 +790,22 @@ extern "C" int vs_dwconv7_ln(const float* x, int B, int H, int W, int C, int64_t
   if (smem > 64 * 1024)
     (void)hipFuncSetAttribute((const void*)dwconv7_ln_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
   hipLaunchKernelGGL(dwconv7_ln_kernel, dim3((unsigned)cdiv64(nstrips, NS)), dim3(256), smem, (hipStream_t)stream, x, B, H, W,
-                     C, ld, wdw, bdw, lnw, lnb, eps, out, out_ld, NS, spr, nstrips);
+                     C, ld, wdw, bdw, lnw, lnb, eps, out, out_ld, NS, spr, nstrips, pl);
   return vs_launch_status();
+}
+
+extern "C" int vs_dwconv7_ln(const float* x, int B, int H, int W, int C, int64_t ld, const float* wdw, const float* bdw,
+                             const float* lnw, const float* lnb, float eps, float* out, int64_t out_ld, void* stream) {
+  return dwconv7_ln_any(x, B, H, W, C, ld, wdw, bdw, lnw, lnb, eps, out, out_ld, stream, PlanesOut{0, 0, 1.f, 0});
+}
+// the same with the LayerNorm output written as the operand planes of vs_conv_gemm tile codes 24 / 25: [2][ceil(C/16)][B*H*W][16] f16
+// (hi / lo of value * a_mul, channels >= C zero)
+extern "C" int vs_dwconv7_ln_planes(const float* x, int B, int H, int W, int C, int64_t ld, const float* wdw, const float* bdw,
+                                    const float* lnw, const float* lnb, float eps, float a_mul, int planes_C, void* planes, void* stream) {
+  VS_REQUIRE(planes && a_mul > 0.f && ((uintptr_t)planes & 15) == 0 && planes_C >= C && planes_C % 16 == 0);
+  const int64_t rows = (int64_t)B * H * W, cstride = rows * 32;
+  return dwconv7_ln_any(x, B, H, W, C, ld, wdw, bdw, lnw, lnb, eps, static_cast<float*>(planes), 8, stream,
+                        PlanesOut{cstride, (int64_t)(planes_C / 16) * cstride, a_mul, planes_C});
 }
 
 extern "C" int vs_grn_scale(const float* h, int B, int HW, int C, int64_t ld, const float* gamma, float* partial,

@@ -162,6 +162,7 @@ class HipEngine:
     """Packed weights + launch sequences for one architecture (ModelCfg) on one device."""
     arith = 2          # arithmetic of the split back-end (vs_conv_desc_t::arith); set per instance from VIDEOSEAL_CONV
     planes_chain = True
+    planes_gemm = True
 
     def __init__(self, cfg, sd: Dict[str, torch.Tensor], device: torch.device):
         self.cfg = cfg
@@ -183,6 +184,7 @@ class HipEngine:
         self.upconv_fused = os.environ.get("VIDEOSEAL_UPCONV", "lowres") != "unfused"    # thin levels: GEMM + gather in one kernel
         self.msg_table_conv = os.environ.get("VIDEOSEAL_MSG_TABLE", "1") != "0"         # first bottleneck block: message channels as a table
         self.planes_chain = os.environ.get("VIDEOSEAL_PLANES", "1") != "0"              # bottleneck chain on pre-split operand planes
+        self.planes_gemm = os.environ.get("VIDEOSEAL_PLANES", "1") != "0"               # ConvNeXt 1x1 GEMMs on operand planes
         # per-shape tile selection: every candidate walks K in the same order, so the result is bit-identical whatever
         # tile wins -- only speed changes (measure, don't guess).  VIDEOSEAL_AUTOTUNE=0 keeps the static heuristic.
         self.autotune = os.environ.get("VIDEOSEAL_AUTOTUNE", "1") != "0"
@@ -656,6 +658,10 @@ class HipEngine:
                   n_store=(cout if out.ld != rup(cout, 4) else None))
         return out
 
+    def _gemm_planes_ok(self, rows: int, n: int) -> bool:
+        """1x1 GEMM on operand planes (gemm_pl.hip): 2 x f16 arithmetic and enough 256-row x 192-column tiles for the 256 CUs"""
+        return self.planes_gemm and self.use_split and self.arith == 2 and ((rows + 255) // 256) * ((n + 191) // 192) >= 200
+
     def _planes_ok(self, x: Act, blocks) -> bool:
         """the bottleneck chain on pre-split operand planes (conv3x3_pl.hip): 2 x f16 arithmetic, eval BatchNorm folded, whole
         16 x 16-pixel tiles, 192-channel column tiles, and enough 256-pixel tiles to give (nearly) every CU a workgroup"""
@@ -819,19 +825,43 @@ class HipEngine:
             nchunk = (HW + 63) // 64
             part = self.buf(f"st{sti}.gp", nchunk * B * 4 * Cc)
             scale = self.buf(f"st{sti}.gs", B * hh.ld + 16)   # +16: the conv A-transform reads whole 16-float chunks
+            # all-DMA GEMM on operand planes (gemm_pl.hip, tile code 24) where its 256-row tiles give every CU work: pwconv1 reads the
+            # LayerNorm output as f16 planes written by the dwconv kernel itself; pwconv2 only for long K (K >= 3072: the GRN apply then
+            # runs in a separate conversion pass, which costs more than it saves on the shorter layers -- tools/bench_gemm.py planes)
+            pw1w = X["stages"][sti][0]["pw1"]
+            pl1 = self._gemm_planes_ok(cur.rows, 4 * Cc) and pw1w.CinP % 16 == 0
+            pl2, sk2 = False, 1
+            if self.planes_gemm and self.use_split and self.arith == 2 and hh.ld >= 3072 and hh.ld % 16 == 0:
+                tiles2 = ((cur.rows + 255) // 256) * ((Cc + 191) // 192)
+                steps2 = hh.ld // 16
+                while tiles2 * sk2 < 200 and steps2 // (sk2 * 2) >= 24 and steps2 % (sk2 * 2) == 0:
+                    sk2 *= 2
+                pl2 = tiles2 * sk2 >= 128
+            tnpl = self.buf(f"st{sti}.npl", cur.rows * pw1w.CinP).view(torch.int16) if pl1 else None
+            hpl = self.buf(f"st{sti}.hpl", cur.rows * hh.ld).view(torch.int16) if pl2 else None
+            ptile = N.CONV_TILE_HI | 8
             for blk in X["stages"][sti]:
-                N.check(L.vs_dwconv7_ln(N.ptr(cur.t), B, cur.H, cur.W, Cc, cur.ld, N.ptr(blk["wdw"]), N.ptr(blk["bdw"]), N.ptr(blk["lnw"]),
-                                        N.ptr(blk["lnb"]), 1e-6, N.ptr(tn.t), tn.ld, st), "vs_dwconv7_ln")
+                if pl1:
+                    N.check(L.vs_dwconv7_ln_planes(N.ptr(cur.t), B, cur.H, cur.W, Cc, cur.ld, N.ptr(blk["wdw"]), N.ptr(blk["bdw"]), N.ptr(blk["lnw"]),
+                                                   N.ptr(blk["lnb"]), 1e-6, A_MUL, pw1w.CinP, N.ptr(tnpl), st), "vs_dwconv7_ln_planes")
+                else:
+                    N.check(L.vs_dwconv7_ln(N.ptr(cur.t), B, cur.H, cur.W, Cc, cur.ld, N.ptr(blk["wdw"]), N.ptr(blk["bdw"]), N.ptr(blk["lnw"]),
+                                            N.ptr(blk["lnb"]), 1e-6, N.ptr(tn.t), tn.ld, st), "vs_dwconv7_ln")
+                kw1 = dict(in_pl=tnpl, tile_hint=ptile) if pl1 else {}
                 if HW % 32 == 0:      # ||h||^2 partials come out of pwconv1's epilogue: no second pass over h
                     part32 = self.buf(f"st{sti}.gp32", B * (HW // 32) * 4 * Cc)
-                    self.conv(tn, blk["pw1"], hh, act=N.ACT_GELU, sumsq=part32)
+                    self.conv(tn, blk["pw1"], hh, act=N.ACT_GELU, sumsq=part32, **kw1)
                     N.check(L.vs_grn_scale_from_partials(N.ptr(part32), B, HW, 4 * Cc, N.ptr(blk["gamma"]), N.ptr(scale), hh.ld, st),
                             "vs_grn_scale_from_partials")
                 else:
-                    self.conv(tn, blk["pw1"], hh, act=N.ACT_GELU)
+                    self.conv(tn, blk["pw1"], hh, act=N.ACT_GELU, **kw1)
                     N.check(L.vs_grn_scale(N.ptr(hh.t), B, HW, 4 * Cc, hh.ld, N.ptr(blk["gamma"]), N.ptr(part), N.ptr(scale), st),
                             "vs_grn_scale")
-                if HW % 64 == 0 or not self.use_split:
+                if pl2:               # GRN apply + operand split in one pass over h, then the planes GEMM (K split by the shape rule)
+                    N.check(L.vs_to_planes_affine(N.ptr(hh.t), hh.rows, hh.ld, hh.ld, A_MUL, N.ptr(scale), hh.ld, N.ptr(blk["beta"]), HW,
+                                                  N.ptr(hpl), st), "vs_to_planes_affine")
+                    self.conv(hh, blk["pw2"], cur, res=cur, in_pl=hpl, tile_hint=ptile, split_k=sk2)
+                elif HW % 64 == 0 or not self.use_split:
                     self.conv(hh, blk["pw2"], cur, res=cur, a_scale=scale, a_scale_ld=hh.ld, a_shift=blk["beta"])
                 else:     # odd feature maps (ChunkySeal: 31 x 31): GRN applied in place + plain GEMM measured faster (109 vs 105 frames/s)
                           # than the GEMM with the fused transform, whose frame-boundary select costs registers
