@@ -348,6 +348,26 @@ struct Runner {
     conv(t, p.c1, out, 1, 1, VS_PAD_ZERO, VS_ACT_RELU, 0, out.ld != rup(p.cout, 4) ? p.cout : -1, nullptr, &x, &p.res);
     return out;
   }
+  // 1x1 GEMM on operand planes (tile code 24, gemm_pl.hip): out = act(in_pl x w + bias) (+ res), optional GRN partials / K split
+  void gemm_pl(int B, int H, int W, const CW& w, const void* in_pl, const Act& out, int act_, const Act* res, float* sumsq, int split_k) {
+    vs_conv_desc_t d;
+    std::memset(&d, 0, sizeof(d));
+    d.B = B; d.H = H; d.W = W; d.Cin = w.CinP; d.KH = d.KW = 1; d.SH = d.SW = 1; d.Ho = H; d.Wo = W;
+    d.wt = w.wt; d.CinP = w.CinP; d.N = w.N; d.bias = w.bias; d.act = act_;
+    d.wt_split = w.split; d.wt_blk = w.blk; d.arith = 2; d.a_mul = A_MUL; d.acc_mul = 1.f / (A_MUL * w.w_mul);
+    d.in_pl = in_pl;
+    d.out = out.p; d.out_ld = out.ld; d.n_store = out.ld;
+    if (res) { d.res = res->p; d.res_ld = res->ld; }
+    d.sumsq_part = sumsq;
+    if (split_k > 1) {
+      const int ws_ld = rup(w.N, 4);
+      d.splitk_ws = alloc((int64_t)split_k * out.rows() * ws_ld);
+      d.splitk_ld = ws_ld;
+      d.split_k = split_k;
+    }
+    d.tile_hint = VS_CONV_TILE_HI | 8;
+    if (live()) chk(vs_conv_gemm(&d, st));
+  }
   // one launch of the all-DMA 3x3 kernel on operand planes (tile code 22, conv3x3_pl.hip); out == nullptr: planes only
   void conv_pl(int B, int H, int W, const CW& w, const void* in_pl, void* out_pl, const Act* out, const CW* w2 = nullptr,
                const void* in2_pl = nullptr) {
@@ -523,16 +543,39 @@ struct Runner {
       float* part = alloc((int64_t)((HW + 63) / 64) * B * 4 * Cc);
       float* part32 = alloc((int64_t)B * ((HW + 31) / 32) * 4 * Cc);
       float* scale = alloc((int64_t)B * hh.ld + 16);
+      // engine.py::extractor_forward: the GEMMs on operand planes where the 256-row tiles fill the chip (pwconv1), resp. for long K (pwconv2)
+      const int64_t rows = cur.rows();
+      const CW& pw1w = m->stages[sti].empty() ? m->stem : m->stages[sti][0].pw1;
+      const bool pl1 = m->arith == 2 && ((rows + 255) / 256) * ((4 * Cc + 191) / 192) >= 200 && pw1w.CinP % 16 == 0 && !m->stages[sti].empty();
+      bool pl2 = false;
+      int sk2 = 1;
+      if (m->arith == 2 && hh.ld >= 3072 && hh.ld % 16 == 0) {
+        const int64_t tiles2 = ((rows + 255) / 256) * ((Cc + 191) / 192);
+        const int steps2 = hh.ld / 16;
+        while (tiles2 * sk2 < 200 && steps2 / (sk2 * 2) >= 24 && steps2 % (sk2 * 2) == 0) sk2 *= 2;
+        pl2 = tiles2 * sk2 >= 128;
+      }
+      void* tnpl = pl1 ? alloc(rows * pw1w.CinP) : nullptr;
+      void* hpl = pl2 ? alloc(rows * hh.ld) : nullptr;
       for (const Blk& blk : m->stages[sti]) {
-        if (live()) chk(vs_dwconv7_ln(cur.p, B, cur.H, cur.W, Cc, cur.ld, blk.wdw, blk.bdw, blk.lnw, blk.lnb, 1e-6f, tn.p, tn.ld, st));
+        if (pl1) {
+          if (live()) chk(vs_dwconv7_ln_planes(cur.p, B, cur.H, cur.W, Cc, cur.ld, blk.wdw, blk.bdw, blk.lnw, blk.lnb, 1e-6f, A_MUL, pw1w.CinP, tnpl, st));
+        } else if (live()) {
+          chk(vs_dwconv7_ln(cur.p, B, cur.H, cur.W, Cc, cur.ld, blk.wdw, blk.bdw, blk.lnw, blk.lnb, 1e-6f, tn.p, tn.ld, st));
+        }
         if (HW % 32 == 0) {
-          conv(tn, blk.pw1, hh, 1, 0, VS_PAD_ZERO, VS_ACT_GELU, 0, -1, nullptr, nullptr, nullptr, nullptr, 0, nullptr, nullptr, part32);
+          if (pl1) gemm_pl(B, cur.H, cur.W, blk.pw1, tnpl, hh, VS_ACT_GELU, nullptr, part32, 1);
+          else conv(tn, blk.pw1, hh, 1, 0, VS_PAD_ZERO, VS_ACT_GELU, 0, -1, nullptr, nullptr, nullptr, nullptr, 0, nullptr, nullptr, part32);
           if (live()) chk(vs_grn_scale_from_partials(part32, B, HW, 4 * Cc, blk.gamma, scale, hh.ld, st));
         } else {
-          conv(tn, blk.pw1, hh, 1, 0, VS_PAD_ZERO, VS_ACT_GELU);
+          if (pl1) gemm_pl(B, cur.H, cur.W, blk.pw1, tnpl, hh, VS_ACT_GELU, nullptr, nullptr, 1);
+          else conv(tn, blk.pw1, hh, 1, 0, VS_PAD_ZERO, VS_ACT_GELU);
           if (live()) chk(vs_grn_scale(hh.p, B, HW, 4 * Cc, hh.ld, blk.gamma, part, scale, st));
         }
-        if (HW % 64 == 0) {
+        if (pl2) {
+          if (live()) chk(vs_to_planes_affine(hh.p, hh.rows(), hh.ld, hh.ld, A_MUL, scale, hh.ld, blk.beta, HW, hpl, st));
+          gemm_pl(B, cur.H, cur.W, blk.pw2, hpl, cur, VS_ACT_NONE, &cur, nullptr, sk2);
+        } else if (HW % 64 == 0) {
           conv(hh, blk.pw2, cur, 1, 0, VS_PAD_ZERO, VS_ACT_NONE, 0, -1, &cur, nullptr, nullptr, scale, hh.ld, blk.beta);
         } else {
           if (live()) chk(vs_grn_apply(hh.p, B, HW, 4 * Cc, hh.ld, scale, hh.ld, blk.beta, st));
