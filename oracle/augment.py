@@ -2,7 +2,10 @@
 
 Geometric / filter ops follow videoseal/augmentation/{geometric,valuemetric}.py and utils/image.py; the colour ops call
 torchvision.transforms.functional in the reference, which is NOT installed and not vendored: they are restated from the
-published torchvision `_functional_tensor.py` semantics -- parity for those is "unpinned".
+published torchvision `_functional_tensor.py` semantics -- parity with torchvision itself is "unpinned"; the
+restatement is checked against independent implementations instead (tests/test_oracle_aug_pins.py): Pillow's ImageEnhance (what
+torchvision's own PIL backend calls) for brightness / contrast / saturation, the standard library's colorsys for hue, scipy.ndimage for
+the Gaussian blur, the rotation and (with a numpy.linalg homography) the perspective warp.
 JPEG is the Pillow round trip itself (pinned: Pillow is the reference's codec).
 """
 from __future__ import annotations
