@@ -367,7 +367,8 @@ def test_gemm_planes_kernel(case):
     cw = ConvW(wt, bias.to(DEV), Nn, 1, 1, cp)
     ra = Act(r.to(DEV).contiguous(), B, H, W, Nn, Nn)
     pl = eng.buf("t.gpl", B * HW * K).view(torch.int16)
-    N.check(eng.lib.vs_to_planes_affine(N.ptr(xa.t), xa.rows, K, xa.ld, 16.0, N.ptr(dv(scale)) if grn else None, K,
+    am = 1.0 if grn else 16.0          # engine.A_MUL_GRN / A_MUL: the range scale the fused GRN path of the other kernels uses
+    N.check(eng.lib.vs_to_planes_affine(N.ptr(xa.t), xa.rows, K, xa.ld, am, N.ptr(dv(scale)) if grn else None, K,
                                         N.ptr(dv(shift)) if grn else None, HW, N.ptr(pl), N.stream()), "to_planes_affine")
     outs = []
     for t in (N.CONV_TILE_HI | (tile - 16), 1):
@@ -376,7 +377,7 @@ def test_gemm_planes_kernel(case):
         part = torch.full((((B * HW + 31) // 32) * Nn,), float("nan"), device=DEV) if sumsq else None
         kw = dict(act=act, res=(ra if res else None), tile_hint=t, arith=2)
         if t != 1:
-            kw.update(in_pl=pl, split_k=sk, sumsq=part)
+            kw.update(in_pl=pl, split_k=sk, sumsq=part, a_mul=am)
         else:
             kw.update(a_scale=(dv(scale) if grn else None), a_scale_ld=K, a_shift=(dv(shift) if grn else None), sumsq=part)
         eng.conv(xa, cw, out, **kw)

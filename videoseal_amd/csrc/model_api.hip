@@ -61,6 +61,7 @@ struct vs_model {
 };
 
 static constexpr float A_MUL = 16.f;      // engine.py::A_MUL
+static constexpr float A_MUL_GRN = 1.f;   // engine.py::A_MUL_GRN (the GRN-scaled operand of pwconv2)
 
 namespace {
 
@@ -282,7 +283,7 @@ struct Runner {
   void conv(const Act& x, const CW& w, const Act& out, int stride = 1, int pad = 0, int pad_mode = VS_PAD_ZERO, int act_ = VS_ACT_NONE,
             int out_coff = 0, int n_store = -1, const Act* res = nullptr, const Act* in2 = nullptr, const CW* w2 = nullptr,
             const float* a_scale = nullptr, int64_t a_scale_ld = 0, const float* a_shift = nullptr, const int* geom = nullptr,
-            float* sumsq = nullptr, int cin_first = 0, bool pre_table = false) {
+            float* sumsq = nullptr, int cin_first = 0, bool pre_table = false, float a_mul_override = 0.f) {
     vs_conv_desc_t d;
     std::memset(&d, 0, sizeof(d));
     int sh = stride, sw = stride, ph = pad, pw = pad, H = x.H, W = x.W, cin = x.ld;
@@ -302,8 +303,9 @@ struct Runner {
     if (in2) { d.in2 = in2->p; d.in2_ld = in2->ld; d.Cin2 = in2->ld; d.Cin2P = w2->CinP; d.wt2 = w2->wt; d.bias2 = w2->bias; }
     d.out = out.p; d.out_ld = out.ld; d.out_coff = out_coff; d.tile_hint = 0;
     d.wt_split = w.split; d.wt_blk = w.blk;
-    d.arith = m->arith; d.a_mul = A_MUL; d.acc_mul = 1.f / (A_MUL * w.w_mul);
-    if (in2) { d.wt2_split = w2->split; d.wt2_blk = w2->blk; d.acc_mul2 = 1.f / (A_MUL * w2->w_mul); }
+    const float am = a_mul_override > 0.f ? a_mul_override : ((a_scale && !pre_table) ? A_MUL_GRN : A_MUL);
+    d.arith = m->arith; d.a_mul = am; d.acc_mul = 1.f / (am * w.w_mul);
+    if (in2) { d.wt2_split = w2->split; d.wt2_blk = w2->blk; d.acc_mul2 = 1.f / (am * w2->w_mul); }
     int split_k = 1;
     const bool dense_rows = d.in_sy == (int64_t)d.W * d.in_sx && d.in_sb == (int64_t)d.H * d.in_sy;
     const bool gemm_pc = d.KH == 1 && d.KW == 1 && sh == 1 && sw == 1 && ph == 0 && pw == 0 && !in2 && d.Ho == d.H && d.Wo == d.W &&
@@ -349,12 +351,13 @@ struct Runner {
     return out;
   }
   // 1x1 GEMM on operand planes (tile code 24, gemm_pl.hip): out = act(in_pl x w + bias) (+ res), optional GRN partials / K split
-  void gemm_pl(int B, int H, int W, const CW& w, const void* in_pl, const Act& out, int act_, const Act* res, float* sumsq, int split_k) {
+  void gemm_pl(int B, int H, int W, const CW& w, const void* in_pl, const Act& out, int act_, const Act* res, float* sumsq, int split_k,
+               float am = A_MUL) {
     vs_conv_desc_t d;
     std::memset(&d, 0, sizeof(d));
     d.B = B; d.H = H; d.W = W; d.Cin = w.CinP; d.KH = d.KW = 1; d.SH = d.SW = 1; d.Ho = H; d.Wo = W;
     d.wt = w.wt; d.CinP = w.CinP; d.N = w.N; d.bias = w.bias; d.act = act_;
-    d.wt_split = w.split; d.wt_blk = w.blk; d.arith = 2; d.a_mul = A_MUL; d.acc_mul = 1.f / (A_MUL * w.w_mul);
+    d.wt_split = w.split; d.wt_blk = w.blk; d.arith = 2; d.a_mul = am; d.acc_mul = 1.f / (am * w.w_mul);
     d.in_pl = in_pl;
     d.out = out.p; d.out_ld = out.ld; d.n_store = out.ld;
     if (res) { d.res = res->p; d.res_ld = res->ld; }
@@ -573,13 +576,13 @@ struct Runner {
           if (live()) chk(vs_grn_scale(hh.p, B, HW, 4 * Cc, hh.ld, blk.gamma, part, scale, st));
         }
         if (pl2) {
-          if (live()) chk(vs_to_planes_affine(hh.p, hh.rows(), hh.ld, hh.ld, A_MUL, scale, hh.ld, blk.beta, HW, hpl, st));
-          gemm_pl(B, cur.H, cur.W, blk.pw2, hpl, cur, VS_ACT_NONE, &cur, nullptr, sk2);
+          if (live()) chk(vs_to_planes_affine(hh.p, hh.rows(), hh.ld, hh.ld, A_MUL_GRN, scale, hh.ld, blk.beta, HW, hpl, st));
+          gemm_pl(B, cur.H, cur.W, blk.pw2, hpl, cur, VS_ACT_NONE, &cur, nullptr, sk2, A_MUL_GRN);
         } else if (HW % 64 == 0) {
           conv(hh, blk.pw2, cur, 1, 0, VS_PAD_ZERO, VS_ACT_NONE, 0, -1, &cur, nullptr, nullptr, scale, hh.ld, blk.beta);
         } else {
           if (live()) chk(vs_grn_apply(hh.p, B, HW, 4 * Cc, hh.ld, scale, hh.ld, blk.beta, st));
-          conv(hh, blk.pw2, cur, 1, 0, VS_PAD_ZERO, VS_ACT_NONE, 0, -1, &cur);
+          conv(hh, blk.pw2, cur, 1, 0, VS_PAD_ZERO, VS_ACT_NONE, 0, -1, &cur, nullptr, nullptr, nullptr, 0, nullptr, nullptr, nullptr, 0, false, A_MUL_GRN);
         }
       }
     }

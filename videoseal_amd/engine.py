@@ -109,6 +109,7 @@ def split_bf16x3(w: torch.Tensor) -> torch.Tensor:
 
 
 A_MUL = 16.0        # power of two the activations are multiplied with before the f16 split (vs_conv_desc_t::a_mul): |a| < 4094
+A_MUL_GRN = 1.0     # the same for the GRN-scaled operand of pwconv2: |a| < 65504
 
 
 def split_f16x2(w: torch.Tensor) -> Tuple[torch.Tensor, float]:
@@ -373,7 +374,7 @@ class HipEngine:
              a_scale=None, a_scale_ld=0, a_shift=None, geom=None, tile_hint=0, prof: Optional[str] = None,
              split_k: Optional[int] = None, sumsq: Optional[torch.Tensor] = None, cin: Optional[int] = None, flops: Optional[float] = None,
              arith: Optional[int] = None, in_pl: Optional[torch.Tensor] = None, in2_pl: Optional[torch.Tensor] = None,
-             out_pl: Optional[torch.Tensor] = None):
+             out_pl: Optional[torch.Tensor] = None, a_mul: Optional[float] = None):
         """cin: read only the first `cin` channels of every pixel (pixel stride stays x.ld)"""
         d = N.ConvDesc()
         if geom is None:
@@ -403,11 +404,14 @@ class HipEngine:
             ar = self.arith if arith is None else arith
             d.wt_split = N.ptr(w.with_blk(ar).split)
             d.wt_blk = N.ptr(w.blk)
-            d.arith, d.a_mul, d.acc_mul = ar, A_MUL, 1.0 / (A_MUL * w.w_mul)
+            # activation range scale of the 2 x f16 split: 2^4 (|a| < 4094) for normalised tensors; the GRN-scaled pwconv2 operand
+            # (h * (1 + gamma * Nx): outlier channels of a trained extractor can be large) keeps the whole f16 range (|a| < 65504)
+            am = a_mul if a_mul is not None else (A_MUL_GRN if (a_scale is not None and not (tile_hint & N.CONV_PRE)) else A_MUL)
+            d.arith, d.a_mul, d.acc_mul = ar, am, 1.0 / (am * w.w_mul)
             if in2 is not None:
                 d.wt2_split = N.ptr(w2.with_blk(ar).split)
                 d.wt2_blk = N.ptr(w2.blk)
-                d.acc_mul2 = 1.0 / (A_MUL * w2.w_mul)
+                d.acc_mul2 = 1.0 / (am * w2.w_mul)
         if in_pl is not None:       # operands as pre-split planes (tile codes 22 / 23, conv3x3_pl.hip)
             d.in_pl, d.in2_pl, d.out_pl = N.ptr(in_pl), N.ptr(in2_pl), N.ptr(out_pl)
             if out.t is None:
@@ -858,15 +862,15 @@ class HipEngine:
                     N.check(L.vs_grn_scale(N.ptr(hh.t), B, HW, 4 * Cc, hh.ld, N.ptr(blk["gamma"]), N.ptr(part), N.ptr(scale), st),
                             "vs_grn_scale")
                 if pl2:               # GRN apply + operand split in one pass over h, then the planes GEMM (K split by the shape rule)
-                    N.check(L.vs_to_planes_affine(N.ptr(hh.t), hh.rows, hh.ld, hh.ld, A_MUL, N.ptr(scale), hh.ld, N.ptr(blk["beta"]), HW,
+                    N.check(L.vs_to_planes_affine(N.ptr(hh.t), hh.rows, hh.ld, hh.ld, A_MUL_GRN, N.ptr(scale), hh.ld, N.ptr(blk["beta"]), HW,
                                                   N.ptr(hpl), st), "vs_to_planes_affine")
-                    self.conv(hh, blk["pw2"], cur, res=cur, in_pl=hpl, tile_hint=ptile, split_k=sk2)
+                    self.conv(hh, blk["pw2"], cur, res=cur, in_pl=hpl, tile_hint=ptile, split_k=sk2, a_mul=A_MUL_GRN)
                 elif HW % 64 == 0 or not self.use_split:
                     self.conv(hh, blk["pw2"], cur, res=cur, a_scale=scale, a_scale_ld=hh.ld, a_shift=blk["beta"])
                 else:     # odd feature maps (ChunkySeal: 31 x 31): GRN applied in place + plain GEMM measured faster (109 vs 105 frames/s)
                           # than the GEMM with the fused transform, whose frame-boundary select costs registers
                     N.check(L.vs_grn_apply(N.ptr(hh.t), B, HW, 4 * Cc, hh.ld, N.ptr(scale), hh.ld, N.ptr(blk["beta"]), st), "vs_grn_apply")
-                    self.conv(hh, blk["pw2"], cur, res=cur)
+                    self.conv(hh, blk["pw2"], cur, res=cur, a_mul=A_MUL_GRN)
         return self._pixel_decoder(cur, X)
 
     def _pixel_decoder(self, cur: Act, X) -> torch.Tensor:
