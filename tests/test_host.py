@@ -99,6 +99,35 @@ def test_aggregation_variants():
         aggregate_bits(p, "median")
 
 
+def test_f16x2_operand_split_of_the_weights():
+    """engine.split_f16x2 (the weight side of the default 2 x f16 arithmetic, conv_common.h Arith<2>): w * w_mul = hi + lo with w_mul a
+    power of two that puts max|w| into [2^13, 2^14); |w * w_mul - hi - lo| <= 2^-23 |w * w_mul| for every weight whose low term is a
+    normal f16 and <= 2^-25 (half a denormal quantum) otherwise; blocked LDS image = a permutation of the planes."""
+    import math
+    import torch
+    from videoseal_amd.engine import pack_blocked, split_bf16x3, split_f16x2
+    g = torch.Generator().manual_seed(5)
+    for scale in (1e-4, 0.02, 1.0, 300.0):
+        w = torch.randn(70, 9 * 32, generator=g) * scale
+        w[0, 0] = 0.0
+        planes, w_mul = split_f16x2(w)
+        assert planes.shape == (2, 70, 288) and planes.dtype == torch.int16
+        assert math.log2(w_mul) == round(math.log2(w_mul))
+        ws = w.double() * w_mul
+        assert 2 ** 13 <= ws.abs().max() < 2 ** 14
+        hi, lo = planes[0].view(torch.float16).double(), planes[1].view(torch.float16).double()
+        err = (ws - hi - lo).abs()
+        normal = (ws - hi).abs() >= 2.0 ** -14
+        assert (err[normal] <= 2.0 ** -23 * ws.abs()[normal]).all()
+        assert (err[~normal] <= 2.0 ** -25 + 1e-30).all()
+        blk = pack_blocked(planes, 9)
+        assert blk.shape == (3, 18, 2, 64, 8) and sorted(blk.reshape(-1).tolist()) == sorted(planes.reshape(-1).tolist() + [0] * (blk.numel() - planes.numel()))
+        # the exact 3 x bf16 split of the other arithmetic: three truncated terms that add up to w exactly
+        p3 = split_bf16x3(w)
+        terms = [(p3[i].to(torch.int32) << 16).view(torch.float32).double() for i in range(3)]
+        assert torch.equal(terms[0] + terms[1] + terms[2], w.double())
+
+
 def test_c_abi_exports_every_declared_symbol():
     """the shared library loads on a machine without a GPU and exports exactly what the header declares."""
     header = open(os.path.join(ROOT, "include", "videoseal_hip.h")).read()
