@@ -129,13 +129,19 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pl_kernel(const vs_conv_desc_t
       }
     }
   }
-  int wstage = 0;                             // ring stage of the next weight tile
-  auto dma_w = [&]() __attribute__((always_inline)) {           // waves 0-3: the next weight tile of the current phase
+  int wstage = 0;                             // ring stage of the next weight tile (phase 2; phase 1 knows it at compile time)
+  auto dma_w2 = [&]() __attribute__((always_inline)) {          // waves 0-3: the next weight tile of phase 2
     unsigned char* st = Bring + wstage * B_STAGE;
 #pragma unroll
     for (int jj = 0; jj < TN; ++jj) dma16(wbase + doff[jj], st + wdst[jj]);
     wbase += WBLK;
     wstage = wstage + 1 == NRING ? 0 : wstage + 1;
+  };
+  auto dma_w = [&](auto stagec) __attribute__((always_inline)) {      // waves 0-3: the next weight tile of phase 1 into a known stage
+    unsigned char* st = Bring + decltype(stagec)::value * B_STAGE;
+#pragma unroll
+    for (int jj = 0; jj < TN; ++jj) dma16(wbase + doff[jj], st + wdst[jj]);
+    wbase += WBLK;
   };
   // patch of chunk cc, slots j0 and j0 + 1
   const char* const inpl = reinterpret_cast<const char*>(d.in_pl);
@@ -149,11 +155,6 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pl_kernel(const vs_conv_desc_t
         if ((pvalid >> j) & 1) dma16(cbase + doff[j], pb + j * 4096);      // halo lanes outside the image stay masked off (zeros in LDS)
       }
     }
-  };
-  auto dma_patch = [&](const int cc, const int tap) __attribute__((always_inline)) {
-    if (tap == 0) dma_patch2(cc, 0);
-    else if (tap == 1) dma_patch2(cc, 2);
-    else dma_patch2(cc, 4);
   };
   // phase 2: in2 chunks as plain rows of the tile's 256 pixels; slots j = 0..3 (instruction k = pw + 4j), buffer c2 & 3
   auto qbuf = [&](const int c2) __attribute__((always_inline)) -> unsigned char* {
@@ -208,28 +209,6 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pl_kernel(const vs_conv_desc_t
   Hi H0, H1;
   bf16x8 lo_a[TM], lo_b[TN];
   auto b_ptr = [&](const int s) __attribute__((always_inline)) -> const unsigned char* { return Bring + (s % NRING) * B_STAGE + b_frag; };
-  auto a_ptr1 = [&](const int i, const int s) __attribute__((always_inline)) -> const unsigned char* {      // phase 1: hi plane of block i
-    const int cc = s / 9, tap = s - cc * 9;
-    const int ky = tap / 3, kx = tap - ky * 3;
-    const int q = q0[i] + ky * PPW + kx;
-    return smem + (cc & 1) * P_BYTES + (2 * q + (g ^ prow[i] ^ (ky & 1))) * 16;       // half swizzled by the parity of the patch row
-  };
-  auto load_hi1 = [&](Hi& H, const int s) __attribute__((always_inline)) {
-    const unsigned char* Bb = b_ptr(s);
-#pragma unroll
-    for (int j = 0; j < TN; ++j) H.b[j] = *reinterpret_cast<const bf16x8*>(Bb + j * 1024);
-#pragma unroll
-    for (int i = 0; i < TM; ++i) H.a[i] = *reinterpret_cast<const bf16x8*>(a_ptr1(i, s));
-  };
-  auto load_alo1 = [&](const int s) __attribute__((always_inline)) {
-#pragma unroll
-    for (int i = 0; i < TM; ++i) lo_a[i] = *reinterpret_cast<const bf16x8*>(a_ptr1(i, s) + PL_UNITS * 16);
-  };
-  auto load_blo = [&](const int s) __attribute__((always_inline)) {
-    const unsigned char* Bb = b_ptr(s) + BN * 32;
-#pragma unroll
-    for (int j = 0; j < TN; ++j) lo_b[j] = *reinterpret_cast<const bf16x8*>(Bb + j * 1024);
-  };
   auto load_all2 = [&](Hi& H, const int c2) __attribute__((always_inline)) {      // phase 2: plain rows of in2
     const unsigned char* Bb = b_ptr(c2);
 #pragma unroll
@@ -264,38 +243,102 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pl_kernel(const vs_conv_desc_t
 #pragma unroll
       for (int j = 0; j < TN; ++j) acc[i][j] = AR::mfma(H.b[j], H.a[i], acc[i][j]);
   };
-  // DMA issue of step s (before the step's fragment reads), and the wait that makes the operands of the NEXT steps visible.
+  // ---- phase 1.  The K loop is written per CHUNK with its nine taps unrolled and the chunk parity as a template argument: ring stage,
+  // patch buffer, tap offset and swizzle parity of every fragment read are then compile-time constants (per-lane base + immediate), and
+  // the DMA / wait schedule of a step is decided by the compiler -- the first version derived all of that from the step index at run
+  // time (s / 9, tap / 3, s % 6 ...): 41 vector and 50 scalar instructions per step and wave next to 18 MFMAs (tools/pmc_pl.sh).
   // Weights: tile t is issued at step t - (NRING-1) into the stage tile t - NRING left at the previous barrier; at the end of step
   // s everything up to tile s + 2 has landed (tile s + 1 is being read during step s, tile s + 2 will be read during step s + 1
   // after one more barrier): NRING - 3 tiles = (NRING-3) * TN instructions of this wave stay in flight.
   // Patch of chunk cc + 1: issued at taps 0-2 of chunk cc (its buffer was last read before the barrier of (cc-1, tap 7)), waited
   // for at tap 7 (first read: the prefetch during tap 8).
-  auto issue1 = [&](const int s) __attribute__((always_inline)) {
-    if (wave < 4) {
-      if (s + NRING - 1 < n1) dma_w();
-    } else {
-      const int cc = s / 9, tap = s - cc * 9;
-      if (tap < 3 && cc + 1 < spt) dma_patch(cc + 1, tap);
-    }
+  int ab[TM];                                 // hi-plane unit of tap (0,0) of this lane's pixel, swizzle bit for an even patch row offset
+#pragma unroll
+  for (int i = 0; i < TM; ++i) ab[i] = (2 * q0[i] + (g ^ prow[i])) * 16;
+  auto ld_hi = [&](Hi& H, auto parc, auto tapc) __attribute__((always_inline)) {
+    constexpr int PAR = decltype(parc)::value, TAP = decltype(tapc)::value;
+    constexpr int ky = TAP / 3, kx = TAP % 3, STAGE = (PAR * 3 + TAP) % NRING;
+    const unsigned char* Bb = Bring + STAGE * B_STAGE + b_frag;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) H.b[j] = *reinterpret_cast<const bf16x8*>(Bb + j * 1024);
+    const unsigned char* Ps = smem + PAR * P_BYTES + (ky * PPW + kx) * 32;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) H.a[i] = *reinterpret_cast<const bf16x8*>(Ps + ((ky & 1) ? (ab[i] ^ 16) : ab[i]));
   };
-  // (the lgkmcnt wait is the builtin, not an asm statement: hipcc's own waitcnt bookkeeping must see it, otherwise it waits lgkmcnt(0) in
-  // front of the next step's first MFMA -- after that step's prefetch reads have been issued)
-  auto finish1 = [&](const int s) __attribute__((always_inline)) {
+  auto ld_alo = [&](auto parc, auto tapc) __attribute__((always_inline)) {
+    constexpr int PAR = decltype(parc)::value, TAP = decltype(tapc)::value;
+    constexpr int ky = TAP / 3, kx = TAP % 3;
+    const unsigned char* Ps = smem + PAR * P_BYTES + PL_UNITS * 16 + (ky * PPW + kx) * 32;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) lo_a[i] = *reinterpret_cast<const bf16x8*>(Ps + ((ky & 1) ? (ab[i] ^ 16) : ab[i]));
+  };
+  auto ld_blo = [&](auto parc, auto tapc) __attribute__((always_inline)) {
+    constexpr int PAR = decltype(parc)::value, TAP = decltype(tapc)::value;
+    constexpr int STAGE = (PAR * 3 + TAP) % NRING;
+    const unsigned char* Bb = Bring + STAGE * B_STAGE + BN * 32 + b_frag;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) lo_b[j] = *reinterpret_cast<const bf16x8*>(Bb + j * 1024);
+  };
+  using P0 = std::integral_constant<int, 0>;
+  using P1 = std::integral_constant<int, 1>;
+  // one step: chunk cc (parity PAR), tap TAP; `last`: cc is the last chunk of the phase
+  auto tapstep = [&](auto parc, auto tapc, const int cc, const bool last) __attribute__((always_inline)) {
+    constexpr int PAR = decltype(parc)::value, TAP = decltype(tapc)::value;
+    constexpr bool ODD = ((PAR + TAP) & 1) != 0;              // step index cc * 9 + TAP is odd
+    const Hi& Hc = ODD ? H1 : H0;
+    Hi& Hn = ODD ? H0 : H1;
+    const int s = cc * 9 + TAP;
+    // the first group of MFMAs goes out right behind the barrier (its operands are in registers): DMA issue and fragment reads run in its shadow
+    mfma_q0(Hc);
+    __builtin_amdgcn_sched_barrier(0);
+    if (wave < 4) {
+      if (s + NRING - 1 < n1) dma_w(std::integral_constant<int, (PAR * 3 + TAP + NRING - 1) % NRING>{});
+    } else if constexpr (TAP < 3) {
+      if (!last) dma_patch2(cc + 1, 2 * TAP);
+    }
+    if constexpr (TAP < 8) {
+      ld_hi(Hn, parc, std::integral_constant<int, TAP + 1>{});
+      ld_alo(parc, std::integral_constant<int, TAP + 1>{});       // lo_a is dead: its six MFMAs have been issued
+    } else if (!last) {
+      ld_hi(Hn, std::integral_constant<int, 1 - PAR>{}, P0{});
+      ld_alo(std::integral_constant<int, 1 - PAR>{}, P0{});
+    }
+    mfma_q1(Hc);
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (TAP < 8) ld_blo(parc, std::integral_constant<int, TAP + 1>{});
+    else if (!last) ld_blo(std::integral_constant<int, 1 - PAR>{}, P0{});
+    mfma_q2(Hc);
     if (wave < 4) {
       if (s + NRING - 1 < n1) wait_vm<(NRING - 3) * TN>();
       else wait_vm<0>();
-    } else {
-      const int cc = s / 9, tap = s - cc * 9;
-      if (tap == 7 && cc + 1 < spt) wait_vm<0>();      // (nothing else of this wave is in flight)
+    } else if constexpr (TAP == 7) {
+      if (!last) wait_vm<0>();                // the next patch (nothing else of this wave is in flight)
     }
+    // (the builtin, not an asm statement: hipcc's own waitcnt bookkeeping must see it, otherwise it waits lgkmcnt(0) in front of the next
+    // step's first MFMA -- after that step's prefetch reads have been issued)
     __builtin_amdgcn_s_waitcnt(0xC07F);       // this wave's fragment reads have returned: the stages they came from may be refilled
     __builtin_amdgcn_s_barrier();
+  };
+  auto chunk = [&](auto parc, const int cc) __attribute__((always_inline)) {
+    const bool last = cc + 1 >= spt;
+    tapstep(parc, std::integral_constant<int, 0>{}, cc, last);
+    tapstep(parc, std::integral_constant<int, 1>{}, cc, last);
+    tapstep(parc, std::integral_constant<int, 2>{}, cc, last);
+    tapstep(parc, std::integral_constant<int, 3>{}, cc, last);
+    tapstep(parc, std::integral_constant<int, 4>{}, cc, last);
+    tapstep(parc, std::integral_constant<int, 5>{}, cc, last);
+    tapstep(parc, std::integral_constant<int, 6>{}, cc, last);
+    tapstep(parc, std::integral_constant<int, 7>{}, cc, last);
+    tapstep(parc, std::integral_constant<int, 8>{}, cc, last);
   };
 
   // ---- prologue: weight tiles 0 .. NRING-2, patch of chunk 0
   if (wave < 4) {
-#pragma unroll
-    for (int t = 0; t < NRING - 1; ++t) dma_w();             // (n1 >= 9 > NRING - 1)
+    dma_w(std::integral_constant<int, 0>{});                 // (n1 >= 9 > NRING - 1)
+    dma_w(std::integral_constant<int, 1>{});
+    dma_w(std::integral_constant<int, 2>{});
+    dma_w(std::integral_constant<int, 3>{});
+    dma_w(std::integral_constant<int, 4>{});
   } else {
     dma_patch2(0, 0);
     dma_patch2(0, 2);
@@ -304,40 +347,14 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pl_kernel(const vs_conv_desc_t
   wait_vm<0>();
   __builtin_amdgcn_s_barrier();
 
-  int s = 0;
-  load_hi1(H0, 0);
-  load_alo1(0);
-  load_blo(0);
+  ld_hi(H0, P0{}, P0{});
+  ld_alo(P0{}, P0{});
+  ld_blo(P0{}, P0{});
   __builtin_amdgcn_s_waitcnt(0xC07F);         // lgkmcnt(0): otherwise hipcc drains the PREFETCH of every iteration in front of its first MFMA
-  // one phase-1 step on the hi set Hc; MORE: step s + 1 is a phase-1 step whose fragments are read meanwhile (hi set Hn)
-  auto step1 = [&](const Hi& Hc, Hi& Hn, const int s, auto more) __attribute__((always_inline)) {
-    constexpr bool MORE = decltype(more)::value;
-    // the first group of MFMAs goes out right behind the barrier (its operands are in registers): the DMA issue and the address
-    // arithmetic of the next step's fragment reads (~60 scalar / vector instructions) run in its shadow instead of in front of it
-    mfma_q0(Hc);
-    __builtin_amdgcn_sched_barrier(0);
-    issue1(s);
-    if constexpr (MORE) {
-      load_hi1(Hn, s + 1);
-      load_alo1(s + 1);                       // lo_a is dead: its six MFMAs have been issued
-    }
-    mfma_q1(Hc);
-    __builtin_amdgcn_sched_barrier(0);
-    if constexpr (MORE) load_blo(s + 1);
-    mfma_q2(Hc);
-    finish1(s);
-  };
-  for (; s + 2 < n1; s += 2) {
-    step1(H0, H1, s, std::true_type{});
-    step1(H1, H0, s + 1, std::true_type{});
+  for (int cc = 0; cc < spt; cc += 2) {
+    chunk(P0{}, cc);
+    if (cc + 1 < spt) chunk(P1{}, cc + 1);
   }
-  if (s + 1 < n1) {                           // one or two steps are left
-    step1(H0, H1, s, std::true_type{});
-    step1(H1, H0, s + 1, std::false_type{});
-  } else {
-    step1(H0, H1, s, std::false_type{});
-  }
-
   // ---- epilogue state.  Operands are swapped in the MFMA (weights first): element e of acc[i][j] is
   //   channel cbase[j] + (e & 3) + 8 * (e >> 2)   (cbase contains the half-wave's 4 * g),  pixel p0[i]
   // (everything below is re-derived from an opaque copy of the lane id: values shared with the K loop's address set-up would otherwise be
@@ -401,7 +418,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pl_kernel(const vs_conv_desc_t
     wbase = reinterpret_cast<const char*>(d.wt2_blk);
     if (wave < 4) {
       weight_off(n2);
-      for (int t = 0; t < NRING - 1 && t < n2; ++t) dma_w();
+      for (int t = 0; t < NRING - 1 && t < n2; ++t) dma_w2();
     } else {
       q_off();
       for (int c = 0; c < 3 && c < n2; ++c) dma_q(c);
@@ -410,7 +427,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pl_kernel(const vs_conv_desc_t
     __builtin_amdgcn_s_barrier();
     for (int c2 = 0; c2 < n2; ++c2) {
       if (wave < 4) {
-        if (c2 + NRING - 1 < n2) dma_w();
+        if (c2 + NRING - 1 < n2) dma_w2();
       } else if (c2 + 3 < n2) {
         dma_q(c2 + 3);
       }
