@@ -44,7 +44,7 @@ extern "C" {
 #define VS_VIDEO_INTERPOLATE 2   /* videoseal.py:101-117 */
 
 /* library / device introspection */
-int vs_version(void);                       /* ABI version, currently 1 */
+int vs_version(void);                       /* ABI version, currently 2 (round 2: vs_conv_desc_t / vs_model_cfg_t grew the arithmetic and planes fields) */
 const char* vs_arch(void);                  /* "gfx950" */
 const char* vs_error_string(int code);
 int vs_sizeof_conv_desc(void);              /* sizeof(vs_conv_desc_t): lets a binding verify its struct mirror */

@@ -1,7 +1,7 @@
 // Library introspection entry points of libvideoseal_hip.so.
 #include "vs_common.h"
 
-extern "C" int vs_version(void) { return 1; }
+extern "C" int vs_version(void) { return 2; }
 extern "C" const char* vs_arch(void) { return "gfx950"; }
 extern "C" const char* vs_error_string(int code) {
   switch (code) {

@@ -140,6 +140,8 @@ def lib() -> C.CDLL:
     L.vs_bn_partial_doubles.argtypes = [I64, I64]
     L.vs_sizeof_conv_desc.restype = C.c_int
     L.vs_sizeof_tail_desc.restype = C.c_int
+    if L.vs_version() != 2:
+        raise NativeError(f"{LIB_PATH} has ABI version {L.vs_version()}, this binding is written for 2: rebuild (make -C videoseal_amd/csrc)")
     if L.vs_sizeof_conv_desc() != C.sizeof(ConvDesc) or L.vs_sizeof_tail_desc() != C.sizeof(TailDesc):
         raise NativeError("ctypes mirrors of vs_conv_desc_t / vs_tail_desc_t are out of date with the shared library")
     _lib = L
