@@ -552,7 +552,7 @@ struct Runner {
       const bool pl1 = m->arith == 2 && ((rows + 255) / 256) * ((4 * Cc + 191) / 192) >= 200 && pw1w.CinP % 16 == 0 && !m->stages[sti].empty();
       bool pl2 = false;
       int sk2 = 1;
-      if (m->arith == 2 && hh.ld >= 3072 && hh.ld % 16 == 0) {
+      if (m->arith == 2 && hh.ld >= 2048 && hh.ld % 16 == 0) {
         const int64_t tiles2 = ((rows + 255) / 256) * ((Cc + 191) / 192);
         const int steps2 = hh.ld / 16;
         while (tiles2 * sk2 < 200 && steps2 / (sk2 * 2) >= 24 && steps2 % (sk2 * 2) == 0) sk2 *= 2;

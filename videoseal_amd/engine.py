@@ -830,12 +830,12 @@ class HipEngine:
             part = self.buf(f"st{sti}.gp", nchunk * B * 4 * Cc)
             scale = self.buf(f"st{sti}.gs", B * hh.ld + 16)   # +16: the conv A-transform reads whole 16-float chunks
             # all-DMA GEMM on operand planes (gemm_pl.hip, tile code 24) where its 256-row tiles give every CU work: pwconv1 reads the
-            # LayerNorm output as f16 planes written by the dwconv kernel itself; pwconv2 only for long K (K >= 3072: the GRN apply then
+            # LayerNorm output as f16 planes written by the dwconv kernel itself; pwconv2 only for long K (K >= 2048: the GRN apply then
             # runs in a separate conversion pass, which costs more than it saves on the shorter layers -- tools/bench_gemm.py planes)
             pw1w = X["stages"][sti][0]["pw1"]
             pl1 = self._gemm_planes_ok(cur.rows, 4 * Cc) and pw1w.CinP % 16 == 0
             pl2, sk2 = False, 1
-            if self.planes_gemm and self.use_split and self.arith == 2 and hh.ld >= 3072 and hh.ld % 16 == 0:
+            if self.planes_gemm and self.use_split and self.arith == 2 and hh.ld >= 2048 and hh.ld % 16 == 0:
                 tiles2 = ((cur.rows + 255) // 256) * ((Cc + 191) // 192)
                 steps2 = hh.ld // 16
                 while tiles2 * sk2 < 200 and steps2 // (sk2 * 2) >= 24 and steps2 % (sk2 * 2) == 0:
