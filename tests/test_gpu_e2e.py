@@ -153,6 +153,29 @@ def test_vs10_every_arithmetic_matches_reference_golden(monkeypatch, mode, name)
     _run_case(s, sd, m, name)
 
 
+def test_f16_range_overflow_is_loud_not_silent(monkeypatch):
+    """2 x f16 arithmetic: an activation beyond the f16 range of the operand split becomes inf / NaN (never a silently wrong finite
+    number); VIDEOSEAL_CHECK_FINITE=1 turns that into an exception, and the exact 3 x bf16 split runs the same weights."""
+    spec = tiny_spec()
+    sd = make_state_dict(spec, seed=3)
+    big = {k: (v * 3e4 if k.endswith("inc.double_conv.0.weight") else v) for k, v in sd.items()}      # first conv: activations ~1e4..1e5
+    imgs = synthetic_frames(2, 64, 64, seed=8).cuda()
+    msgs = synthetic_msgs(2, spec.nbits, seed=8)
+    monkeypatch.setenv("VIDEOSEAL_CHECK_FINITE", "1")
+    monkeypatch.setenv("VIDEOSEAL_CONV", "f16x2")
+    m = make_model(spec, big)
+    with pytest.raises(videoseal_amd.native.NativeError, match="bf16x3"):
+        m.embed(imgs, msgs, is_video=False)
+    monkeypatch.setenv("VIDEOSEAL_CHECK_FINITE", "0")          # without the check the NaN reaches the caller (ReLU / clamp let it through)
+    m0 = make_model(spec, big)
+    assert not torch.isfinite(m0.embed(imgs, msgs, is_video=False)["imgs_w"]).all()
+    monkeypatch.setenv("VIDEOSEAL_CHECK_FINITE", "1")
+    monkeypatch.setenv("VIDEOSEAL_CONV", "bf16x3")
+    m3 = make_model(spec, big)
+    out = m3.embed(imgs, msgs, is_video=False)["imgs_w"]
+    assert torch.isfinite(out).all()
+
+
 def test_bottleneck_planes_chain_is_bit_identical(vs10):
     """26 frames at the processing size give the all-DMA planes kernel a workgroup per CU, so the engine runs the bottleneck chain on
     pre-split operand planes (engine.bottleneck_planes); same products, same K order, same scaling as the per-conv path: bit-identical."""

@@ -103,7 +103,7 @@ __device__ __forceinline__ void apply_act_all(f32x16 (&acc)[TM][TN], const float
 #pragma unroll
       for (int j = 0; j < TN; ++j)
 #pragma unroll
-        for (int e = 0; e < 16; ++e) acc[i][j][e] = fmaxf(acc[i][j][e] + b1[j], 0.f) + b2[j];
+        for (int e = 0; e < 16; ++e) acc[i][j][e] = vs_relu(acc[i][j][e] + b1[j]) + b2[j];
   } else if (act == VS_ACT_GELU) {
 #pragma unroll
     for (int i = 0; i < TM; ++i)

@@ -342,7 +342,7 @@ __global__ __launch_bounds__(256) void splitk_epilogue_kernel(const vs_conv_desc
     const int n = n4 + c;
     if (n >= d.N) { v[c] = 0.f; continue; }
     float t = v[c] + (d.bias ? d.bias[n] : 0.f);
-    if (d.act == VS_ACT_RELU) t = fmaxf(t, 0.f);
+    if (d.act == VS_ACT_RELU) t = vs_relu(t);
     else if (d.act == VS_ACT_GELU) t = vs_gelu(t);
     else if (d.act == VS_ACT_TANH) t = tanhf(t);
     if (d.in2) t += d.splitk_ws[((int64_t)d.split_k * M + m) * d.splitk_ld + n] + (d.bias2 ? d.bias2[n] : 0.f);

@@ -505,7 +505,7 @@ __global__ __launch_bounds__(256) void embed_tail_kernel(TailArgs a, JndTaps k) 
       for (int c = 0; c < 3; ++c) {
         float v = a.scaling_i * px[q][c] + a.scaling_w * d[a.Cd == 1 ? 0 : c];
         if (fwd_order) v = px[q][c] + hm * (v - px[q][c]);
-        if (a.clamp) v = fminf(fmaxf(v, 0.f), 1.f);
+        if (a.clamp) v = v <= 0.f ? 0.f : (v >= 1.f ? 1.f : v);      // (NaN passes: fminf / fmaxf would turn it into 0)
         Px<T>::st(outf, plane, c, pix, v);
       }
     }

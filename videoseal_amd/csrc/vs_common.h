@@ -64,9 +64,13 @@ __device__ __forceinline__ float vs_gelu(float v) {
   return fmaxf(v, 0.f) - (0.5f * a) * e;
 }
 
+// ReLU that lets NaN through (fmaxf / `v > 0 ? v : 0` turn it into 0): an out-of-range operand of the 2 x f16 arithmetic must surface as
+// NaN in the output, not as a silently wrong finite number
+__device__ __forceinline__ float vs_relu(float v) { return v <= 0.f ? 0.f : v; }
+
 __device__ __forceinline__ float vs_apply_act(float v, int act) {
   switch (act) {
-    case VS_ACT_RELU: return v > 0.f ? v : 0.f;
+    case VS_ACT_RELU: return vs_relu(v);
     case VS_ACT_GELU: return vs_gelu(v);
     case VS_ACT_TANH: return tanhf(v);
     case VS_ACT_SILU: return v / (1.0f + __expf(-v));       // nn.SiLU: x * sigmoid(x)

@@ -186,6 +186,9 @@ class HipEngine:
         self.msg_table_conv = os.environ.get("VIDEOSEAL_MSG_TABLE", "1") != "0"         # first bottleneck block: message channels as a table
         self.planes_chain = os.environ.get("VIDEOSEAL_PLANES", "1") != "0"              # bottleneck chain on pre-split operand planes
         self.planes_gemm = os.environ.get("VIDEOSEAL_PLANES", "1") != "0"               # ConvNeXt 1x1 GEMMs on operand planes
+        # VIDEOSEAL_CHECK_FINITE=1: synchronise after every network pass and raise if the output is not finite -- the 2 x f16 arithmetic
+        # turns an activation beyond its f16 range (|a| * a_mul >= 65520) into inf / NaN instead of a silently wrong number
+        self.check_finite = os.environ.get("VIDEOSEAL_CHECK_FINITE", "0") == "1"
         # per-shape tile selection: every candidate walks K in the same order, so the result is bit-identical whatever
         # tile wins -- only speed changes (measure, don't guess).  VIDEOSEAL_AUTOTUNE=0 keeps the static heuristic.
         self.autotune = os.environ.get("VIDEOSEAL_AUTOTUNE", "1") != "0"
@@ -662,6 +665,13 @@ class HipEngine:
                   n_store=(cout if out.ld != rup(cout, 4) else None))
         return out
 
+    def _finite(self, t: torch.Tensor, what: str) -> torch.Tensor:
+        if self.check_finite and not bool(torch.isfinite(t).all()):
+            raise N.NativeError(f"{what}: non-finite output. With the 2 x f16 arithmetic (VIDEOSEAL_CONV=f16x2, the default) an activation "
+                                f"outside the f16 range of the operand split (|a| >= {65520.0 / A_MUL:.0f}; {65520.0 / A_MUL_GRN:.0f} for the GRN-scaled "
+                                f"pwconv2 input) becomes inf; VIDEOSEAL_CONV=bf16x3 selects the range-free exact split.")
+        return t
+
     def _gemm_planes_ok(self, rows: int, n: int) -> bool:
         """1x1 GEMM on operand planes (gemm_pl.hip): 2 x f16 arithmetic and enough 256-row x 192-column tiles for the 256 CUs"""
         return self.planes_gemm and self.use_split and self.arith == 2 and ((rows + 255) // 256) * ((n + 191) // 192) >= 200
@@ -794,7 +804,7 @@ class HipEngine:
         delta = self.buf("delta", B * c.out_ch * xcur.H * xcur.W)
         N.check(L.vs_outc_tanh(N.ptr(xcur.t), xcur.H * xcur.W, B, xcur.C, xcur.ld, N.ptr(E["outc_w"]), N.ptr(E["outc_b"]), c.out_ch,
                                1 if c.last_tanh else 0, N.ptr(delta), st), "vs_outc_tanh")
-        return delta.view(B, c.out_ch, xcur.H, xcur.W)
+        return self._finite(delta, "embedder").view(B, c.out_ch, xcur.H, xcur.W)
 
     # ------------------------------------------------------------------ extractor
     def extractor_forward(self, x: Act) -> torch.Tensor:
@@ -871,7 +881,7 @@ class HipEngine:
                           # than the GEMM with the fused transform, whose frame-boundary select costs registers
                     N.check(L.vs_grn_apply(N.ptr(hh.t), B, HW, 4 * Cc, hh.ld, N.ptr(scale), hh.ld, N.ptr(blk["beta"]), st), "vs_grn_apply")
                     self.conv(hh, blk["pw2"], cur, res=cur, a_mul=A_MUL_GRN)
-        return self._pixel_decoder(cur, X)
+        return self._finite(self._pixel_decoder(cur, X), "extractor")
 
     def _pixel_decoder(self, cur: Act, X) -> torch.Tensor:
         """pixel_decoder.py:61-83 with upscale_stages [1]: reflect-pad conv3x3 -> LayerNorm(cf) -> GELU -> mean(H, W) -> Linear."""
