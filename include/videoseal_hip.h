@@ -51,9 +51,10 @@ int vs_sizeof_conv_desc(void);              /* sizeof(vs_conv_desc_t): lets a bi
 int vs_sizeof_tail_desc(void);              /* sizeof(vs_tail_desc_t) */
 
 /*
- * Implicit-GEMM convolution on the matrix cores, fp32 in / fp32 out.  Two arithmetic back-ends with
- * fp32-rounding-level accuracy: v_mfma_f32_32x32x2_f32 (exact fmaf chain, 157 TF) and the "3 x bf16" split
- * (every operand = sum of three bf16 terms, six v_mfma_f32_32x32x16_bf16 per K chunk, 2.67x faster):
+ * Implicit-GEMM convolution on the matrix cores, fp32 in / fp32 out.  Three arithmetic back-ends with
+ * fp32-rounding-level accuracy: v_mfma_f32_32x32x2_f32 (exact fmaf chain, 157 TF), the "3 x bf16" split
+ * (every operand = sum of three bf16 terms, six v_mfma_f32_32x32x16_bf16 per K chunk, 2.67x faster) and the "2 x f16" split
+ * (arith = 2: two round-to-nearest f16 terms with power-of-two range scaling, three v_mfma_f32_32x32x16_f16 per K chunk):
  *   out[m, n] = epilogue( sum_k A[m,k] * wt[n,k] )    m = (b, oy, ox), n = output channel
  * Replaces every dense conv / nn.Linear of the path:
  *   unet.py:24-39 (ResnetBlock 3x3 + folded BN + ReLU, fused 1x1 res_conv via phase 2),

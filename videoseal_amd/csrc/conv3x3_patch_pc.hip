@@ -1,6 +1,6 @@
 // Wave-specialised version of the 3x3 patch kernel (conv3x3_patch.hip): 512 threads, one workgroup per CU.
-//   waves 0-3  consumers : nothing but ds_read_b128 fragment loads and v_mfma_f32_32x32x16_bf16 (3 x bf16 split, 6 MFMAs
-//                          per 32x32x16 block).  Fragments are double-buffered in registers: while the MFMAs of tap-step s
+//   waves 0-3  consumers : nothing but ds_read_b128 fragment loads and MFMAs (template NP: 3 x bf16 split, 6 v_mfma_f32_32x32x16_bf16
+//                          per 32x32x16 block; 2 x f16 split, 3 v_mfma_f32_32x32x16_f16 -- conv_common.h).  Fragments are double-buffered in registers: while the MFMAs of tap-step s
 //                          run, the fragment reads of step s+1 are already in flight (its weight tile was published one
 //                          barrier earlier, its A rows come from the resident input patch), so the matrix pipe does not
 //                          drain at the barriers.

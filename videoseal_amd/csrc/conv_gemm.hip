@@ -2,9 +2,11 @@
 //
 //   out[m][n] = epilogue( sum_k A[m][k] * wt[n][k] ),  m = (frame, oy, ox) row-major, k = (tap, channel)
 //
-// Two arithmetic back-ends (template parameter SPLIT), both with fp32-rounding-level accuracy:
-//   SPLIT = false : v_mfma_f32_32x32x2_f32 -- exact fmaf chain at the f32 vector rate (157 TF peak).
-//   SPLIT = true  : "3 x bf16".  Every fp32 operand is split EXACTLY into three bf16 terms by truncation,
+// Three arithmetic back-ends (template parameter NPL = number of 16-bit operand planes), all with fp32-rounding-level accuracy:
+//   NPL = 0 : v_mfma_f32_32x32x2_f32 -- exact fmaf chain at the f32 vector rate (157 TF peak).
+//   NPL = 2 : "2 x f16" (the default): round-to-nearest split into two f16 terms with power-of-two range scaling, three partial
+//             products per K chunk on v_mfma_f32_32x32x16_f16 -- see conv_common.h (Arith<2>) for the error analysis and the probe.
+//   NPL = 3 : "3 x bf16".  Every fp32 operand is split EXACTLY into three bf16 terms by truncation,
 //                   x = x1 + x2 + x3 (8+8+8 mantissa bits), and a product is accumulated as its six partial products
 //                   of weight >= 2^-16:  a1b1 + (a1b2 + a2b1) + (a2b2 + a1b3 + a3b1)   (dropped: <= 2^-24 |ab|),
 //                   each one v_mfma_f32_32x32x16_bf16 with fp32 accumulation.  bf16 MFMA has 16x the rate of the

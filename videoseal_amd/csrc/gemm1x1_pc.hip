@@ -1,7 +1,7 @@
 // Wave-specialised GEMM for the 1x1 convolutions (ConvNeXt pwconv1 / pwconv2 of the extractor, convnext.py:96-105 of the
 // reference): out[M][N] = act(A'[M][K] * W[N][K]^T + bias) (+ res),  A' = A or A * grn_scale[frame] + grn_shift.
-// fp32 operands, exact 3 x bf16 split, 6 v_mfma_f32_32x32x16_bf16 per 32x32x16 block, fp32 accumulate -- the same
-// arithmetic and the same K order as conv_gemm_kernel<.., SPLIT = true>, so results are bit-identical to it (split_k = 1).
+// fp32 operands, split arithmetic of conv_common.h (template NP: 2 x f16 = 3 MFMAs, 3 x bf16 = 6 MFMAs per 32x32x16 block), fp32
+// accumulate -- the same arithmetic and the same K order as conv_gemm_kernel of the same NP, so results are bit-identical to it (split_k = 1).
 //
 // 512 threads, one workgroup per CU, one s_barrier per 16-wide K step:
 //   waves 0-3  consumers   : 2 x 2 waves, 64 rows x 32*TN columns each; fragment reads (ds_read_b128) of step s+1 are in
