@@ -33,3 +33,15 @@ def check_sub(g, prefix, t, atol, what=""):
 def psnr_np(a, b):
     d = (255.0 * (a.double() - b.double()))
     return float(20 * np.log10(255.0) - 10 * torch.log10((d ** 2).mean()))
+
+
+# ---- backward fixtures (tests/golden/make_golden_bwd.py): per-parameter gradient summaries
+BWD_FULL = ("embedder.unet.outc.weight", "embedder.unet.msg_processor.msg_embeddings.weight", "detector.pixel_decoder.linear.weight",
+            "detector.pixel_decoder.linear.bias", "embedder.unet.inc.double_conv.1.weight")
+
+
+def projection_vector(name: str, numel: int):
+    """+-1 vector seeded by the parameter name (torch's CPU mt19937 stream for randint: stable across runs and platforms)"""
+    import torch
+    g = torch.Generator().manual_seed(sum(name.encode()) * 7919 + numel)
+    return (torch.randint(0, 2, (numel,), generator=g, dtype=torch.int64) * 2 - 1).double()
