@@ -183,6 +183,14 @@ int64_t vs_bn_partial_doubles(int64_t rows, int64_t ld);
 int vs_bn_batch_stats(const float* x, int64_t rows, int C, int64_t ld, const float* gamma, const float* beta, float eps,
                       float momentum, float* running_mean, float* running_var, double* partial, float* scale, float* shift,
                       void* stream);
+/* The same in two halves for nn.SyncBatchNorm (train.py:438-440 converts the model when training is distributed; torch's
+ * SyncBatchNorm normalises with the statistics of the GLOBAL batch and updates the running statistics with the global unbiased variance):
+ * vs_bn_partial_sums writes sums = [sum x (ld) | sum x^2 (ld) | rows] = 2*ld + 1 doubles for the local rows; the host all-reduces that
+ * vector over the ranks (RCCL, fp64 sum) and vs_bn_finish_sums turns it into scale / shift and the running-statistics update.  Without
+ * the all-reduce the pair is bit-identical to vs_bn_batch_stats (same summation order). */
+int vs_bn_partial_sums(const float* x, int64_t rows, int C, int64_t ld, double* partial, double* sums, void* stream);
+int vs_bn_finish_sums(const double* sums, int C, int64_t ld, const float* gamma, const float* beta, float eps, float momentum,
+                      float* running_mean, float* running_var, float* scale, float* shift, void* stream);
 /* out = act(x * scale[c] + shift[c]) (+ add): the normalisation + ReLU (+ res_conv branch, unet.py:38-39) of a train-mode ResnetBlock.
  * C % 4 == 0. */
 int vs_scale_shift_act(const float* x, int64_t rows, int C, int64_t ld, const float* scale, const float* shift, int act,

@@ -71,3 +71,48 @@ def test_shard_alignment_rules():
         check_alignment(SimpleNamespace(step_size=3, chunk_size=8, video_mode="repeat"), 16)
     with pytest.raises(ValueError, match="interpolate"):
         check_alignment(SimpleNamespace(step_size=4, chunk_size=32, video_mode="interpolate"), 16)
+
+
+# ---- SyncBatchNorm exchange (train.py:438-440): one all-reduce of [sum x | sum x^2 | rows] per BatchNorm layer
+def _bn_worker(rank, world, port, q):
+    from videoseal_amd.dist import bn_all_reduce
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(11, 8, generator=g).double() * 3 + 1       # the global batch: 11 rows of 8 channels, ragged split 7 + 4
+    mine = x[:7] if rank == 0 else x[7:]
+    sums = torch.cat([mine.sum(0), (mine * mine).sum(0), torch.tensor([float(mine.shape[0])], dtype=torch.float64)])
+    bn_all_reduce()(sums)
+    n = float(sums[-1])
+    mean, var = sums[:8] / n, sums[8:16] / n - (sums[:8] / n) ** 2
+    q.put((rank, n, float((mean - x.mean(0)).abs().max()), float((var - x.var(0, unbiased=False)).abs().max())))
+    dist.destroy_process_group()
+
+
+def test_sync_batchnorm_exchange_world2():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_bn_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, n, dm, dv in res:
+        assert n == 11.0 and dm < 1e-12 and dv < 1e-12, (rank, n, dm, dv)      # every rank ends with the GLOBAL batch statistics
+
+
+def test_sync_batchnorm_conversion_is_host_state_only():
+    from types import SimpleNamespace
+    from videoseal_amd.dist import bn_all_reduce, convert_sync_batchnorm
+    m = SimpleNamespace(_bn_sync=None)
+    assert convert_sync_batchnorm(m) is m and callable(m._bn_sync)
+    v = torch.arange(5, dtype=torch.float64)
+    m._bn_sync(v)                                                # no process group: the local statistics are the global ones
+    assert torch.equal(v, torch.arange(5, dtype=torch.float64))
+    with pytest.raises(ValueError, match="float64"):
+        bn_all_reduce()(torch.zeros(5))
+    marker = lambda s: None                                      # noqa: E731
+    assert convert_sync_batchnorm(m, reduce_=marker)._bn_sync is marker

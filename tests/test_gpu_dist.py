@@ -55,3 +55,142 @@ def test_bench_distributed_step_on_one_gpu():
     assert r.returncode == 0, r.stderr[-2000:]
     line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
     assert line["n_gpus"] == 1 and line["value"] > 0 and "all-gather" in line["config"]["workload"]
+
+
+# ---- SyncBatchNorm (train.py:438-440): BatchNorm statistics of the global batch, one all-reduce of fp64 moments per layer
+def test_bn_partial_sums_add_up_to_the_batch_statistics():
+    """vs_bn_partial_sums on two ragged halves, added, then vs_bn_finish_sums == vs_bn_batch_stats on the whole tensor; on one piece the
+    pair is bit-identical to it (same summation order)."""
+    from videoseal_amd import native as N
+    L = N.lib()
+    st = N.stream()
+    g = torch.Generator().manual_seed(3)
+    rows, C, ld = 5000, 20, 24
+    x = torch.zeros(rows, ld)
+    x[:, :C] = torch.randn(rows, C, generator=g) * 2 + 0.5
+    x = x.cuda()
+    gamma, beta = torch.rand(ld, generator=g).cuda() + 0.5, torch.randn(ld, generator=g).cuda()
+
+    def fresh():
+        return torch.zeros(ld).cuda(), torch.ones(ld).cuda(), torch.empty(ld).cuda(), torch.empty(ld).cuda()
+
+    def part(t):
+        return torch.empty(int(L.vs_bn_partial_doubles(t.shape[0], ld)), dtype=torch.float64, device="cuda")
+    rm0, rv0, sc0, sh0 = fresh()
+    N.check(L.vs_bn_batch_stats(N.ptr(x), rows, C, ld, N.ptr(gamma), N.ptr(beta), 1e-5, 0.1, N.ptr(rm0), N.ptr(rv0), N.ptr(part(x)),
+                                N.ptr(sc0), N.ptr(sh0), st), "vs_bn_batch_stats")
+    # one piece: bit-identical
+    sums = torch.empty(2 * ld + 1, dtype=torch.float64, device="cuda")
+    rm1, rv1, sc1, sh1 = fresh()
+    N.check(L.vs_bn_partial_sums(N.ptr(x), rows, C, ld, N.ptr(part(x)), N.ptr(sums), st), "vs_bn_partial_sums")
+    assert float(sums[-1]) == rows
+    N.check(L.vs_bn_finish_sums(N.ptr(sums), C, ld, N.ptr(gamma), N.ptr(beta), 1e-5, 0.1, N.ptr(rm1), N.ptr(rv1), N.ptr(sc1), N.ptr(sh1), st),
+            "vs_bn_finish_sums")
+    for a, b in ((rm0, rm1), (rv0, rv1), (sc0, sc1), (sh0, sh1)):
+        assert torch.equal(a[:C], b[:C])
+    # two ragged pieces (3000 + 2000 rows), moments added as the all-reduce does
+    xa, xb = x[:3000].contiguous(), x[3000:].contiguous()
+    sa, sb = torch.empty_like(sums), torch.empty_like(sums)
+    N.check(L.vs_bn_partial_sums(N.ptr(xa), 3000, C, ld, N.ptr(part(xa)), N.ptr(sa), st), "vs_bn_partial_sums")
+    N.check(L.vs_bn_partial_sums(N.ptr(xb), 2000, C, ld, N.ptr(part(xb)), N.ptr(sb), st), "vs_bn_partial_sums")
+    tot = sa + sb
+    assert float(tot[-1]) == rows and ((tot[:C] - sums[:C]).abs() <= 1e-12 * sums[:C].abs() + 1e-9).all()
+    rm2, rv2, sc2, sh2 = fresh()
+    N.check(L.vs_bn_finish_sums(N.ptr(tot), C, ld, N.ptr(gamma), N.ptr(beta), 1e-5, 0.1, N.ptr(rm2), N.ptr(rv2), N.ptr(sc2), N.ptr(sh2), st),
+            "vs_bn_finish_sums")
+    for a, b in ((rm0, rm2), (rv0, rv2), (sc0, sc2), (sh0, sh2)):
+        assert (a[:C] - b[:C]).abs().max() <= 3e-7 * a[:C].abs().max()
+    # and against torch's own batch statistics
+    xc = x[:, :C].double()
+    mean, var = xc.mean(0), xc.var(0, unbiased=False)
+    assert (sc2[:C].double() - gamma[:C].double() / torch.sqrt(var + 1e-5)).abs().max() < 1e-6
+    assert (rm2[:C].double() - 0.1 * mean).abs().max() < 1e-6
+    assert (rv2[:C].double() - (0.9 + 0.1 * xc.var(0, unbiased=True))).abs().max() < 1e-5
+
+
+def _train_forward(model, imgs, msgs):
+    from videoseal_amd import augmentation as G
+    model.augmenter = G.Augmenter(masks={"kind": "none"}, augs={"identity": 1}, augs_params={}, num_augs=1)
+    model.train()
+    return model(imgs, torch.ones(imgs.shape[0], 1, *imgs.shape[-2:], device=imgs.device), msgs, is_video=False)
+
+
+def _bn_buffers(model):
+    sd = model.state_dict()
+    return torch.cat([v.flatten().float() for k, v in sd.items() if k.endswith(("running_mean", "running_var"))]).cpu()
+
+
+def test_sync_batchnorm_world1_over_rccl_is_bit_identical():
+    import torch.distributed as dist
+    from videoseal_amd.dist import convert_sync_batchnorm
+    spec = tiny_spec()
+    sd = make_state_dict(spec, seed=3)
+    imgs, msgs = synthetic_frames(4, 72, 88, seed=31).cuda(), synthetic_msgs(4, spec.nbits, seed=31)
+    model = make_model(spec, sd)              # ONE instance for both runs: the same tile choices, so the comparison can be bit-exact
+    ref = {k: v.clone() for k, v in _train_forward(model, imgs, msgs).items() if k in ("imgs_w", "preds_w")}
+    ref_bn = _bn_buffers(model)
+    model.load_state_dict(sd, strict=True)    # running statistics back to their initial values
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        convert_sync_batchnorm(model)
+        calls = []
+        inner = model._bn_sync
+        model._bn_sync = lambda s: (calls.append(s.numel()), inner(s))[1]          # fp64 all-reduce on the RCCL communicator
+        out = _train_forward(model, imgs, msgs)
+        torch.cuda.synchronize()
+    finally:
+        dist.destroy_process_group()
+    assert len(calls) > 0 and all(n % 2 == 1 for n in calls)             # one exchange of 2*ld + 1 doubles per BatchNorm layer
+    assert torch.equal(out["imgs_w"], ref["imgs_w"]) and torch.equal(out["preds_w"], ref["preds_w"])
+    assert torch.equal(_bn_buffers(model), ref_bn)
+
+
+def test_sync_batchnorm_two_ranks_reproduce_the_global_batch():
+    """Two model replicas on this GPU, each holding a ragged half of the batch (3 + 1 frames), run in lock step on two host threads; the
+    exchange adds their fp64 moment vectors (what the all-reduce does).  Every rank must produce its slice of the single-process result on
+    the whole batch -- which tests/test_gpu_fwd.py pins to the reference's train-mode forward -- and identical running statistics."""
+    import threading
+    from videoseal_amd.dist import convert_sync_batchnorm
+    spec = tiny_spec()
+    sd = make_state_dict(spec, seed=3)
+    imgs, msgs = synthetic_frames(4, 72, 88, seed=31).cuda(), synthetic_msgs(4, spec.nbits, seed=31)
+    plain = make_model(spec, sd)
+    ref = {k: v.clone() for k, v in _train_forward(plain, imgs, msgs).items() if k in ("imgs_w", "preds_w")}
+    world, cuts = 2, [(0, 3), (3, 4)]
+    bar = threading.Barrier(world, timeout=120)
+    slots = [None] * world
+
+    def reducer(rank):
+        def reduce_(s):
+            slots[rank] = s
+            bar.wait()
+            tot = slots[0] + slots[1]          # same order on every rank; all launches share the default stream
+            bar.wait()
+            s.copy_(tot)
+        return reduce_
+    models = [convert_sync_batchnorm(make_model(spec, sd), reduce_=reducer(r)) for r in range(world)]
+    outs, errs = [None] * world, []
+
+    def run(rank):
+        try:
+            a, b = cuts[rank]
+            outs[rank] = _train_forward(models[rank], imgs[a:b], msgs[a:b])
+        except BaseException as e:       # noqa: BLE001 -- reported below; a broken barrier releases the other thread
+            errs.append((rank, repr(e)))
+            bar.abort()
+    ths = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+    for t in ths:
+        t.start()
+    for t in ths:
+        t.join(timeout=300)
+    assert not errs and all(o is not None for o in outs), errs
+    torch.cuda.synchronize()
+    for (a, b), o in zip(cuts, outs):
+        assert (o["preds_w"] - ref["preds_w"][a:b]).abs().max() <= 1e-5 * ref["preds_w"].abs().max()     # (tile choices may differ with the batch size)
+        assert (o["imgs_w"] - ref["imgs_w"][a:b]).abs().max() <= 1e-5
+    b0, b1, bp = _bn_buffers(models[0]), _bn_buffers(models[1]), _bn_buffers(plain)
+    assert torch.equal(b0, b1)
+    assert (b0 - bp).abs().max() <= 1e-5 * bp.abs().max()
+    local_only = _train_forward(make_model(spec, sd), imgs[:3], msgs[:3])           # without the exchange the result differs
+    assert (local_only["preds_w"] - ref["preds_w"][:3]).abs().max() > 1e-4 * ref["preds_w"].abs().max()

@@ -696,12 +696,12 @@ __global__ __launch_bounds__(256) void bn_finish_kernel(const double* __restrict
                                                         const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
                                                         float momentum, float* __restrict__ running_mean,
                                                         float* __restrict__ running_var, float* __restrict__ scale,
-                                                        float* __restrict__ shift) {
+                                                        float* __restrict__ shift, const double* __restrict__ count) {
   const int c = blockIdx.x * 256 + threadIdx.x;
   if (c >= C) return;
   double s = 0, q = 0;
   for (int k = 0; k < nchunk; ++k) { s += partial[((int64_t)k * 2 + 0) * ld + c]; q += partial[((int64_t)k * 2 + 1) * ld + c]; }
-  const double n = (double)rows;
+  const double n = count ? *count : (double)rows;      // SyncBatchNorm: the row count of ALL ranks, reduced with the sums
   const double mean = s / n;
   double var = q / n - mean * mean;
   if (var < 0) var = 0;
@@ -710,6 +710,18 @@ __global__ __launch_bounds__(256) void bn_finish_kernel(const double* __restrict
   shift[c] = beta[c] - (float)mean * sc;
   if (running_mean) running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mean;
   if (running_var) running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)(n > 1 ? var * n / (n - 1) : var);
+}
+// SyncBatchNorm's local half: the chunk partials of bn_partial_kernel summed in the same fixed order as bn_finish_kernel does, into
+// sums = [sum x | sum x^2 | rows] = 2*ld + 1 doubles -- the vector the ranks all-reduce (train.py:438-440).
+__global__ __launch_bounds__(256) void bn_reduce_kernel(const double* __restrict__ partial, int nchunk, int64_t rows, int64_t ld,
+                                                        double* __restrict__ sums) {
+  const int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (c == 0) sums[2 * ld] = (double)rows;
+  if (c >= ld) return;
+  double s = 0, q = 0;
+  for (int k = 0; k < nchunk; ++k) { s += partial[((int64_t)k * 2 + 0) * ld + c]; q += partial[((int64_t)k * 2 + 1) * ld + c]; }
+  sums[c] = s;
+  sums[ld + c] = q;
 }
 // out[r][c] = act(x[r][c] * scale[c] + shift[c]) (+ add[r][c]);  C % 4 == 0
 __global__ __launch_bounds__(256) void scale_shift_act_kernel(const float* __restrict__ x, int64_t rows, int C, int64_t ld,
@@ -963,7 +975,24 @@ extern "C" int vs_bn_batch_stats(const float* x, int64_t rows, int C, int64_t ld
   const int nchunk = (int)cdiv64(rows, BN_ROWS);
   hipLaunchKernelGGL(bn_partial_kernel, dim3((unsigned)nchunk), dim3(256), 0, (hipStream_t)stream, x, rows, ld, partial);
   hipLaunchKernelGGL(bn_finish_kernel, dim3((unsigned)((C + 255) / 256)), dim3(256), 0, (hipStream_t)stream, partial, nchunk, rows, C, ld,
-                     gamma, beta, eps, momentum, running_mean, running_var, scale, shift);
+                     gamma, beta, eps, momentum, running_mean, running_var, scale, shift, (const double*)nullptr);
+  return vs_launch_status();
+}
+
+extern "C" int vs_bn_partial_sums(const float* x, int64_t rows, int C, int64_t ld, double* partial, double* sums, void* stream) {
+  VS_REQUIRE(x && partial && sums && rows > 0 && C > 0 && ld >= C && (ld & 3) == 0);
+  VS_REQUIRE((((uintptr_t)x) & 15) == 0);
+  const int nchunk = (int)cdiv64(rows, BN_ROWS);
+  hipLaunchKernelGGL(bn_partial_kernel, dim3((unsigned)nchunk), dim3(256), 0, (hipStream_t)stream, x, rows, ld, partial);
+  hipLaunchKernelGGL(bn_reduce_kernel, dim3((unsigned)((ld + 255) / 256)), dim3(256), 0, (hipStream_t)stream, partial, nchunk, rows, ld, sums);
+  return vs_launch_status();
+}
+
+extern "C" int vs_bn_finish_sums(const double* sums, int C, int64_t ld, const float* gamma, const float* beta, float eps, float momentum,
+                                 float* running_mean, float* running_var, float* scale, float* shift, void* stream) {
+  VS_REQUIRE(sums && gamma && beta && scale && shift && C > 0 && ld >= C);
+  hipLaunchKernelGGL(bn_finish_kernel, dim3((unsigned)((C + 255) / 256)), dim3(256), 0, (hipStream_t)stream, sums, 1, (int64_t)0, C, ld,
+                     gamma, beta, eps, momentum, running_mean, running_var, scale, shift, sums + 2 * ld);
   return vs_launch_status();
 }
 

@@ -82,3 +82,25 @@ def embed_sharded(model, local_frames: torch.Tensor, msgs: torch.Tensor, align: 
     disjoint file ranges)."""
     check_alignment(model, align)
     return model.embed(local_frames, msgs, is_video=True, **kw)["imgs_w"]
+
+
+# ---- training under torch.distributed (SURVEY.md 8(f)1; train.py:437-448) ------------------------------------------------------------
+def bn_all_reduce(group=None):
+    """The exchange step of SyncBatchNorm as this library does it: every BatchNorm layer all-reduces ONE vector of 2*ld + 1 doubles --
+    [sum x | sum x^2 | rows] of the local rows (csrc/net_ops.hip::vs_bn_partial_sums) -- and normalises with the statistics of the global
+    batch (vs_bn_finish_sums).  torch's SyncBatchNorm all-gathers (mean, invstd, count) per rank and merges them; summing fp64 moments is
+    the same statistic with one fixed-size collective and no per-rank merge kernel.  Ranks may hold different numbers of rows."""
+    def reduce_(sums: torch.Tensor) -> None:
+        if sums.dtype != torch.float64 or sums.dim() != 1:
+            raise ValueError("the BatchNorm exchange vector is a 1-d float64 tensor")
+        if dist.is_available() and dist.is_initialized():
+            dist.all_reduce(sums, op=dist.ReduceOp.SUM, group=group)
+    return reduce_
+
+
+def convert_sync_batchnorm(model, group=None, reduce_=None):
+    """`nn.SyncBatchNorm.convert_sync_batchnorm(wam)` of train.py:438-440 for a videoseal_amd model: from now on `model.train()` forwards
+    normalise the U-Net's BatchNorm layers with the statistics of the batch of ALL ranks of `group` and update the running statistics with
+    them (identical on every rank).  `reduce_` replaces the collective (tests).  Returns the model, like the torch call."""
+    model._bn_sync = reduce_ if reduce_ is not None else bn_all_reduce(group)
+    return model

@@ -189,6 +189,7 @@ class HipEngine:
         # VIDEOSEAL_CHECK_FINITE=1: synchronise after every network pass and raise if the output is not finite -- the 2 x f16 arithmetic
         # turns an activation beyond its f16 range (|a| * a_mul >= 65520) into inf / NaN instead of a silently wrong number
         self.check_finite = os.environ.get("VIDEOSEAL_CHECK_FINITE", "0") == "1"
+        self.bn_sync = None       # callable(sums: float64 [2*ld + 1]) -> None, in-place sum over the ranks (dist.convert_sync_batchnorm)
         # per-shape tile selection: every candidate walks K in the same order, so the result is bit-identical whatever
         # tile wins -- only speed changes (measure, don't guess).  VIDEOSEAL_AUTOTUNE=0 keeps the static heuristic.
         self.autotune = os.environ.get("VIDEOSEAL_AUTOTUNE", "1") != "0"
@@ -574,13 +575,21 @@ class HipEngine:
 
     def _bn_batch(self, raw: Act, bn: dict, act: int, out: Act, add: Optional[Act] = None):
         """nn.BatchNorm2d training branch on an NHWC tensor + activation (+ the res_conv branch): batch statistics, running
-        statistics updated in place (momentum 0.1, unbiased variance), num_batches_tracked += 1."""
+        statistics updated in place (momentum 0.1, unbiased variance), num_batches_tracked += 1.  With `self.bn_sync` set
+        (videoseal_amd.dist.convert_sync_batchnorm) the statistics are those of the global batch: nn.SyncBatchNorm, train.py:438-440."""
         L, st = self.lib, N.stream()
         part = self.buf("bn.part", 2 * int(L.vs_bn_partial_doubles(raw.rows, raw.ld)))       # doubles = 2 floats each
         ss = self.buf("bn.ss", 2 * raw.ld)
         scale, shift = ss[: raw.ld], ss[raw.ld:]
-        N.check(L.vs_bn_batch_stats(N.ptr(raw.t), raw.rows, raw.C, raw.ld, N.ptr(bn["w"]), N.ptr(bn["b"]), 1e-5, 0.1, N.ptr(bn["rm"]),
-                                    N.ptr(bn["rv"]), N.ptr(part), N.ptr(scale), N.ptr(shift), st), "vs_bn_batch_stats")
+        if self.bn_sync is not None:
+            sums = self.buf("bn.sums", 2 * (2 * raw.ld + 2)).view(torch.float64)[: 2 * raw.ld + 1]     # [sum x | sum x^2 | rows]
+            N.check(L.vs_bn_partial_sums(N.ptr(raw.t), raw.rows, raw.C, raw.ld, N.ptr(part), N.ptr(sums), st), "vs_bn_partial_sums")
+            self.bn_sync(sums)                       # ONE all-reduce of 2*ld + 1 doubles per BatchNorm layer (in place, same stream)
+            N.check(L.vs_bn_finish_sums(N.ptr(sums), raw.C, raw.ld, N.ptr(bn["w"]), N.ptr(bn["b"]), 1e-5, 0.1, N.ptr(bn["rm"]),
+                                        N.ptr(bn["rv"]), N.ptr(scale), N.ptr(shift), st), "vs_bn_finish_sums")
+        else:
+            N.check(L.vs_bn_batch_stats(N.ptr(raw.t), raw.rows, raw.C, raw.ld, N.ptr(bn["w"]), N.ptr(bn["b"]), 1e-5, 0.1, N.ptr(bn["rm"]),
+                                        N.ptr(bn["rv"]), N.ptr(part), N.ptr(scale), N.ptr(shift), st), "vs_bn_batch_stats")
         bn["nbt"].add_(1)
         N.check(L.vs_scale_shift_act(N.ptr(raw.t), raw.rows, raw.C, raw.ld, N.ptr(scale), N.ptr(shift), act,
                                      N.ptr(add.t) if add is not None else None, add.ld if add is not None else 0, N.ptr(out.t), out.ld, st),

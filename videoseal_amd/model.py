@@ -187,6 +187,7 @@ class Wam(nn.Module):
         self._wkeys: Dict[str, tuple] = {}
         self._wgroups: Optional[Dict[str, list]] = None
         self._msg_cache: Optional[tuple] = None
+        self._bn_sync = None          # set by videoseal_amd.dist.convert_sync_batchnorm: the BatchNorm exchange of distributed training
         # hipGraph replay of the per-chunk launch sequences (fixed chunk shapes, e.g. streaming callers): the ~300 kernel
         # launches of an embed / detect chunk are captured once per (shape, flags) and replayed with one launch
         self.use_graphs = os.environ.get("VIDEOSEAL_GRAPHS", "0") == "1"
@@ -250,6 +251,7 @@ class Wam(nn.Module):
         if stale:
             self._eng.invalidate(*stale)
             self._graphs.clear()
+        self._eng.bn_sync = self._bn_sync
         return self._eng
 
     def repack(self) -> None:

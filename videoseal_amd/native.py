@@ -26,7 +26,7 @@ EXPORTS = [
     "vs_upcat2x", "vs_upconv_supported", "vs_upconv_gather_ln", "vs_cat2_scale", "vs_msg_pre", "vs_upconv_fused_supported", "vs_upconv_fused_preferred", "vs_upconv_fused", "vs_im2col3x3", "vs_msg_latent", "vs_broadcast_channels", "vs_outc_tanh", "vs_pool_linear", "vs_resize_pre", "vs_resize_pre_u8",
     "vs_jnd_heatmap", "vs_embed_tail", "vs_aug_color_scratch_floats", "vs_aug_color", "vs_aug_crop_flip", "vs_aug_warp", "vs_resize_nchw",
     "vs_gaussian_blur", "vs_median_filter", "vs_jpeg_workspace_bytes", "vs_jpeg_roundtrip", "vs_h264_proxy_workspace_bytes", "vs_h264_proxy_roundtrip",
-    "vs_bn_partial_doubles", "vs_bn_batch_stats", "vs_scale_shift_act", "vs_aug_mask_blend", "vs_aug_add_scaled", "vs_aug_gather_frames",
+    "vs_bn_partial_doubles", "vs_bn_batch_stats", "vs_bn_partial_sums", "vs_bn_finish_sums", "vs_scale_shift_act", "vs_aug_mask_blend", "vs_aug_add_scaled", "vs_aug_gather_frames",
 ]
 
 
@@ -121,6 +121,8 @@ def lib() -> C.CDLL:
         "vs_jpeg_roundtrip": [P, P, I, I, I, I, P, P],
         "vs_h264_proxy_roundtrip": [P, P, I, I, I, I, I, P, P],
         "vs_bn_batch_stats": [P, I64, I, I64, P, P, F, F, P, P, P, P, P, P],
+        "vs_bn_partial_sums": [P, I64, I, I64, P, P, P],
+        "vs_bn_finish_sums": [P, I, I64, P, P, F, F, P, P, P, P, P],
         "vs_scale_shift_act": [P, I64, I, I64, P, P, I, P, I64, P, I64, P],
         "vs_aug_mask_blend": [P, P, P, P, I, I, I, I, P],
         "vs_aug_add_scaled": [P, P, F, P, I64, P],
