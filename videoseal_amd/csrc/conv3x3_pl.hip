@@ -459,25 +459,38 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pl_kernel(const vs_conv_desc_t
 #pragma unroll
     for (int j = 0; j < TN; ++j)
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int n = cbase[j] + 8 * q;
-        if (n >= d.n_store) continue;
-        f32x4 v = {0.f, 0.f, 0.f, 0.f};          // columns in [N, n_store) are written as zeros
-        if (n < d.N) {
-          v = grp(i, j, q);
-          if (rrow) v += *reinterpret_cast<const f32x4*>(rrow + n);
-          if (n + 4 > d.N)
+      for (int q2 = 0; q2 < 2; ++q2) {           // the two channel groups q = 2 q2, 2 q2 + 1 of one 16-channel chunk
+        f32x4 v[2];
 #pragma unroll
-            for (int e = 0; e < 4; ++e)
-              if (n + e >= d.N) v[e] = 0.f;
+        for (int h = 0; h < 2; ++h) {
+          const int n = cbase[j] + 8 * (2 * q2 + h);
+          v[h] = f32x4{0.f, 0.f, 0.f, 0.f};      // columns in [N, n_store) are written as zeros
+          if (n >= d.n_store) continue;
+          if (n < d.N) {
+            v[h] = grp(i, j, 2 * q2 + h);
+            if (rrow) v[h] += *reinterpret_cast<const f32x4*>(rrow + n);
+            if (n + 4 > d.N)
+#pragma unroll
+              for (int e = 0; e < 4; ++e)
+                if (n + e >= d.N) v[h][e] = 0.f;
+          }
+          if (orow) *reinterpret_cast<f32x4*>(orow + n) = v[h];
         }
-        if (orow) *reinterpret_cast<f32x4*>(orow + n) = v;
-        if (prow && n < d.N) {                   // the next conv's operand planes: hi / lo f16 of v * a_mul, [plane][n / 16][pixel][16]
-          u32x2 ph, pl;
-          split4h(v, d.a_mul, ph, pl);
-          char* dst = prow + (int64_t)(n >> 4) * cstride + (n & 15) * 2;
-          *reinterpret_cast<u32x2*>(dst) = ph;
-          *reinterpret_cast<u32x2*>(dst + opstride) = pl;
+        // the next conv's operand planes: hi / lo f16 of v * a_mul, [plane][n / 16][pixel][16].  A lane holds channels 4g .. 4g+3 and
+        // 8 + 4g .. 8 + 4g+3 of its pixel; v_permlane32_swap trades the middle pieces between the half-waves (same pixel, g = 0 / 1) so
+        // that g = 0 writes channels 0..7 and g = 1 channels 8..15 as ONE 16-byte store each: a tile row becomes 512 contiguous bytes
+        const int n16 = n0 + (wn * TN + j) * 32 + 16 * q2;          // wave-uniform (N % 16 == 0 with planes output)
+        if (prow && n16 < d.N) {
+          u32x2 h0, l0, h1, l1;
+          split4h(v[0], d.a_mul, h0, l0);
+          split4h(v[1], d.a_mul, h1, l1);
+          const auto sh0 = __builtin_amdgcn_permlane32_swap(h0[0], h1[0], false, false);
+          const auto sh1 = __builtin_amdgcn_permlane32_swap(h0[1], h1[1], false, false);
+          const auto sl0 = __builtin_amdgcn_permlane32_swap(l0[0], l1[0], false, false);
+          const auto sl1 = __builtin_amdgcn_permlane32_swap(l0[1], l1[1], false, false);
+          char* dst = prow + (int64_t)(n16 >> 4) * cstride + g_e * 16;
+          *reinterpret_cast<u32x4*>(dst) = u32x4{sh0[0], sh1[0], sh0[1], sh1[1]};
+          *reinterpret_cast<u32x4*>(dst + opstride) = u32x4{sl0[0], sl1[0], sl0[1], sl1[1]};
         }
       }
   }
