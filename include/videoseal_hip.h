@@ -196,6 +196,42 @@ int vs_bn_finish_sums(const double* sums, int C, int64_t ld, const float* gamma,
 int vs_scale_shift_act(const float* x, int64_t rows, int C, int64_t ld, const float* scale, const float* shift, int act,
                        const float* add, int64_t add_ld, float* out, int64_t out_ld, void* stream);
 
+/* ---- backward building blocks of the ConvNeXt-V2 extractor (csrc/bwd_ops.hip; SURVEY.md 8(f)1: the detector fine-tuning step of
+ * train.py:517-523, 626-643).  Backward-DATA products are vs_conv_gemm launches on transposed weights; these are the rest.  All NHWC
+ * fp32, leading dimensions multiples of 4, reductions deterministic (fixed order, fp64 across chunks).
+ * vs_gemm_wgrad: dw[n][k] = sum_rows dy[row][n] * x[row][k] (dense [N][K]); partial = vs_gemm_wgrad_partial_floats floats.
+ * vs_dwconv7: depthwise 7x7 pad 3 (+ bias) (+ add), w = [49][ld]; flip = 1 uses tap 48 - t: the backward-data pass (convnext.py:43).
+ * vs_dwconv7_wgrad: dw[49][ld] of the same; partial = vs_dwconv7_wgrad_partial_floats.
+ * vs_layernorm_bwd: LayerNorm over C (biased variance): dx, d weight, d bias; stats = 2 * rows floats (mean, rstd out); partial =
+ *   vs_colreduce_partial_floats(1, rows, ld).
+ * vs_gelu_grn_bwd: h3 = gamma * (h2 * Nx) + beta + h2, h2 = gelu(h1), Nx = ||h2||_2(H,W) / (mean_c + 1e-6) (common.py:158-169):
+ *   dh1, d gamma, d beta from d3 = dL/dh3; coef = 6 * B * ld floats, partial = vs_colreduce_partial_floats(B, HW, ld).
+ * vs_patchify / vs_unpatch: patch matrix of a P x P stride-P conv in the k order of the packed weights, and its adjoint.
+ * vs_col2im3x3_reflect: adjoint of vs_im2col3x3 with reflection padding.  vs_colmean / vs_pool_gelu_bwd / vs_matmul_small: the head
+ *   (pixel_decoder.py:61-83).  vs_bce_logits: decoding loss (videosealloss.py:150-156) and d preds (column 0 gets 0). */
+int64_t vs_gemm_wgrad_partial_floats(int64_t rows, int N, int K);
+int vs_gemm_wgrad(const float* dy, int64_t dy_ld, int N, const float* x, int64_t x_ld, int K, int64_t rows, float* partial, float* dw,
+                  void* stream);
+int vs_dwconv7(const float* x, int B, int H, int W, int C, int64_t ld, const float* w, const float* bias, int flip, const float* add,
+               int64_t add_ld, float* out, int64_t out_ld, void* stream);
+int64_t vs_dwconv7_wgrad_partial_floats(int B, int H, int64_t ld);
+int vs_dwconv7_wgrad(const float* x, int64_t ld, const float* dy, int64_t dy_ld, int B, int H, int W, int C, float* partial, float* dw,
+                     void* stream);
+int64_t vs_colreduce_partial_floats(int B, int64_t HW, int64_t ld);
+int vs_layernorm_bwd(const float* x, int64_t ld, const float* dy, int64_t dy_ld, const float* w, int64_t rows, int C, float eps, float* dx,
+                     int64_t dx_ld, float* stats, float* partial, float* dw, float* db, void* stream);
+int vs_gelu_grn_bwd(const float* h1, int64_t ld, const float* d3, int64_t d3_ld, const float* gamma, int B, int HW, int C, float* partial,
+                    float* coef, float* dh1, int64_t dh1_ld, float* dgamma, float* dbeta, void* stream);
+int vs_patchify(const float* x, int B, int H, int W, int64_t pld, int P, float* cols, void* stream);
+int vs_unpatch(const float* dcols, int B, int H, int W, int64_t pld, int P, float* dx, void* stream);
+int vs_col2im3x3_reflect(const float* dcols, int B, int H, int W, int64_t ld, float* dx, void* stream);
+int vs_colmean(const float* x, int B, int HW, int64_t ld, float* out, void* stream);
+int vs_pool_gelu_bwd(const float* z, int64_t ld, const float* dpooled, int64_t dp_ld, int B, int HW, int C, float* dz, int64_t dz_ld,
+                     void* stream);
+int vs_matmul_small(const float* A, int64_t lda, const float* Bm, int64_t ldb, int M, int N, int K, float* C, int64_t ldc, void* stream);
+int vs_bce_logits(const float* preds, const int32_t* msgs, int msg_rows, int B, int k, float temperature, float gscale, float* dpreds,
+                  float* loss, void* stream);
+
 /* Bilinear x2 (align_corners=False) of cat(x, skip*skip_scale) along channels.  unet.py:186-191 + common.py:46. */
 int vs_upcat2x(const float* x, int C1, int64_t ld1, const float* skip, int C2, int64_t ld2, float skip_scale,
                int B, int H, int W, float* out, int64_t out_ld, void* stream);

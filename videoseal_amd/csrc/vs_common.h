@@ -48,8 +48,8 @@ static inline int vs_num_cus() {
 //   gelu(v) = max(v, 0) - 0.5 |v| erfc(|v|/sqrt2),   erfc(t) = exp(-P(t)),  P(t) = t * Q8(t) fitted to -ln erfc on [0, 4]
 // with the 1/sqrt2 and -log2(e) factors folded into the coefficients (tools/micro/fit_gelu.py).  Max |error| vs the exact
 // function 2.4e-7 over [-9, 9] -- ATen's own fp32 GELU is off by up to 1.2e-6 there -- and exactly v / 0 beyond |v| = 5.66.
-__device__ __forceinline__ float vs_gelu(float v) {
-  const float a = fabsf(v);
+// erfc(a / sqrt2) for a >= 0 (the fitted factor of vs_gelu; shared with its derivative in bwd_ops.hip)
+__device__ __forceinline__ float vs_erfc_sqrt2(float a) {
   const float u = fminf(a, 5.65685424949238f);
   float q = 5.128553084e-07f;
   q = __builtin_fmaf(q, u, -9.560153558e-06f);
@@ -60,8 +60,18 @@ __device__ __forceinline__ float vs_gelu(float v) {
   q = __builtin_fmaf(q, u, -5.243476480e-02f);
   q = __builtin_fmaf(q, u, -4.592214525e-01f);
   q = __builtin_fmaf(q, u, -1.151104212e+00f);
-  const float e = __builtin_amdgcn_exp2f(q * u);
+  return __builtin_amdgcn_exp2f(q * u);
+}
+__device__ __forceinline__ float vs_gelu(float v) {
+  const float a = fabsf(v);
+  const float e = vs_erfc_sqrt2(a);
   return fmaxf(v, 0.f) - (0.5f * a) * e;
+}
+// d gelu / dv = Phi(v) + v phi(v),  Phi(v) = 1 - erfc(v / sqrt2) / 2
+__device__ __forceinline__ float vs_gelu_grad(float v) {
+  const float e = vs_erfc_sqrt2(fabsf(v));
+  const float Phi = v >= 0.f ? 1.f - 0.5f * e : 0.5f * e;
+  return Phi + v * (0.3989422804014327f * __expf(-0.5f * v * v));
 }
 
 // ReLU that lets NaN through (fmaxf / `v > 0 ? v : 0` turn it into 0): an out-of-range operand of the 2 x f16 arithmetic must surface as

@@ -27,6 +27,9 @@ EXPORTS = [
     "vs_jnd_heatmap", "vs_embed_tail", "vs_aug_color_scratch_floats", "vs_aug_color", "vs_aug_crop_flip", "vs_aug_warp", "vs_resize_nchw",
     "vs_gaussian_blur", "vs_median_filter", "vs_jpeg_workspace_bytes", "vs_jpeg_roundtrip", "vs_h264_proxy_workspace_bytes", "vs_h264_proxy_roundtrip",
     "vs_bn_partial_doubles", "vs_bn_batch_stats", "vs_bn_partial_sums", "vs_bn_finish_sums", "vs_scale_shift_act", "vs_aug_mask_blend", "vs_aug_add_scaled", "vs_aug_gather_frames",
+    "vs_gemm_wgrad_partial_floats", "vs_gemm_wgrad", "vs_dwconv7", "vs_dwconv7_wgrad_partial_floats", "vs_dwconv7_wgrad", "vs_colreduce_partial_floats",
+    "vs_layernorm_bwd", "vs_gelu_grn_bwd", "vs_patchify", "vs_unpatch", "vs_col2im3x3_reflect", "vs_colmean", "vs_pool_gelu_bwd", "vs_matmul_small",
+    "vs_bce_logits",
 ]
 
 
@@ -127,6 +130,18 @@ def lib() -> C.CDLL:
         "vs_aug_mask_blend": [P, P, P, P, I, I, I, I, P],
         "vs_aug_add_scaled": [P, P, F, P, I64, P],
         "vs_aug_gather_frames": [P, P, P, I, I64, P],
+        "vs_gemm_wgrad": [P, I64, I, P, I64, I, I64, P, P, P],
+        "vs_dwconv7": [P, I, I, I, I, I64, P, P, I, P, I64, P, I64, P],
+        "vs_dwconv7_wgrad": [P, I64, P, I64, I, I, I, I, P, P, P],
+        "vs_layernorm_bwd": [P, I64, P, I64, P, I64, I, F, P, I64, P, P, P, P, P],
+        "vs_gelu_grn_bwd": [P, I64, P, I64, P, I, I, I, P, P, P, I64, P, P, P],
+        "vs_patchify": [P, I, I, I, I64, I, P, P],
+        "vs_unpatch": [P, I, I, I, I64, I, P, P],
+        "vs_col2im3x3_reflect": [P, I, I, I, I64, P, P],
+        "vs_colmean": [P, I, I, I64, P, P],
+        "vs_pool_gelu_bwd": [P, I64, P, I64, I, I, I, P, I64, P],
+        "vs_matmul_small": [P, I64, P, I64, I, I, I, P, I64, P],
+        "vs_bce_logits": [P, P, I, I, I, F, F, P, P, P],
     }
     for name, args in sig.items():
         fn = getattr(L, name)
@@ -140,6 +155,10 @@ def lib() -> C.CDLL:
     L.vs_h264_proxy_workspace_bytes.argtypes = [I, I, I]
     L.vs_bn_partial_doubles.restype = C.c_int64
     L.vs_bn_partial_doubles.argtypes = [I64, I64]
+    for name, args in (("vs_gemm_wgrad_partial_floats", [I64, I, I]), ("vs_dwconv7_wgrad_partial_floats", [I, I, I64]),
+                       ("vs_colreduce_partial_floats", [I, I64, I64])):
+        getattr(L, name).restype = C.c_int64
+        getattr(L, name).argtypes = args
     L.vs_sizeof_conv_desc.restype = C.c_int
     L.vs_sizeof_tail_desc.restype = C.c_int
     if L.vs_version() != 2:
