@@ -75,6 +75,79 @@ __global__ __launch_bounds__(256) void gemm_wgrad_kernel(const float* __restrict
   }
 }
 
+// The same product on the matrix cores, fp32 in and out (v_mfma_f32_32x32x2_f32: A[m][k] / B[k][n] with lane = (m or n) + 32 k).  With the
+// reduction index k = row, both fragments are plain reads of 32 consecutive channels of two rows: no transposes and no operand split
+// (fp32 products).  Workgroup = 128 (n) x 128 (k) outputs, 4 waves of 64 x 64 (2 x 2 MFMA tiles), 16 rows per LDS step, the next step's
+// rows are fetched into registers while the matrix cores work.  Selected by VS_WGRAD=mfma (see vs_gemm_wgrad).
+__global__ __launch_bounds__(256) void gemm_wgrad_mfma_kernel(const float* __restrict__ dy, int64_t dy_ld, int N, const float* __restrict__ x,
+                                                              int64_t x_ld, int K, int64_t rows, int64_t rows_per_split,
+                                                              float* __restrict__ partial) {
+  __shared__ __attribute__((aligned(16))) float sa[16][128], sb[16][128];
+  const int n0 = blockIdx.y * 128, k0 = blockIdx.x * 128;
+  const int64_t r_begin = (int64_t)blockIdx.z * rows_per_split;
+  const int64_t r_end = r_begin + rows_per_split < rows ? r_begin + rows_per_split : rows;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int wy = wave >> 1, wx = wave & 1;
+  const int lr = threadIdx.x >> 5, lc = (threadIdx.x & 31) * 4;       // staging: rows lr and lr + 8, 4 floats at column lc
+  const int kq = lane >> 5, c = lane & 31;
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+  f32x4 va[2], vb[2];
+  auto fetch = [&](const int64_t r0) __attribute__((always_inline)) {
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int64_t r = r0 + lr + 8 * h;
+      va[h] = f32x4{0.f, 0.f, 0.f, 0.f};
+      vb[h] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (r < r_end) {
+        if (n0 + lc + 4 <= dy_ld) va[h] = *reinterpret_cast<const f32x4*>(dy + r * dy_ld + n0 + lc);
+        if (k0 + lc + 4 <= x_ld) vb[h] = *reinterpret_cast<const f32x4*>(x + r * x_ld + k0 + lc);
+      }
+    }
+  };
+  fetch(r_begin);
+  for (int64_t r0 = r_begin; r0 < r_end; r0 += 16) {
+    __syncthreads();                       // the previous step's fragment reads are done
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      *reinterpret_cast<f32x4*>(&sa[lr + 8 * h][lc]) = va[h];
+      *reinterpret_cast<f32x4*>(&sb[lr + 8 * h][lc]) = vb[h];
+    }
+    __syncthreads();
+    if (r0 + 16 < r_end) fetch(r0 + 16);
+#pragma unroll
+    for (int rr = 0; rr < 16; rr += 2) {
+      float a[2], b[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) a[i] = sa[rr + kq][wy * 64 + i * 32 + c];
+#pragma unroll
+      for (int j = 0; j < 2; ++j) b[j] = sb[rr + kq][wx * 64 + j * 32 + c];
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+    }
+  }
+  // D[m][n]: lane holds column n = lane & 31 and rows m = (e & 3) + 8 (e >> 2) + 4 (lane >> 5)
+  float* p = partial + (int64_t)blockIdx.z * N * K;
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int k = k0 + wx * 64 + j * 32 + c;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int n = n0 + wy * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * kq;
+        if (n < N && k < K) p[(int64_t)n * K + k] = acc[i][j][e];
+      }
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------
 // Depthwise 7x7, zero padding 3, NHWC: out = (bias) + sum_t w[t'][c] x[.., y+ky-3, x+kx-3, c] (+ add),  t' = flip ? 48 - t : t.
 // flip = 1 is the backward-data pass (convnext.py:43 transposed).  Work item = (4 consecutive x, 4 channels).
@@ -492,8 +565,15 @@ extern "C" int vs_gemm_wgrad(const float* dy, int64_t dy_ld, int N, const float*
   int64_t rps = cdiv64(rows, splits);
   rps = cdiv64(rps, 16) * 16;
   const int64_t used = cdiv64(rows, rps);                  // <= splits
-  hipLaunchKernelGGL(gemm_wgrad_kernel, dim3((unsigned)cdiv64(K, 64), (unsigned)cdiv64(N, 64), (unsigned)used), dim3(256), 0, (hipStream_t)stream,
-                     dy, dy_ld, N, x, x_ld, K, rows, rps, partial);
+  // VS_WGRAD=mfma selects the fp32 matrix-core kernel.  It is compiled and reviewed but has NOT run on hardware yet (the GPU budget of the
+  // round was spent when it was written): validate with `VS_WGRAD=mfma python -m pytest tests/test_gpu_bwd.py` before making it the default.
+  static const bool use_mfma = [] { const char* e = getenv("VS_WGRAD"); return e && !strcmp(e, "mfma"); }();
+  if (use_mfma)
+    hipLaunchKernelGGL(gemm_wgrad_mfma_kernel, dim3((unsigned)cdiv64(K, 128), (unsigned)cdiv64(N, 128), (unsigned)used), dim3(256), 0,
+                       (hipStream_t)stream, dy, dy_ld, N, x, x_ld, K, rows, rps, partial);
+  else
+    hipLaunchKernelGGL(gemm_wgrad_kernel, dim3((unsigned)cdiv64(K, 64), (unsigned)cdiv64(N, 64), (unsigned)used), dim3(256), 0, (hipStream_t)stream,
+                       dy, dy_ld, N, x, x_ld, K, rows, rps, partial);
   hipLaunchKernelGGL(reduce_chunks_kernel, dim3(blocks_for((int64_t)N * K)), dim3(256), 0, (hipStream_t)stream, partial, (int)used,
                      (int64_t)N * K, dw);
   return vs_launch_status();
