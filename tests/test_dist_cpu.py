@@ -116,3 +116,50 @@ def test_sync_batchnorm_conversion_is_host_state_only():
         bn_all_reduce()(torch.zeros(5))
     marker = lambda s: None                                      # noqa: E731
     assert convert_sync_batchnorm(m, reduce_=marker)._bn_sync is marker
+
+
+# ---- gradient exchange of distributed training (train.py:442-443: DistributedDataParallel) for gradients written outside autograd
+def _grad_worker(rank, world, port, bucket_bytes, q):
+    from videoseal_amd.dist import all_reduce_gradients
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    g = torch.Generator().manual_seed(11)
+    shapes = [(3, 5), (7,), (2, 3, 4), (1,), (64, 9)]
+    params = [torch.nn.Parameter(torch.zeros(*s)) for s in shapes]
+    base = [torch.randn(*s, generator=g) for s in shapes]
+    for p, b in zip(params, base):
+        p.grad = b * (rank + 1)                       # rank r holds (r + 1) * base: the mean over 2 ranks is 1.5 * base
+    frozen = torch.nn.Parameter(torch.zeros(4), requires_grad=False)        # frozen parameters (the embedder) take no part
+    nb = all_reduce_gradients(params + [frozen], bucket_bytes=bucket_bytes)
+    err = max(float((p.grad - 1.5 * b).abs().max()) for p, b in zip(params, base))
+    params[1].grad = None
+    try:
+        all_reduce_gradients(params)
+        raised = False
+    except ValueError:
+        raised = True
+    q.put((rank, nb, err, raised, frozen.grad is None))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("bucket_bytes,want_buckets", [(64 << 20, 1), (100, 3), (4, 5)])
+def test_gradient_all_reduce_world2(bucket_bytes, want_buckets):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_grad_worker, args=(r, 2, port, bucket_bytes, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, nb, err, raised, frozen_untouched in res:
+        assert nb == want_buckets and err < 1e-6 and raised and frozen_untouched, (rank, nb, err, raised)
+
+
+def test_gradient_all_reduce_without_a_process_group_is_a_no_op():
+    from videoseal_amd.dist import all_reduce_gradients
+    p = torch.nn.Parameter(torch.zeros(3))
+    p.grad = torch.ones(3)
+    assert all_reduce_gradients([p]) == 0 and torch.equal(p.grad, torch.ones(3))

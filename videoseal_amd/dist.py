@@ -104,3 +104,47 @@ def convert_sync_batchnorm(model, group=None, reduce_=None):
     them (identical on every rank).  `reduce_` replaces the collective (tests).  Returns the model, like the torch call."""
     model._bn_sync = reduce_ if reduce_ is not None else bn_all_reduce(group)
     return model
+
+
+def all_reduce_gradients(params, group=None, bucket_bytes: int = 64 << 20, average: bool = True) -> int:
+    """The gradient exchange `DistributedDataParallel` performs for train.py:442-443, for gradients produced outside autograd
+    (`training.DetectorStep` writes `.grad` directly): the gradients are packed, in parameter order, into flat fp32 buckets of at most
+    `bucket_bytes`, every bucket is summed over the ranks with ONE all-reduce (all issued asynchronously before the first wait; RCCL rings
+    over xGMI are per-link bound, so few large messages -- 64 MiB by default -- rather than one per tensor), divided by the world size
+    (DDP averages) and scattered back into `.grad`.  Every rank must hold a gradient for the same parameters.  Returns the number of
+    buckets.  Without an initialised process group this is a no-op (returns 0)."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return 0
+    plist = [p for p in params if p.requires_grad]
+    missing = [i for i, p in enumerate(plist) if p.grad is None]
+    if missing:
+        raise ValueError(f"parameters {missing[:8]}{'...' if len(missing) > 8 else ''} have no gradient on this rank: the ranks would exchange "
+                         f"different buckets")
+    if bucket_bytes < 4:
+        raise ValueError("bucket_bytes must hold at least one fp32 value")
+    world = dist.get_world_size(group)
+    buckets: List[List[torch.nn.Parameter]] = [[]]
+    fill = 0
+    for p in plist:                                     # parameter order = bucket order on every rank
+        nbytes = p.grad.numel() * 4
+        if buckets[-1] and fill + nbytes > bucket_bytes:
+            buckets.append([])
+            fill = 0
+        buckets[-1].append(p)
+        fill += nbytes
+    buckets = [b for b in buckets if b]
+    flats, works = [], []
+    for b in buckets:
+        flat = torch.cat([p.grad.detach().reshape(-1).float() for p in b])
+        works.append(dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group, async_op=True))
+        flats.append(flat)
+    for b, flat, w in zip(buckets, flats, works):
+        w.wait()
+        if average:
+            flat.div_(world)
+        off = 0
+        for p in b:
+            n = p.grad.numel()
+            p.grad.copy_(flat[off: off + n].view_as(p.grad))
+            off += n
+    return len(buckets)
