@@ -22,29 +22,33 @@ def _free_port():
     s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
 
 
-def test_sharded_extraction_over_rccl_world1():
+@pytest.fixture(scope="module")
+def rccl_world1():
+    """ONE world-size-1 process group over the `nccl` (= RCCL) backend for the tests of this file (initialised once per process)"""
     import torch.distributed as dist
-    from videoseal_amd.dist import embed_sharded, extract_message_sharded, gather_frame_logits, shard_range
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), HSA_ENABLE_IPC_MODE_LEGACY="0")
     dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
-    try:
-        spec = tiny_spec()
-        model = make_model(spec, make_state_dict(spec, seed=3))
-        model.chunk_size, model.step_size = 4, 2
-        frames = synthetic_frames(40, 80, 96, seed=70).cuda()
-        msgs = synthetic_msgs(1, spec.nbits, seed=70)
-        a, b = shard_range(40, 0, 1, 16)
-        assert (a, b) == (0, 40)
-        w = embed_sharded(model, frames[a:b], msgs, align=16)
-        assert torch.equal(w, model.embed(frames, msgs, is_video=True)["imgs_w"])
-        single = model.extract_message(w)
-        for agg in ("avg", "squared_avg", "l1norm_avg", "l2norm_avg"):
-            assert torch.equal(extract_message_sharded(model, w, 40, aggregation=agg), model.extract_message(w, aggregation=agg))
-        assert torch.equal(extract_message_sharded(model, w, 40), single)
-        logits = model.detect(w, is_video=True)["preds"]
-        assert torch.equal(gather_frame_logits(logits, 40, 16), logits)         # one all_gather_into_tensor on the RCCL communicator
-    finally:
-        dist.destroy_process_group()
+    yield dist
+    dist.destroy_process_group()
+
+
+def test_sharded_extraction_over_rccl_world1(rccl_world1):
+    from videoseal_amd.dist import embed_sharded, extract_message_sharded, gather_frame_logits, shard_range
+    spec = tiny_spec()
+    model = make_model(spec, make_state_dict(spec, seed=3))
+    model.chunk_size, model.step_size = 4, 2
+    frames = synthetic_frames(40, 80, 96, seed=70).cuda()
+    msgs = synthetic_msgs(1, spec.nbits, seed=70)
+    a, b = shard_range(40, 0, 1, 16)
+    assert (a, b) == (0, 40)
+    w = embed_sharded(model, frames[a:b], msgs, align=16)
+    assert torch.equal(w, model.embed(frames, msgs, is_video=True)["imgs_w"])
+    single = model.extract_message(w)
+    for agg in ("avg", "squared_avg", "l1norm_avg", "l2norm_avg"):
+        assert torch.equal(extract_message_sharded(model, w, 40, aggregation=agg), model.extract_message(w, aggregation=agg))
+    assert torch.equal(extract_message_sharded(model, w, 40), single)
+    logits = model.detect(w, is_video=True)["preds"]
+    assert torch.equal(gather_frame_logits(logits, 40, 16), logits)         # one all_gather_into_tensor on the RCCL communicator
 
 
 def test_bench_distributed_step_on_one_gpu():
@@ -120,8 +124,7 @@ def _bn_buffers(model):
     return torch.cat([v.flatten().float() for k, v in sd.items() if k.endswith(("running_mean", "running_var"))]).cpu()
 
 
-def test_sync_batchnorm_world1_over_rccl_is_bit_identical():
-    import torch.distributed as dist
+def test_sync_batchnorm_world1_over_rccl_is_bit_identical(rccl_world1):
     from videoseal_amd.dist import convert_sync_batchnorm
     spec = tiny_spec()
     sd = make_state_dict(spec, seed=3)
@@ -130,17 +133,12 @@ def test_sync_batchnorm_world1_over_rccl_is_bit_identical():
     ref = {k: v.clone() for k, v in _train_forward(model, imgs, msgs).items() if k in ("imgs_w", "preds_w")}
     ref_bn = _bn_buffers(model)
     model.load_state_dict(sd, strict=True)    # running statistics back to their initial values
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), HSA_ENABLE_IPC_MODE_LEGACY="0")
-    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
-    try:
-        convert_sync_batchnorm(model)
-        calls = []
-        inner = model._bn_sync
-        model._bn_sync = lambda s: (calls.append(s.numel()), inner(s))[1]          # fp64 all-reduce on the RCCL communicator
-        out = _train_forward(model, imgs, msgs)
-        torch.cuda.synchronize()
-    finally:
-        dist.destroy_process_group()
+    convert_sync_batchnorm(model)
+    calls = []
+    inner = model._bn_sync
+    model._bn_sync = lambda s: (calls.append(s.numel()), inner(s))[1]          # fp64 all-reduce on the RCCL communicator
+    out = _train_forward(model, imgs, msgs)
+    torch.cuda.synchronize()
     assert len(calls) > 0 and all(n % 2 == 1 for n in calls)             # one exchange of 2*ld + 1 doubles per BatchNorm layer
     assert torch.equal(out["imgs_w"], ref["imgs_w"]) and torch.equal(out["preds_w"], ref["preds_w"])
     assert torch.equal(_bn_buffers(model), ref_bn)
