@@ -177,3 +177,17 @@ def test_videoseal_import_shim_resolves_the_reference_paths():
     assert isinstance(m, Videoseal) and m.training and type(m.augmenter).__name__ == "Augmenter"
     with pytest.raises(FileNotFoundError):
         videoseal.load("videoseal")          # card found, checkpoint absent (no network): the reference's error type
+
+
+def test_detector_step_has_no_cpu_path_and_rejects_what_it_does_not_cover():
+    """videoseal_amd.training.DetectorStep (train.py:517-523): loud on a CPU model, on the ViT extractor of the legacy card and on
+    ChunkySeal's overlapping stem; malformed inputs are rejected before any launch."""
+    from videoseal_amd.training import DetectorStep
+    m = videoseal_amd.build("videoseal_1.0").train()
+    step = DetectorStep(m)
+    with pytest.raises(native.NativeError, match="no CPU execution path"):
+        step.step(torch.rand(2, 3, 256, 256), torch.zeros(2, 256))
+    with pytest.raises(native.NativeError, match="ConvNeXt"):
+        DetectorStep(videoseal_amd.build("videoseal_0.0"))
+    with pytest.raises(native.NativeError, match="stem"):
+        DetectorStep(videoseal_amd.build("chunkyseal"))
