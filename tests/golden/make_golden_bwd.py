@@ -20,6 +20,7 @@ import types
 
 import numpy as np
 import torch
+import yaml
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, HERE)
@@ -27,7 +28,7 @@ import make_golden as MG                                   # noqa: E402
 import make_golden_fwd as MF                               # noqa: E402
 
 from oracle.inputs import synthetic_frames, synthetic_msgs          # noqa: E402
-from oracle.weights import make_state_dict, tiny_spec   # noqa: E402
+from oracle.weights import make_state_dict, spec_from_card, tiny_spec   # noqa: E402
 
 from tests._util import BWD_FULL as FULL, projection_vector          # noqa: E402
 
@@ -55,7 +56,8 @@ def extra_stubs():
     sys.modules["timm"].scheduler = stub("timm.scheduler")
 
 
-def run_case(model, Augmenter, VideosealLoss, spec, name, *, n, h, w, seed, is_video, loss_kw, step=None, temperature=1.0, accumulation=1):
+def run_case(model, Augmenter, VideosealLoss, spec, name, *, n, h, w, seed, is_video, loss_kw, step=None, temperature=1.0, accumulation=1,
+             full=FULL):
     imgs = synthetic_frames(n, h, w, seed=seed)
     msgs = synthetic_msgs(1 if is_video else n, spec.nbits, seed=seed)
     masks = torch.ones(n, 1, h, w)
@@ -81,7 +83,8 @@ def run_case(model, Augmenter, VideosealLoss, spec, name, *, n, h, w, seed, is_v
                                  log={k: float(v) for k, v in logs.items()})),
          "grad_names": np.array(names), "grad_summary": rows, "preds": out["preds"].detach().numpy()}
     gd = dict(params)
-    for k in FULL:
+    d["full_names"] = np.array(list(full))
+    for k in full:
         d["grad." + k] = gd[k].grad.numpy()
     np.savez_compressed(os.path.join(HERE, name + ".npz"), **d)
     print(f"{name}: aug={out['selected_aug']} loss={float(loss):.6f} log={ {k: round(float(v), 6) for k, v in logs.items()} } "
@@ -111,6 +114,13 @@ def main():
     # ... and the video forward (key frames every 2, one message, gradient accumulation factor as for a 2-clip batch)
     run_case(tiny_model(), Augmenter, VideosealLoss, ts, "tiny_bwd_vid_recipe", n=6, h=80, w=72, seed=43, is_video=True, step=2,
              loss_kw=recipe, accumulation=2)
+    # ... and the released VideoSeal 1.0 architecture at its working size (2 frames of 256 x 256: no resize either side), recipe weights
+    path = f"{MG.REF}/videoseal/cards/videoseal_1.0.yaml"
+    spec = spec_from_card(path)
+    model = MG.build_reference(spec, yaml.safe_load(open(path)))
+    model.load_state_dict(make_state_dict(spec, seed=0), strict=True)
+    run_case(model, Augmenter, VideosealLoss, spec, "vs10_bwd_img_recipe", n=2, h=256, w=256, seed=44, is_video=False, loss_kw=recipe,
+             full=("embedder.unet.outc.weight", "detector.pixel_decoder.linear.bias", "embedder.unet.inc.double_conv.1.weight"))
 
 
 if __name__ == "__main__":

@@ -13,7 +13,7 @@ import torch.nn.functional as F
 pytestmark = pytest.mark.gpu
 
 from oracle.weights import make_state_dict, tiny_spec  # noqa: E402
-from tests._util import BWD_FULL, load_golden, projection_vector  # noqa: E402
+from tests._util import load_golden, projection_vector  # noqa: E402
 from tests.test_gpu_e2e import make_model  # noqa: E402
 
 from videoseal_amd import native as N  # noqa: E402
@@ -267,7 +267,7 @@ def test_detector_step_matches_the_reference_backward(name):
         assert np.all(np.abs(got - ref[i]) <= tol), (k, got, ref[i], tol)
         checked += 1
     assert checked == sum(k.startswith("detector.") for k in names) > 50
-    for k in BWD_FULL:
+    for k in [str(k) for k in g["full_names"]]:
         if k.startswith("detector."):
             rf = torch.from_numpy(g["grad." + k]).cuda()
             assert (params[k].grad - rf).abs().max() <= 3e-3 * rf.abs().max() + 1e-9, k

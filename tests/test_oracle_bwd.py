@@ -9,10 +9,13 @@ from oracle import augment as A
 from oracle import loss as L
 from oracle import videoseal_ref as R
 from oracle.inputs import synthetic_frames, synthetic_msgs
-from oracle.weights import make_state_dict, tiny_spec
-from tests._util import BWD_FULL as FULL, load_golden, projection_vector
+import os
 
-CASES = ["tiny_bwd_img_recipe", "tiny_bwd_img_balanced", "tiny_bwd_vid_recipe"]
+from oracle.weights import make_state_dict, spec_from_card, tiny_spec
+from tests._util import load_golden, projection_vector
+from tests.test_oracle_golden import CARDS
+
+CASES = ["tiny_bwd_img_recipe", "tiny_bwd_img_balanced", "tiny_bwd_vid_recipe", "vs10_bwd_img_recipe"]
 
 
 def oracle_step(spec, sd0, meta, names):
@@ -40,8 +43,12 @@ def oracle_step(spec, sd0, meta, names):
 
 @pytest.mark.parametrize("name", CASES)
 def test_oracle_backward_matches_reference(name):
-    spec = tiny_spec()
-    sd = make_state_dict(spec, seed=3)
+    if name.startswith("vs10"):          # the released architecture at its working size (339 trainable tensors)
+        spec = spec_from_card(os.path.join(CARDS, "videoseal_1.0.yaml"))
+        sd = make_state_dict(spec, seed=0)
+    else:
+        spec = tiny_spec()
+        sd = make_state_dict(spec, seed=3)
     g = load_golden(name)
     meta = g["meta"]
     names = [str(k) for k in g["grad_names"]]
@@ -60,7 +67,7 @@ def test_oracle_backward_matches_reference(name):
         # absolute tolerance scaled to the tensor's own gradient norm (sum / projection of numel terms), floor for vanishing gradients
         tol = 5e-5 * max(ref[i, 0], 1e-4 * gmax) * max(1.0, np.sqrt(gd.numel()) / 16)
         assert np.all(np.abs(got - ref[i]) <= tol), (k, got, ref[i], tol)
-    for k in FULL:
+    for k in [str(k) for k in g["full_names"]]:
         rf = torch.from_numpy(g["grad." + k])
         assert (grads[k] - rf).abs().max() <= 5e-5 * rf.abs().max() + 1e-9, k
 
