@@ -252,6 +252,7 @@ int vs_im2col3x3_strided(const float* x, int B, int H, int W, int64_t ld, int st
 int vs_upcat2x_bwd(const float* dhi, int64_t hi_ld, int B, int H, int W, int C1, int C2, float skip_scale, float* dx, int64_t ld1,
                    float* dskip, int64_t ld2, void* stream);
 int vs_msg_table_grad(const float* dlat, const int32_t* msgs, int Bm, int nbits, int hidden, float* dtable, void* stream);
+int vs_relu_bwd(const float* z, int64_t ld, const float* dy, int64_t dy_ld, int64_t rows, int C, float* dz, int64_t dz_ld, void* stream);
 int vs_outc_tanh_bwd(const float* delta, const float* ddelta, int64_t rows_per_frame, int B, int C, const float* w, int Cout, int use_tanh,
                      float* dx, int64_t dx_ld, float* dv, void* stream);
 

@@ -224,6 +224,20 @@ __global__ __launch_bounds__(256) void outc_tanh_bwd_kernel(const float* __restr
   }
 }
 
+// ReLU backward on rows: dz = z > 0 ? dy : 0 (columns >= C of the output row are zeroed)
+__global__ __launch_bounds__(256) void relu_bwd_kernel(const float* __restrict__ z, int64_t ld, const float* __restrict__ dy, int64_t dy_ld, int C, int O4,
+                                                       int64_t total, float* __restrict__ dz, int64_t dz_ld) {
+  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= total) return;
+  const int cg = (int)(idx % O4);
+  const int64_t r = idx / O4;
+  f32x4 o = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int e = 0; e < 4; ++e)
+    if (4 * cg + e < C && z[r * ld + 4 * cg + e] > 0.f) o[e] = dy[r * dy_ld + 4 * cg + e];
+  *reinterpret_cast<f32x4*>(dz + r * dz_ld + 4 * cg) = o;
+}
+
 static inline unsigned blocks_for(int64_t n) { return (unsigned)cdiv64(n, 256); }
 
 }  // namespace
@@ -307,5 +321,13 @@ extern "C" int vs_outc_tanh_bwd(const float* delta, const float* ddelta, int64_t
   const int64_t rows = rows_per_frame * B;
   hipLaunchKernelGGL(outc_tanh_bwd_kernel, dim3(blocks_for(rows)), dim3(256), 0, (hipStream_t)stream, delta, ddelta, rows_per_frame, rows, C, w, Cout,
                      use_tanh, dx, dx_ld, dv);
+  return vs_launch_status();
+}
+
+extern "C" int vs_relu_bwd(const float* z, int64_t ld, const float* dy, int64_t dy_ld, int64_t rows, int C, float* dz, int64_t dz_ld, void* stream) {
+  VS_REQUIRE(z && dy && dz && rows > 0 && C > 0 && ld >= C && dy_ld >= C && dz_ld >= C && (dz_ld & 3) == 0 && (((uintptr_t)dz) & 15) == 0);
+  const int O4 = (int)(dz_ld >> 2);
+  const int64_t total = rows * O4;
+  hipLaunchKernelGGL(relu_bwd_kernel, dim3(blocks_for(total)), dim3(256), 0, (hipStream_t)stream, z, ld, dy, dy_ld, C, O4, total, dz, dz_ld);
   return vs_launch_status();
 }

@@ -31,7 +31,7 @@ EXPORTS = [
     "vs_layernorm_bwd", "vs_gelu_grn_bwd", "vs_patchify", "vs_unpatch", "vs_col2im3x3_reflect", "vs_colmean", "vs_pool_gelu_bwd", "vs_matmul_small",
     "vs_bce_logits",
     "vs_bn_mean_rstd", "vs_bn_bwd_partial_floats", "vs_bn_relu_bwd_sums", "vs_bn_relu_bwd_apply", "vs_dilate2", "vs_im2col3x3_strided", "vs_upcat2x_bwd",
-    "vs_msg_table_grad", "vs_outc_tanh_bwd",
+    "vs_msg_table_grad", "vs_outc_tanh_bwd", "vs_relu_bwd",
 ]
 
 
@@ -152,6 +152,7 @@ def lib() -> C.CDLL:
         "vs_upcat2x_bwd": [P, I64, I, I, I, I, I, F, P, I64, P, I64, P],
         "vs_msg_table_grad": [P, P, I, I, I, P, P],
         "vs_outc_tanh_bwd": [P, P, I64, I, I, P, I, I, P, I64, P, P],
+        "vs_relu_bwd": [P, I64, P, I64, I64, I, P, I64, P],
     }
     for name, args in sig.items():
         fn = getattr(L, name)
