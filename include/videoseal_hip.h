@@ -232,6 +232,30 @@ int vs_matmul_small(const float* A, int64_t lda, const float* Bm, int64_t ldb, i
 int vs_bce_logits(const float* preds, const int32_t* msgs, int msg_rows, int B, int k, float temperature, float gscale, float* dpreds,
                   float* loss, void* stream);
 
+/* ---- backward building blocks of the U-Net embedder under model.train() (csrc/bwd_unet.hip; the generator side of train.py:626-643).
+ * NOT yet run on hardware (written at the end of round 2 against CPU-verified formulas).
+ * vs_bn_mean_rstd: batch statistics from the (all-reduced) moment vector of vs_bn_partial_sums.  vs_bn_relu_bwd_sums / _apply: BatchNorm
+ *   on batch statistics (+ the ReLU that follows it) backward in two halves -- sums = [sum g xhat | sum g | rows] (2 * 4 ceil(C/4) + 1
+ *   doubles) is what SyncBatchNorm all-reduces between them; dgamma / dbeta are the local sums.  vs_dilate2 + the forward conv on flipped
+ *   weights = backward-data of the stride-2 down convs; vs_im2col3x3_strided: their patch matrix (zero padding 1) for vs_gemm_wgrad.
+ * vs_upcat2x_bwd: adjoint of vs_upcat2x.  vs_msg_table_grad: the message embedding table.  vs_outc_tanh_bwd: adjoint of vs_outc_tanh
+ *   (dv = [rows][4] dense, for the weight / bias gradients). */
+int vs_bn_mean_rstd(const double* sums, int C, int64_t ld, float eps, float* mean, float* rstd, void* stream);
+int64_t vs_bn_bwd_partial_floats(int64_t rows, int64_t ld);
+int vs_bn_relu_bwd_sums(const float* raw, int64_t ld, const float* dy, int64_t dy_ld, const float* mean, const float* rstd, const float* scale,
+                        const float* shift, int relu, int64_t rows, int C, float* partial, double* sums, float* dgamma, float* dbeta,
+                        void* stream);
+int vs_bn_relu_bwd_apply(const float* raw, int64_t ld, const float* dy, int64_t dy_ld, const float* mean, const float* rstd, const float* scale,
+                         const float* shift, int relu, const double* sums, int64_t rows, int C, float* dx, int64_t dx_ld, void* stream);
+int vs_dilate2(const float* dy, int B, int Ho, int Wo, int64_t ld, int H, int W, float* out, void* stream);
+int vs_im2col3x3_strided(const float* x, int B, int H, int W, int64_t ld, int stride, float* cols, void* stream);
+int vs_upcat2x_bwd(const float* dhi, int64_t hi_ld, int B, int H, int W, int C1, int C2, float skip_scale, float* dx, int64_t ld1,
+                   float* dskip, int64_t ld2, void* stream);
+int vs_msg_table_grad(const float* dlat, const int32_t* msgs, int Bm, int nbits, int hidden, float* dtable, void* stream);
+int vs_relu_bwd(const float* z, int64_t ld, const float* dy, int64_t dy_ld, int64_t rows, int C, float* dz, int64_t dz_ld, void* stream);
+int vs_outc_tanh_bwd(const float* delta, const float* ddelta, int64_t rows_per_frame, int B, int C, const float* w, int Cout, int use_tanh,
+                     float* dx, int64_t dx_ld, float* dv, void* stream);
+
 /* Bilinear x2 (align_corners=False) of cat(x, skip*skip_scale) along channels.  unet.py:186-191 + common.py:46. */
 int vs_upcat2x(const float* x, int C1, int64_t ld1, const float* skip, int C2, int64_t ld2, float skip_scale,
                int B, int H, int W, float* out, int64_t out_ld, void* stream);

@@ -1,0 +1,196 @@
+"""NOT collected by default (the file name does not match test_*.py): GPU tests of the U-Net backward written at the end of round 2
+without GPU time left (csrc/bwd_unet.hip, videoseal_amd.training.EmbedderBackward).  First command of the next round:
+
+    python -m pytest tests/experimental_gpu_bwd_unet.py -q
+
+Once green, rename to tests/test_gpu_bwd_unet.py.  Unit level: every new kernel against torch autograd of the same op on the GPU.
+End to end: all `embedder.*` gradients against autograd through the oracle's functional U-Net (CPU, fp32) for a random d(delta)."""
+import os
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from oracle import videoseal_ref as R  # noqa: E402
+from oracle.inputs import synthetic_frames, synthetic_msgs  # noqa: E402
+from oracle.weights import make_state_dict, spec_from_card, tiny_spec  # noqa: E402
+from tests.test_gpu_bwd import _lib, _padded, _rand  # noqa: E402
+from tests.test_gpu_e2e import make_model  # noqa: E402
+from tests.test_oracle_golden import CARDS  # noqa: E402
+
+from videoseal_amd import native as N  # noqa: E402
+
+
+def _nhwc(t, ld):
+    C = t.shape[1]
+    return _padded(t.detach().permute(0, 2, 3, 1).reshape(-1, C), ld).contiguous()
+
+
+@pytest.mark.parametrize("rows,C,ld", [(300, 8, 8), (1000, 20, 20), (70, 6, 8), (5000, 64, 64)])
+def test_bn_relu_bwd(rows, C, ld):
+    L, st = _lib()
+    raw = (_rand(rows, C, seed=1) * 1.5 + 0.2).requires_grad_(True)
+    gam, bet = (_rand(C, seed=2) * 0.5 + 1).requires_grad_(True), _rand(C, seed=3, scale=0.3).requires_grad_(True)
+    y = F.relu(F.batch_norm(raw, None, None, gam, bet, training=True, eps=1e-5))
+    dy = _rand(rows, C, seed=4)
+    y.backward(dy)
+    ra, dya = _padded(raw.detach(), ld), _padded(dy, ld)
+    part = torch.empty(int(L.vs_bn_partial_doubles(rows, ld)), dtype=torch.float64, device="cuda")
+    sums = torch.empty(2 * ld + 1, dtype=torch.float64, device="cuda")
+    N.check(L.vs_bn_partial_sums(N.ptr(ra), rows, C, ld, N.ptr(part), N.ptr(sums), st), "vs_bn_partial_sums")
+    v = torch.zeros(4, ld, device="cuda")
+    gp, bp = _padded(gam.detach()[None], ld)[0].contiguous(), _padded(bet.detach()[None], ld)[0].contiguous()
+    N.check(L.vs_bn_finish_sums(N.ptr(sums), C, ld, N.ptr(gp), N.ptr(bp), 1e-5, 0.1, None, None, N.ptr(v[0]), N.ptr(v[1]), st), "vs_bn_finish_sums")
+    N.check(L.vs_bn_mean_rstd(N.ptr(sums), C, ld, 1e-5, N.ptr(v[2]), N.ptr(v[3]), st), "vs_bn_mean_rstd")
+    rd = raw.detach().double()
+    assert (v[2][:C].double() - rd.mean(0)).abs().max() < 1e-6
+    assert (v[3][:C].double() - 1 / torch.sqrt(rd.var(0, unbiased=False) + 1e-5)).abs().max() < 1e-5
+    ldp = (C + 3) // 4 * 4
+    bpart = torch.empty(int(L.vs_bn_bwd_partial_floats(rows, ldp)), device="cuda")
+    bsums = torch.empty(2 * ldp + 1, dtype=torch.float64, device="cuda")
+    dg, db = torch.empty(C, device="cuda"), torch.empty(C, device="cuda")
+    N.check(L.vs_bn_relu_bwd_sums(N.ptr(ra), ld, N.ptr(dya), ld, N.ptr(v[2]), N.ptr(v[3]), N.ptr(v[0]), N.ptr(v[1]), 1, rows, C, N.ptr(bpart), N.ptr(bsums),
+                                  N.ptr(dg), N.ptr(db), st), "vs_bn_relu_bwd_sums")
+    assert float(bsums[-1]) == rows
+    dx = torch.full((rows, ld), 7.0, device="cuda")
+    N.check(L.vs_bn_relu_bwd_apply(N.ptr(ra), ld, N.ptr(dya), ld, N.ptr(v[2]), N.ptr(v[3]), N.ptr(v[0]), N.ptr(v[1]), 1, N.ptr(bsums), rows, C, N.ptr(dx),
+                                   ld, st), "vs_bn_relu_bwd_apply")
+    assert (dx[:, :C] - raw.grad).abs().max() <= 5e-5 * raw.grad.abs().max()
+    assert (dx[:, C:] == 0).all()
+    assert (dg - gam.grad).abs().max() <= 5e-5 * gam.grad.abs().max()
+    assert (db - bet.grad).abs().max() <= 5e-5 * bet.grad.abs().max()
+
+
+@pytest.mark.parametrize("B,H,W,C,ld", [(2, 8, 8, 4, 4), (1, 9, 7, 6, 8), (2, 5, 6, 8, 8)])
+def test_stride2_conv_adjoint_pieces(B, H, W, C, ld):
+    """vs_dilate2 (+ the flipped conv, here through F.conv2d) and vs_im2col3x3_strided against autograd of conv2d(stride=2, padding=1)"""
+    L, st = _lib()
+    Co = 5
+    x = _rand(B, C, H, W, seed=5).requires_grad_(True)
+    w = _rand(Co, C, 3, 3, seed=6).requires_grad_(True)
+    y = F.conv2d(x, w, stride=2, padding=1)
+    dy = _rand(*y.shape, seed=7)
+    y.backward(dy)
+    Ho, Wo = y.shape[-2:]
+    dya = _nhwc(dy, 8)
+    dil = torch.full((B * H * W, 8), 7.0, device="cuda")
+    N.check(L.vs_dilate2(N.ptr(dya), B, Ho, Wo, 8, H, W, N.ptr(dil), st), "vs_dilate2")
+    dil_nchw = dil.view(B, H, W, 8)[..., :Co].permute(0, 3, 1, 2)
+    dx = F.conv2d(dil_nchw, w.detach().flip(2, 3).permute(1, 0, 2, 3), padding=1)
+    assert (dx - x.grad).abs().max() < 3e-5
+    xa = _nhwc(x, ld)
+    cols = torch.full((B * Ho * Wo, 9 * ld), 7.0, device="cuda")
+    N.check(L.vs_im2col3x3_strided(N.ptr(xa), B, H, W, ld, 2, N.ptr(cols), st), "vs_im2col3x3_strided")
+    dw = (dya[:, :Co].t() @ cols).view(Co, 3, 3, ld)[..., :C].permute(0, 3, 1, 2)
+    assert (dw - w.grad).abs().max() <= 3e-5 * w.grad.abs().max()
+
+
+@pytest.mark.parametrize("B,H,W,C1,C2", [(2, 4, 5, 4, 8), (1, 1, 3, 4, 4), (2, 7, 3, 8, 4), (1, 2, 2, 4, 4)])
+def test_upcat2x_bwd(B, H, W, C1, C2):
+    L, st = _lib()
+    x, sk = _rand(B, C1, H, W, seed=8).requires_grad_(True), _rand(B, C2, H, W, seed=9).requires_grad_(True)
+    s = 2 ** -0.5
+    y = F.interpolate(torch.cat([x, sk * s], 1), scale_factor=2, mode="bilinear", align_corners=False)
+    dy = _rand(*y.shape, seed=10)
+    y.backward(dy)
+    # forward of the existing kernel first (the adjoint must match ITS tap convention)
+    xa, ska = _nhwc(x, C1), _nhwc(sk, C2)
+    cat = torch.empty(B * 4 * H * W, C1 + C2, device="cuda")
+    N.check(L.vs_upcat2x(N.ptr(xa), C1, C1, N.ptr(ska), C2, C2, s, B, H, W, N.ptr(cat), C1 + C2, st), "vs_upcat2x")
+    assert (cat - _nhwc(y, C1 + C2)).abs().max() < 2e-6
+    dya = _nhwc(dy, C1 + C2)
+    dx, dsk = torch.full((B * H * W, C1), 7.0, device="cuda"), torch.full((B * H * W, C2), 7.0, device="cuda")
+    N.check(L.vs_upcat2x_bwd(N.ptr(dya), C1 + C2, B, H, W, C1, C2, s, N.ptr(dx), C1, N.ptr(dsk), C2, st), "vs_upcat2x_bwd")
+    assert (dx - _nhwc(x.grad, C1)).abs().max() < 2e-5
+    assert (dsk - _nhwc(sk.grad, C2)).abs().max() < 2e-5
+
+
+def test_msg_table_outc_and_relu_adjoints():
+    L, st = _lib()
+    # message table
+    Bm, nbits, hidden = 3, 7, 12
+    table = _rand(2 * nbits, hidden, seed=11).requires_grad_(True)
+    msgs = (torch.rand(Bm, nbits, generator=torch.Generator().manual_seed(12)) > 0.5).cuda()
+    rows_sel = 2 * torch.arange(nbits, device="cuda")[None] + msgs.long()
+    lat = table[rows_sel].sum(1)
+    dlat = _rand(Bm, hidden, seed=13)
+    lat.backward(dlat)
+    dt = torch.empty(2 * nbits, hidden, device="cuda")
+    N.check(L.vs_msg_table_grad(N.ptr(dlat), N.ptr(msgs.to(torch.int32).contiguous()), Bm, nbits, hidden, N.ptr(dt), st), "vs_msg_table_grad")
+    assert (dt - table.grad).abs().max() < 1e-6
+    # output conv + tanh
+    B, HW, C, oc = 2, 30, 8, 3
+    x = _rand(B, HW, C, seed=14).requires_grad_(True)
+    w, b = _rand(oc, C, seed=15).requires_grad_(True), _rand(oc, seed=16).requires_grad_(True)
+    delta = torch.tanh(F.linear(x, w, b)).permute(0, 2, 1).contiguous()                  # planar [B][oc][HW]
+    dd = _rand(B, oc, HW, seed=17)
+    delta.backward(dd)
+    dx = torch.full((B * HW, C), 7.0, device="cuda")
+    dv = torch.empty(B * HW, 4, device="cuda")
+    N.check(L.vs_outc_tanh_bwd(N.ptr(delta.detach()), N.ptr(dd), HW, B, C, N.ptr(w.detach().contiguous()), oc, 1, N.ptr(dx), C, N.ptr(dv), st),
+            "vs_outc_tanh_bwd")
+    assert (dx - x.grad.reshape(-1, C)).abs().max() < 1e-5
+    assert (dv[:, :oc].t() @ x.detach().reshape(-1, C) - w.grad).abs().max() < 1e-4
+    assert (dv[:, :oc].sum(0) - b.grad).abs().max() < 1e-4 and (dv[:, oc:] == 0).all()
+    # ReLU
+    z, dy = _rand(50, 6, seed=18), _rand(50, 6, seed=19)
+    za, dya = _padded(z, 8), _padded(dy, 8)
+    dz = torch.full((50, 8), 7.0, device="cuda")
+    N.check(L.vs_relu_bwd(N.ptr(za), 8, N.ptr(dya), 8, 50, 6, N.ptr(dz), 8, st), "vs_relu_bwd")
+    assert torch.equal(dz[:, :6], dy * (z > 0)) and (dz[:, 6:] == 0).all()
+
+
+def _embedder_case(spec, sd, n, seed):
+    import ctypes as C
+    from videoseal_amd.model import _msgs_i32
+    from videoseal_amd.training import EmbedderBackward
+    S = spec.img_size
+    imgs = synthetic_frames(n, S, S, seed=seed)
+    x01 = imgs if not spec.yuv else (0.299 * imgs[:, 0:1] + 0.587 * imgs[:, 1:2] + 0.114 * imgs[:, 2:3])
+    x01 = x01[:, : spec.in_ch].contiguous()
+    msgs = synthetic_msgs(n, spec.nbits, seed=seed)
+    dd = torch.randn(n, spec.out_ch, S, S, generator=torch.Generator().manual_seed(seed)) * 1e-3
+    # oracle: autograd through the functional U-Net with batch-statistics BatchNorm
+    names = [k for k, v in sd.items() if k.startswith("embedder.unet.") and v.dtype.is_floating_point and "running" not in k]
+    sdg = {k: v.clone() for k, v in sd.items()}
+    for k in names:
+        sdg[k].requires_grad_(True)
+    ref = R.embedder_forward(sdg, spec, x01, msgs, {})
+    ref.backward(dd)
+    # HIP
+    model = make_model(spec, sd).train()
+    eng = model._engine()
+    xd = x01.cuda()
+    key = eng.new_act("t.emb.in", n, S, S, spec.in_ch, 4)
+    ymat = (C.c_float * 3)(1.0, 0.0, 0.0) if spec.in_ch == 1 else None
+    N.check(eng.lib.vs_resize_pre(N.ptr(xd), n, spec.in_ch, S, S, S, S, 0, None, 1.0, 0.0, N.ptr(key.t), 1, ymat, N.stream()), "vs_resize_pre")
+    eb = EmbedderBackward(model)
+    delta, saved = eb.forward_keep(eng, key, _msgs_i32(msgs, eng.dev))
+    assert (delta.cpu() - ref.detach()).abs().max() < 2e-5
+    grads = eb.backward(eng, saved, dd.cuda())
+    torch.cuda.synchronize()
+    worst = 0.0
+    for k in names:
+        rf = sdg[k].grad
+        if rf is None:
+            continue
+        assert k in grads, k
+        got = grads[k].reshape(rf.shape).cpu()
+        err = float((got - rf).abs().max() / rf.abs().max().clamp_min(1e-12))
+        worst = max(worst, err)
+        assert err < 5e-3, (k, err)
+    missing = [k for k in names if sdg[k].grad is not None and k not in grads]
+    assert not missing, missing
+    print(f"worst relative gradient error over {len(names)} tensors: {worst:.2e}")
+
+
+def test_embedder_backward_tiny_matches_oracle_autograd():
+    spec = tiny_spec()
+    _embedder_case(spec, make_state_dict(spec, seed=3), 3, 51)
+
+
+def test_embedder_backward_vs10_matches_oracle_autograd():
+    spec = spec_from_card(os.path.join(CARDS, "videoseal_1.0.yaml"))
+    _embedder_case(spec, make_state_dict(spec, seed=0), 2, 52)

@@ -30,6 +30,8 @@ EXPORTS = [
     "vs_gemm_wgrad_partial_floats", "vs_gemm_wgrad", "vs_dwconv7", "vs_dwconv7_wgrad_partial_floats", "vs_dwconv7_wgrad", "vs_colreduce_partial_floats",
     "vs_layernorm_bwd", "vs_gelu_grn_bwd", "vs_patchify", "vs_unpatch", "vs_col2im3x3_reflect", "vs_colmean", "vs_pool_gelu_bwd", "vs_matmul_small",
     "vs_bce_logits",
+    "vs_bn_mean_rstd", "vs_bn_bwd_partial_floats", "vs_bn_relu_bwd_sums", "vs_bn_relu_bwd_apply", "vs_dilate2", "vs_im2col3x3_strided", "vs_upcat2x_bwd",
+    "vs_msg_table_grad", "vs_outc_tanh_bwd", "vs_relu_bwd",
 ]
 
 
@@ -142,6 +144,15 @@ def lib() -> C.CDLL:
         "vs_pool_gelu_bwd": [P, I64, P, I64, I, I, I, P, I64, P],
         "vs_matmul_small": [P, I64, P, I64, I, I, I, P, I64, P],
         "vs_bce_logits": [P, P, I, I, I, F, F, P, P, P],
+        "vs_bn_mean_rstd": [P, I, I64, F, P, P, P],
+        "vs_bn_relu_bwd_sums": [P, I64, P, I64, P, P, P, P, I, I64, I, P, P, P, P, P],
+        "vs_bn_relu_bwd_apply": [P, I64, P, I64, P, P, P, P, I, P, I64, I, P, I64, P],
+        "vs_dilate2": [P, I, I, I, I64, I, I, P, P],
+        "vs_im2col3x3_strided": [P, I, I, I, I64, I, P, P],
+        "vs_upcat2x_bwd": [P, I64, I, I, I, I, I, F, P, I64, P, I64, P],
+        "vs_msg_table_grad": [P, P, I, I, I, P, P],
+        "vs_outc_tanh_bwd": [P, P, I64, I, I, P, I, I, P, I64, P, P],
+        "vs_relu_bwd": [P, I64, P, I64, I64, I, P, I64, P],
     }
     for name, args in sig.items():
         fn = getattr(L, name)
@@ -156,7 +167,7 @@ def lib() -> C.CDLL:
     L.vs_bn_partial_doubles.restype = C.c_int64
     L.vs_bn_partial_doubles.argtypes = [I64, I64]
     for name, args in (("vs_gemm_wgrad_partial_floats", [I64, I, I]), ("vs_dwconv7_wgrad_partial_floats", [I, I, I64]),
-                       ("vs_colreduce_partial_floats", [I, I64, I64])):
+                       ("vs_colreduce_partial_floats", [I, I64, I64]), ("vs_bn_bwd_partial_floats", [I64, I64])):
         getattr(L, name).restype = C.c_int64
         getattr(L, name).argtypes = args
     L.vs_sizeof_conv_desc.restype = C.c_int

@@ -288,3 +288,255 @@ class DetectorStep:
                 else:
                     prm.grad.add_(gten)
         return loss[0], logits, grads
+
+
+class EmbedderBackward:
+    """Backward of the U-Net embedder under model.train() (unet.py:17-197 with BatchNorm on batch statistics): gradients of every
+    `embedder.*` parameter from d(delta), the gradient with respect to the embedder's output [B, out_ch, S, S] -- the generator side of
+    train.py:626-643 up to the JND / blend / augmentation adjoints that produce d(delta) from the loss.
+
+    STATUS (end of round 2): written against CPU-verified formulas, compiled, NOT yet run on hardware -- tests/experimental_gpu_bwd_unet.py
+    holds the unit tests and the end-to-end comparison with autograd through the oracle; nothing in the product path calls this class."""
+
+    def __init__(self, model):
+        cfg = model.embedder.cfg
+        if cfg.unet_norm == "rms":
+            raise N.NativeError("EmbedderBackward covers the BatchNorm / ReLU U-Net of the released 1.0 / PixelSeal / ChunkySeal cards")
+        self.model = model
+        self.h = DetectorStep.__new__(DetectorStep)          # the small helpers (_act, _vec, _colsum, _wgrad, _ln_bwd, _tw)
+        self.h._ones = {}
+
+    # ------------------------------------------------------------------ pieces
+    def _bn_stats(self, eng: HipEngine, raw: Act, bn: dict):
+        """batch statistics of `raw` (global over the ranks with SyncBatchNorm): scale, shift, mean, rstd -- running statistics untouched"""
+        L, st = eng.lib, N.stream()
+        part = eng.buf("tr.bn.part", 2 * int(L.vs_bn_partial_doubles(raw.rows, raw.ld)))
+        sums = eng.buf("tr.bn.sums", 2 * (2 * raw.ld + 2)).view(torch.float64)[: 2 * raw.ld + 1]
+        N.check(L.vs_bn_partial_sums(N.ptr(raw.t), raw.rows, raw.C, raw.ld, N.ptr(part), N.ptr(sums), st), "vs_bn_partial_sums")
+        if eng.bn_sync is not None:
+            eng.bn_sync(sums)
+        v = torch.zeros(4, raw.ld, device=eng.dev, dtype=torch.float32)
+        N.check(L.vs_bn_finish_sums(N.ptr(sums), raw.C, raw.ld, N.ptr(bn["w"]), N.ptr(bn["b"]), 1e-5, 0.1, None, None, N.ptr(v[0]), N.ptr(v[1]), st),
+                "vs_bn_finish_sums")
+        N.check(L.vs_bn_mean_rstd(N.ptr(sums), raw.C, raw.ld, 1e-5, N.ptr(v[2]), N.ptr(v[3]), st), "vs_bn_mean_rstd")
+        return dict(scale=v[0], shift=v[1], mean=v[2], rstd=v[3])
+
+    def _affine_act(self, eng, x: Act, scale, shift, act, out: Act, add: Optional[Act] = None):
+        N.check(eng.lib.vs_scale_shift_act(N.ptr(x.t), x.rows, rup(x.C, 4), x.ld, N.ptr(scale), N.ptr(shift), act, N.ptr(add.t) if add is not None else None,
+                                           add.ld if add is not None else 0, N.ptr(out.t), out.ld, N.stream()), "vs_scale_shift_act")
+        return out
+
+    def _bn_bwd(self, eng, raw: Act, dy: Act, stt: dict, tag: str):
+        """BatchNorm (batch statistics) + ReLU backward: d raw, d gamma, d beta"""
+        L, st = eng.lib, N.stream()
+        C = raw.C
+        ldp = rup(C, 4)
+        part = eng.buf("tr.bnb.part", int(L.vs_bn_bwd_partial_floats(raw.rows, ldp)))
+        sums = eng.buf("tr.bnb.sums", 2 * (2 * ldp + 2)).view(torch.float64)[: 2 * ldp + 1]
+        dg = torch.empty(C, device=eng.dev, dtype=torch.float32)
+        db = torch.empty(C, device=eng.dev, dtype=torch.float32)
+        N.check(L.vs_bn_relu_bwd_sums(N.ptr(raw.t), raw.ld, N.ptr(dy.t), dy.ld, N.ptr(stt["mean"]), N.ptr(stt["rstd"]), N.ptr(stt["scale"]),
+                                      N.ptr(stt["shift"]), 1, raw.rows, C, N.ptr(part), N.ptr(sums), N.ptr(dg), N.ptr(db), st), "vs_bn_relu_bwd_sums")
+        if eng.bn_sync is not None:
+            eng.bn_sync(sums)                      # SyncBatchNorm's backward exchange: [sum g xhat | sum g | rows]
+        dx = self.h._act(eng, tag, raw.B, raw.H, raw.W, C, raw.ld)
+        N.check(L.vs_bn_relu_bwd_apply(N.ptr(raw.t), raw.ld, N.ptr(dy.t), dy.ld, N.ptr(stt["mean"]), N.ptr(stt["rstd"]), N.ptr(stt["scale"]),
+                                       N.ptr(stt["shift"]), 1, N.ptr(sums), raw.rows, C, N.ptr(dx.t), dx.ld, st), "vs_bn_relu_bwd_apply")
+        return dx, dg, db
+
+    @staticmethod
+    def _flip_t(w4: torch.Tensor, in_ld: int) -> ConvW:
+        """backward-data weights of a 3x3 stride-1 pad-1 conv: W'[ci][co][ky][kx] = W[co][ci][2 - ky][2 - kx]"""
+        wb = w4.float().flip(2, 3).permute(1, 0, 2, 3).contiguous()
+        p, cp = pack_conv(wb, in_ld)
+        return ConvW(p, None, wb.shape[0], 3, 3, cp)
+
+    def _cols_zero(self, eng, x: Act, stride: int, tag: str) -> Act:
+        L, st = eng.lib, N.stream()
+        Ho, Wo = (x.H - 1) // stride + 1, (x.W - 1) // stride + 1
+        cols = Act(eng.buf("tr." + tag, x.B * Ho * Wo * 9 * x.ld, zero=True), x.B, Ho, Wo, 9 * x.ld, 9 * x.ld)
+        if stride == 1:
+            N.check(L.vs_im2col3x3(N.ptr(x.t), x.B, x.H, x.W, x.ld, N.PAD_ZERO, N.ptr(cols.t), st), "vs_im2col3x3")
+        else:
+            N.check(L.vs_im2col3x3_strided(N.ptr(x.t), x.B, x.H, x.W, x.ld, stride, N.ptr(cols.t), st), "vs_im2col3x3_strided")
+        return cols
+
+    def _conv3_wgrad(self, eng, dy: Act, co: int, x: Act, ci: int, stride: int = 1) -> torch.Tensor:
+        cols = self._cols_zero(eng, x, stride, "cols3")
+        dw = self.h._wgrad(eng, dy, co, cols, 9 * x.ld)                       # [co][tap * ld + c]
+        return dw.view(co, 3, 3, x.ld)[..., :ci].permute(0, 3, 1, 2).contiguous()
+
+    # ------------------------------------------------------------------ forward that keeps the backward's operands
+    def _resblock_keep(self, eng, x: Act, p, tag: str, out: Optional[Act] = None):
+        h = self.h
+        cout = p["cout"]
+        raw0 = h._act(eng, tag + ".raw0", x.B, x.H, x.W, cout)
+        eng.conv(x, p["c0"], raw0, pad=1)
+        s0 = self._bn_stats(eng, raw0, p["bn"][0])
+        t = h._act(eng, tag + ".t", x.B, x.H, x.W, cout)
+        self._affine_act(eng, raw0, s0["scale"], s0["shift"], N.ACT_RELU, t)
+        raw1 = h._act(eng, tag + ".raw1", x.B, x.H, x.W, cout)
+        eng.conv(t, p["c1"], raw1, pad=1)
+        s1 = self._bn_stats(eng, raw1, p["bn"][1])
+        rs = h._act(eng, tag + ".rs", x.B, x.H, x.W, cout)
+        eng.conv(x, p["res"], rs)
+        if out is None:
+            out = h._act(eng, tag + ".o", x.B, x.H, x.W, cout)
+        self._affine_act(eng, raw1, s1["scale"], s1["shift"], N.ACT_RELU, out, add=rs)
+        return out, dict(x=x, raw0=raw0, t=t, raw1=raw1, s0=s0, s1=s1)
+
+    def forward_keep(self, eng: HipEngine, x: Act, msgs_i32: torch.Tensor):
+        if eng.Et is None:
+            eng._pack_embedder(eng._g, train=True)
+        c, E, L, st, g, h = eng.cfg, eng.Et, eng.lib, N.stream(), eng._g, self.h
+        B, nlev = x.B, len(c.zc) - 1
+        S = {"downs": [], "bott": [], "ups": []}
+        o, S["inc"] = self._resblock_keep(eng, x, E["inc"], "e.inc")
+        hid = [o]
+        for i in range(nlev):
+            src = hid[-1]
+            Ho, Wo = (src.H - 1) // 2 + 1, (src.W - 1) // 2 + 1
+            dwn = h._act(eng, f"e.down{i}.d", B, Ho, Wo, c.zc[i + 1])
+            eng.conv(src, E["downs"][i]["down"], dwn, stride=2, pad=1)
+            out = h._act(eng, "e.h3", B, Ho, Wo, c.bott) if i == nlev - 1 else None
+            if out is not None:
+                out = Act(out.t, B, Ho, Wo, c.zc[-1], out.ld)               # the resblock writes columns [0, zc[-1]) of [lat | msg]
+            o, rec = self._resblock_keep(eng, dwn, E["downs"][i]["rb"], f"e.down{i}", out=out)
+            S["downs"].append(dict(src=src, dwn=dwn, rb=rec))
+            hid.append(Act(o.t, B, Ho, Wo, c.bott, o.ld) if i == nlev - 1 else o)
+        h3 = hid[-1]
+        Bm = msgs_i32.shape[0]
+        lat = eng.buf("tr.e.lat", Bm * c.hidden)
+        N.check(L.vs_msg_latent(N.ptr(E["table"]), N.ptr(msgs_i32), Bm, c.nbits, c.hidden, N.ptr(lat), st), "vs_msg_latent")
+        N.check(L.vs_broadcast_channels(N.ptr(lat), Bm, c.hidden, N.ptr(h3.t), B, h3.H * h3.W, h3.ld, c.zc[-1], st), "vs_broadcast_channels")
+        xcur = h3
+        for j in range(c.num_blocks):
+            xcur, rec = self._resblock_keep(eng, xcur, E["bott"][j], f"e.bott{j}")
+            S["bott"].append(rec)
+        zz = c.zc[:-1] + [c.bott]
+        for k in range(nlev):
+            skip = hid.pop()
+            up = E["ups"][k]
+            cout = zz[nlev - 1 - k]
+            cat = h._act(eng, f"e.up{k}.cat", B, 2 * xcur.H, 2 * xcur.W, xcur.C + skip.C)
+            N.check(L.vs_upcat2x(N.ptr(xcur.t), xcur.C, xcur.ld, N.ptr(skip.t), skip.C, skip.ld, 2 ** -0.5, B, xcur.H, xcur.W, N.ptr(cat.t), cat.ld, st),
+                    "vs_upcat2x")
+            wup = g(f"embedder.unet.ups.{k}.up.upsample_block.2.weight").float()              # [cout, cin, 3, 3]
+            wcols = torch.zeros(cout, 9, cat.ld, device=eng.dev)
+            wcols[:, :, : cat.C] = wup.permute(0, 2, 3, 1).reshape(cout, 9, cat.C)
+            wcols = wcols.reshape(cout, 9 * cat.ld)
+            pw, cpw = pack_conv(wcols[:, :, None, None], 9 * cat.ld)
+            cols = Act(eng.buf(f"tr.e.up{k}.cols", cat.rows * 9 * cat.ld, zero=True), B, cat.H, cat.W, 9 * cat.ld, 9 * cat.ld)
+            N.check(L.vs_im2col3x3(N.ptr(cat.t), B, cat.H, cat.W, cat.ld, N.PAD_REFLECT, N.ptr(cols.t), st), "vs_im2col3x3")
+            cv = h._act(eng, f"e.up{k}.cv", B, cat.H, cat.W, cout)
+            eng.conv(cols, ConvW(pw, None, cout, 1, 1, cpw), cv)
+            z = h._act(eng, f"e.up{k}.z", B, cat.H, cat.W, cout)
+            eng.layernorm(cv, up["lnw"], up["lnb"], z)
+            ln = h._act(eng, f"e.up{k}.ln", B, cat.H, cat.W, cout)
+            self._affine_act(eng, z, h._vec(eng, z.ld, 1.0), h._vec(eng, z.ld, 0.0), N.ACT_RELU, ln)
+            xin = xcur
+            xcur, rec = self._resblock_keep(eng, ln, up["rb"], f"e.up{k}")
+            S["ups"].append(dict(xin=xin, skip=skip, cat=cat, cols=cols, wcols=wcols, cv=cv, z=z, rb=rec, cout=cout))
+        delta = torch.empty(B * c.out_ch * xcur.H * xcur.W, device=eng.dev, dtype=torch.float32)
+        N.check(L.vs_outc_tanh(N.ptr(xcur.t), xcur.H * xcur.W, B, xcur.C, xcur.ld, N.ptr(E["outc_w"]), N.ptr(E["outc_b"]), c.out_ch,
+                               1 if c.last_tanh else 0, N.ptr(delta), st), "vs_outc_tanh")
+        S.update(last=xcur, delta=delta, msgs=msgs_i32, h3=h3)
+        return delta.view(B, c.out_ch, xcur.H, xcur.W), S
+
+    # ------------------------------------------------------------------ backward
+    def _resblock_bwd(self, eng, rec, p, name: str, dout: Act, G: Dict[str, torch.Tensor], tag: str, need_dx: bool = True,
+                      dx_add: Optional[Act] = None) -> Optional[Act]:
+        """gradients of one ResnetBlock (unet.py:17-39); returns d x (+ dx_add) or None"""
+        h, g = self.h, eng._g
+        x, raw0, t, raw1 = rec["x"], rec["raw0"], rec["t"], rec["raw1"]
+        cin, cout = x.C, raw1.C
+        draw1, dg, db = self._bn_bwd(eng, raw1, dout, rec["s1"], tag + ".draw1")
+        G[name + ".double_conv.4.weight"], G[name + ".double_conv.4.bias"] = dg, db
+        G[name + ".res_conv.weight"] = h._wgrad(eng, dout, cout, x, cin).view(cout, cin, 1, 1)
+        G[name + ".res_conv.bias"] = h._colsum(eng, dout, cout)
+        G[name + ".double_conv.3.weight"] = self._conv3_wgrad(eng, draw1, cout, t, cout)
+        dt = h._act(eng, tag + ".dt", x.B, x.H, x.W, cout)
+        eng.conv(draw1, self._flip_t(g(name + ".double_conv.3.weight"), draw1.ld), dt, pad=1, arith=BWD_ARITH)
+        draw0, dg, db = self._bn_bwd(eng, raw0, dt, rec["s0"], tag + ".draw0")
+        G[name + ".double_conv.1.weight"], G[name + ".double_conv.1.bias"] = dg, db
+        G[name + ".double_conv.0.weight"] = self._conv3_wgrad(eng, draw0, cout, x, cin)
+        if not need_dx:
+            return None
+        dxr = h._act(eng, tag + ".dxr", x.B, x.H, x.W, cin, x.ld)             # through the 1x1 res_conv (+ whatever else flows into x)
+        eng.conv(dout, h._tw(g(name + ".res_conv.weight").reshape(cout, cin), dout.ld), dxr, arith=BWD_ARITH, res=dx_add)
+        dx = h._act(eng, tag + ".dx", x.B, x.H, x.W, cin, x.ld)
+        eng.conv(draw0, self._flip_t(g(name + ".double_conv.0.weight"), draw0.ld), dx, pad=1, arith=BWD_ARITH, res=dxr)
+        return dx
+
+    def backward(self, eng: HipEngine, S, ddelta: torch.Tensor) -> Dict[str, torch.Tensor]:
+        c, E, L, st, g, h = eng.cfg, eng.Et, eng.lib, N.stream(), eng._g, self.h
+        u = "embedder.unet"
+        G: Dict[str, torch.Tensor] = {}
+        nlev = len(c.zc) - 1
+        last = S["last"]
+        B, HW = last.B, last.H * last.W
+        # ---- output conv (+ tanh)
+        dd = N.f32c(ddelta.to(eng.dev)).reshape(-1)
+        dx = h._act(eng, "e.g.outc", B, last.H, last.W, last.C, last.ld)
+        dv = Act(eng.buf("tr.e.g.dv", last.rows * 4, zero=True), B, last.H, last.W, c.out_ch, 4)
+        N.check(L.vs_outc_tanh_bwd(N.ptr(S["delta"]), N.ptr(dd), HW, B, last.C, N.ptr(E["outc_w"]), c.out_ch, 1 if c.last_tanh else 0, N.ptr(dx.t),
+                                   dx.ld, N.ptr(dv.t), st), "vs_outc_tanh_bwd")
+        G[u + ".outc.weight"] = h._wgrad(eng, dv, c.out_ch, last, last.C).view(c.out_ch, last.C, 1, 1)
+        G[u + ".outc.bias"] = h._colsum(eng, dv, c.out_ch)
+        dcur = dx
+        dskips: Dict[int, Act] = {}                     # gradient that reaches hid[i] through its skip connection
+        # ---- up path, last group first
+        for k in range(nlev - 1, -1, -1):
+            rec, up = S["ups"][k], E["ups"][k]
+            name = f"{u}.ups.{k}"
+            dln = self._resblock_bwd(eng, rec["rb"], up["rb"], name + ".conv", dcur, G, f"e.g.up{k}")
+            z, cv, cat, cols, cout = rec["z"], rec["cv"], rec["cat"], rec["cols"], rec["cout"]
+            dz = h._act(eng, f"e.g.up{k}.dz", B, z.H, z.W, cout)
+            N.check(L.vs_relu_bwd(N.ptr(z.t), z.ld, N.ptr(dln.t), dln.ld, z.rows, cout, N.ptr(dz.t), dz.ld, st), "vs_relu_bwd")
+            dcv, dw, db = h._ln_bwd(eng, cv, dz, up["lnw"], f"e.g.up{k}.dcv")
+            G[name + ".up.upsample_block.3.weight"], G[name + ".up.upsample_block.3.bias"] = dw, db
+            dwc = h._wgrad(eng, dcv, cout, cols, 9 * cat.ld)
+            G[name + ".up.upsample_block.2.weight"] = dwc.view(cout, 3, 3, cat.ld)[..., : cat.C].permute(0, 3, 1, 2).contiguous()
+            dcols = Act(eng.buf(f"tr.e.g.up{k}.dcols", cat.rows * 9 * cat.ld, zero=True), B, cat.H, cat.W, 9 * cat.ld, 9 * cat.ld)
+            eng.conv(dcv, h._tw(rec["wcols"], dcv.ld), dcols, arith=BWD_ARITH)
+            dcat = h._act(eng, f"e.g.up{k}.dcat", B, cat.H, cat.W, cat.C, cat.ld)
+            N.check(L.vs_col2im3x3_reflect(N.ptr(dcols.t), B, cat.H, cat.W, cat.ld, N.ptr(dcat.t), st), "vs_col2im3x3_reflect")
+            xin, skip = rec["xin"], rec["skip"]
+            dxin = h._act(eng, f"e.g.up{k}.dxin", B, xin.H, xin.W, xin.C, xin.ld)
+            dsk = h._act(eng, f"e.g.up{k}.dskip", B, skip.H, skip.W, skip.C, skip.ld)
+            N.check(L.vs_upcat2x_bwd(N.ptr(dcat.t), dcat.ld, B, xin.H, xin.W, xin.C, skip.C, 2 ** -0.5, N.ptr(dxin.t), dxin.ld, N.ptr(dsk.t), dsk.ld, st),
+                    "vs_upcat2x_bwd")
+            dskips[nlev - k] = dsk                      # hid index of that skip: k = 0 pops hid[nlev] (= h3), k = nlev - 1 pops hid[1]
+            dcur = dxin
+        # ---- bottleneck
+        for j in range(c.num_blocks - 1, -1, -1):
+            add = dskips.pop(nlev) if j == 0 else None                          # h3 also feeds ups[0] as its skip
+            dcur = self._resblock_bwd(eng, S["bott"][j], E["bott"][j], f"{u}.bottleneck.model.{j}", dcur, G, f"e.g.bott{j}", dx_add=add)
+        # ---- message channels of h3 = [lat | msg]
+        dh3 = dcur
+        Bm = S["msgs"].shape[0]
+        colm = eng.buf("tr.e.g.h3mean", B * dh3.ld)
+        N.check(L.vs_colmean(N.ptr(dh3.t), B, dh3.H * dh3.W, dh3.ld, N.ptr(colm), st), "vs_colmean")
+        dlat = (colm.view(B, dh3.ld)[:, c.zc[-1]: c.zc[-1] + c.hidden] * float(dh3.H * dh3.W)).contiguous()
+        if Bm == 1:
+            dlat = dlat.sum(0, keepdim=True).contiguous()
+        dtab = torch.empty(2 * c.nbits, c.hidden, device=eng.dev, dtype=torch.float32)
+        N.check(L.vs_msg_table_grad(N.ptr(dlat), N.ptr(S["msgs"]), Bm, c.nbits, c.hidden, N.ptr(dtab), st), "vs_msg_table_grad")
+        G[u + ".msg_processor.msg_embeddings.weight"] = dtab
+        dcur = Act(dh3.t, B, dh3.H, dh3.W, c.zc[-1], dh3.ld)                   # the latent part flows on into the last down block
+        # ---- down path
+        for i in range(nlev - 1, -1, -1):
+            rec = S["downs"][i]
+            name = f"{u}.downs.{i}"
+            ddwn = self._resblock_bwd(eng, rec["rb"], E["downs"][i]["rb"], name + ".conv", dcur, G, f"e.g.down{i}")
+            src, dwn = rec["src"], rec["dwn"]
+            co, ci = dwn.C, src.C
+            G[name + ".down.weight"] = self._conv3_wgrad(eng, ddwn, co, src, ci, stride=2)
+            G[name + ".down.bias"] = h._colsum(eng, ddwn, co)
+            dil = h._act(eng, f"e.g.down{i}.dil", B, src.H, src.W, co, ddwn.ld)
+            N.check(L.vs_dilate2(N.ptr(ddwn.t), B, dwn.H, dwn.W, ddwn.ld, src.H, src.W, N.ptr(dil.t), st), "vs_dilate2")
+            dsrc = h._act(eng, f"e.g.down{i}.dsrc", B, src.H, src.W, ci, src.ld)
+            eng.conv(dil, self._flip_t(g(name + ".down.weight"), dil.ld), dsrc, pad=1, arith=BWD_ARITH, res=dskips.pop(i, None))
+            dcur = dsrc
+        self._resblock_bwd(eng, S["inc"], E["inc"], u + ".inc", dcur, G, "e.g.inc", need_dx=False)       # the frames need no gradient
+        return G
