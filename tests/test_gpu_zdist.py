@@ -1,4 +1,5 @@
-"""The RCCL branch on one GPU (world size 1 over the `nccl` backend = RCCL): the sharded extraction equals the single-process
+"""(Named *_zdist so that it is collected LAST: the process-group tests run after every kernel / parity test of the suite.)
+The RCCL branch on one GPU (world size 1 over the `nccl` backend = RCCL): the sharded extraction equals the single-process
 call, and bench.py's distributed step (barrier, all-gather of the logits, max-over-ranks timing) runs end to end."""
 import json
 import os
