@@ -1,7 +1,8 @@
 #!/usr/bin/env python
 """CPU check (float64, torch autograd as the judge) of the index / adjoint formulas the backward kernels are written to:
 reflect-padded 3x3 patch-matrix adjoint, flipped depthwise taps and their weight gradient, stride-2 conv adjoint through zero dilation,
-bilinear x2 adjoint in gather form, BatchNorm(batch statistics) + ReLU, LayerNorm, GELU + GRN.  Runs anywhere: python tools/check_bwd_formulas.py"""
+bilinear x2 adjoint in gather form, BatchNorm(batch statistics) + ReLU, GELU + GRN, and the (anti-aliased) bilinear resize of
+csrc/shell.hip::make_taps with its gather-form adjoint (the kernel for it is still to be written).  Runs anywhere: python tools/check_bwd_formulas.py"""
 import math
 
 import torch
@@ -35,8 +36,52 @@ def up_contrib(y, H):
     return out
 
 
+def tri(x):
+    x = abs(x)
+    return 1 - x if x < 1 else 0.0
+
+
+def resize_taps(i, n_in, n_out, aa):
+    """csrc/shell.hip::make_taps restated: (first source index, normalised weights) of output index i"""
+    scale = n_in / n_out
+    if aa:
+        support = scale if scale >= 1 else 1.0
+        center, inv = scale * (i + 0.5), (1 / scale if scale >= 1 else 1.0)
+        lo, hi = max(int(center - support + 0.5), 0), min(int(center + support + 0.5), n_in)
+        ws = [tri((j + lo - center + 0.5) * inv) for j in range(hi - lo)]
+        tot = sum(ws)
+        return lo, [w / tot for w in ws]
+    src = max(scale * (i + 0.5) - 0.5, 0.0)
+    i0 = min(int(src), n_in - 1)
+    return (i0, [1 - (src - i0), src - i0]) if i0 < n_in - 1 else (i0, [1.0])
+
+
+def resize_candidates(s, n_in, n_out, aa):
+    """outputs whose taps can include source s (the loop bounds of the gather-form adjoint kernel still to be written)"""
+    scale = n_in / n_out
+    support = (scale if scale >= 1 else 1.0) if aa else 1.0
+    return max(math.floor((s + 0.5 - support - 1) / scale - 0.5), 0), min(math.ceil((s + 0.5 + support + 1) / scale - 0.5), n_out - 1)
+
+
 def main():
     worst = 0.0
+    for aa in (True, False):                                            # (anti-aliased) bilinear resize: forward taps and gather-form adjoint
+        for (n_in, n_out) in [(64, 88), (64, 72), (90, 64), (70, 64), (64, 64), (5, 17), (17, 5), (3, 2), (2, 3)]:
+            x = torch.randn(1, 1, 1, n_in, dtype=dt, requires_grad=True)
+            y = F.interpolate(x, size=(1, n_out), mode="bilinear", align_corners=False, antialias=aa)
+            dy = torch.randn_like(y)
+            y.backward(dy)
+            for o in range(n_out):
+                lo, ws = resize_taps(o, n_in, n_out, aa)
+                worst = max(worst, abs(float(sum(w * x.detach()[0, 0, 0, lo + j] for j, w in enumerate(ws)) - y.detach()[0, 0, 0, o])))
+            for s in range(n_in):
+                a, b = resize_candidates(s, n_in, n_out, aa)
+                acc = 0.0
+                for o in range(a, b + 1):
+                    lo, ws = resize_taps(o, n_in, n_out, aa)
+                    if lo <= s < lo + len(ws):
+                        acc += ws[s - lo] * float(dy[0, 0, 0, o])
+                worst = max(worst, abs(acc - float(x.grad[0, 0, 0, s])))
     for (H, W) in [(5, 7), (2, 2), (3, 9), (2, 5)]:                     # col2im, reflect
         C, N = 2, 3
         x = torch.randn(1, C, H, W, dtype=dt, requires_grad=True)
