@@ -233,7 +233,6 @@ int vs_bce_logits(const float* preds, const int32_t* msgs, int msg_rows, int B, 
                   float* loss, void* stream);
 
 /* ---- backward building blocks of the U-Net embedder under model.train() (csrc/bwd_unet.hip; the generator side of train.py:626-643).
- * NOT yet run on hardware (written at the end of round 2 against CPU-verified formulas).
  * vs_bn_mean_rstd: batch statistics from the (all-reduced) moment vector of vs_bn_partial_sums.  vs_bn_relu_bwd_sums / _apply: BatchNorm
  *   on batch statistics (+ the ReLU that follows it) backward in two halves -- sums = [sum g xhat | sum g | rows] (2 * 4 ceil(C/4) + 1
  *   doubles) is what SyncBatchNorm all-reduces between them; dgamma / dbeta are the local sums.  vs_dilate2 + the forward conv on flipped
@@ -255,6 +254,34 @@ int vs_msg_table_grad(const float* dlat, const int32_t* msgs, int Bm, int nbits,
 int vs_relu_bwd(const float* z, int64_t ld, const float* dy, int64_t dy_ld, int64_t rows, int C, float* dz, int64_t dz_ld, void* stream);
 int vs_outc_tanh_bwd(const float* delta, const float* ddelta, int64_t rows_per_frame, int B, int C, const float* w, int Cout, int use_tanh,
                      float* dx, int64_t dx_ld, float* dv, void* stream);
+
+/* ---- adjoints of the full-resolution shell and of the augmentations between embed and detect (csrc/bwd_shell.hip): d(loss)/d(imgs_w) and
+ * d(loss)/d(imgs_aug) -> d(delta), the gradient the U-Net backward starts from (train.py:626-643).  Gather form, deterministic.
+ * vs_resize_nchw_bwd: transpose of vs_resize_nchw (dy [planes][oh][ow] -> dx [planes][H][W]; tmp = planes * oh * W floats); also the transpose of
+ *   the watermark's up-resize inside vs_embed_tail (wam.py:99-101) when called with (H, W) = (S_h, S_w).
+ * vs_embed_tail_bwd: blend / attenuation(imgs, imgs_w) / clamp of wam.py:103-113 (hmap_full = the heat-map of vs_jnd_heatmap or NULL;
+ *   preds = the forward's preds_w): g_full [F][Cd][H][W] from d_imgs_w [F][3][H][W] (and/or d_preds_w).
+ * vs_tail_key_reduce: key-frame expansion adjoint (videoseal.py:80-118) times the low-resolution heat-map (or NULL): d_delta [total_key][Cd][S][S].
+ * vs_aug_crop_flip_bwd / vs_mask_mul / vs_aug_color_bwd / vs_clamp01_bwd: Crop, HorizontalFlip, the mask blend of augmenter.py:175, Brightness /
+ *   Contrast / Saturation / Grayscale (op codes of vs_aug_color; hue has no adjoint here), the clamp in front of JPEG's straight-through estimator.
+ * vs_nhwc_to_nchw_scaled: the extractor's input gradient (NHWC) back to frame planes, times d(x * 2 - 1) / dx.
+ * vs_percep_mse / vs_percep_mse_grad: the "mse" / "yuv" perceptual term (perceptual.py:20-28, yuvloss.py:11-27) and upstream * d loss / d imgs_w;
+ *   partial = vs_percep_partial_doubles(F, H, W) doubles. */
+int vs_resize_nchw_bwd(const float* dy, float* dx, int planes, int H, int W, int oh, int ow, int antialias, float* tmp, void* stream);
+int vs_embed_tail_bwd(const float* imgs, const float* preds, const float* hmap_full, const float* d_imgs_w, const float* d_preds_w, int F, int H, int W,
+                      int Cd, int clamp, float scaling_i, float scaling_w, float* g_full, void* stream);
+int vs_tail_key_reduce(const float* g_low, const float* hmap_low, int F, int Cd, int S_h, int S_w, int step, int video_mode, int total_key,
+                       float* d_delta, void* stream);
+int vs_aug_crop_flip_bwd(const float* dy, float* dx, int planes, int H, int W, int i0, int j0, int h, int w, int flip, void* stream);
+int vs_mask_mul(const float* dy, const float* mask, float* dx, int F, int C, int H, int W, int complement, void* stream);
+int64_t vs_aug_color_bwd_scratch_floats(int F, int H, int W);
+int vs_aug_color_bwd(const float* x, const float* dy, float* dx, int F, int H, int W, int op, float factor, const float* means, float* scratch,
+                     void* stream);
+int vs_clamp01_bwd(const float* x, const float* dy, float* dx, int64_t n, void* stream);
+int vs_nhwc_to_nchw_scaled(const float* src, int F, int H, int W, int C, int64_t ld, float mul, float* dst, void* stream);
+int64_t vs_percep_partial_doubles(int F, int H, int W);
+int vs_percep_mse(const float* imgs, const float* imgs_w, int F, int H, int W, int yuv, double* partial, float* loss, void* stream);
+int vs_percep_mse_grad(const float* imgs, const float* imgs_w, int F, int H, int W, int yuv, float upstream, float* d_imgs_w, void* stream);
 
 /* Bilinear x2 (align_corners=False) of cat(x, skip*skip_scale) along channels.  unet.py:186-191 + common.py:46. */
 int vs_upcat2x(const float* x, int C1, int64_t ld1, const float* skip, int C2, int64_t ld2, float skip_scale,

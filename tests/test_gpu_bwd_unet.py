@@ -1,10 +1,12 @@
-"""NOT collected by default (the file name does not match test_*.py): GPU tests of the U-Net backward written at the end of round 2
-without GPU time left (csrc/bwd_unet.hip, videoseal_amd.training.EmbedderBackward).  First command of the next round:
+"""GPU tests of the U-Net backward (csrc/bwd_unet.hip, videoseal_amd.training.EmbedderBackward).  Unit level: every kernel against torch
+autograd of the same op on the GPU.  End to end: all `embedder.unet.*` gradients against autograd through the oracle's functional U-Net
+(CPU, fp32) for a random d(delta).
 
-    python -m pytest tests/experimental_gpu_bwd_unet.py -q
-
-Once green, rename to tests/test_gpu_bwd_unet.py.  Unit level: every new kernel against torch autograd of the same op on the GPU.
-End to end: all `embedder.*` gradients against autograd through the oracle's functional U-Net (CPU, fp32) for a random d(delta)."""
+The U-Net is piecewise linear in its ReLUs: a forward that differs in the last bits flips a few of the ~10^7 ReLU decisions and moves the
+gradient discretely -- the CPU oracle run in fp32 and in fp64 already differs by up to 1.3 % of a tensor's largest element on the VideoSeal 1.0
+U-Net (median 0.27 %; /tmp-free reproduction: tools/relu_flip_sensitivity.py).  The comparison therefore runs the oracle's autograd WITH THE
+RELU DECISIONS OF THE HIP FORWARD (read back from the operands the backward keeps): every remaining difference is arithmetic, and the
+tolerance is tight.  The unconstrained comparison is kept with the tolerance the fp32-vs-fp64 experiment justifies."""
 import os
 
 import pytest
@@ -142,7 +144,48 @@ def test_msg_table_outc_and_relu_adjoints():
     assert torch.equal(dz[:, :6], dy * (z > 0)) and (dz[:, 6:] == 0).all()
 
 
-def _embedder_case(spec, sd, n, seed):
+class _MaskedF:
+    """stands in for torch.nn.functional inside oracle.videoseal_ref: relu(x) = x * mask_i with the i-th ReLU decision of the HIP forward"""
+
+    def __init__(self, masks):
+        self.masks, self.i = masks, 0
+
+    def __getattr__(self, k):
+        return getattr(F, k)
+
+    def relu(self, x):
+        m = self.masks[self.i]
+        self.i += 1
+        assert m.shape == x.shape, (self.i, m.shape, x.shape)
+        return x * m
+
+
+def hip_relu_masks(model, saved):
+    """the ReLU decisions of EmbedderBackward.forward_keep in the order oracle.videoseal_ref.unet_forward calls F.relu"""
+    eng = model._engine()
+    L, st = eng.lib, N.stream()
+
+    def nchw(act, t=None):
+        tt = act.t if t is None else t
+        return (tt.view(act.B, act.H, act.W, act.ld)[..., : act.C].permute(0, 3, 1, 2) > 0).float().cpu()
+
+    def block(rec):
+        raw1, s1 = rec["raw1"], rec["s1"]
+        tmp = torch.empty_like(raw1.t)
+        N.check(L.vs_scale_shift_act(N.ptr(raw1.t), raw1.rows, (raw1.C + 3) // 4 * 4, raw1.ld, N.ptr(s1["scale"]), N.ptr(s1["shift"]), N.ACT_RELU, None, 0,
+                                     N.ptr(tmp), raw1.ld, st), "vs_scale_shift_act")
+        return [nchw(rec["t"]), nchw(raw1, tmp)]
+    masks = block(saved["inc"])
+    for d in saved["downs"]:
+        masks += block(d["rb"])
+    for rec in saved["bott"]:
+        masks += block(rec)
+    for u in saved["ups"]:
+        masks += [nchw(u["z"])] + block(u["rb"])
+    return masks
+
+
+def _embedder_case(spec, sd, n, seed, masked=True):
     import ctypes as C
     from videoseal_amd.model import _msgs_i32
     from videoseal_amd.training import EmbedderBackward
@@ -152,13 +195,7 @@ def _embedder_case(spec, sd, n, seed):
     x01 = x01[:, : spec.in_ch].contiguous()
     msgs = synthetic_msgs(n, spec.nbits, seed=seed)
     dd = torch.randn(n, spec.out_ch, S, S, generator=torch.Generator().manual_seed(seed)) * 1e-3
-    # oracle: autograd through the functional U-Net with batch-statistics BatchNorm
     names = [k for k, v in sd.items() if k.startswith("embedder.unet.") and v.dtype.is_floating_point and "running" not in k]
-    sdg = {k: v.clone() for k, v in sd.items()}
-    for k in names:
-        sdg[k].requires_grad_(True)
-    ref = R.embedder_forward(sdg, spec, x01, msgs, {})
-    ref.backward(dd)
     # HIP
     model = make_model(spec, sd).train()
     eng = model._engine()
@@ -168,29 +205,53 @@ def _embedder_case(spec, sd, n, seed):
     N.check(eng.lib.vs_resize_pre(N.ptr(xd), n, spec.in_ch, S, S, S, S, 0, None, 1.0, 0.0, N.ptr(key.t), 1, ymat, N.stream()), "vs_resize_pre")
     eb = EmbedderBackward(model)
     delta, saved = eb.forward_keep(eng, key, _msgs_i32(msgs, eng.dev))
-    assert (delta.cpu() - ref.detach()).abs().max() < 2e-5
     grads = eb.backward(eng, saved, dd.cuda())
     torch.cuda.synchronize()
-    worst = 0.0
+    # oracle: autograd through the functional U-Net with batch-statistics BatchNorm (and, masked, the HIP forward's ReLU decisions)
+    sdg = {k: v.clone() for k, v in sd.items()}
+    for k in names:
+        sdg[k].requires_grad_(True)
+    real_F = R.F
+    try:
+        if masked:
+            R.F = _MaskedF(hip_relu_masks(model, saved))
+        ref = R.embedder_forward(sdg, spec, x01, msgs, {})
+        if masked:
+            assert R.F.i == len(R.F.masks)
+    finally:
+        R.F = real_F
+    ref.backward(dd)
+    assert (delta.cpu() - ref.detach()).abs().max() < 2e-5
+    errs = []
     for k in names:
         rf = sdg[k].grad
         if rf is None:
             continue
         assert k in grads, k
         got = grads[k].reshape(rf.shape).cpu()
-        err = float((got - rf).abs().max() / rf.abs().max().clamp_min(1e-12))
-        worst = max(worst, err)
-        assert err < 5e-3, (k, err)
+        errs.append((float((got - rf).abs().max() / rf.abs().max().clamp_min(1e-12)), k))
     missing = [k for k in names if sdg[k].grad is not None and k not in grads]
     assert not missing, missing
-    print(f"worst relative gradient error over {len(names)} tensors: {worst:.2e}")
+    errs.sort(reverse=True)
+    print(f"{'masked' if masked else 'free'}: worst relative gradient errors over {len(errs)} tensors: {[(round(e, 6), k) for e, k in errs[:4]]}; "
+          f"median {errs[len(errs) // 2][0]:.2e}")
+    return errs
 
 
 def test_embedder_backward_tiny_matches_oracle_autograd():
     spec = tiny_spec()
-    _embedder_case(spec, make_state_dict(spec, seed=3), 3, 51)
+    errs = _embedder_case(spec, make_state_dict(spec, seed=3), 3, 51)
+    assert errs[0][0] < 2e-4, errs[:5]            # same ReLU decisions: what is left is fp32 arithmetic
 
 
 def test_embedder_backward_vs10_matches_oracle_autograd():
     spec = spec_from_card(os.path.join(CARDS, "videoseal_1.0.yaml"))
-    _embedder_case(spec, make_state_dict(spec, seed=0), 2, 52)
+    errs = _embedder_case(spec, make_state_dict(spec, seed=0), 2, 52)
+    assert errs[0][0] < 5e-4, errs[:5]
+
+
+def test_embedder_backward_unconstrained_within_the_relu_flip_noise():
+    """without sharing the ReLU decisions the oracle itself moves by ~1 % (fp32 vs fp64 on the CPU): median and worst bounds of that order"""
+    spec = tiny_spec()
+    errs = _embedder_case(spec, make_state_dict(spec, seed=3), 3, 51, masked=False)
+    assert errs[len(errs) // 2][0] < 1e-2 and errs[0][0] < 8e-2, errs[:5]

@@ -8,20 +8,24 @@ so a seeded run picks the same strengths.  Out of scope and loud: the H.264/H.26
 SURVEY 8(f)2).  Rotate / Perspective follow torchvision's grid construction + ATen grid_sample (torchvision itself is
 not vendored by the reference: pinned against oracle/augment.py only).
 
-Forward values only: the reference wraps JPEG / MedianFilter in a straight-through estimator whose forward value
-is the codec / filter output, which is what these kernels produce; there is no autograd here.
+Inside a differentiable forward (model.forward under autograd, videoseal_amd/autograd.py) every op is a graph node whose backward is a HIP
+kernel too: Crop / HorizontalFlip / Resize / Brightness / Contrast / Saturation / Grayscale have exact adjoints, JPEG / MedianFilter /
+GaussianNoise / the codecs are the reference's straight-through estimators (forward value = codec / filter output, identity gradient), and
+the ops without an adjoint kernel (GaussianBlur, Rotate, Perspective, Hue, DropFrame, SpeedChange) raise in backward instead of cutting the graph.
 """
 from __future__ import annotations
 
 import ctypes as C
 import math
 import os
+import warnings
 from typing import Dict, List, Optional, Tuple
 
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from . import autograd as AG
 from . import native as N
 
 COLOR_OPS = {"brightness": 0, "contrast": 1, "saturation": 2, "hue": 3, "grayscale": 4}
@@ -38,6 +42,8 @@ def _planes(x: torch.Tensor) -> Tuple[int, int, int]:
 
 
 def color_op(x: torch.Tensor, op: str, factor: float) -> torch.Tensor:
+    if AG.needs_grad(x):
+        return AG.ColorFn.apply(x, op, factor)
     x = _dev(x)
     F_, Cc, H, W = x.shape
     if Cc != 3:
@@ -50,6 +56,8 @@ def color_op(x: torch.Tensor, op: str, factor: float) -> torch.Tensor:
 
 
 def crop_flip(x: torch.Tensor, i: int, j: int, h: int, w: int, flip: bool = False) -> torch.Tensor:
+    if AG.needs_grad(x):
+        return AG.CropFlipFn.apply(x, i, j, h, w, flip)
     x = _dev(x)
     planes, H, W = _planes(x)
     out = torch.empty(x.shape[0], x.shape[1], h, w, device=x.device, dtype=torch.float32)
@@ -58,6 +66,8 @@ def crop_flip(x: torch.Tensor, i: int, j: int, h: int, w: int, flip: bool = Fals
 
 
 def resize(x: torch.Tensor, size: Tuple[int, int], antialias: bool = True) -> torch.Tensor:
+    if AG.needs_grad(x):
+        return AG.ResizeFn.apply(x, tuple(size), antialias)
     x = _dev(x)
     planes, H, W = _planes(x)
     out = torch.empty(x.shape[0], x.shape[1], size[0], size[1], device=x.device, dtype=torch.float32)
@@ -65,7 +75,33 @@ def resize(x: torch.Tensor, size: Tuple[int, int], antialias: bool = True) -> to
     return out
 
 
+def _ste(x: torch.Tensor, fn, clamp01: bool = False) -> torch.Tensor:
+    """`x + (fn(x) - x).detach()` of valuemetric.py:35, 90 / video.py:113: forward value fn(x), identity gradient (masked to 0 <= x <= 1 when
+    the op clamps first)"""
+    if AG.needs_grad(x):
+        with torch.no_grad():
+            y = fn(x)
+        return AG.SteFn.apply(x, y, clamp01)
+    return fn(x)
+
+
+def _no_adjoint(fn, what: str):
+    """forward values from the kernel; inside a differentiable forward the node raises in backward instead of cutting the graph"""
+    def wrapped(x, *a, **k):
+        if AG.needs_grad(x):
+            with torch.no_grad():
+                y = fn(x, *a, **k)
+            return AG.NoAdjointFn.apply(x, y, what)
+        return fn(x, *a, **k)
+    wrapped.__doc__, wrapped.__name__ = fn.__doc__, fn.__name__
+    return wrapped
+
+
 def gaussian_blur(x: torch.Tensor, kernel_size: int) -> torch.Tensor:
+    if AG.needs_grad(x):
+        with torch.no_grad():
+            y = gaussian_blur(x, kernel_size)
+        return AG.NoAdjointFn.apply(x, y, "GaussianBlur")
     x = _dev(x)
     planes, H, W = _planes(x)
     sigma = 0.3 * ((kernel_size - 1) * 0.5 - 1) + 0.8            # torchvision default when sigma is None
@@ -211,7 +247,9 @@ class GaussianBlur(_Kernel):
 class MedianFilter(_Kernel):
     def forward(self, image, mask=None, kernel_size=None):
         kernel_size = kernel_size or self.get_random_kernel_size()
-        return median_filter(image, kernel_size), mask
+        if self.passthrough:                                   # valuemetric.py:89-90
+            return _ste(image, lambda t: median_filter(t, kernel_size)), mask
+        return _no_adjoint(median_filter, "MedianFilter(passthrough=False)")(image, kernel_size), mask
 
 
 class JPEG(_Aug):
@@ -227,7 +265,11 @@ class JPEG(_Aug):
     def forward(self, image, mask=None, quality=None):
         quality = quality or self.get_random_quality()
         squeeze = image.dim() == 3
-        out = jpeg_compress(image[None] if squeeze else image, quality)
+        img = image[None] if squeeze else image
+        if self.passthrough:                                   # valuemetric.py:33-35, 41: clamp, then the straight-through estimator
+            out = _ste(img, lambda t: jpeg_compress(t, quality), clamp01=True)
+        else:
+            out = _no_adjoint(jpeg_compress, "JPEG(passthrough=False)")(img, quality)
         return (out[0] if squeeze else out), mask
 
 
@@ -246,15 +288,21 @@ class GaussianNoise(_Aug):
 
     def forward(self, image, mask=None, std=None):
         std = self.get_random_std() if std is None else std
-        x = _dev(image)
-        noise = torch.randn_like(x)
-        out = torch.empty_like(x)
-        N.check(N.lib().vs_aug_add_scaled(N.ptr(x), N.ptr(noise), float(std), N.ptr(out), x.numel(), N.stream()), "vs_aug_add_scaled")
-        return out, mask
+        def add(x):
+            x = _dev(x)
+            noise = torch.randn_like(x)
+            out = torch.empty_like(x)
+            N.check(N.lib().vs_aug_add_scaled(N.ptr(x), N.ptr(noise), float(std), N.ptr(out), x.numel(), N.stream()), "vs_aug_add_scaled")
+            return out
+        return _ste(image, add), mask                          # d(x + noise * std) / dx = 1
 
 
 def gather_frames(x: torch.Tensor, indices) -> torch.Tensor:
     """frames[indices] for whole frames (any trailing shape) on the HIP gather kernel."""
+    if AG.needs_grad(x):
+        with torch.no_grad():
+            y = gather_frames(x, indices)
+        return AG.NoAdjointFn.apply(x, y, "DropFrame / SpeedChange")
     x = _dev(x)
     idx = torch.as_tensor(indices, dtype=torch.int32).to(x.device)
     out = torch.empty((idx.numel(),) + tuple(x.shape[1:]), device=x.device, dtype=torch.float32)
@@ -385,6 +433,10 @@ def perspective(x: torch.Tensor, startpoints, endpoints) -> torch.Tensor:
     return out
 
 
+rotate_values, perspective_values = rotate, perspective
+rotate, perspective = _no_adjoint(rotate, "Rotate"), _no_adjoint(perspective, "Perspective")
+
+
 class Rotate(_Aug):
     """geometric.py:28-59: multiples of 90 degrees with expand=True, the remainder with expand=False (both nearest)."""
 
@@ -453,6 +505,7 @@ def h264_proxy(frames: torch.Tensor, crf: int, rgb_mode: bool = False) -> torch.
 
 
 class VideoCompression(_Aug):
+    _warned = False
     """augmentation/video.py:20-119.  The reference encodes + decodes the clip with libx264 / libx265 through PyAV on the CPU and
     returns it behind a straight-through estimator.  Two back-ends here:
       * 'proxy' (default): the on-GPU transform-coding proxy of csrc/h264_proxy.hip -- H.264 4x4 core transform + quantisation at
@@ -466,6 +519,8 @@ class VideoCompression(_Aug):
         self.codec, self.crf, self.fps = codec, crf, fps
         self.pix_fmt = "yuv420p" if codec != "libx264rgb" else "rgb24"
         self.backend = os.environ.get("VIDEOSEAL_CODEC", "proxy")
+        if self.backend not in ("proxy", "pyav"):
+            raise ValueError(f"VIDEOSEAL_CODEC={self.backend!r}: expected 'proxy' or 'pyav'")
 
     def _pyav_roundtrip(self, frames: torch.Tensor, crf: int) -> torch.Tensor:
         try:
@@ -497,11 +552,20 @@ class VideoCompression(_Aug):
             if mask is not None:
                 mask = F.pad(mask, (0, mask.shape[3] % 2, 0, mask.shape[2] % 2))
         if self.backend == "pyav":
-            return self._pyav_roundtrip(frames, self.crf), mask
-        return h264_proxy(frames, self.crf, rgb_mode=(self.pix_fmt == "rgb24")), mask
+            return _ste(frames, lambda t: self._pyav_roundtrip(t, self.crf)), mask            # video.py:113
+        if not VideoCompression._warned:
+            VideoCompression._warned = True
+            warnings.warn(f"{self.codec}: the on-GPU transform-coding PROXY stands in for the real codec (no prediction, deblocking or rate "
+                          f"control: its distortion at a given crf is not libx264's).  VIDEOSEAL_CODEC=pyav selects the reference's PyAV round trip.")
+        return _ste(frames, lambda t: h264_proxy(t, self.crf, rgb_mode=(self.pix_fmt == "rgb24"))), mask
+
+    @property
+    def aug_name(self) -> str:
+        """name reported in `selected_aug` / logs: the class name, marked when the proxy stands in for the codec"""
+        return self.__class__.__name__ + ("proxy" if self.backend != "pyav" else "")
 
     def __repr__(self):
-        return f"Compressor(codec={self.codec}, crf={self.crf}, fps={self.fps})"
+        return f"Compressor(codec={self.codec}, crf={self.crf}, fps={self.fps}, backend={self.backend})"
 
 
 class _CrfCodec(VideoCompression):
@@ -521,7 +585,7 @@ class _CrfCodec(VideoCompression):
         return super().forward(frames, mask, crf or self.get_random_crf())
 
     def __repr__(self):
-        return self.__class__.__name__
+        return self.aug_name
 
 
 class H264(_CrfCodec):
@@ -604,6 +668,8 @@ def get_mask_embedder(kind=None, **kwargs):
 
 def mask_blend(imgs_w: torch.Tensor, imgs: torch.Tensor, mask: torch.Tensor) -> torch.Tensor:
     """augmenter.py:175  imgs_w * m + imgs * (1 - m), m [F,1,H,W]."""
+    if AG.needs_grad(imgs_w, imgs):
+        return AG.MaskBlendFn.apply(imgs_w, imgs, mask)
     a, b, m = _dev(imgs_w), _dev(imgs), _dev(mask)
     F_, Cc, H, W = a.shape
     if b.shape != a.shape or tuple(m.shape) != (F_, 1, H, W):
@@ -645,7 +711,7 @@ class Augmenter(nn.Module):
         if do_resize and image.shape[-2:] != (h, w):
             image = resize(image, (h, w), True)
             mask = resize(mask, (h, w), True)
-        return image, mask, aug.__class__.__name__
+        return image, mask, getattr(aug, "aug_name", aug.__class__.__name__)
 
     def forward(self, imgs_w, imgs, masks, is_video=True, do_resize=True):
         """augmenter.py:154-194.  Training: mask targets from the mask embedder, imgs_w * m + imgs * (1 - m), then num_augs picks.

@@ -8,6 +8,7 @@
 //                 IJG quantisation, jpeg_idct_islow, h2v2 fancy up-sampling, fixed-point YCC->RGB); entropy coding is
 //                 lossless and skipped.  Pinned against Pillow in tests (oracle/jpeg_ref.py is the numpy restatement).
 #include "vs_common.h"
+#include "resize_taps.h"
 
 namespace {
 
@@ -142,34 +143,7 @@ __global__ __launch_bounds__(256) void crop_flip_kernel(const float* __restrict_
   }
 }
 
-// ATen-compatible taps (same as shell.hip; duplicated on purpose to keep the translation units independent)
-struct Taps { int lo, n; float center, inv, total, l1; bool aa; };
-__device__ __forceinline__ float tri(float x) { x = fabsf(x); return x < 1.f ? 1.f - x : 0.f; }
-__device__ __forceinline__ Taps make_taps(int i, int in, int out, bool antialias) {
-  Taps t; t.aa = antialias;
-  const float scale = (float)in / (float)out;
-  if (antialias) {
-    const float support = scale >= 1.f ? scale : 1.f;
-    t.center = scale * (i + 0.5f);
-    t.inv = scale >= 1.f ? 1.f / scale : 1.f;
-    int lo = (int)(t.center - support + 0.5f); lo = lo < 0 ? 0 : lo;
-    int hi = (int)(t.center + support + 0.5f); hi = hi > in ? in : hi;
-    t.lo = lo; t.n = hi - lo;
-    float tot = 0.f;
-    for (int j = 0; j < t.n; ++j) tot += tri((j + lo - t.center + 0.5f) * t.inv);
-    t.total = tot; t.l1 = 0.f;
-  } else {
-    float src = scale * (i + 0.5f) - 0.5f; src = src < 0.f ? 0.f : src;
-    int i0 = (int)src; i0 = i0 > in - 1 ? in - 1 : i0;
-    t.lo = i0; t.n = 1 + (i0 < in - 1); t.l1 = src - i0; t.center = t.inv = t.total = 0.f;
-  }
-  return t;
-}
-__device__ __forceinline__ float tap_w(const Taps& t, int j) {
-  if (t.aa) { const float w = tri((j + t.lo - t.center + 0.5f) * t.inv); return t.total != 0.f ? w / t.total : w; }
-  if (t.n == 1) return 1.f;
-  return j == 0 ? 1.f - t.l1 : t.l1;
-}
+using namespace vs_taps;       // ATen-compatible taps (resize_taps.h)
 __global__ __launch_bounds__(256) void resize_nchw_kernel(const float* __restrict__ src, float* __restrict__ dst, int H, int W, int oh,
                                                           int ow, int antialias) {
   const int ox = blockIdx.x * 32 + (threadIdx.x & 31), oy = blockIdx.y * 8 + (threadIdx.x >> 5);

@@ -3,8 +3,8 @@
 // As in bwd_ops.hip, backward-DATA products are launches of the forward conv / GEMM kernels on flipped / transposed weights and weight
 // gradients are vs_gemm_wgrad over patch matrices; this file holds the adjoints that have no forward counterpart.  Reductions are
 // deterministic (fixed chunking and order, fp64 across chunks).
-//
-// STATUS: written against CPU-verified formulas (tools/check_bwd_formulas.py), compiled for gfx950, NOT yet run on hardware.
+// Index formulas checked in float64 against autograd on the CPU (tools/check_bwd_formulas.py); kernels against autograd on the GPU
+// (tests/test_gpu_bwd_unet.py).
 #include "vs_common.h"
 
 namespace {

@@ -4,80 +4,11 @@
 //   vs_embed_tail    : delta up-resize x JND(img) -> blend -> clamp, one pass over the frame
 // These are the HBM-bound kernels (7.08 MB read + 7.08 MB written per 768x768 frame in the tail).
 #include "vs_common.h"
+#include "resize_taps.h"
 
 namespace {
 
-// ---- ATen-compatible 1-D interpolation taps (aten/native/cpu/UpSampleKernel.cpp semantics) -------------------
-// antialias: triangle filter, support = max(scale,1), weights normalised over the taps that fall inside the input.
-// plain    : 2-tap bilinear, align_corners=False, source index clamped at 0.
-struct Taps {
-  int lo, n;          // first input index, tap count
-  float center, inv, total;   // antialias parameters
-  float l1;           // plain: weight of the second tap
-  bool aa;
-};
-
-__device__ __forceinline__ float tri(float x) { x = fabsf(x); return x < 1.f ? 1.f - x : 0.f; }
-
-__device__ __forceinline__ Taps make_taps(int i, int in, int out, bool antialias) {
-  Taps t;
-  t.aa = antialias;
-  const float scale = (float)in / (float)out;
-  if (antialias) {
-    const float support = scale >= 1.f ? scale : 1.f;
-    t.center = scale * (i + 0.5f);
-    t.inv = scale >= 1.f ? 1.f / scale : 1.f;
-    int lo = (int)(t.center - support + 0.5f);
-    lo = lo < 0 ? 0 : lo;
-    int hi = (int)(t.center + support + 0.5f);
-    hi = hi > in ? in : hi;
-    t.lo = lo;
-    t.n = hi - lo;
-    float tot = 0.f;
-    for (int j = 0; j < t.n; ++j) tot += tri((j + lo - t.center + 0.5f) * t.inv);
-    t.total = tot;
-    t.l1 = 0.f;
-  } else {
-    float src = scale * (i + 0.5f) - 0.5f;
-    src = src < 0.f ? 0.f : src;
-    int i0 = (int)src;
-    i0 = i0 > in - 1 ? in - 1 : i0;
-    t.lo = i0;
-    t.n = 1 + (i0 < in - 1);
-    t.l1 = src - i0;
-    t.center = t.inv = t.total = 0.f;
-  }
-  return t;
-}
-// first input index and tap count only (what make_taps computes, without the weight total)
-__device__ __forceinline__ void tap_range(int i, int in, int out, bool antialias, int& lo, int& n) {
-  const float scale = (float)in / (float)out;
-  if (antialias) {
-    const float support = scale >= 1.f ? scale : 1.f;
-    const float center = scale * (i + 0.5f);
-    int l = (int)(center - support + 0.5f);
-    l = l < 0 ? 0 : l;
-    int h = (int)(center + support + 0.5f);
-    h = h > in ? in : h;
-    lo = l;
-    n = h - l;
-  } else {
-    float src = scale * (i + 0.5f) - 0.5f;
-    src = src < 0.f ? 0.f : src;
-    int i0 = (int)src;
-    i0 = i0 > in - 1 ? in - 1 : i0;
-    lo = i0;
-    n = 1 + (i0 < in - 1);
-  }
-}
-__device__ __forceinline__ float tap_w(const Taps& t, int j) {
-  if (t.aa) {
-    const float w = tri((j + t.lo - t.center + 0.5f) * t.inv);
-    return t.total != 0.f ? w / t.total : w;
-  }
-  if (t.n == 1) return 1.f;   // last row/column: ATen blends the border pixel with itself
-  return j == 0 ? 1.f - t.l1 : t.l1;
-}
+using namespace vs_taps;
 
 // ---- frame element access: fp32 NCHW planes, or uint8 RGB24 (HWC, what inference_streaming.py:26 reads from the ffmpeg
 // pipe).  uint8 -> float is exactly `torch.tensor(clip, dtype=float32) / 255.0`; float -> uint8 is `(x * 255.0).byte()`

@@ -7,15 +7,16 @@ models/wam.py:18-234) for the inference path ``embed / detect / extract_message`
 
 Deliberate differences, each loud rather than silent:
   * no CPU / ATen execution path: the model must live on a ROCm device (``.to('cuda')``);
-  * forward values only: under ``model.train()`` the U-Net's BatchNorm runs on batch statistics and updates its running
-    statistics exactly like nn.BatchNorm2d, but there is no autograd graph (backward kernels are SURVEY.md 8(f)1);
+  * ``forward`` is differentiable (videoseal_amd/autograd.py): with autograd enabled and trainable parameters it returns tensors
+    whose graph nodes run the HIP backward kernels, so train.py's `loss.backward()` / `torch.autograd.grad(loss, last_layer)` / DDP hooks
+    work unchanged; under ``torch.no_grad()`` (or with everything frozen) it is the values-only launch sequence;
   * frames handed over on the CPU are copied to the model's device, processed there end to end and the
     results are copied back to ``imgs.device`` (the reference keeps the full-resolution shell on the CPU).
 """
 from __future__ import annotations
 
 import os
-from typing import Dict, Optional
+from typing import Dict, Optional, Tuple
 
 import torch
 import torch.nn as nn
@@ -188,6 +189,9 @@ class Wam(nn.Module):
         self._wgroups: Optional[Dict[str, list]] = None
         self._msg_cache: Optional[tuple] = None
         self._bn_sync = None          # set by videoseal_amd.dist.convert_sync_batchnorm: the BatchNorm exchange of distributed training
+        self._emb_bwd = self._det_bwd = None      # training.EmbedderBackward / DetectorStep of the differentiable forward (built on first use)
+        self._train_gen: Dict[str, int] = {}      # generation of the operands the HIP backward reads from the engine's workspace
+        self._warned_no_backward = False
         # hipGraph replay of the per-chunk launch sequences (fixed chunk shapes, e.g. streaming callers): the ~300 kernel
         # launches of an embed / detect chunk are captured once per (shape, flags) and replayed with one launch
         self.use_graphs = os.environ.get("VIDEOSEAL_GRAPHS", "0") == "1"
@@ -239,6 +243,8 @@ class Wam(nn.Module):
             self._eng = HipEngine(self.embedder.cfg, self.state_dict, dev)
             self._wkeys = {}
             self._graphs.clear()
+            self._emb_bwd = self._det_bwd = None
+            self._train_gen = {}
         # packed weights go stale when any source tensor is replaced (data_ptr) or written in place (_version): every tensor of
         # the group is part of the key
         stale = []
@@ -419,11 +425,79 @@ class Wam(nn.Module):
         rgb, _ = eng.resize_pre(N.f32c(imgs_aug), S, False, want_rgb=True, mul=2.0, add=-1.0, tag="det.in")
         return imgs_aug, masks, selected, eng.extractor_forward(rgb).clone()
 
-    @torch.no_grad()
+    def _trainable(self) -> Tuple[bool, bool]:
+        """(embedder, detector) have parameters that want gradients in the current autograd mode"""
+        if not torch.is_grad_enabled():
+            return False, False
+        cfg = self.embedder.cfg
+        emb = any(p.requires_grad for p in self.embedder.parameters())
+        det = any(p.requires_grad for p in self.detector.parameters())
+        why = []
+        if emb and cfg.unet_norm == "rms":
+            emb = False
+            why.append("the RMSNorm / SiLU U-Net of the legacy card")
+        if det and (cfg.extractor == "sam" or cfg.stem_stride != 4):
+            det = False
+            why.append("the ViT extractor" if cfg.extractor == "sam" else "the stride-2 stem of ChunkySeal's extractor")
+        if why and not self._warned_no_backward:
+            self._warned_no_backward = True
+            import warnings
+            warnings.warn("no HIP backward for " + " and ".join(why) + ": forward() returns values without a graph for that network "
+                          "(its parameters receive no gradient)")
+        return emb, det
+
+    def _forward_graph(self, x: torch.Tensor, masks, mi: torch.Tensor, *, step: int, video_mode: int, aa: bool, lowres: bool, is_video: bool,
+                       emb_train: bool):
+        """the differentiable forward (wam.py:86-125 / videoseal.py:181-243): EmbedTrainFn -> augmenter nodes -> ResizeFn -> DetectTrainFn"""
+        from . import augmentation as A
+        from . import autograd as AG
+        eng = self._engine()
+        if emb_train:
+            named = [(k, p) for k, p in AG._named_unique(self.embedder, "embedder.")]
+            opts = dict(step=step, video_mode=video_mode, antialias=aa, lowres=lowres)
+            imgs_w, preds_w = AG.EmbedTrainFn.apply(self, x, mi, opts, [k for k, _ in named], *[p for _, p in named])
+        else:
+            with torch.no_grad():
+                imgs_w = torch.empty_like(x)
+                preds_w = torch.empty(x.shape[0], self.embedder.cfg.out_ch, x.shape[-2], x.shape[-1], device=eng.dev, dtype=torch.float32)
+                self._embed_frames(eng, x, mi, imgs_w, step=step, video_mode=video_mode, antialias=aa, lowres=lowres, preds_w=preds_w, fwd_order=True)
+        imgs_aug, masks, selected = self.augmenter(imgs_w, x, masks.to(eng.dev) if torch.is_tensor(masks) else masks, is_video=is_video,
+                                                   do_resize=False)
+        S = (self.img_size, self.img_size)
+        if tuple(imgs_aug.shape[-2:]) != S:
+            imgs_aug = A.resize(imgs_aug, S, aa)
+        named = AG._named_unique(self.detector, "detector.")
+        if imgs_aug.requires_grad or any(p.requires_grad for _, p in named):
+            preds = AG.DetectTrainFn.apply(self, imgs_aug, [k for k, _ in named], *[p for _, p in named])
+        else:
+            with torch.no_grad():
+                rgb, _ = eng.resize_pre(N.f32c(imgs_aug), S, False, want_rgb=True, mul=2.0, add=-1.0, tag="det.in")
+                preds = eng.extractor_forward(rgb).clone()
+        return imgs_w, preds_w, imgs_aug, masks, selected, preds
+
     def forward(self, imgs: torch.Tensor, masks: torch.Tensor, msgs: torch.Tensor = None, interpolation: dict = None) -> dict:
-        """wam.py:68-132 (forward values only): embed (blend, then full-resolution attenuation(imgs, imgs_w), clamp) -> augmenter ->
-        resize to img_size -> detector.  `preds_w` is the UN-attenuated resized delta and `imgs_aug` the resized augmented batch,
-        like the reference.  BatchNorm follows ``self.embedder.training``."""
+        """wam.py:68-132: embed (blend, then full-resolution attenuation(imgs, imgs_w), clamp) -> augmenter -> resize to img_size ->
+        detector.  `preds_w` is the UN-attenuated resized delta and `imgs_aug` the resized augmented batch, like the reference.
+        BatchNorm follows ``self.embedder.training``.  With autograd enabled and trainable parameters the outputs carry a graph whose
+        backward runs on the HIP kernels (autograd.py); otherwise values only."""
+        emb_t, det_t = self._trainable()
+        if not (emb_t or det_t):
+            with torch.no_grad():
+                return self._forward_values(imgs, masks, msgs, interpolation)
+        if msgs is None:
+            msgs = self.get_random_msg(imgs.shape[0]).to(imgs.device)
+        eng = self._engine()
+        aa = _antialias_flag(_DEFAULT_INTERP if interpolation is None else interpolation)
+        back = imgs.device
+        with torch.cuda.device(eng.dev):
+            x = N.f32c(imgs.detach().to(eng.dev))
+            imgs_w, preds_w, imgs_aug, masks, selected, preds = self._forward_graph(
+                x, masks, self._msgs_dev(msgs, eng.dev), step=1, video_mode=0, aa=aa, lowres=False, is_video=False, emb_train=emb_t)
+        to = (lambda t: t.to(back) if torch.is_tensor(t) else t)     # noqa: E731
+        return {"msgs": msgs, "masks": to(masks), "preds_w": to(preds_w), "imgs_w": to(imgs_w), "imgs_aug": to(imgs_aug),
+                "preds": to(preds), "selected_aug": selected}
+
+    def _forward_values(self, imgs: torch.Tensor, masks: torch.Tensor, msgs: torch.Tensor = None, interpolation: dict = None) -> dict:
         if msgs is None:
             msgs = self.get_random_msg(imgs.shape[0]).to(imgs.device)
         eng = self._engine()
@@ -536,9 +610,8 @@ class Videoseal(Wam):
         decoded = aggregate_bits(bit_preds, aggregation)
         return (decoded > 0).squeeze().unsqueeze(0)
 
-    @torch.no_grad()
     def forward(self, imgs: torch.Tensor, masks: torch.Tensor, msgs: torch.Tensor = None, is_video: bool = True):
-        """videoseal.py:120-161 (forward values only)."""
+        """videoseal.py:120-161 (differentiable, see Wam.forward)."""
         assert not (is_video and len(imgs.shape) not in [4, 5]), \
             "If is_video is True, input shape should be [b, frames, c, h, w] or [frames, c, h, w]"
         assert not (not is_video and len(imgs.shape) != 4), "If is_video is False, input shape should be [b, c, h, w]"
@@ -549,7 +622,6 @@ class Videoseal(Wam):
                     for i in range(imgs.shape[0])]
         return self.video_forward(imgs, masks, msgs)
 
-    @torch.no_grad()
     def video_forward(self, imgs, masks, msgs=None, interpolation: dict = None) -> dict:
         """videoseal.py:163-256: the whole clip as one chunk, key frames every step_size, video_mode expansion, attenuation at low
         resolution (self.lowres_attenuation) or as attenuation(imgs, imgs_w) at full resolution, clamp, augment, resize, detect."""
@@ -563,12 +635,18 @@ class Videoseal(Wam):
         eng = self._engine()
         aa = _antialias_flag(_DEFAULT_INTERP if interpolation is None else interpolation)
         back = imgs.device
-        with torch.cuda.device(eng.dev):
-            x = N.f32c(imgs.to(eng.dev))
-            out = torch.empty_like(x)
-            self._embed_frames(eng, x, self._msgs_dev(msgs, eng.dev), out, step=int(self.step_size),
-                               video_mode=N.VIDEO_MODES[self.video_mode], antialias=aa, lowres=bool(self.lowres_attenuation), fwd_order=True)
-            imgs_aug, masks, selected, preds = self._augment_detect(eng, out, x, masks, True, aa)
+        emb_t, det_t = self._trainable()
+        with torch.cuda.device(eng.dev), torch.set_grad_enabled(emb_t or det_t):
+            x = N.f32c(imgs.detach().to(eng.dev))
+            if emb_t or det_t:
+                out, _, imgs_aug, masks, selected, preds = self._forward_graph(
+                    x, masks, self._msgs_dev(msgs, eng.dev), step=int(self.step_size), video_mode=N.VIDEO_MODES[self.video_mode], aa=aa,
+                    lowres=bool(self.lowres_attenuation), is_video=True, emb_train=emb_t)
+            else:
+                out = torch.empty_like(x)
+                self._embed_frames(eng, x, self._msgs_dev(msgs, eng.dev), out, step=int(self.step_size),
+                                   video_mode=N.VIDEO_MODES[self.video_mode], antialias=aa, lowres=bool(self.lowres_attenuation), fwd_order=True)
+                imgs_aug, masks, selected, preds = self._augment_detect(eng, out, x, masks, True, aa)
         to = (lambda t: t.to(back) if torch.is_tensor(t) else t)     # noqa: E731
         return {"msgs": msgs.expand(imgs.shape[0], -1), "masks": to(masks), "imgs_w": to(out), "imgs_aug": to(imgs_aug), "preds": to(preds),
                 "selected_aug": selected}

@@ -32,6 +32,8 @@ EXPORTS = [
     "vs_bce_logits",
     "vs_bn_mean_rstd", "vs_bn_bwd_partial_floats", "vs_bn_relu_bwd_sums", "vs_bn_relu_bwd_apply", "vs_dilate2", "vs_im2col3x3_strided", "vs_upcat2x_bwd",
     "vs_msg_table_grad", "vs_outc_tanh_bwd", "vs_relu_bwd",
+    "vs_resize_nchw_bwd", "vs_embed_tail_bwd", "vs_tail_key_reduce", "vs_aug_crop_flip_bwd", "vs_mask_mul", "vs_aug_color_bwd_scratch_floats",
+    "vs_aug_color_bwd", "vs_clamp01_bwd", "vs_nhwc_to_nchw_scaled", "vs_percep_partial_doubles", "vs_percep_mse", "vs_percep_mse_grad",
 ]
 
 
@@ -153,6 +155,16 @@ def lib() -> C.CDLL:
         "vs_msg_table_grad": [P, P, I, I, I, P, P],
         "vs_outc_tanh_bwd": [P, P, I64, I, I, P, I, I, P, I64, P, P],
         "vs_relu_bwd": [P, I64, P, I64, I64, I, P, I64, P],
+        "vs_resize_nchw_bwd": [P, P, I, I, I, I, I, I, P, P],
+        "vs_embed_tail_bwd": [P, P, P, P, P, I, I, I, I, I, F, F, P, P],
+        "vs_tail_key_reduce": [P, P, I, I, I, I, I, I, I, P, P],
+        "vs_aug_crop_flip_bwd": [P, P, I, I, I, I, I, I, I, I, P],
+        "vs_mask_mul": [P, P, P, I, I, I, I, I, P],
+        "vs_aug_color_bwd": [P, P, P, I, I, I, I, F, P, P, P],
+        "vs_clamp01_bwd": [P, P, P, I64, P],
+        "vs_nhwc_to_nchw_scaled": [P, I, I, I, I, I64, F, P, P],
+        "vs_percep_mse": [P, P, I, I, I, I, P, P, P],
+        "vs_percep_mse_grad": [P, P, I, I, I, I, F, P, P],
     }
     for name, args in sig.items():
         fn = getattr(L, name)
@@ -164,6 +176,9 @@ def lib() -> C.CDLL:
     L.vs_jpeg_workspace_bytes.argtypes = [I, I, I]
     L.vs_h264_proxy_workspace_bytes.restype = C.c_int64
     L.vs_h264_proxy_workspace_bytes.argtypes = [I, I, I]
+    for name in ("vs_aug_color_bwd_scratch_floats", "vs_percep_partial_doubles"):
+        getattr(L, name).restype = C.c_int64
+        getattr(L, name).argtypes = [I, I, I]
     L.vs_bn_partial_doubles.restype = C.c_int64
     L.vs_bn_partial_doubles.argtypes = [I64, I64]
     for name, args in (("vs_gemm_wgrad_partial_floats", [I64, I, I]), ("vs_dwconv7_wgrad_partial_floats", [I, I, I64]),

@@ -21,6 +21,19 @@ from .engine import A_MUL_GRN, Act, ConvW, HipEngine, pack_conv, rup
 BWD_ARITH = 3          # 3 x bf16: exact operand split, fp32 exponent range (vs_conv_desc_t::arith)
 
 
+class _GradSink(dict):
+    """gradient dictionary that drops everything when only the data path is wanted (the adaptive-weight probes of videosealloss.py:72-107
+    differentiate the loss with respect to one layer: no parameter gradient of the extractor is needed there)"""
+
+    def __init__(self, keep: bool = True):
+        super().__init__()
+        self.keep = keep
+
+    def __setitem__(self, k, v):
+        if self.keep:
+            super().__setitem__(k, v)
+
+
 class DetectorStep:
     """`step(imgs_aug, msgs)`: one accumulation step of train.py:626-643 with the embedder frozen.
 
@@ -55,6 +68,8 @@ class DetectorStep:
 
     def _colsum(self, eng, x: Act, n: int) -> torch.Tensor:
         """sum over the rows of the first n columns (bias gradients): the fp64 column sums of the BatchNorm kernels"""
+        if getattr(self, "_skip_w", False):
+            return None
         L = eng.lib
         part = eng.buf("tr.cs.part", 2 * int(L.vs_bn_partial_doubles(x.rows, x.ld)))
         sums = eng.buf("tr.cs.sums", 2 * (2 * x.ld + 2)).view(torch.float64)[: 2 * x.ld + 1]
@@ -63,6 +78,8 @@ class DetectorStep:
 
     def _wgrad(self, eng, dy: Act, n: int, x: Act, k: int) -> torch.Tensor:
         """dW[n][k] = sum_rows dy[row][:n]^T x[row][:k]"""
+        if getattr(self, "_skip_w", False):
+            return None
         L = eng.lib
         part = eng.buf("tr.wg.part", int(L.vs_gemm_wgrad_partial_floats(dy.rows, n, k)))
         dw = torch.empty(n, k, device=eng.dev, dtype=torch.float32)
@@ -158,22 +175,26 @@ class DetectorStep:
         return logits, S
 
     # ------------------------------------------------------------------ backward
-    def _backward(self, eng: HipEngine, S, dlogits: torch.Tensor) -> Dict[str, torch.Tensor]:
+    def _backward(self, eng: HipEngine, S, dlogits: torch.Tensor, want_params: bool = True, want_input: bool = False):
+        """gradients of every `detector.*` parameter (want_params) and / or of the extractor's input frames [B, 3, S, S] in [0, 1]
+        (want_input: the path the generator-side loss takes back to the embedder).  Returns G, or (G, d_input) with want_input."""
         c, X, L, st, g = eng.cfg, eng.X, eng.lib, N.stream(), eng._g
         d = c.dims
-        G: Dict[str, torch.Tensor] = {}
+        G: Dict[str, torch.Tensor] = _GradSink(want_params)
+        self._skip_w = not want_params          # _wgrad / _colsum return None: only the data path runs
         pd, cn = "detector.pixel_decoder", "detector.convnext"
         hl, z, hc, cols, cur = S["hl"], S["z"], S["hc"], S["cols"], S["last"]
         B, HW, Cl, N1 = hl.B, hl.H * hl.W, hl.C, c.nbits + 1
         # ---- Linear on the pooled features
         pooled = eng.buf("tr.head.pooled", B * hl.ld)
         N.check(L.vs_colmean(N.ptr(hl.t), B, HW, hl.ld, N.ptr(pooled), st), "vs_colmean")
-        dlt = dlogits.t().contiguous()                                    # [N1][B]
-        dlw = torch.empty(N1, Cl, device=eng.dev, dtype=torch.float32)
-        N.check(L.vs_matmul_small(N.ptr(dlt), B, N.ptr(pooled), hl.ld, N1, Cl, B, N.ptr(dlw), Cl, st), "vs_matmul_small")
-        dlb = torch.empty(N1, device=eng.dev, dtype=torch.float32)
-        N.check(L.vs_matmul_small(N.ptr(self._vec(eng, B, 1.0)), B, N.ptr(dlogits), N1, 1, N1, B, N.ptr(dlb), N1, st), "vs_matmul_small")
-        G[pd + ".linear.weight"], G[pd + ".linear.bias"] = dlw, dlb
+        if want_params:
+            dlt = dlogits.t().contiguous()                                    # [N1][B]
+            dlw = torch.empty(N1, Cl, device=eng.dev, dtype=torch.float32)
+            N.check(L.vs_matmul_small(N.ptr(dlt), B, N.ptr(pooled), hl.ld, N1, Cl, B, N.ptr(dlw), Cl, st), "vs_matmul_small")
+            dlb = torch.empty(N1, device=eng.dev, dtype=torch.float32)
+            N.check(L.vs_matmul_small(N.ptr(self._vec(eng, B, 1.0)), B, N.ptr(dlogits), N1, 1, N1, B, N.ptr(dlb), N1, st), "vs_matmul_small")
+            G[pd + ".linear.weight"], G[pd + ".linear.bias"] = dlw, dlb
         dpooled = eng.buf("tr.head.dpooled", B * hl.ld)
         N.check(L.vs_matmul_small(N.ptr(dlogits), N1, N.ptr(X["lin_w"]), Cl, B, Cl, N1, N.ptr(dpooled), hl.ld, st), "vs_matmul_small")
         # ---- mean over (H, W), GELU, LayerNorm
@@ -182,8 +203,9 @@ class DetectorStep:
         dhc, dw, db = self._ln_bwd(eng, hc, dz, X["head_ln"][0], "head.dhc")
         G[pd + ".output_upscaling.0.upsample_block.3.weight"], G[pd + ".output_upscaling.0.upsample_block.3.bias"] = dw, db
         # ---- reflect-pad conv3x3 (no bias)
-        dwc = self._wgrad(eng, dhc, Cl, cols, 9 * cur.ld)
-        G[pd + ".output_upscaling.0.upsample_block.2.weight"] = dwc.view(Cl, 3, 3, cur.ld)[..., :Cl].permute(0, 3, 1, 2).contiguous()
+        if want_params:
+            dwc = self._wgrad(eng, dhc, Cl, cols, 9 * cur.ld)
+            G[pd + ".output_upscaling.0.upsample_block.2.weight"] = dwc.view(Cl, 3, 3, cur.ld)[..., :Cl].permute(0, 3, 1, 2).contiguous()
         dcols = Act(eng.buf("tr.head.dcols", cur.rows * 9 * cur.ld, zero=True), B, cur.H, cur.W, 9 * cur.ld, 9 * cur.ld)
         eng.conv(dhc, self._tw(S["head_wcols"], dhc.ld), dcols, arith=BWD_ARITH)
         dy = self._act(eng, "st3.dy", B, cur.H, cur.W, cur.C, cur.ld)
@@ -221,10 +243,11 @@ class DetectorStep:
                 dt0, dw, db = self._ln_bwd(eng, t0, du, blk["lnw"], tg + "dt0")
                 G[p + ".norm.weight"], G[p + ".norm.bias"] = dw, db
                 # depthwise 7x7 (+ the residual branch)
-                dwp = eng.buf("tr.dw.part", int(L.vs_dwconv7_wgrad_partial_floats(Bc, H, xin.ld)))
-                dwd = torch.empty(49, xin.ld, device=eng.dev, dtype=torch.float32)
-                N.check(L.vs_dwconv7_wgrad(N.ptr(xin.t), xin.ld, N.ptr(dt0.t), dt0.ld, Bc, H, W, Cc, N.ptr(dwp), N.ptr(dwd), st), "vs_dwconv7_wgrad")
-                G[p + ".dwconv.weight"] = dwd[:, :Cc].t().reshape(Cc, 1, 7, 7).contiguous()
+                if want_params:
+                    dwp = eng.buf("tr.dw.part", int(L.vs_dwconv7_wgrad_partial_floats(Bc, H, xin.ld)))
+                    dwd = torch.empty(49, xin.ld, device=eng.dev, dtype=torch.float32)
+                    N.check(L.vs_dwconv7_wgrad(N.ptr(xin.t), xin.ld, N.ptr(dt0.t), dt0.ld, Bc, H, W, Cc, N.ptr(dwp), N.ptr(dwd), st), "vs_dwconv7_wgrad")
+                    G[p + ".dwconv.weight"] = dwd[:, :Cc].t().reshape(Cc, 1, 7, 7).contiguous()
                 G[p + ".dwconv.bias"] = self._colsum(eng, dt0, Cc)
                 dx = self._act(eng, tg + f"dx{j & 1}", Bc, H, W, Cc, xin.ld)
                 N.check(L.vs_dwconv7(N.ptr(dt0.t), Bc, H, W, Cc, dt0.ld, N.ptr(blk["wdw"]), None, 1, N.ptr(dy.t), dy.ld, N.ptr(dx.t), dx.ld, st),
@@ -235,10 +258,11 @@ class DetectorStep:
                 cin_act, ln = rec["down_in"], rec["down_ln"]
                 Cin, Bc = d[sti - 1], ln.B
                 CP = dn["conv"].CinP                                                # rup(2 * ln.ld, 16)
-                patches = Act(eng.buf("tr.dn.patches", dy.rows * 2 * CP, zero=True), Bc, dy.H, dy.W, 2 * CP, 2 * CP)
-                N.check(L.vs_patchify(N.ptr(ln.t), Bc, ln.H, ln.W, ln.ld, 2, N.ptr(patches.t), st), "vs_patchify")
-                dwp = self._wgrad(eng, dy, Cc, patches, 2 * CP)                     # [Cout][ky * CP + kx * ld + c]
-                G[p + ".1.weight"] = dwp.view(Cc, 2, CP)[:, :, : 2 * ln.ld].reshape(Cc, 2, 2, ln.ld)[..., :Cin].permute(0, 3, 1, 2).contiguous()
+                if want_params:
+                    patches = Act(eng.buf("tr.dn.patches", dy.rows * 2 * CP, zero=True), Bc, dy.H, dy.W, 2 * CP, 2 * CP)
+                    N.check(L.vs_patchify(N.ptr(ln.t), Bc, ln.H, ln.W, ln.ld, 2, N.ptr(patches.t), st), "vs_patchify")
+                    dwp = self._wgrad(eng, dy, Cc, patches, 2 * CP)                     # [Cout][ky * CP + kx * ld + c]
+                    G[p + ".1.weight"] = dwp.view(Cc, 2, CP)[:, :, : 2 * ln.ld].reshape(Cc, 2, 2, ln.ld)[..., :Cin].permute(0, 3, 1, 2).contiguous()
                 G[p + ".1.bias"] = self._colsum(eng, dy, Cc)
                 dcols = Act(eng.buf("tr.dn.dcols", dy.rows * 2 * CP, zero=True), Bc, dy.H, dy.W, 2 * CP, 2 * CP)
                 eng.conv(dy, self._tw(dn["conv"].wt, dy.ld), dcols, arith=BWD_ARITH)
@@ -251,12 +275,23 @@ class DetectorStep:
         t, x = S["stem_pre"], S["x"]
         dt, dw, db = self._ln_bwd(eng, t, dy, X["stem_ln"][0], "stem.dt")
         G[p + ".1.weight"], G[p + ".1.bias"] = dw, db
-        patches = Act(eng.buf("tr.stem.patches", dt.rows * 64, zero=True), x.B, dt.H, dt.W, 64, 64)
-        N.check(L.vs_patchify(N.ptr(x.t), x.B, x.H, x.W, 4, 4, N.ptr(patches.t), st), "vs_patchify")
-        dws = self._wgrad(eng, dt, d[0], patches, 64)
-        G[p + ".0.weight"] = dws.view(d[0], 4, 4, 4)[..., :3].permute(0, 3, 1, 2).contiguous()
+        if want_params:
+            patches = Act(eng.buf("tr.stem.patches", dt.rows * 64, zero=True), x.B, dt.H, dt.W, 64, 64)
+            N.check(L.vs_patchify(N.ptr(x.t), x.B, x.H, x.W, 4, 4, N.ptr(patches.t), st), "vs_patchify")
+            dws = self._wgrad(eng, dt, d[0], patches, 64)
+            G[p + ".0.weight"] = dws.view(d[0], 4, 4, 4)[..., :3].permute(0, 3, 1, 2).contiguous()
         G[p + ".0.bias"] = self._colsum(eng, dt, d[0])
-        return G
+        if not want_input:
+            return G
+        # backward-data of the stem: d patches = dt W  ([rows][64], k = ky * 16 + kx * 4 + c), un-patched to NHWC, then back to frame planes
+        # times d(x * 2 - 1) / dx (extractor.py:163)
+        dcols = Act(eng.buf("tr.stem.dcols", dt.rows * 64, zero=True), x.B, dt.H, dt.W, 64, 64)
+        eng.conv(dt, self._tw(X["stem"].wt, dt.ld), dcols, arith=BWD_ARITH)
+        drgb = eng.buf("tr.stem.drgb", x.rows * 4, zero=True)
+        N.check(L.vs_unpatch(N.ptr(dcols.t), x.B, x.H, x.W, 4, 4, N.ptr(drgb), st), "vs_unpatch")
+        dimg = torch.empty(x.B, 3, x.H, x.W, device=eng.dev, dtype=torch.float32)
+        N.check(L.vs_nhwc_to_nchw_scaled(N.ptr(drgb), x.B, x.H, x.W, 3, 4, 2.0, N.ptr(dimg), st), "vs_nhwc_to_nchw_scaled")
+        return G, dimg
 
     # ------------------------------------------------------------------ public
     def step(self, imgs_aug: torch.Tensor, msgs: torch.Tensor, temperature: float = 1.0, grad_scale: float = 1.0,
@@ -295,8 +330,8 @@ class EmbedderBackward:
     `embedder.*` parameter from d(delta), the gradient with respect to the embedder's output [B, out_ch, S, S] -- the generator side of
     train.py:626-643 up to the JND / blend / augmentation adjoints that produce d(delta) from the loss.
 
-    STATUS (end of round 2): written against CPU-verified formulas, compiled, NOT yet run on hardware -- tests/experimental_gpu_bwd_unet.py
-    holds the unit tests and the end-to-end comparison with autograd through the oracle; nothing in the product path calls this class."""
+    Called by videoseal_amd.autograd.EmbedTrainFn (the differentiable `Wam.forward`); tests/test_gpu_bwd_unet.py holds the unit tests of its
+    kernels and the comparison of every gradient with autograd through the oracle."""
 
     def __init__(self, model):
         cfg = model.embedder.cfg
@@ -305,19 +340,32 @@ class EmbedderBackward:
         self.model = model
         self.h = DetectorStep.__new__(DetectorStep)          # the small helpers (_act, _vec, _colsum, _wgrad, _ln_bwd, _tw)
         self.h._ones = {}
+        self.update_running = False
+        self.batch_stats = True
 
     # ------------------------------------------------------------------ pieces
     def _bn_stats(self, eng: HipEngine, raw: Act, bn: dict):
-        """batch statistics of `raw` (global over the ranks with SyncBatchNorm): scale, shift, mean, rstd -- running statistics untouched"""
+        """batch statistics of `raw` (global over the ranks with SyncBatchNorm): scale, shift, mean, rstd.  With self.update_running (the
+        real training forward) running_mean / running_var / num_batches_tracked move exactly like nn.BatchNorm2d's (momentum 0.1, unbiased)."""
         L, st = eng.lib, N.stream()
+        if not self.batch_stats:        # embedder.eval() with trainable parameters: BatchNorm is the affine map of its running statistics
+            v = torch.zeros(4, raw.ld, device=eng.dev, dtype=torch.float32)
+            rstd = torch.rsqrt(bn["rv"].float() + 1e-5)
+            v[0, : raw.C] = bn["w"] * rstd
+            v[1, : raw.C] = bn["b"] - bn["rm"].float() * v[0, : raw.C]
+            v[2, : raw.C], v[3, : raw.C] = bn["rm"].float(), rstd
+            return dict(scale=v[0], shift=v[1], mean=v[2], rstd=v[3], frozen=True)
         part = eng.buf("tr.bn.part", 2 * int(L.vs_bn_partial_doubles(raw.rows, raw.ld)))
         sums = eng.buf("tr.bn.sums", 2 * (2 * raw.ld + 2)).view(torch.float64)[: 2 * raw.ld + 1]
         N.check(L.vs_bn_partial_sums(N.ptr(raw.t), raw.rows, raw.C, raw.ld, N.ptr(part), N.ptr(sums), st), "vs_bn_partial_sums")
         if eng.bn_sync is not None:
             eng.bn_sync(sums)
         v = torch.zeros(4, raw.ld, device=eng.dev, dtype=torch.float32)
-        N.check(L.vs_bn_finish_sums(N.ptr(sums), raw.C, raw.ld, N.ptr(bn["w"]), N.ptr(bn["b"]), 1e-5, 0.1, None, None, N.ptr(v[0]), N.ptr(v[1]), st),
-                "vs_bn_finish_sums")
+        upd = self.update_running
+        N.check(L.vs_bn_finish_sums(N.ptr(sums), raw.C, raw.ld, N.ptr(bn["w"]), N.ptr(bn["b"]), 1e-5, 0.1, N.ptr(bn["rm"]) if upd else None,
+                                    N.ptr(bn["rv"]) if upd else None, N.ptr(v[0]), N.ptr(v[1]), st), "vs_bn_finish_sums")
+        if upd:
+            bn["nbt"].add_(1)
         N.check(L.vs_bn_mean_rstd(N.ptr(sums), raw.C, raw.ld, 1e-5, N.ptr(v[2]), N.ptr(v[3]), st), "vs_bn_mean_rstd")
         return dict(scale=v[0], shift=v[1], mean=v[2], rstd=v[3])
 
@@ -337,7 +385,10 @@ class EmbedderBackward:
         db = torch.empty(C, device=eng.dev, dtype=torch.float32)
         N.check(L.vs_bn_relu_bwd_sums(N.ptr(raw.t), raw.ld, N.ptr(dy.t), dy.ld, N.ptr(stt["mean"]), N.ptr(stt["rstd"]), N.ptr(stt["scale"]),
                                       N.ptr(stt["shift"]), 1, raw.rows, C, N.ptr(part), N.ptr(sums), N.ptr(dg), N.ptr(db), st), "vs_bn_relu_bwd_sums")
-        if eng.bn_sync is not None:
+        if stt.get("frozen"):                      # running statistics: no coupling between the rows, d raw = scale * g
+            sums = torch.zeros_like(sums)
+            sums[-1] = raw.rows
+        elif eng.bn_sync is not None:
             eng.bn_sync(sums)                      # SyncBatchNorm's backward exchange: [sum g xhat | sum g | rows]
         dx = self.h._act(eng, tag, raw.B, raw.H, raw.W, C, raw.ld)
         N.check(L.vs_bn_relu_bwd_apply(N.ptr(raw.t), raw.ld, N.ptr(dy.t), dy.ld, N.ptr(stt["mean"]), N.ptr(stt["rstd"]), N.ptr(stt["scale"]),
@@ -385,7 +436,11 @@ class EmbedderBackward:
         self._affine_act(eng, raw1, s1["scale"], s1["shift"], N.ACT_RELU, out, add=rs)
         return out, dict(x=x, raw0=raw0, t=t, raw1=raw1, s0=s0, s1=s1)
 
-    def forward_keep(self, eng: HipEngine, x: Act, msgs_i32: torch.Tensor):
+    def forward_keep(self, eng: HipEngine, x: Act, msgs_i32: torch.Tensor, update_running: bool = False):
+        """the train-mode forward of the U-Net that keeps every operand of the backward; update_running: BatchNorm's running statistics
+        follow (a training step), off for gradient checks that must leave the module untouched.  BatchNorm follows `embedder.training`."""
+        self.batch_stats = bool(self.model.embedder.training)
+        self.update_running = update_running and self.batch_stats
         if eng.Et is None:
             eng._pack_embedder(eng._g, train=True)
         c, E, L, st, g, h = eng.cfg, eng.Et, eng.lib, N.stream(), eng._g, self.h
@@ -468,7 +523,8 @@ class EmbedderBackward:
         eng.conv(draw0, self._flip_t(g(name + ".double_conv.0.weight"), draw0.ld), dx, pad=1, arith=BWD_ARITH, res=dxr)
         return dx
 
-    def backward(self, eng: HipEngine, S, ddelta: torch.Tensor) -> Dict[str, torch.Tensor]:
+    def backward(self, eng: HipEngine, S, ddelta: torch.Tensor, outc_only: bool = False) -> Dict[str, torch.Tensor]:
+        """outc_only: stop after the output convolution -- all `get_last_layer()` needs (the adaptive-weight probes of videosealloss.py:86-90)"""
         c, E, L, st, g, h = eng.cfg, eng.Et, eng.lib, N.stream(), eng._g, self.h
         u = "embedder.unet"
         G: Dict[str, torch.Tensor] = {}
@@ -483,6 +539,8 @@ class EmbedderBackward:
                                    dx.ld, N.ptr(dv.t), st), "vs_outc_tanh_bwd")
         G[u + ".outc.weight"] = h._wgrad(eng, dv, c.out_ch, last, last.C).view(c.out_ch, last.C, 1, 1)
         G[u + ".outc.bias"] = h._colsum(eng, dv, c.out_ch)
+        if outc_only:
+            return G
         dcur = dx
         dskips: Dict[int, Act] = {}                     # gradient that reaches hid[i] through its skip connection
         # ---- up path, last group first
@@ -540,3 +598,59 @@ class EmbedderBackward:
             dcur = dsrc
         self._resblock_bwd(eng, S["inc"], E["inc"], u + ".inc", dcur, G, "e.g.inc", need_dx=False)       # the frames need no gradient
         return G
+
+
+class GeneratorStep:
+    """One accumulation step of train.py:626-643 with the generator branch of `VideosealLoss` (videosealloss.py:111-192, optimizer_idx 0)
+    computed on the HIP path end to end: differentiable forward (autograd.py) -> perceptual ('mse' / 'yuv') and decoding terms
+    (vs_percep_mse, vs_bce_logits) -> adaptive weights through `get_last_layer()` (videosealloss.py:72-107: one backward probe per term that
+    stops at the output convolution) -> backward into `.grad` of every embedder and detector parameter.  The discriminator term is a second
+    trainable network outside this path (disc_weight = 0, what train.py itself uses for lambda_d = 0); the detection term needs a per-pixel
+    mask head, which the ConvNeXt / ViT extractors of the shipped cards do not have (the reference's BCE raises on the shape mismatch too).
+
+    The reference's own loss object works as well -- `model(imgs, masks)` returns graph-carrying tensors -- this class is the same step
+    without ATen in the loss."""
+
+    def __init__(self, model, percep_loss: str = "mse", percep_weight: float = 1.0, decode_weight: float = 0.0, detect_weight: float = 0.0,
+                 balanced: bool = True, total_norm: float = 0.0, temperature: float = 1.0):
+        if detect_weight > 0:
+            raise NotImplementedError("detect_weight > 0: the per-frame extractors predict no mask map (videosealloss.py:140-147 needs [b,1,h,w] logits)")
+        if percep_weight > 0 and percep_loss not in ("mse", "yuv"):
+            raise NotImplementedError(f"perceptual loss {percep_loss!r}: 'mse' and 'yuv' run on the HIP path (the rest are pretrained networks)")
+        self.model, self.percep_loss, self.temperature = model, percep_loss, float(temperature)
+        self.percep_weight, self.decode_weight, self.balanced, self.total_norm = percep_weight, decode_weight, balanced, total_norm
+
+    def losses(self, imgs: torch.Tensor, outputs: dict):
+        from . import autograd as AG
+        losses, weights = {}, {}
+        dev = outputs["imgs_w"].device
+        if self.percep_weight > 0:
+            losses["percep"], weights["percep"] = AG.percep_loss(imgs.to(dev), outputs["imgs_w"], self.percep_loss), self.percep_weight
+        if self.decode_weight > 0:
+            losses["decode"], weights["decode"] = AG.decoding_loss(outputs["preds"], outputs["msgs"], self.temperature), self.decode_weight
+        return losses, weights
+
+    def scales(self, losses: dict, weights: dict):
+        """videosealloss.py:72-107: (w_i / sum w) * N / (eps + ||d loss_i / d last_layer||), N = total_norm or the LAST term's gradient norm"""
+        last = self.model.embedder.get_last_layer()
+        if not (self.balanced and last.requires_grad):
+            return dict(weights)
+        norms = []
+        for v in losses.values():
+            g = torch.autograd.grad(v, last, retain_graph=True, allow_unused=True)[0] if v.requires_grad else None
+            norms.append(torch.norm(g) if g is not None else torch.zeros((), device=last.device))
+        tot = sum(weights.values())
+        n = norms[-1] if self.total_norm <= 0 else self.total_norm
+        return {k: (w / tot) * n / (1e-12 + gn) for (k, w), gn in zip(weights.items(), norms)}
+
+    def step(self, imgs: torch.Tensor, masks: torch.Tensor, msgs: Optional[torch.Tensor] = None, is_video: bool = False,
+             accumulation_steps: int = 1):
+        """returns (total_loss, log, outputs); gradients are accumulated into `.grad` scaled by 1 / accumulation_steps (train.py:641)"""
+        outputs = self.model(imgs, masks, msgs, is_video=is_video)
+        losses, weights = self.losses(imgs, outputs)
+        scales = self.scales(losses, weights)
+        total = sum(scales[k] * losses[k] for k in losses)
+        (total / accumulation_steps).backward()
+        log = {"total_loss": total.detach(), **{f"loss_{k}": v.detach() for k, v in losses.items()},
+               **{f"scale_{k}": torch.as_tensor(v).detach() for k, v in scales.items()}}
+        return total.detach(), log, outputs
