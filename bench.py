@@ -104,7 +104,10 @@ def cpu_baseline(card_path, size, mode, step_size, max_seconds=25.0):
             times.append(dt); t_used += dt; reps += 1
         tried[cores] = round(n / min(times), 3)
     cores = max(tried, key=tried.get)
-    return {"value": tried[cores], "unit": "frames/s", "cores": cores, "host_cpus": host, "kind": "port",
+    cal = os.path.join(ROOT, "profiles", "r03_cpu_port_vs_reference.json")
+    ratio = json.load(open(cal)) if os.path.exists(cal) else None
+    return {"value": tried[cores], "port_over_reference": (ratio["port_over_reference"] if ratio else None),
+            "port_over_reference_note": (ratio["note"] if ratio else None), "unit": "frames/s", "cores": cores, "host_cpus": host, "kind": "port",
             "by_threads": {str(k): v for k, v in tried.items()},
             "sample": f"{n} frames {size}x{size}, {mode} mode, embed" + ("+augment chain" if mode == "chain" else "") + "+detect, best rep after 1 warm-up per thread count, "
                       "torch fp32 CPU oracle (restatement of the reference path pinned by tests/golden; the reference package itself "
@@ -129,7 +132,7 @@ def measure_sustained_mfma():
     return best
 
 
-def main():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
@@ -153,8 +156,14 @@ def main():
     ap.add_argument("--detect-only", action="store_true", help="time model.detect() only (BASELINE config 5: ChunkySeal extractor)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timers", action="store_true")
-    args = ap.parse_args()
+    ap.add_argument("--no-extra", action="store_true", help="default run only: skip the short legs over the other BASELINE configs "
+                    "(video mode, configs[2] chain, configs[3] streaming, configs[4] ChunkySeal detect, the training step)")
+    return ap.parse_args(argv)
 
+
+
+def run(args):
+    """one workload: returns the JSON line (rank 0) or None"""
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -167,10 +176,9 @@ def main():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback for the product path)")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if dist_on:
-        import torch.distributed as dist
+    if dist_on and not torch.distributed.is_initialized():
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=dev)
+        torch.distributed.init_process_group("nccl", device_id=dev)
 
     if args.graphs:
         os.environ["VIDEOSEAL_GRAPHS"] = "1"
@@ -381,6 +389,19 @@ def main():
                                       "algorithmic_MB": pj["algorithmic_mb_per_launch"], "mfma_busy_pct_pmc": pj["mfma_busy_pct"],
                                       "source": pj["source"]}
 
+    if roof is None and not args.no_kernel_timers:       # no bottleneck conv in this workload (detect only): whole-step fraction only
+        roof = {"bound": "mfma", "kernel": None, "unit": "TFLOP/s", "peak": round(peak_split(eng) if eng.use_split else PEAK_F32_MFMA_TFLOPS, 1)}
+    allgather_ms = None
+    if dist_on:          # the one collective of the path, timed on its own: RCCL all-gather of the [frames, 1 + nbits] logits
+        n_tot = args.frames if stream else B * world
+        loc = preds[f0:f1] if (stream and preds.shape[0] == n_tot) else preds[: (f1 - f0) if stream else B]
+        loc = loc.contiguous()
+        barrier()
+        t1 = time.perf_counter()
+        for _ in range(20):
+            gather_frame_logits(loc, n_tot, align=(16 if stream else B))
+        barrier()
+        allgather_ms = (time.perf_counter() - t1) / 20 * 1e3
     if rank == 0:
         total_frames = (args.frames if stream else B * world) * args.steps
         fps = total_frames / elapsed
@@ -415,13 +436,81 @@ def main():
             "value_pipelined_note": "the same steps with detect(batch i) on a second HIP stream under embed(batch i+1) (bench.py --pipeline); `value` is the sequential run",
             "roofline": roof,
         }
+        if allgather_ms is not None:
+            line["allgather_ms"] = round(allgather_ms, 4)
         if not args.no_cpu_baseline and world == 1 and not args.detect_only:
             card_path = os.path.join(ROOT, "videoseal_amd", "cards", args.card + ".yaml")
             line["cpu_baseline"] = cpu_baseline(card_path, S, args.mode, cfg.step_size)
         else:
             line["cpu_baseline"] = None
+        return line
+    return None
+
+
+def gen_step_leg(dev):
+    """the generator-side training step (train.py:626-643 with the published recipe's terms: decoding + 0.1 x yuv perceptual, fixed weights)
+    on VideoSeal 1.0, 16 frames of 256x256: forward + loss + backward on the HIP path (videoseal_amd.training.GeneratorStep)"""
+    import videoseal_amd
+    from videoseal_amd.training import GeneratorStep
+    model = videoseal_amd.build("videoseal_1.0", seed=0).to(dev).train()
+    B = 16
+    frames = synthetic_batch(B, 256, dev, seed=7)
+    masks = torch.ones(B, 1, 256, 256, device=dev)
+    msgs = torch.randint(0, 2, (B, model.embedder.cfg.nbits), generator=torch.Generator().manual_seed(5))
+    gs = GeneratorStep(model, percep_loss="yuv", percep_weight=0.1, decode_weight=1.0, balanced=False)
+    for _ in range(2):
+        model.zero_grad(set_to_none=True)
+        gs.step(frames, masks, msgs)
+    torch.cuda.synchronize()
+    K = 5
+    t0 = time.perf_counter()
+    for _ in range(K):
+        model.zero_grad(set_to_none=True)
+        gs.step(frames, masks, msgs)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / K
+    gflop = 3 * 2 * (28.28 + 6.16) * B               # forward + backward-data + backward-weights of the dense conv / GEMM work
+    return {"value": round(B / dt, 1), "unit": "frames/s", "ms_per_step": round(dt * 1e3, 2),
+            "workload": "videoseal_1.0 generator step (forward + decoding / yuv loss + backward of embedder AND extractor), 16 x 256x256, fp32 gradients",
+            "model_tflops_per_s": round(gflop / dt / 1e3, 1)}
+
+
+def main():
+    args = parse_args()
+    line = run(args)
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    default_run = (args.mode == "image" and args.card == "videoseal_1.0" and args.size == 768 and args.batch in (None, 32) and not args.capi
+                   and not args.detect_only and not args.graphs and not args.pipeline and not args.no_extra)
+    if default_run:
+        # the other BASELINE configs as short legs of the same command, each with its own roofline fractions
+        def leg(extra, steps=5, warmup=2):
+            a = parse_args(["--gpus", str(args.gpus), "--steps", str(steps), "--warmup", str(warmup), "--no-cpu-baseline", "--no-extra"] + extra)
+            r = run(a)
+            if r is None:
+                return None
+            roof = r.get("roofline") or {}
+            return {"value": r["value"], "unit": r["unit"], "ms_per_step": r["ms_per_step"], "scaling": r["scaling"], "n_gpus": r["n_gpus"],
+                    "allgather_ms": r.get("allgather_ms"),
+                    "workload": r["config"]["workload"], "model_tflops_per_s": r["model_tflops_per_s"],
+                    "roofline": {k: roof.get(k) for k in ("kernel", "achieved", "peak", "unit", "frac", "avg_launch_ms", "e2e_frac") if k in roof},
+                    "shell": roof.get("shell")}
+        legs = {}
+        if world == 1:
+            legs["video_step4 (configs[1], video mode)"] = leg(["--mode", "video"])
+            legs["chain (configs[2])"] = leg(["--mode", "chain"])
+        legs["stream_1024 (configs[3], strong scaling over the ranks)"] = leg(["--mode", "stream", "--frames", "1024"], steps=2, warmup=1)
+        legs["chunkyseal_detect_16x1024 (configs[4])"] = leg(["--card", "chunkyseal", "--size", "1024", "--batch", "16", "--detect-only"], steps=3, warmup=1)
+        if world == 1 and rank == 0:
+            try:
+                legs["train_step"] = gen_step_leg(torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0"))))
+            except Exception as e:          # the bench line must survive a failing extra leg
+                legs["train_step"] = {"error": repr(e)[:300]}
+        if line is not None:
+            line["configs"] = legs
+    if line is not None:
         print(json.dumps(line), flush=True)
-    if dist_on:
+    if torch.distributed.is_available() and torch.distributed.is_initialized():
         torch.distributed.destroy_process_group()
 
 

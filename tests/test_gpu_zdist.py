@@ -193,3 +193,38 @@ def test_sync_batchnorm_two_ranks_reproduce_the_global_batch():
     assert (b0 - bp).abs().max() <= 1e-5 * bp.abs().max()
     local_only = _train_forward(make_model(spec, sd), imgs[:3], msgs[:3])           # without the exchange the result differs
     assert (local_only["preds_w"] - ref["preds_w"][:3]).abs().max() > 1e-4 * ref["preds_w"].abs().max()
+
+
+# ---- train.py:442-446: nn.parallel.DistributedDataParallel around the module, gradients through DDP's autograd hooks
+def test_ddp_wrapped_training_step_over_rccl_world1(rccl_world1):
+    """DDP(model) + the unmodified inner loop: the parameters enter the HIP graph nodes as inputs, so DDP's AccumulateGrad hooks fire and its
+    reducer all-reduces the buckets over RCCL (the detector's buckets while the embedder's backward is still running).  World size 1: the
+    gradients must equal the un-wrapped step's; the adaptive-weight probes (torch.autograd.grad with retain_graph) must not trip the reducer."""
+    from oracle import loss as OL
+    from tests._util import load_golden
+    from tests.test_gpu_train import _setup
+    from videoseal_amd.dist import convert_sync_batchnorm
+    spec = tiny_spec()
+    sd = make_state_dict(spec, seed=3)
+    meta = load_golden("tiny_bwd_img_balanced")["meta"]
+
+    def run(wrap):
+        model, imgs, msgs, masks = _setup(spec, sd, meta)
+        fwd = model
+        if wrap:
+            convert_sync_batchnorm(model)                   # train.py:438-440 (here: the moment all-reduce of dist.py over the same communicator)
+            fwd = torch.nn.parallel.DistributedDataParallel(model, device_ids=[0])
+        torch.manual_seed(meta["torch_seed"])
+        out = fwd(imgs.cuda(), masks.cuda(), msgs, is_video=False)
+        out["preds"] /= meta["temperature"]
+        loss, log = OL.videoseal_loss(imgs.cuda(), out["imgs_w"], out["masks"], out["msgs"].cuda(), out["preds"],
+                                      last_layer=model.embedder.get_last_layer(), **meta["loss_kw"])
+        loss.backward()
+        torch.cuda.synchronize()
+        return {k: p.grad.clone() for k, p in model.named_parameters()}, float(loss), {k: float(v) for k, v in log.items()}
+    g0, l0, log0 = run(False)
+    g1, l1, log1 = run(True)
+    assert abs(l0 - l1) < 1e-6 and all(abs(log0[k] - log1[k]) <= 1e-5 * max(1.0, abs(log0[k])) for k in log0)
+    assert set(g0) == set(g1)
+    for k in g0:
+        assert (g0[k] - g1[k]).abs().max() <= 1e-5 * float(g0[k].abs().max()) + 1e-12, k

@@ -257,6 +257,14 @@ class Wam(nn.Module):
         if stale:
             self._eng.invalidate(*stale)
             self._graphs.clear()
+        if self._bn_sync is None and self.embedder.training and os.environ.get("VIDEOSEAL_SYNC_BN", "auto") == "auto":
+            # train.py:438-440 converts every BatchNorm to SyncBatchNorm when it runs distributed; nn.SyncBatchNorm.convert_sync_batchnorm finds
+            # no nn.BatchNorm2d children here (the U-Net is one HIP launch sequence), so the same switch is made when a process group with
+            # more than one rank exists at the first train-mode forward (VIDEOSEAL_SYNC_BN=0 keeps per-rank statistics)
+            import torch.distributed as td
+            if td.is_available() and td.is_initialized() and td.get_world_size() > 1:
+                from .dist import bn_all_reduce
+                self._bn_sync = bn_all_reduce()
         self._eng.bn_sync = self._bn_sync
         return self._eng
 
