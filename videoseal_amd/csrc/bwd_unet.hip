@@ -54,14 +54,17 @@ __global__ __launch_bounds__(256) void bn_bwd_partial_kernel(const float* __rest
     __syncthreads();
   }
 }
-// sums = [sum g * xhat (ldp) | sum g (ldp) | rows] in fp64 (the vector SyncBatchNorm all-reduces in its backward); dgamma / dbeta = the LOCAL sums
-__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restrict__ partial, int nchunk, int64_t rows, int64_t ldp, int C,
-                                                            double* __restrict__ sums, float* __restrict__ dgamma, float* __restrict__ dbeta) {
-  const int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (c == 0) sums[2 * ldp] = (double)rows;
-  if (c >= ldp) return;
+// sums = [sum g * xhat (ldp) | sum g (ldp) | rows] in fp64 (the vector SyncBatchNorm all-reduces in its backward); dgamma / dbeta = the LOCAL sums.
+// One wave per channel: the lanes stride the chunks, then a butterfly (fixed order).
+__global__ __launch_bounds__(64) void bn_bwd_reduce_kernel(const float* __restrict__ partial, int nchunk, int64_t rows, int64_t ldp, int C,
+                                                           double* __restrict__ sums, float* __restrict__ dgamma, float* __restrict__ dbeta) {
+  const int64_t c = blockIdx.x;
   double s = 0, q = 0;
-  for (int k = 0; k < nchunk; ++k) { s += (double)partial[((int64_t)k * 2 + 0) * ldp + c]; q += (double)partial[((int64_t)k * 2 + 1) * ldp + c]; }
+  for (int k = threadIdx.x; k < nchunk; k += 64) { s += (double)partial[((int64_t)k * 2 + 0) * ldp + c]; q += (double)partial[((int64_t)k * 2 + 1) * ldp + c]; }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { s += __shfl_xor(s, o, 64); q += __shfl_xor(q, o, 64); }
+  if (threadIdx.x != 0) return;
+  if (c == 0) sums[2 * ldp] = (double)rows;
   sums[c] = s;
   sums[ldp + c] = q;
   if (c < C) { dgamma[c] = (float)s; dbeta[c] = (float)q; }
@@ -263,7 +266,7 @@ extern "C" int vs_bn_relu_bwd_sums(const float* raw, int64_t ld, const float* dy
   const int nch = (int)cdiv64(rows, CR_ROWS);
   const BnBwd bp{mean, rstd, scale, shift};
   hipLaunchKernelGGL(bn_bwd_partial_kernel, dim3((unsigned)nch), dim3(256), 0, (hipStream_t)stream, raw, ld, dy, dy_ld, bp, relu, rows, C4, ldp, partial);
-  hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(blocks_for(ldp)), dim3(256), 0, (hipStream_t)stream, partial, nch, rows, ldp, C, sums, dgamma, dbeta);
+  hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3((unsigned)ldp), dim3(64), 0, (hipStream_t)stream, partial, nch, rows, ldp, C, sums, dgamma, dbeta);
   return vs_launch_status();
 }
 

@@ -657,50 +657,75 @@ __global__ __launch_bounds__(256) void pool_linear_kernel(const float* __restric
 // ---------------------------------------------------------------------------------------------------
 // BatchNorm2d with BATCH statistics (the U-Net's ResnetBlocks under model.train(): unet.py:26,30 -> nn.BatchNorm2d).
 // Two deterministic stages over an NHWC tensor [rows][ld]:
-//   bn_partial_kernel : every block sums x and x^2 of BN_ROWS rows per channel (fp64 accumulators, fixed order)
+//   bn_partial_kernel : every block sums x and x^2 of one chunk of rows per channel (fp64 accumulators, fixed order)
 //   bn_finish_kernel  : mean / biased variance -> scale = gamma/sqrt(var+eps), shift = beta - mean*scale, and the
 //                       running-statistics update of nn.BatchNorm2d (momentum m, UNBIASED variance) in place.
-constexpr int BN_ROWS = 2048;
-__global__ __launch_bounds__(256) void bn_partial_kernel(const float* __restrict__ x, int64_t rows, int64_t ld,
+// Chunk geometry: a block covers G = min(ld / 4, 64) float4 channel groups x RL = 256 / G row lanes; every row lane reads 16 rows (16
+// independent 16-byte loads in flight per thread), so a chunk is 16 * RL rows and a launch has ceil(rows / chunk) x ceil(ld / 4 / G) blocks --
+// hundreds of workgroups for every tensor of the U-Net (the previous 2048-row chunks gave 8 workgroups for a 32 x 32 x 384 map).
+static inline int bn_groups(int64_t ld) { const int c4 = (int)(ld >> 2); return c4 < 64 ? c4 : 64; }
+static inline int bn_chunk_rows(int64_t ld) { return 16 * (256 / bn_groups(ld)); }
+__global__ __launch_bounds__(256) void bn_partial_kernel(const float* __restrict__ x, int64_t rows, int64_t ld, int G, int RL,
                                                          double* __restrict__ partial) {
   __shared__ double red[2][256][4];
   const int C4 = (int)(ld >> 2);
-  const int RL = 256 / C4 > 0 ? 256 / C4 : 1;          // row lanes per channel group
-  const int g = threadIdx.x % C4, rl = threadIdx.x / C4;
-  const int64_t r0 = (int64_t)blockIdx.x * BN_ROWS, r1 = r0 + BN_ROWS < rows ? r0 + BN_ROWS : rows;
-  for (int gb = 0; gb < C4; gb += 256) {                // C4 > 256 only for very wide tensors
-    const int gg = gb + g;
-    double s[4] = {0, 0, 0, 0}, q[4] = {0, 0, 0, 0};
-    if (rl < RL && gg < C4)
-      for (int64_t r = r0 + rl; r < r1; r += RL) {
-        const f32x4 v = *reinterpret_cast<const f32x4*>(x + r * ld + 4 * gg);
+  const int g = threadIdx.x % G, rl = threadIdx.x / G;
+  const int gg = blockIdx.y * G + g;
+  const int64_t r0 = (int64_t)blockIdx.x * (16 * RL);
+  double s[4] = {0, 0, 0, 0}, q[4] = {0, 0, 0, 0};
+  const bool live = rl < RL && gg < C4;
+  if (live) {
+    f32x4 v[16];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) { s[e] += (double)v[e]; q[e] += (double)v[e] * (double)v[e]; }
-      }
+    for (int j = 0; j < 16; ++j) {
+      const int64_t r = r0 + rl + (int64_t)j * RL;
+      v[j] = r < rows ? *reinterpret_cast<const f32x4*>(x + r * ld + 4 * gg) : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
 #pragma unroll
-    for (int e = 0; e < 4; ++e) { red[0][threadIdx.x][e] = s[e]; red[1][threadIdx.x][e] = q[e]; }
-    __syncthreads();
-    if (rl == 0 && gg < C4) {
+    for (int j = 0; j < 16; ++j)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { s[e] += (double)v[j][e]; q[e] += (double)v[j][e] * (double)v[j][e]; }
+  }
+#pragma unroll
+  for (int e = 0; e < 4; ++e) { red[0][threadIdx.x][e] = s[e]; red[1][threadIdx.x][e] = q[e]; }
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {         // fixed tree over the row lanes (RL <= 256)
+    if (live && rl < o && rl + o < RL)
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        double ss = 0, qq = 0;
-        for (int j = 0; j < RL && j * C4 + g < 256; ++j) { ss += red[0][j * C4 + g][e]; qq += red[1][j * C4 + g][e]; }
-        partial[((int64_t)blockIdx.x * 2 + 0) * ld + 4 * gg + e] = ss;
-        partial[((int64_t)blockIdx.x * 2 + 1) * ld + 4 * gg + e] = qq;
+        red[0][threadIdx.x][e] += red[0][threadIdx.x + o * G][e];
+        red[1][threadIdx.x][e] += red[1][threadIdx.x + o * G][e];
       }
-    }
     __syncthreads();
   }
+  if (live && rl == 0)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      partial[((int64_t)blockIdx.x * 2 + 0) * ld + 4 * gg + e] = red[0][threadIdx.x][e];
+      partial[((int64_t)blockIdx.x * 2 + 1) * ld + 4 * gg + e] = red[1][threadIdx.x][e];
+    }
 }
-__global__ __launch_bounds__(256) void bn_finish_kernel(const double* __restrict__ partial, int nchunk, int64_t rows, int C, int64_t ld,
-                                                        const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
-                                                        float momentum, float* __restrict__ running_mean,
-                                                        float* __restrict__ running_var, float* __restrict__ scale,
-                                                        float* __restrict__ shift, const double* __restrict__ count) {
-  const int c = blockIdx.x * 256 + threadIdx.x;
-  if (c >= C) return;
-  double s = 0, q = 0;
-  for (int k = 0; k < nchunk; ++k) { s += partial[((int64_t)k * 2 + 0) * ld + c]; q += partial[((int64_t)k * 2 + 1) * ld + c]; }
+static inline void launch_bn_partial(const float* x, int64_t rows, int64_t ld, double* partial, hipStream_t st) {
+  const int G = bn_groups(ld), RL = 256 / G;
+  const int C4 = (int)(ld >> 2);
+  hipLaunchKernelGGL(bn_partial_kernel, dim3((unsigned)cdiv64(rows, 16 * RL), (unsigned)((C4 + G - 1) / G)), dim3(256), 0, st, x, rows, ld, G, RL, partial);
+}
+// one wave per channel: the lanes stride the chunks, then a butterfly (every lane ends with the same totals; fixed order)
+__device__ __forceinline__ void bn_chunk_totals(const double* __restrict__ partial, int nchunk, int64_t ld, int64_t c, double& s, double& q) {
+  s = 0; q = 0;
+  for (int k = threadIdx.x; k < nchunk; k += 64) { s += partial[((int64_t)k * 2 + 0) * ld + c]; q += partial[((int64_t)k * 2 + 1) * ld + c]; }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { s += __shfl_xor(s, o, 64); q += __shfl_xor(q, o, 64); }
+}
+__global__ __launch_bounds__(64) void bn_finish_kernel(const double* __restrict__ partial, int nchunk, int64_t rows, int C, int64_t ld,
+                                                       const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
+                                                       float momentum, float* __restrict__ running_mean,
+                                                       float* __restrict__ running_var, float* __restrict__ scale,
+                                                       float* __restrict__ shift, const double* __restrict__ count) {
+  const int c = blockIdx.x;
+  double s, q;
+  bn_chunk_totals(partial, nchunk, ld, c, s, q);
+  if (threadIdx.x != 0) return;
   const double n = count ? *count : (double)rows;      // SyncBatchNorm: the row count of ALL ranks, reduced with the sums
   const double mean = s / n;
   double var = q / n - mean * mean;
@@ -713,13 +738,13 @@ __global__ __launch_bounds__(256) void bn_finish_kernel(const double* __restrict
 }
 // SyncBatchNorm's local half: the chunk partials of bn_partial_kernel summed in the same fixed order as bn_finish_kernel does, into
 // sums = [sum x | sum x^2 | rows] = 2*ld + 1 doubles -- the vector the ranks all-reduce (train.py:438-440).
-__global__ __launch_bounds__(256) void bn_reduce_kernel(const double* __restrict__ partial, int nchunk, int64_t rows, int64_t ld,
-                                                        double* __restrict__ sums) {
-  const int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x;
+__global__ __launch_bounds__(64) void bn_reduce_kernel(const double* __restrict__ partial, int nchunk, int64_t rows, int64_t ld,
+                                                       double* __restrict__ sums) {
+  const int64_t c = blockIdx.x;
+  double s, q;
+  bn_chunk_totals(partial, nchunk, ld, c, s, q);
+  if (threadIdx.x != 0) return;
   if (c == 0) sums[2 * ld] = (double)rows;
-  if (c >= ld) return;
-  double s = 0, q = 0;
-  for (int k = 0; k < nchunk; ++k) { s += partial[((int64_t)k * 2 + 0) * ld + c]; q += partial[((int64_t)k * 2 + 1) * ld + c]; }
   sums[c] = s;
   sums[ld + c] = q;
 }
@@ -965,16 +990,16 @@ extern "C" int vs_pool_linear(const float* x, int B, int HW, int C, int64_t ld, 
   return vs_launch_status();
 }
 
-extern "C" int64_t vs_bn_partial_doubles(int64_t rows, int64_t ld) { return cdiv64(rows, BN_ROWS) * 2 * ld; }
+extern "C" int64_t vs_bn_partial_doubles(int64_t rows, int64_t ld) { return ld >= 4 ? cdiv64(rows, bn_chunk_rows(ld)) * 2 * ld : 0; }
 
 extern "C" int vs_bn_batch_stats(const float* x, int64_t rows, int C, int64_t ld, const float* gamma, const float* beta, float eps,
                                  float momentum, float* running_mean, float* running_var, double* partial, float* scale, float* shift,
                                  void* stream) {
   VS_REQUIRE(x && gamma && beta && partial && scale && shift && rows > 0 && C > 0 && ld >= C && (ld & 3) == 0);
   VS_REQUIRE((((uintptr_t)x) & 15) == 0);
-  const int nchunk = (int)cdiv64(rows, BN_ROWS);
-  hipLaunchKernelGGL(bn_partial_kernel, dim3((unsigned)nchunk), dim3(256), 0, (hipStream_t)stream, x, rows, ld, partial);
-  hipLaunchKernelGGL(bn_finish_kernel, dim3((unsigned)((C + 255) / 256)), dim3(256), 0, (hipStream_t)stream, partial, nchunk, rows, C, ld,
+  const int nchunk = (int)cdiv64(rows, bn_chunk_rows(ld));
+  launch_bn_partial(x, rows, ld, partial, (hipStream_t)stream);
+  hipLaunchKernelGGL(bn_finish_kernel, dim3((unsigned)C), dim3(64), 0, (hipStream_t)stream, partial, nchunk, rows, C, ld,
                      gamma, beta, eps, momentum, running_mean, running_var, scale, shift, (const double*)nullptr);
   return vs_launch_status();
 }
@@ -982,16 +1007,16 @@ extern "C" int vs_bn_batch_stats(const float* x, int64_t rows, int C, int64_t ld
 extern "C" int vs_bn_partial_sums(const float* x, int64_t rows, int C, int64_t ld, double* partial, double* sums, void* stream) {
   VS_REQUIRE(x && partial && sums && rows > 0 && C > 0 && ld >= C && (ld & 3) == 0);
   VS_REQUIRE((((uintptr_t)x) & 15) == 0);
-  const int nchunk = (int)cdiv64(rows, BN_ROWS);
-  hipLaunchKernelGGL(bn_partial_kernel, dim3((unsigned)nchunk), dim3(256), 0, (hipStream_t)stream, x, rows, ld, partial);
-  hipLaunchKernelGGL(bn_reduce_kernel, dim3((unsigned)((ld + 255) / 256)), dim3(256), 0, (hipStream_t)stream, partial, nchunk, rows, ld, sums);
+  const int nchunk = (int)cdiv64(rows, bn_chunk_rows(ld));
+  launch_bn_partial(x, rows, ld, partial, (hipStream_t)stream);
+  hipLaunchKernelGGL(bn_reduce_kernel, dim3((unsigned)ld), dim3(64), 0, (hipStream_t)stream, partial, nchunk, rows, ld, sums);
   return vs_launch_status();
 }
 
 extern "C" int vs_bn_finish_sums(const double* sums, int C, int64_t ld, const float* gamma, const float* beta, float eps, float momentum,
                                  float* running_mean, float* running_var, float* scale, float* shift, void* stream) {
   VS_REQUIRE(sums && gamma && beta && scale && shift && C > 0 && ld >= C);
-  hipLaunchKernelGGL(bn_finish_kernel, dim3((unsigned)((C + 255) / 256)), dim3(256), 0, (hipStream_t)stream, sums, 1, (int64_t)0, C, ld,
+  hipLaunchKernelGGL(bn_finish_kernel, dim3((unsigned)C), dim3(64), 0, (hipStream_t)stream, sums, 1, (int64_t)0, C, ld,
                      gamma, beta, eps, momentum, running_mean, running_var, scale, shift, sums + 2 * ld);
   return vs_launch_status();
 }
