@@ -255,6 +255,11 @@ int vs_relu_bwd(const float* z, int64_t ld, const float* dy, int64_t dy_ld, int6
 int vs_outc_tanh_bwd(const float* delta, const float* ddelta, int64_t rows_per_frame, int B, int C, const float* w, int Cout, int use_tanh,
                      float* dx, int64_t dx_ld, float* dv, void* stream);
 
+/* ---- weight operand packing on the device (csrc/pack.hip): packed fp32 weights [N][K] (k = (tap, channel) with K / ntaps a multiple of 16) ->
+ * the 16-bit planes [P][N][K] and their LDS-image order [ceil(N/32)][K/16][P][64][8] the split kernels read (P = 3 bf16 truncation terms for
+ * arith 3; P = 2 f16 terms of w * w_mul for arith 2).  One launch per layer instead of a dozen ATen ops. */
+int vs_split_block(const float* wt, int N, int64_t K, int ntaps, int arith, float w_mul, void* split, void* blk, void* stream);
+
 /* ---- adjoints of the full-resolution shell and of the augmentations between embed and detect (csrc/bwd_shell.hip): d(loss)/d(imgs_w) and
  * d(loss)/d(imgs_aug) -> d(delta), the gradient the U-Net backward starts from (train.py:626-643).  Gather form, deterministic.
  * vs_resize_nchw_bwd: transpose of vs_resize_nchw (dy [planes][oh][ow] -> dx [planes][H][W]; tmp = planes * oh * W floats); also the transpose of

@@ -35,7 +35,8 @@ def _padded(t, ld):
     return out
 
 
-@pytest.mark.parametrize("rows,n,k,ldn,ldk", [(1000, 20, 36, 20, 36), (4100, 96, 384, 96, 384), (64, 257 - 1, 16, 256, 16), (7, 5, 70, 8, 72)])
+@pytest.mark.parametrize("rows,n,k,ldn,ldk", [(1000, 20, 36, 20, 36), (4100, 96, 384, 96, 384), (64, 257 - 1, 16, 256, 16), (7, 5, 70, 8, 72),
+                                              (2500, 130, 200, 132, 200), (16384, 384, 3456, 384, 3456), (33, 64, 64, 64, 64), (5000, 70, 1000, 72, 1000)])
 def test_gemm_wgrad(rows, n, k, ldn, ldk):
     L, st = _lib()
     dy, x = _padded(_rand(rows, n, seed=1), ldn), _padded(_rand(rows, k, seed=2), ldk)

@@ -781,3 +781,22 @@ def test_jnd_heatmap_nchw(eng):
     N.check(eng.lib.vs_jnd_heatmap(N.ptr(dv(x)), 2, 70, 101, 3 * 70 * 101, 70 * 101, 101, 1, t43, N.ptr(h), N.stream()), "jnd")
     torch.cuda.synchronize()
     assert (h.cpu() - ref).abs().max() < 2e-6      # heat-maps are O(0.05); powf/sqrtf ulp differences only
+
+
+@pytest.mark.parametrize("n,cin,kh,kw,arith", [(20, 16, 3, 3, 3), (384, 384, 3, 3, 2), (96, 48, 1, 1, 3), (257, 768, 1, 1, 2), (33, 4, 4, 1, 3)])
+def test_device_weight_pack_is_bit_identical_to_the_torch_pack(n, cin, kh, kw, arith):
+    """csrc/pack.hip (one launch) against engine.split_f16x2 / split_bf16x3 + pack_blocked"""
+    from videoseal_amd import engine as E
+    g = torch.Generator().manual_seed(n + cin)
+    w = (torch.randn(n, cin, kh, kw, generator=g) * 0.05).cuda()
+    wt, cp = E.pack_conv(w, cin)
+    cw = E.ConvW(wt, None, n, kh, kw, cp).with_blk(arith)
+    # reference on the CPU: torch's CPU float -> half conversion rounds to nearest EVEN like v_cvt_f16_f32 does; the ROCm build's device-side
+    # conversion breaks exact ties the other way (a quarter of the low terms are exact ties), so it is not the yardstick
+    if arith == 2:
+        ref_split, w_mul = E.split_f16x2(wt.cpu())
+    else:
+        ref_split, w_mul = E.split_bf16x3(wt.cpu()), 1.0
+    assert cw.w_mul == w_mul
+    assert torch.equal(cw.split.cpu(), ref_split)
+    assert torch.equal(cw.blk.cpu(), E.pack_blocked(ref_split, kh * kw))

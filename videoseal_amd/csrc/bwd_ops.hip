@@ -14,6 +14,7 @@
 // All reductions are deterministic (fixed chunking, fixed summation order, fp64 across chunks).  First version: correctness and
 // determinism first; the element-wise kernels are HBM-bound as they stand, gemm_wgrad is an fp32-FMA kernel (MFMA version: DESIGN 7).
 #include "vs_common.h"
+#include "conv_common.h"
 
 namespace {
 
@@ -131,6 +132,126 @@ __global__ __launch_bounds__(256) void gemm_wgrad_mfma_kernel(const float* __res
       for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+    }
+  }
+  // D[m][n]: lane holds column n = lane & 31 and rows m = (e & 3) + 8 (e >> 2) + 4 (lane >> 5)
+  float* p = partial + (int64_t)blockIdx.z * N * K;
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int k = k0 + wx * 64 + j * 32 + c;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int n = n0 + wy * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * kq;
+        if (n < N && k < K) p[(int64_t)n * K + k] = acc[i][j][e];
+      }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// The same product on the 16-bit matrix cores with the exact 3 x bf16 operand split (six partial products, fp32 accumulate: the accuracy of
+// the fp32 kernels above at 417 instead of 157 TFLOP/s of ceiling).  v_mfma_f32_32x32x16_bf16 wants 8 consecutive reduction indices per lane,
+// and the reduction index here is the ROW: every thread therefore loads one column of 8 consecutive rows (4-byte loads, coalesced across the
+// wave's 64 consecutive columns), splits the 8 values and writes them as ONE 16-byte LDS store per plane into the transposed tile
+// [plane][column][row] -- the fragment reads are then plain 16-byte reads.  Row pitch 80 bytes (32 rows + 8 pad): conflict-free b128 reads.
+// Workgroup = 128 (n) x 128 (k) outputs, 4 waves of 64 x 64 (2 x 2 MFMA tiles), 32 rows per step; the next step's rows are fetched into
+// registers while the matrix cores work.
+namespace wg16 {
+using vsconv::bf16x8;
+using vsconv::u32x4;
+constexpr int RS = 32;                 // rows per step
+constexpr int PITCH = 40;              // bf16 elements per LDS row (32 + 8 pad)
+constexpr int TILE = 128;
+
+__device__ __forceinline__ void split8(const float (&v)[8], u32x4 (&pl)[3]) {
+  unsigned h[8], m[8], l[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const unsigned u = __float_as_uint(v[i]);
+    h[i] = u & 0xffff0000u;
+    const float r = v[i] - __uint_as_float(h[i]);
+    m[i] = __float_as_uint(r) & 0xffff0000u;
+    l[i] = __float_as_uint(r - __uint_as_float(m[i]));
+  }
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    pl[0][q] = vsconv::pack_hi(h[2 * q], h[2 * q + 1]);
+    pl[1][q] = vsconv::pack_hi(m[2 * q], m[2 * q + 1]);
+    pl[2][q] = vsconv::pack_hi(l[2 * q], l[2 * q + 1]);
+  }
+}
+}  // namespace wg16
+
+__global__ __launch_bounds__(256) void gemm_wgrad_bf16x3_kernel(const float* __restrict__ dy, int64_t dy_ld, int N, const float* __restrict__ x,
+                                                                int64_t x_ld, int K, int64_t rows, int64_t rows_per_split,
+                                                                float* __restrict__ partial) {
+  using namespace wg16;
+  __shared__ __attribute__((aligned(16))) unsigned short sa[3][TILE][PITCH], sb[3][TILE][PITCH];
+  const int n0 = blockIdx.y * TILE, k0 = blockIdx.x * TILE;
+  const int64_t r_begin = (int64_t)blockIdx.z * rows_per_split;
+  const int64_t r_end = r_begin + rows_per_split < rows ? r_begin + rows_per_split : rows;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int wy = wave >> 1, wx = wave & 1;
+  const int col = threadIdx.x & 127, rg = threadIdx.x >> 7;          // staging: column `col`, rows rg * 16 .. + 16 of the step
+  const int kq = lane >> 5, c = lane & 31;
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+  float va[16], vb[16];
+  const bool a_ok = n0 + col < N, b_ok = k0 + col < K;
+  const float* pa = dy + n0 + col;
+  const float* pb = x + k0 + col;
+  auto fetch = [&](const int64_t r0) __attribute__((always_inline)) {
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      const int64_t r = r0 + rg * 16 + j;
+      const bool in = r < r_end;
+      va[j] = (in && a_ok) ? pa[r * dy_ld] : 0.f;
+      vb[j] = (in && b_ok) ? pb[r * x_ld] : 0.f;
+    }
+  };
+  fetch(r_begin);
+  for (int64_t r0 = r_begin; r0 < r_end; r0 += RS) {
+    __syncthreads();                       // the previous step's fragment reads are done
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+      float t[8];
+      u32x4 pl[3];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) t[j] = va[half * 8 + j];
+      split8(t, pl);
+#pragma unroll
+      for (int p = 0; p < 3; ++p) *reinterpret_cast<u32x4*>(&sa[p][col][rg * 16 + half * 8]) = pl[p];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) t[j] = vb[half * 8 + j];
+      split8(t, pl);
+#pragma unroll
+      for (int p = 0; p < 3; ++p) *reinterpret_cast<u32x4*>(&sb[p][col][rg * 16 + half * 8]) = pl[p];
+    }
+    __syncthreads();
+    if (r0 + RS < r_end) fetch(r0 + RS);
+#pragma unroll
+    for (int ks = 0; ks < RS / 16; ++ks) {
+      bf16x8 fa[2][3], fb[2][3];
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int p = 0; p < 3; ++p) {
+          fa[i][p] = *reinterpret_cast<const bf16x8*>(&sa[p][wy * 64 + i * 32 + c][ks * 16 + kq * 8]);
+          fb[i][p] = *reinterpret_cast<const bf16x8*>(&sb[p][wx * 64 + i * 32 + c][ks * 16 + kq * 8]);
+        }
+#pragma unroll
+      for (int q = 0; q < 6; ++q)           // smallest partial products first
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j)
+            acc[i][j] = vsconv::Arith<3>::mfma(fa[i][vsconv::Arith<3>::PA[q]], fb[j][vsconv::Arith<3>::PB[q]], acc[i][j]);
     }
   }
   // D[m][n]: lane holds column n = lane & 31 and rows m = (e & 3) + 8 (e >> 2) + 4 (lane >> 5)
@@ -563,12 +684,17 @@ extern "C" int vs_gemm_wgrad(const float* dy, int64_t dy_ld, int N, const float*
   VS_REQUIRE((((uintptr_t)dy) & 15) == 0 && (((uintptr_t)x) & 15) == 0);
   const int64_t splits = vs_gemm_wgrad_partial_floats(rows, N, K) / ((int64_t)N * K);
   int64_t rps = cdiv64(rows, splits);
-  rps = cdiv64(rps, 16) * 16;
+  rps = cdiv64(rps, 32) * 32;
   const int64_t used = cdiv64(rows, rps);                  // <= splits
   // VS_WGRAD=mfma selects the fp32 matrix-core kernel (validated on hardware: tests/test_gpu_bwd.py passes with it; v_mfma_f32_32x32x2_f32 has the
   // same 157 TFLOP/s peak as the vector FMAs, and the step time is the same within noise -- profiles/r03a_*).
-  static const bool use_mfma = [] { const char* e = getenv("VS_WGRAD"); return e && !strcmp(e, "mfma"); }();
-  if (use_mfma)
+  static const int mode = [] { const char* e = getenv("VS_WGRAD"); return !e ? 0 : (!strcmp(e, "mfma") ? 1 : (!strcmp(e, "fma") ? 2 : 0)); }();
+  // default: the 3 x bf16 matrix-core kernel where a 128 x 128 tile is at least half full, the fp32 vector kernel for the thin layers
+  // (VS_WGRAD=fma / mfma force the two fp32 kernels everywhere)
+  if (mode == 0 && N >= 64 && K >= 64)
+    hipLaunchKernelGGL(gemm_wgrad_bf16x3_kernel, dim3((unsigned)cdiv64(K, 128), (unsigned)cdiv64(N, 128), (unsigned)used), dim3(256), 0,
+                       (hipStream_t)stream, dy, dy_ld, N, x, x_ld, K, rows, rps, partial);
+  else if (mode == 1)
     hipLaunchKernelGGL(gemm_wgrad_mfma_kernel, dim3((unsigned)cdiv64(K, 128), (unsigned)cdiv64(N, 128), (unsigned)used), dim3(256), 0,
                        (hipStream_t)stream, dy, dy_ld, N, x, x_ld, K, rows, rps, partial);
   else

@@ -59,8 +59,21 @@ class ConvW:
     arith: int = 3                         # arithmetic the planes were made for (vs_conv_desc_t::arith)
     w_mul: float = 1.0                     # power of two the weights were multiplied with before the split (arith 2)
 
+    def _device_pack(self, arith: int) -> None:
+        """planes + LDS image in ONE launch (csrc/pack.hip) -- bit-identical to split_f16x2 / split_bf16x3 + pack_blocked"""
+        n, k = self.wt.shape
+        P = 2 if arith == 2 else 3
+        self.arith, self.w_mul = arith, (f16x2_scale(self.wt) if arith == 2 else 1.0)
+        self.split = torch.empty(P, n, k, dtype=torch.int16, device=self.wt.device)
+        self.blk = torch.empty((n + 31) // 32, k // 16, P, 64, 8, dtype=torch.int16, device=self.wt.device)
+        N.check(N.lib().vs_split_block(N.ptr(self.wt), n, k, self.KH * self.KW, arith, float(self.w_mul), N.ptr(self.split), N.ptr(self.blk),
+                                       N.stream()), "vs_split_block")
+
     def with_split(self, arith: int = 3) -> "ConvW":
         if self.split is None or self.arith != arith:
+            if self.wt.is_cuda and self.wt.shape[1] % (16 * self.KH * self.KW) == 0:
+                self._device_pack(arith)
+                return self
             self.arith, self.blk = arith, None
             if arith == 2:
                 self.split, self.w_mul = split_f16x2(self.wt)
@@ -71,7 +84,8 @@ class ConvW:
     def with_blk(self, arith: int = 3) -> "ConvW":
         if self.blk is None or self.arith != arith:
             self.with_split(arith)
-            self.blk = pack_blocked(self.split, self.KH * self.KW)
+            if self.blk is None:
+                self.blk = pack_blocked(self.split, self.KH * self.KW)
         return self
 
 
@@ -110,6 +124,13 @@ def split_bf16x3(w: torch.Tensor) -> torch.Tensor:
 
 A_MUL = 16.0        # power of two the activations are multiplied with before the f16 split (vs_conv_desc_t::a_mul): |a| < 4094
 A_MUL_GRN = 1.0     # the same for the GRN-scaled operand of pwconv2: |a| < 65504
+
+
+def f16x2_scale(w: torch.Tensor) -> float:
+    """the power of two of split_f16x2: max|w| * w_mul in [2^13, 2^14)"""
+    amax = float(w.abs().max()) if w.numel() else 0.0
+    kw = 14 - math.frexp(amax)[1] if amax > 0.0 and math.isfinite(amax) else 0
+    return 2.0 ** max(-100, min(100, kw))
 
 
 def split_f16x2(w: torch.Tensor) -> Tuple[torch.Tensor, float]:
