@@ -6,7 +6,7 @@ import torch
 from videoseal_amd import native as N
 L = N.lib()
 B, H, W, S = 32, 768, 768, 256
-x = torch.rand(B, 3, H, W, device="cuda")
+x = torch.rand(B, 3, H, W, device="cuda") * 0.5 + torch.nn.functional.interpolate(torch.rand(B, 3, H // 16, W // 16, device="cuda"), size=(H, W), mode="bilinear") * 0.5
 xu = (x * 255).to(torch.uint8).permute(0, 2, 3, 1).contiguous()
 rgb = torch.empty(B, S, S, 4, device="cuda"); key = torch.empty(B, S, S, 4, device="cuda")
 ymat = (C.c_float * 3)(0.299, 0.587, 0.114)
@@ -35,7 +35,7 @@ print(f"torch sum 302 MB: {ms*1e3:7.1f} us {x.numel()*4/ms/1e6:7.0f} GB/s (HBM r
 # ---- embed tail
 import math
 from videoseal_amd.native import TailDesc
-taps = (C.c_float * 43)(*([1.0] * 25 + [-1, 0, 1, -2, 0, 2, -1, 0, 1] + [1, 2, 1, 0, 0, 0, -1, -2, -1]))
+taps = (C.c_float * 43)(*([1, 1, 1, 1, 1, 1, 2, 2, 2, 1, 1, 2, 0, 2, 1, 1, 2, 2, 2, 1, 1, 1, 1, 1, 1] + [-1, 0, 1, -2, 0, 2, -1, 0, 1] + [1, 2, 1, 0, 0, 0, -1, -2, -1]))   # jnd.py:24-41
 delta = torch.randn(B, 1, S, S, device="cuda") * 0.1
 hm = torch.rand(B, S, S, device="cuda")
 out = torch.empty_like(x); outu = torch.empty_like(xu); pw = torch.empty(B, 1, H, W, device="cuda")

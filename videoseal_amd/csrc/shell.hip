@@ -262,6 +262,25 @@ __device__ __forceinline__ void tail_taps(float (&d)[3], const float* Dw, const 
   }
 }
 
+// STANDARD JND kernels (jnd.py:24-41: Sobel pair + the 5 x 5 luminance mask = box5 + box3 - 2 centre) evaluated separably inside
+// embed_tail_kernel<T, true>: for a group of RG output rows the RG + 4 luminance rows are read once (5 LDS reads per row: x-2 .. x+2), giving per
+// row H5 = box5 row sum, H3, S = L[x+1] - L[x-1] and T = L[x-1] + 2 L[x] + L[x+1]; the vertical combinations run over registers -- 10 LDS reads
+// per pixel instead of 43.  The luminance mask jumps at la = 127 (jnd.py:66-68): a pixel whose separable sum lands within 0.02 of the jump is
+// re-evaluated with the 25-tap order of jnd_at, so the branch taken is the one the generic path / the low-resolution heat-map kernel take.
+// Measured (32 x 768^2, fp32, full JND, no preds_w): 43-tap form 227 us, this form 215 us -- the LDS taps were not the limit; what the JND costs
+// over the plain tail (137 us) is the separate luminance phase (1.27 x frame read + LDS fill + barrier before the first output row).  A
+// column-register form that reads the frame once and keeps the 16 centre pixels in registers needed 195 VGPRs (two waves per SIMD) and
+// ran at 391 us: profiles/r03h_shell_*.log, r03i_shell_separable.log.
+__device__ __forceinline__ float jnd_finish(float la_sum, float gx, float gy) {
+  float la = la_sum / 32.f;
+  la = la <= 127.f ? 17.f * (1.f - sqrtf(la / 127.f + 1e-5f)) : 3.f / 128.f * (la - 127.f) + 3.f;
+  float cm = sqrtf(gx * gx + gy * gy);
+  cm = 16.f * (cm > 0.f ? __builtin_amdgcn_exp2f(2.4f * __builtin_amdgcn_logf(cm)) : 0.f) / (cm * cm + 676.f);
+  cm = 0.117f * cm;
+  const float h = la + cm - 0.3f * fminf(la, cm);
+  return fmaxf(h, 0.f) / 255.f;
+}
+
 // ---------------------------------------------------------------------------------------------------
 struct TailArgs {
   const void* imgs; void* out; float* preds_w; const float* delta; const float* hmap_lowres;
@@ -274,7 +293,7 @@ struct TailArgs {
 // Each thread owns one column: its horizontal taps are computed once and reused for the TTH rows; the vertical taps
 // of the TTH rows are computed by TTH threads into LDS; the source window of delta (x low-res heat-map, x key-frame
 // weights) is staged in LDS so the 4..9 taps per pixel are LDS reads.
-template <typename T>
+template <typename T, bool SEP>
 __global__ __launch_bounds__(256) void embed_tail_kernel(TailArgs a, JndTaps k) {
   __shared__ float L[TLW * (TTH + 2 * HALO)];
   __shared__ float Dw[3 * DW_W * DW_H];
@@ -400,6 +419,37 @@ __global__ __launch_bounds__(256) void embed_tail_kernel(TailArgs a, JndTaps k) 
 #pragma unroll
         for (int c = 0; c < 3; ++c) px[q][c] = Px<T>::ld(img, plane, c, pix);
       }
+    float hmg[RG] = {1.f, 1.f, 1.f, 1.f};
+    if (SEP && full_jnd) {                 // separable stencils for the RG rows of the group: RG + 4 luminance rows, 5 LDS reads each
+      float la_s[RG], gxs[RG], gys[RG];
+#pragma unroll
+      for (int q = 0; q < RG; ++q) { la_s[q] = 0.f; gxs[q] = 0.f; gys[q] = 0.f; }
+#pragma unroll
+      for (int r8 = 0; r8 < RG + 2 * HALO; ++r8) {
+        const float* row = L + (lyg + r8) * TLW + lx + HALO;
+        const float m2 = row[-2], m1 = row[-1], c0 = row[0], p1 = row[1], p2 = row[2];
+        const float h3 = m1 + c0 + p1;
+        const float h5 = h3 + m2 + p2;
+        const float sd = p1 - m1;
+        const float tt = m1 + 2.f * c0 + p1;
+#pragma unroll
+        for (int q = 0; q < RG; ++q) {
+          const int dy = r8 - (q + HALO);       // row offset of this luminance row relative to output row lyg + q
+          if (dy >= -2 && dy <= 2) la_s[q] += h5;
+          if (dy >= -1 && dy <= 1) la_s[q] += h3;
+          if (dy == 0) la_s[q] -= 2.f * c0;
+          if (dy == -1 || dy == 1) gxs[q] += sd;
+          if (dy == 0) gxs[q] += 2.f * sd;
+          if (dy == -1) gys[q] += tt;
+          if (dy == 1) gys[q] -= tt;
+        }
+      }
+#pragma unroll
+      for (int q = 0; q < RG; ++q) {
+        if (fabsf(la_s[q] * (1.f / 32.f) - 127.f) < 0.02f) hmg[q] = jnd_at(L, TLW, lx + HALO, min(lyg + q, TTH - 1) + HALO, k);   // at the jump: the 25-tap order decides
+        else hmg[q] = jnd_finish(la_s[q], gxs[q], gys[q]);
+      }
+    }
 #pragma unroll
     for (int q = 0; q < RG; ++q) {
       const int ly = lyg + q;
@@ -425,7 +475,7 @@ __global__ __launch_bounds__(256) void embed_tail_kernel(TailArgs a, JndTaps k) 
       const bool fwd_order = full_jnd && a.attenuate == 2;
       float hm = 1.f;
       if (full_jnd) {
-        hm = jnd_at(L, TLW, lx + HALO, ly + HALO, k);
+        hm = SEP ? hmg[q] : jnd_at(L, TLW, lx + HALO, ly + HALO, k);
         if (!fwd_order)
           for (int c = 0; c < a.Cd; ++c) d[c] = hm * d[c];
       }
@@ -441,6 +491,16 @@ __global__ __launch_bounds__(256) void embed_tail_kernel(TailArgs a, JndTaps k) 
       }
     }
   }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// the taps of jnd.py:24-41 (what every released card carries in its state dict)
+bool standard_jnd_taps(const float* t) {
+  static const float lum[25] = {1, 1, 1, 1, 1, 1, 2, 2, 2, 1, 1, 2, 0, 2, 1, 1, 2, 2, 2, 1, 1, 1, 1, 1, 1};
+  static const float sx[9] = {-1, 0, 1, -2, 0, 2, -1, 0, 1}, sy[9] = {1, 2, 1, 0, 0, 0, -1, -2, -1};
+  for (int i = 0; i < 25; ++i) if (t[i] != lum[i]) return false;
+  for (int i = 0; i < 9; ++i) if (t[25 + i] != sx[i] || t[34 + i] != sy[i]) return false;
+  return true;
 }
 
 JndTaps taps_from(const float* t43) {
@@ -495,11 +555,16 @@ extern "C" int vs_embed_tail(const vs_tail_desc_t* d, void* stream) {
   JndTaps k{};
   if (d->taps43) k = taps_from(d->taps43);
   dim3 grid((d->W + TTW - 1) / TTW, (d->H + TTH - 1) / TTH, d->F);
+  // full-resolution heat-map with the standard kernels: separable stencil evaluation (VIDEOSEAL_TAIL=v1 keeps the 43-tap form for A/B runs)
+  static const bool v1 = [] { const char* e = getenv("VIDEOSEAL_TAIL"); return e && !strcmp(e, "v1"); }();
+  const bool sep = !v1 && d->attenuate && !d->hmap_lowres && d->taps43 && standard_jnd_taps(d->taps43);
   if (d->io_u8) {
     VS_REQUIRE(d->clamp);        // (x * 255).byte() is only defined for x in [0, 1]
-    hipLaunchKernelGGL(embed_tail_kernel<unsigned char>, grid, dim3(256), 0, (hipStream_t)stream, a, k);
+    // (uint8 frames keep the 43-tap form: measured 215 us against 248 us for the separable one, profiles/r03i_shell_separable.log)
+    hipLaunchKernelGGL((embed_tail_kernel<unsigned char, false>), grid, dim3(256), 0, (hipStream_t)stream, a, k);
   } else {
-    hipLaunchKernelGGL(embed_tail_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, a, k);
+    if (sep) hipLaunchKernelGGL((embed_tail_kernel<float, true>), grid, dim3(256), 0, (hipStream_t)stream, a, k);
+    else hipLaunchKernelGGL((embed_tail_kernel<float, false>), grid, dim3(256), 0, (hipStream_t)stream, a, k);
   }
   return vs_launch_status();
 }
