@@ -255,6 +255,10 @@ int vs_relu_bwd(const float* z, int64_t ld, const float* dy, int64_t dy_ld, int6
 int vs_outc_tanh_bwd(const float* delta, const float* ddelta, int64_t rows_per_frame, int B, int C, const float* w, int Cout, int use_tanh,
                      float* dx, int64_t dx_ld, float* dv, void* stream);
 
+/* *flag |= 1 when x[0 .. n) holds inf / NaN: the always-on guard of the 2 x f16 arithmetic at the network boundary (engine.py reads the flag
+ * synchronously on the first call with new weights and asynchronously afterwards). */
+int vs_check_finite(const float* x, int64_t n, int* flag, void* stream);
+
 /* ---- weight operand packing on the device (csrc/pack.hip): packed fp32 weights [N][K] (k = (tap, channel) with K / ntaps a multiple of 16) ->
  * the 16-bit planes [P][N][K] and their LDS-image order [ceil(N/32)][K/16][P][64][8] the split kernels read (P = 3 bf16 truncation terms for
  * arith 3; P = 2 f16 terms of w * w_mul for arith 2).  One launch per layer instead of a dozen ATen ops. */

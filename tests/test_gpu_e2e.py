@@ -153,27 +153,73 @@ def test_vs10_every_arithmetic_matches_reference_golden(monkeypatch, mode, name)
     _run_case(s, sd, m, name)
 
 
-def test_f16_range_overflow_is_loud_not_silent(monkeypatch):
-    """2 x f16 arithmetic: an activation beyond the f16 range of the operand split becomes inf / NaN (never a silently wrong finite
-    number); VIDEOSEAL_CHECK_FINITE=1 turns that into an exception, and the exact 3 x bf16 split runs the same weights."""
+def test_f16_range_overflow_is_handled_by_default_and_loud_when_forced(monkeypatch):
+    """2 x f16 arithmetic: an activation beyond the f16 range of the operand split becomes inf / NaN (never a silently wrong finite number).
+    Default (VIDEOSEAL_CONV unset = auto): the always-on guard sees it on the first pass with these weights, switches the network to the exact
+    3 x bf16 split and repeats the pass -- the caller gets correct frames.  Forced f16x2: NaN frames, or an exception with VIDEOSEAL_CHECK_FINITE=1."""
     spec = tiny_spec()
     sd = make_state_dict(spec, seed=3)
     big = {k: (v * 3e4 if k.endswith("inc.double_conv.0.weight") else v) for k, v in sd.items()}      # first conv: activations ~1e4..1e5
     imgs = synthetic_frames(2, 64, 64, seed=8).cuda()
     msgs = synthetic_msgs(2, spec.nbits, seed=8)
+    monkeypatch.delenv("VIDEOSEAL_CONV", raising=False)
+    monkeypatch.delenv("VIDEOSEAL_CHECK_FINITE", raising=False)
+    m = make_model(spec, big)
+    with pytest.warns(UserWarning, match="3 x bf16"):
+        out = m.embed(imgs, msgs, is_video=False)["imgs_w"]
+    ref = R.embed_image(big, spec, imgs.cpu(), msgs)["imgs_w"]
+    assert torch.isfinite(out).all() and (out.cpu() - ref).abs().max() < TOL_IMG
+    assert m._engine().arith_net == {"E": 3, "X": 2}
+    out2 = m.embed(imgs, msgs, is_video=False)["imgs_w"]                     # stays on the safe arithmetic, no second warning / sync
+    assert torch.equal(out, out2)
     monkeypatch.setenv("VIDEOSEAL_CHECK_FINITE", "1")
     monkeypatch.setenv("VIDEOSEAL_CONV", "f16x2")
     m = make_model(spec, big)
     with pytest.raises(videoseal_amd.native.NativeError, match="bf16x3"):
         m.embed(imgs, msgs, is_video=False)
-    monkeypatch.setenv("VIDEOSEAL_CHECK_FINITE", "0")          # without the check the NaN reaches the caller (ReLU / clamp let it through)
+    monkeypatch.setenv("VIDEOSEAL_CHECK_FINITE", "0")          # forced fast arithmetic without the check: the NaN reaches the caller
     m0 = make_model(spec, big)
     assert not torch.isfinite(m0.embed(imgs, msgs, is_video=False)["imgs_w"]).all()
-    monkeypatch.setenv("VIDEOSEAL_CHECK_FINITE", "1")
     monkeypatch.setenv("VIDEOSEAL_CONV", "bf16x3")
     m3 = make_model(spec, big)
-    out = m3.embed(imgs, msgs, is_video=False)["imgs_w"]
-    assert torch.isfinite(out).all()
+    assert torch.isfinite(m3.embed(imgs, msgs, is_video=False)["imgs_w"]).all()
+
+
+def test_grn_outlier_channels_match_the_oracle_by_default(monkeypatch):
+    """GRN gamma x 1e3 (the kind of outlier channel a trained ChunkySeal-size extractor can carry): the pwconv2 operand h * (1 + gamma Nx)
+    leaves the f16 range; with the default arithmetic selection the logits still match the oracle"""
+    monkeypatch.delenv("VIDEOSEAL_CONV", raising=False)
+    spec = tiny_spec()
+    sd = make_state_dict(spec, seed=3)
+    big = {k: (v * 1e3 if k.endswith("grn.gamma") else v) for k, v in sd.items()}
+    imgs = synthetic_frames(3, 64, 64, seed=9)
+    ref = R.detect(big, spec, imgs)["preds"]
+    assert ref.abs().max() < 1e6
+    m = make_model(spec, big)
+    preds = m.detect(imgs.cuda(), is_video=False)["preds"].cpu()
+    assert torch.isfinite(preds).all()
+    assert (preds - ref).abs().max() <= 2e-3 * max(1.0, float(ref.abs().max()))
+
+
+def test_data_dependent_overflow_is_reported_by_the_next_call(monkeypatch):
+    """weights verified on ordinary frames, then an input that drives the stem out of the f16 range: the pass itself cannot be repeated without
+    a synchronisation per call, so its logits are non-finite -- but the next API call says so and the model has moved to 3 x bf16"""
+    monkeypatch.delenv("VIDEOSEAL_CONV", raising=False)
+    spec = tiny_spec()
+    sd = make_state_dict(spec, seed=3)
+    m = make_model(spec, sd)
+    imgs = synthetic_frames(2, 64, 64, seed=10).cuda()
+    ok = m.detector(imgs)                                      # verifies the extractor's weights (synchronous check, passes)
+    assert torch.isfinite(ok).all() and m._engine().verified["X"]
+    bad = m.detector(imgs * 3e4)
+    torch.cuda.synchronize()
+    assert not torch.isfinite(bad).all()
+    with pytest.raises(videoseal_amd.native.NativeError, match="earlier call"):
+        m.detector(imgs)
+    again = m.detector(imgs * 3e4)                             # the range-free arithmetic handles it
+    assert torch.isfinite(again).all() and m._engine().arith_net["X"] == 3
+    ref = R.extractor_forward(sd, spec, imgs.cpu() * 3e4)
+    assert (again.cpu() - ref).abs().max() <= 2e-3 * max(1.0, float(ref.abs().max()))
 
 
 def test_bottleneck_planes_chain_is_bit_identical(vs10):

@@ -773,6 +773,17 @@ inline unsigned grid_for(int64_t total, int per_block = 256, int64_t cap = 256 *
   return (unsigned)(g < 1 ? 1 : (g > cap ? cap : g));
 }
 
+// flag |= 1 when x holds a non-finite value (the guard of the 2 x f16 arithmetic at the network boundary: an activation beyond the f16 range
+// of the operand split surfaces as inf / NaN in the network's output -- NaN-propagating ReLU / clamp keep it alive up to here)
+__global__ __launch_bounds__(256) void check_finite_kernel(const float* __restrict__ x, int64_t n, int* __restrict__ flag) {
+  bool bad = false;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const unsigned u = __float_as_uint(x[i]);
+    bad |= (u & 0x7f800000u) == 0x7f800000u;
+  }
+  if (__any(bad) && (threadIdx.x & 63) == 0) atomicOr(flag, 1);
+}
+
 }  // namespace
 
 extern "C" int vs_layernorm_act(const float* x, int64_t rows, int C, int64_t ld, const float* w, const float* b, float eps,
@@ -1027,5 +1038,13 @@ extern "C" int vs_scale_shift_act(const float* x, int64_t rows, int C, int64_t l
   VS_REQUIRE(!add || (add_ld >= C && (add_ld & 3) == 0));
   hipLaunchKernelGGL(scale_shift_act_kernel, dim3(grid_for(rows * (C >> 2), 256, 1 << 16)), dim3(256), 0, (hipStream_t)stream, x, rows, C,
                      ld, scale, shift, act, add, add_ld, out, out_ld);
+  return vs_launch_status();
+}
+
+extern "C" int vs_check_finite(const float* x, int64_t n, int* flag, void* stream) {
+  VS_REQUIRE(x && flag && n > 0);
+  int64_t g = cdiv64(n, 256 * 8);
+  g = g > 1024 ? 1024 : (g < 1 ? 1 : g);
+  hipLaunchKernelGGL(check_finite_kernel, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, x, n, flag);
   return vs_launch_status();
 }

@@ -195,11 +195,23 @@ class HipEngine:
         self.time_all_convs = False
         # arithmetic back-end of vs_conv_gemm: "f16x2" (2 x f16 split, 3 products), "bf16x3" (exact 3 x bf16 split, 6 products),
         # "f32" (v_mfma_f32_32x32x2_f32); "split" = the default split back-end
-        conv_mode = os.environ.get("VIDEOSEAL_CONV", "split")
-        if conv_mode not in ("split", "f32", "bf16x3", "f16x2"):
-            raise N.NativeError(f"VIDEOSEAL_CONV={conv_mode!r}: expected split, f16x2, bf16x3 or f32")
+        conv_mode = os.environ.get("VIDEOSEAL_CONV", "auto")
+        if conv_mode not in ("auto", "split", "f32", "bf16x3", "f16x2"):
+            raise N.NativeError(f"VIDEOSEAL_CONV={conv_mode!r}: expected auto, f16x2, bf16x3 or f32")
         self.use_split = conv_mode != "f32"
         self.arith = 3 if conv_mode == "bf16x3" else 2
+        # "auto" (default): 2 x f16 with an always-on range guard -- every network pass ends with a finite check of its (small) output on the
+        # device (vs_check_finite).  The first pass with a new set of weights reads the flag synchronously: a network whose activations leave
+        # the f16 range of the operand split (|a| * a_mul >= 65520: e.g. outlier channels of a trained GRN) is switched to the range-free exact
+        # 3 x bf16 split and the pass is repeated, so the caller gets correct frames.  Later passes read the flag asynchronously (no sync in the
+        # steady state); a data-dependent overflow then switches the network as well and is reported by the next API call.
+        # "f16x2" forces the fast arithmetic without the guard (NaN frames on overflow; VIDEOSEAL_CHECK_FINITE=1 raises instead).
+        self.auto_arith = conv_mode in ("auto", "split")
+        self.arith_net = {"E": self.arith, "X": self.arith}
+        self.verified = {"E": False, "X": False}
+        self._nf_flag = torch.zeros(2, dtype=torch.int32, device=device)
+        self._nf_host = torch.zeros(2, dtype=torch.int32).pin_memory() if device.type == "cuda" else None
+        self._nf_event = None
         # Upsample groups as a low-resolution 9-tap GEMM + gather (a quarter of the MACs, no up-sampled concat); 0 = the literal
         # bilinear x2 -> reflect-pad conv3x3 -> LayerNorm sequence (kept for A/B checks)
         self.upconv_lowres = os.environ.get("VIDEOSEAL_UPCONV", "lowres") != "direct"
@@ -261,6 +273,9 @@ class HipEngine:
                 self._pack_misc()
             else:
                 setattr(self, gname, None)
+                net = "X" if gname == "X" else "E"
+                if self.auto_arith:                 # new weights: back to the fast arithmetic, to be verified by the next pass
+                    self.arith_net[net], self.verified[net] = 2, False
 
     # ------------------------------------------------------------------ packing
     def _bn_fold(self, g, p):
@@ -695,12 +710,49 @@ class HipEngine:
                   n_store=(cout if out.ld != rup(cout, 4) else None))
         return out
 
-    def _finite(self, t: torch.Tensor, what: str) -> torch.Tensor:
-        if self.check_finite and not bool(torch.isfinite(t).all()):
-            raise N.NativeError(f"{what}: non-finite output. With the 2 x f16 arithmetic (VIDEOSEAL_CONV=f16x2, the default) an activation "
-                                f"outside the f16 range of the operand split (|a| >= {65520.0 / A_MUL:.0f}; {65520.0 / A_MUL_GRN:.0f} for the GRN-scaled "
-                                f"pwconv2 input) becomes inf; VIDEOSEAL_CONV=bf16x3 selects the range-free exact split.")
-        return t
+    _WHY = (f"with the 2 x f16 arithmetic an activation outside the f16 range of the operand split (|a| >= {65520.0 / A_MUL:.0f}; "
+            f"{65520.0 / A_MUL_GRN:.0f} for the GRN-scaled pwconv2 input) becomes inf; VIDEOSEAL_CONV=bf16x3 selects the range-free exact split")
+
+    def _guard(self, net: str, t: torch.Tensor) -> bool:
+        """finite check of a network's output (see __init__).  False = the pass must be repeated (the network was just switched to 3 x bf16)."""
+        idx = 0 if net == "E" else 1
+        guarded = self.use_split and self.arith_net[net] == 2 and self.auto_arith
+        if not guarded:
+            if self.check_finite and not bool(torch.isfinite(t).all()):
+                raise N.NativeError(f"{'embedder' if net == 'E' else 'extractor'}: non-finite output -- " + self._WHY)
+            return True
+        N.check(self.lib.vs_check_finite(N.ptr(t), t.numel(), self._nf_flag.data_ptr() + 4 * idx, N.stream()), "vs_check_finite")
+        if torch.cuda.is_current_stream_capturing():
+            return True
+        if not self.verified[net]:
+            if int(self._nf_flag[idx].item()):          # one synchronisation per set of weights
+                self._nf_flag[idx] = 0
+                self.arith_net[net] = 3
+                import warnings
+                warnings.warn(f"{'embedder' if net == 'E' else 'extractor'}: activations leave the f16 range of the 2 x f16 operand split with these "
+                              f"weights; this network now runs on the exact, range-free 3 x bf16 split (twice the matrix work)")
+                return False
+            self.verified[net] = True
+            return True
+        self._nf_host.copy_(self._nf_flag, non_blocking=True)
+        self._nf_event = torch.cuda.Event()
+        self._nf_event.record()
+        return True
+
+    def poll_nonfinite(self) -> None:
+        """API entry: has an earlier (already verified) pass tripped the range guard?  Then its frames were non-finite: switch the network to
+        3 x bf16 for everything that follows and tell the caller (no silent NaN frames)."""
+        ev = self._nf_event
+        if ev is None or not ev.query():
+            return
+        self._nf_event = None
+        bad = [n for i, n in enumerate(("E", "X")) if int(self._nf_host[i]) and self.arith_net[n] == 2]
+        if bad:
+            for n in bad:
+                self.arith_net[n] = 3
+            self._nf_flag.zero_()
+            raise N.NativeError("an earlier call produced non-finite values in the " + " and ".join("embedder" if n == "E" else "extractor" for n in bad) +
+                                " (data-dependent overflow): " + self._WHY + ".  The engine has switched to it for this model: repeat the call.")
 
     def _gemm_planes_ok(self, rows: int, n: int) -> bool:
         """1x1 GEMM on operand planes (gemm_pl.hip): 2 x f16 arithmetic and enough 256-row x 192-column tiles for the 256 CUs"""
@@ -742,6 +794,16 @@ class HipEngine:
     def embedder_forward(self, x: Act, msgs_i32: torch.Tensor, bn_train: bool = False) -> torch.Tensor:
         """x: key frames, NHWC(ld 4), already mapped to [-1,1]. Returns delta [B][out_ch][S_h][S_w] (planar).
         bn_train: BatchNorm on batch statistics (module in .train() mode), running statistics updated in place."""
+        for _ in range(2):
+            self.arith = self.arith_net["E"]
+            delta = self._embedder_forward(x, msgs_i32, bn_train)
+            if self._guard("E", delta):
+                return delta
+            if bn_train and self.cfg.unet_norm != "rms":
+                raise N.NativeError("embedder: non-finite output of a train-mode forward (BatchNorm statistics already updated) -- " + self._WHY)
+        return delta
+
+    def _embedder_forward(self, x: Act, msgs_i32: torch.Tensor, bn_train: bool = False) -> torch.Tensor:
         if self.cfg.unet_norm == "rms":
             bn_train = False              # no BatchNorm in the net: train and eval forwards coincide
         if bn_train:
@@ -834,13 +896,19 @@ class HipEngine:
         delta = self.buf("delta", B * c.out_ch * xcur.H * xcur.W)
         N.check(L.vs_outc_tanh(N.ptr(xcur.t), xcur.H * xcur.W, B, xcur.C, xcur.ld, N.ptr(E["outc_w"]), N.ptr(E["outc_b"]), c.out_ch,
                                1 if c.last_tanh else 0, N.ptr(delta), st), "vs_outc_tanh")
-        return self._finite(delta, "embedder").view(B, c.out_ch, xcur.H, xcur.W)
+        return delta.view(B, c.out_ch, xcur.H, xcur.W)
 
     # ------------------------------------------------------------------ extractor
     def extractor_forward(self, x: Act) -> torch.Tensor:
         """x: NHWC(ld 4) RGB already mapped to [-1,1]. Returns logits [B][1+nbits]."""
-        if self.cfg.extractor == "sam":
-            return self.vit_extractor_forward(x)
+        for _ in range(2):
+            self.arith = self.arith_net["X"]
+            logits = self.vit_extractor_forward(x) if self.cfg.extractor == "sam" else self._extractor_forward(x)
+            if self._guard("X", logits):
+                break
+        return logits
+
+    def _extractor_forward(self, x: Act) -> torch.Tensor:
         if self.X is None:
             self._pack_extractor(self._g)
         c, X, L = self.cfg, self.X, self.lib
@@ -911,7 +979,7 @@ class HipEngine:
                           # than the GEMM with the fused transform, whose frame-boundary select costs registers
                     N.check(L.vs_grn_apply(N.ptr(hh.t), B, HW, 4 * Cc, hh.ld, N.ptr(scale), hh.ld, N.ptr(blk["beta"]), st), "vs_grn_apply")
                     self.conv(hh, blk["pw2"], cur, res=cur, a_mul=A_MUL_GRN)
-        return self._finite(self._pixel_decoder(cur, X), "extractor")
+        return self._pixel_decoder(cur, X)
 
     def _pixel_decoder(self, cur: Act, X) -> torch.Tensor:
         """pixel_decoder.py:61-83 with upscale_stages [1]: reflect-pad conv3x3 -> LayerNorm(cf) -> GELU -> mean(H, W) -> Linear."""

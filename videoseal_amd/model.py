@@ -266,6 +266,7 @@ class Wam(nn.Module):
                 from .dist import bn_all_reduce
                 self._bn_sync = bn_all_reduce()
         self._eng.bn_sync = self._bn_sync
+        self._eng.poll_nonfinite()
         return self._eng
 
     def repack(self) -> None:

@@ -106,6 +106,9 @@ class DetectorStep:
 
     # ------------------------------------------------------------------ forward that keeps the backward's operands
     def _forward(self, eng: HipEngine, x: Act):
+        """the training forward runs on the exact, range-free 3 x bf16 split: weights drift during training, and an activation that leaves the
+        f16 range of the fast arithmetic would only show up as a NaN loss"""
+        eng.arith = BWD_ARITH
         if eng.X is None:
             eng._pack_extractor(eng._g)
         c, X, L, st = eng.cfg, eng.X, eng.lib, N.stream()
@@ -441,6 +444,7 @@ class EmbedderBackward:
         follow (a training step), off for gradient checks that must leave the module untouched.  BatchNorm follows `embedder.training`."""
         self.batch_stats = bool(self.model.embedder.training)
         self.update_running = update_running and self.batch_stats
+        eng.arith = BWD_ARITH                  # exact, range-free arithmetic for the training forward (see DetectorStep._forward)
         if eng.Et is None:
             eng._pack_embedder(eng._g, train=True)
         c, E, L, st, g, h = eng.cfg, eng.Et, eng.lib, N.stream(), eng._g, self.h
