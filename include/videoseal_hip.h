@@ -224,6 +224,9 @@ int vs_gelu_grn_bwd(const float* h1, int64_t ld, const float* d3, int64_t d3_ld,
                     float* coef, float* dh1, int64_t dh1_ld, float* dgamma, float* dbeta, void* stream);
 int vs_patchify(const float* x, int B, int H, int W, int64_t pld, int P, float* cols, void* stream);
 int vs_unpatch(const float* dcols, int B, int H, int W, int64_t pld, int P, float* dx, void* stream);
+/* the same for a P x P conv with stride S <= P (overlapping patches: ChunkySeal's 4 x 4 stride-2 stem, convnext.py:109) */
+int vs_patchify_s(const float* x, int B, int H, int W, int64_t pld, int P, int S, float* cols, void* stream);
+int vs_unpatch_s(const float* dcols, int B, int H, int W, int64_t pld, int P, int S, float* dx, void* stream);
 int vs_col2im3x3_reflect(const float* dcols, int B, int H, int W, int64_t ld, float* dx, void* stream);
 int vs_colmean(const float* x, int B, int HW, int64_t ld, float* out, void* stream);
 int vs_pool_gelu_bwd(const float* z, int64_t ld, const float* dpooled, int64_t dp_ld, int B, int HW, int C, float* dz, int64_t dz_ld,
@@ -450,6 +453,8 @@ int vs_aug_mask_blend(const float* imgs_w, const float* imgs, const float* mask,
 int vs_aug_add_scaled(const float* x, const float* noise, float std, float* dst, int64_t n, void* stream);
 /* DropFrame / SpeedChange (augmentation/video.py:491-526, 263-313): dst[f] = src[idx[f]] for n_out whole frames; idx int32 on device */
 int vs_aug_gather_frames(const float* src, const int32_t* idx, float* dst, int n_out, int64_t frame_floats, void* stream);
+/* video.py:411-486 WindowAveraging: (1 - alpha) * f[i] + alpha * mean of the frames within half_window of i */
+int vs_aug_window_average(const float* src, float* dst, int F, int64_t frame_floats, int half_window, float alpha, void* stream);
 /* crop (geometric.py:94-124, zero fill outside) and/or horizontal flip (geometric.py:186-196) of `planes` H x W planes   */
 int vs_aug_crop_flip(const float* src, float* dst, int planes, int H, int W, int i0, int j0, int h, int w, int flip, void* stream);
 /* bilinear resize NCHW -> NCHW, align_corners=False, antialias on/off (geometric.py:62-91; augmenter.py:147-150)        */

@@ -213,3 +213,34 @@ def test_config3_clip_through_the_full_chain():
     acc = R.bit_accuracy(preds[:, 1:], msgs.expand(16, -1).float())
     acc_ref = R.bit_accuracy(pref[:, 1:], msgs.expand(16, -1).float())
     assert (acc - acc_ref).abs().max() < 1e-3
+
+
+def test_temporal_reorder_and_window_averaging_match_the_reference_semantics():
+    """augmentation/video.py:319-486 restated with torch on the CPU (chunk swap by python `random`; sliding-window mean blend)"""
+    import random
+    x = synthetic_frames(11, 24, 20, seed=31)
+    xg = x.cuda()
+    # TemporalReorder: same draws as the reference -> same permutation
+    random.seed(5)
+    y, _ = G.TemporalReorder()(xg, None, 3, 0.7)
+    random.seed(5)
+    nch = 11 // 3
+    order = list(range(nch))
+    for i in range(0, nch - 1, 2):
+        if random.random() < 0.7 and i + 1 < nch:
+            order[i], order[i + 1] = order[i + 1], order[i]
+    ref = torch.cat([x[:9].view(nch, 3, *x.shape[1:])[order].reshape(-1, *x.shape[1:]), x[9:]], 0)
+    assert torch.equal(y.cpu(), ref)
+    short, _ = G.TemporalReorder()(xg[:5], None, 3, 1.0)
+    assert short is xg[:5] or torch.equal(short, xg[:5])
+    # WindowAveraging
+    for ws, alpha in ((3, 1.0), (4, 0.4), (20, 0.6)):
+        y, _ = G.WindowAveraging()(xg, None, ws, alpha)
+        w = min(ws, 11)
+        ref = x.clone()
+        for i in range(11):
+            a, b = max(0, i - w // 2), min(11, i + w // 2 + 1)
+            ref[i] = (1 - alpha) * x[i] + alpha * torch.mean(x[a:b], dim=0, keepdim=True).squeeze(0)
+        assert (y.cpu() - ref).abs().max() <= 1.2e-7, (ws, alpha)
+    with pytest.raises(NotImplementedError, match="pyav"):
+        G.VP9()(xg, None)

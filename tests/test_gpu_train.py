@@ -189,10 +189,13 @@ def test_embed_tail_adjoint(H, W, step, mode, lowres, nf):
     assert (dd.cpu() - ref).abs().max() <= 2e-5 * float(ref.abs().max()), float((dd.cpu() - ref).abs().max() / ref.abs().max())
 
 
-def test_detector_input_gradient_matches_oracle_autograd():
-    """DetectTrainFn: d loss / d imgs_aug (the path of the decoding loss back to the embedder) and the parameter gradients in one pass"""
-    spec = tiny_spec()
-    sd = make_state_dict(spec, seed=3)
+@pytest.mark.parametrize("arch", ["tiny", "tiny_chunky"])
+def test_detector_input_gradient_matches_oracle_autograd(arch):
+    """DetectTrainFn: d loss / d imgs_aug (the path of the decoding loss back to the embedder) and the parameter gradients in one pass.
+    tiny_chunky: ChunkySeal's overlapping 4 x 4 stride-2 stem and odd feature maps (31 -> 15 -> 7 -> 3: the 2 x 2 stride-2 convs drop the last
+    row / column, whose pixels receive no gradient), channel counts that are not multiples of 4"""
+    spec = tiny_spec() if arch == "tiny" else tiny_spec(yuv=False, in_ch=3, out_ch=3, dims=[18, 36, 54, 90], stem_stride=2, hidden=32, nbits=16)
+    sd = make_state_dict(spec, seed=3 if arch == "tiny" else 4)
     S = spec.img_size
     x = synthetic_frames(3, S, S, seed=30)
     names = [k for k in sd if k.startswith("detector.") and sd[k].dtype.is_floating_point]

@@ -180,8 +180,8 @@ def test_videoseal_import_shim_resolves_the_reference_paths():
 
 
 def test_detector_step_has_no_cpu_path_and_rejects_what_it_does_not_cover():
-    """videoseal_amd.training.DetectorStep (train.py:517-523): loud on a CPU model, on the ViT extractor of the legacy card and on
-    ChunkySeal's overlapping stem; malformed inputs are rejected before any launch."""
+    """videoseal_amd.training.DetectorStep (train.py:517-523): loud on a CPU model and on the ViT extractor of the legacy card; malformed
+    inputs are rejected before any launch."""
     from videoseal_amd.training import DetectorStep
     m = videoseal_amd.build("videoseal_1.0").train()
     step = DetectorStep(m)
@@ -189,5 +189,28 @@ def test_detector_step_has_no_cpu_path_and_rejects_what_it_does_not_cover():
         step.step(torch.rand(2, 3, 256, 256), torch.zeros(2, 256))
     with pytest.raises(native.NativeError, match="ConvNeXt"):
         DetectorStep(videoseal_amd.build("videoseal_0.0"))
-    with pytest.raises(native.NativeError, match="stem"):
-        DetectorStep(videoseal_amd.build("chunkyseal"))
+
+
+def test_validation_tables_match_the_reference():
+    """augmentation/__init__.py:12-130 row for row (classes + fixed strengths), incl. the codec rows of the video tables
+    (fixture: tests/golden/make_golden_tables.py run on the unmodified reference)"""
+    import json
+    import os
+    from videoseal_amd import augmentation as A
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "validation_tables.json")) as f:
+        gold = json.load(f)
+
+    def rows(table):
+        out = []
+        for aug, params in table:
+            name = ("Sequential(" + ",".join(t.__class__.__name__ for t in aug.transforms) + ")") if isinstance(aug, A.Sequential) else aug.__class__.__name__
+            out.append([name, [list(p) if isinstance(p, tuple) else p for p in params]])
+        return out
+    assert rows(A.get_validation_augs(False)) == gold["validation_image"]
+    assert rows(A.get_validation_augs(True)) == gold["validation_video"]
+    assert rows(A.get_validation_augs(False, only_identity=True)) == gold["identity"]
+    assert rows(A.get_validation_augs(False, only_combined=True)) == gold["combined_image"]
+    assert rows(A.get_validation_augs(True, only_combined=True)) == gold["combined_video"]
+    assert rows(A.get_validation_augs_subset(False)) == gold["subset_image"]
+    assert rows(A.get_validation_augs_subset(True)) == gold["subset_video"]
+    assert repr(A.H264(20, 30)) == "H264proxy" and "backend=proxy" in repr(A.VideoCompression())      # the stand-in is visible in names and logs

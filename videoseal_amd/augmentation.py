@@ -366,6 +366,83 @@ class SpeedChange(_Aug):
         return f"SpeedChange(min_speed={self.min_speed}, max_speed={self.max_speed})"
 
 
+class TemporalReorder(_Aug):
+    """augmentation/video.py:319-408: neighbouring chunks of frames swapped with probability reorder_prob (python `random`, same draw
+    order as the reference); frames past the last whole chunk stay in place."""
+
+    def __init__(self, min_chunk_size=2, max_chunk_size=5, reorder_prob=0.5):
+        super().__init__()
+        self.min_chunk_size, self.max_chunk_size, self.reorder_prob = min_chunk_size, max_chunk_size, reorder_prob
+
+    def get_random_chunk_size(self):
+        import random
+        if self.min_chunk_size is None or self.max_chunk_size is None:
+            raise ValueError("min_chunk_size and max_chunk_size must be provided")
+        return random.randint(self.min_chunk_size, self.max_chunk_size)
+
+    def forward(self, frames, mask=None, chunk_size=None, swap_probability=None, *args, **kwargs):
+        import random
+        n = frames.shape[0]
+        chunk_size = chunk_size if chunk_size is not None else self.get_random_chunk_size()
+        swap_probability = swap_probability if swap_probability is not None else self.reorder_prob
+        if n < chunk_size * 2:
+            return frames, mask
+        nch = n // chunk_size
+        order = list(range(nch))
+        for i in range(0, nch - 1, 2):
+            if random.random() < swap_probability and i + 1 < nch:
+                order[i], order[i + 1] = order[i + 1], order[i]
+        idx = [c * chunk_size + j for c in order for j in range(chunk_size)] + list(range(nch * chunk_size, n))
+        return gather_frames(frames, idx), (gather_frames(mask, idx) if mask is not None else mask)
+
+    def __repr__(self):
+        return f"TemporalReorder(min_chunk_size={self.min_chunk_size}, max_chunk_size={self.max_chunk_size}, reorder_prob={self.reorder_prob})"
+
+
+def window_average(frames: torch.Tensor, window_size: int, alpha: float) -> torch.Tensor:
+    if AG.needs_grad(frames):
+        with torch.no_grad():
+            y = window_average(frames, window_size, alpha)
+        return AG.NoAdjointFn.apply(frames, y, "WindowAveraging")
+    x = _dev(frames)
+    out = torch.empty_like(x)
+    N.check(N.lib().vs_aug_window_average(N.ptr(x), N.ptr(out), x.shape[0], x[0].numel(), int(window_size) // 2, float(alpha), N.stream()),
+            "vs_aug_window_average")
+    return out
+
+
+class WindowAveraging(_Aug):
+    """augmentation/video.py:411-486: every frame blended with the mean of the frames inside a sliding window."""
+
+    def __init__(self, min_window_size=2, max_window_size=5, min_alpha=0.3, max_alpha=0.7):
+        super().__init__()
+        self.min_window_size, self.max_window_size, self.min_alpha, self.max_alpha = min_window_size, max_window_size, min_alpha, max_alpha
+
+    def get_random_window_size(self):
+        import random
+        if self.min_window_size is None or self.max_window_size is None:
+            raise ValueError("min_window_size and max_window_size must be provided")
+        return random.randint(self.min_window_size, self.max_window_size)
+
+    def get_random_alpha(self):
+        import random
+        if self.min_alpha is None or self.max_alpha is None:
+            raise ValueError("min_alpha and max_alpha must be provided")
+        return random.uniform(self.min_alpha, self.max_alpha)
+
+    def forward(self, frames, mask=None, window_size=None, alpha=None, *args, **kwargs):
+        n = frames.shape[0]
+        if n <= self.min_window_size:
+            return frames, mask
+        window_size = window_size if window_size is not None else self.get_random_window_size()
+        window_size = min(window_size, n)
+        alpha = alpha if alpha is not None else self.get_random_alpha()
+        return window_average(frames, window_size, alpha), mask
+
+    def __repr__(self):
+        return f"WindowAveraging(min_window={self.min_window_size}, max_window={self.max_window_size})"
+
+
 class _NotBuilt(_Aug):
     why = ""
 
@@ -601,6 +678,36 @@ class H265(_CrfCodec):
     CODEC = "libx265"
 
 
+class VP9(VideoCompression):
+    """video.py:208-220 (libvpx-vp9 at its default quality).  The transform-coding proxy models H.264's 4x4 transform only: VP9 / AV1 exist
+    for the evaluation tables and run through the PyAV side path (VIDEOSEAL_CODEC=pyav); with the proxy back-end they raise."""
+
+    def __init__(self, fps=24):
+        super().__init__(codec="libvpx-vp9", fps=fps)
+        self.crf = -1
+
+    def forward(self, frames, mask=None, *args, **kwargs):
+        if self.backend != "pyav":
+            raise NotImplementedError(f"{self.codec}: no on-GPU proxy for this codec; VIDEOSEAL_CODEC=pyav runs the reference's PyAV round trip")
+        return super().forward(frames, mask)
+
+    def __repr__(self):
+        return "VP9"
+
+
+class AV1(_CrfCodec):
+    """video.py:223-241 (libsvtav1)."""
+    CODEC = "libsvtav1"
+
+    def forward(self, frames, mask=None, crf=None):
+        if self.backend != "pyav":
+            raise NotImplementedError(f"{self.codec}: no on-GPU proxy for this codec; VIDEOSEAL_CODEC=pyav runs the reference's PyAV round trip")
+        return super().forward(frames, mask, crf)
+
+    def __repr__(self):
+        return "AV1"
+
+
 class Sequential(nn.Module):
     """augmentation/sequential.py:8-30."""
 
@@ -735,17 +842,35 @@ def get_dummy_augmenter():
     return Augmenter(augs={"identity": 1}, augs_params={}, masks={"kind": "none"})
 
 
+def get_validation_augs_subset(is_video: bool = False) -> list:
+    """augmentation/__init__.py:12-40."""
+    codec, q = (H264, 40) if is_video else (JPEG, 60)
+    return [(Identity(), [0]), (HorizontalFlip(), [0]), (Crop(), [0.71]), (Brightness(), [0.5]), (codec(), [q]),
+            (Sequential(codec(), Crop(), Brightness()), [(q, 0.71, 0.5)])]
+
+
+def get_combined_augs(is_video: bool = False) -> list:
+    """augmentation/__init__.py:43-59."""
+    if is_video:
+        return [(Identity(), [0]), (Sequential(H264(), Crop(), Brightness()), [(30, 0.71, 0.5)]),
+                (Sequential(H264(), Crop(), Brightness()), [(40, 0.71, 0.5)])]
+    return [(Identity(), [0]), (Sequential(JPEG(), Crop(), Brightness()), [(40, 0.71, 0.5)])]
+
+
 def get_validation_augs(is_video: bool = False, only_identity: bool = False, only_combined: bool = False) -> list:
-    """The fixed-strength evaluation table of augmentation/__init__.py:58-124 restricted to the ops built here
-    (codec rows are dropped)."""
+    """The fixed-strength evaluation tables of augmentation/__init__.py:62-130, row for row.  The codec rows run on the back-end selected by
+    VIDEOSEAL_CODEC (default: the on-GPU H.264 proxy, reported as `H264proxy`; VP9 needs the PyAV side path)."""
     if only_identity:
         return [(Identity(), [0])]
     if only_combined:
-        return [(Identity(), [0]), (Sequential(JPEG(), Crop(), Brightness()), [(40, 0.71, 0.5)])]
+        return get_combined_augs(is_video)
     if is_video:
         return [(Identity(), [0]), (HorizontalFlip(), [0]), (Rotate(), [10, 90]), (Resize(), [0.55, 0.71]), (Crop(), [0.55, 0.71]),
                 (Perspective(), [0.5]), (Brightness(), [0.5, 1.5]),
-                (Contrast(), [0.5, 1.5]), (Saturation(), [0.5, 1.5]), (Hue(), [0.25]), (Grayscale(), [-1]), (JPEG(), [40]), (GaussianBlur(), [9])]
+                (Contrast(), [0.5, 1.5]), (Saturation(), [0.5, 1.5]), (Hue(), [0.25]), (Grayscale(), [-1]), (JPEG(), [40]), (GaussianBlur(), [9]),
+                (H264(), [23, 30, 40, 50]), (H264rgb(), [23, 30, 40, 50]), (H265(), [23, 30, 40, 50]), (VP9(), [-1]),
+                (Sequential(H264(), Crop(), Brightness()), [(23, 0.71, 0.5)]), (Sequential(H264(), Crop(), Brightness()), [(30, 0.71, 0.5)]),
+                (Sequential(H264(), Crop(), Brightness()), [(40, 0.71, 0.5)]), (Sequential(H264(), Crop(), Brightness()), [(50, 0.71, 0.5)])]
     return [(Identity(), [0]), (HorizontalFlip(), [0]), (Rotate(), [5, 10, 30, 45, 90]),
             (Resize(), [0.32, 0.45, 0.55, 0.63, 0.71, 0.77, 0.84, 0.89, 0.95, 1.00]),
             (Crop(), [0.32, 0.45, 0.55, 0.63, 0.71, 0.77, 0.84, 0.89, 0.95, 1.00]),

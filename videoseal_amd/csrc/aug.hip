@@ -119,6 +119,23 @@ __global__ __launch_bounds__(256) void add_scaled_kernel(const float* __restrict
   }
 }
 
+// video.py:411-486 (WindowAveraging): out[i] = (1 - alpha) * f[i] + alpha * mean(f[max(0, i - hw) .. min(F, i + hw + 1))), hw = window / 2.
+// ATen's mean over the (few) frames of the window is the sum in frame order divided by the count; the blend rounds both products.
+__global__ __launch_bounds__(256) void window_average_kernel(const float* __restrict__ src, float* __restrict__ dst, int F, int64_t fsz, int hw,
+                                                             float alpha) {
+#pragma clang fp contract(off)
+  const int64_t i = blockIdx.y;
+  const int a = (int)(i - hw < 0 ? 0 : i - hw), b = (int)(i + hw + 1 > F ? F : i + hw + 1);
+  const float inv = (float)(b - a);
+  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < fsz; e += (int64_t)gridDim.x * 256) {
+    float s = 0.f;
+    for (int k = a; k < b; ++k) s += src[(int64_t)k * fsz + e];
+    const float avg = s / inv;
+    const float t0 = (1.f - alpha) * src[i * fsz + e];
+    const float t1 = alpha * avg;
+    dst[i * fsz + e] = t0 + t1;
+  }
+}
 // video.py:507-526 (DropFrame) / 283-313 (SpeedChange): dst[f] = src[idx[f]], whole frames of `fsz` floats (fsz % 4 == 0 fast path)
 __global__ __launch_bounds__(256) void gather_frames_kernel(const float* __restrict__ src, const int32_t* __restrict__ idx,
                                                             float* __restrict__ dst, int64_t fsz) {
@@ -576,5 +593,11 @@ extern "C" int vs_aug_add_scaled(const float* x, const float* noise, float std, 
 extern "C" int vs_aug_gather_frames(const float* src, const int32_t* idx, float* dst, int n_out, int64_t frame_floats, void* stream) {
   VS_REQUIRE(src && idx && dst && n_out > 0 && frame_floats > 0);
   hipLaunchKernelGGL(gather_frames_kernel, dim3(gridx(frame_floats), n_out), dim3(256), 0, (hipStream_t)stream, src, idx, dst, frame_floats);
+  return vs_launch_status();
+}
+
+extern "C" int vs_aug_window_average(const float* src, float* dst, int F, int64_t frame_floats, int half_window, float alpha, void* stream) {
+  VS_REQUIRE(src && dst && F > 0 && frame_floats > 0 && half_window >= 0);
+  hipLaunchKernelGGL(window_average_kernel, dim3(gridx(frame_floats), F), dim3(256), 0, (hipStream_t)stream, src, dst, F, frame_floats, half_window, alpha);
   return vs_launch_status();
 }

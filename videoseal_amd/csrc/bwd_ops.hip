@@ -527,7 +527,7 @@ __global__ __launch_bounds__(256) void gelu_grn_bwd_kernel(const float* __restri
 // ---------------------------------------------------------------------------------------------------
 // P x P, stride P patch convs (ConvNeXt stem and downsample layers): patch matrix in the k order of engine.pack_patch_conv,
 // k = ky * CP + kx * pld + c (CP = P * pld rounded up to 16), and its adjoint
-__global__ __launch_bounds__(256) void patchify_kernel(const float* __restrict__ x, int H, int W, int64_t pld, int P, int Ho, int Wo, int CP,
+__global__ __launch_bounds__(256) void patchify_kernel(const float* __restrict__ x, int H, int W, int64_t pld, int P, int S, int Ho, int Wo, int CP,
                                                        int64_t total, float* __restrict__ cols) {
   const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;       // (row_out, ky, e4)
   if (idx >= total) return;
@@ -541,10 +541,10 @@ __global__ __launch_bounds__(256) void patchify_kernel(const float* __restrict__
   const int oy = (int)(t2 % Ho);
   const int64_t b = t2 / Ho;
   f32x4 v = {0.f, 0.f, 0.f, 0.f};
-  if ((int64_t)4 * e4 < (int64_t)P * pld) v = *reinterpret_cast<const f32x4*>(x + ((b * H + oy * P + ky) * W + (int64_t)ox * P) * pld + 4 * e4);
+  if ((int64_t)4 * e4 < (int64_t)P * pld) v = *reinterpret_cast<const f32x4*>(x + ((b * H + oy * S + ky) * W + (int64_t)ox * S) * pld + 4 * e4);
   *reinterpret_cast<f32x4*>(cols + (ro * P + ky) * CP + 4 * e4) = v;
 }
-__global__ __launch_bounds__(256) void unpatch_kernel(const float* __restrict__ dcols, int H, int W, int64_t pld, int P, int Ho, int Wo, int CP,
+__global__ __launch_bounds__(256) void unpatch_kernel(const float* __restrict__ dcols, int H, int W, int64_t pld, int P, int S, int Ho, int Wo, int CP,
                                                       int64_t total, float* __restrict__ dx) {
   const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;       // (pixel, c4)
   if (idx >= total) return;
@@ -555,10 +555,17 @@ __global__ __launch_bounds__(256) void unpatch_kernel(const float* __restrict__ 
   const int64_t t = pix / W;
   const int yy = (int)(t % H);
   const int64_t b = t / H;
-  const int oy = yy / P, ox = xx / P;
-  f32x4 v = {0.f, 0.f, 0.f, 0.f};          // pixels outside the last whole patch (odd sizes) receive no gradient
-  if (oy < Ho && ox < Wo)
-    v = *reinterpret_cast<const f32x4*>(dcols + (((b * Ho + oy) * Wo + ox) * P + (yy - oy * P)) * CP + (int64_t)(xx - ox * P) * pld + 4 * c4);
+  // the patches (oy, ox) with oy * S <= yy < oy * S + P (and the same in x), in a fixed order: S == P is the non-overlapping case (one patch;
+  // pixels outside the last whole patch receive no gradient), S < P the overlapping stem of ChunkySeal (4 x 4 stride 2: up to 2 x 2 patches)
+  f32x4 v = {0.f, 0.f, 0.f, 0.f};
+  const int oy1 = yy / S, ox1 = xx / S;
+  for (int oy = oy1 - (P - 1) / S; oy <= oy1; ++oy) {
+    if (oy < 0 || oy >= Ho || yy - oy * S >= P) continue;
+    for (int ox = ox1 - (P - 1) / S; ox <= ox1; ++ox) {
+      if (ox < 0 || ox >= Wo || xx - ox * S >= P) continue;
+      v += *reinterpret_cast<const f32x4*>(dcols + (((b * Ho + oy) * Wo + ox) * P + (yy - oy * S)) * CP + (int64_t)(xx - ox * S) * pld + 4 * c4);
+    }
+  }
   *reinterpret_cast<f32x4*>(dx + pix * pld + 4 * c4) = v;
 }
 
@@ -783,22 +790,30 @@ extern "C" int vs_gelu_grn_bwd(const float* h1, int64_t ld, const float* d3, int
   return vs_launch_status();
 }
 
-extern "C" int vs_patchify(const float* x, int B, int H, int W, int64_t pld, int P, float* cols, void* stream) {
-  VS_REQUIRE(x && cols && B > 0 && P > 0 && H >= P && W >= P && pld > 0 && (pld & 3) == 0 && (((uintptr_t)x) & 15) == 0 && (((uintptr_t)cols) & 15) == 0);
-  const int Ho = H / P, Wo = W / P;
+extern "C" int vs_patchify_s(const float* x, int B, int H, int W, int64_t pld, int P, int S, float* cols, void* stream) {
+  VS_REQUIRE(x && cols && B > 0 && P > 0 && S > 0 && S <= P && H >= P && W >= P && pld > 0 && (pld & 3) == 0 && (((uintptr_t)x) & 15) == 0 &&
+             (((uintptr_t)cols) & 15) == 0);
+  const int Ho = (H - P) / S + 1, Wo = (W - P) / S + 1;
   const int CP = (int)(cdiv64((int64_t)P * pld, 16) * 16);
   const int64_t total = (int64_t)B * Ho * Wo * P * (CP / 4);
-  hipLaunchKernelGGL(patchify_kernel, dim3(blocks_for(total)), dim3(256), 0, (hipStream_t)stream, x, H, W, pld, P, Ho, Wo, CP, total, cols);
+  hipLaunchKernelGGL(patchify_kernel, dim3(blocks_for(total)), dim3(256), 0, (hipStream_t)stream, x, H, W, pld, P, S, Ho, Wo, CP, total, cols);
   return vs_launch_status();
 }
+extern "C" int vs_patchify(const float* x, int B, int H, int W, int64_t pld, int P, float* cols, void* stream) {
+  return vs_patchify_s(x, B, H, W, pld, P, P, cols, stream);
+}
 
-extern "C" int vs_unpatch(const float* dcols, int B, int H, int W, int64_t pld, int P, float* dx, void* stream) {
-  VS_REQUIRE(dcols && dx && B > 0 && P > 0 && H >= P && W >= P && pld > 0 && (pld & 3) == 0 && (((uintptr_t)dx) & 15) == 0 && (((uintptr_t)dcols) & 15) == 0);
-  const int Ho = H / P, Wo = W / P;
+extern "C" int vs_unpatch_s(const float* dcols, int B, int H, int W, int64_t pld, int P, int S, float* dx, void* stream) {
+  VS_REQUIRE(dcols && dx && B > 0 && P > 0 && S > 0 && S <= P && H >= P && W >= P && pld > 0 && (pld & 3) == 0 && (((uintptr_t)dx) & 15) == 0 &&
+             (((uintptr_t)dcols) & 15) == 0);
+  const int Ho = (H - P) / S + 1, Wo = (W - P) / S + 1;
   const int CP = (int)(cdiv64((int64_t)P * pld, 16) * 16);
   const int64_t total = (int64_t)B * H * W * (pld / 4);
-  hipLaunchKernelGGL(unpatch_kernel, dim3(blocks_for(total)), dim3(256), 0, (hipStream_t)stream, dcols, H, W, pld, P, Ho, Wo, CP, total, dx);
+  hipLaunchKernelGGL(unpatch_kernel, dim3(blocks_for(total)), dim3(256), 0, (hipStream_t)stream, dcols, H, W, pld, P, S, Ho, Wo, CP, total, dx);
   return vs_launch_status();
+}
+extern "C" int vs_unpatch(const float* dcols, int B, int H, int W, int64_t pld, int P, float* dx, void* stream) {
+  return vs_unpatch_s(dcols, B, H, W, pld, P, P, dx, stream);
 }
 
 extern "C" int vs_col2im3x3_reflect(const float* dcols, int B, int H, int W, int64_t ld, float* dx, void* stream) {

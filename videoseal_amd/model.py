@@ -445,9 +445,9 @@ class Wam(nn.Module):
         if emb and cfg.unet_norm == "rms":
             emb = False
             why.append("the RMSNorm / SiLU U-Net of the legacy card")
-        if det and (cfg.extractor == "sam" or cfg.stem_stride != 4):
+        if det and cfg.extractor == "sam":
             det = False
-            why.append("the ViT extractor" if cfg.extractor == "sam" else "the stride-2 stem of ChunkySeal's extractor")
+            why.append("the ViT extractor")
         if why and not self._warned_no_backward:
             self._warned_no_backward = True
             import warnings

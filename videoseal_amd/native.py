@@ -26,9 +26,9 @@ EXPORTS = [
     "vs_upcat2x", "vs_upconv_supported", "vs_upconv_gather_ln", "vs_cat2_scale", "vs_msg_pre", "vs_upconv_fused_supported", "vs_upconv_fused_preferred", "vs_upconv_fused", "vs_im2col3x3", "vs_msg_latent", "vs_broadcast_channels", "vs_outc_tanh", "vs_pool_linear", "vs_resize_pre", "vs_resize_pre_u8",
     "vs_jnd_heatmap", "vs_embed_tail", "vs_aug_color_scratch_floats", "vs_aug_color", "vs_aug_crop_flip", "vs_aug_warp", "vs_resize_nchw",
     "vs_gaussian_blur", "vs_median_filter", "vs_jpeg_workspace_bytes", "vs_jpeg_roundtrip", "vs_h264_proxy_workspace_bytes", "vs_h264_proxy_roundtrip",
-    "vs_bn_partial_doubles", "vs_bn_batch_stats", "vs_bn_partial_sums", "vs_bn_finish_sums", "vs_scale_shift_act", "vs_aug_mask_blend", "vs_aug_add_scaled", "vs_aug_gather_frames",
+    "vs_bn_partial_doubles", "vs_bn_batch_stats", "vs_bn_partial_sums", "vs_bn_finish_sums", "vs_scale_shift_act", "vs_aug_mask_blend", "vs_aug_add_scaled", "vs_aug_gather_frames", "vs_aug_window_average",
     "vs_gemm_wgrad_partial_floats", "vs_gemm_wgrad", "vs_dwconv7", "vs_dwconv7_wgrad_partial_floats", "vs_dwconv7_wgrad", "vs_colreduce_partial_floats",
-    "vs_layernorm_bwd", "vs_gelu_grn_bwd", "vs_patchify", "vs_unpatch", "vs_col2im3x3_reflect", "vs_colmean", "vs_pool_gelu_bwd", "vs_matmul_small",
+    "vs_layernorm_bwd", "vs_gelu_grn_bwd", "vs_patchify", "vs_unpatch", "vs_patchify_s", "vs_unpatch_s", "vs_col2im3x3_reflect", "vs_colmean", "vs_pool_gelu_bwd", "vs_matmul_small",
     "vs_bce_logits",
     "vs_bn_mean_rstd", "vs_bn_bwd_partial_floats", "vs_bn_relu_bwd_sums", "vs_bn_relu_bwd_apply", "vs_dilate2", "vs_im2col3x3_strided", "vs_upcat2x_bwd",
     "vs_msg_table_grad", "vs_outc_tanh_bwd", "vs_relu_bwd",
@@ -135,6 +135,7 @@ def lib() -> C.CDLL:
         "vs_aug_mask_blend": [P, P, P, P, I, I, I, I, P],
         "vs_aug_add_scaled": [P, P, F, P, I64, P],
         "vs_aug_gather_frames": [P, P, P, I, I64, P],
+        "vs_aug_window_average": [P, P, I, I64, I, F, P],
         "vs_gemm_wgrad": [P, I64, I, P, I64, I, I64, P, P, P],
         "vs_dwconv7": [P, I, I, I, I, I64, P, P, I, P, I64, P, I64, P],
         "vs_dwconv7_wgrad": [P, I64, P, I64, I, I, I, I, P, P, P],
@@ -142,6 +143,8 @@ def lib() -> C.CDLL:
         "vs_gelu_grn_bwd": [P, I64, P, I64, P, I, I, I, P, P, P, I64, P, P, P],
         "vs_patchify": [P, I, I, I, I64, I, P, P],
         "vs_unpatch": [P, I, I, I, I64, I, P, P],
+        "vs_patchify_s": [P, I, I, I, I64, I, I, P, P],
+        "vs_unpatch_s": [P, I, I, I, I64, I, I, P, P],
         "vs_col2im3x3_reflect": [P, I, I, I, I64, P, P],
         "vs_colmean": [P, I, I, I64, P, P],
         "vs_pool_gelu_bwd": [P, I64, P, I64, I, I, I, P, I64, P],

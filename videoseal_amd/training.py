@@ -44,8 +44,6 @@ class DetectorStep:
     def __init__(self, model):
         if model.embedder.cfg.extractor == "sam":
             raise N.NativeError("DetectorStep covers the ConvNeXt-V2 extractor of the released 1.0 / PixelSeal / ChunkySeal cards")
-        if model.embedder.cfg.stem_stride != 4:
-            raise N.NativeError("DetectorStep needs the non-overlapping 4x4 stride-4 stem (VideoSeal 1.0 / PixelSeal)")
         self.model = model
         self._ones: Dict[int, torch.Tensor] = {}
 
@@ -115,9 +113,10 @@ class DetectorStep:
         d, B = c.dims, x.B
         xld = eng._xld
         S = {"x": x, "stages": []}
-        Ho, Wo = x.H // 4, x.W // 4
+        ss = c.stem_stride                      # 4 (VideoSeal 1.0 / PixelSeal) or 2 (ChunkySeal: overlapping 4 x 4 patches, convnext.py:109)
+        Ho, Wo = (x.H - 4) // ss + 1, (x.W - 4) // ss + 1
         t = self._act(eng, "stem.c", B, Ho, Wo, d[0])
-        eng.conv(x, X["stem"], t, geom=(Wo, 16, 16, 4, 1, 0, 0))
+        eng.conv(x, X["stem"], t, geom=(Wo, ss * 4, 16, ss, 1, 0, 0))
         cur = self._act(eng, "st0.in", B, Ho, Wo, d[0], xld(d[0]))
         eng.layernorm(t, X["stem_ln"][0], X["stem_ln"][1], cur)
         S["stem_pre"] = t
@@ -280,7 +279,7 @@ class DetectorStep:
         G[p + ".1.weight"], G[p + ".1.bias"] = dw, db
         if want_params:
             patches = Act(eng.buf("tr.stem.patches", dt.rows * 64, zero=True), x.B, dt.H, dt.W, 64, 64)
-            N.check(L.vs_patchify(N.ptr(x.t), x.B, x.H, x.W, 4, 4, N.ptr(patches.t), st), "vs_patchify")
+            N.check(L.vs_patchify_s(N.ptr(x.t), x.B, x.H, x.W, 4, 4, c.stem_stride, N.ptr(patches.t), st), "vs_patchify_s")
             dws = self._wgrad(eng, dt, d[0], patches, 64)
             G[p + ".0.weight"] = dws.view(d[0], 4, 4, 4)[..., :3].permute(0, 3, 1, 2).contiguous()
         G[p + ".0.bias"] = self._colsum(eng, dt, d[0])
@@ -291,7 +290,7 @@ class DetectorStep:
         dcols = Act(eng.buf("tr.stem.dcols", dt.rows * 64, zero=True), x.B, dt.H, dt.W, 64, 64)
         eng.conv(dt, self._tw(X["stem"].wt, dt.ld), dcols, arith=BWD_ARITH)
         drgb = eng.buf("tr.stem.drgb", x.rows * 4, zero=True)
-        N.check(L.vs_unpatch(N.ptr(dcols.t), x.B, x.H, x.W, 4, 4, N.ptr(drgb), st), "vs_unpatch")
+        N.check(L.vs_unpatch_s(N.ptr(dcols.t), x.B, x.H, x.W, 4, 4, c.stem_stride, N.ptr(drgb), st), "vs_unpatch_s")
         dimg = torch.empty(x.B, 3, x.H, x.W, device=eng.dev, dtype=torch.float32)
         N.check(L.vs_nhwc_to_nchw_scaled(N.ptr(drgb), x.B, x.H, x.W, 3, 4, 2.0, N.ptr(dimg), st), "vs_nhwc_to_nchw_scaled")
         return G, dimg
