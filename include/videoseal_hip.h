@@ -262,6 +262,17 @@ int vs_outc_tanh_bwd(const float* delta, const float* ddelta, int64_t rows_per_f
  * synchronously on the first call with new weights and asynchronously afterwards). */
 int vs_check_finite(const float* x, int64_t n, int* flag, void* stream);
 
+/* ---- ConvNeXt-V2 block body pwconv1 -> GELU -> GRN -> pwconv2 + residual with the 4C-wide tensor kept on chip (csrc/convnext_fused.hip;
+ * convnext.py:47-56, common.py:158-169), C = 96 / 192 (stages 0 / 1 of the VideoSeal extractor), 2 x f16 arithmetic.  Two launches per block:
+ * stats = 1 writes the GRN partial sums [rows / 32][4C] (finished by vs_grn_scale_from_partials), stats = 0 recomputes pwconv1 + GELU, applies
+ * scale [B][scale_ld] / beta and runs pwconv2 (+ bias2 + res -> out; out may alias res).  tn_planes: the f16 operand planes of the LayerNorm output
+ * (vs_dwconv7_ln_planes); wimg: vs_cnx_block_image_bytes(C) bytes packed by the host (engine.pack_cnx_block: per 32 h-channels the W1 rows, the
+ * W2 columns in the k order the accumulator layout dictates, bias1 / beta). */
+int vs_cnx_block_supported(int C, int64_t rows, int HW);
+int64_t vs_cnx_block_image_bytes(int C);
+int vs_cnx_block(const void* tn_planes, const void* wimg, int C, int64_t rows, int HW, int stats, float acc_mul1, float acc_mul2, const float* scale,
+                 int64_t scale_ld, const float* bias2, const float* res, int64_t res_ld, float* out, int64_t out_ld, float* part32, void* stream);
+
 /* ---- weight operand packing on the device (csrc/pack.hip): packed fp32 weights [N][K] (k = (tap, channel) with K / ntaps a multiple of 16) ->
  * the 16-bit planes [P][N][K] and their LDS-image order [ceil(N/32)][K/16][P][64][8] the split kernels read (P = 3 bf16 truncation terms for
  * arith 3; P = 2 f16 terms of w * w_mul for arith 2).  One launch per layer instead of a dozen ATen ops. */

@@ -551,3 +551,34 @@ def test_vs10_768_vs_oracle(vs10):
         p, pr = model.detect(got.cuda(), is_video=True)["preds"].cpu(), R.detect(sd, spec, ref)["preds"]
         assert (p - pr).abs().max().item() < TOL_LOGIT
         assert ((p > 0) == (pr > 0))[pr.abs() > 1e-4].all()
+
+
+def test_fused_convnext_blocks_match_the_unfused_path_and_the_oracle(vs10):
+    """stage 0 / 1 blocks of the extractor with h kept on chip (csrc/convnext_fused.hip: transposed pwconv1 whose accumulator layout is pwconv2's
+    A operand, GRN by a statistics pass) against the per-layer GEMM path and the CPU oracle"""
+    spec, sd, model = vs10
+    imgs = synthetic_frames(3, 256, 256, seed=77)
+    eng = model._engine()
+    if eng.arith_net["X"] != 2 or not eng.fused_blocks:
+        pytest.skip("2 x f16 arithmetic with fused blocks only")
+    calls = []
+    orig = eng.lib.vs_cnx_block
+
+    class Spy:
+        def __call__(self, *a):
+            calls.append(a[5])
+            return orig(*a)
+    try:
+        eng.lib.vs_cnx_block = Spy()
+        p1 = model.detect(imgs.cuda(), is_video=False)["preds"].cpu()
+    finally:
+        eng.lib.vs_cnx_block = orig
+    assert calls.count(1) == 6 and calls.count(0) == 6, "six blocks (stages 0 and 1), one statistics and one apply launch each"
+    eng.fused_blocks = False
+    try:
+        p0 = model.detect(imgs.cuda(), is_video=False)["preds"].cpu()
+    finally:
+        eng.fused_blocks = True
+    ref = R.detect(sd, spec, imgs)["preds"]
+    assert (p1 - p0).abs().max() < 2e-5, float((p1 - p0).abs().max())
+    assert (p1 - ref).abs().max() < 1e-4 and (p0 - ref).abs().max() < 1e-4

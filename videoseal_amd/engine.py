@@ -174,6 +174,34 @@ def pack_patch_conv(w: torch.Tensor, pix_ld: int) -> Tuple[torch.Tensor, int]:
     return out.reshape(n, kh * cinp).contiguous(), cinp
 
 
+def pack_cnx_block(w1: torch.Tensor, b1: torch.Tensor, w2: torch.Tensor, beta: torch.Tensor, device) -> Tuple[torch.Tensor, float, float]:
+    """Weight image of csrc/convnext_fused.hip for one ConvNeXt block: w1 [4C][C] (pwconv1), w2 [C][4C] (pwconv2), b1 / beta [4C].
+    Per block of 32 h-channels: W1 rows as MFMA A fragments [k-step][plane][half][row 32][8], W2 as B fragments
+    [n-block][k-step s][plane][half][n 32][8] with the reduction index enumerated as k(s, half, v) = 8 (2s + v // 4) + 4 half + v % 4 (the order in
+    which the transposed pwconv1 leaves h in the accumulator registers), then b1[32], beta[32].  2 x f16 split (round to nearest even, on the CPU
+    like the reference of pack.hip), per-matrix power-of-two scales.  Returns (uint8 image on `device`, w_mul1, w_mul2)."""
+    w1, w2 = w1.float().cpu(), w2.float().cpu()
+    C = w1.shape[1]
+    H4 = w1.shape[0]
+    nhb, ks1, nb = H4 // 32, C // 16, C // 32
+    m1, m2 = f16x2_scale(w1), f16x2_scale(w2)
+
+    def split(w, mul):
+        ws = w * mul
+        hi = ws.to(torch.float16)
+        lo = (ws - hi.float()).to(torch.float16)
+        return torch.stack([hi, lo], 0)                                   # [plane][...]
+    s1 = split(w1, m1).view(2, nhb, 32, ks1, 2, 8)                        # (plane, hb, m, ks, half, v)
+    img1 = s1.permute(1, 3, 0, 4, 2, 5).contiguous()                      # (hb, ks, plane, half, m, v)
+    s2 = split(w2, m2).view(2, nb, 32, nhb, 2, 2, 2, 4)                   # (plane, nb, n, hb, s, vh, half, e): channel = 32 hb + 8 (2s + vh) + 4 half + e
+    img2 = s2.permute(3, 1, 4, 0, 6, 2, 5, 7).contiguous()                # (hb, nb, s, plane, half, n, vh, e)
+    aux = torch.zeros(nhb, 256, dtype=torch.float32)
+    aux[:, :32] = b1.float().cpu().view(nhb, 32)
+    aux[:, 32:64] = beta.float().cpu()[:H4].view(nhb, 32)
+    img = torch.cat([img1.view(nhb, -1).view(torch.uint8), img2.view(nhb, -1).view(torch.uint8), aux.view(torch.uint8)], dim=1)
+    return img.contiguous().to(device), m1, m2
+
+
 def padvec(v: torch.Tensor, n: int) -> torch.Tensor:
     out = torch.zeros(n, device=v.device, dtype=torch.float32)
     out[: v.numel()] = v.float().reshape(-1)
@@ -219,6 +247,7 @@ class HipEngine:
         self.msg_table_conv = os.environ.get("VIDEOSEAL_MSG_TABLE", "1") != "0"         # first bottleneck block: message channels as a table
         self.planes_chain = os.environ.get("VIDEOSEAL_PLANES", "1") != "0"              # bottleneck chain on pre-split operand planes
         self.planes_gemm = os.environ.get("VIDEOSEAL_PLANES", "1") != "0"               # ConvNeXt 1x1 GEMMs on operand planes
+        self.fused_blocks = os.environ.get("VIDEOSEAL_CNX_FUSED", "1") != "0"           # stage 0 / 1 blocks with h kept on chip (convnext_fused.hip)
         # VIDEOSEAL_CHECK_FINITE=1: synchronise after every network pass and raise if the output is not finite -- the 2 x f16 arithmetic
         # turns an activation beyond its f16 range (|a| * a_mul >= 65520) into inf / NaN instead of a silently wrong number
         self.check_finite = os.environ.get("VIDEOSEAL_CHECK_FINITE", "0") == "1"
@@ -377,7 +406,10 @@ class HipEngine:
                 wdw[:, :Cc] = g(p + ".dwconv.weight").float().reshape(Cc, 49).t()
                 w1, cp1 = pack_conv(g(p + ".pwconv1.weight").float()[:, :, None, None], ld)
                 w2, cp2 = pack_conv(g(p + ".pwconv2.weight").float()[:, :, None, None], ld4)
-                blocks.append(dict(wdw=wdw.contiguous(), bdw=padvec(g(p + ".dwconv.bias"), ld), lnw=padvec(g(p + ".norm.weight"), ld),
+                fuse = None
+                if st < 2 and Cc in (96, 192) and self.use_split and self.fused_blocks:
+                    fuse = pack_cnx_block(g(p + ".pwconv1.weight"), g(p + ".pwconv1.bias"), g(p + ".pwconv2.weight"), g(p + ".grn.beta").reshape(-1), self.dev)
+                blocks.append(dict(fuse=fuse, wdw=wdw.contiguous(), bdw=padvec(g(p + ".dwconv.bias"), ld), lnw=padvec(g(p + ".norm.weight"), ld),
                                    lnb=padvec(g(p + ".norm.bias"), ld),
                                    pw1=ConvW(w1, g(p + ".pwconv1.bias").float().contiguous(), 4 * Cc, 1, 1, cp1),
                                    gamma=g(p + ".grn.gamma").float().reshape(-1).contiguous(), beta=padvec(g(p + ".grn.beta"), rup(ld4, 16)),
@@ -952,7 +984,24 @@ class HipEngine:
             tnpl = self.buf(f"st{sti}.npl", cur.rows * pw1w.CinP).view(torch.int16) if pl1 else None
             hpl = self.buf(f"st{sti}.hpl", cur.rows * hh.ld).view(torch.int16) if pl2 else None
             ptile = N.CONV_TILE_HI | 8
+            fused = (self.fused_blocks and self.arith == 2 and X["stages"][sti] and X["stages"][sti][0].get("fuse") is not None
+                     and pw1w.CinP == Cc and bool(L.vs_cnx_block_supported(Cc, cur.rows, HW)))
+            if fused and tnpl is None:
+                tnpl = self.buf(f"st{sti}.npl", cur.rows * pw1w.CinP).view(torch.int16)
             for blk in X["stages"][sti]:
+                if fused:          # pwconv1 -> GELU -> GRN -> pwconv2 with h on chip: statistics pass, scale, apply pass (in place on cur)
+                    img, m1, m2 = blk["fuse"]
+                    N.check(L.vs_dwconv7_ln_planes(N.ptr(cur.t), B, cur.H, cur.W, Cc, cur.ld, N.ptr(blk["wdw"]), N.ptr(blk["bdw"]), N.ptr(blk["lnw"]),
+                                                   N.ptr(blk["lnb"]), 1e-6, A_MUL, pw1w.CinP, N.ptr(tnpl), st), "vs_dwconv7_ln_planes")
+                    part32 = self.buf(f"st{sti}.gp32", B * (HW // 32) * 4 * Cc)
+                    am1, am2 = 1.0 / (A_MUL * m1), 1.0 / (A_MUL_GRN * m2)
+                    N.check(L.vs_cnx_block(N.ptr(tnpl), N.ptr(img), Cc, cur.rows, HW, 1, am1, am2, None, 0, None, None, 0, None, 0, N.ptr(part32), st),
+                            "vs_cnx_block(stats)")
+                    N.check(L.vs_grn_scale_from_partials(N.ptr(part32), B, HW, 4 * Cc, N.ptr(blk["gamma"]), N.ptr(scale), hh.ld, st),
+                            "vs_grn_scale_from_partials")
+                    N.check(L.vs_cnx_block(N.ptr(tnpl), N.ptr(img), Cc, cur.rows, HW, 0, am1, am2, N.ptr(scale), hh.ld, N.ptr(blk["pw2"].bias),
+                                           N.ptr(cur.t), cur.ld, N.ptr(cur.t), cur.ld, None, st), "vs_cnx_block(apply)")
+                    continue
                 if pl1:
                     N.check(L.vs_dwconv7_ln_planes(N.ptr(cur.t), B, cur.H, cur.W, Cc, cur.ld, N.ptr(blk["wdw"]), N.ptr(blk["bdw"]), N.ptr(blk["lnw"]),
                                                    N.ptr(blk["lnb"]), 1e-6, A_MUL, pw1w.CinP, N.ptr(tnpl), st), "vs_dwconv7_ln_planes")

@@ -34,7 +34,7 @@ EXPORTS = [
     "vs_msg_table_grad", "vs_outc_tanh_bwd", "vs_relu_bwd",
     "vs_resize_nchw_bwd", "vs_embed_tail_bwd", "vs_tail_key_reduce", "vs_aug_crop_flip_bwd", "vs_mask_mul", "vs_aug_color_bwd_scratch_floats",
     "vs_aug_color_bwd", "vs_clamp01_bwd", "vs_nhwc_to_nchw_scaled", "vs_percep_partial_doubles", "vs_percep_mse", "vs_percep_mse_grad",
-    "vs_split_block", "vs_check_finite",
+    "vs_split_block", "vs_check_finite", "vs_cnx_block_supported", "vs_cnx_block_image_bytes", "vs_cnx_block",
 ]
 
 
@@ -171,6 +171,8 @@ def lib() -> C.CDLL:
         "vs_percep_mse_grad": [P, P, I, I, I, I, F, P, P],
         "vs_split_block": [P, I, I64, I, I, F, P, P, P],
         "vs_check_finite": [P, I64, P, P],
+        "vs_cnx_block": [P, P, I, I64, I, I, F, F, P, I64, P, P, I64, P, I64, P, P],
+        "vs_cnx_block_supported": [I, I64, I],
     }
     for name, args in sig.items():
         fn = getattr(L, name)
@@ -185,6 +187,8 @@ def lib() -> C.CDLL:
     for name in ("vs_aug_color_bwd_scratch_floats", "vs_percep_partial_doubles"):
         getattr(L, name).restype = C.c_int64
         getattr(L, name).argtypes = [I, I, I]
+    L.vs_cnx_block_image_bytes.restype = C.c_int64
+    L.vs_cnx_block_image_bytes.argtypes = [I]
     L.vs_bn_partial_doubles.restype = C.c_int64
     L.vs_bn_partial_doubles.argtypes = [I64, I64]
     for name, args in (("vs_gemm_wgrad_partial_floats", [I64, I, I]), ("vs_dwconv7_wgrad_partial_floats", [I, I, I64]),
