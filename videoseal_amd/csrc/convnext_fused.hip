@@ -29,6 +29,27 @@ __device__ __forceinline__ void dma16(const char* gp, unsigned char* lds_base) {
                                    16, 0, 0);
 }
 
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+// vs_gelu on two values at once: the polynomial and the blends as 2-wide fp32 operations (v_pk_fma_f32 / v_pk_mul_f32: two results per VALU slot),
+// only the exp2 stays scalar.  Same coefficients and operation order as vs_gelu / vs_erfc_sqrt2 -> the same values.
+__device__ __forceinline__ f32x2 gelu2(const f32x2 v) {
+  const f32x2 a = {fabsf(v[0]), fabsf(v[1])};
+  const f32x2 u = {fminf(a[0], 5.65685424949238f), fminf(a[1], 5.65685424949238f)};
+  f32x2 q = {5.128553084e-07f, 5.128553084e-07f};
+  q = q * u + f32x2{-9.560153558e-06f, -9.560153558e-06f};
+  q = q * u + f32x2{7.497344632e-05f, 7.497344632e-05f};
+  q = q * u + f32x2{-2.843466646e-04f, -2.843466646e-04f};
+  q = q * u + f32x2{1.498938855e-05f, 1.498938855e-05f};
+  q = q * u + f32x2{6.931120995e-03f, 6.931120995e-03f};
+  q = q * u + f32x2{-5.243476480e-02f, -5.243476480e-02f};
+  q = q * u + f32x2{-4.592214525e-01f, -4.592214525e-01f};
+  q = q * u + f32x2{-1.151104212e+00f, -1.151104212e+00f};
+  const f32x2 t = q * u;
+  const f32x2 e = {__builtin_amdgcn_exp2f(t[0]), __builtin_amdgcn_exp2f(t[1])};
+  const f32x2 m = {fmaxf(v[0], 0.f), fmaxf(v[1], 0.f)};
+  return m - (a * 0.5f) * e;
+}
+
 struct CnxArgs {
   const char* tn_pl;          // [2][C/16][rows][16] f16: LayerNorm output * a_mul1 (vs_dwconv7_ln_planes)
   const char* wimg;           // per 32-channel block of h: [W1: KS1 x 2 planes x 1 KiB][W2: NB x 2 steps x 2 planes x 1 KiB][aux 1 KiB: b1[32], beta[32]]
@@ -147,12 +168,13 @@ __global__ __launch_bounds__(256) void cnx_block_kernel(const CnxArgs a) {
       const float b1c = aux[r32];                               // this lane's channel hb * 32 + r32
 #pragma unroll
       for (int pb = 0; pb < PB; ++pb) {
-        float sq = 0.f;
+        f32x2 sq2 = {0.f, 0.f};
 #pragma unroll
-        for (int e = 0; e < 16; ++e) {
-          const float h = vs_gelu(acc1[pb][e] * a.acc_mul1 + b1c);
-          sq = __builtin_fmaf(h, h, sq);
+        for (int e = 0; e < 16; e += 2) {
+          const f32x2 h = gelu2(f32x2{acc1[pb][e], acc1[pb][e + 1]} * a.acc_mul1 + f32x2{b1c, b1c});
+          sq2 = h * h + sq2;
         }
+        float sq = sq2[0] + sq2[1];
         sq += __shfl_xor(sq, 32);                               // the other half-wave holds the other 16 pixels of the group
         if (hf == 0) a.part32[((p0 >> 5) + pb) * (int64_t)(4 * C) + hb * 32 + r32] = sq;
       }
@@ -165,13 +187,15 @@ __global__ __launch_bounds__(256) void cnx_block_kernel(const CnxArgs a) {
         for (int s = 0; s < 2; ++s) {
           f16x8 hi, lo;
 #pragma unroll
-          for (int v = 0; v < 8; ++v) {
+          for (int v = 0; v < 8; v += 2) {
             const int e = 8 * s + v;
-            const float x1 = acc1[pb][e] * a.acc_mul1 + b1[e >> 2][e & 3];
-            const float h = (a.abl & 1) ? x1 : vs_gelu(x1);
-            const float h3 = h * sc[e >> 2][e & 3] + be[e >> 2][e & 3];          // same expression as the unfused A transform (a_mul = 1)
-            hi[v] = (_Float16)h3;
-            lo[v] = (_Float16)(h3 - (float)hi[v]);
+            const f32x2 x1 = f32x2{acc1[pb][e], acc1[pb][e + 1]} * a.acc_mul1 + f32x2{b1[e >> 2][e & 3], b1[e >> 2][(e & 3) + 1]};
+            const f32x2 h = (a.abl & 1) ? x1 : gelu2(x1);
+            const f32x2 h3 = h * f32x2{sc[e >> 2][e & 3], sc[e >> 2][(e & 3) + 1]} + f32x2{be[e >> 2][e & 3], be[e >> 2][(e & 3) + 1]};   // the unfused A transform (a_mul = 1)
+            hi[v] = (_Float16)h3[0];
+            hi[v + 1] = (_Float16)h3[1];
+            lo[v] = (_Float16)(h3[0] - (float)hi[v]);
+            lo[v + 1] = (_Float16)(h3[1] - (float)hi[v + 1]);
           }
           ahi[pb][s] = __builtin_bit_cast(bf16x8, hi);
           alo[pb][s] = __builtin_bit_cast(bf16x8, lo);
