@@ -70,8 +70,9 @@ __global__ __launch_bounds__(256) void cnx_block_kernel(const CnxArgs a) {
   constexpr int C = KS1 * 16, NB = C / 32, NHB = 4 * C / 32;
   constexpr int W1_KB = KS1 * 2, W2_KB = NB * 4;
   constexpr int BLK_KB = W1_KB + W2_KB + 1;                 // KiB per h-block image
-  constexpr int LD_KB = STATS ? W1_KB + 1 : BLK_KB;         // what a launch needs of it (STATS: W1 + aux, stored first and last -> two ranges)
-  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * BLK_KB * 1024];
+  constexpr int NST = 3;                                    // weight stages: block hb + 2 is in flight while block hb is multiplied (an L2 round trip is
+                                                            // about as long as one block's arithmetic: with two stages every iteration waited for its DMA)
+  __shared__ __attribute__((aligned(16))) unsigned char smem[NST * BLK_KB * 1024];
   __shared__ __attribute__((aligned(16))) float s_scale[STATS ? 4 : 4 * C];      // GRN scale of the workgroup's frame (its 128 * PB pixels lie in one frame)
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -112,17 +113,28 @@ __global__ __launch_bounds__(256) void cnx_block_kernel(const CnxArgs a) {
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc2[pb][nb][e] = 0.f;
   }
-  dma_block(0, 0);
   if constexpr (!STATS) {
     for (int i = threadIdx.x; i < 4 * C; i += 256) s_scale[i] = a.scale[(int64_t)frame * a.scale_ld + i];
   }
-  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+  dma_block(0, 0);
+  dma_block(1, 1);
+  // DMA instructions this wave issues per block (chunks wave, wave + 4, ...): the counted wait below leaves exactly one block in flight
+  constexpr int NCH = STATS ? W1_KB + 1 : BLK_KB;           // chunks a launch moves per block (W1 is a multiple of 4 chunks, then W2, then aux)
+  const int my_dmas = STATS ? (W1_KB / 4 + ((W1_KB + W2_KB) % 4 == wave ? 1 : 0)) : (BLK_KB - wave + 3) / 4;
+  auto wait_older = [&]() __attribute__((always_inline)) {  // everything but the youngest block's DMAs has landed
+    if (my_dmas == NCH / 4 + 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NCH / 4 + 1) : "memory");
+    else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NCH / 4) : "memory");
+  };
+  wait_older();
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
 
+  int stage = 0;
   for (int hb = 0; hb < NHB; ++hb) {
-    const int stage = hb & 1;
-    if (hb + 1 < NHB) dma_block(hb + 1, stage ^ 1);          // the other stage was last read before the barrier that ended iteration hb - 1
+    const int st2 = stage + 2 >= NST ? stage + 2 - NST : stage + 2;
+    if (hb + 2 < NHB) dma_block(hb + 2, st2);                // stage st2 held block hb - 1: last read before the barrier that ended iteration hb - 1
     const unsigned char* Wb = smem + stage * (BLK_KB * 1024);
+    stage = stage + 1 == NST ? 0 : stage + 1;
     // GRN scale of this block's 32 channels for the wave's frame: channels 8q + 4 hf + (0..3)
     f32x4 sc[4];
     if constexpr (!STATS) {
@@ -217,7 +229,8 @@ __global__ __launch_bounds__(256) void cnx_block_kernel(const CnxArgs a) {
           }
         }
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // the next block's image has landed
+    if (hb + 2 < NHB) wait_older();                           // block hb + 1 has landed (block hb + 2 may still be in flight)
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_waitcnt(0xC07F);                       // this wave's LDS reads have returned
     __builtin_amdgcn_s_barrier();
   }
@@ -227,7 +240,7 @@ __global__ __launch_bounds__(256) void cnx_block_kernel(const CnxArgs a) {
     // stages are free now) so that the block's 32 pixels x C channels leave as whole rows: with out_ld == C that is 32 * C * 4 contiguous bytes,
     // 16 bytes per lane -- the direct form (one 128-byte piece per store instruction, 16 * NB * PB instructions) cost 53 of 183 us.
     float* T = reinterpret_cast<float*>(smem) + wave * (32 * (C + 4));          // [32 pixels][C + 4] floats per wave (pad: bank spread)
-    static_assert(4 * 32 * (C + 4) * 4 <= 2 * BLK_KB * 1024, "transpose tile must fit the weight stages");
+    static_assert(4 * 32 * (C + 4) * 4 <= NST * BLK_KB * 1024, "transpose tile must fit the weight stages");
 #pragma unroll
     for (int pb = 0; pb < PB; ++pb) {
 #pragma unroll
