@@ -247,6 +247,35 @@ def test_bottleneck_planes_chain_is_bit_identical(vs10):
     assert (a[:2].cpu() - ref).abs().max() < TOL_IMG
 
 
+@pytest.mark.parametrize("nkey", [4, 8, 3])
+def test_bottleneck_planes_chain_with_k_slices_for_few_key_frames(vs10, nkey):
+    """4 - 8 key frames (a 16- / 32-frame video call) give the planes kernel 32 - 64 output tiles: the chain then runs with K slices (raw partial
+    sums per slice, summed in slice order by the split-K epilogue, which also writes the next conv's operand planes) -- deterministic, and equal to
+    the per-conv path up to the summation order"""
+    spec, sd, model = vs10
+    imgs = synthetic_frames(nkey, 256, 256, seed=43).cuda()
+    msgs = synthetic_msgs(nkey, spec.nbits, seed=43)
+    eng = model._engine()
+    if eng.arith_net["E"] != 2 or not eng.planes_splitk:
+        pytest.skip("2 x f16 arithmetic only")
+    used = []
+    orig = eng.bottleneck_planes
+    eng.bottleneck_planes = lambda *a, **k: (used.append(eng._planes_split(a[0])), orig(*a, **k))[1]
+    try:
+        a = model.embed(imgs, msgs, is_video=False)["imgs_w"].clone()
+        a2 = model.embed(imgs, msgs, is_video=False)["imgs_w"].clone()
+        assert used and used[0] > 1, "the planes chain did not run with K slices"
+        eng.planes_chain = False
+        b = model.embed(imgs, msgs, is_video=False)["imgs_w"].clone()
+    finally:
+        eng.planes_chain = True
+        eng.bottleneck_planes = orig
+    assert torch.equal(a, a2)
+    assert (a - b).abs().max() < 2e-6
+    ref = R.embed_image(sd, spec, imgs.cpu(), msgs)["imgs_w"]
+    assert (a.cpu() - ref).abs().max() < TOL_IMG
+
+
 def test_submodules_match_golden(vs10):
     """model.embedder(y, msgs) / model.detector(x) / model.attenuation.heatmaps(x) (SURVEY 8(b) method surface)."""
     spec, sd, model = vs10

@@ -105,6 +105,47 @@ def test_conv3x3_planes_kernel(cfg):
     assert torch.equal(outs[0], outs[2]) and torch.equal(outs[1], outs[2])
 
 
+@pytest.mark.parametrize("cfg", [(2, 96, 16, 16, 192, True, 2), (2, 96, 16, 16, 192, True, 3), (1, 384, 32, 32, 384, True, 6), (1, 384, 16, 32, 384, False, 8),
+                                 (2, 64, 16, 16, 64, True, 2)])
+def test_conv3x3_planes_kernel_with_k_slices(cfg):
+    """the planes kernel with K slices (few output tiles): partial sums per slice + split-K epilogue (bias, ReLU, the 1x1 phase as its own
+    slice, fp32 and / or planes output) against the unsplit launch (same values up to the summation order) and torch; deterministic"""
+    B, C, H, W, Co, two, sk = cfg
+    eng = Eng(arith=2)
+    g = torch.Generator().manual_seed(31)
+    x = torch.randn(B, C, H, W, generator=g)
+    x2 = torch.randn(B, C, H, W, generator=g)
+    w1 = torch.randn(Co, C, 3, 3, generator=g) / math.sqrt(C * 9)
+    b1 = torch.randn(Co, generator=g)
+    w2 = torch.randn(Co, C, 1, 1, generator=g) / math.sqrt(C)
+    b2 = torch.randn(Co, generator=g)
+    ref = F.relu(F.conv2d(x, w1, b1, padding=1))
+    if two:
+        ref = ref + F.conv2d(x2, w2, b2)
+    xa, xa2 = to_nhwc(x), to_nhwc(x2)
+    wt1, cp1 = pack_conv(w1.to(DEV), xa.ld)
+    wt2, cp2 = pack_conv(w2.to(DEV), xa2.ld)
+    cw1, cw2 = ConvW(wt1, b1.to(DEV), Co, 3, 3, cp1), ConvW(wt2, b2.to(DEV), Co, 1, 1, cp2)
+    xpl, x2pl = eng.to_planes(xa, "t.xpl"), eng.to_planes(xa2, "t.x2pl")
+    tile = N.CONV_TILE_HI | 6
+    outs, pls = [], []
+    for k in (1, sk, sk):
+        out = eng.new_act(f"t.sk{len(outs)}", B, H, W, Co)
+        out.t.fill_(3.0)
+        opl = eng.buf(f"t.skpl{len(outs)}", B * H * W * Co).view(torch.int16)
+        kw = dict(in2=xa2, w2=cw2, in2_pl=x2pl) if two else {}
+        eng.conv(xa, cw1, out, pad=1, act=N.ACT_RELU, tile_hint=tile, arith=2, in_pl=xpl, out_pl=opl, split_k=k, **kw)
+        torch.cuda.synchronize()
+        assert torch.isfinite(out.t).all()
+        assert rel_err(from_nhwc(out), ref) < 2e-5
+        outs.append(out.t.clone())
+        pls.append(opl.clone())
+    assert torch.equal(outs[1], outs[2]) and torch.equal(pls[1], pls[2])
+    assert (outs[0] - outs[1]).abs().max() < 1e-5
+    want = eng.to_planes(Act(outs[1], B, H, W, Co, rup(Co, 4)), "t.wpl")
+    assert torch.equal(pls[1][: want.numel()], want)
+
+
 @pytest.mark.parametrize("cx", [16, 1])
 def test_conv3x3_small_two_phase(eng, cx):
     """thin-layer kernel with the fused 1x1 res_conv (unet.py:38-39) + residual at a channel offset; bit-identical to the patch kernel."""

@@ -22,6 +22,8 @@
 
 #include "conv_common.h"
 
+int vs_splitk_epilogue(const vs_conv_desc_t& d, int M, hipStream_t st);   // gemm1x1_pc.hip
+
 namespace {
 
 using namespace vsconv;
@@ -44,7 +46,7 @@ __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" :
 
 template <int TN>
 __global__ __launch_bounds__(512, 2) void conv3x3_pl_kernel(const vs_conv_desc_t d, const int tiles_x, const int tiles_y, const int mtiles,
-                                                            const int ntiles) {
+                                                            const int ntiles, const int cps) {
   using AR = Arith<2>;
   constexpr int TM = 2;
   constexpr int BN = 2 * TN * 32;
@@ -60,16 +62,24 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pl_kernel(const vs_conv_desc_t
   const int r = lane & 31, g = lane >> 5;
 
   const int bm = blockIdx.x % mtiles;
-  const int bn = blockIdx.x / mtiles;
+  const int bn = (blockIdx.x / mtiles) % ntiles;
+  const int ks = blockIdx.x / (mtiles * ntiles);          // K slice (split_k > 1), see below
   const int n0 = bn * BN;
   const int tx = bm % tiles_x;
   const int ty = (bm / tiles_x) % tiles_y;
   const int fb = bm / (tiles_x * tiles_y);
   const int y0 = ty * PT, x0 = tx * PT;
 
-  const int spt = d.CinP / BK;
+  // split_k > 1 (few output tiles: the 4 - 8 key frames of a video / streaming call give 32 - 64 tiles for 256 CUs): slice ks < split_k
+  // accumulates the 16-channel chunks [ks * cps, (ks + 1) * cps) of phase 1, one extra slice (ks == split_k) the 1x1 second phase; all of them
+  // store raw partial sums, splitk_epilogue_kernel adds them in slice order and applies bias / activation / the plane split (deterministic).
+  const int spt_all = d.CinP / BK;
+  const int sk = d.split_k > 1 ? d.split_k : 1;
+  const bool p2_slice = sk > 1 && ks == sk;
+  const int c_off = (sk > 1 && !p2_slice) ? ks * cps : 0;
+  const int spt = p2_slice ? 0 : (sk > 1 ? min(cps, spt_all - c_off) : spt_all);
   const int n1 = 9 * spt;
-  const int n2 = d.in2_pl ? d.Cin2P / BK : 0;
+  const int n2 = (d.in2_pl && (sk == 1 || p2_slice)) ? d.Cin2P / BK : 0;
   const int64_t Mpix = (int64_t)d.B * d.H * d.W;
   const int abl = d.tile_hint >> 8;           // ablation (tools/bench_ppc.py): 32 no output stores
 
@@ -106,11 +116,11 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pl_kernel(const vs_conv_desc_t
       doff[jj] = (unsigned)(gs * nst) * WBLK + p * 1024 + lane * 16;
     }
   };
-  const char* wbase = reinterpret_cast<const char*>(d.wt_blk);  // + WBLK per issued tile
+  const char* wbase = reinterpret_cast<const char*>(d.wt_blk) + (int64_t)c_off * 9 * WBLK;  // + WBLK per issued tile
   if (wave < 4) {
-    weight_off(n1);
+    weight_off(9 * spt_all);
   } else {
-    const unsigned pstride = (unsigned)(spt * cstride);         // bytes between the two planes (< 4 GiB: checked by the launcher)
+    const unsigned pstride = (unsigned)(spt_all * cstride);     // bytes between the two planes (< 4 GiB: checked by the launcher)
 #pragma unroll
     for (int j = 0; j < 6; ++j) {             // unit U = 64k + lane of [plane][648 units]: pixel q of the patch, half hs
       const int U = (pw + 4 * j) * 64 + lane;
@@ -147,7 +157,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pl_kernel(const vs_conv_desc_t
   const char* const inpl = reinterpret_cast<const char*>(d.in_pl);
   auto dma_patch2 = [&](const int cc, const int j0) __attribute__((always_inline)) {
     unsigned char* pb = smem + (cc & 1) * P_BYTES + pw * 1024;
-    const char* cbase = inpl + cc * cstride;
+    const char* cbase = inpl + (c_off + cc) * cstride;
 #pragma unroll
     for (int jj = 0; jj < 2; ++jj) {
       const int j = j0 + jj;                  // compile-time after inlining
@@ -332,6 +342,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pl_kernel(const vs_conv_desc_t
     tapstep(parc, std::integral_constant<int, 8>{}, cc, last);
   };
 
+  if (spt > 0) {
   // ---- prologue: weight tiles 0 .. NRING-2, patch of chunk 0
   if (wave < 4) {
     dma_w(std::integral_constant<int, 0>{});                 // (n1 >= 9 > NRING - 1)
@@ -355,6 +366,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pl_kernel(const vs_conv_desc_t
     chunk(P0{}, cc);
     if (cc + 1 < spt) chunk(P1{}, cc + 1);
   }
+  }          // (spt > 0: the phase-2 slice of a split launch has no first phase)
   // ---- epilogue state.  Operands are swapped in the MFMA (weights first): element e of acc[i][j] is
   //   channel cbase[j] + (e & 3) + 8 * (e >> 2)   (cbase contains the half-wave's 4 * g),  pixel p0[i]
   // (everything below is re-derived from an opaque copy of the lane id: values shared with the K loop's address set-up would otherwise be
@@ -392,7 +404,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pl_kernel(const vs_conv_desc_t
     pcls[i] = (y == 0 ? 0 : (y >= d.H - 1 ? 2 : 1)) * 3 + (x == 0 ? 0 : (x >= d.W - 1 ? 2 : 1));
   }
   scale_all<TM, TN>(acc, d.acc_mul);          // back to real units (exact: a power of two)
-  {   // v = act(acc (+ border-class table) + bias1) (+ bias2: the activation sits between the two K phases)
+  if (sk == 1) {   // v = act(acc (+ border-class table) + bias1) (+ bias2: the activation sits between the two K phases)
     const float* tb = (d.tile_hint & VS_CONV_PRE) ? d.a_scale + (int64_t)fb * d.a_scale_ld : nullptr;
 #pragma unroll
     for (int j = 0; j < TN; ++j)
@@ -450,6 +462,19 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pl_kernel(const vs_conv_desc_t
     scale_all<TM, TN>(acc, d.acc_mul2);
   }
   if (abl & 32) return;
+  if (sk > 1) {      // raw partial sums of this slice -> workspace [slice][pixel][splitk_ld]
+    float* ws = d.splitk_ws + (int64_t)ks * Mpix * d.splitk_ld;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int n = cbase[j] + 8 * q;
+          if (n < d.N) *reinterpret_cast<f32x4*>(ws + mrow[i] * d.splitk_ld + n) = grp(i, j, q);       // (N % 16 == 0 with planes operands)
+        }
+    return;
+  }
 #pragma unroll
   for (int i = 0; i < TM; ++i) {
     float* orow = d.out ? d.out + mrow[i] * d.out_ld + d.out_coff : nullptr;
@@ -521,10 +546,17 @@ template <int TN>
 int launch_pl(const vs_conv_desc_t& d, hipStream_t st) {
   constexpr int BN = 2 * TN * 32;
   const int tiles_x = d.W / PT, tiles_y = d.H / PT;
-  const int64_t mt = (int64_t)d.B * tiles_x * tiles_y, nt = cdiv64(d.n_store, BN);
-  if (mt * nt > 0x7fffffffLL) return VS_ERR_UNSUPPORTED;
-  hipLaunchKernelGGL((conv3x3_pl_kernel<TN>), dim3((unsigned)(mt * nt)), dim3(512), 0, st, d, tiles_x, tiles_y, (int)mt, (int)nt);
-  return vs_launch_status();
+  const int sk = d.split_k > 1 ? d.split_k : 1;
+  const int64_t mt = (int64_t)d.B * tiles_x * tiles_y, nt = cdiv64(sk > 1 ? d.N : d.n_store, BN);
+  const int spt = d.CinP / BK;
+  const int cps = (spt + sk - 1) / sk;
+  if (sk > 1 && (int64_t)(sk - 1) * cps >= spt) return VS_ERR_BAD_ARG;       // an empty K slice
+  const int slices = sk > 1 ? sk + (d.in2_pl ? 1 : 0) : 1;
+  if (mt * nt * slices > 0x7fffffffLL) return VS_ERR_UNSUPPORTED;
+  hipLaunchKernelGGL((conv3x3_pl_kernel<TN>), dim3((unsigned)(mt * nt * slices)), dim3(512), 0, st, d, tiles_x, tiles_y, (int)mt, (int)nt, cps);
+  int rc = vs_launch_status();
+  if (rc != VS_OK || sk == 1) return rc;
+  return vs_splitk_epilogue(d, (int)((int64_t)d.B * d.H * d.W), st);
 }
 
 }  // namespace

@@ -430,7 +430,8 @@ static int conv_planes(const vs_conv_desc_t& d, int tile, hipStream_t st) {
   VS_REQUIRE(d.arith == 2 && d.a_mul > 0.f && d.acc_mul > 0.f && d.in_pl && d.wt_blk && (d.out || d.out_pl));
   VS_REQUIRE(d.B > 0 && d.H > 0 && d.W > 0 && d.N > 0 && d.KH == 3 && d.KW == 3 && d.SH == 1 && d.SW == 1 && d.PH == 1 && d.PW == 1);
   VS_REQUIRE(d.Ho == d.H && d.Wo == d.W && d.pad_mode == VS_PAD_ZERO && d.CinP >= BK && d.CinP % BK == 0);
-  VS_REQUIRE(al16(d.in_pl) && al16(d.wt_blk) && al16(d.bias) && al16(d.bias2) && d.split_k <= 1 && !d.sumsq_part);
+  VS_REQUIRE(al16(d.in_pl) && al16(d.wt_blk) && al16(d.bias) && al16(d.bias2) && !d.sumsq_part);
+  if (d.split_k > 1) VS_REQUIRE(d.splitk_ws && al16(d.splitk_ws) && d.splitk_ld >= d.N && d.splitk_ld % 4 == 0 && !(d.tile_hint & VS_CONV_PRE) && !d.res);
   if (d.H % 16 || d.W % 16) return VS_ERR_UNSUPPORTED;
   if (2 * (int64_t)d.B * d.H * d.W * std::max(d.CinP, d.in2_pl ? d.Cin2P : 0) * 2 >= 0xffffffffLL) return VS_ERR_UNSUPPORTED;   // 32-bit DMA offsets
   if (d.in2_pl) VS_REQUIRE(d.wt2_blk && al16(d.in2_pl) && al16(d.wt2_blk) && d.Cin2P >= BK && d.Cin2P % BK == 0 && d.acc_mul2 > 0.f);

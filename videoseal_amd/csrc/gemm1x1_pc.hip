@@ -345,10 +345,18 @@ __global__ __launch_bounds__(256) void splitk_epilogue_kernel(const vs_conv_desc
     if (d.act == VS_ACT_RELU) t = vs_relu(t);
     else if (d.act == VS_ACT_GELU) t = vs_gelu(t);
     else if (d.act == VS_ACT_TANH) t = tanhf(t);
-    if (d.in2) t += d.splitk_ws[((int64_t)d.split_k * M + m) * d.splitk_ld + n] + (d.bias2 ? d.bias2[n] : 0.f);
+    if (d.in2 || d.in2_pl) t += d.splitk_ws[((int64_t)d.split_k * M + m) * d.splitk_ld + n] + (d.bias2 ? d.bias2[n] : 0.f);
     if (d.res) t += d.res[m * d.res_ld + n];
     v[c] = t;
   }
+  if (d.out_pl && n4 + 4 <= d.N) {      // the next conv's operand planes (conv3x3_pl.hip): hi / lo f16 of v * a_mul, [plane][N / 16][pixel][16]
+    vsconv::u32x2 hi, lo;
+    vsconv::split4h(f32x4{v[0], v[1], v[2], v[3]}, d.a_mul, hi, lo);
+    char* dst = reinterpret_cast<char*>(d.out_pl) + ((int64_t)(n4 >> 4) * M + m) * 32 + (n4 & 15) * 2;
+    *reinterpret_cast<vsconv::u32x2*>(dst) = hi;
+    *reinterpret_cast<vsconv::u32x2*>(dst + (int64_t)(d.N / 16) * M * 32) = lo;
+  }
+  if (!d.out) return;
   float* o = d.out + m * d.out_ld + d.out_coff + n4;
   if (vec && n4 + 4 <= d.n_store) {
     *reinterpret_cast<f32x4*>(o) = f32x4{v[0], v[1], v[2], v[3]};

@@ -248,6 +248,7 @@ class HipEngine:
         self.planes_chain = os.environ.get("VIDEOSEAL_PLANES", "1") != "0"              # bottleneck chain on pre-split operand planes
         self.planes_gemm = os.environ.get("VIDEOSEAL_PLANES", "1") != "0"               # ConvNeXt 1x1 GEMMs on operand planes
         self.fused_blocks = os.environ.get("VIDEOSEAL_CNX_FUSED", "1") != "0"           # stage 0 / 1 blocks with h kept on chip (convnext_fused.hip)
+        self.planes_splitk = os.environ.get("VIDEOSEAL_PLANES_SPLITK", "1") != "0"      # planes chain with K slices for 4 - 8 key frames
         # VIDEOSEAL_CHECK_FINITE=1: synchronise after every network pass and raise if the output is not finite -- the 2 x f16 arithmetic
         # turns an activation beyond its f16 range (|a| * a_mul >= 65520) into inf / NaN instead of a silently wrong number
         self.check_finite = os.environ.get("VIDEOSEAL_CHECK_FINITE", "0") == "1"
@@ -500,7 +501,7 @@ class HipEngine:
                 split_k = self._split_k_rule_patch(d)
         if split_k > 1:
             ws_ld = rup(w.N, 4)
-            slices = split_k + (1 if (patch_pc and in2 is not None) else 0)     # + the slice of the 1x1 second phase
+            slices = split_k + (1 if ((patch_pc or in_pl is not None) and in2 is not None) else 0)     # + the slice of the 1x1 second phase
             d.splitk_ws, d.splitk_ld, d.split_k = N.ptr(self.buf(f"splitk.ws@{N.stream()}", slices * out.rows * ws_ld)), ws_ld, split_k
             if tile_hint == 0 and not self.autotune:
                 d.tile_hint = self._static_split_tile(d)
@@ -790,11 +791,26 @@ class HipEngine:
         """1x1 GEMM on operand planes (gemm_pl.hip): 2 x f16 arithmetic and enough 256-row x 192-column tiles for the 256 CUs"""
         return self.planes_gemm and self.use_split and self.arith == 2 and ((rows + 255) // 256) * ((n + 191) // 192) >= 200
 
+    def _planes_split(self, x: Act) -> int:
+        """K slices of the planes conv for few key frames (shape-only rule, never timing: a K split changes the summation order): the smallest
+        divisor-like count of the C/16 chunks that gives the 256 CUs >= 192 workgroups, every slice at least two chunks; 0 = not applicable"""
+        tiles = x.B * (x.H // 16) * (x.W // 16) * (x.C // 192)
+        if tiles >= 200:
+            return 1
+        if not self.planes_splitk:
+            return 0
+        spt = x.C // 16
+        for sk in (2, 3, 4, 6, 8, 12):
+            cps = (spt + sk - 1) // sk
+            if cps >= 2 and (sk - 1) * cps < spt and tiles * sk >= 192:
+                return sk
+        return 0
+
     def _planes_ok(self, x: Act, blocks) -> bool:
         """the bottleneck chain on pre-split operand planes (conv3x3_pl.hip): 2 x f16 arithmetic, eval BatchNorm folded, whole
-        16 x 16-pixel tiles, 192-channel column tiles, and enough 256-pixel tiles to give (nearly) every CU a workgroup"""
+        16 x 16-pixel tiles, 192-channel column tiles, and enough 256-pixel tiles (x K slices) to give (nearly) every CU a workgroup"""
         return (self.planes_chain and self.use_split and self.arith == 2 and len(blocks) > 0 and x.ld == x.C and x.C % 192 == 0 and
-                x.H % 16 == 0 and x.W % 16 == 0 and x.B * (x.H // 16) * (x.W // 16) * (x.C // 192) >= 200 and
+                x.H % 16 == 0 and x.W % 16 == 0 and self._planes_split(x) >= 1 and
                 all("bn" not in p and "rms" not in p and p["cout"] == x.C and p["c0"].CinP == x.C and p["res"].CinP == x.C for p in blocks))
 
     def bottleneck_planes(self, x: Act, blocks, last_out: Optional[Act]) -> Act:
@@ -804,6 +820,8 @@ class HipEngine:
         B, H, W, C = x.B, x.H, x.W, x.C
         self.planes_chain_ran = True                      # (bench.py names the dominant kernel after it)
         tile = N.CONV_TILE_HI | 6
+        sk = self._planes_split(x)
+        kw = dict(split_k=sk) if sk > 1 else {}
         ghost = Act(None, B, H, W, C, C)                  # geometry only: the tensor exists as planes
         xpl = self.to_planes(x, "bott.pl0")
         tpl = self.buf("bott.plt", x.rows * C).view(torch.int16)
@@ -811,14 +829,14 @@ class HipEngine:
         out = None
         for j, p in enumerate(blocks):
             last = j == len(blocks) - 1
-            self.conv(ghost, p["c0"], ghost, pad=1, act=N.ACT_RELU, tile_hint=tile, in_pl=xpl, out_pl=tpl, prof="bott.conv3x3")
+            self.conv(ghost, p["c0"], ghost, pad=1, act=N.ACT_RELU, tile_hint=tile, in_pl=xpl, out_pl=tpl, prof="bott.conv3x3", **kw)
             if last:
                 out = last_out if last_out is not None else self.new_act("bott.o", B, H, W, C)
                 self.conv(ghost, p["c1"], out, pad=1, act=N.ACT_RELU, in2=ghost, w2=p["res"], tile_hint=tile, in_pl=tpl, in2_pl=xpl,
-                          n_store=(C if out.ld != rup(C, 4) else None))
+                          n_store=(C if out.ld != rup(C, 4) else None), **kw)
             else:
                 self.conv(ghost, p["c1"], ghost, pad=1, act=N.ACT_RELU, in2=ghost, w2=p["res"], tile_hint=tile, in_pl=tpl, in2_pl=xpl,
-                          out_pl=ypl)
+                          out_pl=ypl, **kw)
                 xpl, ypl = ypl, xpl
         return out
 
