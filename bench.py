@@ -409,7 +409,10 @@ def run(args):
         gmac = (28.28 if not is_video else 28.28 / cfg.step_size) + 6.16
         if args.detect_only:
             gmac = 613.6 if args.card == "chunkyseal" else 6.16
-        if roof is not None:
+        known_macs = args.card == "videoseal_1.0" or (args.card == "chunkyseal" and args.detect_only)     # SURVEY 8(d) counts these two networks
+        if not known_macs:
+            gmac = 0.0
+        if roof is not None and known_macs:
             roof["e2e_frac"] = round(fps * gmac * 2e9 / 1e12 / world / (peak_split(eng) if eng.use_split else PEAK_F32_MFMA_TFLOPS), 4)
             roof["e2e_note"] = "whole-step dense conv/GEMM FLOP/s (SURVEY 8(d) per-frame GMAC x frames/s) over the same MFMA ceiling"
         metric = f"frames/sec embed+extract {cfg.nbits}-bit @{S}x{S}"
@@ -431,7 +434,7 @@ def run(args):
                                    + (", hipGraph replay" if args.graphs else ""),
                        "card": args.card, "weights": "random-init (seeded), no checkpoint offline", "batch_per_gpu": B,
                        "frame": [S, S], "mode": args.mode},
-            "model_tflops_per_s": round(fps * gmac * 2e9 / 1e12 / world, 2),
+            "model_tflops_per_s": (round(fps * gmac * 2e9 / 1e12 / world, 2) if known_macs else None),
             "value_pipelined": (round(pipelined, 2) if pipelined else None),
             "value_pipelined_note": "the same steps with detect(batch i) on a second HIP stream under embed(batch i+1) (bench.py --pipeline); `value` is the sequential run",
             "roofline": roof,
@@ -501,6 +504,9 @@ def main():
             legs["chain (configs[2])"] = leg(["--mode", "chain"])
         legs["stream_1024 (configs[3], strong scaling over the ranks)"] = leg(["--mode", "stream", "--frames", "1024"], steps=2, warmup=1)
         legs["chunkyseal_detect_16x1024 (configs[4])"] = leg(["--card", "chunkyseal", "--size", "1024", "--batch", "16", "--detect-only"], steps=3, warmup=1)
+        if world == 1:      # the other released cards on the configs[1] workload (no MAC count from the survey: frames/s only)
+            legs["pixelseal image mode 32x768"] = leg(["--card", "pixelseal"], steps=5, warmup=2)
+            legs["videoseal_0.0 (RMSNorm U-Net + ViT extractor) image mode 32x768"] = leg(["--card", "videoseal_0.0"], steps=5, warmup=2)
         if world == 1 and rank == 0:
             try:
                 legs["train_step"] = gen_step_leg(torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0"))))
