@@ -231,7 +231,7 @@ __global__ __launch_bounds__(256) void jnd_heatmap_kernel(const float* __restric
 }
 
 // delta taps of one output pixel from the staged source window: d[c] = sum_jy wy * sum_jx wx * Dw[c][..] (Dw = hm*(wa*key_a+wb*key_b))
-template <int NT>
+template <int NT, int DWH = DW_H>
 __device__ __forceinline__ void tail_taps(float (&d)[3], const float* Dw, const int Cd, const int base, const int xn, const int yn,
                                           const float* wxp, const float* wyp) {
   int ox[NT], oy[NT];
@@ -244,7 +244,7 @@ __device__ __forceinline__ void tail_taps(float (&d)[3], const float* Dw, const 
     wy[j] = wyp[j];
   }
   for (int c = 0; c < Cd; ++c) {
-    const float* p = Dw + c * (DW_W * DW_H) + base;
+    const float* p = Dw + c * (DW_W * DWH) + base;
     float v[NT][NT];
 #pragma unroll
     for (int jy = 0; jy < NT; ++jy)
@@ -293,10 +293,17 @@ struct TailArgs {
 // Each thread owns one column: its horizontal taps are computed once and reused for the TTH rows; the vertical taps
 // of the TTH rows are computed by TTH threads into LDS; the source window of delta (x low-res heat-map, x key-frame
 // weights) is staged in LDS so the 4..9 taps per pixel are LDS reads.
-template <typename T, bool SEP>
+// TH = rows per tile; KEEP: the tile's own pixels are parked in LDS by the luminance phase and the blend phase reads them from there -- the frame is
+// fetched from HBM ONCE.  (Calibrated counters, profiles/r03r_hbm_counter_calibration.md: with the second read from global memory the kernel fetches
+// 543 MiB per launch for a 216 MiB batch -- the re-read does not hit in L2 -- and runs at the 4 TB/s the HBM delivers for that traffic; KEEP with
+// 8-row tiles (24 KiB of pixels + 12 luminance rows: still three workgroups per CU) fetches 1.5 x the frame instead of 2.27 x.)
+template <typename T, bool SEP, int TH, bool KEEP>
 __global__ __launch_bounds__(256) void embed_tail_kernel(TailArgs a, JndTaps k) {
+  constexpr int TTH = TH;
+  constexpr int DWH = TH == 8 ? 8 : DW_H;              // rows of the watermark's source window (8-row tiles at >= 2x up-scale need <= 8)
+  __shared__ float Pk[KEEP ? 3 * TH * TTW : 4];
   __shared__ float L[TLW * (TTH + 2 * HALO)];
-  __shared__ float Dw[3 * DW_W * DW_H];
+  __shared__ float Dw[3 * DW_W * DWH];
   __shared__ int ty_lo[TTH], ty_n[TTH];
   __shared__ float ty_w[TTH][4];
   __shared__ int s_xhi, s_nmax, s_xlo;
@@ -325,8 +332,12 @@ __global__ __launch_bounds__(256) void embed_tail_kernel(TailArgs a, JndTaps k) 
         }
       }
 #pragma unroll
-      for (int rr = 0; rr < NR; ++rr)
+      for (int rr = 0; rr < NR; ++rr) {
         L[rr * TLW + lxx] = 0.299f * (255.f * v[rr][0]) + 0.587f * (255.f * v[rr][1]) + 0.114f * (255.f * v[rr][2]);
+        if (KEEP && rr >= HALO && rr < HALO + TTH && lxx >= HALO && lxx < HALO + TTW)
+#pragma unroll
+          for (int c = 0; c < 3; ++c) Pk[(c * TTH + rr - HALO) * TTW + lxx - HALO] = v[rr][c];
+      }
     };
     lum_column(threadIdx.x + HALO);
     if (threadIdx.x < 2 * HALO) lum_column(threadIdx.x < HALO ? threadIdx.x : TTW + threadIdx.x);
@@ -382,7 +393,7 @@ __global__ __launch_bounds__(256) void embed_tail_kernel(TailArgs a, JndTaps k) 
   const int wx0 = s_xlo, wy0 = ty_lo[0];
   const int dww = s_xhi - wx0, dwh = ty_lo[lasty] + ty_n[lasty] - wy0;
   const int blk_n = s_nmax;
-  const bool staged = blk_n <= 4 && dww <= DW_W && dwh <= DW_H;
+  const bool staged = blk_n <= 4 && dww <= DW_W && dwh <= DWH;
   const int wx0b = wx0;
   if (staged) {
     for (int i = threadIdx.x; i < dwh * dww; i += 256) {
@@ -392,7 +403,7 @@ __global__ __launch_bounds__(256) void embed_tail_kernel(TailArgs a, JndTaps k) 
       for (int c = 0; c < a.Cd; ++c) {
         float v = wa * dka[c * splane + sp];
         if (wb != 0.f) v += wb * dkb[c * splane + sp];
-        Dw[c * (DW_W * DW_H) + yy * DW_W + xx] = hm * v;
+        Dw[c * (DW_W * DWH) + yy * DW_W + xx] = hm * v;
       }
     }
   }
@@ -417,7 +428,7 @@ __global__ __launch_bounds__(256) void embed_tail_kernel(TailArgs a, JndTaps k) 
       if (lyg + q <= lasty) {
         const int64_t pix = (int64_t)(y0 + lyg + q) * a.W + x;
 #pragma unroll
-        for (int c = 0; c < 3; ++c) px[q][c] = Px<T>::ld(img, plane, c, pix);
+        for (int c = 0; c < 3; ++c) px[q][c] = (KEEP && full_jnd) ? Pk[(c * TTH + lyg + q) * TTW + lx] : Px<T>::ld(img, plane, c, pix);
       }
     float hmg[RG] = {1.f, 1.f, 1.f, 1.f};
     if (SEP && full_jnd) {                 // separable stencils for the RG rows of the group: RG + 4 luminance rows, 5 LDS reads each
@@ -459,8 +470,8 @@ __global__ __launch_bounds__(256) void embed_tail_kernel(TailArgs a, JndTaps k) 
       const int ylo = ty_lo[ly], yn = ty_n[ly];
       if (staged) {
         const int basep = (ylo - wy0) * DW_W + (tx.lo - wx0b);
-        if (blk_n <= 3) tail_taps<3>(d, Dw, a.Cd, basep, tx.n, yn, wxs, ty_w[ly]);
-        else tail_taps<4>(d, Dw, a.Cd, basep, tx.n, yn, wxs, ty_w[ly]);
+        if (blk_n <= 3) tail_taps<3, DWH>(d, Dw, a.Cd, basep, tx.n, yn, wxs, ty_w[ly]);
+        else tail_taps<4, DWH>(d, Dw, a.Cd, basep, tx.n, yn, wxs, ty_w[ly]);
       } else {
         const Taps ty = make_taps(y, a.Sh, a.H, a.antialias);
         for (int jy = 0; jy < ty.n; ++jy) {
@@ -555,16 +566,21 @@ extern "C" int vs_embed_tail(const vs_tail_desc_t* d, void* stream) {
   JndTaps k{};
   if (d->taps43) k = taps_from(d->taps43);
   dim3 grid((d->W + TTW - 1) / TTW, (d->H + TTH - 1) / TTH, d->F);
-  // full-resolution heat-map with the standard kernels: separable stencil evaluation (VIDEOSEAL_TAIL=v1 keeps the 43-tap form for A/B runs)
-  static const bool v1 = [] { const char* e = getenv("VIDEOSEAL_TAIL"); return e && !strcmp(e, "v1"); }();
-  const bool sep = !v1 && d->attenuate && !d->hmap_lowres && d->taps43 && standard_jnd_taps(d->taps43);
+  dim3 grid8((d->W + TTW - 1) / TTW, (d->H + 7) / 8, d->F);
+  // full-resolution heat-map with the standard kernels: separable stencil evaluation on 16-row tiles (default).  VIDEOSEAL_TAIL=v1 keeps the 43-tap
+  // form, =keep selects 8-row tiles whose pixels stay in LDS between the luminance and the blend phase -- it fetches 1.5 x the frame instead of
+  // 2.27 x but runs at 281 us against 215 us (32 x 768^2): twice the workgroups, and the per-workgroup set-up (taps, watermark window, two
+  // barriers before the first output row), not HBM traffic, is what the tail pays for (profiles/r03s_shell_keep_form.log)
+  static const int mode = [] { const char* e = getenv("VIDEOSEAL_TAIL"); return !e ? 1 : (!strcmp(e, "v1") ? 0 : (!strcmp(e, "keep") ? 2 : 1)); }();
+  const bool sep = mode > 0 && d->attenuate && !d->hmap_lowres && d->taps43 && standard_jnd_taps(d->taps43);
   if (d->io_u8) {
     VS_REQUIRE(d->clamp);        // (x * 255).byte() is only defined for x in [0, 1]
     // (uint8 frames keep the 43-tap form: measured 215 us against 248 us for the separable one, profiles/r03i_shell_separable.log)
-    hipLaunchKernelGGL((embed_tail_kernel<unsigned char, false>), grid, dim3(256), 0, (hipStream_t)stream, a, k);
+    hipLaunchKernelGGL((embed_tail_kernel<unsigned char, false, 16, false>), grid, dim3(256), 0, (hipStream_t)stream, a, k);
   } else {
-    if (sep) hipLaunchKernelGGL((embed_tail_kernel<float, true>), grid, dim3(256), 0, (hipStream_t)stream, a, k);
-    else hipLaunchKernelGGL((embed_tail_kernel<float, false>), grid, dim3(256), 0, (hipStream_t)stream, a, k);
+    if (sep && mode == 2) hipLaunchKernelGGL((embed_tail_kernel<float, true, 8, true>), grid8, dim3(256), 0, (hipStream_t)stream, a, k);
+    else if (sep) hipLaunchKernelGGL((embed_tail_kernel<float, true, 16, false>), grid, dim3(256), 0, (hipStream_t)stream, a, k);
+    else hipLaunchKernelGGL((embed_tail_kernel<float, false, 16, false>), grid, dim3(256), 0, (hipStream_t)stream, a, k);
   }
   return vs_launch_status();
 }
