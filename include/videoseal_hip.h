@@ -212,6 +212,14 @@ int vs_scale_shift_act(const float* x, int64_t rows, int C, int64_t ld, const fl
 int64_t vs_gemm_wgrad_partial_floats(int64_t rows, int N, int K);
 int vs_gemm_wgrad(const float* dy, int64_t dy_ld, int N, const float* x, int64_t x_ld, int K, int64_t rows, float* partial, float* dw,
                   void* stream);
+/* vs_conv3x3_wgrad: weight gradient of a 3x3 conv (zero padding 1, stride 1 | 2; unet.py:21-27, 52) straight from the NHWC image:
+ * dw[n][tap * ld + c] -- the result of vs_im2col3x3(_strided) + vs_gemm_wgrad without the patch matrix.  Supported shapes
+ * (vs_conv3x3_wgrad_supported): N >= 64 and ld >= 64 (matrix cores), or N, ld <= 32 with N % 4 == 0 (the thin outer levels).
+ * partial: vs_conv3x3_wgrad_partial_floats(N, ld, B, H, W, stride) floats. */
+int vs_conv3x3_wgrad_supported(int N, int64_t ld);
+int64_t vs_conv3x3_wgrad_partial_floats(int N, int64_t ld, int B, int H, int W, int stride);
+int vs_conv3x3_wgrad(const float* dy, int64_t dy_ld, int N, const float* x, int64_t ld, int B, int H, int W, int stride, float* partial,
+                     float* dw, void* stream);
 int vs_dwconv7(const float* x, int B, int H, int W, int C, int64_t ld, const float* w, const float* bias, int flip, const float* add,
                int64_t add_ld, float* out, int64_t out_ld, void* stream);
 int64_t vs_dwconv7_wgrad_partial_floats(int B, int H, int64_t ld);

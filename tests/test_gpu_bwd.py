@@ -50,7 +50,39 @@ def test_gemm_wgrad(rows, n, k, ldn, ldk):
     assert torch.equal(dw, dw2)          # deterministic
 
 
-@pytest.mark.parametrize("B,H,W,C,ld", [(2, 9, 11, 6, 8), (3, 16, 16, 24, 24), (1, 5, 4, 4, 4)])
+@pytest.mark.parametrize("B,H,W,ci,co,stride", [(2, 12, 10, 64, 64, 1), (3, 9, 11, 70, 130, 1), (2, 16, 16, 128, 64, 2), (2, 15, 13, 64, 96, 2),
+                                                (1, 33, 17, 384, 384, 1), (16, 32, 32, 384, 384, 1),
+                                                # the thin outer levels (register-tile kernel): inc, down0, ups of the U-Net and odd shapes
+                                                (2, 20, 18, 16, 16, 1), (1, 256, 256, 3, 16, 1), (2, 33, 31, 16, 32, 2), (3, 40, 24, 32, 32, 1),
+                                                (2, 64, 64, 12, 8, 1), (4, 128, 128, 16, 32, 2), (1, 5, 3, 4, 4, 1)])
+def test_conv3x3_wgrad_from_the_image(B, H, W, ci, co, stride):
+    """vs_conv3x3_wgrad (matrix-core kernel on the implicit patch matrix) against the fp64 weight gradient of F.conv2d(stride, padding=1), in the
+    [co][tap * ld + c] layout of the patch-matrix route it replaces (unet.py:21-27 double_conv, :52 the stride-2 down conv)"""
+    L, st = _lib()
+    ld = (ci + 3) // 4 * 4
+    x = _rand(B, ci, H, W, seed=21)
+    Ho, Wo = (H - 1) // stride + 1, (W - 1) // stride + 1
+    dy = _rand(B, co, Ho, Wo, seed=23)
+    cols = F.unfold(x.double(), 3, padding=1, stride=stride)                    # [B, ci * 9, Ho * Wo]
+    wgrad = torch.einsum("bnl,bkl->nk", dy.double().reshape(B, co, -1), cols).reshape(co, ci, 3, 3)     # = autograd of F.conv2d w.r.t. the weight
+    xa = _padded(x.permute(0, 2, 3, 1).reshape(-1, ci), ld).contiguous()
+    dya = dy.permute(0, 2, 3, 1).reshape(-1, co).contiguous()
+    ldn = (co + 3) // 4 * 4
+    dya = _padded(dya, ldn)
+    rows = B * Ho * Wo
+    assert L.vs_conv3x3_wgrad_supported(co, ld)
+    part = torch.empty(int(L.vs_conv3x3_wgrad_partial_floats(co, ld, B, H, W, stride)), device="cuda")
+    dw = torch.full((co, 9 * ld), 7.0, device="cuda")
+    N.check(L.vs_conv3x3_wgrad(N.ptr(dya), ldn, co, N.ptr(xa), ld, B, H, W, stride, N.ptr(part), N.ptr(dw), st), "vs_conv3x3_wgrad")
+    got = dw.view(co, 3, 3, ld)[..., :ci].permute(0, 3, 1, 2)
+    assert (got.double() - wgrad).abs().max() <= 2e-5 * wgrad.abs().max()
+    assert (dw.view(co, 9, ld)[..., ci:] == 0).all()
+    dw2 = torch.empty_like(dw)
+    N.check(L.vs_conv3x3_wgrad(N.ptr(dya), ldn, co, N.ptr(xa), ld, B, H, W, stride, N.ptr(part), N.ptr(dw2), st), "vs_conv3x3_wgrad")
+    assert torch.equal(dw, dw2)          # deterministic
+
+
+@pytest.mark.parametrize("B,H,W,C,ld", [(2, 9, 11, 6, 8), (3, 16, 16, 24, 24), (1, 5, 4, 4, 4), (1, 3, 2, 4, 4), (36, 64, 9, 8, 8), (2, 8, 23, 96, 96)])
 def test_dwconv7_forward_flip_and_wgrad(B, H, W, C, ld):
     L, st = _lib()
     x = _rand(B, C, H, W, seed=3).requires_grad_(True)
@@ -84,7 +116,7 @@ def test_dwconv7_forward_flip_and_wgrad(B, H, W, C, ld):
     assert (dw[:, :C] - ref).abs().max() <= 2e-5 * ref.abs().max()
 
 
-@pytest.mark.parametrize("rows,C,ld", [(37, 16, 16), (1000, 96, 96), (300, 18, 20), (5, 130, 160)])
+@pytest.mark.parametrize("rows,C,ld", [(37, 16, 16), (1000, 96, 96), (300, 18, 20), (5, 130, 160), (700, 1100, 1100)])
 def test_layernorm_bwd(rows, C, ld):
     L, st = _lib()
     x = (_rand(rows, C, seed=8) * 2 + 0.3).requires_grad_(True)
@@ -105,7 +137,7 @@ def test_layernorm_bwd(rows, C, ld):
     assert (db - b.grad).abs().max() <= 2e-5 * b.grad.abs().max()
 
 
-@pytest.mark.parametrize("B,HW,C,ld", [(3, 20, 8, 8), (2, 300, 64, 64), (4, 64, 24, 32), (1, 1000, 12, 12)])
+@pytest.mark.parametrize("B,HW,C,ld", [(3, 20, 8, 8), (2, 300, 64, 64), (4, 64, 24, 32), (1, 1000, 12, 12), (2, 333, 1536, 1536)])
 def test_gelu_grn_bwd(B, HW, C, ld):
     L, st = _lib()
     h1 = _rand(B, HW, C, seed=12).requires_grad_(True)

@@ -228,3 +228,40 @@ def test_ddp_wrapped_training_step_over_rccl_world1(rccl_world1):
     assert set(g0) == set(g1)
     for k in g0:
         assert (g0[k] - g1[k]).abs().max() <= 1e-5 * float(g0[k].abs().max()) + 1e-12, k
+
+
+def test_ddp_two_ranks_on_one_gpu_match_the_single_process_step(tmp_path):
+    """World size 2 for real: two processes, each with half of the batch, SyncBatchNorm conversion + DistributedDataParallel as in
+    train.py:438-446 (tests/_ddp_worker.py).  Both ranks must end with the gradients of the single-process step on the whole batch (DDP
+    averages; the loss terms are batch means) and with the whole batch's BatchNorm running statistics."""
+    import os
+    import subprocess
+    import sys
+    from tests import _ddp_worker as W
+    model, imgs, msgs = W.batch_and_model()
+    loss_ref, g_ref = W.step(model, model, imgs, msgs)
+    bn_ref = torch.cat([b.detach().double().flatten().cpu() for k, b in model.named_buffers() if "running" in k])
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    outs = [str(tmp_path / f"rank{r}.pt") for r in range(2)]
+    procs = [subprocess.Popen([sys.executable, "-m", "tests._ddp_worker", outs[r]], cwd=root, env=dict(env, RANK=str(r)),
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT) for r in range(2)]
+    logs = []
+    for p in procs:
+        try:
+            logs.append(p.communicate(timeout=600)[0].decode(errors="replace")[-3000:])
+        except subprocess.TimeoutExpired:
+            p.kill()
+            logs.append("timeout")
+    assert all(p.returncode == 0 for p in procs), logs
+    res = [torch.load(o) for o in outs]
+    if any("unsupported" in r for r in res):
+        pytest.skip(f"gloo cannot reduce device tensors in this build: {[r.get('unsupported') for r in res]}")
+    assert (res[0]["bn"] - res[1]["bn"]).abs().max() == 0
+    assert (res[0]["bn"] - bn_ref).abs().max() <= 1e-5 * bn_ref.abs().max()
+    assert abs(0.5 * (res[0]["loss"] + res[1]["loss"]) - loss_ref) <= 1e-5 * abs(loss_ref)
+    assert set(res[0]["grads"]) == set(g_ref) == set(res[1]["grads"])
+    for k in g_ref:
+        a, b, r = res[0]["grads"][k], res[1]["grads"][k], g_ref[k]
+        assert torch.equal(a, b), k                                             # both ranks hold the averaged gradient
+        assert (a - r).abs().max() <= 1e-4 * float(r.abs().max()) + 1e-10, (k, float((a - r).abs().max()), float(r.abs().max()))

@@ -18,16 +18,32 @@
 
 namespace {
 
-constexpr int CR_ROWS = 256;      // rows per chunk of the column reductions
+constexpr int CR_ROWS = 64;       // rows per chunk of the column reductions
 
 // ---------------------------------------------------------------------------------------------------
-// sum over chunks: out[i] = sum_k partial[k][i]  (fp64, fixed order);  n elements per chunk
+// sum over chunks: out[i] = sum_k partial[k][i]  (fp64, fixed order);  n elements per chunk.  Workgroup = 64 elements x 4 chunk lanes: lane g
+// adds the chunks k = g, g + 4, ... (eight loads in flight), the four lane sums are combined in the order g = 0..3 -- the order depends on
+// nchunk only, never on the launch.
 __global__ __launch_bounds__(256) void reduce_chunks_kernel(const float* __restrict__ partial, int nchunk, int64_t n, float* __restrict__ out) {
-  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (i >= n) return;
+  __shared__ double sh[4][64];
+  const int e = threadIdx.x & 63, g = threadIdx.x >> 6;
+  const int64_t i = (int64_t)blockIdx.x * 64 + e;
   double s = 0;
-  for (int k = 0; k < nchunk; ++k) s += (double)partial[(int64_t)k * n + i];
-  out[i] = (float)s;
+  if (i < n) {
+    const float* p = partial + i;
+    int k = g;
+    for (; k + 28 < nchunk; k += 32) {
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = p[(int64_t)(k + 4 * u) * n];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) s += (double)v[u];
+    }
+    for (; k < nchunk; k += 4) s += (double)p[(int64_t)k * n];
+  }
+  sh[g][e] = s;
+  __syncthreads();
+  if (g == 0 && i < n) out[i] = (float)(((sh[0][e] + sh[1][e]) + sh[2][e]) + sh[3][e]);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -152,11 +168,13 @@ __global__ __launch_bounds__(256) void gemm_wgrad_mfma_kernel(const float* __res
 // ---------------------------------------------------------------------------------------------------
 // The same product on the 16-bit matrix cores with the exact 3 x bf16 operand split (six partial products, fp32 accumulate: the accuracy of
 // the fp32 kernels above at 417 instead of 157 TFLOP/s of ceiling).  v_mfma_f32_32x32x16_bf16 wants 8 consecutive reduction indices per lane,
-// and the reduction index here is the ROW: every thread therefore loads one column of 8 consecutive rows (4-byte loads, coalesced across the
-// wave's 64 consecutive columns), splits the 8 values and writes them as ONE 16-byte LDS store per plane into the transposed tile
-// [plane][column][row] -- the fragment reads are then plain 16-byte reads.  Row pitch 80 bytes (32 rows + 8 pad): conflict-free b128 reads.
+// and the reduction index here is the ROW: a thread therefore loads 4 consecutive columns of 8 consecutive rows (eight 16-byte loads; threads
+// 0..127 stage dY, 128..255 stage X), splits the 8 values of each column and writes them as ONE 16-byte LDS store per plane into the transposed
+// tile [plane][column][row] -- the fragment reads are then plain 16-byte reads.  Row pitch 80 bytes (32 rows + 8 pad): conflict-free b128
+// reads; the 8-row group g of column col sits at group g ^ ((col >> 4) & 3), which makes the column-strided 16-byte stores conflict-free too.
 // Workgroup = 128 (n) x 128 (k) outputs, 4 waves of 64 x 64 (2 x 2 MFMA tiles), 32 rows per step; the next step's rows are fetched into
-// registers while the matrix cores work.
+// registers while the matrix cores work.  (First version: 4-byte loads, one column of 16 rows per thread -- 64 load instructions per thread
+// and step against 48 MFMAs per wave; profiles/r03g_generator_step_torch_profile.log.)
 namespace wg16 {
 using vsconv::bf16x8;
 using vsconv::u32x4;
@@ -183,17 +201,25 @@ __device__ __forceinline__ void split8(const float (&v)[8], u32x4 (&pl)[3]) {
 }
 }  // namespace wg16
 
-__global__ __launch_bounds__(256) void gemm_wgrad_bf16x3_kernel(const float* __restrict__ dy, int64_t dy_ld, int N, const float* __restrict__ x,
+// CONV = true: the X operand is the implicit 3 x 3 patch matrix of an NHWC image (zero padding 1, stride cs): blockIdx.x = (tap, column
+// tile of the image row), row r of dY is output pixel (b, oy, ox) and reads image pixel (oy * cs + ky - 1, ox * cs + kx - 1) -- the
+// weight gradient of a 3 x 3 conv without materialising rows x 9 ld floats of patches.  K is then the image's ld, dw is [N][9 * ld].
+struct wgrad_conv_t { int H, W, Ho, Wo, cs, ktiles; };
+template <bool CONV>
+__global__ __launch_bounds__(256, 2) void gemm_wgrad_bf16x3_kernel(const float* __restrict__ dy, int64_t dy_ld, int N, const float* __restrict__ x,
                                                                 int64_t x_ld, int K, int64_t rows, int64_t rows_per_split,
-                                                                float* __restrict__ partial) {
+                                                                float* __restrict__ partial, const wgrad_conv_t cv) {
   using namespace wg16;
-  __shared__ __attribute__((aligned(16))) unsigned short sa[3][TILE][PITCH], sb[3][TILE][PITCH];
-  const int n0 = blockIdx.y * TILE, k0 = blockIdx.x * TILE;
+  __shared__ __attribute__((aligned(16))) unsigned short sm[2][3][TILE][PITCH];          // [operand: dY, X][plane][column][row]
+  const int tap = CONV ? blockIdx.x / cv.ktiles : 0;
+  const int n0 = blockIdx.y * TILE, k0 = (CONV ? blockIdx.x - tap * cv.ktiles : blockIdx.x) * TILE;
   const int64_t r_begin = (int64_t)blockIdx.z * rows_per_split;
   const int64_t r_end = r_begin + rows_per_split < rows ? r_begin + rows_per_split : rows;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int wy = wave >> 1, wx = wave & 1;
-  const int col = threadIdx.x & 127, rg = threadIdx.x >> 7;          // staging: column `col`, rows rg * 16 .. + 16 of the step
+  const int op = threadIdx.x >> 7;                                   // which operand this thread stages
+  const int cg = threadIdx.x & 31, rgp = (threadIdx.x >> 5) & 3;     // columns 4 cg .. 4 cg + 3, rows 8 rgp .. 8 rgp + 7 of the step
+  const int sw = (cg >> 2) & 3;                                      // 8-row group g of column col is stored at group g ^ ((col >> 4) & 3)
   const int kq = lane >> 5, c = lane & 31;
   f32x16 acc[2][2];
 #pragma unroll
@@ -202,39 +228,49 @@ __global__ __launch_bounds__(256) void gemm_wgrad_bf16x3_kernel(const float* __r
     for (int j = 0; j < 2; ++j)
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
-  float va[16], vb[16];
-  const bool a_ok = n0 + col < N, b_ok = k0 + col < K;
-  const float* pa = dy + n0 + col;
-  const float* pb = x + k0 + col;
-  auto fetch = [&](const int64_t r0) __attribute__((always_inline)) {
+  const int64_t sld = op ? x_ld : dy_ld;
+  const int col0 = (op ? k0 : n0) + 4 * cg;
+  const bool c_ok = col0 + 4 <= sld;                                 // the 16 bytes lie inside the row (columns past N / K only feed outputs that
+  const float* src = (op ? x : dy) + col0;                           // are never stored)
+  const int ky = tap / 3, kx = tap - 3 * ky;
+  auto fetch = [&](f32x4 (&v)[8], const int64_t r0) __attribute__((always_inline)) {
+    if (CONV && op) {                      // image pixel of each of the 8 rows: one decomposition, then a walk along the output row
+      const unsigned rf = (unsigned)(r0 + rgp * 8);
+      unsigned q = rf / (unsigned)cv.Wo;
+      int ox = (int)(rf - q * (unsigned)cv.Wo);
+      unsigned b = q / (unsigned)cv.Ho;
+      int oy = (int)(q - b * (unsigned)cv.Ho);
 #pragma unroll
-    for (int j = 0; j < 16; ++j) {
-      const int64_t r = r0 + rg * 16 + j;
-      const bool in = r < r_end;
-      va[j] = (in && a_ok) ? pa[r * dy_ld] : 0.f;
-      vb[j] = (in && b_ok) ? pb[r * x_ld] : 0.f;
+      for (int j = 0; j < 8; ++j) {
+        const int iy = oy * cv.cs + ky - 1, ix = ox * cv.cs + kx - 1;
+        const bool in = c_ok && (int64_t)rf + j < r_end && iy >= 0 && iy < cv.H && ix >= 0 && ix < cv.W;
+        v[j] = in ? *reinterpret_cast<const f32x4*>(src + (((int64_t)b * cv.H + iy) * cv.W + ix) * sld) : f32x4{0.f, 0.f, 0.f, 0.f};
+        if (++ox == cv.Wo) { ox = 0; if (++oy == cv.Ho) { oy = 0; ++b; } }
+      }
+      return;
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int64_t r = r0 + rgp * 8 + j;
+      v[j] = (c_ok && r < r_end) ? *reinterpret_cast<const f32x4*>(src + r * sld) : f32x4{0.f, 0.f, 0.f, 0.f};
     }
   };
-  fetch(r_begin);
-  for (int64_t r0 = r_begin; r0 < r_end; r0 += RS) {
+  // one step: split + transposed LDS stores of the rows in `v`, refill `v` with the rows TWO steps ahead (the other register set holds the
+  // rows of the next step, already in flight: a load has a whole step of matrix work to arrive), fragments, 48 MFMAs per wave
+  auto step = [&](f32x4 (&v)[8], const int64_t r0) __attribute__((always_inline)) {
     __syncthreads();                       // the previous step's fragment reads are done
 #pragma unroll
-    for (int half = 0; half < 2; ++half) {
+    for (int j = 0; j < 4; ++j) {
       float t[8];
       u32x4 pl[3];
 #pragma unroll
-      for (int j = 0; j < 8; ++j) t[j] = va[half * 8 + j];
+      for (int q = 0; q < 8; ++q) t[q] = v[q][j];
       split8(t, pl);
 #pragma unroll
-      for (int p = 0; p < 3; ++p) *reinterpret_cast<u32x4*>(&sa[p][col][rg * 16 + half * 8]) = pl[p];
-#pragma unroll
-      for (int j = 0; j < 8; ++j) t[j] = vb[half * 8 + j];
-      split8(t, pl);
-#pragma unroll
-      for (int p = 0; p < 3; ++p) *reinterpret_cast<u32x4*>(&sb[p][col][rg * 16 + half * 8]) = pl[p];
+      for (int p = 0; p < 3; ++p) *reinterpret_cast<u32x4*>(&sm[op][p][4 * cg + j][(rgp ^ sw) * 8]) = pl[p];
     }
     __syncthreads();
-    if (r0 + RS < r_end) fetch(r0 + RS);
+    if (r0 + 2 * RS < r_end) fetch(v, r0 + 2 * RS);
 #pragma unroll
     for (int ks = 0; ks < RS / 16; ++ks) {
       bf16x8 fa[2][3], fb[2][3];
@@ -242,8 +278,9 @@ __global__ __launch_bounds__(256) void gemm_wgrad_bf16x3_kernel(const float* __r
       for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int p = 0; p < 3; ++p) {
-          fa[i][p] = *reinterpret_cast<const bf16x8*>(&sa[p][wy * 64 + i * 32 + c][ks * 16 + kq * 8]);
-          fb[i][p] = *reinterpret_cast<const bf16x8*>(&sb[p][wx * 64 + i * 32 + c][ks * 16 + kq * 8]);
+          const int ca = wy * 64 + i * 32 + c, cb = wx * 64 + i * 32 + c;
+          fa[i][p] = *reinterpret_cast<const bf16x8*>(&sm[0][p][ca][((ks * 2 + kq) ^ ((ca >> 4) & 3)) * 8]);
+          fb[i][p] = *reinterpret_cast<const bf16x8*>(&sm[1][p][cb][((ks * 2 + kq) ^ ((cb >> 4) & 3)) * 8]);
         }
 #pragma unroll
       for (int q = 0; q < 6; ++q)           // smallest partial products first
@@ -253,9 +290,17 @@ __global__ __launch_bounds__(256) void gemm_wgrad_bf16x3_kernel(const float* __r
           for (int j = 0; j < 2; ++j)
             acc[i][j] = vsconv::Arith<3>::mfma(fa[i][vsconv::Arith<3>::PA[q]], fb[j][vsconv::Arith<3>::PB[q]], acc[i][j]);
     }
+  };
+  f32x4 v0[8], v1[8];
+  fetch(v0, r_begin);
+  if (r_begin + RS < r_end) fetch(v1, r_begin + RS);
+  for (int64_t r0 = r_begin; r0 < r_end; r0 += 2 * RS) {
+    step(v0, r0);
+    if (r0 + RS < r_end) step(v1, r0 + RS);
   }
   // D[m][n]: lane holds column n = lane & 31 and rows m = (e & 3) + 8 (e >> 2) + 4 (lane >> 5)
-  float* p = partial + (int64_t)blockIdx.z * N * K;
+  const int64_t Kt = CONV ? 9 * (int64_t)K : K;                      // row length of dw
+  float* p = partial + (int64_t)blockIdx.z * N * Kt + (CONV ? (int64_t)tap * K : 0);
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -264,9 +309,92 @@ __global__ __launch_bounds__(256) void gemm_wgrad_bf16x3_kernel(const float* __r
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
         const int n = n0 + wy * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * kq;
-        if (n < N && k < K) p[(int64_t)n * K + k] = acc[i][j][e];
+        if (n < N && k < K) p[(int64_t)n * Kt + k] = acc[i][j][e];
       }
     }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Weight gradient of a THIN 3 x 3 conv (co, ci <= 32: the U-Net's outer levels, unet.py:21-27 at 256^2 / 128^2 -- a million rows against a
+// 16 x 144 result) straight from the image.  These layers are not GEMM-shaped: the patch-matrix route wrote and re-read rows x 9 ld floats to
+// produce a few thousand numbers.  Here a workgroup walks over 16 x 16 (or 8 x 16) tiles of output pixels; per tile the dY tile and the x tile
+// with its halo go to LDS once, thread (a, b, p) owns the 9 x 4 x 4 results of output channels 4a.., input channels 4b.. and adds the pixels
+// p, p + L, .. of the tile: per pixel one 16-byte read of dY and nine of x feed 144 FMAs.  The workgroup keeps its sums in registers over
+// all of its tiles; at the end the L pixel lanes are added through LDS in lane order and the workgroup writes ONE partial result
+// [co][9 * ld]; reduce_chunks_kernel adds the workgroups' partials (fixed grid for a shape: deterministic).
+struct wgrad_thin_t { int H, W, Ho, Wo, cs, TH, tw_shift, tiles_x, tiles_y, ntiles, co, L; };
+
+__global__ __launch_bounds__(256, 2) void conv3x3_wgrad_thin_kernel(const float* __restrict__ dy, int64_t dy_ld, const float* __restrict__ x, int64_t ld,
+                                                                    const wgrad_thin_t g, float* __restrict__ partial) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int nb = (int)(ld >> 2), na = g.co >> 2, combos = na * nb;
+  const int TW = 1 << g.tw_shift, TH = g.TH, cs = g.cs;
+  const int IW = (TW - 1) * cs + 3, IH = (TH - 1) * cs + 3;
+  float* sx = lds;                                   // [IH * IW][ld]
+  float* sd = lds + (int64_t)IH * IW * ld;           // [TH * TW][co]
+  const int t = threadIdx.x;
+  const int p = t / combos, cb = t - p * combos;
+  const int a = cb / nb, b = cb - a * nb;
+  const bool active = p < g.L;
+  f32x4 acc[9][4];
+#pragma unroll
+  for (int k = 0; k < 9; ++k)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) acc[k][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int tile = blockIdx.x; tile < g.ntiles; tile += gridDim.x) {
+    const int tx = tile % g.tiles_x, q = tile / g.tiles_x;
+    const int ty = q % g.tiles_y, bi = q / g.tiles_y;
+    const int oy0 = ty * TH, ox0 = tx * TW;
+    const int iy0 = oy0 * cs - 1, ix0 = ox0 * cs - 1;
+    __syncthreads();                                 // the previous tile's reads are done
+    for (int i = t; i < IH * IW * nb; i += 256) {
+      const int c4 = i % nb, pix = i / nb;
+      const int yy = pix / IW, xx = pix - yy * IW;
+      const int gy = iy0 + yy, gx = ix0 + xx;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (gy >= 0 && gy < g.H && gx >= 0 && gx < g.W) v = *reinterpret_cast<const f32x4*>(x + (((int64_t)bi * g.H + gy) * g.W + gx) * ld + 4 * c4);
+      *reinterpret_cast<f32x4*>(sx + (int64_t)pix * ld + 4 * c4) = v;
+    }
+    for (int i = t; i < TH * TW * na; i += 256) {
+      const int c4 = i % na, pix = i / na;
+      const int oy = oy0 + (pix >> g.tw_shift), ox = ox0 + (pix & (TW - 1));
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (oy < g.Ho && ox < g.Wo) v = *reinterpret_cast<const f32x4*>(dy + (((int64_t)bi * g.Ho + oy) * g.Wo + ox) * dy_ld + 4 * c4);
+      *reinterpret_cast<f32x4*>(sd + (int64_t)pix * g.co + 4 * c4) = v;
+    }
+    __syncthreads();
+    if (active)
+      for (int i = p; i < TH * TW; i += g.L) {
+        const int py = i >> g.tw_shift, px = i & (TW - 1);
+        const f32x4 d4 = *reinterpret_cast<const f32x4*>(sd + i * g.co + 4 * a);
+        const float* xb = sx + ((int64_t)(py * cs) * IW + px * cs) * ld + 4 * b;
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+          for (int kx = 0; kx < 3; ++kx) {
+            const f32x4 x4 = *reinterpret_cast<const f32x4*>(xb + (int64_t)(ky * IW + kx) * ld);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[ky * 3 + kx][e] += d4[e] * x4;
+          }
+      }
+  }
+  // the L pixel lanes of every (a, b) are added in lane order, one tap at a time through 16 KB of LDS
+  const int64_t K9 = 9 * ld;
+  float* out = partial + (int64_t)blockIdx.x * g.co * K9;
+#pragma unroll
+  for (int k = 0; k < 9; ++k) {
+    __syncthreads();
+#pragma unroll
+    for (int e = 0; e < 4; ++e) *reinterpret_cast<f32x4*>(lds + t * 16 + 4 * e) = acc[k][e];
+    __syncthreads();
+    for (int idx = t; idx < combos * 16; idx += 256) {
+      const int c2 = idx >> 4, e = idx & 15;
+      float sum = 0.f;
+      for (int pp = 0; pp < g.L; ++pp) sum += lds[(pp * combos + c2) * 16 + e];
+      const int a2 = c2 / nb, b2 = c2 - a2 * nb;
+      out[(int64_t)(4 * a2 + (e >> 2)) * K9 + k * ld + 4 * b2 + (e & 3)] = sum;
+    }
+  }
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -316,8 +444,11 @@ __global__ __launch_bounds__(256) void dwconv7_kernel(const float* __restrict__ 
   }
 }
 
-// d w[t][c] = sum_{b,y,x} dy[b,y,x,c] * x[b, y+ky-3, x+kx-3, c]: chunk = (frame, band of RB image rows), thread items = (tap, 4 channels);
-// partial[chunk][49][ld] in fp32 (RB * W terms each), summed over the chunks by reduce_chunks_kernel
+// d w[t][c] = sum_{b,y,x} dy[b,y,x,c] * x[b, y+ky-3, x+kx-3, c]: chunk = (frame, band of RB image rows), thread items = (tap ROW ky, 4 channels).
+// An item walks along the image row with a sliding window of seven x pixels in registers, so every x / dy value is loaded once per tap row and
+// feeds 7 x 4 FMAs (the first version had one item per tap: two loads per 4 FMAs, load-issue bound).  The walk is unrolled by seven: the
+// window slot of pixel u is u % 7, a compile-time index.  partial[chunk][49][ld] in fp32 (RB * W terms each), summed over the chunks by
+// reduce_chunks_kernel.
 __global__ __launch_bounds__(256) void dwconv7_wgrad_kernel(const float* __restrict__ x, int64_t ld, const float* __restrict__ dy,
                                                             int64_t dy_ld, int H, int W, int RB, int nband, int C4,
                                                             float* __restrict__ partial) {
@@ -325,21 +456,39 @@ __global__ __launch_bounds__(256) void dwconv7_wgrad_kernel(const float* __restr
   const int ya = band * RB, yb = ya + RB < H ? ya + RB : H;
   const float* xb = x + (int64_t)b * H * W * ld;
   const float* db = dy + (int64_t)b * H * W * dy_ld;
-  for (int it = threadIdx.x; it < 49 * C4; it += 256) {
-    const int t = it / C4, cg = it - t * C4;
-    const int ky = t / 7, kx = t - ky * 7;
-    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  for (int it = threadIdx.x; it < 7 * C4; it += 256) {
+    const int ky = it / C4, cg = it - ky * C4;
+    f32x4 acc[7];
+#pragma unroll
+    for (int k = 0; k < 7; ++k) acc[k] = f32x4{0.f, 0.f, 0.f, 0.f};
     for (int y = ya; y < yb; ++y) {
       const int iy = y + ky - 3;
       if (iy < 0 || iy >= H) continue;
-      const int xa = kx < 3 ? 3 - kx : 0, xe = W + 3 - kx < W ? W + 3 - kx : W;       // 0 <= xx + kx - 3 < W
-      for (int xx = xa; xx < xe; ++xx) {
-        const f32x4 g = *reinterpret_cast<const f32x4*>(db + ((int64_t)y * W + xx) * dy_ld + 4 * cg);
-        const f32x4 v = *reinterpret_cast<const f32x4*>(xb + ((int64_t)iy * W + xx + kx - 3) * ld + 4 * cg);
-        acc += g * v;
+      const float* xr = xb + (int64_t)iy * W * ld + 4 * cg;
+      const float* gr = db + (int64_t)y * W * dy_ld + 4 * cg;
+      f32x4 win[7];                        // slot (u + 3) % 7 holds x[u] for u = xx - 3 .. xx + 3 (zeros outside the row)
+#pragma unroll
+      for (int k = 0; k < 7; ++k) win[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int u = 0; u < 3; ++u)
+        if (u < W) win[u + 3] = *reinterpret_cast<const f32x4*>(xr + (int64_t)u * ld);
+      for (int x0 = 0; x0 < W; x0 += 7) {
+#pragma unroll
+        for (int j = 0; j < 7; ++j) {
+          const int xx = x0 + j;
+          if (xx < W) {
+            // x[xx + 3] enters slot (xx + 6) % 7 = (j + 6) % 7 (x0 is a multiple of 7), replacing x[xx - 4]
+            win[(j + 6) % 7] = xx + 3 < W ? *reinterpret_cast<const f32x4*>(xr + (int64_t)(xx + 3) * ld) : f32x4{0.f, 0.f, 0.f, 0.f};
+            const f32x4 g = *reinterpret_cast<const f32x4*>(gr + (int64_t)xx * dy_ld);
+#pragma unroll
+            for (int kx = 0; kx < 7; ++kx) acc[kx] += g * win[(j + kx) % 7];       // x[xx + kx - 3] sits in slot (xx + kx) % 7
+          }
+        }
       }
     }
-    *reinterpret_cast<f32x4*>(partial + ((int64_t)blockIdx.x * 49 + t) * ld + 4 * cg) = acc;
+#pragma unroll
+    for (int kx = 0; kx < 7; ++kx)
+      *reinterpret_cast<f32x4*>(partial + ((int64_t)blockIdx.x * 49 + ky * 7 + kx) * ld + 4 * cg) = acc[kx];
   }
 }
 
@@ -387,43 +536,52 @@ __global__ __launch_bounds__(256) void colreduce_kernel(const float* __restrict_
   const int frame = blockIdx.x / nchf, ch = blockIdx.x % nchf;
   const int64_t r0 = (int64_t)frame * HW + (int64_t)ch * CR_ROWS;
   const int64_t r1 = (int64_t)frame * HW + (((int64_t)ch + 1) * CR_ROWS < HW ? ((int64_t)ch + 1) * CR_ROWS : HW);
-  const int G = C4 < 256 ? C4 : 256;                   // channel groups handled per sweep
+  const int G = C4 < 256 ? C4 : 256;                   // channel groups handled per workgroup (blockIdx.y = sweep)
   const int RL = 256 / G;                              // row lanes per channel group
   const int g = threadIdx.x % G, rl = threadIdx.x / G;
-  for (int gb = 0; gb < C4; gb += G) {
-    const int gg = gb + g;
-    f32x4 acc[NV];
+  const int gg = blockIdx.y * G + g;
+  f32x4 acc[NV];
 #pragma unroll
-    for (int k = 0; k < NV; ++k) acc[k] = f32x4{0.f, 0.f, 0.f, 0.f};
-    if (rl < RL && gg < C4)
-      for (int64_t r = r0 + rl; r < r1; r += RL) {
-        const f32x4 va = *reinterpret_cast<const f32x4*>(a + r * a_ld + 4 * gg);
-        const f32x4 vb = *reinterpret_cast<const f32x4*>(b + r * b_ld + 4 * gg);
-        if constexpr (MODE == 0) {
-          const float mean = stats[2 * r], rstd = stats[2 * r + 1];
-          acc[0] += vb * ((va - mean) * rstd);
-          acc[1] += vb;
-        } else {
-          f32x4 ge;
+  for (int k = 0; k < NV; ++k) acc[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+  auto term = [&](const f32x4& va, const f32x4& vb, const int64_t r) __attribute__((always_inline)) {
+    if constexpr (MODE == 0) {
+      const float mean = stats[2 * r], rstd = stats[2 * r + 1];
+      acc[0] += vb * ((va - mean) * rstd);
+      acc[1] += vb;
+    } else {
+      f32x4 ge;
 #pragma unroll
-          for (int e = 0; e < 4; ++e) ge[e] = vs_gelu(va[e]);
-          acc[0] += ge * ge;
-          acc[1] += vb * ge;
-          acc[2] += vb;
-        }
-      }
-#pragma unroll
-    for (int k = 0; k < NV; ++k) *reinterpret_cast<f32x4*>(&red[k][threadIdx.x][0]) = acc[k];
-    __syncthreads();
-    if (rl == 0 && gg < C4) {
-#pragma unroll
-      for (int k = 0; k < NV; ++k) {
-        f32x4 s = {0.f, 0.f, 0.f, 0.f};
-        for (int j = 0; j < RL; ++j) s += *reinterpret_cast<const f32x4*>(&red[k][j * G + g][0]);
-        *reinterpret_cast<f32x4*>(partial + ((int64_t)blockIdx.x * NV + k) * ldp + 4 * gg) = s;
-      }
+      for (int e = 0; e < 4; ++e) ge[e] = vs_gelu(va[e]);
+      acc[0] += ge * ge;
+      acc[1] += vb * ge;
+      acc[2] += vb;
     }
-    __syncthreads();
+  };
+  if (rl < RL && gg < C4) {
+    int64_t r = r0 + rl;
+    for (; r + 3 * RL < r1; r += 4 * RL) {               // four rows in flight, added in row order
+      f32x4 va[4], vb[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        va[u] = *reinterpret_cast<const f32x4*>(a + (r + u * RL) * a_ld + 4 * gg);
+        vb[u] = *reinterpret_cast<const f32x4*>(b + (r + u * RL) * b_ld + 4 * gg);
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) term(va[u], vb[u], r + u * RL);
+    }
+    for (; r < r1; r += RL)
+      term(*reinterpret_cast<const f32x4*>(a + r * a_ld + 4 * gg), *reinterpret_cast<const f32x4*>(b + r * b_ld + 4 * gg), r);
+  }
+#pragma unroll
+  for (int k = 0; k < NV; ++k) *reinterpret_cast<f32x4*>(&red[k][threadIdx.x][0]) = acc[k];
+  __syncthreads();
+  if (rl == 0 && gg < C4) {
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+      f32x4 s = {0.f, 0.f, 0.f, 0.f};
+      for (int j = 0; j < RL; ++j) s += *reinterpret_cast<const f32x4*>(&red[k][j * G + g][0]);
+      *reinterpret_cast<f32x4*>(partial + ((int64_t)blockIdx.x * NV + k) * ldp + 4 * gg) = s;
+    }
   }
 }
 
@@ -434,11 +592,22 @@ __global__ __launch_bounds__(256) void grn_sums_kernel(const float* __restrict__
   const int c = blockIdx.x * 256 + threadIdx.x;
   if (c >= C) return;
   double g2 = 0, ss = 0, tt = 0;
-  for (int k = 0; k < nchf; ++k) {
-    const float* p = partial + ((int64_t)frame * nchf + k) * 3 * ldp;
-    g2 += (double)p[c];
-    ss += (double)p[ldp + c];
-    tt += (double)p[2 * ldp + c];
+  const float* p0 = partial + (int64_t)frame * nchf * 3 * ldp + c;
+  int k = 0;
+  for (; k + 4 <= nchf; k += 4) {                       // twelve loads in flight, added in chunk order
+    float v[4][3];
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+      for (int q = 0; q < 3; ++q) v[u][q] = p0[((int64_t)(k + u) * 3 + q) * ldp];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) { g2 += (double)v[u][0]; ss += (double)v[u][1]; tt += (double)v[u][2]; }
+  }
+  for (; k < nchf; ++k) {
+    const float* p = p0 + (int64_t)k * 3 * ldp;
+    g2 += (double)p[0];
+    ss += (double)p[ldp];
+    tt += (double)p[2 * ldp];
   }
   G[(int64_t)frame * ldp + c] = (float)sqrt(g2);
   s[(int64_t)frame * ldp + c] = (float)ss;
@@ -675,14 +844,24 @@ static inline unsigned blocks_for(int64_t n) { return (unsigned)cdiv64(n, 256); 
 }  // namespace
 
 // ===================================================================================================== C-ABI
+// kernel choice and number of row slices: functions of the shape (and of VS_WGRAD, read once) only -- the summation order never depends on the launch
+static int wgrad_mode() {
+  static const int mode = [] { const char* e = getenv("VS_WGRAD"); return !e ? 0 : (!strcmp(e, "mfma") ? 1 : (!strcmp(e, "fma") ? 2 : 0)); }();
+  return mode;
+}
+static int64_t wgrad_splits(int64_t rows, int N, int64_t K) {
+  int64_t splits, maxs = cdiv64(rows, 256);
+  if (wgrad_mode() == 0 && N >= 64 && K >= 64)           // 128 x 128 tiles, two workgroups per CU: aim at 512 workgroups
+    splits = 512 / (cdiv64(N, 128) * cdiv64(K, 128));
+  else
+    splits = cdiv64(1024, cdiv64(N, 64) * cdiv64(K, 64));
+  if (splits > maxs) splits = maxs;
+  return splits < 1 ? 1 : splits;
+}
+
 extern "C" int64_t vs_gemm_wgrad_partial_floats(int64_t rows, int N, int K) {
   if (rows <= 0 || N <= 0 || K <= 0) return 0;
-  const int64_t tiles = cdiv64(N, 64) * cdiv64(K, 64);
-  int64_t splits = cdiv64(1024, tiles);
-  const int64_t maxs = cdiv64(rows, 256);
-  if (splits > maxs) splits = maxs;
-  if (splits < 1) splits = 1;
-  return splits * (int64_t)N * K;
+  return wgrad_splits(rows, N, K) * (int64_t)N * K;
 }
 
 extern "C" int vs_gemm_wgrad(const float* dy, int64_t dy_ld, int N, const float* x, int64_t x_ld, int K, int64_t rows, float* partial,
@@ -695,20 +874,83 @@ extern "C" int vs_gemm_wgrad(const float* dy, int64_t dy_ld, int N, const float*
   const int64_t used = cdiv64(rows, rps);                  // <= splits
   // VS_WGRAD=mfma selects the fp32 matrix-core kernel (validated on hardware: tests/test_gpu_bwd.py passes with it; v_mfma_f32_32x32x2_f32 has the
   // same 157 TFLOP/s peak as the vector FMAs, and the step time is the same within noise -- profiles/r03a_*).
-  static const int mode = [] { const char* e = getenv("VS_WGRAD"); return !e ? 0 : (!strcmp(e, "mfma") ? 1 : (!strcmp(e, "fma") ? 2 : 0)); }();
+  const int mode = wgrad_mode();
   // default: the 3 x bf16 matrix-core kernel where a 128 x 128 tile is at least half full, the fp32 vector kernel for the thin layers
   // (VS_WGRAD=fma / mfma force the two fp32 kernels everywhere)
   if (mode == 0 && N >= 64 && K >= 64)
-    hipLaunchKernelGGL(gemm_wgrad_bf16x3_kernel, dim3((unsigned)cdiv64(K, 128), (unsigned)cdiv64(N, 128), (unsigned)used), dim3(256), 0,
-                       (hipStream_t)stream, dy, dy_ld, N, x, x_ld, K, rows, rps, partial);
+    hipLaunchKernelGGL(gemm_wgrad_bf16x3_kernel<false>, dim3((unsigned)cdiv64(K, 128), (unsigned)cdiv64(N, 128), (unsigned)used), dim3(256), 0,
+                       (hipStream_t)stream, dy, dy_ld, N, x, x_ld, K, rows, rps, partial, wgrad_conv_t{});
   else if (mode == 1)
     hipLaunchKernelGGL(gemm_wgrad_mfma_kernel, dim3((unsigned)cdiv64(K, 128), (unsigned)cdiv64(N, 128), (unsigned)used), dim3(256), 0,
                        (hipStream_t)stream, dy, dy_ld, N, x, x_ld, K, rows, rps, partial);
   else
     hipLaunchKernelGGL(gemm_wgrad_kernel, dim3((unsigned)cdiv64(K, 64), (unsigned)cdiv64(N, 64), (unsigned)used), dim3(256), 0, (hipStream_t)stream,
                        dy, dy_ld, N, x, x_ld, K, rows, rps, partial);
-  hipLaunchKernelGGL(reduce_chunks_kernel, dim3(blocks_for((int64_t)N * K)), dim3(256), 0, (hipStream_t)stream, partial, (int)used,
+  hipLaunchKernelGGL(reduce_chunks_kernel, dim3((unsigned)cdiv64((int64_t)N * K, 64)), dim3(256), 0, (hipStream_t)stream, partial, (int)used,
                      (int64_t)N * K, dw);
+  return vs_launch_status();
+}
+
+// Weight gradient of a 3 x 3 conv (zero padding 1, stride 1 or 2) straight from the NHWC image: dw[n][tap * ld + c] = sum over output pixels of
+// dy[b, oy, ox, n] * x[b, oy * stride + ky - 1, ox * stride + kx - 1, c] -- what vs_im2col3x3(_strided) + vs_gemm_wgrad compute, without the patch
+// matrix.  Two kernels: the matrix-core kernel on the implicit patch matrix (N >= 64 and ld >= 64) and the register-tile kernel of the thin
+// outer levels (N, ld <= 32, N % 4 == 0); other shapes are not supported (the host keeps the patch-matrix route for them).
+static bool c3w_mfma(int N, int64_t ld) { return N >= 64 && ld >= 64; }
+static bool c3w_thin(int N, int64_t ld) { return N >= 4 && N <= 32 && (N & 3) == 0 && ld >= 4 && ld <= 32 && (ld & 3) == 0; }
+static wgrad_thin_t c3w_thin_geom(int N, int64_t ld, int B, int H, int W, int stride, size_t* lds_bytes, int* nwg) {
+  wgrad_thin_t g{};
+  g.H = H; g.W = W; g.cs = stride; g.co = N;
+  g.Ho = (H - 1) / stride + 1; g.Wo = (W - 1) / stride + 1;
+  g.tw_shift = 4;
+  g.TH = 16;
+  auto bytes = [&](int TH) { return (size_t)(((TH - 1) * stride + 3) * (15 * stride + 3) * ld + TH * 16 * N) * sizeof(float); };
+  while (g.TH > 2 && bytes(g.TH) > (size_t)40 << 10) g.TH >>= 1;        // two workgroups per CU with room to spare
+  g.tiles_x = (int)cdiv64(g.Wo, 16); g.tiles_y = (int)cdiv64(g.Ho, g.TH);
+  g.ntiles = B * g.tiles_x * g.tiles_y;
+  const int combos = (N >> 2) * (int)(ld >> 2);
+  g.L = 256 / combos;
+  *lds_bytes = bytes(g.TH) > (size_t)16 << 10 ? bytes(g.TH) : (size_t)16 << 10;
+  *nwg = g.ntiles < 512 ? g.ntiles : 512;
+  return g;
+}
+
+extern "C" int vs_conv3x3_wgrad_supported(int N, int64_t ld) { return (c3w_mfma(N, ld) || c3w_thin(N, ld)) ? 1 : 0; }
+
+extern "C" int64_t vs_conv3x3_wgrad_partial_floats(int N, int64_t ld, int B, int H, int W, int stride) {
+  if (N <= 0 || ld <= 0 || B <= 0 || H <= 0 || W <= 0 || (stride != 1 && stride != 2)) return 0;
+  if (c3w_mfma(N, ld)) return vs_gemm_wgrad_partial_floats((int64_t)B * ((H - 1) / stride + 1) * ((W - 1) / stride + 1), N, (int)(9 * ld));
+  if (!c3w_thin(N, ld)) return 0;
+  size_t lb; int nwg;
+  c3w_thin_geom(N, ld, B, H, W, stride, &lb, &nwg);
+  return (int64_t)nwg * N * 9 * ld;
+}
+
+extern "C" int vs_conv3x3_wgrad(const float* dy, int64_t dy_ld, int N, const float* x, int64_t ld, int B, int H, int W, int stride, float* partial,
+                                float* dw, void* stream) {
+  VS_REQUIRE(dy && x && partial && dw && vs_conv3x3_wgrad_supported(N, ld) && B > 0 && H > 0 && W > 0 && (stride == 1 || stride == 2) && dy_ld >= N &&
+             (dy_ld & 3) == 0 && (ld & 3) == 0);
+  VS_REQUIRE((((uintptr_t)dy) & 15) == 0 && (((uintptr_t)x) & 15) == 0);
+  const int Ho = (H - 1) / stride + 1, Wo = (W - 1) / stride + 1;
+  const int64_t rows = (int64_t)B * Ho * Wo;
+  VS_REQUIRE(rows < ((int64_t)1 << 31));
+  const int64_t K9 = 9 * ld;
+  int64_t used;
+  if (c3w_mfma(N, ld)) {
+    const int64_t splits = vs_gemm_wgrad_partial_floats(rows, N, (int)K9) / ((int64_t)N * K9);
+    int64_t rps = cdiv64(rows, splits);
+    rps = cdiv64(rps, 32) * 32;
+    used = cdiv64(rows, rps);
+    const int ktiles = (int)cdiv64(ld, 128);
+    hipLaunchKernelGGL(gemm_wgrad_bf16x3_kernel<true>, dim3((unsigned)(9 * ktiles), (unsigned)cdiv64(N, 128), (unsigned)used), dim3(256), 0,
+                       (hipStream_t)stream, dy, dy_ld, N, x, ld, (int)ld, rows, rps, partial, wgrad_conv_t{H, W, Ho, Wo, stride, ktiles});
+  } else {
+    size_t lb; int nwg;
+    const wgrad_thin_t g = c3w_thin_geom(N, ld, B, H, W, stride, &lb, &nwg);
+    hipLaunchKernelGGL(conv3x3_wgrad_thin_kernel, dim3((unsigned)nwg), dim3(256), lb, (hipStream_t)stream, dy, dy_ld, x, ld, g, partial);
+    used = nwg;
+  }
+  hipLaunchKernelGGL(reduce_chunks_kernel, dim3((unsigned)cdiv64((int64_t)N * K9, 64)), dim3(256), 0, (hipStream_t)stream, partial, (int)used,
+                     (int64_t)N * K9, dw);
   return vs_launch_status();
 }
 
@@ -724,16 +966,18 @@ extern "C" int vs_dwconv7(const float* x, int B, int H, int W, int C, int64_t ld
   return vs_launch_status();
 }
 
-extern "C" int64_t vs_dwconv7_wgrad_partial_floats(int B, int H, int64_t ld) { return (int64_t)B * cdiv64(H, 4) * 49 * ld; }
+// rows per chunk: single rows up to 2048 chunks, then bands (shape-only rule)
+static int vs_dwconv7_wgrad_rb(int B, int H) { return (int)cdiv64((int64_t)B * H, 2048); }
+extern "C" int64_t vs_dwconv7_wgrad_partial_floats(int B, int H, int64_t ld) { return (int64_t)B * cdiv64(H, vs_dwconv7_wgrad_rb(B, H)) * 49 * ld; }
 
 extern "C" int vs_dwconv7_wgrad(const float* x, int64_t ld, const float* dy, int64_t dy_ld, int B, int H, int W, int C, float* partial,
                                 float* dw, void* stream) {
   VS_REQUIRE(x && dy && partial && dw && B > 0 && H > 0 && W > 0 && C > 0 && ld >= C && (ld & 3) == 0 && dy_ld >= ld && (dy_ld & 3) == 0);
   VS_REQUIRE((((uintptr_t)x) & 15) == 0 && (((uintptr_t)dy) & 15) == 0);
-  const int RB = 4, nband = (int)cdiv64(H, RB);
+  const int RB = vs_dwconv7_wgrad_rb(B, H), nband = (int)cdiv64(H, RB);
   hipLaunchKernelGGL(dwconv7_wgrad_kernel, dim3((unsigned)(B * nband)), dim3(256), 0, (hipStream_t)stream, x, ld, dy, dy_ld, H, W, RB, nband,
                      (int)(ld >> 2), partial);
-  hipLaunchKernelGGL(reduce_chunks_kernel, dim3(blocks_for(49 * ld)), dim3(256), 0, (hipStream_t)stream, partial, B * nband, 49 * ld, dw);
+  hipLaunchKernelGGL(reduce_chunks_kernel, dim3((unsigned)cdiv64(49 * ld, 64)), dim3(256), 0, (hipStream_t)stream, partial, B * nband, 49 * ld, dw);
   return vs_launch_status();
 }
 
@@ -750,10 +994,10 @@ extern "C" int vs_layernorm_bwd(const float* x, int64_t ld, const float* dy, int
   const int64_t ldp = 4 * (int64_t)C4;
   const int nch = (int)cdiv64(rows, CR_ROWS);
   VS_REQUIRE(ldp <= ld && ldp <= dy_ld);
-  hipLaunchKernelGGL(colreduce_kernel<0>, dim3((unsigned)nch), dim3(256), 0, (hipStream_t)stream, x, ld, dy, dy_ld, stats, (int)rows, nch, C4, ldp,
+  hipLaunchKernelGGL(colreduce_kernel<0>, dim3((unsigned)nch, (unsigned)cdiv64(C4, 256)), dim3(256), 0, (hipStream_t)stream, x, ld, dy, dy_ld, stats, (int)rows, nch, C4, ldp,
                      partial);
   // partial[chunk][2][ldp]: element (v, c) of chunk k sits at k * 2 * ldp + v * ldp + c -> one reduction over 2 * ldp values, split afterwards
-  hipLaunchKernelGGL(reduce_chunks_kernel, dim3(blocks_for(2 * ldp)), dim3(256), 0, (hipStream_t)stream, partial, nch, 2 * ldp,
+  hipLaunchKernelGGL(reduce_chunks_kernel, dim3((unsigned)cdiv64(2 * ldp, 64)), dim3(256), 0, (hipStream_t)stream, partial, nch, 2 * ldp,
                      partial + (int64_t)nch * 2 * ldp);
   const float* tot = partial + (int64_t)nch * 2 * ldp;
   if (hipMemcpyAsync(dw, tot, (size_t)C * sizeof(float), hipMemcpyDeviceToDevice, (hipStream_t)stream) != hipSuccess) return VS_ERR_LAUNCH;
@@ -778,7 +1022,7 @@ extern "C" int vs_gelu_grn_bwd(const float* h1, int64_t ld, const float* d3, int
   float* cb = coef + 4 * (int64_t)B * ldp;
   float* nx = coef + 5 * (int64_t)B * ldp;
   hipStream_t st = (hipStream_t)stream;
-  hipLaunchKernelGGL(colreduce_kernel<1>, dim3((unsigned)(B * nchf)), dim3(256), 0, st, h1, ld, d3, d3_ld, (const float*)nullptr, HW, nchf, C4, ldp,
+  hipLaunchKernelGGL(colreduce_kernel<1>, dim3((unsigned)(B * nchf), (unsigned)cdiv64(C4, 256)), dim3(256), 0, st, h1, ld, d3, d3_ld, (const float*)nullptr, HW, nchf, C4, ldp,
                      partial);
   hipLaunchKernelGGL(grn_sums_kernel, dim3((unsigned)cdiv64(C, 256), (unsigned)B), dim3(256), 0, st, partial, nchf, ldp, C, G, s, t);
   hipLaunchKernelGGL(grn_coef_kernel, dim3((unsigned)B), dim3(256), 0, st, G, s, gamma, C, ldp, ca, cb, nx);

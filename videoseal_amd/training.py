@@ -11,6 +11,7 @@ exponent range for the gradients); everything else is csrc/bwd_ops.hip.  No CPU 
 Pinned against the reference's own `loss.backward()` (tests/golden/make_golden_bwd.py -> tests/test_gpu_bwd.py)."""
 from __future__ import annotations
 
+import os
 from typing import Dict, List, Optional, Tuple
 
 import torch
@@ -18,6 +19,7 @@ import torch
 from . import native as N
 from .engine import A_MUL_GRN, Act, ConvW, HipEngine, pack_conv, rup
 
+DIRECT_WGRAD = os.environ.get("VIDEOSEAL_DIRECT_WGRAD", "1") != "0"       # 0: 3x3 weight gradients through the explicit patch matrix (A/B)
 BWD_ARITH = 3          # 3 x bf16: exact operand split, fp32 exponent range (vs_conv_desc_t::arith)
 
 
@@ -415,8 +417,15 @@ class EmbedderBackward:
         return cols
 
     def _conv3_wgrad(self, eng, dy: Act, co: int, x: Act, ci: int, stride: int = 1) -> torch.Tensor:
-        cols = self._cols_zero(eng, x, stride, "cols3")
-        dw = self.h._wgrad(eng, dy, co, cols, 9 * x.ld)                       # [co][tap * ld + c]
+        L = eng.lib
+        if DIRECT_WGRAD and L.vs_conv3x3_wgrad_supported(co, x.ld):      # straight from the image (no rows x 9 ld floats of patches)
+            part = eng.buf("tr.wg.part", int(L.vs_conv3x3_wgrad_partial_floats(co, x.ld, x.B, x.H, x.W, stride)))
+            dw = torch.empty(co, 9 * x.ld, device=eng.dev, dtype=torch.float32)
+            N.check(L.vs_conv3x3_wgrad(N.ptr(dy.t), dy.ld, co, N.ptr(x.t), x.ld, x.B, x.H, x.W, stride, N.ptr(part), N.ptr(dw), N.stream()),
+                    "vs_conv3x3_wgrad")
+        else:
+            cols = self._cols_zero(eng, x, stride, "cols3")
+            dw = self.h._wgrad(eng, dy, co, cols, 9 * x.ld)                   # [co][tap * ld + c]
         return dw.view(co, 3, 3, x.ld)[..., :ci].permute(0, 3, 1, 2).contiguous()
 
     # ------------------------------------------------------------------ forward that keeps the backward's operands
