@@ -212,14 +212,18 @@ int vs_scale_shift_act(const float* x, int64_t rows, int C, int64_t ld, const fl
 int64_t vs_gemm_wgrad_partial_floats(int64_t rows, int N, int K);
 int vs_gemm_wgrad(const float* dy, int64_t dy_ld, int N, const float* x, int64_t x_ld, int K, int64_t rows, float* partial, float* dw,
                   void* stream);
-/* vs_conv3x3_wgrad: weight gradient of a 3x3 conv (zero padding 1, stride 1 | 2; unet.py:21-27, 52) straight from the NHWC image:
- * dw[n][tap * ld + c] -- the result of vs_im2col3x3(_strided) + vs_gemm_wgrad without the patch matrix.  Supported shapes
- * (vs_conv3x3_wgrad_supported): N >= 64 and ld >= 64 (matrix cores), or N, ld <= 32 with N % 4 == 0 (the thin outer levels).
- * partial: vs_conv3x3_wgrad_partial_floats(N, ld, B, H, W, stride) floats. */
-int vs_conv3x3_wgrad_supported(int N, int64_t ld);
+/* vs_conv3x3_wgrad: weight gradient of a 3x3 conv (padding 1: VS_PAD_ZERO with stride 1 | 2, unet.py:21-27, 52; VS_PAD_REFLECT with stride 1,
+ * the Upsample conv of unet.py:170-197) straight from the NHWC image: dw[n][tap * ld + c] -- the result of vs_im2col3x3(_strided) +
+ * vs_gemm_wgrad without the patch matrix.  Supported shapes (vs_conv3x3_wgrad_supported): N >= 64 and ld >= 64 (matrix cores), or
+ * N <= 32, ld <= 96 with N % 4 == 0 (the thin outer levels).  partial: vs_conv3x3_wgrad_partial_floats(N, ld, B, H, W, stride) floats.
+ * vs_pad_embed1 / vs_reflect_fold1: the backward-DATA pass of the reflection-padded conv = a zero-padded conv of the gradient placed in
+ * a zero canvas [B, H + 2, W + 2] (vs_pad_embed1), folded back onto [B, H, W] (vs_reflect_fold1: adjoint of reflection padding 1). */
+int vs_conv3x3_wgrad_supported(int N, int64_t ld, int stride);
 int64_t vs_conv3x3_wgrad_partial_floats(int N, int64_t ld, int B, int H, int W, int stride);
-int vs_conv3x3_wgrad(const float* dy, int64_t dy_ld, int N, const float* x, int64_t ld, int B, int H, int W, int stride, float* partial,
-                     float* dw, void* stream);
+int vs_conv3x3_wgrad(const float* dy, int64_t dy_ld, int N, const float* x, int64_t ld, int B, int H, int W, int stride, int pad_mode,
+                     float* partial, float* dw, void* stream);
+int vs_pad_embed1(const float* dy, int B, int H, int W, int64_t ld, float* out, void* stream);
+int vs_reflect_fold1(const float* dxp, int B, int H, int W, int64_t ld, float* out, void* stream);
 int vs_dwconv7(const float* x, int B, int H, int W, int C, int64_t ld, const float* w, const float* bias, int flip, const float* add,
                int64_t add_ld, float* out, int64_t out_ld, void* stream);
 int64_t vs_dwconv7_wgrad_partial_floats(int B, int H, int64_t ld);

@@ -50,36 +50,62 @@ def test_gemm_wgrad(rows, n, k, ldn, ldk):
     assert torch.equal(dw, dw2)          # deterministic
 
 
-@pytest.mark.parametrize("B,H,W,ci,co,stride", [(2, 12, 10, 64, 64, 1), (3, 9, 11, 70, 130, 1), (2, 16, 16, 128, 64, 2), (2, 15, 13, 64, 96, 2),
-                                                (1, 33, 17, 384, 384, 1), (16, 32, 32, 384, 384, 1),
-                                                # the thin outer levels (register-tile kernel): inc, down0, ups of the U-Net and odd shapes
-                                                (2, 20, 18, 16, 16, 1), (1, 256, 256, 3, 16, 1), (2, 33, 31, 16, 32, 2), (3, 40, 24, 32, 32, 1),
-                                                (2, 64, 64, 12, 8, 1), (4, 128, 128, 16, 32, 2), (1, 5, 3, 4, 4, 1)])
-def test_conv3x3_wgrad_from_the_image(B, H, W, ci, co, stride):
-    """vs_conv3x3_wgrad (matrix-core kernel on the implicit patch matrix) against the fp64 weight gradient of F.conv2d(stride, padding=1), in the
-    [co][tap * ld + c] layout of the patch-matrix route it replaces (unet.py:21-27 double_conv, :52 the stride-2 down conv)"""
+@pytest.mark.parametrize("B,H,W,ci,co,stride,reflect", [
+    (2, 12, 10, 64, 64, 1, 0), (3, 9, 11, 70, 130, 1, 0), (2, 16, 16, 128, 64, 2, 0), (2, 15, 13, 64, 96, 2, 0), (1, 33, 17, 384, 384, 1, 0),
+    (16, 32, 32, 384, 384, 1, 0),
+    # the thin outer levels (register-tile kernel): inc, down0, ups of the U-Net and odd shapes
+    (2, 20, 18, 16, 16, 1, 0), (1, 256, 256, 3, 16, 1, 0), (2, 33, 31, 16, 32, 2, 0), (3, 40, 24, 32, 32, 1, 0), (2, 64, 64, 12, 8, 1, 0),
+    (4, 128, 128, 16, 32, 2, 0), (1, 5, 3, 4, 4, 1, 0),
+    # reflection padding: the Upsample convs (cat of the up-sampled map and the skip: 48 -> 16 @256^2, 96 -> 32, 512 -> 128)
+    (2, 64, 48, 48, 16, 1, 1), (2, 40, 40, 96, 32, 1, 1), (2, 16, 24, 512, 128, 1, 1), (1, 2, 2, 8, 4, 1, 1), (1, 19, 35, 20, 12, 1, 1)])
+def test_conv3x3_wgrad_from_the_image(B, H, W, ci, co, stride, reflect):
+    """vs_conv3x3_wgrad (matrix-core kernel on the implicit patch matrix / register-tile kernel) against the fp64 weight gradient of
+    F.conv2d(stride, padding=1, zeros | reflect), in the [co][tap * ld + c] layout of the patch-matrix route it replaces
+    (unet.py:21-27 double_conv, :52 the stride-2 down conv, :170-197 the Upsample conv)"""
     L, st = _lib()
     ld = (ci + 3) // 4 * 4
     x = _rand(B, ci, H, W, seed=21)
     Ho, Wo = (H - 1) // stride + 1, (W - 1) // stride + 1
     dy = _rand(B, co, Ho, Wo, seed=23)
-    cols = F.unfold(x.double(), 3, padding=1, stride=stride)                    # [B, ci * 9, Ho * Wo]
+    xp = F.pad(x.double(), (1, 1, 1, 1), mode="reflect") if reflect else F.pad(x.double(), (1, 1, 1, 1))
+    cols = F.unfold(xp, 3, padding=0, stride=stride)                            # [B, ci * 9, Ho * Wo]
     wgrad = torch.einsum("bnl,bkl->nk", dy.double().reshape(B, co, -1), cols).reshape(co, ci, 3, 3)     # = autograd of F.conv2d w.r.t. the weight
     xa = _padded(x.permute(0, 2, 3, 1).reshape(-1, ci), ld).contiguous()
     dya = dy.permute(0, 2, 3, 1).reshape(-1, co).contiguous()
     ldn = (co + 3) // 4 * 4
     dya = _padded(dya, ldn)
-    rows = B * Ho * Wo
-    assert L.vs_conv3x3_wgrad_supported(co, ld)
+    assert L.vs_conv3x3_wgrad_supported(co, ld, stride)
     part = torch.empty(int(L.vs_conv3x3_wgrad_partial_floats(co, ld, B, H, W, stride)), device="cuda")
     dw = torch.full((co, 9 * ld), 7.0, device="cuda")
-    N.check(L.vs_conv3x3_wgrad(N.ptr(dya), ldn, co, N.ptr(xa), ld, B, H, W, stride, N.ptr(part), N.ptr(dw), st), "vs_conv3x3_wgrad")
+    pm = N.PAD_REFLECT if reflect else N.PAD_ZERO
+    N.check(L.vs_conv3x3_wgrad(N.ptr(dya), ldn, co, N.ptr(xa), ld, B, H, W, stride, pm, N.ptr(part), N.ptr(dw), st), "vs_conv3x3_wgrad")
     got = dw.view(co, 3, 3, ld)[..., :ci].permute(0, 3, 1, 2)
     assert (got.double() - wgrad).abs().max() <= 2e-5 * wgrad.abs().max()
     assert (dw.view(co, 9, ld)[..., ci:] == 0).all()
     dw2 = torch.empty_like(dw)
-    N.check(L.vs_conv3x3_wgrad(N.ptr(dya), ldn, co, N.ptr(xa), ld, B, H, W, stride, N.ptr(part), N.ptr(dw2), st), "vs_conv3x3_wgrad")
+    N.check(L.vs_conv3x3_wgrad(N.ptr(dya), ldn, co, N.ptr(xa), ld, B, H, W, stride, pm, N.ptr(part), N.ptr(dw2), st), "vs_conv3x3_wgrad")
     assert torch.equal(dw, dw2)          # deterministic
+
+
+@pytest.mark.parametrize("B,H,W,C,ld", [(2, 6, 7, 8, 8), (1, 2, 2, 4, 4), (3, 3, 9, 10, 12), (1, 64, 48, 48, 48)])
+def test_pad_embed_and_reflect_fold_are_the_adjoint_of_reflection_padding(B, H, W, C, ld):
+    """backward data of a reflection-padded conv = zero-padded conv over the padded map + vs_reflect_fold1; checked against autograd of F.pad"""
+    L, st = _lib()
+    x = _rand(B, C, H, W, seed=31).requires_grad_(True)
+    xp = F.pad(x, (1, 1, 1, 1), mode="reflect")
+    dxp = _rand(B, C, H + 2, W + 2, seed=32)
+    xp.backward(dxp)
+    dxpa = _padded(dxp.permute(0, 2, 3, 1).reshape(-1, C), ld).contiguous()
+    out = torch.full((B * H * W, ld), 7.0, device="cuda")
+    N.check(L.vs_reflect_fold1(N.ptr(dxpa), B, H, W, ld, N.ptr(out), st), "vs_reflect_fold1")
+    ref = x.grad.permute(0, 2, 3, 1).reshape(-1, C)
+    assert (out[:, :C] - ref).abs().max() <= 1e-6 * ref.abs().max()
+    dy = _padded(_rand(B * H * W, C, seed=33), ld)
+    canvas = torch.full((B * (H + 2) * (W + 2), ld), 7.0, device="cuda")
+    N.check(L.vs_pad_embed1(N.ptr(dy), B, H, W, ld, N.ptr(canvas), st), "vs_pad_embed1")
+    cv = canvas.view(B, H + 2, W + 2, ld)
+    assert torch.equal(cv[:, 1:-1, 1:-1], dy.view(B, H, W, ld))
+    assert (cv[:, 0] == 0).all() and (cv[:, -1] == 0).all() and (cv[:, :, 0] == 0).all() and (cv[:, :, -1] == 0).all()
 
 
 @pytest.mark.parametrize("B,H,W,C,ld", [(2, 9, 11, 6, 8), (3, 16, 16, 24, 24), (1, 5, 4, 4, 4), (1, 3, 2, 4, 4), (36, 64, 9, 8, 8), (2, 8, 23, 96, 96)])

@@ -201,10 +201,10 @@ __device__ __forceinline__ void split8(const float (&v)[8], u32x4 (&pl)[3]) {
 }
 }  // namespace wg16
 
-// CONV = true: the X operand is the implicit 3 x 3 patch matrix of an NHWC image (zero padding 1, stride cs): blockIdx.x = (tap, column
+// CONV = true: the X operand is the implicit 3 x 3 patch matrix of an NHWC image (zero or reflection padding 1, stride cs): blockIdx.x = (tap, column
 // tile of the image row), row r of dY is output pixel (b, oy, ox) and reads image pixel (oy * cs + ky - 1, ox * cs + kx - 1) -- the
 // weight gradient of a 3 x 3 conv without materialising rows x 9 ld floats of patches.  K is then the image's ld, dw is [N][9 * ld].
-struct wgrad_conv_t { int H, W, Ho, Wo, cs, ktiles; };
+struct wgrad_conv_t { int H, W, Ho, Wo, cs, ktiles, reflect; };
 template <bool CONV>
 __global__ __launch_bounds__(256, 2) void gemm_wgrad_bf16x3_kernel(const float* __restrict__ dy, int64_t dy_ld, int N, const float* __restrict__ x,
                                                                 int64_t x_ld, int K, int64_t rows, int64_t rows_per_split,
@@ -242,7 +242,11 @@ __global__ __launch_bounds__(256, 2) void gemm_wgrad_bf16x3_kernel(const float* 
       int oy = (int)(q - b * (unsigned)cv.Ho);
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
-        const int iy = oy * cv.cs + ky - 1, ix = ox * cv.cs + kx - 1;
+        int iy = oy * cv.cs + ky - 1, ix = ox * cv.cs + kx - 1;
+        if (cv.reflect) {                  // reflection padding 1: -1 -> 1, H -> H - 2
+          iy = iy < 0 ? -iy : (iy >= cv.H ? 2 * cv.H - 2 - iy : iy);
+          ix = ix < 0 ? -ix : (ix >= cv.W ? 2 * cv.W - 2 - ix : ix);
+        }
         const bool in = c_ok && (int64_t)rf + j < r_end && iy >= 0 && iy < cv.H && ix >= 0 && ix < cv.W;
         v[j] = in ? *reinterpret_cast<const f32x4*>(src + (((int64_t)b * cv.H + iy) * cv.W + ix) * sld) : f32x4{0.f, 0.f, 0.f, 0.f};
         if (++ox == cv.Wo) { ox = 0; if (++oy == cv.Ho) { oy = 0; ++b; } }
@@ -315,14 +319,14 @@ __global__ __launch_bounds__(256, 2) void gemm_wgrad_bf16x3_kernel(const float* 
 }
 
 // ---------------------------------------------------------------------------------------------------
-// Weight gradient of a THIN 3 x 3 conv (co, ci <= 32: the U-Net's outer levels, unet.py:21-27 at 256^2 / 128^2 -- a million rows against a
+// Weight gradient of a THIN 3 x 3 conv (co <= 32, ci <= 96: the U-Net's outer levels, unet.py:21-27 at 256^2 / 128^2 -- a million rows against a
 // 16 x 144 result) straight from the image.  These layers are not GEMM-shaped: the patch-matrix route wrote and re-read rows x 9 ld floats to
 // produce a few thousand numbers.  Here a workgroup walks over 16 x 16 (or 8 x 16) tiles of output pixels; per tile the dY tile and the x tile
 // with its halo go to LDS once, thread (a, b, p) owns the 9 x 4 x 4 results of output channels 4a.., input channels 4b.. and adds the pixels
 // p, p + L, .. of the tile: per pixel one 16-byte read of dY and nine of x feed 144 FMAs.  The workgroup keeps its sums in registers over
 // all of its tiles; at the end the L pixel lanes are added through LDS in lane order and the workgroup writes ONE partial result
 // [co][9 * ld]; reduce_chunks_kernel adds the workgroups' partials (fixed grid for a shape: deterministic).
-struct wgrad_thin_t { int H, W, Ho, Wo, cs, TH, tw_shift, tiles_x, tiles_y, ntiles, co, L; };
+struct wgrad_thin_t { int H, W, Ho, Wo, cs, TH, tw_shift, tiles_x, tiles_y, ntiles, co, L, reflect; };
 
 __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_thin_kernel(const float* __restrict__ dy, int64_t dy_ld, const float* __restrict__ x, int64_t ld,
                                                                     const wgrad_thin_t g, float* __restrict__ partial) {
@@ -350,7 +354,11 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_thin_kernel(const float*
     for (int i = t; i < IH * IW * nb; i += 256) {
       const int c4 = i % nb, pix = i / nb;
       const int yy = pix / IW, xx = pix - yy * IW;
-      const int gy = iy0 + yy, gx = ix0 + xx;
+      int gy = iy0 + yy, gx = ix0 + xx;
+      if (g.reflect) {                               // the one-pixel ring of reflection padding; further out only dY = 0 pixels look
+        gy = gy == -1 ? 1 : (gy == g.H ? g.H - 2 : gy);
+        gx = gx == -1 ? 1 : (gx == g.W ? g.W - 2 : gx);
+      }
       f32x4 v = {0.f, 0.f, 0.f, 0.f};
       if (gy >= 0 && gy < g.H && gx >= 0 && gx < g.W) v = *reinterpret_cast<const f32x4*>(x + (((int64_t)bi * g.H + gy) * g.W + gx) * ld + 4 * c4);
       *reinterpret_cast<f32x4*>(sx + (int64_t)pix * ld + 4 * c4) = v;
@@ -893,43 +901,52 @@ extern "C" int vs_gemm_wgrad(const float* dy, int64_t dy_ld, int N, const float*
 
 // Weight gradient of a 3 x 3 conv (zero padding 1, stride 1 or 2) straight from the NHWC image: dw[n][tap * ld + c] = sum over output pixels of
 // dy[b, oy, ox, n] * x[b, oy * stride + ky - 1, ox * stride + kx - 1, c] -- what vs_im2col3x3(_strided) + vs_gemm_wgrad compute, without the patch
-// matrix.  Two kernels: the matrix-core kernel on the implicit patch matrix (N >= 64 and ld >= 64) and the register-tile kernel of the thin
-// outer levels (N, ld <= 32, N % 4 == 0); other shapes are not supported (the host keeps the patch-matrix route for them).
+// matrix; pad_mode VS_PAD_REFLECT (stride 1) is the Upsample conv of unet.py:170-197.  Two kernels: the matrix-core kernel on the implicit patch
+// matrix (N >= 64 and ld >= 64) and the register-tile kernel of the thin outer levels (N <= 32, ld <= 96, N % 4 == 0); other shapes are
+// not supported (the host keeps the patch-matrix route for them).
 static bool c3w_mfma(int N, int64_t ld) { return N >= 64 && ld >= 64; }
-static bool c3w_thin(int N, int64_t ld) { return N >= 4 && N <= 32 && (N & 3) == 0 && ld >= 4 && ld <= 32 && (ld & 3) == 0; }
-static wgrad_thin_t c3w_thin_geom(int N, int64_t ld, int B, int H, int W, int stride, size_t* lds_bytes, int* nwg) {
+static size_t c3w_thin_bytes(int N, int64_t ld, int stride, int TH) {
+  return (size_t)(((TH - 1) * stride + 3) * (15 * stride + 3) * ld + TH * 16 * N) * sizeof(float);
+}
+static bool c3w_thin(int N, int64_t ld, int stride) {
+  return N >= 4 && N <= 32 && (N & 3) == 0 && ld >= 4 && ld <= 96 && (ld & 3) == 0 && (N >> 2) * (ld >> 2) <= 256 &&
+         c3w_thin_bytes(N, ld, stride, 2) <= ((size_t)40 << 10);
+}
+static wgrad_thin_t c3w_thin_geom(int N, int64_t ld, int B, int H, int W, int stride, int reflect, size_t* lds_bytes, int* nwg) {
   wgrad_thin_t g{};
-  g.H = H; g.W = W; g.cs = stride; g.co = N;
+  g.H = H; g.W = W; g.cs = stride; g.co = N; g.reflect = reflect;
   g.Ho = (H - 1) / stride + 1; g.Wo = (W - 1) / stride + 1;
   g.tw_shift = 4;
   g.TH = 16;
-  auto bytes = [&](int TH) { return (size_t)(((TH - 1) * stride + 3) * (15 * stride + 3) * ld + TH * 16 * N) * sizeof(float); };
-  while (g.TH > 2 && bytes(g.TH) > (size_t)40 << 10) g.TH >>= 1;        // two workgroups per CU with room to spare
+  while (g.TH > 2 && c3w_thin_bytes(N, ld, stride, g.TH) > ((size_t)40 << 10)) g.TH >>= 1;        // two workgroups per CU with room to spare
   g.tiles_x = (int)cdiv64(g.Wo, 16); g.tiles_y = (int)cdiv64(g.Ho, g.TH);
   g.ntiles = B * g.tiles_x * g.tiles_y;
   const int combos = (N >> 2) * (int)(ld >> 2);
   g.L = 256 / combos;
-  *lds_bytes = bytes(g.TH) > (size_t)16 << 10 ? bytes(g.TH) : (size_t)16 << 10;
+  const size_t tb = c3w_thin_bytes(N, ld, stride, g.TH);
+  *lds_bytes = tb > ((size_t)16 << 10) ? tb : ((size_t)16 << 10);
   *nwg = g.ntiles < 512 ? g.ntiles : 512;
   return g;
 }
 
-extern "C" int vs_conv3x3_wgrad_supported(int N, int64_t ld) { return (c3w_mfma(N, ld) || c3w_thin(N, ld)) ? 1 : 0; }
+extern "C" int vs_conv3x3_wgrad_supported(int N, int64_t ld, int stride) {
+  return ((stride == 1 || stride == 2) && (c3w_mfma(N, ld) || c3w_thin(N, ld, stride))) ? 1 : 0;
+}
 
 extern "C" int64_t vs_conv3x3_wgrad_partial_floats(int N, int64_t ld, int B, int H, int W, int stride) {
-  if (N <= 0 || ld <= 0 || B <= 0 || H <= 0 || W <= 0 || (stride != 1 && stride != 2)) return 0;
+  if (N <= 0 || ld <= 0 || B <= 0 || H <= 0 || W <= 0 || !vs_conv3x3_wgrad_supported(N, ld, stride)) return 0;
   if (c3w_mfma(N, ld)) return vs_gemm_wgrad_partial_floats((int64_t)B * ((H - 1) / stride + 1) * ((W - 1) / stride + 1), N, (int)(9 * ld));
-  if (!c3w_thin(N, ld)) return 0;
   size_t lb; int nwg;
-  c3w_thin_geom(N, ld, B, H, W, stride, &lb, &nwg);
+  c3w_thin_geom(N, ld, B, H, W, stride, 0, &lb, &nwg);
   return (int64_t)nwg * N * 9 * ld;
 }
 
-extern "C" int vs_conv3x3_wgrad(const float* dy, int64_t dy_ld, int N, const float* x, int64_t ld, int B, int H, int W, int stride, float* partial,
-                                float* dw, void* stream) {
-  VS_REQUIRE(dy && x && partial && dw && vs_conv3x3_wgrad_supported(N, ld) && B > 0 && H > 0 && W > 0 && (stride == 1 || stride == 2) && dy_ld >= N &&
-             (dy_ld & 3) == 0 && (ld & 3) == 0);
+extern "C" int vs_conv3x3_wgrad(const float* dy, int64_t dy_ld, int N, const float* x, int64_t ld, int B, int H, int W, int stride, int pad_mode,
+                                float* partial, float* dw, void* stream) {
+  VS_REQUIRE(dy && x && partial && dw && vs_conv3x3_wgrad_supported(N, ld, stride) && B > 0 && H > 0 && W > 0 && dy_ld >= N &&
+             (dy_ld & 3) == 0 && (ld & 3) == 0 && (pad_mode == VS_PAD_ZERO || (pad_mode == VS_PAD_REFLECT && stride == 1 && H >= 2 && W >= 2)));
   VS_REQUIRE((((uintptr_t)dy) & 15) == 0 && (((uintptr_t)x) & 15) == 0);
+  const int reflect = pad_mode == VS_PAD_REFLECT ? 1 : 0;
   const int Ho = (H - 1) / stride + 1, Wo = (W - 1) / stride + 1;
   const int64_t rows = (int64_t)B * Ho * Wo;
   VS_REQUIRE(rows < ((int64_t)1 << 31));
@@ -942,10 +959,10 @@ extern "C" int vs_conv3x3_wgrad(const float* dy, int64_t dy_ld, int N, const flo
     used = cdiv64(rows, rps);
     const int ktiles = (int)cdiv64(ld, 128);
     hipLaunchKernelGGL(gemm_wgrad_bf16x3_kernel<true>, dim3((unsigned)(9 * ktiles), (unsigned)cdiv64(N, 128), (unsigned)used), dim3(256), 0,
-                       (hipStream_t)stream, dy, dy_ld, N, x, ld, (int)ld, rows, rps, partial, wgrad_conv_t{H, W, Ho, Wo, stride, ktiles});
+                       (hipStream_t)stream, dy, dy_ld, N, x, ld, (int)ld, rows, rps, partial, wgrad_conv_t{H, W, Ho, Wo, stride, ktiles, reflect});
   } else {
     size_t lb; int nwg;
-    const wgrad_thin_t g = c3w_thin_geom(N, ld, B, H, W, stride, &lb, &nwg);
+    const wgrad_thin_t g = c3w_thin_geom(N, ld, B, H, W, stride, reflect, &lb, &nwg);
     hipLaunchKernelGGL(conv3x3_wgrad_thin_kernel, dim3((unsigned)nwg), dim3(256), lb, (hipStream_t)stream, dy, dy_ld, x, ld, g, partial);
     used = nwg;
   }

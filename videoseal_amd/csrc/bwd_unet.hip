@@ -130,6 +130,46 @@ __global__ __launch_bounds__(256) void dilate2_kernel(const float* __restrict__ 
   if (!(y & 1) && !(x & 1) && (y >> 1) < Ho && (x >> 1) < Wo) v = *reinterpret_cast<const f32x4*>(dy + ((b * Ho + (y >> 1)) * Wo + (x >> 1)) * ld + 4 * c4);
   *reinterpret_cast<f32x4*>(out + pix * ld + 4 * c4) = v;
 }
+// Adjoint of reflection padding 1 (the Upsample conv of unet.py:170-197 pads its input by reflection): dxp is the gradient on the padded
+// (H + 2) x (W + 2) map, out[y][x] = dxp[y + 1][x + 1] + the ring pixels that mirror onto (y, x): padded row 0 is row 1 again, padded row
+// H + 1 is row H - 2 (same for the columns).  Gather form, fixed order.
+__global__ __launch_bounds__(256) void reflect_fold_kernel(const float* __restrict__ dxp, int H, int W, int64_t ld, int64_t total, float* __restrict__ out) {
+  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;       // (pixel of the H x W map, c4)
+  if (idx >= total) return;
+  const int C4 = (int)(ld / 4);
+  const int c4 = (int)(idx % C4);
+  const int64_t pix = idx / C4;
+  const int x = (int)(pix % W);
+  const int64_t t = pix / W;
+  const int y = (int)(t % H);
+  const int64_t b = t / H;
+  int ys[3], xs[3], ny = 0, nx = 0;
+  ys[ny++] = y + 1;
+  if (y == 1) ys[ny++] = 0;
+  if (y == H - 2) ys[ny++] = H + 1;
+  xs[nx++] = x + 1;
+  if (x == 1) xs[nx++] = 0;
+  if (x == W - 2) xs[nx++] = W + 1;
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  for (int i = 0; i < ny; ++i)
+    for (int j = 0; j < nx; ++j) acc += *reinterpret_cast<const f32x4*>(dxp + ((b * (H + 2) + ys[i]) * (W + 2) + xs[j]) * ld + 4 * c4);
+  *reinterpret_cast<f32x4*>(out + pix * ld + 4 * c4) = acc;
+}
+// dy [B, H, W] rows -> the interior of a zero canvas [B, H + 2, W + 2] (the backward-data conv of a padded input runs over the padded map)
+__global__ __launch_bounds__(256) void pad_embed_kernel(const float* __restrict__ dy, int H, int W, int64_t ld, int64_t total, float* __restrict__ out) {
+  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;       // (pixel of the (H + 2) x (W + 2) canvas, c4)
+  if (idx >= total) return;
+  const int C4 = (int)(ld / 4);
+  const int c4 = (int)(idx % C4);
+  const int64_t pix = idx / C4;
+  const int x = (int)(pix % (W + 2));
+  const int64_t t = pix / (W + 2);
+  const int y = (int)(t % (H + 2));
+  const int64_t b = t / (H + 2);
+  f32x4 v = {0.f, 0.f, 0.f, 0.f};
+  if (y >= 1 && y <= H && x >= 1 && x <= W) v = *reinterpret_cast<const f32x4*>(dy + ((b * H + y - 1) * W + x - 1) * ld + 4 * c4);
+  *reinterpret_cast<f32x4*>(out + pix * ld + 4 * c4) = v;
+}
 // patch matrix of a 3x3 conv with zero padding 1 and stride s: cols[(b, oy, ox)][tap * ld + c] = x[b][oy s + ky - 1][ox s + kx - 1][c] or 0
 __global__ __launch_bounds__(256) void im2col3x3_zs_kernel(const float* __restrict__ x, int H, int W, int64_t ld, int s, int Ho, int Wo, int64_t total,
                                                            float* __restrict__ cols) {
@@ -289,6 +329,20 @@ extern "C" int vs_dilate2(const float* dy, int B, int Ho, int Wo, int64_t ld, in
   VS_REQUIRE((((uintptr_t)dy) & 15) == 0 && (((uintptr_t)out) & 15) == 0);
   const int64_t total = (int64_t)B * H * W * (ld / 4);
   hipLaunchKernelGGL(dilate2_kernel, dim3(blocks_for(total)), dim3(256), 0, (hipStream_t)stream, dy, Ho, Wo, ld, H, W, total, out);
+  return vs_launch_status();
+}
+
+extern "C" int vs_pad_embed1(const float* dy, int B, int H, int W, int64_t ld, float* out, void* stream) {
+  VS_REQUIRE(dy && out && B > 0 && H > 0 && W > 0 && ld > 0 && (ld & 3) == 0 && (((uintptr_t)dy) & 15) == 0 && (((uintptr_t)out) & 15) == 0);
+  const int64_t total = (int64_t)B * (H + 2) * (W + 2) * (ld / 4);
+  hipLaunchKernelGGL(pad_embed_kernel, dim3(blocks_for(total)), dim3(256), 0, (hipStream_t)stream, dy, H, W, ld, total, out);
+  return vs_launch_status();
+}
+
+extern "C" int vs_reflect_fold1(const float* dxp, int B, int H, int W, int64_t ld, float* out, void* stream) {
+  VS_REQUIRE(dxp && out && B > 0 && H >= 2 && W >= 2 && ld > 0 && (ld & 3) == 0 && (((uintptr_t)dxp) & 15) == 0 && (((uintptr_t)out) & 15) == 0);
+  const int64_t total = (int64_t)B * H * W * (ld / 4);
+  hipLaunchKernelGGL(reflect_fold_kernel, dim3(blocks_for(total)), dim3(256), 0, (hipStream_t)stream, dxp, H, W, ld, total, out);
   return vs_launch_status();
 }
 

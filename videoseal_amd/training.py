@@ -416,15 +416,19 @@ class EmbedderBackward:
             N.check(L.vs_im2col3x3_strided(N.ptr(x.t), x.B, x.H, x.W, x.ld, stride, N.ptr(cols.t), st), "vs_im2col3x3_strided")
         return cols
 
-    def _conv3_wgrad(self, eng, dy: Act, co: int, x: Act, ci: int, stride: int = 1) -> torch.Tensor:
+    def _conv3_wgrad(self, eng, dy: Act, co: int, x: Act, ci: int, stride: int = 1, pad_mode: int = N.PAD_ZERO) -> torch.Tensor:
         L = eng.lib
-        if DIRECT_WGRAD and L.vs_conv3x3_wgrad_supported(co, x.ld):      # straight from the image (no rows x 9 ld floats of patches)
+        if DIRECT_WGRAD and L.vs_conv3x3_wgrad_supported(co, x.ld, stride):      # straight from the image (no rows x 9 ld floats of patches)
             part = eng.buf("tr.wg.part", int(L.vs_conv3x3_wgrad_partial_floats(co, x.ld, x.B, x.H, x.W, stride)))
             dw = torch.empty(co, 9 * x.ld, device=eng.dev, dtype=torch.float32)
-            N.check(L.vs_conv3x3_wgrad(N.ptr(dy.t), dy.ld, co, N.ptr(x.t), x.ld, x.B, x.H, x.W, stride, N.ptr(part), N.ptr(dw), N.stream()),
+            N.check(L.vs_conv3x3_wgrad(N.ptr(dy.t), dy.ld, co, N.ptr(x.t), x.ld, x.B, x.H, x.W, stride, pad_mode, N.ptr(part), N.ptr(dw), N.stream()),
                     "vs_conv3x3_wgrad")
         else:
-            cols = self._cols_zero(eng, x, stride, "cols3")
+            if pad_mode == N.PAD_REFLECT:
+                cols = Act(eng.buf("tr.cols3", x.rows * 9 * x.ld, zero=True), x.B, x.H, x.W, 9 * x.ld, 9 * x.ld)
+                N.check(L.vs_im2col3x3(N.ptr(x.t), x.B, x.H, x.W, x.ld, N.PAD_REFLECT, N.ptr(cols.t), N.stream()), "vs_im2col3x3")
+            else:
+                cols = self._cols_zero(eng, x, stride, "cols3")
             dw = self.h._wgrad(eng, dy, co, cols, 9 * x.ld)                   # [co][tap * ld + c]
         return dw.view(co, 3, 3, x.ld)[..., :ci].permute(0, 3, 1, 2).contiguous()
 
@@ -488,22 +492,17 @@ class EmbedderBackward:
             cat = h._act(eng, f"e.up{k}.cat", B, 2 * xcur.H, 2 * xcur.W, xcur.C + skip.C)
             N.check(L.vs_upcat2x(N.ptr(xcur.t), xcur.C, xcur.ld, N.ptr(skip.t), skip.C, skip.ld, 2 ** -0.5, B, xcur.H, xcur.W, N.ptr(cat.t), cat.ld, st),
                     "vs_upcat2x")
-            wup = g(f"embedder.unet.ups.{k}.up.upsample_block.2.weight").float()              # [cout, cin, 3, 3]
-            wcols = torch.zeros(cout, 9, cat.ld, device=eng.dev)
-            wcols[:, :, : cat.C] = wup.permute(0, 2, 3, 1).reshape(cout, 9, cat.C)
-            wcols = wcols.reshape(cout, 9 * cat.ld)
-            pw, cpw = pack_conv(wcols[:, :, None, None], 9 * cat.ld)
-            cols = Act(eng.buf(f"tr.e.up{k}.cols", cat.rows * 9 * cat.ld, zero=True), B, cat.H, cat.W, 9 * cat.ld, 9 * cat.ld)
-            N.check(L.vs_im2col3x3(N.ptr(cat.t), B, cat.H, cat.W, cat.ld, N.PAD_REFLECT, N.ptr(cols.t), st), "vs_im2col3x3")
+            wup = g(f"embedder.unet.ups.{k}.up.upsample_block.2.weight").float()              # [cout, cin, 3, 3]; reflection padding (unet.py:181)
+            pw, cpw = pack_conv(wup, cat.ld)
             cv = h._act(eng, f"e.up{k}.cv", B, cat.H, cat.W, cout)
-            eng.conv(cols, ConvW(pw, None, cout, 1, 1, cpw), cv)
+            eng.conv(cat, ConvW(pw, None, cout, 3, 3, cpw), cv, pad=1, pad_mode=N.PAD_REFLECT)
             z = h._act(eng, f"e.up{k}.z", B, cat.H, cat.W, cout)
             eng.layernorm(cv, up["lnw"], up["lnb"], z)
             ln = h._act(eng, f"e.up{k}.ln", B, cat.H, cat.W, cout)
             self._affine_act(eng, z, h._vec(eng, z.ld, 1.0), h._vec(eng, z.ld, 0.0), N.ACT_RELU, ln)
             xin = xcur
             xcur, rec = self._resblock_keep(eng, ln, up["rb"], f"e.up{k}")
-            S["ups"].append(dict(xin=xin, skip=skip, cat=cat, cols=cols, wcols=wcols, cv=cv, z=z, rb=rec, cout=cout))
+            S["ups"].append(dict(xin=xin, skip=skip, cat=cat, cv=cv, z=z, rb=rec, cout=cout))
         delta = torch.empty(B * c.out_ch * xcur.H * xcur.W, device=eng.dev, dtype=torch.float32)
         N.check(L.vs_outc_tanh(N.ptr(xcur.t), xcur.H * xcur.W, B, xcur.C, xcur.ld, N.ptr(E["outc_w"]), N.ptr(E["outc_b"]), c.out_ch,
                                1 if c.last_tanh else 0, N.ptr(delta), st), "vs_outc_tanh")
@@ -560,17 +559,20 @@ class EmbedderBackward:
             rec, up = S["ups"][k], E["ups"][k]
             name = f"{u}.ups.{k}"
             dln = self._resblock_bwd(eng, rec["rb"], up["rb"], name + ".conv", dcur, G, f"e.g.up{k}")
-            z, cv, cat, cols, cout = rec["z"], rec["cv"], rec["cat"], rec["cols"], rec["cout"]
+            z, cv, cat, cout = rec["z"], rec["cv"], rec["cat"], rec["cout"]
             dz = h._act(eng, f"e.g.up{k}.dz", B, z.H, z.W, cout)
             N.check(L.vs_relu_bwd(N.ptr(z.t), z.ld, N.ptr(dln.t), dln.ld, z.rows, cout, N.ptr(dz.t), dz.ld, st), "vs_relu_bwd")
             dcv, dw, db = h._ln_bwd(eng, cv, dz, up["lnw"], f"e.g.up{k}.dcv")
             G[name + ".up.upsample_block.3.weight"], G[name + ".up.upsample_block.3.bias"] = dw, db
-            dwc = h._wgrad(eng, dcv, cout, cols, 9 * cat.ld)
-            G[name + ".up.upsample_block.2.weight"] = dwc.view(cout, 3, 3, cat.ld)[..., : cat.C].permute(0, 3, 1, 2).contiguous()
-            dcols = Act(eng.buf(f"tr.e.g.up{k}.dcols", cat.rows * 9 * cat.ld, zero=True), B, cat.H, cat.W, 9 * cat.ld, 9 * cat.ld)
-            eng.conv(dcv, h._tw(rec["wcols"], dcv.ld), dcols, arith=BWD_ARITH)
+            wname = name + ".up.upsample_block.2.weight"
+            G[wname] = self._conv3_wgrad(eng, dcv, cout, cat, cat.C, pad_mode=N.PAD_REFLECT)
+            # backward data of the reflection-padded conv: the zero-padded transposed conv over the PADDED map, folded back onto the image
+            canvas = h._act(eng, f"e.g.up{k}.canvas", B, cat.H + 2, cat.W + 2, cout, dcv.ld)
+            N.check(L.vs_pad_embed1(N.ptr(dcv.t), B, cat.H, cat.W, dcv.ld, N.ptr(canvas.t), st), "vs_pad_embed1")
+            dxp = h._act(eng, f"e.g.up{k}.dxp", B, cat.H + 2, cat.W + 2, cat.C, cat.ld)
+            eng.conv(canvas, self._flip_t(g(wname), canvas.ld), dxp, pad=1, arith=BWD_ARITH)
             dcat = h._act(eng, f"e.g.up{k}.dcat", B, cat.H, cat.W, cat.C, cat.ld)
-            N.check(L.vs_col2im3x3_reflect(N.ptr(dcols.t), B, cat.H, cat.W, cat.ld, N.ptr(dcat.t), st), "vs_col2im3x3_reflect")
+            N.check(L.vs_reflect_fold1(N.ptr(dxp.t), B, cat.H, cat.W, cat.ld, N.ptr(dcat.t), st), "vs_reflect_fold1")
             xin, skip = rec["xin"], rec["skip"]
             dxin = h._act(eng, f"e.g.up{k}.dxin", B, xin.H, xin.W, xin.C, xin.ld)
             dsk = h._act(eng, f"e.g.up{k}.dskip", B, skip.H, skip.W, skip.C, skip.ld)
