@@ -659,7 +659,10 @@ def test_rmsnorm_act(eng, shape):
     assert (out.cpu()[:, :Cc] - ref).abs().max() < 2e-6 and (out.cpu()[:, Cc:] == 0).all()
 
 
-@pytest.mark.parametrize("cfg", [(2, 16, 16, 6, 64, 0), (2, 16, 16, 6, 64, 8), (3, 8, 8, 2, 16, 4), (1, 8, 12, 3, 32, 0), (2, 8, 8, 2, 16, 0)])
+@pytest.mark.parametrize("cfg", [(2, 16, 16, 6, 64, 0), (2, 16, 16, 6, 64, 8), (3, 8, 8, 2, 16, 4), (1, 8, 12, 3, 32, 0), (2, 8, 8, 2, 16, 0),
+                                 # matrix-core kernel: 64 / 128 / 256 tokens per group x head sizes 16 / 32 / 64 (the first two rows above as well)
+                                 (1, 8, 16, 2, 32, 0), (1, 16, 16, 2, 16, 0), (2, 16, 8, 3, 32, 8), (1, 16, 16, 1, 32, 0), (1, 16, 8, 2, 64, 0),
+                                 (2, 32, 16, 2, 16, 8)])
 def test_vit_attention(eng, cfg):
     """vit.py:302-360 Attention.forward core (scaled q.k^T + decomposed relative positions, softmax, @v) incl. the window partition
     of vit.py:363-402, against the same maths in torch fp32"""

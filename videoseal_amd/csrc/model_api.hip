@@ -30,7 +30,10 @@ struct CW {                      // one conv / linear layer on the device
 struct RB { CW c0, c1, res; int cout = 0; };
 struct Up { CW conv; CW gemm; bool lowres = false; float* lnw = nullptr; float* lnb = nullptr; RB rb; };   // gemm: nine taps at the low resolution (vs_upconv_gather_ln)
 struct Down { float* lnw = nullptr; float* lnb = nullptr; CW conv; };
-struct Blk { float *wdw = nullptr, *bdw = nullptr, *lnw = nullptr, *lnb = nullptr, *gamma = nullptr, *beta = nullptr; CW pw1, pw2; };
+struct Blk {
+  float *wdw = nullptr, *bdw = nullptr, *lnw = nullptr, *lnb = nullptr, *gamma = nullptr, *beta = nullptr; CW pw1, pw2;
+  void* fuse = nullptr; float fm1 = 1.f, fm2 = 1.f;      // weight image of the fused block kernel (vs_cnx_block) and its two power-of-two scales
+};
 
 struct Act { float* p; int B, H, W, C, ld; int64_t rows() const { return (int64_t)B * H * W; } };
 
@@ -148,6 +151,42 @@ struct Packer {
             }
           }
       }
+  }
+  // engine.py::pack_cnx_block: weight image of csrc/convnext_fused.hip for one ConvNeXt block.  w1 [4C][C], w2 [C][4C], b1 / beta [4C].
+  // Per block of 32 h-channels: W1 rows as A fragments [k-step][plane][half][row 32][8]; W2 as B fragments [n-block][s][plane][half][n 32][8]
+  // with the reduction index enumerated as k(s, half, v) = 8 (2 s + v / 4) + 4 half + v % 4; then 256 floats: b1[32], beta[32], zeros.
+  void* cnx_image(const HostT& w1, const HostT& b1, const HostT& w2, const HostT& beta, int C, float& m1, float& m2) {
+    const int H4 = 4 * C, nhb = H4 / 32, ks1 = C / 16, nb = C / 32;
+    if (!w1.p || !b1.p || !w2.p || !beta.p || w1.n != (int64_t)H4 * C || w2.n != (int64_t)H4 * C || b1.n < H4 || beta.n < H4) return nullptr;
+    std::vector<uint16_t> p1, p2;
+    m1 = split2(std::vector<float>(w1.p, w1.p + w1.n), p1);          // [plane][4C][C]
+    m2 = split2(std::vector<float>(w2.p, w2.p + w2.n), p2);          // [plane][C][4C]
+    const size_t per_hb = (size_t)2048 * (ks1 + nb) + 1024;
+    if ((int64_t)(per_hb * nhb) != vs_cnx_block_image_bytes(C)) return nullptr;
+    std::vector<uint8_t> img(per_hb * nhb, 0);
+    const size_t n1 = (size_t)H4 * C;
+    for (int hb = 0; hb < nhb; ++hb) {
+      uint16_t* i1 = reinterpret_cast<uint16_t*>(img.data() + per_hb * hb);
+      uint16_t* i2 = i1 + (size_t)1024 * ks1;
+      float* aux = reinterpret_cast<float*>(img.data() + per_hb * hb + (size_t)2048 * (ks1 + nb));
+      for (int ks = 0; ks < ks1; ++ks)
+        for (int pl = 0; pl < 2; ++pl)
+          for (int half = 0; half < 2; ++half)
+            for (int mm = 0; mm < 32; ++mm)
+              for (int v = 0; v < 8; ++v)
+                i1[((((size_t)ks * 2 + pl) * 2 + half) * 32 + mm) * 8 + v] = p1[pl * n1 + (size_t)(hb * 32 + mm) * C + ks * 16 + half * 8 + v];
+      for (int b = 0; b < nb; ++b)
+        for (int s2 = 0; s2 < 2; ++s2)
+          for (int pl = 0; pl < 2; ++pl)
+            for (int half = 0; half < 2; ++half)
+              for (int n = 0; n < 32; ++n)
+                for (int vh = 0; vh < 2; ++vh)
+                  for (int e = 0; e < 4; ++e)
+                    i2[((((((size_t)b * 2 + s2) * 2 + pl) * 2 + half) * 32 + n) * 2 + vh) * 4 + e] =
+                        p2[pl * n1 + (size_t)(b * 32 + n) * H4 + 32 * hb + 8 * (2 * s2 + vh) + 4 * half + e];
+      for (int i = 0; i < 32; ++i) { aux[i] = b1.p[hb * 32 + i]; aux[32 + i] = beta.p[hb * 32 + i]; }
+    }
+    return upload(img);
   }
   void finish(CW& cw, const std::vector<float>& wt, const std::vector<float>& bias, bool has_bias, CW* as_gemm = nullptr) {
     cw.wt = upload(wt);
@@ -558,9 +597,21 @@ struct Runner {
         while (tiles2 * sk2 < 200 && steps2 / (sk2 * 2) >= 24 && steps2 % (sk2 * 2) == 0) sk2 *= 2;
         pl2 = tiles2 * sk2 >= 128;
       }
-      void* tnpl = pl1 ? alloc(rows * pw1w.CinP) : nullptr;
+      // engine.py::_extractor_forward: pwconv1 -> GELU -> GRN -> pwconv2 with h on chip (statistics pass, scale, apply pass in place on cur)
+      const bool fused = m->arith == 2 && !m->stages[sti].empty() && m->stages[sti][0].fuse && pw1w.CinP == Cc && vs_cnx_block_supported(Cc, rows, HW);
+      void* tnpl = (pl1 || fused) ? alloc(rows * pw1w.CinP) : nullptr;
       void* hpl = pl2 ? alloc(rows * hh.ld) : nullptr;
       for (const Blk& blk : m->stages[sti]) {
+        if (fused && blk.fuse) {
+          if (live()) {
+            chk(vs_dwconv7_ln_planes(cur.p, B, cur.H, cur.W, Cc, cur.ld, blk.wdw, blk.bdw, blk.lnw, blk.lnb, 1e-6f, A_MUL, pw1w.CinP, tnpl, st));
+            const float am1 = 1.f / (A_MUL * blk.fm1), am2 = 1.f / (A_MUL_GRN * blk.fm2);
+            chk(vs_cnx_block(tnpl, blk.fuse, Cc, rows, HW, 1, am1, am2, nullptr, 0, nullptr, nullptr, 0, nullptr, 0, part32, st));
+            chk(vs_grn_scale_from_partials(part32, B, HW, 4 * Cc, blk.gamma, scale, hh.ld, st));
+            chk(vs_cnx_block(tnpl, blk.fuse, Cc, rows, HW, 0, am1, am2, scale, hh.ld, blk.pw2.bias, cur.p, cur.ld, cur.p, cur.ld, nullptr, st));
+          }
+          continue;
+        }
         if (pl1) {
           if (live()) chk(vs_dwconv7_ln_planes(cur.p, B, cur.H, cur.W, Cc, cur.ld, blk.wdw, blk.bdw, blk.lnw, blk.lnb, 1e-6f, A_MUL, pw1w.CinP, tnpl, st));
         } else if (live()) {
@@ -723,6 +774,9 @@ extern "C" int vs_model_create(const vs_model_cfg_t* cfg, const vs_tensor_t* ten
       b.beta = P.vec(p + ".grn.beta", rup(ld4, 16));
       P.conv(b.pw1, p + ".pwconv1.weight", Cc, 1, 1, ld, nullptr, nullptr, p + ".pwconv1.bias");
       P.conv(b.pw2, p + ".pwconv2.weight", 4 * Cc, 1, 1, ld4, nullptr, nullptr, p + ".pwconv2.bias");
+      if (s < 2 && (Cc == 96 || Cc == 192) && m->arith == 2)      // engine.py::_pack_extractor: the fused block kernel of stages 0 / 1
+        b.fuse = P.cnx_image(P.get(p + ".pwconv1.weight"), P.get(p + ".pwconv1.bias"), P.get(p + ".pwconv2.weight"), P.get(p + ".grn.beta"), Cc,
+                             b.fm1, b.fm2);
     }
   }
   const std::string pd = "detector.pixel_decoder";
