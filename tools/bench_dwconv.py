@@ -9,8 +9,9 @@ L = N.lib()
 B = 32
 print("VS_DWCONV =", os.environ.get("VS_DWCONV", "auto"))
 for HW, Cc in ((64, 96), (32, 192), (16, 384), (8, 768)):
-    x = torch.randn(B, HW, HW, Cc, device="cuda"); out = torch.empty_like(x)
-    wdw = torch.randn(49, Cc, device="cuda"); v = [torch.randn(Cc, device="cuda") for _ in range(3)]
+    g = torch.Generator(device="cuda").manual_seed(HW)
+    x = torch.randn(B, HW, HW, Cc, device="cuda", generator=g); out = torch.empty_like(x)
+    wdw = torch.randn(49, Cc, device="cuda", generator=g); v = [torch.randn(Cc, device="cuda", generator=g) for _ in range(3)]
     fn = lambda: N.check(L.vs_dwconv7_ln(N.ptr(x), B, HW, HW, Cc, Cc, N.ptr(wdw), N.ptr(v[0]), N.ptr(v[1]), N.ptr(v[2]), 1e-6, N.ptr(out), Cc, N.stream()), "dw")
     for _ in range(3): fn()
     torch.cuda.synchronize()
@@ -21,4 +22,5 @@ for HW, Cc in ((64, 96), (32, 192), (16, 384), (8, 768)):
         for _ in range(20): fn()
         e1.record(); torch.cuda.synchronize()
         best = min(best, e0.elapsed_time(e1) / 20)
-    print(f"dwconv7_ln {HW}x{HW} C={Cc}: {best*1e3:7.1f} us  {2*x.numel()*4/best/1e6:6.0f} GB/s  ({49*x.numel()*2/best/1e9:5.1f} TFLOP/s fp32 FMA)")
+    bits = int(out.view(torch.int32).to(torch.int64).sum())          # every configuration must print the same number (bit-identical outputs)
+    print(f"dwconv7_ln {HW}x{HW} C={Cc}: {best*1e3:7.1f} us  {2*x.numel()*4/best/1e6:6.0f} GB/s  ({49*x.numel()*2/best/1e9:5.1f} TFLOP/s fp32 FMA)  bits {bits}")
