@@ -223,6 +223,15 @@ int64_t vs_conv3x3_wgrad_partial_floats(int N, int64_t ld, int B, int H, int W, 
 int vs_conv3x3_wgrad(const float* dy, int64_t dy_ld, int N, const float* x, int64_t ld, int B, int H, int W, int stride, int pad_mode,
                      float* partial, float* dw, void* stream);
 int vs_pad_embed1(const float* dy, int B, int H, int W, int64_t ld, float* out, void* stream);
+/* ---- backward of the SAM-style ViT extractor of the legacy card (csrc/bwd_vit.hip; vit.py:146-193, 302-360, 436-470).
+ * vs_gelu_bwd: dz = dy * gelu'(z) (rows of C values; pad columns of dz are zeroed).
+ * vs_vit_attention_bwd: adjoint of vs_vit_attention.  qkv / out: the forward's operand and result, dout: gradient of out; dqkv receives
+ * (dq | dk | dv) in qkv's layout; drel_h / drel_w [2 * T - 1][hd] the gradients of the two relative-position tables (NULL with rel_h ==
+ * NULL).  scratch: vs_vit_attention_bwd_scratch_floats(...) floats.  Deterministic (no atomics). */
+int vs_gelu_bwd(const float* z, int64_t ld, const float* dy, int64_t dy_ld, int64_t rows, int C, float* dz, int64_t dz_ld, void* stream);
+int64_t vs_vit_attention_bwd_scratch_floats(int frames, int H, int W, int heads, int window);
+int vs_vit_attention_bwd(const float* qkv, const float* out, const float* dout, int frames, int H, int W, int heads, int hd, int window,
+                         const float* rel_h, const float* rel_w, float* dqkv, float* scratch, float* drel_h, float* drel_w, void* stream);
 int vs_reflect_fold1(const float* dxp, int B, int H, int W, int64_t ld, float* out, void* stream);
 int vs_dwconv7(const float* x, int B, int H, int W, int C, int64_t ld, const float* w, const float* bias, int flip, const float* add,
                int64_t add_ld, float* out, int64_t out_ld, void* stream);

@@ -373,3 +373,110 @@ def test_detector_step_full_size_architecture_matches_oracle_autograd():
         worst = max(worst, err)
         assert err < 3e-3, (k, err)
     print(f"worst relative gradient error over {len(names)} tensors: {worst:.2e}")
+
+
+# ---------------------------------------------------------------------------------------------------------- ViT extractor (legacy card)
+@pytest.mark.parametrize("rows,C,ld", [(100, 20, 20), (37, 130, 132), (1000, 1536, 1536)])
+def test_gelu_bwd(rows, C, ld):
+    L, st = _lib()
+    z = _rand(rows, C, seed=41).requires_grad_(True)
+    dy = _rand(rows, C, seed=42)
+    F.gelu(z).backward(dy)
+    dz = torch.full((rows, ld), 7.0, device="cuda")
+    za, dya = _padded(z.detach(), ld), _padded(dy, ld)          # (kept alive: the C-ABI only sees raw pointers)
+    N.check(L.vs_gelu_bwd(N.ptr(za), ld, N.ptr(dya), ld, rows, C, N.ptr(dz), ld, st), "vs_gelu_bwd")
+    assert (dz[:, :C] - z.grad).abs().max() <= 2e-6 * z.grad.abs().max() + 1e-7
+    assert (dz[:, C:] == 0).all()
+
+
+@pytest.mark.parametrize("cfg", [(2, 16, 16, 6, 64, 0), (2, 16, 16, 6, 64, 8), (3, 8, 8, 2, 16, 4), (1, 8, 12, 3, 32, 0), (2, 8, 8, 2, 16, 0),
+                                 (1, 16, 8, 2, 32, 8), (2, 4, 4, 1, 16, 0)])
+def test_vit_attention_bwd(cfg):
+    """vs_vit_attention_bwd against torch autograd of vit.py:302-360 (scaled q.k^T + decomposed relative positions, softmax, @v) incl. the
+    window partition: d qkv and the two relative-position tables"""
+    L, st = _lib()
+    B, H, W, heads, hd, win = cfg
+    D = heads * hd
+    g = torch.Generator().manual_seed(43)
+    qkv = torch.randn(B, H, W, 3 * D, generator=g).cuda().requires_grad_(True)
+    Th, Tw = (win, win) if win else (H, W)
+    rel_h = (0.3 * torch.randn(2 * Th - 1, hd, generator=g)).cuda().requires_grad_(True)
+    rel_w = (0.3 * torch.randn(2 * Tw - 1, hd, generator=g)).cuda().requires_grad_(True)
+    x = qkv
+    if win:
+        x = x.view(B, H // win, win, W // win, win, 3 * D).permute(0, 1, 3, 2, 4, 5).reshape(-1, win, win, 3 * D)
+    Bw = x.shape[0]
+    q, k, v = x.reshape(Bw, Th * Tw, 3, heads, hd).permute(2, 0, 3, 1, 4).reshape(3, Bw * heads, Th * Tw, hd).unbind(0)
+    attn = (q * hd ** -0.5) @ k.transpose(-2, -1)
+    ih = (torch.arange(Th)[:, None] - torch.arange(Th)[None, :] + Th - 1).cuda()
+    iw = (torch.arange(Tw)[:, None] - torch.arange(Tw)[None, :] + Tw - 1).cuda()
+    rq = q.reshape(Bw * heads, Th, Tw, hd)
+    attn = (attn.view(Bw * heads, Th, Tw, Th, Tw) + torch.einsum("bhwc,hkc->bhwk", rq, rel_h[ih])[:, :, :, :, None]
+            + torch.einsum("bhwc,wkc->bhwk", rq, rel_w[iw])[:, :, :, None, :]).view(Bw * heads, Th * Tw, Th * Tw)
+    o = (attn.softmax(-1) @ v).view(Bw, heads, Th, Tw, hd).permute(0, 2, 3, 1, 4).reshape(Bw, Th, Tw, D)
+    if win:
+        o = o.view(B, H // win, W // win, win, win, D).permute(0, 1, 3, 2, 4, 5).reshape(B, H, W, D)
+    do = torch.randn(B, H, W, D, generator=g).cuda()
+    o.backward(do)
+    out = torch.empty(B, H, W, D, device="cuda")
+    qd, rh, rw = qkv.detach().contiguous(), rel_h.detach().contiguous(), rel_w.detach().contiguous()
+    N.check(L.vs_vit_attention(N.ptr(qd), B, H, W, heads, hd, win, N.ptr(rh), N.ptr(rw), N.ptr(out), st), "attn")
+    dqkv = torch.full((B, H, W, 3 * D), 7.0, device="cuda")
+    scr = torch.empty(int(L.vs_vit_attention_bwd_scratch_floats(B, H, W, heads, win)), device="cuda")
+    drh, drw = torch.full_like(rh, 7.0), torch.full_like(rw, 7.0)
+    N.check(L.vs_vit_attention_bwd(N.ptr(qd), N.ptr(out), N.ptr(do), B, H, W, heads, hd, win, N.ptr(rh), N.ptr(rw), N.ptr(dqkv), N.ptr(scr), N.ptr(drh),
+                                   N.ptr(drw), st), "vs_vit_attention_bwd")
+    torch.cuda.synchronize()
+    assert (dqkv - qkv.grad).abs().max() <= 2e-4 * qkv.grad.abs().max()
+    assert (drh - rel_h.grad).abs().max() <= 2e-4 * rel_h.grad.abs().max()
+    assert (drw - rel_w.grad).abs().max() <= 2e-4 * rel_w.grad.abs().max()
+    dq2 = torch.empty_like(dqkv)
+    N.check(L.vs_vit_attention_bwd(N.ptr(qd), N.ptr(out), N.ptr(do), B, H, W, heads, hd, win, N.ptr(rh), N.ptr(rw), N.ptr(dq2), N.ptr(scr), N.ptr(drh),
+                                   N.ptr(drw), st), "vs_vit_attention_bwd")
+    assert torch.equal(dqkv, dq2)          # deterministic
+
+
+@pytest.mark.parametrize("which", ["tiny", "card"])
+def test_detector_step_vit_extractor_matches_oracle_autograd(which):
+    """The detector fine-tuning step for `extractor: sam` (the legacy videoseal_0.0 card; vit.py:14-144): every `detector.*` gradient -- patch
+    embedding, absolute and relative position tables, attention / MLP / LayerNorm weights of every block, neck, pixel decoder -- against torch
+    autograd through the oracle's functional forward (CPU, fp32).  'tiny': 8 x 8 tokens, 4 x 4 windows + global blocks, 16-wide heads;
+    'card': the released architecture (16 x 16 tokens, windows of 8, 64-wide heads) on two frames.  The position tables are zero-initialised
+    in the reference (vit.py:66-69, 334-336): seeded random values here so that their terms take part."""
+    import os
+    from oracle import loss as OL
+    from oracle import videoseal_ref as R
+    from oracle.inputs import synthetic_frames, synthetic_msgs
+    from oracle.weights import legacy_tiny_spec, spec_from_card
+    from tests.test_oracle_golden import CARDS
+    from videoseal_amd.training import DetectorStep
+    spec = legacy_tiny_spec() if which == "tiny" else spec_from_card(os.path.join(CARDS, "videoseal_0.0.yaml"))
+    sd = make_state_dict(spec, seed=5)
+    gen = torch.Generator().manual_seed(9)
+    for k in sd:
+        if k.endswith(("pos_embed", "rel_pos_h", "rel_pos_w")):
+            sd[k] = 0.2 * torch.randn(sd[k].shape, generator=gen)
+    nfr = 3 if which == "tiny" else 2
+    imgs = synthetic_frames(nfr, spec.img_size, spec.img_size, seed=78)
+    msgs = synthetic_msgs(nfr, spec.nbits, seed=78)
+    names = [k for k, v in sd.items() if k.startswith("detector.") and v.dtype.is_floating_point]
+    sdg = {k: v.clone() for k, v in sd.items()}
+    for k in names:
+        sdg[k].requires_grad_(True)
+    preds = R.extractor_forward(sdg, spec, imgs)
+    loss_ref = OL.decoding_loss(preds, msgs, None)
+    loss_ref.backward()
+    model = make_model(spec, sd)
+    loss, logits, grads = DetectorStep(model).step(imgs.cuda(), msgs, accumulate=False)
+    torch.cuda.synchronize()
+    assert (logits.cpu() - preds.detach()).abs().max() < 2e-4
+    assert abs(float(loss) - float(loss_ref.detach())) < 1e-5
+    assert set(grads) == set(names), (set(names) - set(grads), set(grads) - set(names))
+    worst = 0.0
+    for k in names:
+        ref = sdg[k].grad
+        got = grads[k].reshape(ref.shape).cpu()
+        err = float((got - ref).abs().max() / ref.abs().max().clamp_min(1e-12))
+        worst = max(worst, err)
+        assert err < 3e-3, (k, err)
+    print(f"worst relative gradient error over {len(names)} tensors: {worst:.2e}")

@@ -44,9 +44,8 @@ class DetectorStep:
     `grad_scale` (= 1 / accumulation_steps in train.py:641)."""
 
     def __init__(self, model):
-        if model.embedder.cfg.extractor == "sam":
-            raise N.NativeError("DetectorStep covers the ConvNeXt-V2 extractor of the released 1.0 / PixelSeal / ChunkySeal cards")
         self.model = model
+        self.vit = model.embedder.cfg.extractor == "sam"       # the legacy card's SAM-style ViT (vit.py:14-144): _forward_vit / _backward_vit
         self._ones: Dict[int, torch.Tensor] = {}
 
     # ------------------------------------------------------------------ small helpers
@@ -86,14 +85,14 @@ class DetectorStep:
         N.check(L.vs_gemm_wgrad(N.ptr(dy.t), dy.ld, n, N.ptr(x.t), x.ld, k, dy.rows, N.ptr(part), N.ptr(dw), N.stream()), "vs_gemm_wgrad")
         return dw
 
-    def _ln_bwd(self, eng, x: Act, dy: Act, w: torch.Tensor, tag: str) -> Tuple[Act, torch.Tensor, torch.Tensor]:
+    def _ln_bwd(self, eng, x: Act, dy: Act, w: torch.Tensor, tag: str, eps: float = 1e-6) -> Tuple[Act, torch.Tensor, torch.Tensor]:
         L = eng.lib
         dx = self._act(eng, tag, x.B, x.H, x.W, x.C, x.ld)
         stats = eng.buf("tr.ln.stats", 2 * x.rows)
         part = eng.buf("tr.ln.part", int(L.vs_colreduce_partial_floats(1, x.rows, x.ld)))
         dw = torch.empty(x.C, device=eng.dev, dtype=torch.float32)
         db = torch.empty(x.C, device=eng.dev, dtype=torch.float32)
-        N.check(L.vs_layernorm_bwd(N.ptr(x.t), x.ld, N.ptr(dy.t), dy.ld, N.ptr(w), x.rows, x.C, 1e-6, N.ptr(dx.t), dx.ld, N.ptr(stats), N.ptr(part),
+        N.check(L.vs_layernorm_bwd(N.ptr(x.t), x.ld, N.ptr(dy.t), dy.ld, N.ptr(w), x.rows, x.C, eps, N.ptr(dx.t), dx.ld, N.ptr(stats), N.ptr(part),
                                    N.ptr(dw), N.ptr(db), N.stream()), "vs_layernorm_bwd")
         return dx, dw, db
 
@@ -109,6 +108,8 @@ class DetectorStep:
         """the training forward runs on the exact, range-free 3 x bf16 split: weights drift during training, and an activation that leaves the
         f16 range of the fast arithmetic would only show up as a NaN loss"""
         eng.arith = BWD_ARITH
+        if self.vit:
+            return self._forward_vit(eng, x)
         if eng.X is None:
             eng._pack_extractor(eng._g)
         c, X, L, st = eng.cfg, eng.X, eng.lib, N.stream()
@@ -155,8 +156,162 @@ class DetectorStep:
                 rec["blocks"].append(dict(x=cur, t0=t0, u=u, h1=h1, h3=h3))
                 cur = out
             S["stages"].append(rec)
-        # pixel decoder (upscale_stages [1]): reflect-pad conv3x3 as patch matrix + GEMM, LayerNorm, GELU, mean, Linear
-        Cl = d[-1]
+        logits = self._head_forward(eng, cur, X, S)
+        return logits, S
+
+    # ------------------------------------------------------------------ the legacy card's SAM-style ViT extractor (vit.py:14-144)
+    def _forward_vit(self, eng: HipEngine, x: Act):
+        """engine.vit_extractor_forward with every operand of the backward kept: per block the input of each LayerNorm, qkv, the attention
+        output, the MLP's pre-activation and its GELU; the neck's four maps."""
+        if eng.X is None:
+            eng._pack_vit(eng._g)
+        c, V, L, st, B = eng.cfg, eng.X, eng.lib, N.stream(), x.B
+        P, D_ = c.vit_patch, c.vit_dim
+        gh, gw = x.H // P, x.W // P
+        if gh * gw * D_ != V["pos"].numel():
+            raise N.NativeError(f"ViT extractor: {x.H}x{x.W} input does not match the position table")
+        pos = V["pos"].repeat(B, 1).contiguous()
+        tok = self._act(eng, "vit.x", B, gh, gw, D_)
+        eng.conv(x, V["patch"], tok, geom=(gw, P * 4, P * 4, P, 1, 0, 0), res=Act(pos, B, gh, gw, D_, D_))
+        hd, hid = D_ // c.vit_heads, int(D_ * c.vit_mlp_ratio)
+        S = {"x": x, "blocks": [], "grid": (gh, gw)}
+        for i, blk in enumerate(V["blocks"]):
+            tg = f"vit.b{i}."
+            n1 = self._act(eng, tg + "n1", B, gh, gw, D_)
+            eng.layernorm(tok, blk["n1"][0], blk["n1"][1], n1, eps=1e-5)               # nn.LayerNorm default eps
+            qkv = self._act(eng, tg + "qkv", B, gh, gw, 3 * D_)
+            eng.conv(n1, blk["qkv"], qkv)
+            att = self._act(eng, tg + "att", B, gh, gw, D_)
+            N.check(L.vs_vit_attention(N.ptr(qkv.t), B, gh, gw, c.vit_heads, hd, blk["window"], N.ptr(blk["rel_h"]), N.ptr(blk["rel_w"]),
+                                       N.ptr(att.t), st), "vs_vit_attention")
+            mid = self._act(eng, tg + "tokm", B, gh, gw, D_)
+            eng.conv(att, blk["proj"], mid, res=tok)                                   # x = shortcut + proj(attn)
+            n2 = self._act(eng, tg + "n2", B, gh, gw, D_)
+            eng.layernorm(mid, blk["n2"][0], blk["n2"][1], n2, eps=1e-5)
+            z1 = self._act(eng, tg + "z1", B, gh, gw, hid)
+            eng.conv(n2, blk["lin1"], z1)
+            a1 = self._act(eng, tg + "a1", B, gh, gw, hid)
+            self._gelu(eng, z1, a1)
+            out = self._act(eng, tg + "out", B, gh, gw, D_)
+            eng.conv(a1, blk["lin2"], out, res=mid)                                    # x = x + mlp(norm2(x))
+            S["blocks"].append(dict(x=tok, n1=n1, qkv=qkv, att=att, mid=mid, n2=n2, z1=z1, a1=a1))
+            tok = out
+        n0 = self._act(eng, "vit.neck0", B, gh, gw, c.vit_out)
+        eng.conv(tok, V["neck0"], n0)
+        n1 = self._act(eng, "vit.neck1", B, gh, gw, c.vit_out, eng._xld(c.vit_out))
+        eng.layernorm(n0, V["neck1"][0], V["neck1"][1], n1)
+        n2 = self._act(eng, "vit.neck2", B, gh, gw, c.vit_out)
+        eng.conv(n1, V["neck2"], n2, pad=1)
+        n3 = self._act(eng, "vit.neck3", B, gh, gw, c.vit_out, eng._xld(c.vit_out))
+        eng.layernorm(n2, V["neck3"][0], V["neck3"][1], n3)
+        S.update(tok_last=tok, n0=n0, n1=n1, n2=n2)
+        logits = self._head_forward(eng, n3, V, S)
+        return logits, S
+
+    def _backward_vit(self, eng: HipEngine, S, dlogits: torch.Tensor, want_params: bool = True, want_input: bool = False):
+        """gradients of every `detector.*` parameter of the ViT extractor (vit.py:55-127 neck / blocks / patch embedding, 302-360 attention with
+        its relative-position tables) and / or of the input frames"""
+        c, V, L, st, g = eng.cfg, eng.X, eng.lib, N.stream(), eng._g
+        G: Dict[str, torch.Tensor] = _GradSink(want_params)
+        self._skip_w = not want_params
+        ie = "detector.image_encoder"
+        D_, O_ = c.vit_dim, c.vit_out
+        hd, hid = D_ // c.vit_heads, int(D_ * c.vit_mlp_ratio)
+        gh, gw = S["grid"]
+        B = S["x"].B
+        dn3 = self._head_backward(eng, S, dlogits, V, G, want_params)
+        # ---- neck: conv1x1 -> LayerNorm2d -> conv3x3 (zero padding 1) -> LayerNorm2d, no biases (vit.py:104-121)
+        n0, n1, n2, tok = S["n0"], S["n1"], S["n2"], S["tok_last"]
+        dn2, dw, db = self._ln_bwd(eng, n2, dn3, V["neck3"][0], "vit.g.dn2")
+        G[ie + ".neck.3.weight"], G[ie + ".neck.3.bias"] = dw, db
+        if want_params:
+            part = eng.buf("tr.wg.part", int(L.vs_conv3x3_wgrad_partial_floats(O_, n1.ld, B, gh, gw, 1)))
+            dwn = torch.empty(O_, 9 * n1.ld, device=eng.dev, dtype=torch.float32)
+            if L.vs_conv3x3_wgrad_supported(O_, n1.ld, 1):
+                N.check(L.vs_conv3x3_wgrad(N.ptr(dn2.t), dn2.ld, O_, N.ptr(n1.t), n1.ld, B, gh, gw, 1, N.PAD_ZERO, N.ptr(part), N.ptr(dwn), st),
+                        "vs_conv3x3_wgrad")
+            else:
+                cols = Act(eng.buf("tr.vit.cols", n1.rows * 9 * n1.ld, zero=True), B, gh, gw, 9 * n1.ld, 9 * n1.ld)
+                N.check(L.vs_im2col3x3(N.ptr(n1.t), B, gh, gw, n1.ld, N.PAD_ZERO, N.ptr(cols.t), st), "vs_im2col3x3")
+                dwn = self._wgrad(eng, dn2, O_, cols, 9 * n1.ld)
+            G[ie + ".neck.2.weight"] = dwn.view(O_, 3, 3, n1.ld)[..., :O_].permute(0, 3, 1, 2).contiguous()
+        dn1 = self._act(eng, "vit.g.dn1", B, gh, gw, O_, n1.ld)
+        eng.conv(dn2, EmbedderBackward._flip_t(g(ie + ".neck.2.weight"), dn2.ld), dn1, pad=1, arith=BWD_ARITH)
+        dn0, dw, db = self._ln_bwd(eng, n0, dn1, V["neck1"][0], "vit.g.dn0")
+        G[ie + ".neck.1.weight"], G[ie + ".neck.1.bias"] = dw, db
+        w0 = g(ie + ".neck.0.weight").reshape(O_, D_)
+        G[ie + ".neck.0.weight"] = self._wgrad(eng, dn0, O_, tok, D_)
+        if want_params:
+            G[ie + ".neck.0.weight"] = G[ie + ".neck.0.weight"].view(O_, D_, 1, 1)
+        dtok = self._act(eng, "vit.g.dtok", B, gh, gw, D_)
+        eng.conv(dn0, self._tw(w0, dn0.ld), dtok, arith=BWD_ARITH)
+        # ---- blocks, last to first (vit.py:146-193)
+        for i in range(len(S["blocks"]) - 1, -1, -1):
+            sv, blk, p = S["blocks"][i], V["blocks"][i], f"{ie}.blocks.{i}"
+            tg = f"vit.g.b{i & 1}."
+            # x = mid + lin2(gelu(lin1(norm2(mid))))
+            G[p + ".mlp.lin2.weight"] = self._wgrad(eng, dtok, D_, sv["a1"], hid)
+            G[p + ".mlp.lin2.bias"] = self._colsum(eng, dtok, D_)
+            da1 = self._act(eng, tg + "da1", B, gh, gw, hid)
+            eng.conv(dtok, self._tw(g(p + ".mlp.lin2.weight"), dtok.ld), da1, arith=BWD_ARITH)
+            dz1 = self._act(eng, tg + "dz1", B, gh, gw, hid)
+            N.check(L.vs_gelu_bwd(N.ptr(sv["z1"].t), sv["z1"].ld, N.ptr(da1.t), da1.ld, da1.rows, hid, N.ptr(dz1.t), dz1.ld, st), "vs_gelu_bwd")
+            G[p + ".mlp.lin1.weight"] = self._wgrad(eng, dz1, hid, sv["n2"], D_)
+            G[p + ".mlp.lin1.bias"] = self._colsum(eng, dz1, hid)
+            dn2b = self._act(eng, tg + "dn2", B, gh, gw, D_)
+            eng.conv(dz1, self._tw(g(p + ".mlp.lin1.weight"), dz1.ld), dn2b, arith=BWD_ARITH)
+            dmid_ln, dw, db = self._ln_bwd(eng, sv["mid"], dn2b, blk["n2"][0], tg + "dmidln", eps=1e-5)
+            G[p + ".norm2.weight"], G[p + ".norm2.bias"] = dw, db
+            dmid = self._act(eng, tg + "dmid", B, gh, gw, D_)
+            torch.add(dtok.t, dmid_ln.t, out=dmid.t)                                   # the residual branch + the MLP branch
+            # mid = x + proj(attention(qkv(norm1(x))))
+            G[p + ".attn.proj.weight"] = self._wgrad(eng, dmid, D_, sv["att"], D_)
+            G[p + ".attn.proj.bias"] = self._colsum(eng, dmid, D_)
+            datt = self._act(eng, tg + "datt", B, gh, gw, D_)
+            eng.conv(dmid, self._tw(g(p + ".attn.proj.weight"), dmid.ld), datt, arith=BWD_ARITH)
+            dqkv = self._act(eng, tg + "dqkv", B, gh, gw, 3 * D_)
+            scr = eng.buf("tr.vit.attn.scratch", int(L.vs_vit_attention_bwd_scratch_floats(B, gh, gw, c.vit_heads, blk["window"])))
+            rel = blk["rel_h"] is not None
+            drh = torch.empty_like(blk["rel_h"]) if (rel and want_params) else None
+            drw = torch.empty_like(blk["rel_w"]) if (rel and want_params) else None
+            N.check(L.vs_vit_attention_bwd(N.ptr(sv["qkv"].t), N.ptr(sv["att"].t), N.ptr(datt.t), B, gh, gw, c.vit_heads, hd, blk["window"],
+                                           N.ptr(blk["rel_h"]), N.ptr(blk["rel_w"]), N.ptr(dqkv.t), N.ptr(scr), N.ptr(drh), N.ptr(drw), st),
+                    "vs_vit_attention_bwd")
+            if rel:
+                G[p + ".attn.rel_pos_h"], G[p + ".attn.rel_pos_w"] = drh, drw
+            G[p + ".attn.qkv.weight"] = self._wgrad(eng, dqkv, 3 * D_, sv["n1"], D_)
+            G[p + ".attn.qkv.bias"] = self._colsum(eng, dqkv, 3 * D_)
+            dn1b = self._act(eng, tg + "dn1", B, gh, gw, D_)
+            eng.conv(dqkv, self._tw(g(p + ".attn.qkv.weight"), dqkv.ld), dn1b, arith=BWD_ARITH)
+            dx_ln, dw, db = self._ln_bwd(eng, sv["x"], dn1b, blk["n1"][0], tg + "dxln", eps=1e-5)
+            G[p + ".norm1.weight"], G[p + ".norm1.bias"] = dw, db
+            dtok = self._act(eng, tg + "dx", B, gh, gw, D_)
+            torch.add(dmid.t, dx_ln.t, out=dtok.t)
+        # ---- patch embedding (conv P x P stride P + bias) + absolute positions (vit.py:66-69, 129-131)
+        x = S["x"]
+        P = c.vit_patch
+        CP = rup(P * x.ld, 16)
+        if want_params:
+            G[ie + ".pos_embed"] = dtok.t.view(B, gh * gw * D_).sum(0).view(1, gh, gw, D_) if B > 1 else dtok.t.view(1, gh, gw, D_).clone()
+            patches = Act(eng.buf("tr.vit.patches", dtok.rows * P * CP, zero=True), B, gh, gw, P * CP, P * CP)
+            N.check(L.vs_patchify_s(N.ptr(x.t), B, x.H, x.W, x.ld, P, P, N.ptr(patches.t), st), "vs_patchify_s")
+            dwp = self._wgrad(eng, dtok, D_, patches, P * CP)                               # [D][ky * CP + kx * ld + c]
+            G[ie + ".patch_embed.proj.weight"] = dwp.view(D_, P, CP)[:, :, : P * x.ld].reshape(D_, P, P, x.ld)[..., :3].permute(0, 3, 1, 2).contiguous()
+        G[ie + ".patch_embed.proj.bias"] = self._colsum(eng, dtok, D_)
+        if not want_input:
+            return G
+        dcols = Act(eng.buf("tr.vit.dcols", dtok.rows * P * CP, zero=True), B, gh, gw, P * CP, P * CP)
+        eng.conv(dtok, self._tw(V["patch"].wt, dtok.ld), dcols, arith=BWD_ARITH)
+        drgb = eng.buf("tr.stem.drgb", x.rows * 4, zero=True)
+        N.check(L.vs_unpatch_s(N.ptr(dcols.t), B, x.H, x.W, x.ld, P, P, N.ptr(drgb), st), "vs_unpatch_s")
+        dimg = torch.empty(B, 3, x.H, x.W, device=eng.dev, dtype=torch.float32)
+        N.check(L.vs_nhwc_to_nchw_scaled(N.ptr(drgb), B, x.H, x.W, 3, 4, 2.0, N.ptr(dimg), st), "vs_nhwc_to_nchw_scaled")
+        return G, dimg
+
+    def _head_forward(self, eng: HipEngine, cur: Act, X, S) -> torch.Tensor:
+        """pixel decoder (pixel_decoder.py:61-83, upscale_stages [1]): reflect-pad conv3x3 as patch matrix + GEMM, LayerNorm, GELU, mean, Linear"""
+        c, L, st, B = eng.cfg, eng.lib, N.stream(), cur.B
+        Cl = cur.C
         g = eng._g
         wh = g("detector.pixel_decoder.output_upscaling.0.upsample_block.2.weight").float()            # [Cl, Cl, 3, 3]
         wcols = torch.zeros(Cl, 9, cur.ld, device=eng.dev)
@@ -176,17 +331,12 @@ class DetectorStep:
         N.check(L.vs_pool_linear(N.ptr(hl.t), B, hl.H * hl.W, hl.C, hl.ld, N.ptr(X["lin_w"]), N.ptr(X["lin_b"]), c.nbits + 1, N.ptr(logits), st),
                 "vs_pool_linear")
         S.update(last=cur, cols=cols, hc=hc, z=z, hl=hl)
-        return logits, S
+        return logits
 
-    # ------------------------------------------------------------------ backward
-    def _backward(self, eng: HipEngine, S, dlogits: torch.Tensor, want_params: bool = True, want_input: bool = False):
-        """gradients of every `detector.*` parameter (want_params) and / or of the extractor's input frames [B, 3, S, S] in [0, 1]
-        (want_input: the path the generator-side loss takes back to the embedder).  Returns G, or (G, d_input) with want_input."""
-        c, X, L, st, g = eng.cfg, eng.X, eng.lib, N.stream(), eng._g
-        d = c.dims
-        G: Dict[str, torch.Tensor] = _GradSink(want_params)
-        self._skip_w = not want_params          # _wgrad / _colsum return None: only the data path runs
-        pd, cn = "detector.pixel_decoder", "detector.convnext"
+    def _head_backward(self, eng: HipEngine, S, dlogits: torch.Tensor, X, G, want_params: bool) -> Act:
+        """pixel decoder backward: fills the `detector.pixel_decoder.*` gradients, returns the gradient of its input map"""
+        c, L, st = eng.cfg, eng.lib, N.stream()
+        pd = "detector.pixel_decoder"
         hl, z, hc, cols, cur = S["hl"], S["z"], S["hc"], S["cols"], S["last"]
         B, HW, Cl, N1 = hl.B, hl.H * hl.W, hl.C, c.nbits + 1
         # ---- Linear on the pooled features
@@ -214,6 +364,20 @@ class DetectorStep:
         eng.conv(dhc, self._tw(S["head_wcols"], dhc.ld), dcols, arith=BWD_ARITH)
         dy = self._act(eng, "st3.dy", B, cur.H, cur.W, cur.C, cur.ld)
         N.check(L.vs_col2im3x3_reflect(N.ptr(dcols.t), B, cur.H, cur.W, cur.ld, N.ptr(dy.t), st), "vs_col2im3x3_reflect")
+        return dy
+
+    # ------------------------------------------------------------------ backward
+    def _backward(self, eng: HipEngine, S, dlogits: torch.Tensor, want_params: bool = True, want_input: bool = False):
+        """gradients of every `detector.*` parameter (want_params) and / or of the extractor's input frames [B, 3, S, S] in [0, 1]
+        (want_input: the path the generator-side loss takes back to the embedder).  Returns G, or (G, d_input) with want_input."""
+        if self.vit:
+            return self._backward_vit(eng, S, dlogits, want_params, want_input)
+        c, X, L, st, g = eng.cfg, eng.X, eng.lib, N.stream(), eng._g
+        d = c.dims
+        G: Dict[str, torch.Tensor] = _GradSink(want_params)
+        self._skip_w = not want_params          # _wgrad / _colsum return None: only the data path runs
+        cn = "detector.convnext"
+        dy = self._head_backward(eng, S, dlogits, X, G, want_params)
         # ---- stages, last to first
         for sti in (3, 2, 1, 0):
             rec = S["stages"][sti]
