@@ -440,3 +440,38 @@ def test_frozen_embedder_and_eval_batchnorm():
     worst = max(float((hip[k].grad.cpu() - sdg[k].grad).abs().max() / sdg[k].grad.abs().max().clamp_min(1e-12)) for k in names)
     assert worst < 2e-3, worst
     assert torch.equal(model2.state_dict()["embedder.unet.inc.double_conv.1.num_batches_tracked"].cpu(), sd["embedder.unet.inc.double_conv.1.num_batches_tracked"])
+
+
+def test_legacy_card_detector_fine_tuning_under_the_unmodified_loop():
+    """The legacy architecture (RMSNorm / SiLU U-Net, ViT extractor) with the embedder frozen (train.py:507-523): `model(imgs, masks, msgs)` ->
+    decoding loss -> `loss.backward()` fills the gradient of every ViT parameter (attention incl. the relative-position tables, MLP, neck,
+    pixel decoder) through the HIP backward; same values as `DetectorStep.step` on the forward's own `imgs_aug` (which tests/test_gpu_bwd.py
+    holds to oracle autograd)."""
+    from oracle.weights import legacy_tiny_spec
+    from videoseal_amd.training import DetectorStep
+    spec = legacy_tiny_spec()
+    sd = make_state_dict(spec, seed=5)
+    model = make_model(spec, sd)
+    model.augmenter = G.Augmenter(masks={"kind": "none"}, augs={"identity": 1}, augs_params={}, num_augs=1)
+    model.train()
+    model.embedder.requires_grad_(False)
+    imgs = synthetic_frames(3, 64, 64, seed=12).cuda()
+    msgs = synthetic_msgs(3, spec.nbits, seed=12)
+    masks = torch.ones(3, 1, 64, 64, device="cuda")
+    out = model(imgs, masks, msgs, is_video=False)
+    assert out["preds"].requires_grad and not out["imgs_w"].requires_grad
+    OL.decoding_loss(out["preds"], out["msgs"].cuda(), None).backward()
+    got = {k: p.grad.clone() for k, p in model.named_parameters() if p.grad is not None}
+    assert all(k.startswith("detector.") for k in got) and len(got) == sum(1 for k, _ in model.detector.named_parameters())
+    _, _, ref = DetectorStep(model).step(out["imgs_aug"].detach(), msgs, accumulate=False)
+    torch.cuda.synchronize()
+    for k, v in got.items():
+        r = ref[k].reshape(v.shape)
+        assert (v - r).abs().max() <= 1e-6 * r.abs().max() + 1e-12, k
+    # a trainable legacy embedder: its RMSNorm U-Net has no backward here -- warned once, values without a graph for that network
+    model2 = make_model(spec, sd)
+    model2.augmenter = model.augmenter
+    model2.train()
+    with pytest.warns(UserWarning, match="RMSNorm"):
+        out2 = model2(imgs, masks, msgs, is_video=False)
+    assert out2["preds"].requires_grad and not out2["imgs_w"].requires_grad

@@ -445,9 +445,6 @@ class Wam(nn.Module):
         if emb and cfg.unet_norm == "rms":
             emb = False
             why.append("the RMSNorm / SiLU U-Net of the legacy card")
-        if det and cfg.extractor == "sam":
-            det = False
-            why.append("the ViT extractor")
         if why and not self._warned_no_backward:
             self._warned_no_backward = True
             import warnings
