@@ -229,6 +229,12 @@ int vs_pad_embed1(const float* dy, int B, int H, int W, int64_t ld, float* out, 
  * (dq | dk | dv) in qkv's layout; drel_h / drel_w [2 * T - 1][hd] the gradients of the two relative-position tables (NULL with rel_h ==
  * NULL).  scratch: vs_vit_attention_bwd_scratch_floats(...) floats.  Deterministic (no atomics). */
 int vs_gelu_bwd(const float* z, int64_t ld, const float* dy, int64_t dy_ld, int64_t rows, int C, float* dz, int64_t dz_ld, void* stream);
+/* vs_act_bwd: dz = dy * act'(z) for VS_ACT_RELU | GELU | TANH | SILU (z = the pre-activation value).
+ * vs_rmsnorm_act_bwd: adjoint of vs_rmsnorm_act (ChanRMSNorm + activation of the legacy U-Net, common.py:172-179): dx, and term[r][c] whose
+ * column sums over the rows are d gamma. */
+int vs_act_bwd(const float* z, int64_t ld, const float* dy, int64_t dy_ld, int64_t rows, int C, int act, float* dz, int64_t dz_ld, void* stream);
+int vs_rmsnorm_act_bwd(const float* x, int64_t rows, int C, int64_t ld, const float* gamma, int act, const float* dy, int64_t dy_ld, float* dx,
+                       int64_t dx_ld, float* term, int64_t term_ld, void* stream);
 int64_t vs_vit_attention_bwd_scratch_floats(int frames, int H, int W, int heads, int window);
 int vs_vit_attention_bwd(const float* qkv, const float* out, const float* dout, int frames, int H, int W, int heads, int hd, int window,
                          const float* rel_h, const float* rel_w, float* dqkv, float* scratch, float* drel_h, float* drel_w, void* stream);

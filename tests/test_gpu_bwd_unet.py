@@ -255,3 +255,31 @@ def test_embedder_backward_unconstrained_within_the_relu_flip_noise():
     spec = tiny_spec()
     errs = _embedder_case(spec, make_state_dict(spec, seed=3), 3, 51, masked=False)
     assert errs[len(errs) // 2][0] < 1e-2 and errs[0][0] < 8e-2, errs[:5]
+
+
+@pytest.mark.parametrize("rows,C,act", [(300, 16, "silu"), (77, 64, "silu"), (50, 128, "relu"), (9, 384, "silu"), (40, 24, "gelu")])
+def test_rmsnorm_act_bwd_and_act_bwd(rows, C, act):
+    """ChanRMSNorm + activation of the legacy U-Net (common.py:172-179: F.normalize(x, dim=1) * sqrt(C) * gamma, then the activation) and the
+    plain activation derivative, against torch autograd"""
+    L, st = N.lib(), N.stream()
+    fn = {"silu": F.silu, "relu": F.relu, "gelu": F.gelu}[act]
+    code = {"silu": N.ACT_SILU, "relu": N.ACT_RELU, "gelu": N.ACT_GELU}[act]
+    g = torch.Generator().manual_seed(rows + C)
+    x = (torch.randn(rows, C, generator=g) * 1.5).cuda().requires_grad_(True)
+    gamma = (1 + 0.3 * torch.randn(C, generator=g)).cuda().requires_grad_(True)
+    dy = torch.randn(rows, C, generator=g).cuda()
+    y = fn(F.normalize(x, dim=1) * (C ** 0.5) * gamma)
+    y.backward(dy)
+    xd, gd = x.detach().contiguous(), gamma.detach().contiguous()
+    dx = torch.full((rows, C), 7.0, device="cuda")
+    term = torch.full((rows, C), 7.0, device="cuda")
+    N.check(L.vs_rmsnorm_act_bwd(N.ptr(xd), rows, C, C, N.ptr(gd), code, N.ptr(dy), C, N.ptr(dx), C, N.ptr(term), C, st), "vs_rmsnorm_act_bwd")
+    assert (dx - x.grad).abs().max() <= 2e-5 * x.grad.abs().max()
+    dg = term.double().sum(0)
+    assert (dg - gamma.grad.double()).abs().max() <= 2e-5 * gamma.grad.abs().max()
+    z = torch.randn(rows, C, generator=g).cuda().requires_grad_(True)
+    fn(z).backward(dy)
+    zd = z.detach().contiguous()
+    dz = torch.full((rows, C), 7.0, device="cuda")
+    N.check(L.vs_act_bwd(N.ptr(zd), C, N.ptr(dy), C, rows, C, code, N.ptr(dz), C, st), "vs_act_bwd")
+    assert (dz - z.grad).abs().max() <= 2e-6 * z.grad.abs().max() + 1e-7

@@ -468,10 +468,50 @@ def test_legacy_card_detector_fine_tuning_under_the_unmodified_loop():
     for k, v in got.items():
         r = ref[k].reshape(v.shape)
         assert (v - r).abs().max() <= 1e-6 * r.abs().max() + 1e-12, k
-    # a trainable legacy embedder: its RMSNorm U-Net has no backward here -- warned once, values without a graph for that network
-    model2 = make_model(spec, sd)
-    model2.augmenter = model.augmenter
-    model2.train()
-    with pytest.warns(UserWarning, match="RMSNorm"):
-        out2 = model2(imgs, masks, msgs, is_video=False)
-    assert out2["preds"].requires_grad and not out2["imgs_w"].requires_grad
+
+
+def test_legacy_card_full_training_step_matches_oracle_autograd():
+    """The whole legacy architecture trainable under the unmodified loop: RMSNorm / SiLU U-Net (common.py:172-179; vs_rmsnorm_act_bwd, vs_act_bwd),
+    RGB watermark without JND, ViT extractor.  Frames at 72 x 88 (resize both ways around the 64 x 64 networks), perceptual + decoding terms
+    with fixed weights: every gradient against torch autograd through the oracle (CPU, fp32).  All activations are smooth here (no ReLU
+    decisions to share): the comparison is element-wise at 2e-3 of each tensor's largest entry."""
+    from oracle.weights import legacy_tiny_spec
+    spec = legacy_tiny_spec()
+    sd = make_state_dict(spec, seed=5)
+    gen = torch.Generator().manual_seed(9)
+    for k in sd:
+        if k.endswith(("pos_embed", "rel_pos_h", "rel_pos_w")):
+            sd[k] = 0.2 * torch.randn(sd[k].shape, generator=gen)
+    model = make_model(spec, sd)
+    model.augmenter = G.Augmenter(masks={"kind": "none"}, augs={"identity": 1}, augs_params={}, num_augs=1)
+    model.train()
+    imgs = synthetic_frames(3, 72, 88, seed=13)
+    msgs = synthetic_msgs(3, spec.nbits, seed=13)
+    masks = torch.ones(3, 1, 72, 88)
+    kw = dict(percep_loss="mse", percep_weight=1.0, detect_weight=0.0, decode_weight=0.5, balanced=False)
+    out = model(imgs.cuda(), masks.cuda(), msgs, is_video=False)
+    assert out["imgs_w"].requires_grad and out["preds"].requires_grad
+    loss, _ = OL.videoseal_loss(imgs.cuda(), out["imgs_w"], out["masks"], out["msgs"].cuda(), out["preds"], last_layer=None, **kw)
+    loss.backward()
+    torch.cuda.synchronize()
+    names = [k for k, p in model.named_parameters() if p.requires_grad]
+    got = dict(model.named_parameters())
+    sdg = {k: v.clone() for k, v in sd.items()}
+    for k in names:
+        sdg[AG._ALIASES.get(k, k)].requires_grad_(True)
+    oo = R.forward_image(sdg, spec, imgs, masks, msgs, OA.Augmenter({"identity": 1}, {}, 1))
+    lref, _ = OL.videoseal_loss(imgs, oo["imgs_w"], oo["masks"], oo["msgs"], oo["preds"], last_layer=None, **kw)
+    lref.backward()
+    assert abs(float(loss) - float(lref)) <= 1e-5 * abs(float(lref))
+    worst, n = 0.0, 0
+    for k in names:
+        ref = sdg[AG._ALIASES.get(k, k)].grad
+        if ref is None:
+            assert got[k].grad is None or float(got[k].grad.abs().max()) == 0.0, k
+            continue
+        assert got[k].grad is not None, k
+        err = float((got[k].grad.cpu() - ref).abs().max() / ref.abs().max().clamp_min(1e-12))
+        worst, n = max(worst, err), n + 1
+        assert err < 2e-3, (k, err)
+    assert n > 100
+    print(f"legacy card: worst relative gradient error over {n} tensors: {worst:.2e}")

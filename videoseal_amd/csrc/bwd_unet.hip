@@ -281,6 +281,88 @@ __global__ __launch_bounds__(256) void relu_bwd_kernel(const float* __restrict__
   *reinterpret_cast<f32x4*>(dz + r * dz_ld + 4 * cg) = o;
 }
 
+// derivative of vs_apply_act at the PRE-activation value
+__device__ __forceinline__ float act_grad(float v, int act) {
+  switch (act) {
+    case VS_ACT_RELU: return v > 0.f ? 1.f : 0.f;
+    case VS_ACT_GELU: return vs_gelu_grad(v);
+    case VS_ACT_TANH: { const float t = tanhf(v); return 1.f - t * t; }
+    case VS_ACT_SILU: { const float sg = 1.0f / (1.0f + __expf(-v)); return sg * (1.f + v * (1.f - sg)); }
+    default: return 1.f;
+  }
+}
+__global__ __launch_bounds__(256) void act_bwd_kernel(const float* __restrict__ z, int64_t ld, const float* __restrict__ dy, int64_t dy_ld, int C, int O4,
+                                                      int act, int64_t total, float* __restrict__ dz, int64_t dz_ld) {
+  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= total) return;
+  const int cg = (int)(idx % O4);
+  const int64_t r = idx / O4;
+  f32x4 o = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int e = 0; e < 4; ++e)
+    if (4 * cg + e < C) o[e] = dy[r * dy_ld + 4 * cg + e] * act_grad(z[r * ld + 4 * cg + e], act);
+  *reinterpret_cast<f32x4*>(dz + r * dz_ld + 4 * cg) = o;
+}
+
+// ChanRMSNorm + activation (common.py:172-179: y = act(F.normalize(x, dim = channels) * sqrt(C) * gamma)) backward, LPP lanes per pixel row as in
+// the forward (vit_ops.hip::rmsnorm_act_kernel).  With n = x / den (den = max(|x|, 1e-12)), u = n * sqrt(C) * gamma:
+//   du = dy * act'(u),  g = du * sqrt(C) * gamma,  dx = (g - n (n . g)) / den;   term = du * sqrt(C) * n  (its column sums are d gamma)
+template <int LPP>
+__global__ __launch_bounds__(256) void rmsnorm_act_bwd_kernel(const float* __restrict__ x, int64_t rows, int C, int64_t ld, const float* __restrict__ gamma,
+                                                              float scale, int act, const float* __restrict__ dy, int64_t dy_ld, float* __restrict__ dx,
+                                                              int64_t dx_ld, float* __restrict__ term, int64_t t_ld) {
+  const int q = threadIdx.x & (LPP - 1);
+  const int64_t row = ((int64_t)blockIdx.x * 256 + threadIdx.x) / LPP;
+  const bool live = row < rows;
+  const float* xr = x + (live ? row : 0) * ld;
+  const float* gr = dy + (live ? row : 0) * dy_ld;
+  const int C4 = C >> 2, O4 = (int)(dx_ld >> 2), T4 = (int)(t_ld >> 2);
+  float ss = 0.f;
+  for (int c4 = q; c4 < C4; c4 += LPP) {
+    const f32x4 v = *reinterpret_cast<const f32x4*>(xr + 4 * c4);
+    ss += (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
+  }
+#pragma unroll
+  for (int o = 1; o < LPP; o <<= 1) ss += __shfl_xor(ss, o, 64);
+  const float nrm = sqrtf(ss);
+  const float den = fmaxf(nrm, 1e-12f);
+  float dot = 0.f;                                   // n . g
+  for (int c4 = q; c4 < C4; c4 += LPP) {
+    const f32x4 v = *reinterpret_cast<const f32x4*>(xr + 4 * c4), gm = *reinterpret_cast<const f32x4*>(gamma + 4 * c4);
+    const f32x4 d = *reinterpret_cast<const f32x4*>(gr + 4 * c4);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float n = v[e] / den;
+      const float u = (n * scale) * gm[e];
+      dot += n * (d[e] * act_grad(u, act) * scale * gm[e]);
+    }
+  }
+#pragma unroll
+  for (int o = 1; o < LPP; o <<= 1) dot += __shfl_xor(dot, o, 64);
+  if (!live) return;
+  const bool clamped = nrm < 1e-12f;                 // F.normalize's clamp_min: den is then a constant, no projection term
+  float* orow = dx + row * dx_ld;
+  float* trow = term + row * t_ld;
+  const int M4 = O4 > T4 ? O4 : T4;
+  for (int c4 = q; c4 < M4; c4 += LPP) {
+    f32x4 o = {0.f, 0.f, 0.f, 0.f}, tt = {0.f, 0.f, 0.f, 0.f};
+    if (c4 < C4) {
+      const f32x4 v = *reinterpret_cast<const f32x4*>(xr + 4 * c4), gm = *reinterpret_cast<const f32x4*>(gamma + 4 * c4);
+      const f32x4 d = *reinterpret_cast<const f32x4*>(gr + 4 * c4);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float n = v[e] / den;
+        const float du = d[e] * act_grad((n * scale) * gm[e], act);
+        const float g = du * scale * gm[e];
+        o[e] = (g - (clamped ? 0.f : n * dot)) / den;
+        tt[e] = du * scale * n;
+      }
+    }
+    if (c4 < O4) *reinterpret_cast<f32x4*>(orow + 4 * c4) = o;
+    if (c4 < T4) *reinterpret_cast<f32x4*>(trow + 4 * c4) = tt;
+  }
+}
+
 static inline unsigned blocks_for(int64_t n) { return (unsigned)cdiv64(n, 256); }
 
 }  // namespace
@@ -378,6 +460,30 @@ extern "C" int vs_outc_tanh_bwd(const float* delta, const float* ddelta, int64_t
   const int64_t rows = rows_per_frame * B;
   hipLaunchKernelGGL(outc_tanh_bwd_kernel, dim3(blocks_for(rows)), dim3(256), 0, (hipStream_t)stream, delta, ddelta, rows_per_frame, rows, C, w, Cout,
                      use_tanh, dx, dx_ld, dv);
+  return vs_launch_status();
+}
+
+extern "C" int vs_act_bwd(const float* z, int64_t ld, const float* dy, int64_t dy_ld, int64_t rows, int C, int act, float* dz, int64_t dz_ld,
+                          void* stream) {
+  VS_REQUIRE(z && dy && dz && rows > 0 && C > 0 && ld >= C && dy_ld >= C && dz_ld >= C && (dz_ld & 3) == 0 && (((uintptr_t)dz) & 15) == 0);
+  const int O4 = (int)(dz_ld >> 2);
+  const int64_t total = rows * O4;
+  hipLaunchKernelGGL(act_bwd_kernel, dim3(blocks_for(total)), dim3(256), 0, (hipStream_t)stream, z, ld, dy, dy_ld, C, O4, act, total, dz, dz_ld);
+  return vs_launch_status();
+}
+
+extern "C" int vs_rmsnorm_act_bwd(const float* x, int64_t rows, int C, int64_t ld, const float* gamma, int act, const float* dy, int64_t dy_ld,
+                                  float* dx, int64_t dx_ld, float* term, int64_t term_ld, void* stream) {
+  VS_REQUIRE(x && gamma && dy && dx && term && rows > 0 && C > 0 && C % 4 == 0 && ld % 4 == 0 && ld >= C && dy_ld % 4 == 0 && dy_ld >= C &&
+             dx_ld % 4 == 0 && dx_ld >= C && term_ld % 4 == 0 && term_ld >= C);
+  VS_REQUIRE(((((uintptr_t)x) | ((uintptr_t)dy) | ((uintptr_t)dx) | ((uintptr_t)term) | ((uintptr_t)gamma)) & 15) == 0);
+  const float scale = sqrtf((float)C);
+  hipStream_t st = (hipStream_t)stream;
+#define VS_RMSB(L_) hipLaunchKernelGGL(rmsnorm_act_bwd_kernel<L_>, dim3((unsigned)cdiv64(rows * L_, 256)), dim3(256), 0, st, x, rows, C, ld, gamma, scale, act, dy, dy_ld, dx, dx_ld, term, term_ld)
+  if (C <= 64) VS_RMSB(4);
+  else if (C <= 256) VS_RMSB(16);
+  else VS_RMSB(64);
+#undef VS_RMSB
   return vs_launch_status();
 }
 

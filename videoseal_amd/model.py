@@ -441,15 +441,6 @@ class Wam(nn.Module):
         cfg = self.embedder.cfg
         emb = any(p.requires_grad for p in self.embedder.parameters())
         det = any(p.requires_grad for p in self.detector.parameters())
-        why = []
-        if emb and cfg.unet_norm == "rms":
-            emb = False
-            why.append("the RMSNorm / SiLU U-Net of the legacy card")
-        if why and not self._warned_no_backward:
-            self._warned_no_backward = True
-            import warnings
-            warnings.warn("no HIP backward for " + " and ".join(why) + ": forward() returns values without a graph for that network "
-                          "(its parameters receive no gradient)")
         return emb, det
 
     def _forward_graph(self, x: torch.Tensor, masks, mi: torch.Tensor, *, step: int, video_mode: int, aa: bool, lowres: bool, is_video: bool,

@@ -503,8 +503,10 @@ class EmbedderBackward:
 
     def __init__(self, model):
         cfg = model.embedder.cfg
-        if cfg.unet_norm == "rms":
-            raise N.NativeError("EmbedderBackward covers the BatchNorm / ReLU U-Net of the released 1.0 / PixelSeal / ChunkySeal cards")
+        self.rms = cfg.unet_norm == "rms"        # the legacy card: ChanRMSNorm instead of BatchNorm (common.py:172-194), no batch statistics
+        self.act = N.ACT_SILU if cfg.unet_act == "silu" else N.ACT_RELU
+        if not self.rms and self.act != N.ACT_RELU:
+            raise N.NativeError("EmbedderBackward: BatchNorm U-Nets are covered with ReLU only")
         self.model = model
         self.h = DetectorStep.__new__(DetectorStep)          # the small helpers (_act, _vec, _colsum, _wgrad, _ln_bwd, _tw)
         self.h._ones = {}
@@ -597,9 +599,36 @@ class EmbedderBackward:
         return dw.view(co, 3, 3, x.ld)[..., :ci].permute(0, 3, 1, 2).contiguous()
 
     # ------------------------------------------------------------------ forward that keeps the backward's operands
+    def _rms_act(self, eng, raw: Act, gamma: torch.Tensor, out: Act, add: Optional[Act] = None):
+        N.check(eng.lib.vs_rmsnorm_act(N.ptr(raw.t), raw.rows, raw.C, raw.ld, N.ptr(gamma), self.act, N.ptr(add.t) if add is not None else None,
+                                       add.ld if add is not None else 0, N.ptr(out.t), out.ld, N.stream()), "vs_rmsnorm_act")
+        return out
+
+    def _rms_bwd(self, eng, raw: Act, gamma: torch.Tensor, dy: Act, tag: str):
+        """ChanRMSNorm + activation backward: d raw, d gamma [C, 1, 1]"""
+        h = self.h
+        dx = h._act(eng, tag, raw.B, raw.H, raw.W, raw.C, raw.ld)
+        term = h._act(eng, "e.g.rmsterm", raw.B, raw.H, raw.W, raw.C, raw.ld)
+        N.check(eng.lib.vs_rmsnorm_act_bwd(N.ptr(raw.t), raw.rows, raw.C, raw.ld, N.ptr(gamma), self.act, N.ptr(dy.t), dy.ld, N.ptr(dx.t), dx.ld,
+                                           N.ptr(term.t), term.ld, N.stream()), "vs_rmsnorm_act_bwd")
+        dg = h._colsum(eng, term, raw.C)
+        return dx, (dg.view(-1, 1, 1) if dg is not None else None)
+
     def _resblock_keep(self, eng, x: Act, p, tag: str, out: Optional[Act] = None):
         h = self.h
         cout = p["cout"]
+        if self.rms:              # silu(rms(conv(silu(rms(conv(x)))))) + res_conv(x): unet.py:17-39 with common.py:118-119, 172-179
+            raw0 = h._act(eng, tag + ".raw0", x.B, x.H, x.W, cout)
+            eng.conv(x, p["c0"], raw0, pad=1)
+            t = self._rms_act(eng, raw0, p["rms"][0], h._act(eng, tag + ".t", x.B, x.H, x.W, cout))
+            raw1 = h._act(eng, tag + ".raw1", x.B, x.H, x.W, cout)
+            eng.conv(t, p["c1"], raw1, pad=1)
+            rs = h._act(eng, tag + ".rs", x.B, x.H, x.W, cout)
+            eng.conv(x, p["res"], rs)
+            if out is None:
+                out = h._act(eng, tag + ".o", x.B, x.H, x.W, cout)
+            self._rms_act(eng, raw1, p["rms"][1], out, add=rs)
+            return out, dict(x=x, raw0=raw0, t=t, raw1=raw1)
         raw0 = h._act(eng, tag + ".raw0", x.B, x.H, x.W, cout)
         eng.conv(x, p["c0"], raw0, pad=1)
         s0 = self._bn_stats(eng, raw0, p["bn"][0])
@@ -663,7 +692,7 @@ class EmbedderBackward:
             z = h._act(eng, f"e.up{k}.z", B, cat.H, cat.W, cout)
             eng.layernorm(cv, up["lnw"], up["lnb"], z)
             ln = h._act(eng, f"e.up{k}.ln", B, cat.H, cat.W, cout)
-            self._affine_act(eng, z, h._vec(eng, z.ld, 1.0), h._vec(eng, z.ld, 0.0), N.ACT_RELU, ln)
+            self._affine_act(eng, z, h._vec(eng, z.ld, 1.0), h._vec(eng, z.ld, 0.0), self.act, ln)        # unet.py:61-62: the U-Net's act_layer
             xin = xcur
             xcur, rec = self._resblock_keep(eng, ln, up["rb"], f"e.up{k}")
             S["ups"].append(dict(xin=xin, skip=skip, cat=cat, cv=cv, z=z, rb=rec, cout=cout))
@@ -680,15 +709,23 @@ class EmbedderBackward:
         h, g = self.h, eng._g
         x, raw0, t, raw1 = rec["x"], rec["raw0"], rec["t"], rec["raw1"]
         cin, cout = x.C, raw1.C
-        draw1, dg, db = self._bn_bwd(eng, raw1, dout, rec["s1"], tag + ".draw1")
-        G[name + ".double_conv.4.weight"], G[name + ".double_conv.4.bias"] = dg, db
+        if self.rms:
+            draw1, dg = self._rms_bwd(eng, raw1, p["rms"][1], dout, tag + ".draw1")
+            G[name + ".double_conv.4.gamma"] = dg
+        else:
+            draw1, dg, db = self._bn_bwd(eng, raw1, dout, rec["s1"], tag + ".draw1")
+            G[name + ".double_conv.4.weight"], G[name + ".double_conv.4.bias"] = dg, db
         G[name + ".res_conv.weight"] = h._wgrad(eng, dout, cout, x, cin).view(cout, cin, 1, 1)
         G[name + ".res_conv.bias"] = h._colsum(eng, dout, cout)
         G[name + ".double_conv.3.weight"] = self._conv3_wgrad(eng, draw1, cout, t, cout)
         dt = h._act(eng, tag + ".dt", x.B, x.H, x.W, cout)
         eng.conv(draw1, self._flip_t(g(name + ".double_conv.3.weight"), draw1.ld), dt, pad=1, arith=BWD_ARITH)
-        draw0, dg, db = self._bn_bwd(eng, raw0, dt, rec["s0"], tag + ".draw0")
-        G[name + ".double_conv.1.weight"], G[name + ".double_conv.1.bias"] = dg, db
+        if self.rms:
+            draw0, dg = self._rms_bwd(eng, raw0, p["rms"][0], dt, tag + ".draw0")
+            G[name + ".double_conv.1.gamma"] = dg
+        else:
+            draw0, dg, db = self._bn_bwd(eng, raw0, dt, rec["s0"], tag + ".draw0")
+            G[name + ".double_conv.1.weight"], G[name + ".double_conv.1.bias"] = dg, db
         G[name + ".double_conv.0.weight"] = self._conv3_wgrad(eng, draw0, cout, x, cin)
         if not need_dx:
             return None
@@ -725,7 +762,7 @@ class EmbedderBackward:
             dln = self._resblock_bwd(eng, rec["rb"], up["rb"], name + ".conv", dcur, G, f"e.g.up{k}")
             z, cv, cat, cout = rec["z"], rec["cv"], rec["cat"], rec["cout"]
             dz = h._act(eng, f"e.g.up{k}.dz", B, z.H, z.W, cout)
-            N.check(L.vs_relu_bwd(N.ptr(z.t), z.ld, N.ptr(dln.t), dln.ld, z.rows, cout, N.ptr(dz.t), dz.ld, st), "vs_relu_bwd")
+            N.check(L.vs_act_bwd(N.ptr(z.t), z.ld, N.ptr(dln.t), dln.ld, z.rows, cout, self.act, N.ptr(dz.t), dz.ld, st), "vs_act_bwd")
             dcv, dw, db = h._ln_bwd(eng, cv, dz, up["lnw"], f"e.g.up{k}.dcv")
             G[name + ".up.upsample_block.3.weight"], G[name + ".up.upsample_block.3.bias"] = dw, db
             wname = name + ".up.upsample_block.2.weight"
