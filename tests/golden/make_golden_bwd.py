@@ -28,7 +28,7 @@ import make_golden as MG                                   # noqa: E402
 import make_golden_fwd as MF                               # noqa: E402
 
 from oracle.inputs import synthetic_frames, synthetic_msgs          # noqa: E402
-from oracle.weights import make_state_dict, spec_from_card, tiny_spec   # noqa: E402
+from oracle.weights import legacy_tiny_spec, make_state_dict, spec_from_card, tiny_spec   # noqa: E402
 
 from tests._util import BWD_FULL as FULL, projection_vector          # noqa: E402
 
@@ -91,6 +91,17 @@ def run_case(model, Augmenter, VideosealLoss, spec, name, *, n, h, w, seed, is_v
           f"params with grad={len(names)} without={missing} |g|max={rows[:, 0].max():.4g}")
 
 
+def legacy_sd(spec, seed=6):
+    """state dict of the tiny legacy architecture with seeded values in the position tables (vit.py:66-69, 334-336 initialise them with zeros:
+    their terms would not take part); tests/test_gpu_train.py rebuilds the same tensors"""
+    sd = make_state_dict(spec, seed=seed)
+    gen = torch.Generator().manual_seed(9)
+    for k in sd:
+        if k.endswith(("pos_embed", "rel_pos_h", "rel_pos_w")):
+            sd[k] = 0.2 * torch.randn(sd[k].shape, generator=gen)
+    return sd
+
+
 def main():
     torch.set_num_threads(8)
     MG.import_reference()
@@ -121,6 +132,16 @@ def main():
     model.load_state_dict(make_state_dict(spec, seed=0), strict=True)
     run_case(model, Augmenter, VideosealLoss, spec, "vs10_bwd_img_recipe", n=2, h=256, w=256, seed=44, is_video=False, loss_kw=recipe,
              full=("embedder.unet.outc.weight", "detector.pixel_decoder.linear.bias", "embedder.unet.inc.double_conv.1.weight"))
+    # ... and the legacy videoseal_0.0 family (RMSNorm / SiLU RGB U-Net, ViT extractor with windowed + global attention and relative positions,
+    # no JND) at its tiny size, adaptive weights; the position tables the reference initialises with zeros get seeded values (legacy_sd)
+    tv = legacy_tiny_spec()
+    tm = MG.build_reference(tv, MG.card_for_spec(tv))
+    tm.load_state_dict(legacy_sd(tv), strict=True)
+    run_case(tm, Augmenter, VideosealLoss, tv, "tinyv_bwd_img_balanced", n=3, h=72, w=88, seed=45, is_video=False,
+             loss_kw=dict(balanced=True, percep_weight=1.0, detect_weight=0.0, decode_weight=1.0, percep_loss="mse"),
+             full=("embedder.unet.outc.weight", "detector.pixel_decoder.linear.bias", "embedder.unet.inc.double_conv.1.gamma",
+                   "detector.image_encoder.blocks.0.attn.rel_pos_h", "detector.image_encoder.blocks.1.attn.rel_pos_w",
+                   "detector.image_encoder.pos_embed"))
 
 
 if __name__ == "__main__":

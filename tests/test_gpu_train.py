@@ -273,11 +273,20 @@ def _spec_sd(name):
     if name.startswith("vs10"):
         spec = spec_from_card(os.path.join(CARDS, "videoseal_1.0.yaml"))
         return spec, make_state_dict(spec, seed=0)
+    if name.startswith("tinyv"):          # the legacy family; position tables seeded as in tests/golden/make_golden_bwd.py::legacy_sd
+        from oracle.weights import legacy_tiny_spec
+        spec = legacy_tiny_spec()
+        sd = make_state_dict(spec, seed=6)
+        gen = torch.Generator().manual_seed(9)
+        for k in sd:
+            if k.endswith(("pos_embed", "rel_pos_h", "rel_pos_w")):
+                sd[k] = 0.2 * torch.randn(sd[k].shape, generator=gen)
+        return spec, sd
     spec = tiny_spec()
     return spec, make_state_dict(spec, seed=3)
 
 
-CASES = ["tiny_bwd_img_recipe", "tiny_bwd_img_balanced", "tiny_bwd_vid_recipe", "vs10_bwd_img_recipe"]
+CASES = ["tiny_bwd_img_recipe", "tiny_bwd_img_balanced", "tiny_bwd_vid_recipe", "vs10_bwd_img_recipe", "tinyv_bwd_img_balanced"]
 
 
 @pytest.mark.parametrize("name", CASES)
