@@ -179,16 +179,14 @@ def test_videoseal_import_shim_resolves_the_reference_paths():
         videoseal.load("videoseal")          # card found, checkpoint absent (no network): the reference's error type
 
 
-def test_detector_step_has_no_cpu_path_and_rejects_what_it_does_not_cover():
-    """videoseal_amd.training.DetectorStep (train.py:517-523): loud on a CPU model and on the ViT extractor of the legacy card; malformed
-    inputs are rejected before any launch."""
+def test_detector_step_has_no_cpu_path():
+    """videoseal_amd.training.DetectorStep (train.py:517-523): loud on a CPU model, for the ConvNeXt-V2 extractor and for the ViT extractor of
+    the legacy card alike (no CPU fallback of the training path either)"""
     from videoseal_amd.training import DetectorStep
-    m = videoseal_amd.build("videoseal_1.0").train()
-    step = DetectorStep(m)
-    with pytest.raises(native.NativeError, match="no CPU execution path"):
-        step.step(torch.rand(2, 3, 256, 256), torch.zeros(2, 256))
-    with pytest.raises(native.NativeError, match="ConvNeXt"):
-        DetectorStep(videoseal_amd.build("videoseal_0.0"))
+    for card in ("videoseal_1.0", "videoseal_0.0"):
+        m = videoseal_amd.build(card).train()
+        with pytest.raises(native.NativeError, match="no CPU execution path"):
+            DetectorStep(m).step(torch.rand(2, 3, 256, 256), torch.zeros(2, m.embedder.cfg.nbits))
 
 
 def test_validation_tables_match_the_reference():
