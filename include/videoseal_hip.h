@@ -304,6 +304,10 @@ int vs_cnx_block(const void* tn_planes, const void* wimg, int C, int64_t rows, i
  * the 16-bit planes [P][N][K] and their LDS-image order [ceil(N/32)][K/16][P][64][8] the split kernels read (P = 3 bf16 truncation terms for
  * arith 3; P = 2 f16 terms of w * w_mul for arith 2).  One launch per layer instead of a dozen ATen ops. */
 int vs_split_block(const float* wt, int N, int64_t K, int ntaps, int arith, float w_mul, void* split, void* blk, void* stream);
+/* vs_pack_conv: fp32 conv weights [Co][Ci][KH][KW] -> the packed matrix [rows][KH*KW*cinp] (k = (ky * KW + kx) * cinp + c, pad channels zero) that
+ * vs_conv_gemm / vs_split_block read.  transpose = 0: rows = Co, channels = Ci (the forward weights); transpose = 1: rows = Ci, channels = Co,
+ * taps flipped -- the backward-data weights of the same layer (for 1x1: the transposed GEMM matrix). */
+int vs_pack_conv(const float* w, int Co, int Ci, int KH, int KW, int cinp, int transpose, float* out, void* stream);
 
 /* ---- adjoints of the full-resolution shell and of the augmentations between embed and detect (csrc/bwd_shell.hip): d(loss)/d(imgs_w) and
  * d(loss)/d(imgs_aug) -> d(delta), the gradient the U-Net backward starts from (train.py:626-643).  Gather form, deterministic.

@@ -844,3 +844,20 @@ def test_device_weight_pack_is_bit_identical_to_the_torch_pack(n, cin, kh, kw, a
     assert cw.w_mul == w_mul
     assert torch.equal(cw.split.cpu(), ref_split)
     assert torch.equal(cw.blk.cpu(), E.pack_blocked(ref_split, kh * kw))
+
+
+@pytest.mark.parametrize("co,ci,k,in_ld", [(16, 3, 3, 4), (384, 384, 3, 384), (40, 130, 1, 132), (24, 64, 2, 64), (7, 5, 3, 8)])
+def test_pack_conv_on_the_device(co, ci, k, in_ld):
+    """vs_pack_conv (one launch) == the ATen formulation of engine.pack_conv, and its transpose mode == pack_conv of the flipped / transposed
+    weights (the backward-data weights of training.py)"""
+    from videoseal_amd.engine import pack_conv_bwd
+    g = torch.Generator().manual_seed(co + ci)
+    w = torch.randn(co, ci, k, k, generator=g)
+    ref, cp = pack_conv(w, in_ld)                       # CPU tensor: the ATen path
+    got, cp2 = pack_conv(w.to(DEV), in_ld)
+    assert cp == cp2 and torch.equal(got.cpu(), ref)
+    out_ld = (co + 3) // 4 * 4
+    wb = w.flip(2, 3).permute(1, 0, 2, 3).contiguous()
+    refb, cpb = pack_conv(wb, out_ld)
+    gotb, cpb2 = pack_conv_bwd(w.to(DEV), out_ld)
+    assert cpb == cpb2 and torch.equal(gotb.cpu(), refb)

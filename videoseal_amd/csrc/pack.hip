@@ -47,6 +47,28 @@ __global__ __launch_bounds__(256) void split_block_kernel(const float* __restric
   }
 }
 
+// fp32 conv weights [N][Cin][KH][KW] -> the packed matrix [N'][KH*KW*CinP] the conv / GEMM kernels read, k = (ky * KW + kx) * CinP + c, channels
+// >= Cin' zero (engine.pack_conv) -- one launch instead of zeros + permute + copy.  transpose = 1 packs the BACKWARD-DATA weights directly:
+// rows = input channels, columns = output channels, taps flipped (W'[ci][co][ky][kx] = W[co][ci][KH-1-ky][KW-1-kx]; for a 1x1 layer the plain
+// transpose of a Linear / GEMM matrix).
+__global__ __launch_bounds__(256) void pack_conv_kernel(const float* __restrict__ w, int Co, int Ci, int KH, int KW, int cinp, int transpose,
+                                                        int64_t total, float* __restrict__ out) {
+  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= total) return;
+  const int c = (int)(idx % cinp);
+  const int64_t r = idx / cinp;
+  const int t = (int)(r % (KH * KW));
+  const int n = (int)(r / (KH * KW));
+  const int ky = t / KW, kx = t - ky * KW;
+  float v = 0.f;
+  if (!transpose) {
+    if (c < Ci) v = w[(((int64_t)n * Ci + c) * KH + ky) * KW + kx];
+  } else {
+    if (c < Co) v = w[(((int64_t)c * Ci + n) * KH + (KH - 1 - ky)) * KW + (KW - 1 - kx)];
+  }
+  out[idx] = v;
+}
+
 }  // namespace
 
 extern "C" int vs_split_block(const float* wt, int N, int64_t K, int ntaps, int arith, float w_mul, void* split, void* blk, void* stream) {
@@ -59,5 +81,12 @@ extern "C" int vs_split_block(const float* wt, int N, int64_t K, int ntaps, int 
   else
     hipLaunchKernelGGL(split_block_kernel<3>, dim3(grid), dim3(256), 0, (hipStream_t)stream, wt, N, K, ntaps, w_mul, (unsigned short*)split,
                        (unsigned short*)blk);
+  return vs_launch_status();
+}
+
+extern "C" int vs_pack_conv(const float* w, int Co, int Ci, int KH, int KW, int cinp, int transpose, float* out, void* stream) {
+  VS_REQUIRE(w && out && Co > 0 && Ci > 0 && KH > 0 && KW > 0 && cinp >= (transpose ? Co : Ci) && (transpose == 0 || transpose == 1));
+  const int64_t total = (int64_t)(transpose ? Ci : Co) * KH * KW * cinp;
+  hipLaunchKernelGGL(pack_conv_kernel, dim3((unsigned)cdiv64(total, 256)), dim3(256), 0, (hipStream_t)stream, w, Co, Ci, KH, KW, cinp, transpose, total, out);
   return vs_launch_status();
 }

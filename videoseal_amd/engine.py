@@ -152,12 +152,30 @@ def pack_conv(w: torch.Tensor, in_ld: int, scale: Optional[torch.Tensor] = None)
     `scale` (per output channel, e.g. folded BatchNorm) multiplies the rows."""
     n, cin, kh, kw = w.shape
     cinp = rup(max(in_ld, cin), 16)
+    if w.is_cuda and scale is None:           # one launch (csrc/pack.hip) instead of zeros + permute + copy: a training step packs every layer
+        wf = N.f32c(w)
+        out = torch.empty(n, kh * kw * cinp, device=w.device, dtype=torch.float32)
+        with torch.cuda.device(w.device):
+            N.check(N.lib().vs_pack_conv(N.ptr(wf), n, cin, kh, kw, cinp, 0, N.ptr(out), N.stream()), "vs_pack_conv")
+        return out, cinp
     out = torch.zeros(n, kh * kw, cinp, device=w.device, dtype=torch.float32)
     wk = w.float().permute(0, 2, 3, 1).reshape(n, kh * kw, cin)
     if scale is not None:
         wk = wk * scale.float()[:, None, None]
     out[:, :, :cin] = wk
     return out.reshape(n, kh * kw * cinp).contiguous(), cinp
+
+
+def pack_conv_bwd(w: torch.Tensor, in_ld: int) -> Tuple[torch.Tensor, int]:
+    """the backward-DATA weights of a conv [Co,Ci,KH,KW] (stride 1, 'same' padding) packed like pack_conv: rows = input channels, columns = output
+    channels, taps flipped (dX = conv(dY, W')); for a 1x1 / Linear layer [N,K,1,1] the transposed GEMM matrix.  `in_ld`: row stride of dY."""
+    co, ci, kh, kw = w.shape
+    cinp = rup(max(in_ld, co), 16)
+    wf = N.f32c(w)
+    out = torch.empty(ci, kh * kw * cinp, device=w.device, dtype=torch.float32)
+    with torch.cuda.device(w.device):
+        N.check(N.lib().vs_pack_conv(N.ptr(wf), co, ci, kh, kw, cinp, 1, N.ptr(out), N.stream()), "vs_pack_conv")
+    return out, cinp
 
 
 def pack_patch_conv(w: torch.Tensor, pix_ld: int) -> Tuple[torch.Tensor, int]:

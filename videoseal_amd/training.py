@@ -17,7 +17,7 @@ from typing import Dict, List, Optional, Tuple
 import torch
 
 from . import native as N
-from .engine import A_MUL_GRN, Act, ConvW, HipEngine, pack_conv, rup
+from .engine import A_MUL_GRN, Act, ConvW, HipEngine, pack_conv, pack_conv_bwd, rup
 
 DIRECT_WGRAD = os.environ.get("VIDEOSEAL_DIRECT_WGRAD", "1") != "0"       # 0: 3x3 weight gradients through the explicit patch matrix (A/B)
 BWD_ARITH = 3          # 3 x bf16: exact operand split, fp32 exponent range (vs_conv_desc_t::arith)
@@ -99,9 +99,8 @@ class DetectorStep:
     @staticmethod
     def _tw(weight2d: torch.Tensor, in_ld: int) -> ConvW:
         """the transposed matrix of a Linear / 1x1 layer as a forward GEMM weight: dX = dY W"""
-        wt = weight2d.float().t().contiguous()                    # [K_out = fan_in][fan_out]
-        p, cp = pack_conv(wt[:, :, None, None], in_ld)
-        return ConvW(p, None, wt.shape[0], 1, 1, cp)
+        p, cp = pack_conv_bwd(weight2d[:, :, None, None], in_ld)   # [K_out = fan_in][fan_out]: one launch (csrc/pack.hip)
+        return ConvW(p, None, weight2d.shape[1], 1, 1, cp)
 
     # ------------------------------------------------------------------ forward that keeps the backward's operands
     def _forward(self, eng: HipEngine, x: Act):
@@ -568,9 +567,8 @@ class EmbedderBackward:
     @staticmethod
     def _flip_t(w4: torch.Tensor, in_ld: int) -> ConvW:
         """backward-data weights of a 3x3 stride-1 pad-1 conv: W'[ci][co][ky][kx] = W[co][ci][2 - ky][2 - kx]"""
-        wb = w4.float().flip(2, 3).permute(1, 0, 2, 3).contiguous()
-        p, cp = pack_conv(wb, in_ld)
-        return ConvW(p, None, wb.shape[0], 3, 3, cp)
+        p, cp = pack_conv_bwd(w4, in_ld)
+        return ConvW(p, None, w4.shape[1], 3, 3, cp)
 
     def _cols_zero(self, eng, x: Act, stride: int, tag: str) -> Act:
         L, st = eng.lib, N.stream()
