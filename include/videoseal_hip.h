@@ -332,6 +332,14 @@ int64_t vs_aug_color_bwd_scratch_floats(int F, int H, int W);
 int vs_aug_color_bwd(const float* x, const float* dy, float* dx, int F, int H, int W, int op, float factor, const float* means, float* scratch,
                      void* stream);
 int vs_clamp01_bwd(const float* x, const float* dy, float* dx, int64_t n, void* stream);
+/* vs_gaussian_blur_bwd: adjoint of vs_gaussian_blur (reflection padding folded back); tmp: planes * H * W floats.
+ * vs_aug_warp_bwd: adjoint of vs_aug_warp (Rotate: nearest, Perspective: bilinear; zero padding), gather form, deterministic.  inv[9]: the
+ * row-major 3 x 3 map from input pixel-centre coordinates (x + 0.5, y + 0.5, 1) to homogeneous output pixel-centre coordinates -- the inverse
+ * of the sampling map, used only to bound the search (every candidate is re-sampled with the forward arithmetic).
+ * vs_aug_color_bwd now covers the hue op as well (chain rule through torchvision's RGB -> HSV -> RGB with autograd's conventions). */
+int vs_gaussian_blur_bwd(const float* dy, float* tmp, float* dx, int planes, int H, int W, int k, float sigma, void* stream);
+int vs_aug_warp_bwd(const float* dy, float* dx, int planes, int H, int W, int oh, int ow, int kind, const float* coeffs, int bilinear,
+                    const float* inv, void* stream);
 int vs_nhwc_to_nchw_scaled(const float* src, int F, int H, int W, int C, int64_t ld, float mul, float* dst, void* stream);
 int64_t vs_percep_partial_doubles(int F, int H, int W);
 int vs_percep_mse(const float* imgs, const float* imgs_w, int F, int H, int W, int yuv, double* partial, float* loss, void* stream);

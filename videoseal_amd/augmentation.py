@@ -99,9 +99,7 @@ def _no_adjoint(fn, what: str):
 
 def gaussian_blur(x: torch.Tensor, kernel_size: int) -> torch.Tensor:
     if AG.needs_grad(x):
-        with torch.no_grad():
-            y = gaussian_blur(x, kernel_size)
-        return AG.NoAdjointFn.apply(x, y, "GaussianBlur")
+        return AG.BlurFn.apply(x, kernel_size)
     x = _dev(x)
     planes, H, W = _planes(x)
     sigma = 0.3 * ((kernel_size - 1) * 0.5 - 1) + 0.8            # torchvision default when sigma is None
@@ -483,7 +481,10 @@ def rotate(x: torch.Tensor, angle: float, expand: bool = False) -> torch.Tensor:
     ow, oh = _affine_out_size(m, W, H) if expand else (W, H)
     th = np.array(m, dtype=np.float32).reshape(2, 3)
     resc = (th.T / np.array([0.5 * W, 0.5 * H], dtype=np.float32)).astype(np.float32)      # [3][2], as _gen_affine_grid
-    coeffs = (C.c_float * 6)(*[float(resc[k][0]) for k in range(3)], *[float(resc[k][1]) for k in range(3)])
+    cl = [float(resc[k][0]) for k in range(3)] + [float(resc[k][1]) for k in range(3)]
+    if AG.needs_grad(x):
+        return AG.WarpFn.apply(x, 0, cl, 0, (oh, ow))
+    coeffs = (C.c_float * 6)(*cl)
     out = torch.empty(x.shape[0], x.shape[1], oh, ow, device=x.device, dtype=torch.float32)
     N.check(N.lib().vs_aug_warp(N.ptr(x), N.ptr(out), planes, H, W, oh, ow, 0, coeffs, 0, N.stream()), "vs_aug_warp")
     return out
@@ -504,14 +505,16 @@ def perspective(x: torch.Tensor, startpoints, endpoints) -> torch.Tensor:
     """torchvision F.perspective(img, startpoints, endpoints, interpolation=BILINEAR, fill=None) on vs_aug_warp."""
     x = _dev(x)
     planes, H, W = _planes(x)
-    coeffs = (C.c_float * 8)(*perspective_coeffs(startpoints, endpoints))
+    pc = perspective_coeffs(startpoints, endpoints)
+    if AG.needs_grad(x):
+        return AG.WarpFn.apply(x, 1, pc, 1, (H, W))
+    coeffs = (C.c_float * 8)(*pc)
     out = torch.empty_like(x)
     N.check(N.lib().vs_aug_warp(N.ptr(x), N.ptr(out), planes, H, W, H, W, 1, coeffs, 1, N.stream()), "vs_aug_warp")
     return out
 
 
 rotate_values, perspective_values = rotate, perspective
-rotate, perspective = _no_adjoint(rotate, "Rotate"), _no_adjoint(perspective, "Perspective")
 
 
 class Rotate(_Aug):

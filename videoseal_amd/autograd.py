@@ -101,14 +101,12 @@ class MaskBlendFn(torch.autograd.Function):
 
 
 class ColorFn(torch.autograd.Function):
-    """valuemetric.py:53-175: brightness / contrast / saturation (torchvision's blend + clamp) and grayscale; hue has no adjoint here"""
+    """valuemetric.py:53-175: brightness / contrast / saturation (torchvision's blend + clamp), grayscale, and hue (the chain rule through
+    torchvision's RGB -> HSV -> RGB round trip with autograd's conventions, bwd_shell.hip::hue_bwd)"""
 
     @staticmethod
     def forward(ctx, x, op, factor):
         from . import augmentation as A
-        if op == "hue":
-            raise NotImplementedError("Hue inside a differentiable forward: its HSV round trip has no adjoint kernel here (draw another "
-                                      "augmentation, or run the augmenter under torch.no_grad())")
         x = A._dev(x)
         F_, Cc, H, W = x.shape
         L = N.lib()
@@ -130,6 +128,69 @@ class ColorFn(torch.autograd.Function):
         N.check(L.vs_aug_color_bwd(N.ptr(x), N.ptr(dy), N.ptr(dx), F_, H, W, ctx.op, ctx.factor, N.ptr(means) if means.numel() else None,
                                    N.ptr(scratch), N.stream()), "vs_aug_color_bwd")
         return dx, None, None
+
+
+class BlurFn(torch.autograd.Function):
+    """valuemetric.py:108-128 GaussianBlur (torchvision gaussian_blur, reflection padding): forward kernel, adjoint = the same separable filter
+    over the reflection-padded gradient folded back (vs_gaussian_blur_bwd)"""
+
+    @staticmethod
+    def forward(ctx, x, kernel_size):
+        from . import augmentation as A
+        with torch.no_grad():
+            y = A.gaussian_blur(x.detach(), kernel_size)
+        ctx.k, ctx.shape = int(kernel_size), tuple(x.shape)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        dy = _c(dy)
+        k = ctx.k
+        planes, H, W = ctx.shape[0] * ctx.shape[1], ctx.shape[-2], ctx.shape[-1]
+        sigma = 0.3 * ((k - 1) * 0.5 - 1) + 0.8
+        tmp, dx = torch.empty_like(dy), torch.empty_like(dy)
+        N.check(N.lib().vs_gaussian_blur_bwd(N.ptr(dy), N.ptr(tmp), N.ptr(dx), planes, H, W, k, sigma, N.stream()), "vs_gaussian_blur_bwd")
+        return dx, None
+
+
+class WarpFn(torch.autograd.Function):
+    """geometric.py:28-59 Rotate (nearest) and :127-183 Perspective (bilinear) on vs_aug_warp; adjoint in gather form (vs_aug_warp_bwd).
+    coeffs: the kernel's sampling coefficients; out_hw: output size; the 3 x 3 inverse that bounds the adjoint's search is computed here in fp64."""
+
+    @staticmethod
+    def forward(ctx, x, kind, coeffs, bilinear, out_hw):
+        import ctypes as C
+        import numpy as np
+        from . import augmentation as A
+        x = A._dev(x)
+        planes, H, W = x.shape[0] * x.shape[1], x.shape[-2], x.shape[-1]
+        oh, ow = out_hw
+        t = [float(v) for v in coeffs]
+        carr = (C.c_float * len(t))(*t)
+        out = torch.empty(x.shape[0], x.shape[1], oh, ow, device=x.device, dtype=torch.float32)
+        N.check(N.lib().vs_aug_warp(N.ptr(x), N.ptr(out), planes, H, W, oh, ow, int(kind), carr, int(bilinear), N.stream()), "vs_aug_warp")
+        # M: (cx, cy, 1) of an output pixel centre -> homogeneous input pixel-centre coordinates (ix + 0.5, iy + 0.5, 1) * w  (aug.hip::warp_kernel)
+        if kind == 0:
+            M = np.array([[0.5 * W * t[0], 0.5 * W * t[1], 0.5 * W * (t[2] + 1.0 - 0.5 * ow * t[0] - 0.5 * oh * t[1])],
+                          [0.5 * H * t[3], 0.5 * H * t[4], 0.5 * H * (t[5] + 1.0 - 0.5 * ow * t[3] - 0.5 * oh * t[4])],
+                          [0.0, 0.0, 1.0]], dtype=np.float64)
+        else:
+            M = np.array([[W / ow * t[0], W / ow * t[1], W / ow * t[2]], [H / oh * t[3], H / oh * t[4], H / oh * t[5]], [t[6], t[7], 1.0]],
+                         dtype=np.float64)
+        inv = np.linalg.inv(M)
+        inv = inv / inv[2, 2] if abs(inv[2, 2]) > 1e-12 else inv
+        ctx.args = (planes, H, W, oh, ow, int(kind), t, int(bilinear), [float(v) for v in inv.reshape(-1)])
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        import ctypes as C
+        planes, H, W, oh, ow, kind, t, bilinear, inv = ctx.args
+        dy = _c(dy)
+        dx = torch.empty(dy.shape[0], dy.shape[1], H, W, device=dy.device, dtype=torch.float32)
+        N.check(N.lib().vs_aug_warp_bwd(N.ptr(dy), N.ptr(dx), planes, H, W, oh, ow, kind, (C.c_float * len(t))(*t), bilinear, (C.c_float * 9)(*inv),
+                                        N.stream()), "vs_aug_warp_bwd")
+        return dx, None, None, None, None
 
 
 class SteFn(torch.autograd.Function):

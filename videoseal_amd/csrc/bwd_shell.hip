@@ -192,6 +192,66 @@ __global__ void color_bwd_finish_kernel(const double* __restrict__ partial, int 
   for (int k = 0; k < nblk; ++k) s += partial[(int64_t)f * nblk + k];
   sums[f] = (float)s;
 }
+// ---- Hue (torchvision adjust_hue = _rgb2hsv -> (h + factor) % 1 -> _hsv2rgb, valuemetric.py:168-171): the chain rule through exactly the
+// operations of aug.hip::hue_shift, with autograd's conventions: max / min send their gradient to the arg-max / arg-min channel (first index on
+// ties), comparisons and floor carry none, fmod / % pass it through, clamp passes it inside [0, 1] (bounds included).
+__device__ __forceinline__ void hue_bwd(const float (&x)[3], const float (&gy)[3], float factor, float (&dx)[3]) {
+  const float r = x[0], g = x[1], b = x[2];
+  const float maxc = fmaxf(r, fmaxf(g, b)), minc = fminf(r, fminf(g, b));
+  const int imax = (r == maxc) ? 0 : ((g == maxc) ? 1 : 2);
+  const int imin = (r == minc) ? 0 : ((g == minc) ? 1 : 2);
+  const bool eqc = maxc == minc;
+  const float cr = maxc - minc;
+  const float sdiv = eqc ? 1.f : maxc, div = eqc ? 1.f : cr;
+  const float s = cr / sdiv;
+  const float rc = (maxc - r) / div, gc = (maxc - g) / div, bc = (maxc - b) / div;
+  const int branch = (maxc == r) ? 0 : ((maxc == g) ? 1 : 2);
+  const float hsum = branch == 0 ? (bc - gc) : (branch == 1 ? (2.0f + rc - bc) : (4.0f + gc - rc));
+  float h = fmodf(hsum / 6.0f + 1.0f, 1.0f);
+  const float v = maxc;
+  h = h + factor;
+  h = h - floorf(h);
+  const float h6 = h * 6.0f;
+  const float fi = floorf(h6);
+  const float f = h6 - fi;
+  int i = (int)fi;
+  i = ((i % 6) + 6) % 6;
+  const float pu = v * (1.0f - s), qu = v * (1.0f - s * f), tu = v * (1.0f - s * (1.0f - f));
+  // gradients of the selected outputs
+  float dv = 0.f, dp = 0.f, dq = 0.f, dt = 0.f;
+  switch (i) {
+    case 0: dv = gy[0]; dt = gy[1]; dp = gy[2]; break;
+    case 1: dq = gy[0]; dv = gy[1]; dp = gy[2]; break;
+    case 2: dp = gy[0]; dv = gy[1]; dt = gy[2]; break;
+    case 3: dp = gy[0]; dq = gy[1]; dv = gy[2]; break;
+    case 4: dt = gy[0]; dp = gy[1]; dv = gy[2]; break;
+    default: dv = gy[0]; dp = gy[1]; dq = gy[2]; break;
+  }
+  if (!pass01(pu)) dp = 0.f;
+  if (!pass01(qu)) dq = 0.f;
+  if (!pass01(tu)) dt = 0.f;
+  float ds = 0.f, df = 0.f;
+  dv += dp * (1.0f - s) + dq * (1.0f - s * f) + dt * (1.0f - s * (1.0f - f));
+  ds += -dp * v - dq * v * f - dt * v * (1.0f - f);
+  df += -dq * v * s + dt * v * s;
+  const float dhsum = df;                              // f = 6 h - i, h = (hsum / 6 + 1) mod 1 (+ factor, mod 1)
+  float drc = 0.f, dgc = 0.f, dbc = 0.f;
+  if (branch == 0) { dbc += dhsum; dgc -= dhsum; }
+  else if (branch == 1) { drc += dhsum; dbc -= dhsum; }
+  else { dgc += dhsum; drc -= dhsum; }
+  float dmax = dv, dmin = 0.f, dcr = 0.f;
+  dx[0] = -drc / div; dx[1] = -dgc / div; dx[2] = -dbc / div;
+  dmax += (drc + dgc + dbc) / div;
+  if (!eqc) {
+    dcr -= (drc * (maxc - r) + dgc * (maxc - g) + dbc * (maxc - b)) / (div * div);
+    dmax -= ds * cr / (maxc * maxc);
+  }
+  dcr += ds / sdiv;
+  dmax += dcr; dmin -= dcr;
+  dx[imax] += dmax;
+  dx[imin] += dmin;
+}
+
 __global__ __launch_bounds__(256) void color_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ dx, int64_t plane,
                                                         int op, float factor, const float* __restrict__ means, const float* __restrict__ sums) {
   const int f = blockIdx.y;
@@ -218,6 +278,9 @@ __global__ __launch_bounds__(256) void color_bwd_kernel(const float* __restrict_
         for (int c = 0; c < 3; ++c) { pg[c] = pass01(factor * v[c] + m) ? gy[c] : 0.f; tot += pg[c]; }
         for (int c = 0; c < 3; ++c) o[c] = factor * pg[c] + (1.0f - factor) * gw[c] * tot;
       } break;
+      case OP_HUE:
+        hue_bwd(v, gy, factor, o);
+        break;
       default: {                                                                 // grayscale: y_c = 0.299 r + 0.587 g + 0.114 b for every c
         const float tot = gy[0] + gy[1] + gy[2];
         o[0] = 0.299f * tot; o[1] = 0.587f * tot; o[2] = 0.114f * tot;
@@ -225,6 +288,94 @@ __global__ __launch_bounds__(256) void color_bwd_kernel(const float* __restrict_
     }
     d[i] = o[0]; d[plane + i] = o[1]; d[2 * plane + i] = o[2];
   }
+}
+
+// ---- GaussianBlur (torchvision gaussian_blur: reflection padding k / 2, separable kernel; valuemetric.py:108-128): adjoint of one 1-d pass,
+// gather form.  Forward y[o] = sum_t w[t] x[refl(o + t - r)]; the padded position i = o + t - r collects dxp[i] = sum_t w[t] dy[i - t + r]
+// (outputs outside the row contribute nothing), and position u of the row receives dxp[u] + dxp[-u] (1 <= u <= r) + dxp[2 (n - 1) - u]
+// (n - 1 - r <= u <= n - 2): the adjoint of the reflection.
+struct GaussW { float w[33]; int k; };
+__global__ __launch_bounds__(256) void blur_bwd_pass_kernel(const float* __restrict__ src, float* __restrict__ dst, int H, int W, GaussW g, int vertical) {
+  const int x = blockIdx.x * 32 + (threadIdx.x & 31), y = blockIdx.y * 8 + (threadIdx.x >> 5);
+  if (x >= W || y >= H) return;
+  const float* sp = src + (int64_t)blockIdx.z * H * W;
+  const int r = g.k / 2, n = vertical ? H : W, u = vertical ? y : x;
+  const int64_t stride = vertical ? W : 1;
+  const float* line = sp + (vertical ? x : (int64_t)y * W);
+  auto dxp = [&](int i) -> float {
+    float a = 0.f;
+    for (int t = 0; t < g.k; ++t) {
+      const int o = i - t + r;
+      if (o >= 0 && o < n) a += g.w[t] * line[(int64_t)o * stride];
+    }
+    return a;
+  };
+  float acc = dxp(u);
+  if (u >= 1 && u <= r) acc += dxp(-u);
+  if (u >= n - 1 - r && u <= n - 2) acc += dxp(2 * (n - 1) - u);
+  dst[((int64_t)blockIdx.z * H + y) * W + x] = acc;
+}
+
+// ---- Rotate (nearest) / Perspective (bilinear): adjoint of aug.hip::warp_kernel (torchvision's affine / perspective grid + grid_sample with zero
+// padding, align_corners = False; geometric.py:28-59, 127-183), gather form: thread = input pixel u.  `inv` maps the pixel-centre coordinates of
+// the INPUT to those of the output (the 3 x 3 inverse of the sampling map, computed by the host in fp64): it only bounds the search -- every output
+// pixel of the bounding box of u's 2 x 2 footprint (+- 1.5) is re-sampled with the forward kernel's own arithmetic and contributes with the
+// weight the forward gave u (nearest: 1 if it rounded to u).
+struct WarpB { float t[8]; float inv[9]; int kind, bilinear; };
+__device__ __forceinline__ void warp_sample(const WarpB& a, int ox, int oy, int ow, int oh, int W, int H, float& ix, float& iy) {
+  float gx, gy;
+  if (a.kind == 0) {
+    const float bx = (float)ox + (0.5f - ow * 0.5f), by = (float)oy + (0.5f - oh * 0.5f);
+    gx = (bx * a.t[0] + by * a.t[1]) + a.t[2];
+    gy = (bx * a.t[3] + by * a.t[4]) + a.t[5];
+  } else {
+    const float bx = (float)ox + 0.5f, by = (float)oy + 0.5f;
+    const float n1 = (bx * (a.t[0] / (0.5f * ow)) + by * (a.t[1] / (0.5f * ow))) + a.t[2] / (0.5f * ow);
+    const float n2 = (bx * (a.t[3] / (0.5f * oh)) + by * (a.t[4] / (0.5f * oh))) + a.t[5] / (0.5f * oh);
+    const float den = (bx * a.t[6] + by * a.t[7]) + 1.0f;
+    gx = n1 / den - 1.0f;
+    gy = n2 / den - 1.0f;
+  }
+  ix = ((gx + 1.f) * W - 1.f) / 2.f;
+  iy = ((gy + 1.f) * H - 1.f) / 2.f;
+}
+__global__ __launch_bounds__(256) void warp_bwd_kernel(const float* __restrict__ dy, float* __restrict__ dx, int H, int W, int oh, int ow, WarpB a) {
+  const int ux = blockIdx.x * 32 + (threadIdx.x & 31), uy = blockIdx.y * 8 + (threadIdx.x >> 5);
+  if (ux >= W || uy >= H) return;
+  const float* gp = dy + (int64_t)blockIdx.z * oh * ow;
+  // bounding box, in output pixels, of the input square [ux - 1, ux + 1] x [uy - 1, uy + 1]
+  float lox = 1e30f, hix = -1e30f, loy = 1e30f, hiy = -1e30f;
+  bool whole = false;
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    const float px = (float)ux + 0.5f + ((c & 1) ? 1.f : -1.f), py = (float)uy + 0.5f + ((c & 2) ? 1.f : -1.f);
+    const float cw = a.inv[6] * px + a.inv[7] * py + a.inv[8];
+    if (!(cw > 1e-6f)) { whole = true; continue; }
+    const float cx = (a.inv[0] * px + a.inv[1] * py + a.inv[2]) / cw - 0.5f, cy = (a.inv[3] * px + a.inv[4] * py + a.inv[5]) / cw - 0.5f;
+    lox = fminf(lox, cx); hix = fmaxf(hix, cx); loy = fminf(loy, cy); hiy = fmaxf(hiy, cy);
+  }
+  int x0 = 0, x1 = ow - 1, y0 = 0, y1 = oh - 1;
+  if (!whole) {
+    x0 = max(0, (int)floorf(lox - 1.5f)); x1 = min(ow - 1, (int)ceilf(hix + 1.5f));
+    y0 = max(0, (int)floorf(loy - 1.5f)); y1 = min(oh - 1, (int)ceilf(hiy + 1.5f));
+  }
+  float acc = 0.f;
+  for (int oy = y0; oy <= y1; ++oy)
+    for (int ox = x0; ox <= x1; ++ox) {
+      float ix, iy;
+      warp_sample(a, ox, oy, ow, oh, W, H, ix, iy);
+      float wgt = 0.f;
+      if (!a.bilinear) {
+        if (nearbyintf(ix) == (float)ux && nearbyintf(iy) == (float)uy) wgt = 1.f;
+      } else {
+        const float fx = floorf(ix), fy = floorf(iy);
+        const float wx = fx == (float)ux ? (fx + 1.f - ix) : (fx + 1.f == (float)ux ? (ix - fx) : 0.f);
+        const float wy = fy == (float)uy ? (fy + 1.f - iy) : (fy + 1.f == (float)uy ? (iy - fy) : 0.f);
+        wgt = wx * wy;
+      }
+      if (wgt != 0.f) acc += wgt * gp[(int64_t)oy * ow + ox];
+    }
+  dx[((int64_t)blockIdx.z * H + uy) * W + ux] = acc;
 }
 
 // ---- JPEG.forward's clamp in front of the straight-through estimator (valuemetric.py:41): dx = dy where 0 <= x <= 1
@@ -346,7 +497,7 @@ extern "C" int64_t vs_aug_color_bwd_scratch_floats(int F, int H, int W) {
 extern "C" int vs_aug_color_bwd(const float* x, const float* dy, float* dx, int F, int H, int W, int op, float factor, const float* means, float* scratch,
                                 void* stream) {
   // `means`: the per-frame gray means the forward pass used (vs_aug_color's scratch, first F floats); only the contrast op reads it
-  VS_REQUIRE(x && dy && dx && F > 0 && H > 0 && W > 0 && op >= 0 && op <= 4 && op != OP_HUE);
+  VS_REQUIRE(x && dy && dx && F > 0 && H > 0 && W > 0 && op >= 0 && op <= 4);
   const int64_t plane = (int64_t)H * W;
   float* sums = nullptr;
   hipStream_t st = (hipStream_t)stream;
@@ -389,5 +540,34 @@ extern "C" int vs_percep_mse_grad(const float* imgs, const float* imgs_w, int F,
   const float gs = upstream * 2.0f / (3.0f * (float)F * (float)plane);
   hipLaunchKernelGGL(percep_grad_kernel, dim3(gridx((int64_t)F * plane)), dim3(256), 0, (hipStream_t)stream, imgs, imgs_w, F, plane, yuv, yuv_matrix(), gs,
                      d_imgs_w);
+  return vs_launch_status();
+}
+
+extern "C" int vs_gaussian_blur_bwd(const float* dy, float* tmp, float* dx, int planes, int H, int W, int k, float sigma, void* stream) {
+  VS_REQUIRE(dy && tmp && dx && planes > 0 && H > 0 && W > 0 && k >= 1 && (k & 1) && k <= 33 && sigma > 0.f && k / 2 < H && k / 2 < W);
+  GaussW g; g.k = k;
+  float sum = 0.f;                       // the weights of aug.hip::vs_gaussian_blur (torchvision _get_gaussian_kernel1d), same arithmetic
+  const float half = (k - 1) * 0.5f;
+  for (int i = 0; i < k; ++i) {
+    const float x = (k == 1) ? 0.f : (-half + (2.f * half) * (float)i / (float)(k - 1));
+    g.w[i] = expf(-0.5f * (x / sigma) * (x / sigma));
+    sum += g.w[i];
+  }
+  for (int i = 0; i < k; ++i) g.w[i] /= sum;
+  dim3 grid((W + 31) / 32, (H + 7) / 8, planes);
+  // the forward runs the horizontal pass, then the vertical one: adjoint in the reverse order
+  hipLaunchKernelGGL(blur_bwd_pass_kernel, grid, dim3(256), 0, (hipStream_t)stream, dy, tmp, H, W, g, 1);
+  hipLaunchKernelGGL(blur_bwd_pass_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const float*)tmp, dx, H, W, g, 0);
+  return vs_launch_status();
+}
+
+extern "C" int vs_aug_warp_bwd(const float* dy, float* dx, int planes, int H, int W, int oh, int ow, int kind, const float* coeffs, int bilinear,
+                               const float* inv, void* stream) {
+  VS_REQUIRE(dy && dx && coeffs && inv && planes > 0 && H > 0 && W > 0 && oh > 0 && ow > 0 && (kind == 0 || kind == 1));
+  WarpB a;
+  for (int i = 0; i < 8; ++i) a.t[i] = i < (kind == 0 ? 6 : 8) ? coeffs[i] : 0.f;
+  for (int i = 0; i < 9; ++i) a.inv[i] = inv[i];
+  a.kind = kind; a.bilinear = bilinear;
+  hipLaunchKernelGGL(warp_bwd_kernel, dim3((W + 31) / 32, (H + 7) / 8, planes), dim3(256), 0, (hipStream_t)stream, dy, dx, H, W, oh, ow, a);
   return vs_launch_status();
 }
