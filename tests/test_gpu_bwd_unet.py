@@ -4,7 +4,7 @@ autograd of the same op on the GPU.  End to end: all `embedder.unet.*` gradients
 
 The U-Net is piecewise linear in its ReLUs: a forward that differs in the last bits flips a few of the ~10^7 ReLU decisions and moves the
 gradient discretely -- the CPU oracle run in fp32 and in fp64 already differs by up to 1.3 % of a tensor's largest element on the VideoSeal 1.0
-U-Net (median 0.27 %; /tmp-free reproduction: tools/relu_flip_sensitivity.py).  The comparison therefore runs the oracle's autograd WITH THE
+U-Net (median 0.27 %; /tmp-free reproduction: tests/tools/relu_flip_sensitivity.py).  The comparison therefore runs the oracle's autograd WITH THE
 RELU DECISIONS OF THE HIP FORWARD (read back from the operands the backward keeps): every remaining difference is arithmetic, and the
 tolerance is tight.  The unconstrained comparison is kept with the tolerance the fp32-vs-fp64 experiment justifies."""
 import os

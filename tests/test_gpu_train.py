@@ -9,7 +9,7 @@ VideoSeal 1.0), and two optimizer steps against autograd through the oracle.
 
 Tolerances: the extractor is smooth (GELU / LayerNorm / GRN) -- its 71 / 201 tensors are held to 3e-3 on norm, sum and a seeded projection.
 The U-Net is piecewise linear in ~10^7 ReLU decisions; a forward that differs in the last bits flips a few and moves the gradient
-discretely (the CPU oracle in fp32 vs fp64: worst 1.3 %, tools/relu_flip_sensitivity.py).  Its tensors are therefore compared twice: against
+discretely (the CPU oracle in fp32 vs fp64: worst 1.3 %, tests/tools/relu_flip_sensitivity.py).  Its tensors are therefore compared twice: against
 the reference fixture with a bound of that order, and against the oracle's autograd run with the HIP forward's own ReLU decisions, tightly."""
 import os
 

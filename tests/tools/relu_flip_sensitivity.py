@@ -3,7 +3,7 @@ in fp32 against fp64, and fp32 with two thread counts.  The net is piecewise lin
 decisions and shift the gradient discretely: this is the noise floor of any gradient comparison that does not share the ReLU decisions
 (tests/test_gpu_bwd_unet.py shares them).  Measured here: worst 1.3 %, median 0.27 % of a tensor's largest gradient element (fp32 vs fp64)."""
 import torch, sys, os
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from oracle import videoseal_ref as R
 from oracle.inputs import synthetic_frames, synthetic_msgs
 from oracle.weights import make_state_dict, spec_from_card

@@ -6,12 +6,12 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import videoseal_amd
 from videoseal_amd.training import DetectorStep
-from oracle.inputs import synthetic_frames, synthetic_msgs
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 16
 model = videoseal_amd.build("videoseal_1.0").eval().to("cuda")      # seeded random weights of the card's architecture (no checkpoint offline)
-imgs = synthetic_frames(B, 256, 256, seed=1).cuda()
-msgs = synthetic_msgs(B, model.embedder.cfg.nbits, seed=1)
+g = torch.Generator().manual_seed(1)
+imgs = torch.rand(B, 3, 256, 256, generator=g).cuda()
+msgs = torch.randint(0, 2, (B, model.embedder.cfg.nbits), generator=g)
 step = DetectorStep(model)
 
 
