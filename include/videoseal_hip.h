@@ -337,6 +337,10 @@ int vs_clamp01_bwd(const float* x, const float* dy, float* dx, int64_t n, void* 
  * row-major 3 x 3 map from input pixel-centre coordinates (x + 0.5, y + 0.5, 1) to homogeneous output pixel-centre coordinates -- the inverse
  * of the sampling map, used only to bound the search (every candidate is re-sampled with the forward arithmetic).
  * vs_aug_color_bwd now covers the hue op as well (chain rule through torchvision's RGB -> HSV -> RGB with autograd's conventions). */
+/* vs_aug_gather_frames_bwd: adjoint of vs_aug_gather_frames; start [n_src + 1] / outs: per source frame the outputs that copied it (CSR, ascending).
+ * vs_aug_window_average_bwd: adjoint of vs_aug_window_average. */
+int vs_aug_gather_frames_bwd(const float* dy, const int32_t* start, const int32_t* outs, float* dx, int n_src, int64_t frame_floats, void* stream);
+int vs_aug_window_average_bwd(const float* dy, float* dx, int F, int64_t frame_floats, int half_window, float alpha, void* stream);
 int vs_gaussian_blur_bwd(const float* dy, float* tmp, float* dx, int planes, int H, int W, int k, float sigma, void* stream);
 int vs_aug_warp_bwd(const float* dy, float* dx, int planes, int H, int W, int oh, int ow, int kind, const float* coeffs, int bilinear,
                     const float* inv, void* stream);

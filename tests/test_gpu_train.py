@@ -632,3 +632,45 @@ def test_every_augmentation_of_the_default_training_config_has_a_backward(name):
     gd = [p.grad for k, p in model.named_parameters() if k.startswith("detector.")]
     assert all(g is not None and torch.isfinite(g).all() for g in ge + gd)
     assert max(float(g.abs().max()) for g in ge) > 0.0, f"{out['selected_aug']}: no gradient reached the embedder"
+
+
+def test_temporal_augmentation_adjoints():
+    """whole-frame gathers (DropFrame / SpeedChange / TemporalReorder, video.py:283-405, 491-529) and WindowAveraging (video.py:411-486): exact
+    adjoints against torch autograd of the same index / window arithmetic; the augmentation classes run under autograd"""
+    import random
+    x0 = synthetic_frames(9, 24, 40, seed=31).cuda()
+    idx = [0, 0, 2, 5, 5, 5, 8, 1, 3, 3, 7]
+    xr = x0.clone().requires_grad_(True)
+    dy = _rand(len(idx), 3, 24, 40, seed=32)
+    xr[torch.tensor(idx, device="cuda")].backward(dy)
+    xg = x0.clone().requires_grad_(True)
+    yg = G.gather_frames(xg, idx)
+    assert torch.equal(yg.detach(), x0[torch.tensor(idx, device="cuda")])
+    yg.backward(dy)
+    assert (xg.grad - xr.grad).abs().max() <= 1e-6 * xr.grad.abs().max()
+    assert (xg.grad[4] == 0).all() and (xg.grad[6] == 0).all()           # frames nobody copied
+    for ws, alpha in ((3, 0.4), (5, 0.7), (2, 1.0)):
+        hw = ws // 2
+        xr = x0.clone().requires_grad_(True)
+        rows = []
+        for i in range(9):
+            a, b = max(0, i - hw), min(9, i + hw + 1)
+            rows.append((1 - alpha) * xr[i] + alpha * xr[a:b].mean(0))
+        yr = torch.stack(rows)
+        dy = _rand(9, 3, 24, 40, seed=33)
+        yr.backward(dy)
+        xg = x0.clone().requires_grad_(True)
+        yg = G.window_average(xg, ws, alpha)
+        assert (yg.detach() - yr.detach()).abs().max() < 1e-6
+        yg.backward(dy)
+        assert (xg.grad - xr.grad).abs().max() <= 2e-6 * xr.grad.abs().max()
+    random.seed(3)
+    torch.manual_seed(3)
+    for aug in (G.DropFrame(0.3), G.SpeedChange(0.5, 1.5) if hasattr(G, "SpeedChange") else None, G.TemporalReorder() if hasattr(G, "TemporalReorder") else None,
+                G.WindowAveraging()):
+        if aug is None:
+            continue
+        xg = x0.clone().requires_grad_(True)
+        y, _ = aug(xg, None)
+        y.sum().backward()
+        assert xg.grad is not None and torch.isfinite(xg.grad).all() and abs(float(xg.grad.sum()) - y.numel()) <= 1e-3 * y.numel()

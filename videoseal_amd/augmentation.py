@@ -298,9 +298,7 @@ class GaussianNoise(_Aug):
 def gather_frames(x: torch.Tensor, indices) -> torch.Tensor:
     """frames[indices] for whole frames (any trailing shape) on the HIP gather kernel."""
     if AG.needs_grad(x):
-        with torch.no_grad():
-            y = gather_frames(x, indices)
-        return AG.NoAdjointFn.apply(x, y, "DropFrame / SpeedChange")
+        return AG.GatherFramesFn.apply(x, indices)
     x = _dev(x)
     idx = torch.as_tensor(indices, dtype=torch.int32).to(x.device)
     out = torch.empty((idx.numel(),) + tuple(x.shape[1:]), device=x.device, dtype=torch.float32)
@@ -399,9 +397,7 @@ class TemporalReorder(_Aug):
 
 def window_average(frames: torch.Tensor, window_size: int, alpha: float) -> torch.Tensor:
     if AG.needs_grad(frames):
-        with torch.no_grad():
-            y = window_average(frames, window_size, alpha)
-        return AG.NoAdjointFn.apply(frames, y, "WindowAveraging")
+        return AG.WindowAverageFn.apply(frames, window_size, alpha)
     x = _dev(frames)
     out = torch.empty_like(x)
     N.check(N.lib().vs_aug_window_average(N.ptr(x), N.ptr(out), x.shape[0], x[0].numel(), int(window_size) // 2, float(alpha), N.stream()),

@@ -193,6 +193,59 @@ class WarpFn(torch.autograd.Function):
         return dx, None, None, None, None
 
 
+class GatherFramesFn(torch.autograd.Function):
+    """whole-frame gathers of augmentation/video.py (DropFrame :491-529, SpeedChange :283-313, TemporalReorder :319-405): out[o] = frames[idx[o]];
+    adjoint: every source frame receives the sum of the outputs that copied it (lists built on the host, summed in ascending output order)"""
+
+    @staticmethod
+    def forward(ctx, x, indices):
+        from . import augmentation as A
+        with torch.no_grad():
+            y = A.gather_frames(x.detach(), indices)
+        idx = [int(i) for i in torch.as_tensor(indices).reshape(-1).tolist()]
+        ctx.idx, ctx.shape = idx, tuple(x.shape)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        dy = _c(dy)
+        n_src = ctx.shape[0]
+        lists = [[] for _ in range(n_src)]
+        for o, f in enumerate(ctx.idx):
+            lists[f].append(o)
+        start, outs = [0], []
+        for l in lists:
+            outs.extend(l)
+            start.append(len(outs))
+        dev = dy.device
+        st_t = torch.tensor(start, dtype=torch.int32, device=dev)
+        ou_t = torch.tensor(outs if outs else [0], dtype=torch.int32, device=dev)
+        dx = torch.empty(ctx.shape, device=dev, dtype=torch.float32)
+        fsz = dx[0].numel()
+        N.check(N.lib().vs_aug_gather_frames_bwd(N.ptr(dy), N.ptr(st_t), N.ptr(ou_t), N.ptr(dx), n_src, fsz, N.stream()), "vs_aug_gather_frames_bwd")
+        return dx, None
+
+
+class WindowAverageFn(torch.autograd.Function):
+    """augmentation/video.py:411-486 WindowAveraging: forward kernel, exact adjoint (vs_aug_window_average_bwd)"""
+
+    @staticmethod
+    def forward(ctx, x, window_size, alpha):
+        from . import augmentation as A
+        with torch.no_grad():
+            y = A.window_average(x.detach(), window_size, alpha)
+        ctx.hw, ctx.alpha = int(window_size) // 2, float(alpha)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        dy = _c(dy)
+        dx = torch.empty_like(dy)
+        N.check(N.lib().vs_aug_window_average_bwd(N.ptr(dy), N.ptr(dx), dy.shape[0], dy[0].numel(), ctx.hw, ctx.alpha, N.stream()),
+                "vs_aug_window_average_bwd")
+        return dx, None, None
+
+
 class SteFn(torch.autograd.Function):
     """straight-through estimator `x + (op(x) - x).detach()` of JPEG / MedianFilter / the video codecs (valuemetric.py:35, 90; video.py:113):
     forward value op(x), identity gradient.  clamp01: JPEG.forward clamps to [0, 1] in front of the estimator (valuemetric.py:41), which

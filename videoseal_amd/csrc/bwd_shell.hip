@@ -378,6 +378,33 @@ __global__ __launch_bounds__(256) void warp_bwd_kernel(const float* __restrict__
   dx[((int64_t)blockIdx.z * H + uy) * W + ux] = acc;
 }
 
+// ---- whole-frame gathers (DropFrame / SpeedChange / TemporalReorder, video.py:283-313, 319-405, 491-529: dst[o] = src[idx[o]]): adjoint in gather
+// form.  The host lists, per SOURCE frame f, the outputs that copied it (CSR: start[f] .. start[f + 1] into `outs`, ascending): dx[f] = their sum.
+__global__ __launch_bounds__(256) void gather_frames_bwd_kernel(const float* __restrict__ dy, const int32_t* __restrict__ start, const int32_t* __restrict__ outs,
+                                                                float* __restrict__ dx, int64_t fsz) {
+  const int64_t f = blockIdx.y;
+  const int a = start[f], b = start[f + 1];
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < fsz; i += (int64_t)gridDim.x * 256) {
+    float s = 0.f;
+    for (int k = a; k < b; ++k) s += dy[(int64_t)outs[k] * fsz + i];
+    dx[f * fsz + i] = s;
+  }
+}
+// ---- WindowAveraging (video.py:411-486): y[i] = (1 - alpha) x[i] + alpha mean(x[a_i .. b_i)) with the clipped window of aug.hip::window_average_kernel;
+// adjoint: dx[k] = (1 - alpha) dy[k] + alpha sum over the frames i whose window holds k of dy[i] / (b_i - a_i), ascending i
+__global__ __launch_bounds__(256) void window_average_bwd_kernel(const float* __restrict__ dy, float* __restrict__ dx, int F, int64_t fsz, int hw, float alpha) {
+  const int64_t k = blockIdx.y;
+  const int lo = (int)(k - hw < 0 ? 0 : k - hw), hi = (int)(k + hw + 1 > F ? F : k + hw + 1);       // frames i with |i - k| <= hw
+  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < fsz; e += (int64_t)gridDim.x * 256) {
+    float s = 0.f;
+    for (int i = lo; i < hi; ++i) {
+      const int a = i - hw < 0 ? 0 : i - hw, b = i + hw + 1 > F ? F : i + hw + 1;
+      s += dy[(int64_t)i * fsz + e] / (float)(b - a);
+    }
+    dx[k * fsz + e] = (1.f - alpha) * dy[k * fsz + e] + alpha * s;
+  }
+}
+
 // ---- JPEG.forward's clamp in front of the straight-through estimator (valuemetric.py:41): dx = dy where 0 <= x <= 1
 __global__ __launch_bounds__(256) void clamp01_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ dx, int64_t n) {
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) dx[i] = pass01(x[i]) ? dy[i] : 0.f;
@@ -569,5 +596,17 @@ extern "C" int vs_aug_warp_bwd(const float* dy, float* dx, int planes, int H, in
   for (int i = 0; i < 9; ++i) a.inv[i] = inv[i];
   a.kind = kind; a.bilinear = bilinear;
   hipLaunchKernelGGL(warp_bwd_kernel, dim3((W + 31) / 32, (H + 7) / 8, planes), dim3(256), 0, (hipStream_t)stream, dy, dx, H, W, oh, ow, a);
+  return vs_launch_status();
+}
+
+extern "C" int vs_aug_gather_frames_bwd(const float* dy, const int32_t* start, const int32_t* outs, float* dx, int n_src, int64_t frame_floats, void* stream) {
+  VS_REQUIRE(dy && start && outs && dx && n_src > 0 && frame_floats > 0);
+  hipLaunchKernelGGL(gather_frames_bwd_kernel, dim3(gridx(frame_floats), n_src), dim3(256), 0, (hipStream_t)stream, dy, start, outs, dx, frame_floats);
+  return vs_launch_status();
+}
+
+extern "C" int vs_aug_window_average_bwd(const float* dy, float* dx, int F, int64_t frame_floats, int half_window, float alpha, void* stream) {
+  VS_REQUIRE(dy && dx && F > 0 && frame_floats > 0 && half_window >= 0);
+  hipLaunchKernelGGL(window_average_bwd_kernel, dim3(gridx(frame_floats), F), dim3(256), 0, (hipStream_t)stream, dy, dx, F, frame_floats, half_window, alpha);
   return vs_launch_status();
 }

@@ -27,7 +27,7 @@ EXPORTS = [
     "vs_jnd_heatmap", "vs_embed_tail", "vs_aug_color_scratch_floats", "vs_aug_color", "vs_aug_crop_flip", "vs_aug_warp", "vs_resize_nchw",
     "vs_gaussian_blur", "vs_median_filter", "vs_jpeg_workspace_bytes", "vs_jpeg_roundtrip", "vs_h264_proxy_workspace_bytes", "vs_h264_proxy_roundtrip",
     "vs_bn_partial_doubles", "vs_bn_batch_stats", "vs_bn_partial_sums", "vs_bn_finish_sums", "vs_scale_shift_act", "vs_aug_mask_blend", "vs_aug_add_scaled", "vs_aug_gather_frames", "vs_aug_window_average",
-    "vs_gemm_wgrad_partial_floats", "vs_gemm_wgrad", "vs_conv3x3_wgrad", "vs_conv3x3_wgrad_supported", "vs_conv3x3_wgrad_partial_floats", "vs_pad_embed1", "vs_reflect_fold1", "vs_pack_conv", "vs_gaussian_blur_bwd", "vs_aug_warp_bwd", "vs_gelu_bwd", "vs_act_bwd", "vs_rmsnorm_act_bwd", "vs_vit_attention_bwd_scratch_floats", "vs_vit_attention_bwd", "vs_dwconv7", "vs_dwconv7_wgrad_partial_floats", "vs_dwconv7_wgrad", "vs_colreduce_partial_floats",
+    "vs_gemm_wgrad_partial_floats", "vs_gemm_wgrad", "vs_conv3x3_wgrad", "vs_conv3x3_wgrad_supported", "vs_conv3x3_wgrad_partial_floats", "vs_pad_embed1", "vs_reflect_fold1", "vs_pack_conv", "vs_gaussian_blur_bwd", "vs_aug_warp_bwd", "vs_aug_gather_frames_bwd", "vs_aug_window_average_bwd", "vs_gelu_bwd", "vs_act_bwd", "vs_rmsnorm_act_bwd", "vs_vit_attention_bwd_scratch_floats", "vs_vit_attention_bwd", "vs_dwconv7", "vs_dwconv7_wgrad_partial_floats", "vs_dwconv7_wgrad", "vs_colreduce_partial_floats",
     "vs_layernorm_bwd", "vs_gelu_grn_bwd", "vs_patchify", "vs_unpatch", "vs_patchify_s", "vs_unpatch_s", "vs_col2im3x3_reflect", "vs_colmean", "vs_pool_gelu_bwd", "vs_matmul_small",
     "vs_bce_logits",
     "vs_bn_mean_rstd", "vs_bn_bwd_partial_floats", "vs_bn_relu_bwd_sums", "vs_bn_relu_bwd_apply", "vs_dilate2", "vs_im2col3x3_strided", "vs_upcat2x_bwd",
@@ -144,6 +144,8 @@ def lib() -> C.CDLL:
         "vs_pack_conv": [P, I, I, I, I, I, I, P, P],
         "vs_gaussian_blur_bwd": [P, P, P, I, I, I, I, F, P],
         "vs_aug_warp_bwd": [P, P, I, I, I, I, I, I, P, I, P, P],
+        "vs_aug_gather_frames_bwd": [P, P, P, P, I, I64, P],
+        "vs_aug_window_average_bwd": [P, P, I, I64, I, F, P],
         "vs_gelu_bwd": [P, I64, P, I64, I64, I, P, I64, P],
         "vs_act_bwd": [P, I64, P, I64, I64, I, I, P, I64, P],
         "vs_rmsnorm_act_bwd": [P, I64, I, I64, P, I, P, I64, P, I64, P, I64, P],
