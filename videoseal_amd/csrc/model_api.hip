@@ -161,14 +161,14 @@ struct Packer {
     std::vector<uint16_t> p1, p2;
     m1 = split2(std::vector<float>(w1.p, w1.p + w1.n), p1);          // [plane][4C][C]
     m2 = split2(std::vector<float>(w2.p, w2.p + w2.n), p2);          // [plane][C][4C]
-    const size_t per_hb = (size_t)2048 * (ks1 + nb) + 1024;
-    if ((int64_t)(per_hb * nhb) != vs_cnx_block_image_bytes(C)) return nullptr;
+    const size_t per_hb = (size_t)2048 * ks1 + (size_t)4096 * nb + 1024;      // W1 fragments, W2 fragments (two k-steps per n-block), 256 floats
+    if ((int64_t)(per_hb * nhb) != vs_cnx_block_image_bytes(C)) { fail = true; return nullptr; }      // (layout drifted from convnext_fused.hip: loud)
     std::vector<uint8_t> img(per_hb * nhb, 0);
     const size_t n1 = (size_t)H4 * C;
     for (int hb = 0; hb < nhb; ++hb) {
       uint16_t* i1 = reinterpret_cast<uint16_t*>(img.data() + per_hb * hb);
       uint16_t* i2 = i1 + (size_t)1024 * ks1;
-      float* aux = reinterpret_cast<float*>(img.data() + per_hb * hb + (size_t)2048 * (ks1 + nb));
+      float* aux = reinterpret_cast<float*>(img.data() + per_hb * hb + (size_t)2048 * ks1 + (size_t)4096 * nb);
       for (int ks = 0; ks < ks1; ++ks)
         for (int pl = 0; pl < 2; ++pl)
           for (int half = 0; half < 2; ++half)
