@@ -489,7 +489,10 @@ def main():
         # the other BASELINE configs as short legs of the same command, each with its own roofline fractions
         def leg(extra, steps=5, warmup=2):
             a = parse_args(["--gpus", str(args.gpus), "--steps", str(steps), "--warmup", str(warmup), "--no-cpu-baseline", "--no-extra"] + extra)
-            r = run(a)
+            try:
+                r = run(a)
+            except Exception as e:          # the headline line must survive a failing extra leg
+                return {"error": repr(e)[:300]}
             if r is None:
                 return None
             roof = r.get("roofline") or {}
