@@ -491,7 +491,9 @@ def main():
             a = parse_args(["--gpus", str(args.gpus), "--steps", str(steps), "--warmup", str(warmup), "--no-cpu-baseline", "--no-extra"] + extra)
             try:
                 r = run(a)
-            except Exception as e:          # the headline line must survive a failing extra leg
+            except Exception as e:          # the headline line must survive a failing extra leg (one process: with several ranks a
+                if world > 1:               # rank that carried on alone would leave the others in a collective -- let the launcher end the job)
+                    raise
                 return {"error": repr(e)[:300]}
             if r is None:
                 return None
