@@ -302,6 +302,48 @@ def test_cpu_inputs_round_trip(tiny):
     assert a["msgs"].shape == (4, spec.nbits)
 
 
+def test_cpu_callers_get_the_device_results_through_pinned_host_memory(tiny):
+    """every no-grad entry point with the frames on the CPU: results on the CPU, bit-equal to the device-resident call, delivered
+    through torch's pinned allocator (asynchronous copies + one synchronise; videoseal_amd/model.py::_result_buffer) -- also when the
+    clip goes through in several chunks, for uint8 clips, and for a second call that reuses the cached host blocks."""
+    spec, sd, model = tiny
+    imgs = synthetic_frames(6, 64, 80, seed=22)
+    dev = imgs.cuda()
+    msgs = synthetic_msgs(6, spec.nbits, seed=22)
+    model.chunk_size, model.step_size, model.video_mode = 4, 2, "repeat"          # 6 frames = two chunks
+
+    def same(a, b, keys):
+        for k in keys:
+            assert a[k].device.type == "cpu" and a[k].is_pinned(), k
+            assert torch.equal(a[k], b[k].cpu()), k
+
+    for _ in range(2):
+        same(model.embed(imgs, msgs, is_video=False), model.embed(dev, msgs, is_video=False), ("imgs_w", "preds_w"))
+        same(model.embed(imgs, msgs[:1], is_video=True, lowres_attenuation=True),
+             model.embed(dev, msgs[:1], is_video=True, lowres_attenuation=True), ("imgs_w",))
+        pa, pb = model.detect(imgs, is_video=True)["preds"], model.detect(dev, is_video=True)["preds"]
+        assert pa.device.type == "cpu" and torch.equal(pa, pb.cpu())
+    with torch.no_grad():
+        masks = torch.ones(6, 1, 64, 80)
+        fa, fb = model(imgs, masks, msgs, is_video=False), model(dev, masks.cuda(), msgs, is_video=False)
+        for k in ("imgs_w", "preds_w"):                    # (the augmenter draws from the global RNG: compare what does not depend on it)
+            assert fa[k].device.type == "cpu" and torch.equal(fa[k], fb[k].cpu()), k
+        assert fa["imgs_w"].is_pinned()
+    u8 = (imgs * 255).to(torch.uint8).permute(0, 2, 3, 1).contiguous()
+    ua, ub = model.embed_u8(u8, msgs[:1]), model.embed_u8(u8.cuda(), msgs[:1])
+    assert ua["imgs_w"].dtype == torch.uint8 and ua["imgs_w"].is_pinned() and torch.equal(ua["imgs_w"], ub["imgs_w"].cpu())
+
+
+def test_pageable_results_on_request(tiny, monkeypatch):
+    import videoseal_amd.model as M
+    spec, sd, model = tiny
+    monkeypatch.setattr(M, "_PINNED_RESULTS", False)
+    imgs = synthetic_frames(2, 64, 64, seed=23)
+    msgs = synthetic_msgs(2, spec.nbits, seed=23)
+    a, b = model.embed(imgs, msgs, is_video=False), model.embed(imgs.cuda(), msgs, is_video=False)
+    assert not a["imgs_w"].is_pinned() and torch.equal(a["imgs_w"], b["imgs_w"].cpu()) and torch.equal(a["preds_w"], b["preds_w"].cpu())
+
+
 def test_errors_are_loud(tiny):
     spec, sd, model = tiny
     imgs = synthetic_frames(2, 64, 64, seed=1).cuda()

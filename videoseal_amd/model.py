@@ -11,7 +11,8 @@ Deliberate differences, each loud rather than silent:
     whose graph nodes run the HIP backward kernels, so train.py's `loss.backward()` / `torch.autograd.grad(loss, last_layer)` / DDP hooks
     work unchanged; under ``torch.no_grad()`` (or with everything frozen) it is the values-only launch sequence;
   * frames handed over on the CPU are copied to the model's device, processed there end to end and the
-    results are copied back to ``imgs.device`` (the reference keeps the full-resolution shell on the CPU).
+    results are copied back to ``imgs.device`` (the reference keeps the full-resolution shell on the CPU); for a CPU caller the
+    no-grad entry points return tensors from torch's caching pinned allocator (``_result_buffer``).
 """
 from __future__ import annotations
 
@@ -26,6 +27,35 @@ from .engine import Act, HipEngine
 from .layout import ModelCfg, build_tree, detector_entries, embedder_entries
 
 _DEFAULT_INTERP = {"mode": "bilinear", "align_corners": False, "antialias": True}
+
+
+_PINNED_RESULTS = os.environ.get("VIDEOSEAL_PINNED_RESULTS", "1") != "0"
+
+
+def _result_buffer(shape, dtype, device) -> torch.Tensor:
+    """Where a result goes when the caller's frames are not on the model's device.  For a CPU caller (the calling convention of
+    videoseal.py:286-297 / inference_av.py: the clip stays on the CPU) the tensor comes from torch's caching PINNED allocator: the copy
+    back runs at link speed instead of through a freshly mapped pageable tensor (32 x 768^2 fp32 frames: 4 ms instead of ~40 ms,
+    tools/bench_pcie.py).  It is an ordinary CPU tensor for the caller; VIDEOSEAL_PINNED_RESULTS=0 returns pageable memory."""
+    device = torch.device(device)
+    if device.type == "cpu" and _PINNED_RESULTS:
+        try:
+            return torch.empty(tuple(shape), dtype=dtype, pin_memory=True)
+        except RuntimeError:          # the host refuses to lock that much memory: pageable result, same values
+            pass
+    return torch.empty(tuple(shape), dtype=dtype, device=device)
+
+
+def _to_caller(t, device):
+    """device tensor -> the caller's device (no-grad result paths)"""
+    if not torch.is_tensor(t) or t.device == torch.device(device):
+        return t
+    if torch.device(device).type != "cpu" or not t.is_cuda:
+        return t.to(device)
+    out = _result_buffer(t.shape, t.dtype, device)
+    out.copy_(t, non_blocking=True)
+    torch.cuda.current_stream(t.device).synchronize()
+    return out
 
 
 def _antialias_flag(interpolation: Optional[dict]) -> bool:
@@ -371,7 +401,7 @@ class Wam(nn.Module):
             out = torch.empty_like(src) if want_out else None
         else:
             src = imgs
-            out = torch.empty(imgs.shape, dtype=(imgs.dtype if imgs.dtype == torch.uint8 else torch.float32), device=imgs.device) if want_out else None
+            out = _result_buffer(imgs.shape, imgs.dtype if imgs.dtype == torch.uint8 else torch.float32, imgs.device) if want_out else None
         for a in range(0, imgs.shape[0], span):
             b = min(imgs.shape[0], a + span)
             if on_dev:
@@ -382,7 +412,9 @@ class Wam(nn.Module):
                 oc = torch.empty_like(ch) if want_out else None
                 fn(ch, oc, a, b)
                 if want_out:
-                    out[a:b].copy_(oc)
+                    out[a:b].copy_(oc, non_blocking=True)
+        if not on_dev:                 # the copies into (pinned) host memory are asynchronous: the results are valid from here on
+            torch.cuda.current_stream(eng.dev).synchronize()
         return out
 
     @torch.no_grad()
@@ -401,14 +433,14 @@ class Wam(nn.Module):
             raise ValueError(f"msgs has {msgs.shape[0]} rows for {B} images")
         with torch.cuda.device(eng.dev):
             mi = self._msgs_dev(msgs, eng.dev)
-            preds_w = torch.empty(B, cd, imgs.shape[-2], imgs.shape[-1], device=imgs.device, dtype=torch.float32)
             on_dev = imgs.device == eng.dev
+            preds_w = _result_buffer((B, cd, imgs.shape[-2], imgs.shape[-1]), torch.float32, imgs.device)
 
             def one(fr, oc, a, b):
                 pw = preds_w[a:b] if on_dev else torch.empty(b - a, cd, fr.shape[-2], fr.shape[-1], device=eng.dev, dtype=torch.float32)
                 self._embed_frames(eng, fr, mi[a:b], oc, step=1, video_mode=0, antialias=aa, lowres=lowres_attenuation, preds_w=pw)
                 if not on_dev:
-                    preds_w[a:b].copy_(pw)
+                    preds_w[a:b].copy_(pw, non_blocking=True)       # _run_chunks synchronises before it returns
             out = self._run_chunks(eng, imgs, max(1, int(getattr(self, "chunk_size", 32))), one)
         return {"msgs": msgs, "preds_w": preds_w, "imgs_w": out}
 
@@ -508,7 +540,7 @@ class Wam(nn.Module):
             self._embed_frames(eng, x, self._msgs_dev(msgs, eng.dev), out, step=1, video_mode=0, antialias=aa, lowres=False,
                                preds_w=preds_w, fwd_order=True)
             imgs_aug, masks, selected, preds = self._augment_detect(eng, out, x, masks, False, aa)
-        to = (lambda t: t.to(back) if torch.is_tensor(t) else t)     # noqa: E731
+        to = (lambda t: _to_caller(t, back))     # noqa: E731
         return {"msgs": msgs, "masks": to(masks), "preds_w": to(preds_w), "imgs_w": to(out), "imgs_aug": to(imgs_aug),
                 "preds": to(preds), "selected_aug": selected}
 
@@ -644,7 +676,7 @@ class Videoseal(Wam):
                 self._embed_frames(eng, x, self._msgs_dev(msgs, eng.dev), out, step=int(self.step_size),
                                    video_mode=N.VIDEO_MODES[self.video_mode], antialias=aa, lowres=bool(self.lowres_attenuation), fwd_order=True)
                 imgs_aug, masks, selected, preds = self._augment_detect(eng, out, x, masks, True, aa)
-        to = (lambda t: t.to(back) if torch.is_tensor(t) else t)     # noqa: E731
+        to = (lambda t: (t.to(back) if torch.is_tensor(t) else t) if (emb_t or det_t) else _to_caller(t, back))     # noqa: E731
         return {"msgs": msgs.expand(imgs.shape[0], -1), "masks": to(masks), "imgs_w": to(out), "imgs_aug": to(imgs_aug), "preds": to(preds),
                 "selected_aug": selected}
 
