@@ -212,3 +212,19 @@ def test_validation_tables_match_the_reference():
     assert rows(A.get_validation_augs_subset(False)) == gold["subset_image"]
     assert rows(A.get_validation_augs_subset(True)) == gold["subset_video"]
     assert repr(A.H264(20, 30)) == "H264proxy" and "backend=proxy" in repr(A.VideoCompression())      # the stand-in is visible in names and logs
+
+
+def test_result_buffers_of_a_cpu_caller():
+    """videoseal_amd/model.py::_result_buffer / _to_caller: shape / dtype / device of what a CPU caller gets back, pass-through of
+    non-tensors and of tensors already on the caller's device, pageable memory on request (no GPU needed for any of it)."""
+    import videoseal_amd.model as M
+    t = M._result_buffer((2, 3, 4), torch.uint8, "cpu")
+    assert t.shape == (2, 3, 4) and t.dtype == torch.uint8 and t.device.type == "cpu"
+    x = torch.arange(6.0)
+    assert M._to_caller(x, "cpu") is x and M._to_caller(None, "cpu") is None and M._to_caller("crop_0.5", "cpu") == "crop_0.5"
+    old = M._PINNED_RESULTS
+    try:
+        M._PINNED_RESULTS = False
+        assert not M._result_buffer((4,), torch.float32, torch.device("cpu")).is_pinned()
+    finally:
+        M._PINNED_RESULTS = old
