@@ -50,6 +50,24 @@ def arith_name(eng):
     return "2 x f16 operand split, 3 products on v_mfma_f32_32x32x16_f16" if eng.arith == 2 else "3 x bf16 exact operand split, 6 products on v_mfma_f32_32x32x16_bf16"
 
 
+def current_profile(key):
+    """path of the tracked profile summary `key` named by profiles/CURRENT.json (None if absent) -- an explicit pointer, not 'newest by name'"""
+    idx = os.path.join(ROOT, "profiles", "CURRENT.json")
+    if not os.path.exists(idx):
+        return None
+    name = json.load(open(idx)).get(key)
+    path = os.path.join(ROOT, "profiles", name) if name else None
+    return path if path and os.path.exists(path) else None
+
+
+def arith_used(eng):
+    """which operand split each network actually ran on (the range guard may have switched one to 3 x bf16: half the matrix rate)"""
+    if not eng.use_split:
+        return {"embedder": "f32", "extractor": "f32"}
+    nm = {2: "f16x2", 3: "bf16x3"}
+    return {"embedder": nm[eng.arith_net["E"]], "extractor": nm[eng.arith_net["X"]], "selection": "auto (range guard)" if eng.auto_arith else "forced"}
+
+
 def synthetic_batch(n, size, device, seed):
     """device-resident synthetic frames in [0,1]: low-pass noise + noise (content does not change the work)."""
     g = torch.Generator(device=device).manual_seed(seed)
@@ -94,7 +112,7 @@ def cpu_baseline(card_path, size, mode, step_size, max_seconds=25.0):
     host = os.cpu_count() or 1
     tried = {}
     # every host core is opt-in (VS_BENCH_CPU_ALL_CORES=1): on the 256-CPU GPU box 256 threads ran the same sample 83x SLOWER than
-    # 32 threads (0.086 vs 7.18 frames/s, profiles/r02a_cpu_threads.json) and took 5 minutes of the run
+    # 32 threads (0.086 vs 7.18 frames/s, profiles/archive/r02a_cpu_threads.json) and took 5 minutes of the run
     for cores in sorted({min(host, 32)} | ({host} if os.environ.get("VS_BENCH_CPU_ALL_CORES") == "1" else set())):
         torch.set_num_threads(cores)
         t0 = time.time(); run(); warm = time.time() - t0
@@ -104,8 +122,8 @@ def cpu_baseline(card_path, size, mode, step_size, max_seconds=25.0):
             times.append(dt); t_used += dt; reps += 1
         tried[cores] = round(n / min(times), 3)
     cores = max(tried, key=tried.get)
-    cal = os.path.join(ROOT, "profiles", "r03_cpu_port_vs_reference.json")
-    ratio = json.load(open(cal)) if os.path.exists(cal) else None
+    cal = current_profile("cpu_port_vs_reference")
+    ratio = json.load(open(cal)) if cal else None
     return {"value": tried[cores], "port_over_reference": (ratio["port_over_reference"] if ratio else None),
             "port_over_reference_note": (ratio["note"] if ratio else None), "unit": "frames/s", "cores": cores, "host_cpus": host, "kind": "port",
             "by_threads": {str(k): v for k, v in tried.items()},
@@ -148,10 +166,14 @@ def parse_args(argv=None):
     ap.add_argument("--u8", action="store_true", help="stream mode: uint8 RGB24 clips in and out (inference_streaming.py's data format) "
                     "through embed_u8 / detect_u8 instead of fp32 NCHW tensors")
     ap.add_argument("--frames", type=int, default=1024, help="stream mode: total frames of the clip (sharded over the ranks)")
+    ap.add_argument("--group", type=int, default=None, help="stream mode: 16-frame chunks whose key frames share one U-Net pass (default: enough "
+                    "for 32 key frames = 8 chunks; 1 = the literal per-chunk calls of round 3)")
     ap.add_argument("--graphs", action="store_true", help="replay the per-chunk launch sequences from hipGraphs")
     ap.add_argument("--batch", type=int, default=None, help="frames per GPU and step (default 32; 16 in chain mode)")
     ap.add_argument("--size", type=int, default=768)
     ap.add_argument("--card", default="videoseal_1.0")
+    ap.add_argument("--conv", choices=["auto", "f16x2", "bf16x3", "f32"], default=None, help="arithmetic of the dense layers (VIDEOSEAL_CONV; default auto = "
+                    "2 x f16 split behind the range guard, which falls back to the exact 3 x bf16 split per network)")
     ap.add_argument("--lowres-attenuation", action="store_true")
     ap.add_argument("--detect-only", action="store_true", help="time model.detect() only (BASELINE config 5: ChunkySeal extractor)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -170,7 +192,7 @@ def run(args):
     dist_on = world > 1 or os.environ.get("VS_BENCH_FORCE_DIST") == "1"   # the env switch exercises the RCCL path on one GPU
     if args.gpus != world and dist_on:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    if args.gpus > 1 and not dist_on:
+    if args.gpus > 1 and not dist_on:       # (main() re-executes a plain `python bench.py --gpus N` under the launcher before it gets here)
         raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback for the product path)")
@@ -179,9 +201,28 @@ def run(args):
     if dist_on and not torch.distributed.is_initialized():
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         torch.distributed.init_process_group("nccl", device_id=dev)
+    n_ranks_seen = None
+    if dist_on:      # how many ranks RCCL itself sees: a sum of ones over the communicator (not the launcher's environment variable)
+        one = torch.ones(1, device=dev, dtype=torch.int32)
+        torch.distributed.all_reduce(one)
+        n_ranks_seen = int(one.item())
 
     if args.graphs:
         os.environ["VIDEOSEAL_GRAPHS"] = "1"
+    conv_env = os.environ.get("VIDEOSEAL_CONV")
+    if args.conv:
+        os.environ["VIDEOSEAL_CONV"] = args.conv          # read when the engine is built (first model call)
+    try:
+        return _run(args, world, rank, dev, dist_on, n_ranks_seen)
+    finally:
+        if args.conv:
+            if conv_env is None:
+                os.environ.pop("VIDEOSEAL_CONV", None)
+            else:
+                os.environ["VIDEOSEAL_CONV"] = conv_env
+
+
+def _run(args, world, rank, dev, dist_on, n_ranks_seen):
     import videoseal_amd
     from videoseal_amd.dist import gather_frame_logits, shard_range
     model = videoseal_amd.build(args.card, seed=0).eval().to(dev)
@@ -205,7 +246,7 @@ def run(args):
 
     def step_stream_overlapped():     # videoseal_amd/streaming.py: detect(chunk i) on a second HIP stream while embed(chunk i+1) is issued
         from videoseal_amd.streaming import embed_detect_chunks
-        preds = embed_detect_chunks(model, frames_u8 if args.u8 else frames, msgs, chunk=16, lowres_attenuation=True, overlap=True)
+        preds = embed_detect_chunks(model, frames_u8 if args.u8 else frames, msgs, chunk=16, lowres_attenuation=True, overlap=True, group=args.group)
         if dist_on:
             preds = gather_frame_logits(preds, args.frames, align=16)
         return preds
@@ -305,6 +346,7 @@ def run(args):
     if not args.no_kernel_timers:
         eng.kernel_timers = []
         eng.shell_timers = []
+        eng.prof_extractor = bool(args.detect_only)
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -342,10 +384,15 @@ def run(args):
         split = eng.use_split
         nprod = products(eng)
         peak = peak_split(eng) if split else PEAK_F32_MFMA_TFLOPS
+        prof_name = eng.kernel_timers[0][0]
+        dom_is_bottleneck = prof_name.startswith("bott.")
+        if dom_is_bottleneck:
+            kname = (("conv3x3_pl_kernel" if getattr(eng, "planes_chain_ran", False) else "conv3x3_patch_pc_kernel")
+                     if split else "conv_gemm_kernel") + " (U-Net bottleneck 3x3 conv 384->384 @32x32, "
+        else:       # detect-only workloads: the extractor GEMM that carries most of the step (engine.prof_extractor names it)
+            kname = prof_name + " ("
         roof = {"bound": "mfma",
-                "kernel": (("conv3x3_pl_kernel" if getattr(eng, "planes_chain_ran", False) else "conv3x3_patch_pc_kernel")
-                           if split else "conv_gemm_kernel") + " (U-Net bottleneck 3x3 conv 384->384 @32x32, " +
-                          (arith_name(eng) + ", fp32 accumulate)" if split else "v_mfma_f32_32x32x2_f32)"),
+                "kernel": kname + (arith_name(eng) + ", fp32 accumulate)" if split else "v_mfma_f32_32x32x2_f32)"),
                 "achieved": round(ach, 2), "peak": round(peak, 1), "unit": "TFLOP/s", "frac": round(ach / peak, 4),
                 "peak_note": (f"2500 TF dense 16-bit MFMA / {nprod} partial products per fp32-accurate product" if split
                               else "f32-input MFMA, 64 FLOP/clk/SIMD"),
@@ -370,17 +417,15 @@ def run(args):
                 roof["mfma_sustained_measured"] = {"bf16_tflops": round(sus, 1), "split_equiv_tflops": round(sus / nprod, 1),
                                                    "frac_of_sustained": round(ach / (sus / nprod), 4),
                                                    "how": "tools/micro/mfma_peak.hip: register-only MFMA loop, random operands, 8 waves/CU x 4 blocks"}
-        import glob
-        # the same kernel's average duration in the tracked rocprofv3 --kernel-trace --stats run of this command (profiles/):
+        # the same kernel's average duration in the tracked rocprofv3 --kernel-trace --stats run of this command (profiles/CURRENT.json):
         # both fractions are printed so that the bench line and the profile can be compared directly
-        rp = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_rocprof_dominant.json")))
-        if rp and B == 32 and S == 768 and split and args.mode == "image" and json.load(open(rp[-1])).get("arith", 3) == eng.arith:
-            rj = json.load(open(rp[-1]))
+        rp = current_profile("rocprof_dominant")
+        if rp and B == 32 and S == 768 and split and args.mode == "image" and json.load(open(rp)).get("arith", 3) == eng.arith and dom_is_bottleneck:
+            rj = json.load(open(rp))
             roof["frac_rocprof"] = round(flops / (rj["avg_ms"] * 1e-3) / 1e12 / peak, 4)
             roof["rocprof"] = {"avg_launch_ms": rj["avg_ms"], "launches": rj["calls"], "source": rj["source"]}
-        pmcs = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_dominant.json")))
-        pmc = pmcs[-1] if pmcs else ""
-        if os.path.exists(pmc) and B == 32 and S == 768 and split and json.load(open(pmc)).get("arith", 3) == eng.arith:     # counters were collected on this exact workload
+        pmc = current_profile("pmc_dominant")
+        if pmc and B == 32 and S == 768 and split and json.load(open(pmc)).get("arith", 3) == eng.arith and dom_is_bottleneck:     # counters were collected on this exact workload
             pj = json.load(open(pmc))
             # HBM bytes per launch of the dominant kernel from the PMC passes (read + write), then the break-down
             roof["traffic"] = round((pj["fetch_mb_per_launch"] + pj["write_mb_per_launch"]) * 1e6)
@@ -429,7 +474,7 @@ def run(args):
                                    f"({'embedder on every frame' if not is_video else 'key frames every %d' % cfg.step_size}, "
                                    f"{'low-res' if args.lowres_attenuation else 'full-res'} JND), " + ("detect only" if args.detect_only else "embed + detect")
                                    + (", all-gather of bit logits" if dist_on else "")
-                                   + (f"; streaming: {args.frames}-frame clip as 16-frame calls, low-res JND" + (", uint8 RGB24 in/out" if args.u8 else "") + (", detect overlapped with the next embed on a second stream" if args.overlap else "") if stream else "")
+                                   + (f"; streaming: {args.frames}-frame clip in 16-frame chunks" + (", one embed + detect call per chunk" if (args.group == 1 or not args.overlap) else f", key frames of {args.group or 8} chunks per U-Net pass, extractor on 32 frames per pass, watermark expanded and handed on chunk by chunk") + ", low-res JND" + (", uint8 RGB24 in/out" if args.u8 else "") + (", detect overlapped with the next embed on a second stream" if args.overlap else "") if stream else "")
                                    + (", chain JPEG(40) -> Crop(0.71) -> Resize(0.71) -> Brightness(0.5) -> Contrast(1.5) -> Saturation(1.5) -> Hue(0.1) between embed and detect" if chain else "")
                                    + (", hipGraph replay" if args.graphs else ""),
                        "card": args.card, "weights": "random-init (seeded), no checkpoint offline", "batch_per_gpu": B,
@@ -438,9 +483,11 @@ def run(args):
             "value_pipelined": (round(pipelined, 2) if pipelined else None),
             "value_pipelined_note": "the same steps with detect(batch i) on a second HIP stream under embed(batch i+1) (bench.py --pipeline); `value` is the sequential run",
             "roofline": roof,
+            "arith_used": arith_used(eng),
         }
         if allgather_ms is not None:
             line["allgather_ms"] = round(allgather_ms, 4)
+            line["n_ranks_seen"] = n_ranks_seen
         if not args.no_cpu_baseline and world == 1 and not args.detect_only:
             card_path = os.path.join(ROOT, "videoseal_amd", "cards", args.card + ".yaml")
             line["cpu_baseline"] = cpu_baseline(card_path, S, args.mode, cfg.step_size)
@@ -484,8 +531,29 @@ def gen_step_leg(dev):
             "model_tflops_per_s": round(gflop / dt / 1e3, 1)}
 
 
+def self_launch(args):
+    """`python bench.py --gpus N` (N > 1) without a launcher: re-execute under torch.distributed.run, one rank per GPU of this node
+    (rendezvous on 127.0.0.1: the container hostname may not resolve).  Too few GPUs: ONE JSON error line, exit code 2."""
+    import socket
+    import subprocess
+    n = torch.cuda.device_count()
+    if n < args.gpus:
+        print(json.dumps({"error": f"--gpus {args.gpus} but this node shows {n} GPU(s)", "n_gpus_requested": args.gpus, "n_gpus_visible": n}), flush=True)
+        sys.exit(2)
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    sys.exit(subprocess.call(cmd, env=env))
+
+
 def main():
     args = parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ and os.environ.get("VS_BENCH_FORCE_DIST") != "1":
+        self_launch(args)
     line = run(args)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -505,12 +573,14 @@ def main():
                 return None
             roof = r.get("roofline") or {}
             return {"value": r["value"], "unit": r["unit"], "ms_per_step": r["ms_per_step"], "scaling": r["scaling"], "n_gpus": r["n_gpus"],
-                    "allgather_ms": r.get("allgather_ms"),
+                    "allgather_ms": r.get("allgather_ms"), "arith_used": r.get("arith_used"),
                     "workload": r["config"]["workload"], "model_tflops_per_s": r["model_tflops_per_s"],
                     "roofline": {k: roof.get(k) for k in ("kernel", "achieved", "peak", "unit", "frac", "avg_launch_ms", "e2e_frac") if k in roof},
                     "shell": roof.get("shell")}
         legs = {}
         if world == 1:
+            legs["image 32x256x256 (north_star's 256x256 clips)"] = leg(["--size", "256"])
+            legs["image 32x768 on the exact 3 x bf16 split (what the range guard falls back to: worst-case arithmetic)"] = leg(["--conv", "bf16x3"])
             legs["video_step4 (configs[1], video mode)"] = leg(["--mode", "video"])
             legs["chain (configs[2])"] = leg(["--mode", "chain"])
         legs["stream_1024 (configs[3], strong scaling over the ranks)"] = leg(["--mode", "stream", "--frames", "1024"], steps=2, warmup=1)

@@ -592,6 +592,50 @@ def test_streaming_overlap_equals_sequential(tiny):
     assert (a[:16].cpu() - ref).abs().max().item() < TOL_LOGIT
 
 
+@pytest.mark.parametrize("mode", ["repeat", "alternate", "interpolate"])
+def test_streaming_key_frame_groups_equal_the_per_chunk_calls(tiny, mode):
+    """streaming.embed_detect_chunks with the key frames of several chunks in ONE U-Net pass (group > 1) against the literal per-chunk calls
+    (group = 1 = inference_streaming.py:83-164), every video mode (videoseal.py:303-344: 'interpolate' treats the last key frame of each CHUNK
+    specially, so the watermark must still be expanded chunk by chunk), ragged last chunk, fp32 and uint8 clips.  Not bit-equal by
+    construction: whether a dense layer splits K is a function of the batch shape -> fp32 summation order."""
+    from videoseal_amd.streaming import default_group, embed_detect_chunks
+    spec, sd, model = tiny
+    model.chunk_size, model.step_size, model.video_mode = 4, 4, mode
+    try:
+        frames = synthetic_frames(44, 96, 80, seed=52).cuda()
+        msgs = synthetic_msgs(1, spec.nbits, seed=52)
+        assert default_group(16, 4) == 8 and default_group(16, 5) == 1 and default_group(8, 4) == 16
+        one_w, grp_w = [], []
+        a = embed_detect_chunks(model, frames, msgs, chunk=16, overlap=False, group=1, sink=lambda i, w: one_w.append((i, w.clone())))
+        b = embed_detect_chunks(model, frames, msgs, chunk=16, overlap=True, group=2, sink=lambda i, w: grp_w.append((i, w.clone())))
+        torch.cuda.synchronize()
+        assert [i for i, _ in one_w] == [i for i, _ in grp_w] == [0, 16, 32]
+        assert [w.shape[0] for _, w in grp_w] == [16, 16, 12]
+        for (_, x), (_, y) in zip(one_w, grp_w):
+            assert (x - y).abs().max().item() < 1e-5
+        assert (a - b).abs().max().item() < 1e-3
+        # the per-chunk expansion matters: one tail launch over the whole group differs in 'interpolate' mode (frames 13-15 of a chunk)
+        if mode == "interpolate":
+            model.chunk_size = 8                       # embed() itself with 32-frame chunks: a different (legal) chunking of the clip
+            whole = model.embed(frames[:32], msgs, is_video=True, lowres_attenuation=True)["imgs_w"]
+            assert (whole[13:16] - one_w[0][1][13:16]).abs().max().item() > 1e-6
+            assert (whole[:13] - one_w[0][1][:13]).abs().max().item() < 1e-5
+        clip = (frames * 255).to(torch.uint8).permute(0, 2, 3, 1).contiguous()
+        model.chunk_size = 4
+        u1, u2 = [], []
+        c = embed_detect_chunks(model, clip, msgs, chunk=16, overlap=False, group=1, sink=lambda i, w: u1.append(w.clone()))
+        d = embed_detect_chunks(model, clip, msgs, chunk=16, overlap=True, sink=lambda i, w: u2.append(w.clone()))
+        torch.cuda.synchronize()
+        for x, y in zip(u1, u2):             # uint8 frames: a 1e-7 difference may cross a rounding boundary of (x * 255).byte() in rare pixels
+            assert (x.int() - y.int()).abs().max().item() <= 1
+            assert (x != y).float().mean().item() < 1e-4
+        assert (c - d).abs().max().item() < 5e-3
+        with pytest.raises(ValueError):
+            embed_detect_chunks(model, frames, msgs, chunk=10, group=2)
+    finally:
+        model.video_mode = "repeat"
+
+
 def test_chunkyseal_released_size_detector_vs_oracle():
     """BASELINE config 5 architecture at its released size (ConvNeXt dims 362/724/1448/2896, depths 3/3/27/3, 774 M extractor
     parameters, 1024 bits, stride-2 stem -> 127/63/31/15 feature maps): HIP detect vs the CPU oracle on two frames."""

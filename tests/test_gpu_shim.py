@@ -74,3 +74,38 @@ def test_readme_quick_start_calls():
     assert hidden.shape == (spec.nbits,)
     from videoseal.evals.metrics import psnr
     assert float(psnr(imgs_w, img)) > 25
+
+
+def test_model_built_by_the_train_py_factories_runs_like_the_card_built_one():
+    """train.py:262-305: build_embedder + build_extractor + Videoseal(...) -> the same HIP engine configuration as the card path: with one
+    state_dict both models return bit-identical frames and logits; a train-mode forward of the factory-built model carries gradients to the
+    optimizer's parameter list (train.py:330, 626-643)"""
+    from videoseal.augmentation.augmenter import get_dummy_augmenter
+    from videoseal.models import build_embedder, build_extractor
+    from videoseal.modules.jnd import JND
+    spec = tiny_spec()
+    sd = make_state_dict(spec, seed=3)
+    ref_model = make_model(spec, sd)
+    emb_cfg = {"msg_processor": {"nbits": 16, "hidden_size": 32, "msg_processor_type": "binary+concat"},
+               "unet": {"in_channels": spec.in_ch, "out_channels": spec.out_ch, "z_channels": spec.z, "num_blocks": spec.num_blocks, "activation": "relu",
+                        "normalization": "batch", "z_channels_mults": list(spec.mults), "last_tanh": spec.last_tanh}}
+    ext_cfg = {"encoder": {"depths": list(spec.depths), "dims": list(spec.dims)}, "pixel_decoder": {"upscale_stages": [1], "nbits": 16}}
+    embedder = build_embedder("unet_tiny_yuv_quant" if spec.yuv else "unet_tiny_quant", emb_cfg, spec.nbits, spec.hidden / spec.nbits)
+    extractor = build_extractor("convnext_tiny", ext_cfg, spec.img_size, spec.nbits)
+    wam = Videoseal(embedder, extractor, get_dummy_augmenter(), JND(in_channels=1, out_channels=1), spec.scaling_w, spec.scaling_i,
+                    img_size=spec.img_size, chunk_size=spec.chunk_size, step_size=spec.step_size, blending_method="additive", lowres_attenuation=False)
+    msg = wam.load_state_dict(sd, strict=True)
+    assert not msg.missing_keys and not msg.unexpected_keys
+    wam = wam.to("cuda").eval()
+    x = synthetic_frames(6, 112, 96, seed=63).cuda()
+    msgs = torch.randint(0, 2, (1, spec.nbits), generator=torch.Generator().manual_seed(1))
+    a = ref_model.embed(x, msgs, is_video=True)["imgs_w"]
+    b = wam.embed(x, msgs, is_video=True)["imgs_w"]
+    assert torch.equal(a, b)
+    assert torch.equal(ref_model.detect(a, is_video=True)["preds"], wam.detect(b, is_video=True)["preds"])
+    wam.train()
+    params = list(embedder.parameters()) + list(extractor.parameters())
+    out = wam(x[:2], torch.ones(2, 1, 112, 96, device="cuda"), torch.randint(0, 2, (2, spec.nbits)).cuda(), is_video=False)
+    loss = out["preds"][:, 1:].square().mean() + (out["imgs_w"] - x[:2]).square().mean()
+    loss.backward()
+    assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in params if p.requires_grad)

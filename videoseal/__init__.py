@@ -11,7 +11,13 @@ README quick start):
     model = videoseal.load("videoseal")          # videoseal/__init__.py:13-17
 
 Everything here is a re-export of ``videoseal_amd`` (host plumbing over libvideoseal_hip.so); there is no second code path.
+Modules outside the path (``videoseal.losses``, ``videoseal.data``, ``videoseal.utils.optim`` ...: what train.py:55-72 imports besides
+the model) resolve to a reference checkout named by ``VIDEOSEAL_REFERENCE_ROOT`` when that is set (videoseal/_overlay.py).
 """
 from videoseal_amd import __version__, available_cards, build, load  # noqa: F401
 
 from . import augmentation, evals, models, modules, utils  # noqa: E402,F401
+
+from ._overlay import extend as _extend, fallback_getattr as _fallback  # noqa: E402
+_extend(__path__)
+__getattr__ = _fallback(__name__, "")

@@ -1,0 +1,4 @@
+"""videoseal.models.extractor (models/extractor.py:40-213): the ConvNeXt-V2 / ViT extractors and their factory on the HIP path."""
+from videoseal_amd.builders import build_extractor  # noqa: F401
+from videoseal_amd.model import Extractor  # noqa: F401
+ConvnextExtractor = SegmentationExtractor = Extractor

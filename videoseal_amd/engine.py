@@ -238,6 +238,7 @@ class HipEngine:
         self.lib = N.lib()
         self._ws: Dict[tuple, torch.Tensor] = {}
         self.kernel_timers = None        # list of (name, start_event, end_event, flops) when bench.py enables it
+        self.prof_extractor = False      # time the extractor's stage-2 pwconv1 launches instead (detect-only workloads: no bottleneck conv)
         self.time_all_convs = False
         # arithmetic back-end of vs_conv_gemm: "f16x2" (2 x f16 split, 3 products), "bf16x3" (exact 3 x bf16 split, 6 products),
         # "f32" (v_mfma_f32_32x32x2_f32); "split" = the default split back-end
@@ -1045,6 +1046,10 @@ class HipEngine:
                     N.check(L.vs_dwconv7_ln(N.ptr(cur.t), B, cur.H, cur.W, Cc, cur.ld, N.ptr(blk["wdw"]), N.ptr(blk["bdw"]), N.ptr(blk["lnw"]),
                                             N.ptr(blk["lnb"]), 1e-6, N.ptr(tn.t), tn.ld, st), "vs_dwconv7_ln")
                 kw1 = dict(in_pl=tnpl, tile_hint=ptile) if pl1 else {}
+                if self.prof_extractor and sti == 2:      # bench.py --detect-only: the dominant GEMM of an extractor-only workload
+                    kw1["prof"] = (f"{'gemm_pl_kernel' if pl1 else 'gemm1x1_pc_kernel / conv_gemm_kernel'}: ConvNeXt stage-2 pwconv1 "
+                                   f"{Cc}->{4 * Cc} @{cur.H}x{cur.W}")
+                    kw1["flops"] = 2.0 * cur.rows * Cc * 4 * Cc      # algorithmic (unpadded) FLOPs
                 if HW % 32 == 0:      # ||h||^2 partials come out of pwconv1's epilogue: no second pass over h
                     part32 = self.buf(f"st{sti}.gp32", B * (HW // 32) * 4 * Cc)
                     self.conv(tn, blk["pw1"], hh, act=N.ACT_GELU, sumsq=part32, **kw1)

@@ -201,6 +201,22 @@ def _msgs_i32(msgs: torch.Tensor, dev) -> torch.Tensor:
     return m.to(torch.int32).contiguous()
 
 
+_EXTRACTOR_FIELDS = ("depths", "dims", "stem_stride", "extractor", "vit_dim", "vit_depth", "vit_heads", "vit_patch", "vit_window", "vit_global",
+                     "vit_out", "vit_mlp_ratio", "vit_rel_pos")
+
+
+def merge_cfg(embedder: "Embedder", detector: "Extractor", **own) -> ModelCfg:
+    """One ModelCfg for the engine out of the halves `build_embedder` / `build_extractor` produced (videoseal_amd/builders.py, train.py:262-281)
+    + the numbers the Wam / Videoseal constructor was given.  Models built from a card already share one cfg."""
+    import dataclasses
+    e, d = embedder.cfg, detector.cfg
+    if e is d:
+        return e
+    if e.nbits != d.nbits:
+        raise ValueError(f"embedder carries {e.nbits} bits, extractor {d.nbits}")
+    return dataclasses.replace(e, **{f: getattr(d, f) for f in _EXTRACTOR_FIELDS}, **own)
+
+
 class Wam(nn.Module):
     """Image path (models/wam.py:18-234)."""
 
@@ -208,6 +224,10 @@ class Wam(nn.Module):
                  scaling_w: float = 1.0, scaling_i: float = 1.0, clamp: bool = True, img_size: int = 256,
                  blending_method: str = "additive") -> None:
         super().__init__()
+        if embedder.cfg is not detector.cfg:      # halves from build_embedder / build_extractor (train.py:262-305)
+            jnd = (attenuation.in_channels, attenuation.out_channels) if attenuation is not None else (0, 0)
+            embedder.cfg = detector.cfg = merge_cfg(embedder, detector, img_size=int(img_size), scaling_w=float(scaling_w), scaling_i=float(scaling_i),
+                                                    blending_method=str(blending_method), jnd_in=jnd[0], jnd_out=jnd[1])
         self.embedder, self.detector, self.augmenter = embedder, detector, augmenter
         self.img_size = img_size
         self.rgb2yuv = RGB2YUV()
@@ -349,11 +369,11 @@ class Wam(nn.Module):
     # ---- core of embed: one chunk of frames on the device
     def _embed_frames(self, eng: HipEngine, fr: torch.Tensor, msgs_i32: torch.Tensor, out: torch.Tensor, *, step: int,
                       video_mode: int, antialias: bool, lowres: bool, preds_w: Optional[torch.Tensor] = None,
-                      fwd_order: bool = False) -> None:
+                      fwd_order: bool = False, tail_span: int = 0) -> None:
         bn_train = self.embedder.training
         if self.use_graphs and not bn_train and not torch.cuda.is_current_stream_capturing():
             key = ("emb", fr.dtype, tuple(fr.shape), tuple(msgs_i32.shape), step, video_mode, antialias, lowres, preds_w is not None, self.img_size,
-                   self.clamp, float(self.blender.scaling_i), float(self.blender.scaling_w), self.attenuation is not None, fwd_order, id(eng))
+                   self.clamp, float(self.blender.scaling_i), float(self.blender.scaling_w), self.attenuation is not None, fwd_order, tail_span, id(eng))
             ent = self._graphs.get(key)
             if ent is None:
                 sin = {"fr": fr.clone(), "msgs": msgs_i32.clone()}
@@ -361,12 +381,12 @@ class Wam(nn.Module):
                 spw = torch.empty_like(preds_w) if preds_w is not None else None
                 for _ in range(2):
                     self._embed_frames_eager(eng, sin["fr"], sin["msgs"], sout, step=step, video_mode=video_mode, antialias=antialias,
-                                             lowres=lowres, preds_w=spw, fwd_order=fwd_order)
+                                             lowres=lowres, preds_w=spw, fwd_order=fwd_order, tail_span=tail_span)
                 torch.cuda.synchronize()
                 g = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(g):
                     self._embed_frames_eager(eng, sin["fr"], sin["msgs"], sout, step=step, video_mode=video_mode, antialias=antialias,
-                                             lowres=lowres, preds_w=spw, fwd_order=fwd_order)
+                                             lowres=lowres, preds_w=spw, fwd_order=fwd_order, tail_span=tail_span)
                 ent = {"g": g, "in": sin, "out": sout, "pw": spw}
                 self._graphs[key] = ent
             ent["in"]["fr"].copy_(fr)
@@ -377,19 +397,34 @@ class Wam(nn.Module):
                 preds_w.copy_(ent["pw"])
             return
         self._embed_frames_eager(eng, fr, msgs_i32, out, step=step, video_mode=video_mode, antialias=antialias, lowres=lowres,
-                                 preds_w=preds_w, fwd_order=fwd_order)
+                                 preds_w=preds_w, fwd_order=fwd_order, tail_span=tail_span)
 
     def _embed_frames_eager(self, eng: HipEngine, fr: torch.Tensor, msgs_i32: torch.Tensor, out: torch.Tensor, *, step: int,
                             video_mode: int, antialias: bool, lowres: bool, preds_w: Optional[torch.Tensor] = None,
-                            fwd_order: bool = False) -> None:
+                            fwd_order: bool = False, tail_span: int = 0) -> None:
+        """tail_span > 0 (a multiple of `step`): `fr` is a GROUP of consecutive caller chunks of tail_span frames each.  The key frames of the
+        whole group go through the U-Net as one batch (the matrix kernels want >= 32 key frames to fill 256 CUs), the watermark is then
+        expanded chunk by chunk exactly as the per-chunk calls would do it (videoseal.py:303-344: the last key frame of a chunk has no
+        successor in 'interpolate' mode), so the group equals the sequence of per-chunk calls up to the summation order of the dense layers."""
         S = (self.img_size, self.img_size)
         att = self.attenuation is not None
         rgb, key = eng.resize_pre(fr, S, antialias, want_rgb=(att and lowres), want_key=True, key_step=step)
         delta = eng.embedder_forward(key, msgs_i32, bn_train=self.embedder.training)
         hmap = eng.jnd_lowres(rgb) if (att and lowres) else None
-        eng.embed_tail(fr, out, delta, step=step, video_mode=video_mode, hmap_low=hmap,
-                       attenuate=(2 if (att and fwd_order and not lowres) else int(att)), clamp=self.clamp,
-                       antialias=antialias, scaling_i=self.blender.scaling_i, scaling_w=self.blender.scaling_w, preds_w=preds_w)
+        kw = dict(step=step, video_mode=video_mode, attenuate=(2 if (att and fwd_order and not lowres) else int(att)), clamp=self.clamp,
+                  antialias=antialias, scaling_i=self.blender.scaling_i, scaling_w=self.blender.scaling_w)
+        F_ = fr.shape[0]
+        if tail_span <= 0 or tail_span >= F_ or video_mode == N.VIDEO_MODES["repeat"]:
+            # 'repeat' looks at one key frame per output frame: one launch over the group is the per-chunk launches
+            eng.embed_tail(fr, out, delta, hmap_low=hmap, preds_w=preds_w, **kw)
+            return
+        if tail_span % step:
+            raise ValueError("tail_span must be a multiple of the key-frame step")
+        hw = S[0] * S[1]
+        for a in range(0, F_, tail_span):
+            b = min(F_, a + tail_span)
+            eng.embed_tail(fr[a:b], out[a:b], delta[a // step:(b + step - 1) // step], hmap_low=(hmap[a * hw:b * hw] if hmap is not None else None),
+                           preds_w=(preds_w[a:b] if preds_w is not None else None), **kw)
 
     def _run_chunks(self, eng: HipEngine, imgs: torch.Tensor, span: int, fn, *, want_out: bool = True, extra=None):
         """Drive `fn(chunk_on_device, out_chunk_on_device, a, b)` over [a, b) frame ranges of `span` frames.  Frames that are not
@@ -553,6 +588,9 @@ class Videoseal(Wam):
                  blending_method: str = "additive", video_mode: str = "repeat", lowres_attenuation: bool = False) -> None:
         super().__init__(embedder, detector, augmenter, attenuation, scaling_w, scaling_i, clamp, img_size, blending_method)
         self.chunk_size, self.step_size = chunk_size, step_size
+        if self.embedder.cfg.chunk_size != int(chunk_size) or self.embedder.cfg.step_size != int(step_size):
+            import dataclasses            # (a fresh object: a card's cfg may be shared between models)
+            self.embedder.cfg = self.detector.cfg = dataclasses.replace(self.embedder.cfg, chunk_size=int(chunk_size), step_size=int(step_size))
         self.video_mode = video_mode
         self.lowres_attenuation = lowres_attenuation
 
@@ -568,6 +606,35 @@ class Videoseal(Wam):
             return self._run_chunks(eng, imgs, ck * step,       # frames per chunk (videoseal.py:292-297)
                                     lambda fr, oc, a, b: self._embed_frames(eng, fr, mi, oc, step=step, video_mode=vm, antialias=aa,
                                                                             lowres=lowres_attenuation))
+
+    @torch.no_grad()
+    def embed_group(self, frames: torch.Tensor, msgs: torch.Tensor, chunk: int, interpolation: dict = None,
+                    lowres_attenuation: bool = False) -> torch.Tensor:
+        """`frames` (device-resident fp32 [F,3,H,W] or uint8 RGB24 [F,H,W,3]) = consecutive caller chunks of `chunk` frames (the last one may be
+        short), `chunk` a multiple of step_size.  Returns what `torch.cat([embed(c, msgs, is_video=True)['imgs_w'] for c in chunks])` returns
+        (embed_u8 for uint8), with the key frames of ALL chunks going through the U-Net as one batch: 16-frame streaming calls
+        (inference_streaming.py:83-107) carry 4 key frames each, which leaves the matrix kernels at a third of the rate they reach with 32.
+        The per-chunk semantics of videoseal.py:303-344 are kept by expanding the watermark chunk by chunk (`_embed_frames_eager`); values
+        differ from the per-chunk calls only by the summation order of the dense layers (a K split is a function of the batch shape)."""
+        if self.video_mode not in N.VIDEO_MODES:
+            raise ValueError(f"unknown video_mode {self.video_mode}")
+        assert msgs.shape[0] == 1, "Message should be unique"
+        eng = self._engine()
+        step = int(self.step_size)
+        if chunk % step:
+            raise ValueError(f"chunk ({chunk}) must be a multiple of step_size ({step}): the key frames of the group are every step-th frame")
+        if frames.device != eng.dev:
+            raise ValueError("embed_group wants device-resident frames")
+        u8 = frames.dtype == torch.uint8
+        if u8 and not self.clamp:
+            raise NotImplementedError("uint8 output needs clamp=True ((x * 255).byte() is undefined outside [0, 1])")
+        aa = _antialias_flag(interpolation)
+        with torch.cuda.device(eng.dev):
+            src = frames.contiguous() if u8 else N.f32c(frames)
+            out = torch.empty_like(src)
+            self._embed_frames(eng, src, self._msgs_dev(msgs, eng.dev), out, step=step, video_mode=N.VIDEO_MODES[self.video_mode], antialias=aa,
+                               lowres=lowres_attenuation, tail_span=int(chunk))
+        return out
 
     @torch.no_grad()
     def embed(self, imgs: torch.Tensor, msgs: torch.Tensor = None, is_video: bool = True, interpolation: dict = None,

@@ -1,48 +1,91 @@
 """Clip-level driver for the streaming configuration (inference_streaming.py:83-164): a long clip goes through the model as
-16-frame `embed(..., is_video=True, lowres_attenuation=True)` + `detect` calls.  With 4 key frames / 16 frames per call most
-kernels cannot fill 256 CUs on their own, so detect(chunk i) is issued on a second HIP stream while embed(chunk i+1) runs on the
-first.  The calls, their arguments and their results are unchanged; only their placement on streams differs.
-Safe because: embedder and extractor use disjoint named workspace buffers, K-split workspaces are per stream, every watermarked
-chunk is a fresh tensor (recorded on the consuming stream), and the extractor's logits are cloned on the detect stream."""
+16-frame `embed(..., is_video=True, lowres_attenuation=True)` + `detect` calls.  With 4 key frames / 16 frames per call the matrix
+kernels cannot fill 256 CUs (the U-Net bottleneck conv runs at 0.19 of its ceiling instead of 0.53), so when the clip is resident:
+
+  * the key frames of `group` consecutive chunks go through the U-Net as ONE batch (`Videoseal.embed_group`; default: enough chunks for
+    32 key frames), the watermark is expanded chunk by chunk as the per-chunk calls would do it, and `sink` still sees chunk after chunk;
+  * the extractor runs on >= 32 watermarked frames at a time, whatever the caller's chunk;
+  * detect(group i) is issued on a second HIP stream while embed(group i+1) runs on the first.
+
+`group=1` is exactly the sequence of per-chunk calls (bit-identical; the round-3 behaviour); larger groups differ from it only by the
+summation order of the dense layers, because whether K is split is a function of the batch shape (engine._split_k_rule*).
+Stream safety: embedder and extractor use disjoint named workspace buffers, K-split workspaces are per stream, every watermarked
+group is a fresh tensor (recorded on the consuming stream), and the extractor's logits are cloned on the detect stream."""
 from __future__ import annotations
 
 from typing import Callable, Optional, Tuple
 
 import torch
 
+KEY_BATCH = 32      # key frames per U-Net pass at which conv3x3_pl_kernel has one 256-pixel tile x 192 channels per CU (B * 4 * 2 = 256)
+DET_BATCH = 32      # frames per extractor pass
+
+
+def default_group(chunk: int, step: int) -> int:
+    """chunks per U-Net pass: enough for KEY_BATCH key frames; 1 (= the per-chunk calls) when the chunks' key frames are not the group's
+    every-step-th frames"""
+    if chunk % step:
+        return 1
+    return max(1, (KEY_BATCH * step + chunk - 1) // chunk)
+
 
 def embed_detect_chunks(model, frames: torch.Tensor, msgs: torch.Tensor, chunk: int = 16, lowres_attenuation: bool = True,
-                        overlap: bool = True, sink: Optional[Callable[[int, torch.Tensor], None]] = None) -> torch.Tensor:
+                        overlap: bool = True, sink: Optional[Callable[[int, torch.Tensor], None]] = None,
+                        group: Optional[int] = None) -> torch.Tensor:
     """frames [F,3,H,W] fp32 or uint8 [F,H,W,3] on the device -> logits [F, 1+nbits].  `sink(first_frame, imgs_w_chunk)` receives
-    every watermarked chunk (e.g. to hand it to an encoder); it is called on the embed stream's timeline."""
+    every watermarked chunk in clip order (e.g. to hand it to an encoder); it is called on the embed stream's timeline.
+    group: chunks per U-Net pass (None = default_group; 1 = the literal per-chunk calls)."""
     u8 = frames.dtype == torch.uint8
-    emb = (lambda x: model.embed_u8(x, msgs, lowres_attenuation=lowres_attenuation)) if u8 else \
-          (lambda x: model.embed(x, msgs, is_video=True, lowres_attenuation=lowres_attenuation))
-    det = (lambda w: model.detect_u8(w)) if u8 else (lambda w: model.detect(w, is_video=True))
+    step = int(model.step_size)
+    if group is None:
+        group = default_group(chunk, step)
+    if group > 1 and chunk % step:
+        raise ValueError(f"group > 1 needs chunk ({chunk}) to be a multiple of step_size ({step})")
     F_ = frames.shape[0]
+    span = chunk * group
+
+    def emb(x):
+        if group == 1:       # the caller's own calls
+            return (model.embed_u8(x, msgs, lowres_attenuation=lowres_attenuation) if u8 else
+                    model.embed(x, msgs, is_video=True, lowres_attenuation=lowres_attenuation))["imgs_w"]
+        return model.embed_group(x, msgs, chunk, lowres_attenuation=lowres_attenuation)
+
+    def det(w):
+        # detect_u8 / detect(is_video=True) walk `w` in model.chunk_size frames; raise it to DET_BATCH for this call so that the extractor
+        # sees full batches (frames are independent: the logits of a frame do not depend on the batch it is in, up to the K-split rule)
+        old = model.chunk_size
+        model.chunk_size = max(int(old), DET_BATCH) if group > 1 else old
+        try:
+            return (model.detect_u8(w) if u8 else model.detect(w, is_video=True))["preds"]
+        finally:
+            model.chunk_size = old
+
+    def feed_sink(a, w):
+        if sink:
+            for c in range(0, w.shape[0], chunk):
+                sink(a + c, w[c:c + chunk])
+
     logits = []
     if not overlap:
-        for a in range(0, F_, chunk):
-            w = emb(frames[a:a + chunk])["imgs_w"]
-            if sink:
-                sink(a, w)
-            logits.append(det(w)["preds"])
+        for a in range(0, F_, span):
+            w = emb(frames[a:a + span])
+            feed_sink(a, w)
+            logits.append(det(w))
         return torch.cat(logits, 0)
     cur = torch.cuda.current_stream()
     s_emb, s_det = _streams(frames.device)
     s_emb.wait_stream(cur)
     s_det.wait_stream(cur)
-    for a in range(0, F_, chunk):
+    for a in range(0, F_, span):
         with torch.cuda.stream(s_emb):
-            w = emb(frames[a:a + chunk])["imgs_w"]
-            if sink:
-                sink(a, w)
+            w = emb(frames[a:a + span])
+            feed_sink(a, w)
             ev = torch.cuda.Event()
             ev.record(s_emb)
         with torch.cuda.stream(s_det):
             s_det.wait_event(ev)
             w.record_stream(s_det)
-            logits.append(det(w)["preds"])
+            logits.append(det(w))
     cur.wait_stream(s_emb)
     cur.wait_stream(s_det)
     out = torch.cat(logits, 0)
