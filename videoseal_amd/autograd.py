@@ -316,6 +316,7 @@ class EmbedTrainFn(torch.autograd.Function):
         if model._emb_bwd is None:
             model._emb_bwd = EmbedderBackward(model)
         eb = model._emb_bwd
+        eng.begin_training_pass()
         S = (model.img_size, model.img_size)
         step, vm, aa, lowres = opts["step"], opts["video_mode"], opts["antialias"], opts["lowres"]
         att = model.attenuation is not None
@@ -382,6 +383,7 @@ class DetectTrainFn(torch.autograd.Function):
         if model._det_bwd is None:
             model._det_bwd = DetectorStep(model)
         ds = model._det_bwd
+        eng.begin_training_pass()
         x = N.f32c(x)
         rgb, _ = eng.resize_pre(x, (x.shape[-2], x.shape[-1]), False, want_rgb=True, mul=2.0, add=-1.0, tag="tr.det.in")
         logits, saved = ds._forward(eng, rgb)

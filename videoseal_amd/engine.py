@@ -237,6 +237,8 @@ class HipEngine:
         self.dev = device
         self.lib = N.lib()
         self._ws: Dict[tuple, torch.Tensor] = {}
+        self._ws_used: Dict[tuple, int] = {}      # 'tr.*' keys: the training pass that last touched them (begin_training_pass)
+        self._tr_pass = 0
         self.kernel_timers = None        # list of (name, start_event, end_event, flops) when bench.py enables it
         self.prof_extractor = False      # time the extractor's stage-2 pwconv1 launches instead (detect-only workloads: no bottleneck conv)
         self.time_all_convs = False
@@ -325,6 +327,8 @@ class HipEngine:
                 net = "X" if gname == "X" else "E"
                 if self.auto_arith:                 # new weights: back to the fast arithmetic, to be verified by the next pass
                     self.arith_net[net], self.verified[net] = 2, False
+                    self._nf_flag[0 if net == "E" else 1] = 0       # a flag raised by the OLD weights must not downgrade the new ones
+                    self._nf_event = None
 
     # ------------------------------------------------------------------ packing
     def _bn_fold(self, g, p):
@@ -446,15 +450,31 @@ class HipEngine:
 
     # ------------------------------------------------------------------ workspace
     def buf(self, tag: str, numel: int, zero: bool = False) -> torch.Tensor:
+        """named persistent workspace: stable addresses across calls of one shape (hipGraph-capturable)"""
         key = (tag, numel)
         t = self._ws.get(key)
         if t is None:
             t = torch.zeros(numel, device=self.dev, dtype=torch.float32) if zero else torch.empty(numel, device=self.dev, dtype=torch.float32)
             self._ws[key] = t
+        if tag.startswith("tr."):
+            self._ws_used[key] = self._tr_pass
         return t
+
+    def begin_training_pass(self) -> None:
+        """Called at the start of every training forward (EmbedTrainFn / DetectTrainFn / DetectorStep.step).  The training path's buffers
+        ('tr.*': every saved activation of both networks) are keyed by size like all workspaces, but frame counts vary there (DropFrame /
+        SpeedChange, a last partial batch, clips of different lengths) and a full activation set per distinct size would accumulate until
+        the device is full: sizes that no pass of the last three touched are dropped.  The operands a pending backward needs are held by
+        the references its saved dicts carry, so dropping the engine's handle never frees memory a graph still reads."""
+        self._tr_pass += 1
+        stale = [k for k, g in self._ws_used.items() if g < self._tr_pass - 3]
+        for k in stale:
+            self._ws.pop(k, None)
+            del self._ws_used[k]
 
     def release_workspace(self):
         self._ws.clear()
+        self._ws_used.clear()
 
     def new_act(self, tag: str, B: int, H: int, W: int, Cc: int, ld: Optional[int] = None) -> Act:
         ld = ld or rup(Cc, 4)
@@ -786,10 +806,27 @@ class HipEngine:
                 return False
             self.verified[net] = True
             return True
+        self.note_guard()
+        return True
+
+    def note_guard(self) -> None:
+        """steady state (verified weights) and hipGraph replays: copy the guard flags to pinned host memory behind the pass, no synchronisation"""
+        if not (self.use_split and self.auto_arith) or self._nf_host is None:
+            return
         self._nf_host.copy_(self._nf_flag, non_blocking=True)
         self._nf_event = torch.cuda.Event()
         self._nf_event.record()
-        return True
+
+    def _take_guard(self) -> List[str]:
+        """networks whose (already delivered) guard flags say 'non-finite': switched to 3 x bf16 here, flags cleared"""
+        self._nf_event = None
+        bad = [n for i, n in enumerate(("E", "X")) if int(self._nf_host[i]) and self.arith_net[n] == 2]
+        if bad:
+            for n in bad:
+                self.arith_net[n] = 3
+            self._nf_flag.zero_()
+            self._nf_host.zero_()
+        return bad
 
     def poll_nonfinite(self) -> None:
         """API entry: has an earlier (already verified) pass tripped the range guard?  Then its frames were non-finite: switch the network to
@@ -797,14 +834,24 @@ class HipEngine:
         ev = self._nf_event
         if ev is None or not ev.query():
             return
-        self._nf_event = None
-        bad = [n for i, n in enumerate(("E", "X")) if int(self._nf_host[i]) and self.arith_net[n] == 2]
+        bad = self._take_guard()
         if bad:
-            for n in bad:
-                self.arith_net[n] = 3
-            self._nf_flag.zero_()
             raise N.NativeError("an earlier call produced non-finite values in the " + " and ".join("embedder" if n == "E" else "extractor" for n in bad) +
                                 " (data-dependent overflow): " + self._WHY + ".  The engine has switched to it for this model: repeat the call.")
+
+    def guard_tripped_after_sync(self) -> bool:
+        """For entry points that synchronise anyway before they return (results for a CPU caller): after that synchronisation the flags of
+        every pass of the call are on the host.  True = a network overflowed and has been switched to 3 x bf16 -- the caller repeats the
+        work instead of handing out non-finite frames (and instead of reporting it one call late)."""
+        if self._nf_event is None:
+            return False
+        self._nf_event.synchronize()
+        bad = self._take_guard()
+        if bad:
+            import warnings
+            warnings.warn(" and ".join("embedder" if n == "E" else "extractor" for n in bad) + ": data-dependent overflow of the 2 x f16 operand split; "
+                          "switched to the exact 3 x bf16 split and repeated the call")
+        return bool(bad)
 
     def _gemm_planes_ok(self, rows: int, n: int) -> bool:
         """1x1 GEMM on operand planes (gemm_pl.hip): 2 x f16 arithmetic and enough 256-row x 192-column tiles for the 256 CUs"""

@@ -345,8 +345,8 @@ class Wam(nn.Module):
         if ent is None:
             static_in = {k: v.clone() for k, v in ins.items()}
             run(static_in)
-            run(static_in)
-            torch.cuda.synchronize()
+            run(static_in)          # (the first eager pass verifies new weights and may switch the network to 3 x bf16: the capture below
+            torch.cuda.synchronize()    # then records the kernels of the arithmetic in force; keys carry arith_net, so it is found again)
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g):
                 outs = run(static_in)
@@ -362,8 +362,10 @@ class Wam(nn.Module):
             rgb, _ = eng.resize_pre(si["fr"], S, antialias, want_rgb=True, mul=2.0, add=-1.0, tag="det.in")
             return {"preds": eng.extractor_forward(rgb)}
         if self.use_graphs and not torch.cuda.is_current_stream_capturing():
-            key = ("det", fr.dtype, tuple(fr.shape), tuple(S), antialias, id(eng))
-            return self._graphed(key, {"fr": fr}, run)["preds"].clone()
+            key = ("det", fr.dtype, tuple(fr.shape), tuple(S), antialias, id(eng), eng.arith_net["X"])
+            out = self._graphed(key, {"fr": fr}, run)["preds"].clone()
+            eng.note_guard()           # the captured vs_check_finite has run: deliver its flag like an eager steady-state pass does
+            return out
         return run({"fr": fr})["preds"].clone()
 
     # ---- core of embed: one chunk of frames on the device
@@ -373,7 +375,7 @@ class Wam(nn.Module):
         bn_train = self.embedder.training
         if self.use_graphs and not bn_train and not torch.cuda.is_current_stream_capturing():
             key = ("emb", fr.dtype, tuple(fr.shape), tuple(msgs_i32.shape), step, video_mode, antialias, lowres, preds_w is not None, self.img_size,
-                   self.clamp, float(self.blender.scaling_i), float(self.blender.scaling_w), self.attenuation is not None, fwd_order, tail_span, id(eng))
+                   self.clamp, float(self.blender.scaling_i), float(self.blender.scaling_w), self.attenuation is not None, fwd_order, tail_span, id(eng), eng.arith_net["E"])
             ent = self._graphs.get(key)
             if ent is None:
                 sin = {"fr": fr.clone(), "msgs": msgs_i32.clone()}
@@ -383,6 +385,9 @@ class Wam(nn.Module):
                     self._embed_frames_eager(eng, sin["fr"], sin["msgs"], sout, step=step, video_mode=video_mode, antialias=antialias,
                                              lowres=lowres, preds_w=spw, fwd_order=fwd_order, tail_span=tail_span)
                 torch.cuda.synchronize()
+                if eng.arith_net["E"] != key[-1]:      # the verification pass switched the embedder to 3 x bf16: capture under the new key
+                    return self._embed_frames(eng, fr, msgs_i32, out, step=step, video_mode=video_mode, antialias=antialias, lowres=lowres,
+                                              preds_w=preds_w, fwd_order=fwd_order, tail_span=tail_span)
                 g = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(g):
                     self._embed_frames_eager(eng, sin["fr"], sin["msgs"], sout, step=step, video_mode=video_mode, antialias=antialias,
@@ -392,6 +397,7 @@ class Wam(nn.Module):
             ent["in"]["fr"].copy_(fr)
             ent["in"]["msgs"].copy_(msgs_i32)
             ent["g"].replay()
+            eng.note_guard()
             out.copy_(ent["out"])
             if preds_w is not None:
                 preds_w.copy_(ent["pw"])
@@ -437,19 +443,28 @@ class Wam(nn.Module):
         else:
             src = imgs
             out = _result_buffer(imgs.shape, imgs.dtype if imgs.dtype == torch.uint8 else torch.float32, imgs.device) if want_out else None
-        for a in range(0, imgs.shape[0], span):
-            b = min(imgs.shape[0], a + span)
+        for attempt in range(2):
+            for a in range(0, imgs.shape[0], span):
+                b = min(imgs.shape[0], a + span)
+                if on_dev:
+                    fn(src[a:b], out[a:b] if want_out else None, a, b)
+                else:
+                    ch = src[a:b].to(eng.dev)
+                    ch = ch.contiguous() if ch.dtype == torch.uint8 else N.f32c(ch)
+                    oc = torch.empty_like(ch) if want_out else None
+                    fn(ch, oc, a, b)
+                    if want_out:
+                        out[a:b].copy_(oc, non_blocking=True)
             if on_dev:
-                fn(src[a:b], out[a:b] if want_out else None, a, b)
-            else:
-                ch = src[a:b].to(eng.dev)
-                ch = ch.contiguous() if ch.dtype == torch.uint8 else N.f32c(ch)
-                oc = torch.empty_like(ch) if want_out else None
-                fn(ch, oc, a, b)
-                if want_out:
-                    out[a:b].copy_(oc, non_blocking=True)
-        if not on_dev:                 # the copies into (pinned) host memory are asynchronous: the results are valid from here on
+                break
+            # the copies into (pinned) host memory are asynchronous: the results are valid from here on.  This entry point synchronises
+            # anyway, so the range guard of every pass of the call is read here: a data-dependent overflow repeats the call on the exact
+            # split instead of handing non-finite frames to the caller
             torch.cuda.current_stream(eng.dev).synchronize()
+            if attempt or not eng.guard_tripped_after_sync():
+                break
+            if extra is not None:
+                extra()               # (the caller's per-call accumulators, e.g. the list of logits, start over)
         return out
 
     @torch.no_grad()
@@ -656,7 +671,7 @@ class Videoseal(Wam):
         preds = []
         with torch.cuda.device(eng.dev):
             self._run_chunks(eng, imgs, max(1, int(self.chunk_size)),
-                             lambda fr, oc, a, b: preds.append(self._detect_frames(eng, fr, S, aa)), want_out=False)
+                             lambda fr, oc, a, b: preds.append(self._detect_frames(eng, fr, S, aa)), want_out=False, extra=preds.clear)
             return torch.cat(preds, dim=0).to(imgs.device)
 
     @torch.no_grad()

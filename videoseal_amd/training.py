@@ -465,6 +465,10 @@ class DetectorStep:
              accumulate: bool = True):
         model = self.model
         eng = model._engine()
+        eng.begin_training_pass()
+        # this pass rewrites the 'tr.*' operands an earlier model(...) graph of the detector would read in its backward: make that backward
+        # raise (autograd._check_generation) instead of silently using overwritten operands
+        model._train_gen["detector"] = model._train_gen.get("detector", 0) + 1
         with torch.cuda.device(eng.dev):
             x = N.f32c(imgs_aug.to(eng.dev))
             if tuple(x.shape[-2:]) != (model.img_size, model.img_size):
