@@ -168,6 +168,7 @@ def parse_args(argv=None):
     ap.add_argument("--frames", type=int, default=1024, help="stream mode: total frames of the clip (sharded over the ranks)")
     ap.add_argument("--group", type=int, default=None, help="stream mode: 16-frame chunks whose key frames share one U-Net pass (default: enough "
                     "for 32 key frames = 8 chunks; 1 = the literal per-chunk calls of round 3)")
+    ap.add_argument("--det-batch", type=int, default=None, help="stream mode: frames per extractor pass (default 32)")
     ap.add_argument("--graphs", action="store_true", help="replay the per-chunk launch sequences from hipGraphs")
     ap.add_argument("--batch", type=int, default=None, help="frames per GPU and step (default 32; 16 in chain mode)")
     ap.add_argument("--size", type=int, default=768)
@@ -246,7 +247,7 @@ def _run(args, world, rank, dev, dist_on, n_ranks_seen):
 
     def step_stream_overlapped():     # videoseal_amd/streaming.py: detect(chunk i) on a second HIP stream while embed(chunk i+1) is issued
         from videoseal_amd.streaming import embed_detect_chunks
-        preds = embed_detect_chunks(model, frames_u8 if args.u8 else frames, msgs, chunk=16, lowres_attenuation=True, overlap=True, group=args.group)
+        preds = embed_detect_chunks(model, frames_u8 if args.u8 else frames, msgs, chunk=16, lowres_attenuation=True, overlap=True, group=args.group, det_batch=args.det_batch)
         if dist_on:
             preds = gather_frame_logits(preds, args.frames, align=16)
         return preds
@@ -351,6 +352,7 @@ def _run(args, world, rank, dev, dist_on, n_ranks_seen):
     t0 = time.perf_counter()
     for _ in range(args.steps):
         preds = step()
+    host_issue = time.perf_counter() - t0            # how long the host needed to ISSUE the steps (the GPU runs behind it)
     barrier()
     elapsed = time.perf_counter() - t0
     if dist_on:
@@ -468,6 +470,7 @@ def _run(args, world, rank, dev, dist_on, n_ranks_seen):
         line = {
             "metric": metric, "value": round(fps, 2), "unit": "frames/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 3),
+            "host_issue_ms_per_step": round(1e3 * host_issue / args.steps, 3),
             "higher_is_better": True, "scaling": "strong" if stream else "weak", "vs_baseline": None,
             "dtype": f"f32 ({arith_name(eng)}, fp32 accumulate)" if eng.use_split else "f32", "data": "synthetic",
             "config": {"workload": f"{args.card} {cfg.nbits}-bit, {B} frames {S}x{S} per GPU, {args.mode} mode "
@@ -572,7 +575,7 @@ def main():
             if r is None:
                 return None
             roof = r.get("roofline") or {}
-            return {"value": r["value"], "unit": r["unit"], "ms_per_step": r["ms_per_step"], "scaling": r["scaling"], "n_gpus": r["n_gpus"],
+            return {"value": r["value"], "unit": r["unit"], "ms_per_step": r["ms_per_step"], "host_issue_ms_per_step": r.get("host_issue_ms_per_step"), "scaling": r["scaling"], "n_gpus": r["n_gpus"],
                     "allgather_ms": r.get("allgather_ms"), "arith_used": r.get("arith_used"),
                     "workload": r["config"]["workload"], "model_tflops_per_s": r["model_tflops_per_s"],
                     "roofline": {k: roof.get(k) for k in ("kernel", "achieved", "peak", "unit", "frac", "avg_launch_ms", "e2e_frac") if k in roof},

@@ -265,3 +265,87 @@ def test_ddp_two_ranks_on_one_gpu_match_the_single_process_step(tmp_path):
         a, b, r = res[0]["grads"][k], res[1]["grads"][k], g_ref[k]
         assert torch.equal(a, b), k                                             # both ranks hold the averaged gradient
         assert (a - r).abs().max() <= 1e-4 * float(r.abs().max()) + 1e-10, (k, float((a - r).abs().max()), float(r.abs().max()))
+
+
+# ------------------------------------------------------------------------------------------------ two DEVICES over RCCL (needs a >= 2-GPU box)
+two_gpus = pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs (RCCL refuses two ranks on one device)")
+
+
+def _run_two_ranks(tmp_path, job):
+    env = dict(os.environ, WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), HSA_ENABLE_IPC_MODE_LEGACY="0",
+               VS_DDP_BACKEND="nccl", VS_DDP_JOB=job)
+    outs = [str(tmp_path / f"{job}_rank{r}.pt") for r in range(2)]
+    procs = [subprocess.Popen([sys.executable, "-m", "tests._ddp_worker", outs[r]], cwd=ROOT, env=dict(env, RANK=str(r), LOCAL_RANK=str(r)),
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT) for r in range(2)]
+    logs = []
+    for p in procs:
+        try:
+            logs.append(p.communicate(timeout=900)[0].decode(errors="replace")[-3000:])
+        except subprocess.TimeoutExpired:
+            p.kill()
+            logs.append("timeout")
+    assert all(p.returncode == 0 for p in procs), logs
+    res = [torch.load(o) for o in outs]
+    assert not any("unsupported" in r for r in res), res
+    return res
+
+
+@two_gpus
+def test_sharded_extraction_on_two_devices_over_rccl(tmp_path):
+    """videoseal_amd/dist.py for real: rank r embeds and detects its contiguous 16-aligned frame range on cuda:r, ONE RCCL all-gather of the
+    logits, every aggregation of extract_message -- equal to the single-process call on the whole clip (frames are independent)"""
+    res = _run_two_ranks(tmp_path, "extract")
+    spec = tiny_spec()
+    model = make_model(spec, make_state_dict(spec, seed=3))
+    model.chunk_size, model.step_size = 4, 2
+    frames = synthetic_frames(40, 80, 96, seed=70).cuda()
+    msgs = synthetic_msgs(1, spec.nbits, seed=70)
+    w = model.embed(frames, msgs, is_video=True)["imgs_w"]
+    logits = model.detect(w, is_video=True)["preds"].cpu()
+    assert [r["range"] for r in res] == [(0, 32), (32, 40)] and [r["device"] for r in res] == [0, 1]
+    assert torch.equal(torch.cat([r["imgs_w"] for r in res]), w.cpu())
+    for r in res:           # shard boundaries are chunk boundaries (16 | 8 frames per embed chunk, 4 per detect batch): bit-identical to the whole clip
+        assert torch.equal(r["logits"], logits)
+        for agg, bits in r["bits"].items():
+            assert torch.equal(bits, model.extract_message(w, aggregation=agg).cpu()), agg
+
+
+@two_gpus
+def test_ddp_on_two_devices_over_rccl_matches_the_single_process_step(tmp_path):
+    """train.py:438-446 on two devices: SyncBatchNorm conversion + DistributedDataParallel over RCCL, half of the batch per rank -> both ranks
+    end with the single-process gradients of the whole batch and its BatchNorm running statistics"""
+    from tests import _ddp_worker as W
+    model, imgs, msgs = W.batch_and_model()
+    loss_ref, g_ref = W.step(model, model, imgs, msgs)
+    bn_ref = torch.cat([b.detach().double().flatten().cpu() for k, b in model.named_buffers() if "running" in k])
+    res = _run_two_ranks(tmp_path, "ddp")
+    assert (res[0]["bn"] - res[1]["bn"]).abs().max() == 0
+    assert (res[0]["bn"] - bn_ref).abs().max() <= 1e-5 * bn_ref.abs().max()
+    assert abs(0.5 * (res[0]["loss"] + res[1]["loss"]) - loss_ref) <= 1e-5 * abs(loss_ref)
+    for k in g_ref:
+        a, b, r = res[0]["grads"][k], res[1]["grads"][k], g_ref[k]
+        assert torch.equal(a, b), k
+        assert (a - r).abs().max() <= 1e-4 * float(r.abs().max()) + 1e-10, (k, float((a - r).abs().max()), float(r.abs().max()))
+
+
+@two_gpus
+def test_bench_launches_itself_on_two_gpus():
+    """`python bench.py --gpus 2` without a launcher re-executes under torch.distributed.run and prints ONE line with n_gpus 2"""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "4", "--size", "256",
+                        "--no-cpu-baseline", "--no-extra"], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["n_ranks_seen"] == 2 and line["allgather_ms"] > 0 and line["scaling"] == "weak"
+
+
+@pytest.mark.skipif(torch.cuda.device_count() >= 2, reason="the refusal path of a 1-GPU box")
+def test_bench_refuses_more_gpus_than_the_node_has():
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"], env=env, capture_output=True,
+                       text=True, timeout=300)
+    assert r.returncode == 2
+    err = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert err["n_gpus_requested"] == 2 and err["n_gpus_visible"] == torch.cuda.device_count() and "error" in err

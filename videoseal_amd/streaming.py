@@ -31,10 +31,10 @@ def default_group(chunk: int, step: int) -> int:
 
 def embed_detect_chunks(model, frames: torch.Tensor, msgs: torch.Tensor, chunk: int = 16, lowres_attenuation: bool = True,
                         overlap: bool = True, sink: Optional[Callable[[int, torch.Tensor], None]] = None,
-                        group: Optional[int] = None) -> torch.Tensor:
+                        group: Optional[int] = None, det_batch: Optional[int] = None) -> torch.Tensor:
     """frames [F,3,H,W] fp32 or uint8 [F,H,W,3] on the device -> logits [F, 1+nbits].  `sink(first_frame, imgs_w_chunk)` receives
     every watermarked chunk in clip order (e.g. to hand it to an encoder); it is called on the embed stream's timeline.
-    group: chunks per U-Net pass (None = default_group; 1 = the literal per-chunk calls)."""
+    group: chunks per U-Net pass (None = default_group; 1 = the literal per-chunk calls); det_batch: frames per extractor pass (None = DET_BATCH)."""
     u8 = frames.dtype == torch.uint8
     step = int(model.step_size)
     if group is None:
@@ -54,7 +54,7 @@ def embed_detect_chunks(model, frames: torch.Tensor, msgs: torch.Tensor, chunk: 
         # detect_u8 / detect(is_video=True) walk `w` in model.chunk_size frames; raise it to DET_BATCH for this call so that the extractor
         # sees full batches (frames are independent: the logits of a frame do not depend on the batch it is in, up to the K-split rule)
         old = model.chunk_size
-        model.chunk_size = max(int(old), DET_BATCH) if group > 1 else old
+        model.chunk_size = max(int(old), int(det_batch or DET_BATCH)) if group > 1 else old
         try:
             return (model.detect_u8(w) if u8 else model.detect(w, is_video=True))["preds"]
         finally:
