@@ -289,6 +289,12 @@ int vs_outc_tanh_bwd(const float* delta, const float* ddelta, int64_t rows_per_f
  * synchronously on the first call with new weights and asynchronously afterwards). */
 int vs_check_finite(const float* x, int64_t n, int* flag, void* stream);
 
+/* *bits = max(*bits, bit pattern of max |x[0 .. n)|) (non-negative floats order like their bit patterns; inf / NaN sort above every finite
+ * value).  The calibration pass of the per-layer arithmetic choice (engine.py `_calibrate_extractor`): after the range guard has tripped, the
+ * extractor runs once on the exact 3 x bf16 split recording the largest operand of every dense layer; only the layers whose operand leaves the
+ * f16 range of the 2 x f16 split stay on the exact split (no reference counterpart: the reference computes in fp32 on ATen). */
+int vs_absmax(const float* x, int64_t n, unsigned* bits, void* stream);
+
 /* ---- ConvNeXt-V2 block body pwconv1 -> GELU -> GRN -> pwconv2 + residual with the 4C-wide tensor kept on chip (csrc/convnext_fused.hip;
  * convnext.py:47-56, common.py:158-169), C = 96 / 192 (stages 0 / 1 of the VideoSeal extractor), 2 x f16 arithmetic.  Two launches per block:
  * stats = 1 writes the GRN partial sums [rows / 32][4C] (finished by vs_grn_scale_from_partials), stats = 0 recomputes pwconv1 + GELU, applies

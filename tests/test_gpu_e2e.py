@@ -201,6 +201,38 @@ def test_grn_outlier_channels_match_the_oracle_by_default(monkeypatch):
     assert (preds - ref).abs().max() <= 2e-3 * max(1.0, float(ref.abs().max()))
 
 
+def test_one_outlier_block_keeps_the_rest_of_the_extractor_on_the_fast_split(monkeypatch):
+    """the arithmetic is chosen per LAYER: GRN gamma x 1e3 in ONE block -> the calibration pass (engine._calibrate_extractor, vs_absmax of every
+    block GEMM's operand on the exact split) pins that block's pwconv2 to 3 x bf16 and leaves every other layer on the 2 x f16 split; logits
+    match the oracle; VIDEOSEAL_LAYER_ARITH=0 keeps the whole-network switch"""
+    monkeypatch.delenv("VIDEOSEAL_CONV", raising=False)
+    spec = tiny_spec()
+    sd = make_state_dict(spec, seed=3)
+    key = "detector.convnext.stages.1.0.grn.gamma"
+    big = {k: (v * 1e3 if k == key else v) for k, v in sd.items()}
+    imgs = synthetic_frames(3, 64, 64, seed=9)
+    ref = R.detect(big, spec, imgs)["preds"]
+    m = make_model(spec, big)
+    with pytest.warns(UserWarning, match="keep the exact 3 x bf16 split"):
+        preds = m.detect(imgs.cuda(), is_video=False)["preds"].cpu()
+    eng = m._engine()
+    assert eng.arith_net["X"] == 2 and eng.verified["X"] and set(eng.layer_arith) == {(1, 0, "pw2")}
+    assert eng.calib_absmax[(1, 0, "pw2")] > 65504 / 4 and max(v for k, v in eng.calib_absmax.items() if k != (1, 0, "pw2")) * 16 < 65504 / 4
+    assert torch.isfinite(preds).all()
+    assert (preds - ref).abs().max() <= 2e-3 * max(1.0, float(ref.abs().max()))
+    again = m.detect(imgs.cuda(), is_video=False)["preds"].cpu()           # steady state: same configuration, same values
+    assert torch.equal(again, preds)
+    m.load_state_dict(sd)                                                   # new weights: back to the fast split everywhere
+    ok = m.detect(imgs.cuda(), is_video=False)["preds"].cpu()
+    assert not m._engine().layer_arith and m._engine().arith_net["X"] == 2
+    assert (ok - R.detect(sd, spec, imgs)["preds"]).abs().max() <= 1e-3
+    monkeypatch.setenv("VIDEOSEAL_LAYER_ARITH", "0")
+    m2 = make_model(spec, big)
+    p2 = m2.detect(imgs.cuda(), is_video=False)["preds"].cpu()
+    assert m2._engine().arith_net["X"] == 3 and not m2._engine().layer_arith
+    assert (p2 - ref).abs().max() <= 2e-3 * max(1.0, float(ref.abs().max()))
+
+
 def test_data_dependent_overflow_is_reported_by_the_next_call(monkeypatch):
     """weights verified on ordinary frames, then an input that drives the stem out of the f16 range: the pass itself cannot be repeated without
     a synchronisation per call, so its logits are non-finite -- but the next API call says so and the model has moved to 3 x bf16"""

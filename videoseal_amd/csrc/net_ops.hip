@@ -784,6 +784,22 @@ __global__ __launch_bounds__(256) void check_finite_kernel(const float* __restri
   if (__any(bad) && (threadIdx.x & 63) == 0) atomicOr(flag, 1);
 }
 
+// *bits = max(*bits, bit pattern of max |x|): non-negative floats order like their bit patterns (inf / NaN sort above every finite value).
+// Calibration of the per-layer arithmetic choice (engine.py): which dense layers see operands beyond the f16 range of the 2 x f16 split.
+__global__ __launch_bounds__(256) void absmax_kernel(const float* __restrict__ x, int64_t n, unsigned* __restrict__ bits) {
+  unsigned m = 0;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const unsigned u = __float_as_uint(x[i]) & 0x7fffffffu;
+    m = u > m ? u : m;
+  }
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) {
+    const unsigned v = (unsigned)__shfl_xor((int)m, o);
+    m = v > m ? v : m;
+  }
+  if ((threadIdx.x & 63) == 0 && m) atomicMax(bits, m);
+}
+
 }  // namespace
 
 extern "C" int vs_layernorm_act(const float* x, int64_t rows, int C, int64_t ld, const float* w, const float* b, float eps,
@@ -1046,5 +1062,13 @@ extern "C" int vs_check_finite(const float* x, int64_t n, int* flag, void* strea
   int64_t g = cdiv64(n, 256 * 8);
   g = g > 1024 ? 1024 : (g < 1 ? 1 : g);
   hipLaunchKernelGGL(check_finite_kernel, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, x, n, flag);
+  return vs_launch_status();
+}
+
+extern "C" int vs_absmax(const float* x, int64_t n, unsigned* bits, void* stream) {
+  VS_REQUIRE(x && bits && n > 0);
+  int64_t g = cdiv64(n, 256 * 8);
+  g = g > 2048 ? 2048 : (g < 1 ? 1 : g);
+  hipLaunchKernelGGL(absmax_kernel, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, x, n, bits);
   return vs_launch_status();
 }

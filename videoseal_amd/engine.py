@@ -237,6 +237,7 @@ class HipEngine:
         self.dev = device
         self.lib = N.lib()
         self._ws: Dict[tuple, torch.Tensor] = {}
+        self._lane = ""                           # suffix of the workspace tags of the lane being issued (see lane())
         self._ws_used: Dict[tuple, int] = {}      # 'tr.*' keys: the training pass that last touched them (begin_training_pass)
         self._tr_pass = 0
         self.kernel_timers = None        # list of (name, start_event, end_event, flops) when bench.py enables it
@@ -258,6 +259,14 @@ class HipEngine:
         self.auto_arith = conv_mode in ("auto", "split")
         self.arith_net = {"E": self.arith, "X": self.arith}
         self.verified = {"E": False, "X": False}
+        # per-LAYER arithmetic of the ConvNeXt extractor: when the guard trips, one calibration pass on the exact split records the largest
+        # operand of every dense layer (vs_absmax); only the layers whose operand leaves the f16 range (with a 4 x margin for other data) stay
+        # on 3 x bf16, the rest of the network keeps the fast split -- one GRN outlier channel does not halve the whole extractor.
+        # key (stage, block, 'pw1' | 'pw2') -> 3.  VIDEOSEAL_LAYER_ARITH=0: whole-network switch only.
+        self.per_layer_arith = os.environ.get("VIDEOSEAL_LAYER_ARITH", "1") != "0"
+        self.layer_arith: Dict[tuple, int] = {}
+        self._calib: Optional[Dict[tuple, int]] = None        # during the calibration pass: key -> slot of _calib_bits
+        self._calib_bits: Optional[torch.Tensor] = None
         self._nf_flag = torch.zeros(2, dtype=torch.int32, device=device)
         self._nf_host = torch.zeros(2, dtype=torch.int32).pin_memory() if device.type == "cuda" else None
         self._nf_event = None
@@ -329,6 +338,8 @@ class HipEngine:
                     self.arith_net[net], self.verified[net] = 2, False
                     self._nf_flag[0 if net == "E" else 1] = 0       # a flag raised by the OLD weights must not downgrade the new ones
                     self._nf_event = None
+                if net == "X":
+                    self.layer_arith.clear()
 
     # ------------------------------------------------------------------ packing
     def _bn_fold(self, g, p):
@@ -451,7 +462,7 @@ class HipEngine:
     # ------------------------------------------------------------------ workspace
     def buf(self, tag: str, numel: int, zero: bool = False) -> torch.Tensor:
         """named persistent workspace: stable addresses across calls of one shape (hipGraph-capturable)"""
-        key = (tag, numel)
+        key = (tag + self._lane, numel)
         t = self._ws.get(key)
         if t is None:
             t = torch.zeros(numel, device=self.dev, dtype=torch.float32) if zero else torch.empty(numel, device=self.dev, dtype=torch.float32)
@@ -459,6 +470,21 @@ class HipEngine:
         if tag.startswith("tr."):
             self._ws_used[key] = self._tr_pass
         return t
+
+    def lane(self, name: str):
+        """context manager: the launch sequences issued inside use their own set of named workspace buffers ('<tag>@<name>'), so that two
+        passes of one network can be in flight on two HIP streams at once (frames are independent: the extractor on two halves of a batch,
+        streaming.py).  Weights are shared (read-only); K-split workspaces are per stream already."""
+        eng = self
+
+        class _Lane:
+            def __enter__(self_):
+                self_.old = eng._lane
+                eng._lane = "@" + name if name else ""
+
+            def __exit__(self_, *exc):
+                eng._lane = self_.old
+        return _Lane()
 
     def begin_training_pass(self) -> None:
         """Called at the start of every training forward (EmbedTrainFn / DetectTrainFn / DetectorStep.step).  The training path's buffers
@@ -1017,12 +1043,44 @@ class HipEngine:
     # ------------------------------------------------------------------ extractor
     def extractor_forward(self, x: Act) -> torch.Tensor:
         """x: NHWC(ld 4) RGB already mapped to [-1,1]. Returns logits [B][1+nbits]."""
-        for _ in range(2):
+        for attempt in range(3):
             self.arith = self.arith_net["X"]
             logits = self.vit_extractor_forward(x) if self.cfg.extractor == "sam" else self._extractor_forward(x)
             if self._guard("X", logits):
                 break
+            # the guard tripped on new weights and switched the network to 3 x bf16
+            if self.layer_arith:                 # ... in the mixed configuration: it was calibrated on other data -- whole network exact
+                self.layer_arith.clear()
+            elif attempt == 0 and self.per_layer_arith and self.cfg.extractor != "sam":
+                self._calibrate_extractor(x)     # may put the network back on the fast split with the overflowing layers pinned to 3 x bf16
         return logits
+
+    def _note_absmax(self, key: tuple, t: torch.Tensor, numel: int) -> None:
+        if self._calib is None:
+            return
+        slot = self._calib.setdefault(key, len(self._calib))
+        N.check(self.lib.vs_absmax(N.ptr(t), numel, self._calib_bits.data_ptr() + 4 * slot, N.stream()), "vs_absmax")
+
+    def _calibrate_extractor(self, x: Act) -> None:
+        """one pass of the ConvNeXt extractor on the exact split that records max |operand| of every block GEMM, then the per-layer choice"""
+        self._calib, self._calib_bits = {}, torch.zeros(4096, dtype=torch.int32, device=self.dev)
+        try:
+            self.arith = 3
+            self._extractor_forward(x)
+            bits = self._calib_bits.cpu()        # (one synchronisation per set of weights, like the guard's first read)
+            keys = dict(self._calib)
+        finally:
+            self._calib = self._calib_bits = None
+        amax = {k: float(bits[slot:slot + 1].view(torch.float32)) for k, slot in keys.items()}
+        limit = 65504.0 / 4.0                    # 4 x head-room: the calibration saw one batch only
+        over = {k for k, v in amax.items() if not (v * (A_MUL_GRN if k[-1] == "pw2" else A_MUL) < limit)}
+        self.calib_absmax = amax
+        if over and len(over) < len(amax):
+            self.layer_arith = {k: 3 for k in over}
+            self.arith_net["X"], self.verified["X"] = 2, False       # verified by the next pass of extractor_forward's loop
+            import warnings
+            warnings.warn(f"extractor: {len(over)} of {len(amax)} block GEMMs keep the exact 3 x bf16 split (operands beyond the f16 range of the "
+                          f"2 x f16 split: {sorted(over)[:6]}{' ...' if len(over) > 6 else ''}); the other layers stay on the fast split")
 
     def _extractor_forward(self, x: Act) -> torch.Tensor:
         if self.X is None:
@@ -1072,8 +1130,14 @@ class HipEngine:
                      and pw1w.CinP == Cc and bool(L.vs_cnx_block_supported(Cc, cur.rows, HW)))
             if fused and tnpl is None:
                 tnpl = self.buf(f"st{sti}.npl", cur.rows * pw1w.CinP).view(torch.int16)
-            for blk in X["stages"][sti]:
-                if fused:          # pwconv1 -> GELU -> GRN -> pwconv2 with h on chip: statistics pass, scale, apply pass (in place on cur)
+            calib = self._calib is not None
+            for bj, blk in enumerate(X["stages"][sti]):
+                # arithmetic of this block's two GEMMs: the network's, unless the calibration pinned the layer to the exact split
+                a1 = 3 if (self.arith == 3 or self.layer_arith.get((sti, bj, "pw1")) == 3) else 2
+                a2 = 3 if (self.arith == 3 or self.layer_arith.get((sti, bj, "pw2")) == 3) else 2
+                mixed = self.arith == 2 and (a1 == 3 or a2 == 3)
+                kwa1, kwa2 = (dict(arith=a1) if mixed else {}), (dict(arith=a2) if mixed else {})
+                if fused and a1 == 2 and a2 == 2:    # pwconv1 -> GELU -> GRN -> pwconv2 with h on chip: statistics pass, scale, apply pass (in place on cur)
                     img, m1, m2 = blk["fuse"]
                     N.check(L.vs_dwconv7_ln_planes(N.ptr(cur.t), B, cur.H, cur.W, Cc, cur.ld, N.ptr(blk["wdw"]), N.ptr(blk["bdw"]), N.ptr(blk["lnw"]),
                                                    N.ptr(blk["lnb"]), 1e-6, A_MUL, pw1w.CinP, N.ptr(tnpl), st), "vs_dwconv7_ln_planes")
@@ -1086,15 +1150,17 @@ class HipEngine:
                     N.check(L.vs_cnx_block(N.ptr(tnpl), N.ptr(img), Cc, cur.rows, HW, 0, am1, am2, N.ptr(scale), hh.ld, N.ptr(blk["pw2"].bias),
                                            N.ptr(cur.t), cur.ld, N.ptr(cur.t), cur.ld, None, st), "vs_cnx_block(apply)")
                     continue
-                if pl1:
+                bpl1, bpl2 = pl1 and a1 == 2, pl2 and a2 == 2
+                if bpl1:
                     N.check(L.vs_dwconv7_ln_planes(N.ptr(cur.t), B, cur.H, cur.W, Cc, cur.ld, N.ptr(blk["wdw"]), N.ptr(blk["bdw"]), N.ptr(blk["lnw"]),
                                                    N.ptr(blk["lnb"]), 1e-6, A_MUL, pw1w.CinP, N.ptr(tnpl), st), "vs_dwconv7_ln_planes")
                 else:
                     N.check(L.vs_dwconv7_ln(N.ptr(cur.t), B, cur.H, cur.W, Cc, cur.ld, N.ptr(blk["wdw"]), N.ptr(blk["bdw"]), N.ptr(blk["lnw"]),
                                             N.ptr(blk["lnb"]), 1e-6, N.ptr(tn.t), tn.ld, st), "vs_dwconv7_ln")
-                kw1 = dict(in_pl=tnpl, tile_hint=ptile) if pl1 else {}
+                    self._note_absmax((sti, bj, "pw1"), tn.t, tn.rows * tn.ld)
+                kw1 = dict(in_pl=tnpl, tile_hint=ptile) if bpl1 else dict(kwa1)
                 if self.prof_extractor and sti == 2:      # bench.py --detect-only: the dominant GEMM of an extractor-only workload
-                    kw1["prof"] = (f"{'gemm_pl_kernel' if pl1 else 'gemm1x1_pc_kernel / conv_gemm_kernel'}: ConvNeXt stage-2 pwconv1 "
+                    kw1["prof"] = (f"{'gemm_pl_kernel' if bpl1 else 'gemm1x1_pc_kernel / conv_gemm_kernel'}: ConvNeXt stage-2 pwconv1 "
                                    f"{Cc}->{4 * Cc} @{cur.H}x{cur.W}")
                     kw1["flops"] = 2.0 * cur.rows * Cc * 4 * Cc      # algorithmic (unpadded) FLOPs
                 if HW % 32 == 0:      # ||h||^2 partials come out of pwconv1's epilogue: no second pass over h
@@ -1106,16 +1172,18 @@ class HipEngine:
                     self.conv(tn, blk["pw1"], hh, act=N.ACT_GELU, **kw1)
                     N.check(L.vs_grn_scale(N.ptr(hh.t), B, HW, 4 * Cc, hh.ld, N.ptr(blk["gamma"]), N.ptr(part), N.ptr(scale), st),
                             "vs_grn_scale")
-                if pl2:               # GRN apply + operand split in one pass over h, then the planes GEMM (K split by the shape rule)
+                if bpl2:              # GRN apply + operand split in one pass over h, then the planes GEMM (K split by the shape rule)
                     N.check(L.vs_to_planes_affine(N.ptr(hh.t), hh.rows, hh.ld, hh.ld, A_MUL_GRN, N.ptr(scale), hh.ld, N.ptr(blk["beta"]), HW,
                                                   N.ptr(hpl), st), "vs_to_planes_affine")
                     self.conv(hh, blk["pw2"], cur, res=cur, in_pl=hpl, tile_hint=ptile, split_k=sk2, a_mul=A_MUL_GRN)
-                elif HW % 64 == 0 or not self.use_split:
-                    self.conv(hh, blk["pw2"], cur, res=cur, a_scale=scale, a_scale_ld=hh.ld, a_shift=blk["beta"])
+                elif (HW % 64 == 0 or not self.use_split) and not calib:
+                    self.conv(hh, blk["pw2"], cur, res=cur, a_scale=scale, a_scale_ld=hh.ld, a_shift=blk["beta"], **kwa2)
                 else:     # odd feature maps (ChunkySeal: 31 x 31): GRN applied in place + plain GEMM measured faster (109 vs 105 frames/s)
-                          # than the GEMM with the fused transform, whose frame-boundary select costs registers
+                          # than the GEMM with the fused transform, whose frame-boundary select costs registers; the calibration pass takes
+                          # this form everywhere because it measures the operand h * scale + beta itself
                     N.check(L.vs_grn_apply(N.ptr(hh.t), B, HW, 4 * Cc, hh.ld, N.ptr(scale), hh.ld, N.ptr(blk["beta"]), st), "vs_grn_apply")
-                    self.conv(hh, blk["pw2"], cur, res=cur, a_mul=A_MUL_GRN)
+                    self._note_absmax((sti, bj, "pw2"), hh.t, hh.rows * hh.ld)
+                    self.conv(hh, blk["pw2"], cur, res=cur, a_mul=A_MUL_GRN, **kwa2)
         return self._pixel_decoder(cur, X)
 
     def _pixel_decoder(self, cur: Act, X) -> torch.Tensor:

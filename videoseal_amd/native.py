@@ -34,7 +34,7 @@ EXPORTS = [
     "vs_msg_table_grad", "vs_outc_tanh_bwd", "vs_relu_bwd",
     "vs_resize_nchw_bwd", "vs_embed_tail_bwd", "vs_tail_key_reduce", "vs_aug_crop_flip_bwd", "vs_mask_mul", "vs_aug_color_bwd_scratch_floats",
     "vs_aug_color_bwd", "vs_clamp01_bwd", "vs_nhwc_to_nchw_scaled", "vs_percep_partial_doubles", "vs_percep_mse", "vs_percep_mse_grad",
-    "vs_split_block", "vs_check_finite", "vs_cnx_block_supported", "vs_cnx_block_image_bytes", "vs_cnx_block",
+    "vs_split_block", "vs_check_finite", "vs_absmax", "vs_cnx_block_supported", "vs_cnx_block_image_bytes", "vs_cnx_block",
 ]
 
 
@@ -184,6 +184,7 @@ def lib() -> C.CDLL:
         "vs_percep_mse_grad": [P, P, I, I, I, I, F, P, P],
         "vs_split_block": [P, I, I64, I, I, F, P, P, P],
         "vs_check_finite": [P, I64, P, P],
+        "vs_absmax": [P, I64, P, P],
         "vs_cnx_block": [P, P, I, I64, I, I, F, F, P, I64, P, P, I64, P, I64, P, P],
         "vs_cnx_block_supported": [I, I64, I],
     }
