@@ -285,6 +285,24 @@ int vs_relu_bwd(const float* z, int64_t ld, const float* dy, int64_t dy_ld, int6
 int vs_outc_tanh_bwd(const float* delta, const float* ddelta, int64_t rows_per_frame, int B, int C, const float* w, int Cout, int use_tanh,
                      float* dx, int64_t dx_ld, float* dv, void* stream);
 
+/* ---- ResnetBlock of the thin full-resolution U-Net levels in one launch (csrc/resblock_thin.hip; unet.py:24-39 with eval BatchNorm folded
+ * into the convolutions, ReLU):   out = relu(conv3x3_1(t) + b1) + (conv1x1_res(x) + br),   t = relu(conv3x3_0(x) + b0)
+ * x: NHWC fp32 [B][H][W][x_ld], Cin <= 16 channels read per pixel (multiple of 4); 16 mid and 16 output channels (VideoSeal 1.0: `inc`, last `ups`
+ * block); t stays on chip.  Weights as the operand planes of vs_split_block for K = 9 * 16 resp. 16 ([P][16][K] 16-bit patterns, P = 2 f16 terms
+ * of w * w_mul / 3 bf16 terms; channels >= Cin zero); acc_mul* = 1 / (a_mul * w_mul) of each convolution (arith 2).  Replaces two vs_conv_gemm
+ * launches (and the HBM round trip of t) where vs_resblock_thin_supported(x_ld, mid, out) says so. */
+typedef struct vs_resblock_thin_desc {
+  const float* x; int64_t x_ld;
+  int32_t B, H, W, Cin;
+  const void *w0_split, *w1_split, *wr_split;
+  const float *b0, *b1, *br;                /* [16] each or NULL                                                  */
+  int32_t arith, reserved_;                 /* 2 = 2 x f16, 3 = 3 x bf16                                          */
+  float a_mul, acc_mul0, acc_mul1, acc_mulr;
+  float* out; int64_t out_ld;
+} vs_resblock_thin_desc_t;
+int vs_resblock_thin_supported(int cin_ld, int cmid, int cout);
+int vs_resblock_thin(const vs_resblock_thin_desc_t* d, void* stream);
+
 /* *flag |= 1 when x[0 .. n) holds inf / NaN: the always-on guard of the 2 x f16 arithmetic at the network boundary (engine.py reads the flag
  * synchronously on the first call with new weights and asynchronously afterwards). */
 int vs_check_finite(const float* x, int64_t n, int* flag, void* stream);
@@ -454,7 +472,10 @@ typedef struct vs_tail_desc {
   int32_t step, video_mode, total_key;      /* key-frame expansion                         */
   int32_t attenuate, clamp, antialias;
   float scaling_i, scaling_w;
-  int32_t io_u8, reserved_;
+  int32_t io_u8;
+  int32_t variant;          /* 0 = default (row-streaming kernel where it applies, VIDEOSEAL_TAIL overrides); 1 = 43-tap JND on 16-row tiles,   */
+                            /* 2 = separable stencils on 16-row tiles, 3 = 8-row tiles with the pixels parked in LDS, 4 = row-streaming:        */
+                            /* same values from every form (tests/test_gpu_kernels.py), A/B handle for tools/bench_shell.py                      */
 } vs_tail_desc_t;
 int vs_embed_tail(const vs_tail_desc_t* d, void* stream);
 

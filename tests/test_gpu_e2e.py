@@ -209,7 +209,7 @@ def test_one_outlier_block_keeps_the_rest_of_the_extractor_on_the_fast_split(mon
     spec = tiny_spec()
     sd = make_state_dict(spec, seed=3)
     key = "detector.convnext.stages.1.0.grn.gamma"
-    big = {k: (v * 1e3 if k == key else v) for k, v in sd.items()}
+    big = {k: (v * 1e5 if k == key else v) for k, v in sd.items()}           # (x 1e3 in this one block stays inside the f16 range: no switch at all)
     imgs = synthetic_frames(3, 64, 64, seed=9)
     ref = R.detect(big, spec, imgs)["preds"]
     m = make_model(spec, big)
@@ -217,7 +217,7 @@ def test_one_outlier_block_keeps_the_rest_of_the_extractor_on_the_fast_split(mon
         preds = m.detect(imgs.cuda(), is_video=False)["preds"].cpu()
     eng = m._engine()
     assert eng.arith_net["X"] == 2 and eng.verified["X"] and set(eng.layer_arith) == {(1, 0, "pw2")}
-    assert eng.calib_absmax[(1, 0, "pw2")] > 65504 / 4 and max(v for k, v in eng.calib_absmax.items() if k != (1, 0, "pw2")) * 16 < 65504 / 4
+    assert eng.calib_absmax[(1, 0, "pw2")] > 65504 and len(eng.calib_absmax) == 2 * sum(spec.depths)
     assert torch.isfinite(preds).all()
     assert (preds - ref).abs().max() <= 2e-3 * max(1.0, float(ref.abs().max()))
     again = m.detect(imgs.cuda(), is_video=False)["preds"].cpu()           # steady state: same configuration, same values

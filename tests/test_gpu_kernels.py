@@ -191,6 +191,8 @@ class Eng(HipEngine):
         self.time_all_convs = False
         self._tile_cache = {}
         self.msg_table_conv = True
+        self._ws_used = {}
+        self.layer_arith = {}
 
 
 @pytest.fixture(scope="module", params=["split", "h2", "f32"])
@@ -861,3 +863,95 @@ def test_pack_conv_on_the_device(co, ci, k, in_ld):
     refb, cpb = pack_conv(wb, out_ld)
     gotb, cpb2 = pack_conv_bwd(w.to(DEV), out_ld)
     assert cpb == cpb2 and torch.equal(gotb.cpu(), refb)
+
+
+@pytest.mark.parametrize("case", ["full_jnd", "full_jnd_fwd_order_preds", "lowres_hmap", "no_attenuation_rgb_delta", "interpolate_mode", "white_noise_at_the_jump"])
+def test_embed_tail_forms_are_bit_identical(case):
+    """vs_embed_tail's kernels: separable stencils on 16-row tiles (variant 2, round 3's default) and the row-streaming strip kernel (4 = default:
+    frame fetched once, luminance ring, running stencil sums) return the same bits -- same expressions, same summation order; the 43-tap form
+    (1) agrees to rounding
+    (jnd.py:63-108, wam.py:183-197, videoseal.py:303-344).  Ragged sizes (W not a multiple of 256, H not a multiple of 4), strips of several
+    heights, every key-frame mode, Cd = 1 / 3, the training forward's order of operations, frames that sit on the la = 127 jump."""
+    import os
+    from videoseal_amd.native import TailDesc
+    L = N.lib()
+    g = torch.Generator(device="cuda").manual_seed(11)
+    F_, H, W, S = 6, 333, 541, 96
+    lo = torch.rand(F_, 3, H // 16 + 1, W // 16 + 1, device="cuda", generator=g)
+    x = (0.8 * torch.nn.functional.interpolate(lo, size=(H, W), mode="bilinear") + 0.2 * torch.rand(F_, 3, H, W, device="cuda", generator=g)).clamp_(0, 1).contiguous()
+    if case == "white_noise_at_the_jump":
+        x = (0.498 + 0.01 * torch.randn(F_, 3, H, W, device="cuda", generator=g)).clamp_(0, 1).contiguous()      # 255 x ~ 127: the branch of jnd.py:66-68
+    Cd = 3 if case == "no_attenuation_rgb_delta" else 1
+    step = 2 if case in ("interpolate_mode", "lowres_hmap") else 1
+    nkey = (F_ + step - 1) // step
+    delta = (0.3 * torch.randn(nkey, Cd, S, S, device="cuda", generator=g)).contiguous()
+    hm = torch.rand(F_, S, S, device="cuda", generator=g).contiguous()
+    taps = (C.c_float * 43)(*([1, 1, 1, 1, 1, 1, 2, 2, 2, 1, 1, 2, 0, 2, 1, 1, 2, 2, 2, 1, 1, 1, 1, 1, 1] + [-1, 0, 1, -2, 0, 2, -1, 0, 1] + [1, 2, 1, 0, 0, 0, -1, -2, -1]))
+    att = {"full_jnd": 1, "full_jnd_fwd_order_preds": 2, "lowres_hmap": 1, "no_attenuation_rgb_delta": 0, "interpolate_mode": 1, "white_noise_at_the_jump": 1}[case]
+    low = case == "lowres_hmap"
+    want_pw = case == "full_jnd_fwd_order_preds"
+    vm = 2 if case == "interpolate_mode" else (1 if case == "lowres_hmap" else 0)
+
+    def run(variant, strip=None):
+        out = torch.full_like(x, -7.0)
+        pw = torch.full((F_, Cd, H, W), -7.0, device="cuda") if want_pw else None
+        d = TailDesc()
+        d.imgs, d.out, d.preds_w = N.ptr(x), N.ptr(out), N.ptr(pw)
+        d.delta, d.hmap_lowres, d.taps43 = N.ptr(delta), (N.ptr(hm) if low else None), C.cast(taps, C.c_void_p)
+        d.F, d.H, d.W, d.S_h, d.S_w, d.Cd = F_, H, W, S, S, Cd
+        d.step, d.video_mode, d.total_key = step, vm, nkey
+        d.attenuate, d.clamp, d.antialias = att, 1, 1
+        d.scaling_i, d.scaling_w, d.io_u8, d.variant = 1.0, 0.2, 0, variant
+        if strip:
+            os.environ["VS_TAIL_STRIP_TEST"] = str(strip)
+        try:
+            N.check(L.vs_embed_tail(C.byref(d), N.stream()), "vs_embed_tail")
+            torch.cuda.synchronize()
+        finally:
+            os.environ.pop("VS_TAIL_STRIP_TEST", None)
+        return out, pw
+    ref, ref_pw = run(2)
+    assert float(ref.min()) >= 0.0                      # every pixel written
+    v1, _ = run(1)                                      # the 43-tap order is a different association of the same stencils: rounding-level difference
+    assert (v1 - ref).abs().max().item() <= (1e-6 if case != "white_noise_at_the_jump" else 1e-3)
+    for variant, strip in ((4, None), (4, 4), (4, 20), (4, 52), (4, 96), (4, 512)):
+        got, got_pw = run(variant, strip)
+        assert torch.equal(got, ref), (case, variant, strip, float((got - ref).abs().max()))
+        if want_pw:
+            assert torch.equal(got_pw, ref_pw), (case, variant, strip)
+
+
+@pytest.mark.parametrize("arith", [2, 3])
+@pytest.mark.parametrize("shape", [(3, 1, 40, 56), (2, 16, 37, 29), (2, 12, 8, 16), (1, 16, 64, 64)])
+def test_resblock_thin_fused_kernel(arith, shape):
+    """vs_resblock_thin (unet.py:24-39 with eval BatchNorm folded; `inc` and the last `ups` block of VideoSeal 1.0): the whole ResnetBlock in one
+    launch, t on chip, v_mfma_f32_16x16x32 with two taps per instruction -- against torch fp32 on the CPU and against the two-launch path of the
+    same engine (same arithmetic, different K order: fp32-rounding agreement, 2e-5 of the output range like every conv test here).  Ragged maps
+    (not multiples of the 8 x 16 tile), 1 / 12 / 16 input channels, both operand splits."""
+    B, Cin, H, W = shape
+    e = Eng(arith=arith)
+    g = torch.Generator().manual_seed(31 + Cin)
+    x = torch.randn(B, Cin, H, W, generator=g)
+    w0 = torch.randn(16, Cin, 3, 3, generator=g) / math.sqrt(Cin * 9)
+    b0 = torch.randn(16, generator=g) * 0.3
+    w1 = torch.randn(16, 16, 3, 3, generator=g) / math.sqrt(16 * 9)
+    b1 = torch.randn(16, generator=g) * 0.3
+    wr = torch.randn(16, Cin, 1, 1, generator=g) / math.sqrt(Cin)
+    br = torch.randn(16, generator=g) * 0.3
+    ref = F.relu(F.conv2d(F.relu(F.conv2d(x, w0, b0, padding=1)), w1, b1, padding=1)) + F.conv2d(x, wr, br)
+    xa = to_nhwc(x)
+
+    def packed():
+        wt0, cp0 = pack_conv(w0.to(DEV), xa.ld)
+        wt1, cp1 = pack_conv(w1.to(DEV), 16)
+        wtr, cpr = pack_conv(wr.to(DEV), xa.ld)
+        return dict(c0=ConvW(wt0, dv(b0), 16, 3, 3, cp0), c1=ConvW(wt1, dv(b1), 16, 3, 3, cp1), res=ConvW(wtr, dv(br), 16, 1, 1, cpr), cout=16)
+    p = packed()
+    assert e._thin_ok(xa, p, None)
+    got = from_nhwc(e.resblock(xa, p, "thin"))
+    torch.cuda.synchronize()
+    assert rel_err(got, ref) < 2e-5
+    e.thin_fused = False
+    two = from_nhwc(e.resblock(xa, packed(), "thin2"))
+    torch.cuda.synchronize()
+    assert rel_err(two, ref) < 2e-5 and rel_err(got, two) < 2e-5

@@ -39,8 +39,9 @@ taps = (C.c_float * 43)(*([1, 1, 1, 1, 1, 1, 2, 2, 2, 1, 1, 2, 0, 2, 1, 1, 2, 2,
 delta = torch.randn(B, 1, S, S, device="cuda") * 0.1
 hm = torch.rand(B, S, S, device="cuda")
 out = torch.empty_like(x); outu = torch.empty_like(xu); pw = torch.empty(B, 1, H, W, device="cuda")
-def tail(u8, att, low, with_pw, aa=1, step=1):
+def tail(u8, att, low, with_pw, aa=1, step=1, variant=0):
     d = TailDesc()
+    d.variant = variant
     src, dst = (xu, outu) if u8 else (x, out)
     d.imgs, d.out, d.preds_w = N.ptr(src), N.ptr(dst), (N.ptr(pw) if with_pw else None)
     d.delta, d.hmap_lowres = N.ptr(delta), (N.ptr(hm) if low else None)
@@ -55,3 +56,9 @@ for name, u8, att, low, wpw in [("fp32 full JND + preds_w", 0, 1, 0, 1), ("fp32 
     ms = timeit(tail(u8, att, low, wpw))
     nbytes = (2 * xu.numel() if u8 else 2 * x.numel() * 4) + (pw.numel() * 4 if wpw else 0)
     print(f"embed_tail {name:24s}: {ms*1e3:7.1f} us  {nbytes/ms/1e6:7.0f} GB/s")
+# the forms of the fp32 tail side by side (vs_tail_desc_t::variant): 1 = 43-tap JND on 16-row tiles, 2 = separable stencils on 16-row tiles,
+# 4 = row-streaming strips (default); VS_TAIL_STRIP=<rows> overrides the strip height of the streaming form
+for name, att, low in [("fp32 full JND", 1, 0), ("fp32 lowres JND", 1, 1), ("fp32 no JND", 0, 0)]:
+    for variant in (1, 2, 4):
+        ms = timeit(tail(0, att, low, 0, variant=variant))
+        print(f"embed_tail {name:18s} variant {variant}: {ms*1e3:7.1f} us  {2 * x.numel() * 4/ms/1e6:7.0f} GB/s")

@@ -1,0 +1,268 @@
+// ResnetBlock of the thin, full-resolution U-Net levels in ONE kernel (unet.py:24-39, eval BatchNorm folded):
+//     out = relu(conv3x3_1(t) + b1) + (conv1x1_res(x) + b_res),     t = relu(conv3x3_0(x) + b0)
+// for <= 16 input channels and 16 mid / output channels at 256^2 (VideoSeal 1.0: `inc` 1 -> 16 -> 16 and the last `ups` block 16 -> 16 -> 16).
+// As two launches these layers are HBM-bound at a third of what the memory delivers: every conv reads a 134 MB map and writes one (32 frames),
+// and `t` makes the round trip for nothing (profiles/r04b_stage_times_image.json: 137 + 168 us per block).  Here `t` never leaves the chip:
+//   * workgroup = 8 x 16 output pixels; the 12 x 20 input patch (two-pixel halo) is split once into operand planes in LDS (double-buffered,
+//     persistent workgroups: the next tile's patch is in flight during this tile's products);
+//   * conv0 is evaluated on the 10 x 18 tile of `t` the second conv needs (one-pixel halo recomputed: 180 instead of 128 pixels), bias + ReLU +
+//     operand split happen on the accumulator registers and the planes of `t` go to LDS -- positions outside the image are the zero padding of
+//     conv1, not conv0 of padded data;
+//   * conv1 and the 1x1 res_conv read `t` / the patch centre from LDS; every lane ends with four consecutive channels of one pixel: 16-byte stores,
+//     a wave writes one contiguous KiB.
+// Matrix instruction: v_mfma_f32_16x16x32 (16 channels x 16 pixels x K = 32): the 16 output channels fill the tile (the 32x32x16 form of
+// conv3x3_small_kernel wastes half of it on N = 16), and K = 32 is TWO taps of 16 channels -- lanes 0-31 read the patch shifted by the first tap,
+// lanes 32-63 by the second, so the nine taps are five instructions per partial product.  Per 128 output pixels and wave: 81 instructions of
+// ~16 cycles against 108 of 32 for the two separate launches.  Same operand splits, scales and partial-product order as every other kernel of the
+// arithmetic (Arith<NP>); the K order differs from the 32x32x16 kernels (tap pairs), so results agree with them to fp32 rounding, not bit for bit.
+#include "conv_common.h"
+
+namespace {
+
+using namespace vsconv;
+
+constexpr int TH = 8, TW = 16;
+constexpr int T_W = TW + 2, T_H = TH + 2, T_PX = T_W * T_H;          // 18 x 10 = 180 pixels of t
+constexpr int X_W = TW + 4, X_H = TH + 4, X_PX = X_W * X_H;          // 20 x 12 = 240 pixels of x
+constexpr int XITEMS = X_PX * 4;                                     // float4 items of the patch (16 channels per pixel)
+constexpr int NXI = (XITEMS + 255) / 256;                            // 4 per thread
+constexpr int G0_PER_WAVE = 3;                                       // conv0: 12 groups of 16 t pixels (192 >= 180) over 4 waves
+constexpr int G1_PER_WAVE = 2;                                       // conv1: 8 output rows of 16 pixels over 4 waves
+
+template <int NP> struct Arith16;
+template <> struct Arith16<3> {
+  static __device__ __forceinline__ f32x4 mfma(const bf16x8& a, const bf16x8& b, const f32x4& c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+  }
+};
+template <> struct Arith16<2> {
+  static __device__ __forceinline__ f32x4 mfma(const bf16x8& a, const bf16x8& b, const f32x4& c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+  }
+};
+
+struct RbArgs {
+  const float* x; int64_t x_sb, x_sy, x_sx; int B, H, W, Cin;
+  const void *w0, *w1, *wr;                 // split planes [NP][16][144], [NP][16][144], [NP][16][16]
+  const float *b0, *b1, *br;
+  float a_mul, acc_mul0, acc_mul1, acc_mulr;
+  float* out; int64_t out_ld;
+};
+
+__device__ __forceinline__ bf16x8 zero_frag() {
+  const u32x4 z = {0u, 0u, 0u, 0u};
+  return __builtin_bit_cast(bf16x8, z);
+}
+
+template <int NP>
+__global__ __launch_bounds__(256, 2) void resblock_thin_kernel(const RbArgs d, const int tiles_x, const int tiles_y, const int ntiles_total,
+                                                               const int tiles_per_wg) {
+  using AR = Arith<NP>;
+  using A16 = Arith16<NP>;
+  constexpr int XP_BYTES = NP * X_PX * ROWB;                         // one patch buffer
+  constexpr int TT_BYTES = NP * T_PX * ROWB;
+  constexpr int NBUF = NP == 2 ? 2 : 1;                              // (three planes: one patch buffer, 59 KB; static LDS stays below 64 KB)
+  __shared__ __attribute__((aligned(16))) unsigned char smem[NBUF * XP_BYTES + TT_BYTES];
+  unsigned char* const Tt = smem + NBUF * XP_BYTES;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int n = lane & 15, kb = lane >> 4;                           // operand row (channel / pixel) and 8-wide K block of this lane
+  const int hi = kb >> 1;                                            // which tap of the pair
+  const int kh = (kb & 1) * 8;                                       // channel offset inside the tap
+
+  // ---- weights: A fragment of step s = row n, k = (tap 2s + hi, channels kh .. kh + 7); tap 9 does not exist -> zero
+  bf16x8 w0f[5][NP], w1f[5][NP], wrf[NP];
+#pragma unroll
+  for (int s = 0; s < 5; ++s) {
+    const int tap = 2 * s + hi;
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+      if (tap < 9) {
+        w0f[s][p] = *reinterpret_cast<const bf16x8*>(static_cast<const char*>(d.w0) + ((int64_t)p * 16 * 144 + n * 144 + tap * 16 + kh) * 2);
+        w1f[s][p] = *reinterpret_cast<const bf16x8*>(static_cast<const char*>(d.w1) + ((int64_t)p * 16 * 144 + n * 144 + tap * 16 + kh) * 2);
+      } else {
+        w0f[s][p] = zero_frag();
+        w1f[s][p] = zero_frag();
+      }
+    }
+  }
+#pragma unroll
+  for (int p = 0; p < NP; ++p)
+    wrf[p] = hi == 0 ? *reinterpret_cast<const bf16x8*>(static_cast<const char*>(d.wr) + ((int64_t)p * 16 * 16 + n * 16 + kh) * 2) : zero_frag();
+  // accumulator layout D[channel][pixel]: lane = pixel n, registers e = channels 4 kb + e
+  float b0v[4], b1v[4], brv[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    b0v[e] = d.b0 ? d.b0[4 * kb + e] : 0.f;
+    b1v[e] = d.b1 ? d.b1[4 * kb + e] : 0.f;
+    brv[e] = d.br ? d.br[4 * kb + e] : 0.f;
+  }
+
+  // ---- patch items of this thread (positions relative to the tile origin are constant)
+  int p_dy[NXI], p_dx[NXI], p_lds[NXI];
+  bool p_have[NXI];
+  const int k4 = (tid & 3) * 4;
+  const bool cok = k4 < d.Cin;
+#pragma unroll
+  for (int i = 0; i < NXI; ++i) {
+    const int item = tid + i * 256;
+    p_have[i] = item < XITEMS;
+    const int prow = p_have[i] ? item >> 2 : 0;
+    p_dy[i] = prow / X_W - 2;
+    p_dx[i] = prow % X_W - 2;
+    p_lds[i] = prow * ROWB + k4 * 2;
+  }
+  // ---- fragment addresses (bytes inside a plane): conv0 group gi of this wave = t pixels 16 (3 wave + gi) + n
+  int a0[G0_PER_WAVE], t_i[G0_PER_WAVE];
+#pragma unroll
+  for (int gi = 0; gi < G0_PER_WAVE; ++gi) {
+    int i = 16 * (wave * G0_PER_WAVE + gi) + n;
+    t_i[gi] = i;
+    i = i < T_PX ? i : T_PX - 1;
+    a0[gi] = ((i / T_W) * X_W + (i % T_W)) * ROWB + kh * 2;
+  }
+  int a1[G1_PER_WAVE], ar[G1_PER_WAVE];
+#pragma unroll
+  for (int gi = 0; gi < G1_PER_WAVE; ++gi) {
+    const int row = wave * G1_PER_WAVE + gi;
+    a1[gi] = (row * T_W + n) * ROWB + kh * 2;
+    ar[gi] = ((row + 2) * X_W + (n + 2)) * ROWB + kh * 2;
+  }
+  const float amul = NP == 2 ? d.a_mul : 1.f;
+  const float am0 = NP == 2 ? d.acc_mul0 : 1.f, am1 = NP == 2 ? d.acc_mul1 : 1.f, amr = NP == 2 ? d.acc_mulr : 1.f;
+
+  f32x4 rp[NXI];
+  auto load_tile = [&](const int fb, const int y0, const int x0) __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < NXI; ++i) {
+      const int iy = y0 + p_dy[i], ix = x0 + p_dx[i];
+      const bool ok = p_have[i] && cok && iy >= 0 && iy < d.H && ix >= 0 && ix < d.W;
+      const int cy = iy < 0 ? 0 : (iy >= d.H ? d.H - 1 : iy), cx = ix < 0 ? 0 : (ix >= d.W ? d.W - 1 : ix);
+      const f32x4 v = *reinterpret_cast<const f32x4*>(d.x + (int64_t)fb * d.x_sb + (int64_t)cy * d.x_sy + (int64_t)cx * d.x_sx + (cok ? k4 : 0));
+      rp[i] = ok ? v : f32x4{0.f, 0.f, 0.f, 0.f};               // unconditional load from a clamped address, zeroed afterwards (zero padding)
+    }
+  };
+  auto store_tile = [&](const int buf) __attribute__((always_inline)) {
+    unsigned char* Ps = smem + buf * XP_BYTES;
+#pragma unroll
+    for (int i = 0; i < NXI; ++i)
+      if (p_have[i]) {
+        u32x2 pl[NP];
+        split4n<NP>(rp[i], amul, pl);
+#pragma unroll
+        for (int p = 0; p < NP; ++p) *reinterpret_cast<u32x2*>(Ps + p * X_PX * ROWB + p_lds[i]) = pl[p];
+      }
+  };
+
+  const int t_begin = blockIdx.x * tiles_per_wg;
+  const int t_end = min(ntiles_total, t_begin + tiles_per_wg);
+  if (t_begin >= t_end) return;
+  int tx = t_begin % tiles_x, ty = (t_begin / tiles_x) % tiles_y, fb = t_begin / (tiles_x * tiles_y);
+  load_tile(fb, ty * TH, tx * TW);
+  store_tile(0);
+  __syncthreads();
+  for (int t = t_begin; t < t_end; ++t) {
+    const int buf = NBUF == 2 ? (t - t_begin) & 1 : 0;
+    int ntx = tx + 1, nty = ty, nfb = fb;
+    if (ntx == tiles_x) { ntx = 0; if (++nty == tiles_y) { nty = 0; ++nfb; } }
+    if (t + 1 < t_end) load_tile(nfb, nty * TH, ntx * TW);      // in flight during this tile's products
+    const unsigned char* Ps = smem + buf * XP_BYTES;
+    const int y0 = ty * TH, x0 = tx * TW;
+
+    // ---- conv0 on the 10 x 18 tile of t
+#pragma unroll
+    for (int gi = 0; gi < G0_PER_WAVE; ++gi) {
+      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int s = 0; s < 5; ++s) {
+        const int tap0 = 2 * s, tap1 = 2 * s + 1 < 9 ? 2 * s + 1 : 8;      // (the ninth tap has no partner: zero weights on the second half)
+        const int off = a0[gi] + (hi ? ((tap1 / 3) * X_W + tap1 % 3) * ROWB : ((tap0 / 3) * X_W + tap0 % 3) * ROWB);
+        bf16x8 xf[NP];
+#pragma unroll
+        for (int p = 0; p < NP; ++p) xf[p] = *reinterpret_cast<const bf16x8*>(Ps + p * X_PX * ROWB + off);
+#pragma unroll
+        for (int q = 0; q < AR::NPROD; ++q) acc = A16::mfma(w0f[s][AR::PB[q]], xf[AR::PA[q]], acc);
+      }
+      // t = relu(acc + b0) inside the image, 0 outside (conv1's zero padding); split into operand planes -> LDS
+      const int i = t_i[gi];
+      if (i < T_PX) {
+        const int gy = y0 - 1 + i / T_W, gx = x0 - 1 + i % T_W;
+        const bool in = gy >= 0 && gy < d.H && gx >= 0 && gx < d.W;
+        f32x4 v;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float a = NP == 2 ? acc[e] * am0 : acc[e];
+          v[e] = in ? vs_relu(a + b0v[e]) : 0.f;
+        }
+        u32x2 pl[NP];
+        split4n<NP>(v, amul, pl);
+#pragma unroll
+        for (int p = 0; p < NP; ++p) *reinterpret_cast<u32x2*>(Tt + p * T_PX * ROWB + i * ROWB + 8 * kb) = pl[p];
+      }
+    }
+    __syncthreads();                                              // t complete
+
+    // ---- conv1 + res_conv on the 8 x 16 output pixels
+#pragma unroll
+    for (int gi = 0; gi < G1_PER_WAVE; ++gi) {
+      f32x4 acc = {0.f, 0.f, 0.f, 0.f}, accr = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int s = 0; s < 5; ++s) {
+        const int tap0 = 2 * s, tap1 = 2 * s + 1 < 9 ? 2 * s + 1 : 8;
+        const int off = a1[gi] + (hi ? ((tap1 / 3) * T_W + tap1 % 3) * ROWB : ((tap0 / 3) * T_W + tap0 % 3) * ROWB);
+        bf16x8 tf[NP];
+#pragma unroll
+        for (int p = 0; p < NP; ++p) tf[p] = *reinterpret_cast<const bf16x8*>(Tt + p * T_PX * ROWB + off);
+#pragma unroll
+        for (int q = 0; q < AR::NPROD; ++q) acc = A16::mfma(w1f[s][AR::PB[q]], tf[AR::PA[q]], acc);
+      }
+      {
+        bf16x8 xf[NP];
+#pragma unroll
+        for (int p = 0; p < NP; ++p) xf[p] = *reinterpret_cast<const bf16x8*>(Ps + p * X_PX * ROWB + ar[gi]);
+#pragma unroll
+        for (int q = 0; q < AR::NPROD; ++q) accr = A16::mfma(wrf[AR::PB[q]], xf[AR::PA[q]], accr);
+      }
+      const int y = y0 + wave * G1_PER_WAVE + gi, x = x0 + n;
+      if (y < d.H && x < d.W) {
+        f32x4 v;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float a = NP == 2 ? acc[e] * am1 : acc[e];
+          const float r = NP == 2 ? accr[e] * amr : accr[e];
+          v[e] = vs_relu(a + b1v[e]) + (r + brv[e]);
+        }
+        *reinterpret_cast<f32x4*>(d.out + (((int64_t)fb * d.H + y) * d.W + x) * d.out_ld + 4 * kb) = v;
+      }
+    }
+    if (NBUF == 1) __syncthreads();               // single patch buffer: every wave must be done reading it
+    if (t + 1 < t_end) store_tile(NBUF == 2 ? buf ^ 1 : 0);   // (two buffers: the other one was last read in tile t - 1, behind that tile's second barrier)
+    __syncthreads();                              // next patch visible; t may be overwritten
+    tx = ntx; ty = nty; fb = nfb;
+  }
+}
+
+}  // namespace
+
+extern "C" int vs_resblock_thin_supported(int cin_ld, int cmid, int cout) { return (cin_ld >= 4 && cin_ld <= 16 && (cin_ld & 3) == 0 && cmid == 16 && cout == 16) ? 1 : 0; }
+
+extern "C" int vs_resblock_thin(const vs_resblock_thin_desc_t* d, void* stream) {
+  VS_REQUIRE(d && d->x && d->out && d->w0_split && d->w1_split && d->wr_split && d->B > 0 && d->H > 0 && d->W > 0);
+  VS_REQUIRE(vs_resblock_thin_supported(d->Cin, 16, 16) && d->x_ld >= d->Cin && (d->x_ld & 3) == 0 && d->out_ld >= 16 && (d->out_ld & 3) == 0);
+  VS_REQUIRE(d->arith == 2 || d->arith == 3);
+  VS_REQUIRE((((uintptr_t)d->x | (uintptr_t)d->out | (uintptr_t)d->w0_split | (uintptr_t)d->w1_split | (uintptr_t)d->wr_split) & 15) == 0);
+  RbArgs a{d->x, (int64_t)d->H * d->W * d->x_ld, (int64_t)d->W * d->x_ld, d->x_ld, d->B, d->H, d->W, d->Cin,
+           d->w0_split, d->w1_split, d->wr_split, d->b0, d->b1, d->br, d->a_mul, d->acc_mul0, d->acc_mul1, d->acc_mulr, d->out, d->out_ld};
+  const int tiles_x = (d->W + TW - 1) / TW, tiles_y = (d->H + TH - 1) / TH;
+  const int64_t nt = (int64_t)d->B * tiles_x * tiles_y;
+  if (nt > 0x7fffffffLL) return VS_ERR_UNSUPPORTED;
+  // persistent workgroups: 2 per CU, each walks a contiguous run of tiles (weights are loaded once per workgroup)
+  const int64_t want = (int64_t)vs_num_cus() * 2;
+  const int per = (int)((nt + want - 1) / want);
+  const int tpw = per < 1 ? 1 : per;
+  const unsigned grid = (unsigned)((nt + tpw - 1) / tpw);
+  if (d->arith == 2) hipLaunchKernelGGL((resblock_thin_kernel<2>), dim3(grid), dim3(256), 0, (hipStream_t)stream, a, tiles_x, tiles_y, (int)nt, tpw);
+  else hipLaunchKernelGGL((resblock_thin_kernel<3>), dim3(grid), dim3(256), 0, (hipStream_t)stream, a, tiles_x, tiles_y, (int)nt, tpw);
+  return vs_launch_status();
+}

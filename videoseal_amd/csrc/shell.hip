@@ -505,6 +505,248 @@ __global__ __launch_bounds__(256) void embed_tail_kernel(TailArgs a, JndTaps k) 
 }
 
 // ---------------------------------------------------------------------------------------------------
+// Row-streaming form of the tail (round 4): workgroup = 256 columns x a STRIP of `strip` rows of one frame, walked top to bottom in groups
+// of SG = 4 rows.  What the 16-row-tile kernel above pays per tile is paid once per strip: the column taps, the key-frame expansion, the
+// pipeline fill; the frame is fetched ONCE (the 16-row form reads every tile for the luminance phase and again for the blend: 2.27 x the
+// frame through HBM, profiles/r03r_hbm_counter_calibration.md) and the halo is 4 rows per strip instead of 4 per 16.
+//   * every thread owns one column; the pixels of the next group (SG rows x 3 planes) are requested before the current group is consumed;
+//   * JND: the luminance of an incoming row goes into a 12-row LDS ring (the only cross-thread traffic: 5 reads per pixel); its horizontal sums
+//     (box5, box3, centre, Sobel pair) are added straight into the accumulators of the five output rows it touches -- eight accumulator sets
+//     per thread, rotated by four per group -- in the SAME order (top row first) and with the same expressions as the separable 16-row form,
+//     so the heat-map is bit-identical to it; an output row is finished two rows behind the incoming one, its pixels wait in registers;
+//   * a pixel whose luminance mask lands within 0.02 of the la = 127 jump is re-evaluated in the 25-tap order from the ring (jnd.py:66-68);
+//   * the watermark's source window (x low-res heat-map, x key-frame weights) is staged per 16 output rows into a double-buffered LDS window
+//     one group ahead of its first use; ONE barrier per group covers ring, window and row taps (three-slot ring / two-slot window: a writer
+//     is always at least one barrier behind the last reader of the slot it overwrites).
+// Needs an up-scale by >= 2 in both directions (<= 3 taps per direction, window <= 136 x 12); everything else takes the tile kernel.
+constexpr int SG = 4, RING = 3 * SG, SUBR = 16;
+
+__device__ __forceinline__ float jnd_at_ring(const float* Lr, const int cslot, const int lxh, const JndTaps& k) {
+  // jnd_at() on the ring: rows cslot - 2 .. cslot + 2 (mod RING), columns lxh - 2 .. lxh + 2; same summation order
+  float la = 0.f;
+#pragma unroll
+  for (int i = 0; i < 5; ++i) {
+    const float* row = Lr + ((cslot + i + RING - 2) % RING) * TLW + lxh;
+#pragma unroll
+    for (int j = 0; j < 5; ++j) la += k.lum[i * 5 + j] * row[j - 2];
+  }
+  la = la / 32.f;
+  la = la <= 127.f ? 17.f * (1.f - sqrtf(la / 127.f + 1e-5f)) : 3.f / 128.f * (la - 127.f) + 3.f;
+  float gx = 0.f, gy = 0.f;
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    const float* row = Lr + ((cslot + i + RING - 1) % RING) * TLW + lxh;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      const float v = row[j - 1];
+      gx += k.sx[i * 3 + j] * v;
+      gy += k.sy[i * 3 + j] * v;
+    }
+  }
+  float cm = sqrtf(gx * gx + gy * gy);
+  cm = 16.f * (cm > 0.f ? __builtin_amdgcn_exp2f(2.4f * __builtin_amdgcn_logf(cm)) : 0.f) / (cm * cm + 676.f);
+  cm = 0.117f * cm;
+  const float h = la + cm - 0.3f * fminf(la, cm);
+  return fmaxf(h, 0.f) / 255.f;
+}
+
+template <bool JND, int OCC>
+__global__ __launch_bounds__(256, OCC) void embed_tail_stream_kernel(TailArgs a, JndTaps k, const int strip) {
+  extern __shared__ float dyn_smem[];
+  float* Lr = dyn_smem;                                        // [RING][TLW] luminance ring (JND only)
+  float* DwB = dyn_smem + (JND ? RING * TLW : 0);              // [2][Cd][DW_H][DW_W] watermark source windows
+  __shared__ int ty_lo[2][SUBR], ty_n[2][SUBR], s_wy0[2];
+  __shared__ float ty_w[2][SUBR][4];
+  __shared__ int s_xhi, s_xlo;
+  const int dwsz = a.Cd * DW_W * DW_H;
+  const int x0 = blockIdx.x * TTW, y0 = blockIdx.y * strip, f = blockIdx.z;
+  const int ys_end = min(a.H, y0 + strip);
+  const int64_t plane = (int64_t)a.H * a.W;
+  const float* img = static_cast<const float*>(a.imgs) + (int64_t)f * 3 * plane;
+  float* outf = static_cast<float*>(a.out) + (int64_t)f * 3 * plane;
+  const int lx = threadIdx.x;
+  const int x = x0 + lx;
+  const bool xin = x < a.W;
+  const int cx = xin ? x : a.W - 1;
+  if (threadIdx.x == 0) s_xhi = 0;
+  __syncthreads();
+  const Taps tx = make_taps(cx, a.Sw, a.W, a.antialias);
+  float wxs[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) wxs[j] = j < tx.n ? tap_w(tx, j) : 0.f;
+  if (xin) atomicMax(&s_xhi, tx.lo + tx.n);
+  if (threadIdx.x == 0) s_xlo = tx.lo;
+  // halo columns of the luminance ring: threads 0 .. 3 carry one extra column each (x0 - 2, x0 - 1, x0 + 256, x0 + 257)
+  const bool hal = JND && lx < 2 * HALO;
+  const int hgx = lx < HALO ? x0 - HALO + lx : x0 + TTW + (lx - HALO);
+  const int hl = lx < HALO ? lx : TTW + lx;
+  const bool hin = hal && hgx >= 0 && hgx < a.W;
+  const int hcx = hgx < 0 ? 0 : (hgx >= a.W ? a.W - 1 : hgx);
+
+  // key-frame expansion (videoseal.py:80-118): value = wa*key[ka] + wb*key[kb]   (same as the tile kernel)
+  int ka = 0, kb = 0;
+  float wa = 1.f, wb = 0.f;
+  if (a.video_mode == VS_VIDEO_REPEAT) {
+    ka = f / a.step;
+  } else if (a.video_mode == VS_VIDEO_ALTERNATE) {
+    ka = f / a.step;
+    wa = (f % a.step) == 0 ? 1.f : 0.f;
+  } else {
+    const int ninter = ((a.F - 1) / a.step) * a.step;
+    if (f < ninter) {
+      ka = f / a.step; kb = ka + 1;
+      const int j = f % a.step;
+      const float lin = a.step > 1 ? (float)j / (float)(a.step - 1) : 0.f;
+      wa = 1.f - lin; wb = 1.f - wa;
+    } else {
+      ka = a.total_key - 1;
+    }
+  }
+  if (ka >= a.total_key) ka = a.total_key - 1;
+  if (kb >= a.total_key) kb = a.total_key - 1;
+  const int splane = a.Sh * a.Sw;
+  const float* dka = a.delta + (int64_t)ka * a.Cd * splane;
+  const float* dkb = a.delta + (int64_t)kb * a.Cd * splane;
+  const float* hml = a.hmap_lowres ? a.hmap_lowres + (int64_t)f * splane : nullptr;
+  __syncthreads();                                             // s_xlo / s_xhi
+  const int wx0 = s_xlo, dww = s_xhi - s_xlo;
+
+  auto stage = [&](const int sub, const int b) __attribute__((always_inline)) {      // source window + row taps of output rows [16 sub, 16 sub + 16)
+    const int sy0 = y0 + SUBR * sub;
+    const int lasty = min(SUBR, ys_end - sy0) - 1;
+    int wy0, n0, wyl, nl;
+    tap_range(sy0, a.Sh, a.H, a.antialias, wy0, n0);
+    tap_range(sy0 + lasty, a.Sh, a.H, a.antialias, wyl, nl);
+    const int dwh = wyl + nl - wy0;
+    if (threadIdx.x < SUBR) {
+      const int yy = sy0 + threadIdx.x;
+      const Taps tp = make_taps(yy < a.H ? yy : a.H - 1, a.Sh, a.H, a.antialias);
+      ty_lo[b][threadIdx.x] = tp.lo;
+      ty_n[b][threadIdx.x] = tp.n;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) ty_w[b][threadIdx.x][j] = j < tp.n ? tap_w(tp, j) : 0.f;
+      if (threadIdx.x == 0) s_wy0[b] = wy0;
+    }
+    float* Dw = DwB + b * dwsz;
+    for (int i = threadIdx.x; i < dwh * dww; i += 256) {
+      const int yy = i / dww, xx = i - yy * dww;
+      const int sp = (wy0 + yy) * a.Sw + wx0 + xx;
+      const float hm = hml ? hml[sp] : 1.f;
+      for (int c = 0; c < a.Cd; ++c) {
+        float v = wa * dka[c * splane + sp];
+        if (wb != 0.f) v += wb * dkb[c * splane + sp];
+        Dw[c * (DW_W * DW_H) + yy * DW_W + xx] = hm * v;
+      }
+    }
+  };
+  const int ymax_need = min(a.H - 1, ys_end + (JND ? HALO - 1 : -1));     // last row any thread of this strip reads
+  float pf[SG][3], pfh[SG][3];
+  auto load_rows = [&](const int r0) __attribute__((always_inline)) {     // rows r0 .. r0 + SG - 1 of the own (and halo) column -> pf / pfh
+#pragma unroll
+    for (int q = 0; q < SG; ++q) {
+      const int gy = r0 + q;
+      const int cy = gy < 0 ? 0 : (gy > ymax_need ? ymax_need : gy);       // always a valid address; rows outside are zeroed when used
+      const int64_t pix = (int64_t)cy * a.W;
+#pragma unroll
+      for (int c = 0; c < 3; ++c) pf[q][c] = img[c * plane + pix + cx];
+      if (hal) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) pfh[q][c] = img[c * plane + pix + hcx];
+      }
+    }
+  };
+
+  const int nrows = ys_end - y0;
+  const int niter = (nrows + SG - 1) / SG;
+  float acc_la[2 * SG], acc_gx[2 * SG], acc_gy[2 * SG];
+#pragma unroll
+  for (int i = 0; i < 2 * SG; ++i) { acc_la[i] = 0.f; acc_gx[i] = 0.f; acc_gy[i] = 0.f; }
+  float hist[2][3] = {{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}};
+  load_rows(y0 - HALO);
+  stage(0, 0);
+  for (int it = -1; it < niter; ++it) {
+    const int r0 = y0 + SG * it + HALO;                       // first incoming row of this group; its output rows are r0 - 2 .. r0 + 1
+    const int slot0 = ((it + 1) % 3) * SG;
+    float cu[SG][3];
+#pragma unroll
+    for (int q = 0; q < SG; ++q)
+#pragma unroll
+      for (int c = 0; c < 3; ++c) cu[q][c] = pf[q][c];
+    if (JND) {
+#pragma unroll
+      for (int q = 0; q < SG; ++q) {
+        const int gy = r0 + q;
+        const bool rok = gy >= 0 && gy < a.H;
+        Lr[(slot0 + q) * TLW + lx + HALO] = (rok && xin) ? 0.299f * (255.f * cu[q][0]) + 0.587f * (255.f * cu[q][1]) + 0.114f * (255.f * cu[q][2]) : 0.f;
+        if (hal) Lr[(slot0 + q) * TLW + hl] = (rok && hin) ? 0.299f * (255.f * pfh[q][0]) + 0.587f * (255.f * pfh[q][1]) + 0.114f * (255.f * pfh[q][2]) : 0.f;
+      }
+    }
+    if (it + 1 < niter) {
+      load_rows(r0 + SG);                                      // in flight while this group is consumed
+      if (((it + 1) & 3) == 0 && it + 1 > 0) stage((it + 1) >> 2, ((it + 1) >> 2) & 1);
+    }
+    __syncthreads();
+    const int sb = (it >> 2) & 1;
+    const float* Dw = DwB + sb * dwsz;
+#pragma unroll
+    for (int j = 0; j < SG; ++j) {
+      if (JND) {
+        const float* row = Lr + (slot0 + j) * TLW + lx + HALO;
+        const float m2 = row[-2], m1 = row[-1], c0 = row[0], p1 = row[1], p2 = row[2];
+        const float h3 = m1 + c0 + p1;
+        const float h5 = h3 + m2 + p2;
+        const float sd = p1 - m1;
+        const float tt = m1 + 2.f * c0 + p1;
+#pragma unroll
+        for (int i = j; i <= j + 4; ++i) {
+          const int dy = 2 + j - i;                            // incoming row - output row
+          if (dy >= -2 && dy <= 2) acc_la[i] += h5;
+          if (dy >= -1 && dy <= 1) acc_la[i] += h3;
+          if (dy == 0) acc_la[i] -= 2.f * c0;
+          if (dy == -1 || dy == 1) acc_gx[i] += sd;
+          if (dy == 0) acc_gx[i] += 2.f * sd;
+          if (dy == -1) acc_gy[i] += tt;
+          if (dy == 1) acc_gy[i] -= tt;
+        }
+      }
+      const int y = r0 - HALO + j;                             // the output row this incoming row completes
+      if (it >= 0 && y < ys_end && xin) {
+        float hm = 1.f;
+        if (JND) {
+          if (fabsf(acc_la[j] * (1.f / 32.f) - 127.f) < 0.02f) hm = jnd_at_ring(Lr, (slot0 + j + RING - HALO) % RING, lx + HALO, k);
+          else hm = jnd_finish(acc_la[j], acc_gx[j], acc_gy[j]);
+        }
+        const int ly = (SG * it + j) & (SUBR - 1);
+        float d[3] = {0.f, 0.f, 0.f};
+        const int basep = (ty_lo[sb][ly] - s_wy0[sb]) * DW_W + (tx.lo - wx0);
+        tail_taps<3, DW_H>(d, Dw, a.Cd, basep, tx.n, ty_n[sb][ly], wxs, ty_w[sb][ly]);
+        const bool fwd_order = JND && a.attenuate == 2;
+        if (JND && !fwd_order)
+          for (int c = 0; c < a.Cd; ++c) d[c] = hm * d[c];
+        const int64_t pix = (int64_t)y * a.W + x;
+        if (a.preds_w)
+          for (int c = 0; c < a.Cd; ++c) a.preds_w[((int64_t)f * a.Cd + c) * plane + pix] = d[c];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+          const float p = j < 2 ? hist[j][c] : cu[j - 2][c];
+          float v = a.scaling_i * p + a.scaling_w * d[a.Cd == 1 ? 0 : c];
+          if (fwd_order) v = p + hm * (v - p);
+          if (a.clamp) v = v <= 0.f ? 0.f : (v >= 1.f ? 1.f : v);      // (NaN passes)
+          outf[c * plane + pix] = v;
+        }
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < SG; ++i) {
+      acc_la[i] = acc_la[i + SG]; acc_gx[i] = acc_gx[i + SG]; acc_gy[i] = acc_gy[i + SG];
+      acc_la[i + SG] = 0.f; acc_gx[i + SG] = 0.f; acc_gy[i + SG] = 0.f;
+    }
+#pragma unroll
+    for (int c = 0; c < 3; ++c) { hist[0][c] = cu[2][c]; hist[1][c] = cu[3][c]; }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------
 // the taps of jnd.py:24-41 (what every released card carries in its state dict)
 bool standard_jnd_taps(const float* t) {
   static const float lum[25] = {1, 1, 1, 1, 1, 1, 2, 2, 2, 1, 1, 2, 0, 2, 1, 1, 2, 2, 2, 1, 1, 1, 1, 1, 1};
@@ -571,8 +813,36 @@ extern "C" int vs_embed_tail(const vs_tail_desc_t* d, void* stream) {
   // form, =keep selects 8-row tiles whose pixels stay in LDS between the luminance and the blend phase -- it fetches 1.5 x the frame instead of
   // 2.27 x but runs at 281 us against 215 us (32 x 768^2): twice the workgroups, and the per-workgroup set-up (taps, watermark window, two
   // barriers before the first output row), not HBM traffic, is what the tail pays for (profiles/r03s_shell_keep_form.log)
-  static const int mode = [] { const char* e = getenv("VIDEOSEAL_TAIL"); return !e ? 1 : (!strcmp(e, "v1") ? 0 : (!strcmp(e, "keep") ? 2 : 1)); }();
-  const bool sep = mode > 0 && d->attenuate && !d->hmap_lowres && d->taps43 && standard_jnd_taps(d->taps43);
+  // VIDEOSEAL_TAIL: stream (default) = the row-streaming kernel where it applies, sep = separable stencils on 16-row tiles (round 3's default),
+  // v1 = 43-tap form, keep = 8-row tiles with the pixels parked in LDS.  d->variant (1 = v1, 2 = sep, 3 = keep, 4 = stream) overrides it per call.
+  static const int env_mode = [] { const char* e = getenv("VIDEOSEAL_TAIL"); return !e ? 3 : (!strcmp(e, "v1") ? 0 : (!strcmp(e, "keep") ? 2 : (!strcmp(e, "sep") ? 1 : 3))); }();
+  const int mode = d->variant >= 1 && d->variant <= 4 ? d->variant - 1 : env_mode;
+  const bool full_jnd = d->attenuate && !d->hmap_lowres;
+  const bool sep = mode > 0 && full_jnd && d->taps43 && standard_jnd_taps(d->taps43);
+  if (mode == 3 && !d->io_u8 && (sep || !full_jnd) && d->W >= 2 * d->S_w && d->H >= 2 * d->S_h) {
+    // strip height: all workgroups of a launch should be resident at once, or come in whole rounds -- 256 CUs x 4 workgroups (four waves per
+    // SIMD at <= 128 VGPRs); a strip costs its rows + the pipeline fill, a launch costs rounds x strip cost.  Measured at 32 x 768^2 (full JND):
+    // 32 rows 180 us, 64 rows (1152 workgroups = 1.5 rounds at three per CU) 203 us, 96 rows (768: one round) 175 us, 128 rows 222 us.
+    // VS_TAIL_STRIP overrides.
+    static const int env_strip = [] { const char* e = getenv("VS_TAIL_STRIP"); return e ? atoi(e) : 0; }();
+    const int64_t cols = (d->W + TTW - 1) / TTW;
+    int strip = 32;
+    int64_t best = -1;
+    for (int cand : {32, 48, 64, 80, 96, 112, 128, 160, 192, 256}) {
+      const int64_t wgs = cols * ((d->H + cand - 1) / cand) * d->F;
+      const int64_t cost = ((wgs + 1023) / 1024) * (cand + 12);
+      if (best < 0 || cost < best || (cost == best && cand <= 96)) { best = cost; strip = cand; }
+    }
+    if (env_strip >= 4) strip = (env_strip + 3) / 4 * 4;
+    if (const char* e = getenv("VS_TAIL_STRIP_TEST")) { const int v = atoi(e); if (v >= 4) strip = (v + 3) / 4 * 4; }     // tests: every strip height, per call
+    dim3 gs((unsigned)cols, (d->H + strip - 1) / strip, d->F);
+    const size_t lds_w = (size_t)2 * d->Cd * DW_W * DW_H * sizeof(float);
+    static const int occ = [] { const char* e = getenv("VS_TAIL_OCC"); return e ? atoi(e) : 4; }();      // A/B: 3 = no register cap (132 VGPRs)
+    if (full_jnd && occ == 3) hipLaunchKernelGGL((embed_tail_stream_kernel<true, 3>), gs, dim3(256), lds_w + RING * TLW * sizeof(float), (hipStream_t)stream, a, k, strip);
+    else if (full_jnd) hipLaunchKernelGGL((embed_tail_stream_kernel<true, 4>), gs, dim3(256), lds_w + RING * TLW * sizeof(float), (hipStream_t)stream, a, k, strip);
+    else hipLaunchKernelGGL((embed_tail_stream_kernel<false, 4>), gs, dim3(256), lds_w, (hipStream_t)stream, a, k, strip);
+    return vs_launch_status();
+  }
   if (d->io_u8) {
     VS_REQUIRE(d->clamp);        // (x * 255).byte() is only defined for x in [0, 1]
     // (uint8 frames keep the 43-tap form: measured 215 us against 248 us for the separable one, profiles/r03i_shell_separable.log)

@@ -231,6 +231,13 @@ class HipEngine:
     arith = 2          # arithmetic of the split back-end (vs_conv_desc_t::arith); set per instance from VIDEOSEAL_CONV
     planes_chain = True
     planes_gemm = True
+    # (class-level defaults: test harnesses build engines without a model, tests/test_gpu_kernels.py::Eng)
+    _lane = ""
+    _tr_pass = 0
+    _calib = None
+    thin_fused = True
+    tail_variant = 0
+    prof_extractor = False
 
     def __init__(self, cfg, sd: Dict[str, torch.Tensor], device: torch.device):
         self.cfg = cfg
@@ -278,6 +285,7 @@ class HipEngine:
         self.planes_chain = os.environ.get("VIDEOSEAL_PLANES", "1") != "0"              # bottleneck chain on pre-split operand planes
         self.planes_gemm = os.environ.get("VIDEOSEAL_PLANES", "1") != "0"               # ConvNeXt 1x1 GEMMs on operand planes
         self.fused_blocks = os.environ.get("VIDEOSEAL_CNX_FUSED", "1") != "0"           # stage 0 / 1 blocks with h kept on chip (convnext_fused.hip)
+        self.thin_fused = os.environ.get("VIDEOSEAL_THIN_FUSED", "1") != "0"              # 16-channel ResnetBlocks in one launch (resblock_thin.hip)
         self.planes_splitk = os.environ.get("VIDEOSEAL_PLANES_SPLITK", "1") != "0"      # planes chain with K slices for 4 - 8 key frames
         # VIDEOSEAL_CHECK_FINITE=1: synchronise after every network pass and raise if the output is not finite -- the 2 x f16 arithmetic
         # turns an activation beyond its f16 range (|a| * a_mul >= 65520) into inf / NaN instead of a silently wrong number
@@ -286,6 +294,7 @@ class HipEngine:
         # per-shape tile selection: every candidate walks K in the same order, so the result is bit-identical whatever
         # tile wins -- only speed changes (measure, don't guess).  VIDEOSEAL_AUTOTUNE=0 keeps the static heuristic.
         self.autotune = os.environ.get("VIDEOSEAL_AUTOTUNE", "1") != "0"
+        self.tail_variant = 0            # vs_tail_desc_t::variant (0 = default: row-streaming kernel where it applies)
         self.shell_timers: Optional[list] = None     # bench.py: (kernel, ev0, ev1, algorithmic bytes) of the HBM-bound shell kernels
         self._tile_cache: Dict[tuple, int] = {}
         # optional on-disk copy of the tile choices (VIDEOSEAL_TILE_CACHE=path.json): a profiled run then has no tuning launches
@@ -800,12 +809,42 @@ class HipEngine:
             assert out_coff == 0
             return self.resblock_train(x, p, tag, out)
         cout = p["cout"]
+        if out_coff == 0 and self._thin_ok(x, p, out):
+            return self.resblock_thin(x, p, tag, out)
         t = self.new_act(tag + ".t", x.B, x.H, x.W, cout)
         self.conv(x, p["c0"], t, pad=1, act=N.ACT_RELU, prof=("bott.conv3x3" if tag.startswith("bott") else None))
         if out is None:
             out = self.new_act(tag + ".o", x.B, x.H, x.W, cout)
         self.conv(t, p["c1"], out, pad=1, act=N.ACT_RELU, in2=x, w2=p["res"], out_coff=out_coff,
                   n_store=(cout if out.ld != rup(cout, 4) else None))
+        return out
+
+    def _thin_ok(self, x: Act, p, out: Optional[Act]) -> bool:
+        """the whole ResnetBlock in one launch with t on chip (csrc/resblock_thin.hip): <= 16 input channels, 16 mid / output channels"""
+        return (self.thin_fused and self.use_split and "bn" not in p and "rms" not in p and p["cout"] == 16 and x.ld <= 16 and
+                p["c0"].CinP == 16 and p["c1"].CinP == 16 and p["res"].CinP == 16 and (out is None or out.ld == 16) and
+                bool(self.lib.vs_resblock_thin_supported(x.ld, 16, 16)))
+
+    def resblock_thin(self, x: Act, p, tag: str, out: Optional[Act] = None) -> Act:
+        ar = self.arith
+        c0, c1, cr = p["c0"].with_split(ar), p["c1"].with_split(ar), p["res"].with_split(ar)
+        if out is None:
+            out = self.new_act(tag + ".o", x.B, x.H, x.W, 16)
+        d = N.ResblockThinDesc()
+        d.x, d.x_ld, d.B, d.H, d.W, d.Cin = N.ptr(x.t), x.ld, x.B, x.H, x.W, x.ld
+        d.w0_split, d.w1_split, d.wr_split = N.ptr(c0.split), N.ptr(c1.split), N.ptr(cr.split)
+        d.b0, d.b1, d.br = N.ptr(c0.bias), N.ptr(c1.bias), N.ptr(cr.bias)
+        d.arith, d.a_mul = ar, A_MUL
+        d.acc_mul0, d.acc_mul1, d.acc_mulr = 1.0 / (A_MUL * c0.w_mul), 1.0 / (A_MUL * c1.w_mul), 1.0 / (A_MUL * cr.w_mul)
+        d.out, d.out_ld = N.ptr(out.t), out.ld
+        timed = self.kernel_timers is not None and self.time_all_convs and not torch.cuda.is_current_stream_capturing()
+        if timed:
+            ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            ev0.record()
+        N.check(self.lib.vs_resblock_thin(C.byref(d), N.stream()), "vs_resblock_thin")
+        if timed:
+            ev1.record()
+            self.kernel_timers.append((f"resblock_thin {x.C}->16->16 @{x.H}x{x.W}", ev0, ev1, 2.0 * x.rows * 16 * (2 * 144 + 16)))
         return out
 
     _WHY = (f"with the 2 x f16 arithmetic an activation outside the f16 range of the operand split (|a| >= {65520.0 / A_MUL:.0f}; "
@@ -1361,6 +1400,7 @@ class HipEngine:
         d.step, d.video_mode, d.total_key = step, video_mode, delta.shape[0]
         d.attenuate, d.clamp, d.antialias = int(attenuate), int(clamp), int(antialias)
         d.scaling_i, d.scaling_w = float(scaling_i), float(scaling_w)
+        d.variant = int(self.tail_variant)
         ev = self._shell_t0()
         N.check(self.lib.vs_embed_tail(C.byref(d), N.stream()), "vs_embed_tail")
         # algorithmic HBM bytes: frame read + watermarked frame written (+ preds_w); the 256^2 delta / heat-map reads are cache hits

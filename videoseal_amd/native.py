@@ -34,7 +34,7 @@ EXPORTS = [
     "vs_msg_table_grad", "vs_outc_tanh_bwd", "vs_relu_bwd",
     "vs_resize_nchw_bwd", "vs_embed_tail_bwd", "vs_tail_key_reduce", "vs_aug_crop_flip_bwd", "vs_mask_mul", "vs_aug_color_bwd_scratch_floats",
     "vs_aug_color_bwd", "vs_clamp01_bwd", "vs_nhwc_to_nchw_scaled", "vs_percep_partial_doubles", "vs_percep_mse", "vs_percep_mse_grad",
-    "vs_split_block", "vs_check_finite", "vs_absmax", "vs_cnx_block_supported", "vs_cnx_block_image_bytes", "vs_cnx_block",
+    "vs_split_block", "vs_check_finite", "vs_absmax", "vs_resblock_thin", "vs_resblock_thin_supported", "vs_cnx_block_supported", "vs_cnx_block_image_bytes", "vs_cnx_block",
 ]
 
 
@@ -70,7 +70,19 @@ class TailDesc(C.Structure):
         ("F", C.c_int32), ("H", C.c_int32), ("W", C.c_int32), ("S_h", C.c_int32), ("S_w", C.c_int32), ("Cd", C.c_int32),
         ("step", C.c_int32), ("video_mode", C.c_int32), ("total_key", C.c_int32),
         ("attenuate", C.c_int32), ("clamp", C.c_int32), ("antialias", C.c_int32),
-        ("scaling_i", C.c_float), ("scaling_w", C.c_float), ("io_u8", C.c_int32), ("reserved_", C.c_int32),
+        ("scaling_i", C.c_float), ("scaling_w", C.c_float), ("io_u8", C.c_int32), ("variant", C.c_int32),
+    ]
+
+
+class ResblockThinDesc(C.Structure):
+    """mirror of vs_resblock_thin_desc_t"""
+    _fields_ = [
+        ("x", C.c_void_p), ("x_ld", C.c_int64), ("B", C.c_int32), ("H", C.c_int32), ("W", C.c_int32), ("Cin", C.c_int32),
+        ("w0_split", C.c_void_p), ("w1_split", C.c_void_p), ("wr_split", C.c_void_p),
+        ("b0", C.c_void_p), ("b1", C.c_void_p), ("br", C.c_void_p),
+        ("arith", C.c_int32), ("reserved_", C.c_int32),
+        ("a_mul", C.c_float), ("acc_mul0", C.c_float), ("acc_mul1", C.c_float), ("acc_mulr", C.c_float),
+        ("out", C.c_void_p), ("out_ld", C.c_int64),
     ]
 
 
@@ -185,6 +197,8 @@ def lib() -> C.CDLL:
         "vs_split_block": [P, I, I64, I, I, F, P, P, P],
         "vs_check_finite": [P, I64, P, P],
         "vs_absmax": [P, I64, P, P],
+        "vs_resblock_thin": [P, P],
+        "vs_resblock_thin_supported": [I, I, I],
         "vs_cnx_block": [P, P, I, I64, I, I, F, F, P, I64, P, P, I64, P, I64, P, P],
         "vs_cnx_block_supported": [I, I64, I],
     }
