@@ -341,7 +341,7 @@ int vs_pack_conv(const float* w, int Co, int Ci, int KH, int KW, int cinp, int t
  *   preds = the forward's preds_w): g_full [F][Cd][H][W] from d_imgs_w [F][3][H][W] (and/or d_preds_w).
  * vs_tail_key_reduce: key-frame expansion adjoint (videoseal.py:80-118) times the low-resolution heat-map (or NULL): d_delta [total_key][Cd][S][S].
  * vs_aug_crop_flip_bwd / vs_mask_mul / vs_aug_color_bwd / vs_clamp01_bwd: Crop, HorizontalFlip, the mask blend of augmenter.py:175, Brightness /
- *   Contrast / Saturation / Grayscale (op codes of vs_aug_color; hue has no adjoint here), the clamp in front of JPEG's straight-through estimator.
+ *   Contrast / Saturation / Grayscale / Hue (op codes of vs_aug_color), the clamp in front of JPEG's straight-through estimator.
  * vs_nhwc_to_nchw_scaled: the extractor's input gradient (NHWC) back to frame planes, times d(x * 2 - 1) / dx.
  * vs_percep_mse / vs_percep_mse_grad: the "mse" / "yuv" perceptual term (perceptual.py:20-28, yuvloss.py:11-27) and upstream * d loss / d imgs_w;
  *   partial = vs_percep_partial_doubles(F, H, W) doubles. */

@@ -955,3 +955,46 @@ def test_resblock_thin_fused_kernel(arith, shape):
     two = from_nhwc(e.resblock(xa, packed(), "thin2"))
     torch.cuda.synchronize()
     assert rel_err(two, ref) < 2e-5 and rel_err(got, two) < 2e-5
+
+
+@pytest.mark.parametrize("cfg", [(5, 333, 541, 96, 96, 1, 2), (3, 768, 768, 256, 256, 1, 1), (4, 200, 300, 128, 160, 0, 3), (2, 96, 80, 256, 256, 1, 1),
+                                 (3, 256, 256, 256, 256, 0, 1), (2, 700, 1100, 224, 352, 1, 4)])
+def test_resize_pre_forms_are_bit_identical(cfg):
+    """vs_resize_pre (wam.py:161-172 + the RGB -> Y / x*2-1 pre-processing): the row-streaming separable kernel (default: every input row fetched
+    once per 128-column tile, filtered horizontally once) against the 32 x 8 tile kernel -- same expressions, same order, same bits; down- and
+    up-scales, antialias on / off, ragged sizes, key frames every `step`, rgb / key / both outputs."""
+    import os
+    B, H, W, oh, ow, aa, step = cfg
+    L = N.lib()
+    g = torch.Generator(device="cuda").manual_seed(5)
+    x = torch.rand(B, 3, H, W, device="cuda", generator=g).contiguous()
+    ymat = (C.c_float * 3)(0.299, 0.587, 0.114)
+    nk = (B + step - 1) // step
+
+    def run(form, want_rgb=True, want_key=True, y=True):
+        rgb = torch.full((B, oh, ow, 4), -9.0, device="cuda") if want_rgb else None
+        key = torch.full((nk, oh, ow, 4), -9.0, device="cuda") if want_key else None
+        if form:
+            os.environ["VIDEOSEAL_RESIZE"] = form
+        try:
+            N.check(L.vs_resize_pre(N.ptr(x), B, 3, H, W, oh, ow, aa, N.ptr(rgb), 2.0, -1.0, N.ptr(key), step, ymat if y else None, N.stream()), "vs_resize_pre")
+            torch.cuda.synchronize()
+        finally:
+            os.environ.pop("VIDEOSEAL_RESIZE", None)
+        return rgb, key
+    r0, k0 = run("tile")
+    r1, k1 = run(None)
+    assert float(r0.min()) > -9.0 and float(k0.min()) > -9.0
+    assert torch.equal(r0, r1) and torch.equal(k0, k1)
+    ref = F.interpolate(x.cpu(), size=(oh, ow), mode="bilinear", align_corners=False, antialias=bool(aa))
+    assert (r1[..., :3].permute(0, 3, 1, 2).cpu() - (ref * 2 - 1)).abs().max() < 2e-6
+    for kw in (dict(want_rgb=False), dict(want_key=False), dict(y=False)):
+        a, b = run("tile", **kw), run(None, **kw)
+        assert all((p is None and q is None) or torch.equal(p, q) for p, q in zip(a, b))
+    for strip in (2, 6, 512):
+        os.environ["VS_RESIZE_STRIP_TEST"] = str(strip)
+        try:
+            r2, k2 = run(None)
+        finally:
+            os.environ.pop("VS_RESIZE_STRIP_TEST", None)
+        assert torch.equal(r2, r0) and torch.equal(k2, k0), strip

@@ -211,7 +211,8 @@ def test_validation_tables_match_the_reference():
     assert rows(A.get_validation_augs(True, only_combined=True)) == gold["combined_video"]
     assert rows(A.get_validation_augs_subset(False)) == gold["subset_image"]
     assert rows(A.get_validation_augs_subset(True)) == gold["subset_video"]
-    assert repr(A.H264(20, 30)) == "H264proxy" and "backend=proxy" in repr(A.VideoCompression())      # the stand-in is visible in names and logs
+    assert repr(A.H264(20, 30)) == "H264proxy" and "backend=proxy" in repr(A.VideoCompression())      # the stand-in is visible in tables and logs
+    assert A.H264(20, 30).aug_name == "H264" and A.H264(20, 30).backend_name == "H264proxy"            # `selected_aug` stays the reference's class name
 
 
 def test_result_buffers_of_a_cpu_caller():

@@ -9,9 +9,10 @@ SURVEY 8(f)2).  Rotate / Perspective follow torchvision's grid construction + AT
 not vendored by the reference: pinned against oracle/augment.py only).
 
 Inside a differentiable forward (model.forward under autograd, videoseal_amd/autograd.py) every op is a graph node whose backward is a HIP
-kernel too: Crop / HorizontalFlip / Resize / Brightness / Contrast / Saturation / Grayscale have exact adjoints, JPEG / MedianFilter /
-GaussianNoise / the codecs are the reference's straight-through estimators (forward value = codec / filter output, identity gradient), and
-the ops without an adjoint kernel (GaussianBlur, Rotate, Perspective, Hue, DropFrame, SpeedChange) raise in backward instead of cutting the graph.
+kernel too: Crop / HorizontalFlip / Resize / Brightness / Contrast / Saturation / Grayscale / Hue / GaussianBlur / Rotate / Perspective and the
+temporal ops (DropFrame / SpeedChange / TemporalReorder / WindowAveraging) have exact adjoints (csrc/bwd_shell.hip), JPEG / MedianFilter /
+GaussianNoise / the codecs are the reference's straight-through estimators (forward value = codec / filter output, identity gradient); only
+`passthrough=False` JPEG / MedianFilter -- which the reference cannot differentiate either -- raise in backward instead of cutting the graph.
 """
 from __future__ import annotations
 
@@ -637,7 +638,12 @@ class VideoCompression(_Aug):
 
     @property
     def aug_name(self) -> str:
-        """name reported in `selected_aug` / logs: the class name, marked when the proxy stands in for the codec"""
+        """name reported in `selected_aug`: the class name, exactly like the reference (train.py builds image file names and log keys from it)"""
+        return self.__class__.__name__
+
+    @property
+    def backend_name(self) -> str:
+        """which implementation produces the distortion: '<Class>proxy' for the on-GPU transform-coding stand-in, the class name for PyAV"""
         return self.__class__.__name__ + ("proxy" if self.backend != "pyav" else "")
 
     def __repr__(self):
@@ -660,8 +666,8 @@ class _CrfCodec(VideoCompression):
     def forward(self, frames, mask=None, crf=None):
         return super().forward(frames, mask, crf or self.get_random_crf())
 
-    def __repr__(self):
-        return self.aug_name
+    def __repr__(self):          # (the evaluation tables and logs print this: the stand-in stays visible there; `selected_aug` is the class name)
+        return self.backend_name
 
 
 class H264(_CrfCodec):

@@ -270,8 +270,8 @@ class SteFn(torch.autograd.Function):
 
 
 class NoAdjointFn(torch.autograd.Function):
-    """an augmentation whose transpose is not built (blur, rotate, perspective, hue): the forward value is exact, the backward raises instead
-    of silently cutting the graph between the decoding loss and the embedder"""
+    """an op that has no derivative in the reference either (`passthrough=False` JPEG / MedianFilter): the forward value is exact, the backward
+    raises instead of silently cutting the graph between the decoding loss and the embedder"""
 
     @staticmethod
     def forward(ctx, x, y, what):
@@ -433,8 +433,8 @@ class PercepLossFn(torch.autograd.Function):
         a, b = ctx.saved_tensors
         F_, _, H, W = a.shape
         d = torch.empty_like(b)
-        N.check(N.lib().vs_percep_mse_grad(N.ptr(a), N.ptr(b), F_, H, W, ctx.yuv, float(up), N.ptr(d), N.stream()), "vs_percep_mse_grad")
-        return None, d, None
+        N.check(N.lib().vs_percep_mse_grad(N.ptr(a), N.ptr(b), F_, H, W, ctx.yuv, 1.0, N.ptr(d), N.stream()), "vs_percep_mse_grad")
+        return None, d.mul_(up), None           # upstream gradient applied on the device (float(up) was a host synchronisation per backward)
 
 
 class DecodeLossFn(torch.autograd.Function):

@@ -157,8 +157,138 @@ __global__ __launch_bounds__(256) void resize_pre_kernel(const T* __restrict__ s
   }
 }
 
+// ---- row-streaming separable form of resize_pre (round 4) -------------------------------------------------------------------------------
+// The tile kernel above stages a (32 scale + support) x (8 scale + support) window per 32 x 8 outputs: at 768 -> 256 that is 102 x 30 pixels for
+// 96 x 24 useful ones, and a 408-byte row piece at an arbitrary offset touches 4-5 cache lines -- 1.51 x the frame through HBM (calibrated
+// counters, profiles/r03r_hbm_counter_calibration.md) and the horizontal filter of an input row is recomputed by every output row that uses it.
+// Here a workgroup owns 128 output columns x a strip of output rows and walks the INPUT rows of the strip top to bottom, eight at a time:
+//   1. the eight rows x three planes x (128 scale + support) columns go to LDS with coalesced loads (the next eight are requested first);
+//   2. horizontal pass: every (input row, output column) pair is filtered ONCE into a 16-row ring of horizontally resized rows;
+//   3. vertical pass: every output row whose tap window is complete is combined from the ring and stored (NHWC rgb / Y key frames).
+// The expressions and their order are those of the tile kernel (r += wx * pixel over the taps, then acc += wy * r): bit-identical outputs.
+// An input row is fetched once per 128-column tile (+ the strip's first window): ~1.15 x the frame.
+constexpr int RSO_W = 128, RS_GI = 8, RS_RING = 16, RS_INW = 448;       // output columns per workgroup, input rows per group, ring rows, LDS row pitch
+
+__global__ __launch_bounds__(256) void resize_pre_stream_kernel(const float* __restrict__ src, int B, int H, int W, int oh, int ow, int antialias,
+                                                                float* __restrict__ dst_rgb, float mul, float add, float* __restrict__ dst_key,
+                                                                int key_step, int key_mode, float y0c, float y1c, float y2c, int strip) {
+  extern __shared__ float rs_smem[];
+  float* In = rs_smem;                                   // [RS_GI][3][RS_INW]
+  float* Hr = rs_smem + RS_GI * 3 * RS_INW;              // [RS_RING][3][RSO_W]
+  const int ox0 = blockIdx.x * RSO_W, oy0 = blockIdx.y * strip, b = blockIdx.z;
+  const int oy_end = min(oh, oy0 + strip);
+  const int64_t plane = (int64_t)H * W;
+  const float* base = src + (int64_t)b * 3 * plane;
+  const int tid = threadIdx.x;
+  const int oxl = tid & (RSO_W - 1), half = tid >> 7;
+  const int ox = min(ox0 + oxl, ow - 1);
+  const bool ox_ok = ox0 + oxl < ow;
+  // input window of the tile: columns [x_lo, x_lo + ww), rows [y_lo, y_end)
+  int x_lo, x_hi, n_;
+  tap_range(ox0, W, ow, antialias, x_lo, n_);
+  tap_range(min(ox0 + RSO_W - 1, ow - 1), W, ow, antialias, x_hi, n_);
+  const int ww = x_hi + n_ - x_lo;
+  int y_lo, y_hi;
+  tap_range(oy0, H, oh, antialias, y_lo, n_);
+  tap_range(oy_end - 1, H, oh, antialias, y_hi, n_);
+  const int y_end = y_hi + n_;
+  const Taps tx = make_taps(ox, W, ow, antialias);
+  float wxs[MAXT];
+#pragma unroll
+  for (int jx = 0; jx < MAXT; ++jx) wxs[jx] = jx < tx.n ? tap_w(tx, jx) : 0.f;
+  const int xoff = tx.lo - x_lo;
+
+  // loads of one group: row-plane rp = 0 .. 23 (row = rp / 3, channel = rp % 3), elements tid and tid + 256 of its ww floats
+  float pre[RS_GI * 3][2];
+  auto load_group = [&](const int r0) __attribute__((always_inline)) {
+#pragma unroll
+    for (int rp = 0; rp < RS_GI * 3; ++rp) {
+      const int row = r0 + rp / 3, c = rp % 3;
+      const int cy = row < y_end ? row : y_end - 1;                         // rows past the window: a valid address, never used
+      const float* p = base + c * plane + (int64_t)cy * W + x_lo;
+      pre[rp][0] = p[tid < ww ? tid : ww - 1];
+      pre[rp][1] = p[tid + 256 < ww ? tid + 256 : ww - 1];
+    }
+  };
+  int oy_next = oy0 + half;                               // next output row this thread finalises (thread halves take alternate rows)
+  load_group(y_lo);
+  for (int r0 = y_lo; r0 < y_end; r0 += RS_GI) {
+#pragma unroll
+    for (int rp = 0; rp < RS_GI * 3; ++rp) {
+      if (tid < ww) In[rp * RS_INW + tid] = pre[rp][0];
+      if (tid + 256 < ww) In[rp * RS_INW + tid + 256] = pre[rp][1];
+    }
+    if (r0 + RS_GI < y_end) load_group(r0 + RS_GI);       // in flight during the two passes below
+    __syncthreads();
+    // horizontal pass: this thread's column, rows half * 4 .. + 3 of the group
+#pragma unroll
+    for (int q = 0; q < RS_GI / 2; ++q) {
+      const int rl = half * (RS_GI / 2) + q;
+      const int row = r0 + rl;
+      if (row < y_end) {
+        float r[3] = {0.f, 0.f, 0.f};
+        const float* Lp = In + rl * 3 * RS_INW + xoff;
+#pragma unroll
+        for (int jx = 0; jx < MAXT; ++jx)
+          if (jx < tx.n) {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) r[c] += wxs[jx] * Lp[c * RS_INW + jx];
+          }
+#pragma unroll
+        for (int c = 0; c < 3; ++c) Hr[((row & (RS_RING - 1)) * 3 + c) * RSO_W + oxl] = r[c];
+      }
+    }
+    __syncthreads();
+    // vertical pass: output rows whose window ends inside the rows processed so far
+    const int done = min(r0 + RS_GI, y_end);
+    while (oy_next < oy_end) {
+      const Taps ty = make_taps(oy_next, H, oh, antialias);
+      if (ty.lo + ty.n > done) break;
+      float acc[3] = {0.f, 0.f, 0.f};
+      for (int jy = 0; jy < ty.n; ++jy) {
+        const float wy = tap_w(ty, jy);
+        const float* hp = Hr + (((ty.lo + jy) & (RS_RING - 1)) * 3) * RSO_W + oxl;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) acc[c] += wy * hp[c * RSO_W];
+      }
+      if (ox_ok) {
+        const int64_t opix = ((int64_t)oy_next * ow + ox);
+        if (dst_rgb) {
+          f32x4 v = {acc[0] * mul + add, acc[1] * mul + add, acc[2] * mul + add, 0.f};
+          *reinterpret_cast<f32x4*>(dst_rgb + ((int64_t)b * oh * ow + opix) * 4) = v;
+        }
+        if (dst_key && (b % key_step) == 0) {
+          f32x4 v;
+          if (key_mode == 0) {
+            const float y = y0c * acc[0] + y1c * acc[1] + y2c * acc[2];
+            v = f32x4{y * 2.f - 1.f, 0.f, 0.f, 0.f};
+          } else {
+            v = f32x4{acc[0] * 2.f - 1.f, acc[1] * 2.f - 1.f, acc[2] * 2.f - 1.f, 0.f};
+          }
+          *reinterpret_cast<f32x4*>(dst_key + ((int64_t)(b / key_step) * oh * ow + opix) * 4) = v;
+        }
+      }
+      oy_next += 2;
+    }
+  }
+}
+
 // ---- JND (jnd.py:63-108) on a luminance tile held in LDS --------------------------------------------------
 struct JndTaps { float lum[25]; float sx[9]; float sy[9]; };
+
+// luminance of 255 * rgb (jnd.py:86-89) and the blend (blender.py:61-68, wam.py:103-113 / jnd.py:110-114) evaluated the way ATen does: separate
+// multiplications and additions, no fused multiply-add.  Every kernel of the tail calls these two functions, so its forms agree bit for bit
+// (hipcc's contraction of `a * b + c * d` picks either product for the fma depending on the surrounding code).
+__device__ __forceinline__ float lum255(const float r, const float g, const float b) {
+#pragma clang fp contract(off)
+  return 0.299f * (255.f * r) + 0.587f * (255.f * g) + 0.114f * (255.f * b);
+}
+__device__ __forceinline__ float blend_px(const float si, const float sw, const float p, const float dw, const float hm, const bool fwd_order) {
+#pragma clang fp contract(off)
+  float v = si * p + sw * dw;
+  if (fwd_order) v = p + hm * (v - p);
+  return v;
+}
 
 __device__ __forceinline__ float jnd_at(const float* L, int stride, int x, int y, const JndTaps& k) {
   // L points at tile origin, (x,y) is the centre inside the tile with a 2-pixel halo available
@@ -198,7 +328,7 @@ __device__ __forceinline__ void load_lum_tile(float* L, const float* img, int64_
     float v = 0.f;
     if (gx >= 0 && gx < W && gy >= 0 && gy < H) {
       const float* p = img + (int64_t)gy * sy + (int64_t)gx * sx;
-      v = 0.299f * (255.f * p[0]) + 0.587f * (255.f * p[sc]) + 0.114f * (255.f * p[2 * sc]);
+      v = lum255(p[0], p[sc], p[2 * sc]);
     }
     L[i] = v;
   }
@@ -212,8 +342,7 @@ __device__ __forceinline__ void load_lum_tile_px(float* L, const T* img, int64_t
     float v = 0.f;
     if (gx >= 0 && gx < W && gy >= 0 && gy < H) {
       const int64_t pix = (int64_t)gy * W + gx;
-      v = 0.299f * (255.f * Px<T>::ld(img, plane, 0, pix)) + 0.587f * (255.f * Px<T>::ld(img, plane, 1, pix)) +
-          0.114f * (255.f * Px<T>::ld(img, plane, 2, pix));
+      v = lum255(Px<T>::ld(img, plane, 0, pix), Px<T>::ld(img, plane, 1, pix), Px<T>::ld(img, plane, 2, pix));
     }
     L[i] = v;
   }
@@ -333,7 +462,7 @@ __global__ __launch_bounds__(256) void embed_tail_kernel(TailArgs a, JndTaps k) 
       }
 #pragma unroll
       for (int rr = 0; rr < NR; ++rr) {
-        L[rr * TLW + lxx] = 0.299f * (255.f * v[rr][0]) + 0.587f * (255.f * v[rr][1]) + 0.114f * (255.f * v[rr][2]);
+        L[rr * TLW + lxx] = lum255(v[rr][0], v[rr][1], v[rr][2]);
         if (KEEP && rr >= HALO && rr < HALO + TTH && lxx >= HALO && lxx < HALO + TTW)
 #pragma unroll
           for (int c = 0; c < 3; ++c) Pk[(c * TTH + rr - HALO) * TTW + lxx - HALO] = v[rr][c];
@@ -495,8 +624,7 @@ __global__ __launch_bounds__(256) void embed_tail_kernel(TailArgs a, JndTaps k) 
         for (int c = 0; c < a.Cd; ++c) a.preds_w[((int64_t)f * a.Cd + c) * plane + pix] = d[c];
 #pragma unroll
       for (int c = 0; c < 3; ++c) {
-        float v = a.scaling_i * px[q][c] + a.scaling_w * d[a.Cd == 1 ? 0 : c];
-        if (fwd_order) v = px[q][c] + hm * (v - px[q][c]);
+        float v = blend_px(a.scaling_i, a.scaling_w, px[q][c], d[a.Cd == 1 ? 0 : c], hm, fwd_order);
         if (a.clamp) v = v <= 0.f ? 0.f : (v >= 1.f ? 1.f : v);      // (NaN passes: fminf / fmaxf would turn it into 0)
         Px<T>::st(outf, plane, c, pix, v);
       }
@@ -677,8 +805,8 @@ __global__ __launch_bounds__(256, OCC) void embed_tail_stream_kernel(TailArgs a,
       for (int q = 0; q < SG; ++q) {
         const int gy = r0 + q;
         const bool rok = gy >= 0 && gy < a.H;
-        Lr[(slot0 + q) * TLW + lx + HALO] = (rok && xin) ? 0.299f * (255.f * cu[q][0]) + 0.587f * (255.f * cu[q][1]) + 0.114f * (255.f * cu[q][2]) : 0.f;
-        if (hal) Lr[(slot0 + q) * TLW + hl] = (rok && hin) ? 0.299f * (255.f * pfh[q][0]) + 0.587f * (255.f * pfh[q][1]) + 0.114f * (255.f * pfh[q][2]) : 0.f;
+        Lr[(slot0 + q) * TLW + lx + HALO] = (rok && xin) ? lum255(cu[q][0], cu[q][1], cu[q][2]) : 0.f;
+        if (hal) Lr[(slot0 + q) * TLW + hl] = (rok && hin) ? lum255(pfh[q][0], pfh[q][1], pfh[q][2]) : 0.f;
       }
     }
     if (it + 1 < niter) {
@@ -729,8 +857,7 @@ __global__ __launch_bounds__(256, OCC) void embed_tail_stream_kernel(TailArgs a,
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
           const float p = j < 2 ? hist[j][c] : cu[j - 2][c];
-          float v = a.scaling_i * p + a.scaling_w * d[a.Cd == 1 ? 0 : c];
-          if (fwd_order) v = p + hm * (v - p);
+          float v = blend_px(a.scaling_i, a.scaling_w, p, d[a.Cd == 1 ? 0 : c], hm, fwd_order);
           if (a.clamp) v = v <= 0.f ? 0.f : (v >= 1.f ? 1.f : v);      // (NaN passes)
           outf[c * plane + pix] = v;
         }
@@ -771,6 +898,27 @@ extern "C" int vs_resize_pre(const float* src, int B, int C, int H, int W, int o
   VS_REQUIRE(!dst_key || key_step >= 1);
   const int key_mode = ymat3 ? 0 : 1;
   const float y0 = ymat3 ? ymat3[0] : 0.f, y1 = ymat3 ? ymat3[1] : 0.f, y2 = ymat3 ? ymat3[2] : 0.f;
+  // row-streaming separable kernel (default) where its windows fit: 3 planes, <= 8 taps per direction, <= 448 input columns per 128 outputs
+  // (scales up to 3.4); VIDEOSEAL_RESIZE=tile keeps the 32 x 8 tile kernel, VS_RESIZE_STRIP=<output rows> overrides the strip height
+  const char* const env_form = getenv("VIDEOSEAL_RESIZE");          // (read per call: tests and tools switch forms inside one process)
+  const bool tile_only = env_form && !strcmp(env_form, "tile");
+  static const int env_strip = [] { const char* e = getenv("VS_RESIZE_STRIP"); return e ? atoi(e) : 0; }();
+  const float sx = (float)W / (float)ow, sy = (float)H / (float)oh;
+  const float supx = antialias ? (sx >= 1.f ? sx : 1.f) : 1.f, supy = antialias ? (sy >= 1.f ? sy : 1.f) : 1.f;
+  if (!tile_only && C == 3 && 2.f * supx + 2.f <= (float)MAXT && 2.f * supy + 2.f <= (float)MAXT && (float)RSO_W * sx + 2.f * supx + 4.f <= (float)RS_INW &&
+      2.f * supy + 2.f + (float)RS_GI <= (float)RS_RING) {
+    const int cols = (ow + RSO_W - 1) / RSO_W;
+    int strip = 32;
+    for (int cand : {64, 48, 32, 24, 16})            // tallest strip that still gives every CU two workgroups (one round at two resident per CU)
+      if ((int64_t)cols * ((oh + cand - 1) / cand) * B >= 512) { strip = cand; break; }
+    if (env_strip >= 2) strip = env_strip;
+    if (const char* e = getenv("VS_RESIZE_STRIP_TEST")) { const int v = atoi(e); if (v >= 1) strip = v; }     // tests: any strip height, per call
+    dim3 gs(cols, (oh + strip - 1) / strip, B);
+    const size_t lds = (size_t)(RS_GI * 3 * RS_INW + RS_RING * 3 * RSO_W) * sizeof(float);
+    hipLaunchKernelGGL(resize_pre_stream_kernel, gs, dim3(256), lds, (hipStream_t)stream, src, B, H, W, oh, ow, antialias, dst_rgb, mul, add, dst_key,
+                       key_step < 1 ? 1 : key_step, key_mode, y0, y1, y2, strip);
+    return vs_launch_status();
+  }
   dim3 grid((ow + 31) / 32, (oh + 7) / 8, B);
   hipLaunchKernelGGL(resize_pre_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, src, B, C, H, W, oh, ow, antialias, dst_rgb, mul,
                      add, dst_key, key_step < 1 ? 1 : key_step, key_mode, y0, y1, y2);
@@ -826,12 +974,10 @@ extern "C" int vs_embed_tail(const vs_tail_desc_t* d, void* stream) {
     // VS_TAIL_STRIP overrides.
     static const int env_strip = [] { const char* e = getenv("VS_TAIL_STRIP"); return e ? atoi(e) : 0; }();
     const int64_t cols = (d->W + TTW - 1) / TTW;
-    int strip = 32;
-    int64_t best = -1;
-    for (int cand : {32, 48, 64, 80, 96, 112, 128, 160, 192, 256}) {
-      const int64_t wgs = cols * ((d->H + cand - 1) / cand) * d->F;
-      const int64_t cost = ((wgs + 1023) / 1024) * (cand + 12);
-      if (best < 0 || cost < best || (cost == best && cand <= 96)) { best = cost; strip = cand; }
+    int strip = 32;             // 96 rows when that puts every workgroup in flight at once with at least three per CU, else 32 (short strips, many rounds)
+    {
+      const int64_t w96 = cols * ((d->H + 95) / 96) * d->F;
+      if (w96 >= 768 && w96 <= 1024) strip = 96;
     }
     if (env_strip >= 4) strip = (env_strip + 3) / 4 * 4;
     if (const char* e = getenv("VS_TAIL_STRIP_TEST")) { const int v = atoi(e); if (v >= 4) strip = (v + 3) / 4 * 4; }     // tests: every strip height, per call
