@@ -61,8 +61,8 @@ __global__ __launch_bounds__(256, OCC) void resblock_thin_kernel(const RbArgs d,
   using A16 = Arith16<NP>;
   constexpr int XP_BYTES = NP * X_PX * ROWB;                         // one patch buffer
   constexpr int TT_BYTES = NP * T_PX * ROWB;
-  // NBUF = 2: the next tile's patch lands in the other buffer (63 KB: two workgroups per CU); NBUF = 1: one buffer + one more barrier per tile
-  // (40 KB: three workgroups per CU at <= 168 VGPRs).  Three planes always take one buffer (static LDS stays below 64 KB).
+  // NBUF = 2: the next tile's patch lands in the other buffer (63 KB: two workgroups per CU); NBUF = 1 (three planes: static LDS stays below
+  // 64 KB): one buffer + one more barrier per tile.
   __shared__ __attribute__((aligned(16))) unsigned char smem[NBUF * XP_BYTES + TT_BYTES];
   unsigned char* const Tt = smem + NBUF * XP_BYTES;
   const int tid = threadIdx.x;
@@ -258,16 +258,13 @@ extern "C" int vs_resblock_thin(const vs_resblock_thin_desc_t* d, void* stream) 
   const int tiles_x = (d->W + TW - 1) / TW, tiles_y = (d->H + TH - 1) / TH;
   const int64_t nt = (int64_t)d->B * tiles_x * tiles_y;
   if (nt > 0x7fffffffLL) return VS_ERR_UNSUPPORTED;
-  // persistent workgroups, each walks a contiguous run of tiles (weights are loaded once per workgroup).  VS_THIN_FORM=1: single patch buffer,
-  // three workgroups per CU (A/B handle; default = double-buffered patch, two per CU)
-  static const int form = [] { const char* e = getenv("VS_THIN_FORM"); return e ? atoi(e) : 0; }();
-  const int per_cu = (d->arith == 2 && form == 1) ? 3 : 2;
-  const int64_t want = (int64_t)vs_num_cus() * per_cu;
+  // persistent workgroups: two per CU (63 KB of LDS each), each walks a contiguous run of tiles (weights are loaded once per workgroup).
+  // (A single patch buffer + three workgroups per CU measured slower: embed 6.33 against 6.14 ms, profiles/r04g_*.)
+  const int64_t want = (int64_t)vs_num_cus() * 2;
   const int per = (int)((nt + want - 1) / want);
   const int tpw = per < 1 ? 1 : per;
   const unsigned grid = (unsigned)((nt + tpw - 1) / tpw);
-  if (d->arith == 2 && form == 1) hipLaunchKernelGGL((resblock_thin_kernel<2, 1, 3>), dim3(grid), dim3(256), 0, (hipStream_t)stream, a, tiles_x, tiles_y, (int)nt, tpw);
-  else if (d->arith == 2) hipLaunchKernelGGL((resblock_thin_kernel<2, 2, 2>), dim3(grid), dim3(256), 0, (hipStream_t)stream, a, tiles_x, tiles_y, (int)nt, tpw);
+  if (d->arith == 2) hipLaunchKernelGGL((resblock_thin_kernel<2, 2, 2>), dim3(grid), dim3(256), 0, (hipStream_t)stream, a, tiles_x, tiles_y, (int)nt, tpw);
   else hipLaunchKernelGGL((resblock_thin_kernel<3, 1, 2>), dim3(grid), dim3(256), 0, (hipStream_t)stream, a, tiles_x, tiles_y, (int)nt, tpw);
   return vs_launch_status();
 }

@@ -678,8 +678,11 @@ __device__ __forceinline__ float jnd_at_ring(const float* Lr, const int cslot, c
   return fmaxf(h, 0.f) / 255.f;
 }
 
-template <bool JND, int OCC>
-__global__ __launch_bounds__(256, OCC) void embed_tail_stream_kernel(TailArgs a, JndTaps k, const int strip) {
+// (No waves-per-SIMD hint and no wrapper around the body: `__launch_bounds__(256, 3 | 4)` as well as a __forceinline__ body called from two
+// __global__ wrappers made hipcc spill 16-40 bytes per lane; a scratch reload waits for every older global load -- the row prefetch -- and the
+// JND form ran 40 % slower: 175-180 -> 245-265 us at 32 x 768^2, profiles/r04_tail_forms.md.)
+template <bool JND>
+__global__ __launch_bounds__(256) void embed_tail_stream_kernel(TailArgs a, JndTaps k, const int strip) {
   extern __shared__ float dyn_smem[];
   float* Lr = dyn_smem;                                        // [RING][TLW] luminance ring (JND only)
   float* DwB = dyn_smem + (JND ? RING * TLW : 0);              // [2][Cd][DW_H][DW_W] watermark source windows
@@ -873,6 +876,10 @@ __global__ __launch_bounds__(256, OCC) void embed_tail_stream_kernel(TailArgs a,
   }
 }
 
+// (no waves-per-SIMD hint on the JND form: with `__launch_bounds__(256, 3)` or `(256, 4)` hipcc schedules the same body 40 % slower -- 132
+// VGPRs and three waves per SIMD either way, measured 175 -> 245-260 us at 32 x 768^2, profiles/r04_tail_forms.md)
+
+
 // ---------------------------------------------------------------------------------------------------
 // the taps of jnd.py:24-41 (what every released card carries in its state dict)
 bool standard_jnd_taps(const float* t) {
@@ -983,10 +990,8 @@ extern "C" int vs_embed_tail(const vs_tail_desc_t* d, void* stream) {
     if (const char* e = getenv("VS_TAIL_STRIP_TEST")) { const int v = atoi(e); if (v >= 4) strip = (v + 3) / 4 * 4; }     // tests: every strip height, per call
     dim3 gs((unsigned)cols, (d->H + strip - 1) / strip, d->F);
     const size_t lds_w = (size_t)2 * d->Cd * DW_W * DW_H * sizeof(float);
-    static const int occ = [] { const char* e = getenv("VS_TAIL_OCC"); return e ? atoi(e) : 4; }();      // A/B: 3 = no register cap (132 VGPRs)
-    if (full_jnd && occ == 3) hipLaunchKernelGGL((embed_tail_stream_kernel<true, 3>), gs, dim3(256), lds_w + RING * TLW * sizeof(float), (hipStream_t)stream, a, k, strip);
-    else if (full_jnd) hipLaunchKernelGGL((embed_tail_stream_kernel<true, 4>), gs, dim3(256), lds_w + RING * TLW * sizeof(float), (hipStream_t)stream, a, k, strip);
-    else hipLaunchKernelGGL((embed_tail_stream_kernel<false, 4>), gs, dim3(256), lds_w, (hipStream_t)stream, a, k, strip);
+    if (full_jnd) hipLaunchKernelGGL((embed_tail_stream_kernel<true>), gs, dim3(256), lds_w + RING * TLW * sizeof(float), (hipStream_t)stream, a, k, strip);
+    else hipLaunchKernelGGL((embed_tail_stream_kernel<false>), gs, dim3(256), lds_w, (hipStream_t)stream, a, k, strip);
     return vs_launch_status();
   }
   if (d->io_u8) {
