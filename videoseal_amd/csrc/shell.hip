@@ -975,17 +975,16 @@ extern "C" int vs_embed_tail(const vs_tail_desc_t* d, void* stream) {
   const bool full_jnd = d->attenuate && !d->hmap_lowres;
   const bool sep = mode > 0 && full_jnd && d->taps43 && standard_jnd_taps(d->taps43);
   if (mode == 3 && !d->io_u8 && (sep || !full_jnd) && d->W >= 2 * d->S_w && d->H >= 2 * d->S_h) {
-    // strip height: all workgroups of a launch should be resident at once, or come in whole rounds -- 256 CUs x 4 workgroups (four waves per
-    // SIMD at <= 128 VGPRs); a strip costs its rows + the pipeline fill, a launch costs rounds x strip cost.  Measured at 32 x 768^2 (full JND):
-    // 32 rows 180 us, 64 rows (1152 workgroups = 1.5 rounds at three per CU) 203 us, 96 rows (768: one round) 175 us, 128 rows 222 us.
-    // VS_TAIL_STRIP overrides.
+    // VS_TAIL_STRIP overrides the strip height
     static const int env_strip = [] { const char* e = getenv("VS_TAIL_STRIP"); return e ? atoi(e) : 0; }();
     const int64_t cols = (d->W + TTW - 1) / TTW;
-    int strip = 32;             // 96 rows when that puts every workgroup in flight at once with at least three per CU, else 32 (short strips, many rounds)
-    {
-      const int64_t w96 = cols * ((d->H + 95) / 96) * d->F;
-      if (w96 >= 768 && w96 <= 1024) strip = 96;
-    }
+    // strip height, from tools/bench_tail_sweep.py (profiles/r04h_tail_sweep.log, 768^2; us for 16 / 32 / 128 frames): without the luminance phase
+    // short strips win (32 rows: 44 / 107 / 384 against 69 / 122 / 411 for 96); with it the strip should be tall (4 halo rows + the pipeline fill
+    // per strip) as long as the launch still has three workgroups per CU: 96 rows 138 / 177 / 661, 48 rows 91 / 180 / 671, 32 rows 107 / 183 / 684
+    int strip = 32;
+    if (full_jnd)
+      for (int cand : {96, 48})
+        if (cols * ((d->H + cand - 1) / cand) * d->F >= 768) { strip = cand; break; }
     if (env_strip >= 4) strip = (env_strip + 3) / 4 * 4;
     if (const char* e = getenv("VS_TAIL_STRIP_TEST")) { const int v = atoi(e); if (v >= 4) strip = (v + 3) / 4 * 4; }     // tests: every strip height, per call
     dim3 gs((unsigned)cols, (d->H + strip - 1) / strip, d->F);
