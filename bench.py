@@ -170,7 +170,6 @@ def parse_args(argv=None):
     ap.add_argument("--group", type=int, default=None, help="stream mode: 16-frame chunks whose key frames share one U-Net pass (default: enough "
                     "for 32 key frames = 8 chunks; 1 = the literal per-chunk calls of round 3)")
     ap.add_argument("--det-batch", type=int, default=None, help="stream mode: frames per extractor pass (default 32)")
-    ap.add_argument("--detect-lanes", type=int, default=None, help="extractor passes in flight per detect() call (model.detect_lanes; default: the model's)")
     ap.add_argument("--graphs", action="store_true", help="replay the per-chunk launch sequences from hipGraphs")
     ap.add_argument("--batch", type=int, default=None, help="frames per GPU and step (default 32; 16 in chain mode)")
     ap.add_argument("--size", type=int, default=768)
@@ -244,8 +243,6 @@ def _run(args, world, rank, dev, dist_on, n_ranks_seen):
     is_video = args.mode in ("video", "stream", "chain")
     msgs = torch.randint(0, 2, (1 if is_video else B, cfg.nbits), generator=gm)
     model.chunk_size = max(model.chunk_size, B)
-    if args.detect_lanes is not None:
-        model.detect_lanes = args.detect_lanes
 
     two_streams = stream and args.overlap
 

@@ -232,7 +232,6 @@ class HipEngine:
     planes_chain = True
     planes_gemm = True
     # (class-level defaults: test harnesses build engines without a model, tests/test_gpu_kernels.py::Eng)
-    _lane = ""
     _tr_pass = 0
     _calib = None
     thin_fused = True
@@ -244,7 +243,6 @@ class HipEngine:
         self.dev = device
         self.lib = N.lib()
         self._ws: Dict[tuple, torch.Tensor] = {}
-        self._lane = ""                           # suffix of the workspace tags of the lane being issued (see lane())
         self._ws_used: Dict[tuple, int] = {}      # 'tr.*' keys: the training pass that last touched them (begin_training_pass)
         self._tr_pass = 0
         self.kernel_timers = None        # list of (name, start_event, end_event, flops) when bench.py enables it
@@ -471,7 +469,7 @@ class HipEngine:
     # ------------------------------------------------------------------ workspace
     def buf(self, tag: str, numel: int, zero: bool = False) -> torch.Tensor:
         """named persistent workspace: stable addresses across calls of one shape (hipGraph-capturable)"""
-        key = (tag + self._lane, numel)
+        key = (tag, numel)
         t = self._ws.get(key)
         if t is None:
             t = torch.zeros(numel, device=self.dev, dtype=torch.float32) if zero else torch.empty(numel, device=self.dev, dtype=torch.float32)
@@ -479,21 +477,6 @@ class HipEngine:
         if tag.startswith("tr."):
             self._ws_used[key] = self._tr_pass
         return t
-
-    def lane(self, name: str):
-        """context manager: the launch sequences issued inside use their own set of named workspace buffers ('<tag>@<name>'), so that two
-        passes of one network can be in flight on two HIP streams at once (frames are independent: the extractor on two halves of a batch,
-        streaming.py).  Weights are shared (read-only); K-split workspaces are per stream already."""
-        eng = self
-
-        class _Lane:
-            def __enter__(self_):
-                self_.old = eng._lane
-                eng._lane = "@" + name if name else ""
-
-            def __exit__(self_, *exc):
-                eng._lane = self_.old
-        return _Lane()
 
     def begin_training_pass(self) -> None:
         """Called at the start of every training forward (EmbedTrainFn / DetectTrainFn / DetectorStep.step).  The training path's buffers

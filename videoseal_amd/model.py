@@ -608,7 +608,6 @@ class Videoseal(Wam):
             self.embedder.cfg = self.detector.cfg = dataclasses.replace(self.embedder.cfg, chunk_size=int(chunk_size), step_size=int(step_size))
         self.video_mode = video_mode
         self.lowres_attenuation = lowres_attenuation
-        self.detect_lanes = int(os.environ.get("VIDEOSEAL_DETECT_LANES", "1"))      # extractor passes in flight per detect() call (_detect_lanes)
 
     def _embed_clip(self, imgs: torch.Tensor, msgs: torch.Tensor, interpolation, lowres_attenuation: bool) -> torch.Tensor:
         if self.video_mode not in N.VIDEO_MODES:
@@ -665,45 +664,11 @@ class Videoseal(Wam):
         out = self._embed_clip(imgs, msgs, interpolation, lowres_attenuation)
         return {"imgs_w": out, "msgs": msgs[0:1].repeat(len(imgs), 1)}
 
-    def _detect_lanes(self, eng: HipEngine, imgs: torch.Tensor, S, aa: bool, lanes: int) -> torch.Tensor:
-        """the frames of a device-resident batch as `lanes` contiguous parts, each part's extractor pass on its own HIP stream with its own
-        workspace lane (engine.lane): frames are independent, and the extractor's launches are short (stage 2 / 3: a few thousand rows, K of
-        a few hundred) -- two passes in flight fill the CUs that one pass leaves idle between and inside its launches.  Same kernels, same
-        per-frame arithmetic whenever the parts have the batch size the single pass would use for its K-split rule."""
-        from .streaming import lane_streams
-        cur = torch.cuda.current_stream(eng.dev)
-        F_ = imgs.shape[0]
-        span = min(max(1, int(self.chunk_size)), -(-F_ // lanes))         # frames per extractor pass; pass i runs in lane i % lanes
-        streams = lane_streams(eng.dev, lanes)
-        outs, ev0 = [], torch.cuda.Event()
-        ev0.record(cur)
-        for st in streams:
-            st.wait_event(ev0)
-        for i, a in enumerate(range(0, F_, span)):
-            st = streams[i % lanes]
-            with torch.cuda.stream(st), eng.lane(f"det{i % lanes}"):
-                outs.append(self._detect_frames(eng, imgs[a:a + span], S, aa))
-        imgs.record_stream(streams[0])
-        for st in streams:
-            if st is not streams[0]:
-                imgs.record_stream(st)
-            ev = torch.cuda.Event()
-            ev.record(st)
-            cur.wait_event(ev)
-        for t in outs:
-            t.record_stream(cur)
-        return torch.cat(outs, dim=0)
-
     def _detect_clip(self, imgs: torch.Tensor, interpolation) -> torch.Tensor:
         eng = self._engine()
         aa = _antialias_flag(interpolation)
         S = (self.img_size, self.img_size)
         preds = []
-        lanes = int(getattr(self, "detect_lanes", 1))
-        if lanes > 1 and imgs.device == eng.dev and imgs.shape[0] >= 2 * lanes and not torch.cuda.is_current_stream_capturing():
-            with torch.cuda.device(eng.dev):
-                src = imgs if imgs.dtype == torch.uint8 else N.f32c(imgs)
-                return self._detect_lanes(eng, src, S, aa, lanes)
         with torch.cuda.device(eng.dev):
             self._run_chunks(eng, imgs, max(1, int(self.chunk_size)),
                              lambda fr, oc, a, b: preds.append(self._detect_frames(eng, fr, S, aa)), want_out=False, extra=preds.clear)

@@ -95,17 +95,6 @@ def embed_detect_chunks(model, frames: torch.Tensor, msgs: torch.Tensor, chunk: 
 
 
 _STREAMS = {}
-_LANES = {}
-
-
-def lane_streams(device, n: int):
-    """n side streams for concurrent passes of one network over independent frames (model._detect_lanes)"""
-    key = str(device)
-    have = _LANES.setdefault(key, [])
-    while len(have) < n:
-        have.append(torch.cuda.Stream(device))
-    return have[:n]
-
 
 def _streams(device) -> Tuple[torch.cuda.Stream, torch.cuda.Stream]:
     key = str(device)
