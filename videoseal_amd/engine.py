@@ -619,7 +619,8 @@ class HipEngine:
         blocks = ((rows + 127) // 128) * ((d.N + 127) // 128)
         pairs = d.CinP // 32
         sk = 1
-        while blocks * sk < 256 and pairs % (sk * 2) == 0 and pairs // (sk * 2) >= 4:
+        target = int(os.environ.get("VS_SPLITK_TARGET", "256"))        # (experiment handle: workgroups the rule aims at)
+        while blocks * sk < target and pairs % (sk * 2) == 0 and pairs // (sk * 2) >= 4:
             sk *= 2
         return sk
 
