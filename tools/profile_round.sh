@@ -14,6 +14,7 @@ cd /tmp
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O -o img -- python $R/bench.py --no-extra --no-cpu-baseline --no-kernel-timers --steps 10 --warmup 2 > $O/img.log 2>&1
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O -o chain -- python $R/bench.py --mode chain --no-cpu-baseline --no-kernel-timers --steps 10 --warmup 2 > $O/chain.log 2>&1
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O -o vid -- python $R/bench.py --mode video --no-cpu-baseline --no-kernel-timers --steps 10 --warmup 2 > $O/vid.log 2>&1
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O -o stream -- python $R/bench.py --mode stream --no-cpu-baseline --no-kernel-timers --steps 2 --warmup 1 > $O/stream.log 2>&1
 for P in "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE" "FETCH_SIZE" "WRITE_SIZE"; do
   N=$(echo $P | cut -d' ' -f1)
   timeout 300 rocprofv3 --pmc $P --output-format csv -d $O/pmc -o $N -- python $R/bench.py --no-extra --no-cpu-baseline --no-kernel-timers --steps 2 --warmup 1 > $O/pmc_$N.log 2>&1
