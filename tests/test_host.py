@@ -229,3 +229,20 @@ def test_result_buffers_of_a_cpu_caller():
         assert not M._result_buffer((4,), torch.float32, torch.device("cpu")).is_pinned()
     finally:
         M._PINNED_RESULTS = old
+
+
+def test_bench_gpus_n_without_a_launcher_refuses_cleanly_when_the_node_has_too_few_gpus():
+    """`python bench.py --gpus 2` (no torch.distributed.run around it): bench.py launches itself, or -- fewer GPUs than asked for, here none --
+    prints ONE JSON error line and exits with code 2 instead of dying with a launcher message"""
+    import json
+    import subprocess
+    import sys
+    if torch.cuda.device_count() >= 2:
+        pytest.skip("this box could run it")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 2, r.stderr[-500:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    err = json.loads(lines[0])
+    assert err["n_gpus_requested"] == 2 and err["n_gpus_visible"] == torch.cuda.device_count() and "error" in err
