@@ -365,23 +365,30 @@ __global__ __launch_bounds__(1024) void grn_finish_kernel(const float* __restric
     float s[NB];
 #pragma unroll
     for (int j = 0; j < NB; ++j) s[j] = 0.f;
-    if (frame_major) {
-      for (int k = k0; k < k1; ++k) {
-        const float* row = partial + ((int64_t)b * nchunk + k) * C;
+    // chunk rows four at a time: the 4 x NB loads are issued before the first addition (a loop that adds each value as it arrives is a chain of
+    // k1 - k0 dependent L2 round trips: up to 32 of them for the 64 x 64 maps); additions stay in ascending chunk order
+    const int64_t kstride = frame_major ? (int64_t)C : (int64_t)B * C;
+    const float* rowp = frame_major ? partial + ((int64_t)b * nchunk + k0) * C : partial + ((int64_t)k0 * B + b) * C;
+    int k = k0;
+    for (; k + 4 <= k1; k += 4, rowp += 4 * kstride) {
+      float v[4][NB];
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
 #pragma unroll
         for (int j = 0; j < NB; ++j) {
           const int c = cb0 + j * 256 + cl;
-          if (c < C) s[j] += row[c];
+          v[q][j] = c < C ? rowp[q * kstride + c] : 0.f;
         }
-      }
-    } else {
-      for (int k = k0; k < k1; ++k) {
-        const float* row = partial + ((int64_t)k * B + b) * C;
 #pragma unroll
-        for (int j = 0; j < NB; ++j) {
-          const int c = cb0 + j * 256 + cl;
-          if (c < C) s[j] += row[c];
-        }
+      for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int j = 0; j < NB; ++j) s[j] += v[q][j];
+    }
+    for (; k < k1; ++k, rowp += kstride) {
+#pragma unroll
+      for (int j = 0; j < NB; ++j) {
+        const int c = cb0 + j * 256 + cl;
+        if (c < C) s[j] += rowp[c];
       }
     }
 #pragma unroll
