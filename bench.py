@@ -170,7 +170,6 @@ def parse_args(argv=None):
     ap.add_argument("--group", type=int, default=None, help="stream mode: 16-frame chunks whose key frames share one U-Net pass (default: enough "
                     "for 32 key frames = 8 chunks; 1 = the literal per-chunk calls of round 3)")
     ap.add_argument("--det-batch", type=int, default=None, help="stream mode: frames per extractor pass (default 32)")
-    ap.add_argument("--first", type=int, default=2, help="stream mode: chunks of the first (ramp-up) group (default 2)")
     ap.add_argument("--graphs", action="store_true", help="replay the per-chunk launch sequences from hipGraphs")
     ap.add_argument("--batch", type=int, default=None, help="frames per GPU and step (default 32; 16 in chain mode)")
     ap.add_argument("--size", type=int, default=768)
@@ -249,7 +248,7 @@ def _run(args, world, rank, dev, dist_on, n_ranks_seen):
 
     def step_stream_overlapped():     # videoseal_amd/streaming.py: detect(chunk i) on a second HIP stream while embed(chunk i+1) is issued
         from videoseal_amd.streaming import embed_detect_chunks
-        preds = embed_detect_chunks(model, frames_u8 if args.u8 else frames, msgs, chunk=16, lowres_attenuation=True, overlap=True, group=args.group, det_batch=args.det_batch, first=args.first)
+        preds = embed_detect_chunks(model, frames_u8 if args.u8 else frames, msgs, chunk=16, lowres_attenuation=True, overlap=True, group=args.group, det_batch=args.det_batch)
         if dist_on:
             preds = gather_frame_logits(preds, args.frames, align=16)
         return preds

@@ -31,11 +31,10 @@ def default_group(chunk: int, step: int) -> int:
 
 def embed_detect_chunks(model, frames: torch.Tensor, msgs: torch.Tensor, chunk: int = 16, lowres_attenuation: bool = True,
                         overlap: bool = True, sink: Optional[Callable[[int, torch.Tensor], None]] = None,
-                        group: Optional[int] = None, det_batch: Optional[int] = None, first: int = 2) -> torch.Tensor:
+                        group: Optional[int] = None, det_batch: Optional[int] = None) -> torch.Tensor:
     """frames [F,3,H,W] fp32 or uint8 [F,H,W,3] on the device -> logits [F, 1+nbits].  `sink(first_frame, imgs_w_chunk)` receives
     every watermarked chunk in clip order (e.g. to hand it to an encoder); it is called on the embed stream's timeline.
-    group: chunks per U-Net pass (None = default_group; 1 = the literal per-chunk calls); first: chunks of the first (ramp-up) group;
-    det_batch: frames per extractor pass (None = DET_BATCH)."""
+    group: chunks per U-Net pass (None = default_group; 1 = the literal per-chunk calls); det_batch: frames per extractor pass (None = DET_BATCH)."""
     u8 = frames.dtype == torch.uint8
     step = int(model.step_size)
     if group is None:
@@ -43,15 +42,7 @@ def embed_detect_chunks(model, frames: torch.Tensor, msgs: torch.Tensor, chunk: 
     if group > 1 and chunk % step:
         raise ValueError(f"group > 1 needs chunk ({chunk}) to be a multiple of step_size ({step})")
     F_ = frames.shape[0]
-    # frame ranges of the groups.  The extractor is the longer half of the pipeline, so the clip is done when the LAST extractor pass is: the first
-    # group is kept short (`first` chunks, default 2) -- its extractor pass starts after one short U-Net pass instead of a full one -- and every
-    # later group has `group` chunks (full U-Net batches, hidden under the previous group's extractor pass)
-    first = max(1, min(int(first), group)) if group > 1 else 1
-    bounds, a = [], 0
-    while a < F_:
-        n = chunk * (first if (a == 0 and F_ > chunk * first) else group)
-        bounds.append((a, min(F_, a + n)))
-        a += n
+    span = chunk * group
 
     def emb(x):
         if group == 1:       # the caller's own calls
@@ -76,8 +67,8 @@ def embed_detect_chunks(model, frames: torch.Tensor, msgs: torch.Tensor, chunk: 
 
     logits = []
     if not overlap:
-        for a, b in bounds:
-            w = emb(frames[a:b])
+        for a in range(0, F_, span):
+            w = emb(frames[a:a + span])
             feed_sink(a, w)
             logits.append(det(w))
         return torch.cat(logits, 0)
@@ -85,9 +76,9 @@ def embed_detect_chunks(model, frames: torch.Tensor, msgs: torch.Tensor, chunk: 
     s_emb, s_det = _streams(frames.device)
     s_emb.wait_stream(cur)
     s_det.wait_stream(cur)
-    for a, b in bounds:
+    for a in range(0, F_, span):
         with torch.cuda.stream(s_emb):
-            w = emb(frames[a:b])
+            w = emb(frames[a:a + span])
             feed_sink(a, w)
             ev = torch.cuda.Event()
             ev.record(s_emb)
