@@ -287,8 +287,9 @@ int vs_outc_tanh_bwd(const float* delta, const float* ddelta, int64_t rows_per_f
 
 /* ---- ResnetBlock of the thin full-resolution U-Net levels in one launch (csrc/resblock_thin.hip; unet.py:24-39 with eval BatchNorm folded
  * into the convolutions, ReLU):   out = relu(conv3x3_1(t) + b1) + (conv1x1_res(x) + br),   t = relu(conv3x3_0(x) + b0)
- * x: NHWC fp32 [B][H][W][x_ld], Cin <= 16 channels read per pixel (multiple of 4); 16 mid and 16 output channels (VideoSeal 1.0: `inc`, last `ups`
- * block); t stays on chip.  Weights as the operand planes of vs_split_block for K = 9 * 16 resp. 16 ([P][16][K] 16-bit patterns, P = 2 f16 terms
+ * x: NHWC fp32 [B][H][W][x_ld], Cin channels read per pixel (multiple of 4); Cout = 16 mid and output channels with Cin <= 16 (VideoSeal 1.0: `inc`,
+ * last `ups` block) or 32 with Cin <= 32 (the 128^2 level; PixelSeal's `inc`; 2 x f16 arithmetic only: the weights live in LDS); t stays on chip.
+ * Weights as the operand planes of vs_split_block for K = 9 * Cout resp. Cout ([P][Cout][K] 16-bit patterns, P = 2 f16 terms
  * of w * w_mul / 3 bf16 terms; channels >= Cin zero); acc_mul* = 1 / (a_mul * w_mul) of each convolution (arith 2).  Replaces two vs_conv_gemm
  * launches (and the HBM round trip of t) where vs_resblock_thin_supported(x_ld, mid, out) says so. */
 typedef struct vs_resblock_thin_desc {
@@ -296,7 +297,8 @@ typedef struct vs_resblock_thin_desc {
   int32_t B, H, W, Cin;
   const void *w0_split, *w1_split, *wr_split;
   const float *b0, *b1, *br;                /* [16] each or NULL                                                  */
-  int32_t arith, reserved_;                 /* 2 = 2 x f16, 3 = 3 x bf16                                          */
+  int32_t arith;                            /* 2 = 2 x f16, 3 = 3 x bf16 (16 channels only)                       */
+  int32_t Cout;                             /* mid = output channels: 16 (or 0) / 32; weights then [P][Cout][9 * K], K = 16 / 32  */
   float a_mul, acc_mul0, acc_mul1, acc_mulr;
   float* out; int64_t out_ld;
 } vs_resblock_thin_desc_t;

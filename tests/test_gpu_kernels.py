@@ -998,3 +998,39 @@ def test_resize_pre_forms_are_bit_identical(cfg):
         finally:
             os.environ.pop("VS_RESIZE_STRIP_TEST", None)
         assert torch.equal(r2, r0) and torch.equal(k2, k0), strip
+
+
+@pytest.mark.parametrize("shape", [(2, 32, 37, 29), (3, 32, 16, 48), (1, 32, 128, 128)])
+def test_resblock_thin_fused_kernel_32_channels(shape):
+    """the 32-channel form of vs_resblock_thin (VideoSeal 1.0's 128^2 level: `downs.0.conv`, `ups.1.conv`; weights in LDS, one tap x 32 channels per
+    matrix instruction, 2 x f16 arithmetic): against torch fp32 on the CPU and the two-launch path; ragged maps; the exact 3 x bf16 split keeps the
+    two-launch path (its three planes do not fit the kernel's LDS)"""
+    B, Cin, H, W = shape
+    e = Eng(arith=2)
+    g = torch.Generator().manual_seed(77)
+    x = torch.randn(B, Cin, H, W, generator=g)
+    w0 = torch.randn(32, Cin, 3, 3, generator=g) / math.sqrt(Cin * 9)
+    b0 = torch.randn(32, generator=g) * 0.3
+    w1 = torch.randn(32, 32, 3, 3, generator=g) / math.sqrt(32 * 9)
+    b1 = torch.randn(32, generator=g) * 0.3
+    wr = torch.randn(32, Cin, 1, 1, generator=g) / math.sqrt(Cin)
+    br = torch.randn(32, generator=g) * 0.3
+    ref = F.relu(F.conv2d(F.relu(F.conv2d(x, w0, b0, padding=1)), w1, b1, padding=1)) + F.conv2d(x, wr, br)
+    xa = to_nhwc(x)
+
+    def packed():
+        wt0, cp0 = pack_conv(w0.to(DEV), xa.ld)
+        wt1, cp1 = pack_conv(w1.to(DEV), 32)
+        wtr, cpr = pack_conv(wr.to(DEV), xa.ld)
+        return dict(c0=ConvW(wt0, dv(b0), 32, 3, 3, cp0), c1=ConvW(wt1, dv(b1), 32, 3, 3, cp1), res=ConvW(wtr, dv(br), 32, 1, 1, cpr), cout=32)
+    p = packed()
+    assert e._thin_ok(xa, p, None)
+    got = from_nhwc(e.resblock(xa, p, "thin32"))
+    torch.cuda.synchronize()
+    assert rel_err(got, ref) < 2e-5
+    e.thin_fused = False
+    two = from_nhwc(e.resblock(xa, packed(), "thin32b"))
+    torch.cuda.synchronize()
+    assert rel_err(two, ref) < 2e-5 and rel_err(got, two) < 2e-5
+    e3 = Eng(arith=3)
+    assert not e3._thin_ok(xa, packed(), None)

@@ -383,15 +383,16 @@ struct Runner {
     if (live()) chk(vs_layernorm_act(x.p, x.rows(), x.C, x.ld, w, b, 1e-6f, act_, out.p, out.ld, st));
   }
   Act resblock(const Act& x, const RB& p, const Act* out_in = nullptr) {                      // engine.py::resblock
-    if (p.cout == 16 && x.ld <= 16 && p.c0.CinP == 16 && p.c1.CinP == 16 && p.res.CinP == 16 && (!out_in || out_in->ld == 16) &&
-        vs_resblock_thin_supported(x.ld, 16, 16)) {                                            // engine.py::resblock_thin: t stays on chip
-      Act out = out_in ? *out_in : act(x.B, x.H, x.W, 16);
+    const int tk = p.cout == 16 ? 16 : 32;
+    if ((p.cout == 16 || (p.cout == 32 && m->arith == 2)) && x.ld <= tk && p.c0.CinP == tk && p.c1.CinP == tk && p.res.CinP == tk &&
+        (!out_in || out_in->ld == p.cout) && vs_resblock_thin_supported(x.ld, p.cout, p.cout)) {   // engine.py::resblock_thin: t stays on chip
+      Act out = out_in ? *out_in : act(x.B, x.H, x.W, p.cout);
       vs_resblock_thin_desc_t d;
       std::memset(&d, 0, sizeof(d));
       d.x = x.p; d.x_ld = x.ld; d.B = x.B; d.H = x.H; d.W = x.W; d.Cin = x.ld;
       d.w0_split = p.c0.split; d.w1_split = p.c1.split; d.wr_split = p.res.split;
       d.b0 = p.c0.bias; d.b1 = p.c1.bias; d.br = p.res.bias;
-      d.arith = m->arith; d.a_mul = A_MUL;
+      d.arith = m->arith; d.Cout = p.cout; d.a_mul = A_MUL;
       d.acc_mul0 = 1.f / (A_MUL * p.c0.w_mul); d.acc_mul1 = 1.f / (A_MUL * p.c1.w_mul); d.acc_mulr = 1.f / (A_MUL * p.res.w_mul);
       d.out = out.p; d.out_ld = out.ld;
       if (live()) chk(vs_resblock_thin(&d, st));

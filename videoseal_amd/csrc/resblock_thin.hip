@@ -244,27 +244,264 @@ __global__ __launch_bounds__(256, OCC) void resblock_thin_kernel(const RbArgs d,
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------------
+// The same block for 32 mid / output channels (<= 32 input channels): VideoSeal 1.0's 128^2 level (`downs.0.conv`, `ups.1.conv`), PixelSeal's
+// `inc`.  K = 32 of the matrix instruction is ONE tap x 32 channels, the 32 output channels are two 16-row halves, and the weights
+// (2 x 36 KB + 4 KB of f16 planes) no longer fit the register file next to the accumulators: they live in LDS, row-swizzled (16-byte unit
+// kb ^ (n >> 2) of the 64-byte row of output channel n: conflict-free fragment reads without padding), and a weight fragment is read once per
+// tap and used for every pixel group of the wave (3 groups in conv0, 2 in conv1).  145 KB of LDS: one persistent workgroup per CU, one patch
+// buffer (the next tile's patch waits in registers), three barriers per tile.  2 x f16 arithmetic only (three planes do not fit).
+constexpr int ROWB32 = 80;                                  // 32 halves + 16 bytes of padding: conflict-free 16-lane fragment reads
+constexpr int XITEMS32 = X_PX * 8;                          // float4 items of the patch (32 channels per pixel)
+constexpr int NXI32 = (XITEMS32 + 255) / 256;               // 8 per thread
+constexpr int XP32_BYTES = 2 * X_PX * ROWB32, TT32_BYTES = 2 * T_PX * ROWB32;
+constexpr int W32_CONV = 9 * 2 * 2 * 16 * 64, W32_RES = 2 * 2 * 16 * 64;       // [tap][half][plane][n][64 B]
+
+__global__ __launch_bounds__(256) void resblock_thin32_kernel(const RbArgs d, const int tiles_x, const int tiles_y, const int ntiles_total,
+                                                              const int tiles_per_wg) {
+  using AR = Arith<2>;
+  using A16 = Arith16<2>;
+  __shared__ __attribute__((aligned(16))) unsigned char smem[XP32_BYTES + TT32_BYTES + 2 * W32_CONV + W32_RES];
+  unsigned char* const Ps = smem;
+  unsigned char* const Tt = smem + XP32_BYTES;
+  unsigned char* const Wl = Tt + TT32_BYTES;                // conv0 | conv1 | res
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int n = lane & 15, kb = lane >> 4;
+
+  // ---- weights -> LDS (once per workgroup)
+  for (int u = tid; u < 2 * 2304; u += 256) {
+    const int conv = u / 2304, r = u - conv * 2304;
+    const int tap = r >> 8, r2 = r & 255;
+    const int half = r2 >> 7, plane = (r2 >> 6) & 1, nn = (r2 >> 2) & 15, kbu = r2 & 3;
+    const char* src = static_cast<const char*>(conv ? d.w1 : d.w0) + ((int64_t)(plane * 32 + half * 16 + nn) * 288 + tap * 32 + kbu * 8) * 2;
+    unsigned char* dst = Wl + conv * W32_CONV + ((((tap * 2 + half) * 2 + plane) * 16 + nn) * 64) + ((kbu ^ ((nn >> 2) & 3)) * 16);
+    *reinterpret_cast<u32x4*>(dst) = *reinterpret_cast<const u32x4*>(src);
+  }
+  {
+    const int u = tid;
+    const int half = u >> 7, plane = (u >> 6) & 1, nn = (u >> 2) & 15, kbu = u & 3;
+    const char* src = static_cast<const char*>(d.wr) + ((int64_t)(plane * 32 + half * 16 + nn) * 32 + kbu * 8) * 2;
+    *reinterpret_cast<u32x4*>(Wl + 2 * W32_CONV + (((half * 2 + plane) * 16 + nn) * 64) + ((kbu ^ ((nn >> 2) & 3)) * 16)) = *reinterpret_cast<const u32x4*>(src);
+  }
+  const int aw = n * 64 + ((kb ^ ((n >> 2) & 3)) * 16);     // this lane's 16 bytes inside a [16][64 B] weight fragment
+  float b0v[2][4], b1v[2][4], brv[2][4];
+#pragma unroll
+  for (int h = 0; h < 2; ++h)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int c = h * 16 + 4 * kb + e;
+      b0v[h][e] = d.b0 ? d.b0[c] : 0.f;
+      b1v[h][e] = d.b1 ? d.b1[c] : 0.f;
+      brv[h][e] = d.br ? d.br[c] : 0.f;
+    }
+
+  // ---- patch items of this thread: 8 float4 per pixel, item = tid + 256 i -> pixel (tid >> 3) + 32 i, channels 4 (tid & 7) ..
+  const int k4 = (tid & 7) * 4;
+  const bool cok = k4 < d.Cin;
+  int p_dy[NXI32], p_dx[NXI32], p_lds[NXI32];
+  bool p_have[NXI32];
+#pragma unroll
+  for (int i = 0; i < NXI32; ++i) {
+    const int prow = (tid >> 3) + 32 * i;
+    p_have[i] = prow < X_PX;
+    const int pr = p_have[i] ? prow : 0;
+    p_dy[i] = pr / X_W - 2;
+    p_dx[i] = pr % X_W - 2;
+    p_lds[i] = pr * ROWB32 + k4 * 2;
+  }
+  int a0[G0_PER_WAVE], t_i[G0_PER_WAVE];
+#pragma unroll
+  for (int gi = 0; gi < G0_PER_WAVE; ++gi) {
+    int i = 16 * (wave * G0_PER_WAVE + gi) + n;
+    t_i[gi] = i;
+    i = i < T_PX ? i : T_PX - 1;
+    a0[gi] = ((i / T_W) * X_W + (i % T_W)) * ROWB32 + kb * 16;
+  }
+  int a1[G1_PER_WAVE], ar[G1_PER_WAVE];
+#pragma unroll
+  for (int gi = 0; gi < G1_PER_WAVE; ++gi) {
+    const int row = wave * G1_PER_WAVE + gi;
+    a1[gi] = (row * T_W + n) * ROWB32 + kb * 16;
+    ar[gi] = ((row + 2) * X_W + (n + 2)) * ROWB32 + kb * 16;
+  }
+  const float amul = d.a_mul, am0 = d.acc_mul0, am1 = d.acc_mul1, amr = d.acc_mulr;
+
+  f32x4 rp[NXI32];
+  auto load_tile = [&](const int fb, const int y0, const int x0) __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < NXI32; ++i) {
+      const int iy = y0 + p_dy[i], ix = x0 + p_dx[i];
+      const bool ok = p_have[i] && cok && iy >= 0 && iy < d.H && ix >= 0 && ix < d.W;
+      const int cy = iy < 0 ? 0 : (iy >= d.H ? d.H - 1 : iy), cx = ix < 0 ? 0 : (ix >= d.W ? d.W - 1 : ix);
+      const f32x4 v = *reinterpret_cast<const f32x4*>(d.x + (int64_t)fb * d.x_sb + (int64_t)cy * d.x_sy + (int64_t)cx * d.x_sx + (cok ? k4 : 0));
+      rp[i] = ok ? v : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+  };
+  auto store_tile = [&]() __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < NXI32; ++i)
+      if (p_have[i]) {
+        u32x2 pl[2];
+        split4n<2>(rp[i], amul, pl);
+#pragma unroll
+        for (int p = 0; p < 2; ++p) *reinterpret_cast<u32x2*>(Ps + p * X_PX * ROWB32 + p_lds[i]) = pl[p];
+      }
+  };
+
+  const int t_begin = blockIdx.x * tiles_per_wg;
+  const int t_end = min(ntiles_total, t_begin + tiles_per_wg);
+  if (t_begin >= t_end) return;
+  int tx = t_begin % tiles_x, ty = (t_begin / tiles_x) % tiles_y, fb = t_begin / (tiles_x * tiles_y);
+  load_tile(fb, ty * TH, tx * TW);
+  store_tile();
+  __syncthreads();                                            // patch + weights visible
+  for (int t = t_begin; t < t_end; ++t) {
+    int ntx = tx + 1, nty = ty, nfb = fb;
+    if (ntx == tiles_x) { ntx = 0; if (++nty == tiles_y) { nty = 0; ++nfb; } }
+    if (t + 1 < t_end) load_tile(nfb, nty * TH, ntx * TW);
+    const int y0 = ty * TH, x0 = tx * TW;
+
+    // ---- conv0 on the 10 x 18 tile of t: 3 pixel groups x 2 channel halves per wave
+    {
+      f32x4 acc[G0_PER_WAVE][2];
+#pragma unroll
+      for (int gi = 0; gi < G0_PER_WAVE; ++gi)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) acc[gi][h] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int tap = 0; tap < 9; ++tap) {
+        bf16x8 wf[2][2];
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+          for (int p = 0; p < 2; ++p) wf[h][p] = *reinterpret_cast<const bf16x8*>(Wl + ((tap * 2 + h) * 2 + p) * 1024 + aw);
+        const int toff = ((tap / 3) * X_W + tap % 3) * ROWB32;
+#pragma unroll
+        for (int gi = 0; gi < G0_PER_WAVE; ++gi) {
+          bf16x8 xf[2];
+#pragma unroll
+          for (int p = 0; p < 2; ++p) xf[p] = *reinterpret_cast<const bf16x8*>(Ps + p * X_PX * ROWB32 + a0[gi] + toff);
+#pragma unroll
+          for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int q = 0; q < AR::NPROD; ++q) acc[gi][h] = A16::mfma(wf[h][AR::PB[q]], xf[AR::PA[q]], acc[gi][h]);
+        }
+      }
+#pragma unroll
+      for (int gi = 0; gi < G0_PER_WAVE; ++gi) {
+        const int i = t_i[gi];
+        if (i < T_PX) {
+          const int gy = y0 - 1 + i / T_W, gx = x0 - 1 + i % T_W;
+          const bool in = gy >= 0 && gy < d.H && gx >= 0 && gx < d.W;
+#pragma unroll
+          for (int h = 0; h < 2; ++h) {
+            f32x4 v;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = in ? vs_relu(acc[gi][h][e] * am0 + b0v[h][e]) : 0.f;
+            u32x2 pl[2];
+            split4n<2>(v, amul, pl);
+#pragma unroll
+            for (int p = 0; p < 2; ++p) *reinterpret_cast<u32x2*>(Tt + p * T_PX * ROWB32 + i * ROWB32 + (h * 16 + 4 * kb) * 2) = pl[p];
+          }
+        }
+      }
+    }
+    __syncthreads();                                            // t complete
+
+    // ---- conv1 + res_conv on the 8 x 16 output pixels: 2 rows x 2 channel halves per wave
+    {
+      f32x4 acc[G1_PER_WAVE][2], accr[G1_PER_WAVE][2];
+#pragma unroll
+      for (int gi = 0; gi < G1_PER_WAVE; ++gi)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) { acc[gi][h] = f32x4{0.f, 0.f, 0.f, 0.f}; accr[gi][h] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+      for (int tap = 0; tap < 9; ++tap) {
+        bf16x8 wf[2][2];
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+          for (int p = 0; p < 2; ++p) wf[h][p] = *reinterpret_cast<const bf16x8*>(Wl + W32_CONV + ((tap * 2 + h) * 2 + p) * 1024 + aw);
+        const int toff = ((tap / 3) * T_W + tap % 3) * ROWB32;
+#pragma unroll
+        for (int gi = 0; gi < G1_PER_WAVE; ++gi) {
+          bf16x8 tf[2];
+#pragma unroll
+          for (int p = 0; p < 2; ++p) tf[p] = *reinterpret_cast<const bf16x8*>(Tt + p * T_PX * ROWB32 + a1[gi] + toff);
+#pragma unroll
+          for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int q = 0; q < AR::NPROD; ++q) acc[gi][h] = A16::mfma(wf[h][AR::PB[q]], tf[AR::PA[q]], acc[gi][h]);
+        }
+      }
+      {
+        bf16x8 wf[2][2];
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+          for (int p = 0; p < 2; ++p) wf[h][p] = *reinterpret_cast<const bf16x8*>(Wl + 2 * W32_CONV + (h * 2 + p) * 1024 + aw);
+#pragma unroll
+        for (int gi = 0; gi < G1_PER_WAVE; ++gi) {
+          bf16x8 xf[2];
+#pragma unroll
+          for (int p = 0; p < 2; ++p) xf[p] = *reinterpret_cast<const bf16x8*>(Ps + p * X_PX * ROWB32 + ar[gi]);
+#pragma unroll
+          for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int q = 0; q < AR::NPROD; ++q) accr[gi][h] = A16::mfma(wf[h][AR::PB[q]], xf[AR::PA[q]], accr[gi][h]);
+        }
+      }
+#pragma unroll
+      for (int gi = 0; gi < G1_PER_WAVE; ++gi) {
+        const int y = y0 + wave * G1_PER_WAVE + gi, x = x0 + n;
+        if (y < d.H && x < d.W) {
+          float* orow = d.out + (((int64_t)fb * d.H + y) * d.W + x) * d.out_ld;
+#pragma unroll
+          for (int h = 0; h < 2; ++h) {
+            f32x4 v;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = vs_relu(acc[gi][h][e] * am1 + b1v[h][e]) + (accr[gi][h][e] * amr + brv[h][e]);
+            *reinterpret_cast<f32x4*>(orow + h * 16 + 4 * kb) = v;
+          }
+        }
+      }
+    }
+    __syncthreads();                              // every wave is done reading the patch
+    if (t + 1 < t_end) store_tile();
+    __syncthreads();                              // next patch visible; t may be overwritten
+    tx = ntx; ty = nty; fb = nfb;
+  }
+}
+
 }  // namespace
 
-extern "C" int vs_resblock_thin_supported(int cin_ld, int cmid, int cout) { return (cin_ld >= 4 && cin_ld <= 16 && (cin_ld & 3) == 0 && cmid == 16 && cout == 16) ? 1 : 0; }
+extern "C" int vs_resblock_thin_supported(int cin_ld, int cmid, int cout) {
+  if (cin_ld < 4 || (cin_ld & 3)) return 0;
+  return ((cmid == 16 && cout == 16 && cin_ld <= 16) || (cmid == 32 && cout == 32 && cin_ld <= 32)) ? 1 : 0;      // (32 channels: arith 2 only)
+}
 
 extern "C" int vs_resblock_thin(const vs_resblock_thin_desc_t* d, void* stream) {
   VS_REQUIRE(d && d->x && d->out && d->w0_split && d->w1_split && d->wr_split && d->B > 0 && d->H > 0 && d->W > 0);
-  VS_REQUIRE(vs_resblock_thin_supported(d->Cin, 16, 16) && d->x_ld >= d->Cin && (d->x_ld & 3) == 0 && d->out_ld >= 16 && (d->out_ld & 3) == 0);
-  VS_REQUIRE(d->arith == 2 || d->arith == 3);
+  const int C = d->Cout == 32 ? 32 : 16;
+  VS_REQUIRE(d->Cout == 0 || d->Cout == 16 || d->Cout == 32);
+  VS_REQUIRE(vs_resblock_thin_supported(d->Cin, C, C) && d->x_ld >= d->Cin && (d->x_ld & 3) == 0 && d->out_ld >= C && (d->out_ld & 3) == 0);
+  VS_REQUIRE(d->arith == 2 || (d->arith == 3 && C == 16));
   VS_REQUIRE((((uintptr_t)d->x | (uintptr_t)d->out | (uintptr_t)d->w0_split | (uintptr_t)d->w1_split | (uintptr_t)d->wr_split) & 15) == 0);
   RbArgs a{d->x, (int64_t)d->H * d->W * d->x_ld, (int64_t)d->W * d->x_ld, d->x_ld, d->B, d->H, d->W, d->Cin,
            d->w0_split, d->w1_split, d->wr_split, d->b0, d->b1, d->br, d->a_mul, d->acc_mul0, d->acc_mul1, d->acc_mulr, d->out, d->out_ld};
   const int tiles_x = (d->W + TW - 1) / TW, tiles_y = (d->H + TH - 1) / TH;
   const int64_t nt = (int64_t)d->B * tiles_x * tiles_y;
   if (nt > 0x7fffffffLL) return VS_ERR_UNSUPPORTED;
-  // persistent workgroups: two per CU (63 KB of LDS each), each walks a contiguous run of tiles (weights are loaded once per workgroup).
-  // (A single patch buffer + three workgroups per CU measured slower: embed 6.33 against 6.14 ms, profiles/r04g_*.)
-  const int64_t want = (int64_t)vs_num_cus() * 2;
+  // persistent workgroups, each walks a contiguous run of tiles (weights are loaded once per workgroup): two per CU for 16 channels (63 KB of LDS
+  // each; a single patch buffer + three per CU measured slower: embed 6.33 against 6.14 ms, profiles/r04g_*), one per CU for 32 (145 KB)
+  const int64_t want = (int64_t)vs_num_cus() * (C == 32 ? 1 : 2);
   const int per = (int)((nt + want - 1) / want);
   const int tpw = per < 1 ? 1 : per;
   const unsigned grid = (unsigned)((nt + tpw - 1) / tpw);
-  if (d->arith == 2) hipLaunchKernelGGL((resblock_thin_kernel<2, 2, 2>), dim3(grid), dim3(256), 0, (hipStream_t)stream, a, tiles_x, tiles_y, (int)nt, tpw);
+  if (C == 32) hipLaunchKernelGGL(resblock_thin32_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, a, tiles_x, tiles_y, (int)nt, tpw);
+  else if (d->arith == 2) hipLaunchKernelGGL((resblock_thin_kernel<2, 2, 2>), dim3(grid), dim3(256), 0, (hipStream_t)stream, a, tiles_x, tiles_y, (int)nt, tpw);
   else hipLaunchKernelGGL((resblock_thin_kernel<3, 1, 2>), dim3(grid), dim3(256), 0, (hipStream_t)stream, a, tiles_x, tiles_y, (int)nt, tpw);
   return vs_launch_status();
 }

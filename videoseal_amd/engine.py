@@ -803,21 +803,25 @@ class HipEngine:
         return out
 
     def _thin_ok(self, x: Act, p, out: Optional[Act]) -> bool:
-        """the whole ResnetBlock in one launch with t on chip (csrc/resblock_thin.hip): <= 16 input channels, 16 mid / output channels"""
-        return (self.thin_fused and self.use_split and "bn" not in p and "rms" not in p and p["cout"] == 16 and x.ld <= 16 and
-                p["c0"].CinP == 16 and p["c1"].CinP == 16 and p["res"].CinP == 16 and (out is None or out.ld == 16) and
-                bool(self.lib.vs_resblock_thin_supported(x.ld, 16, 16)))
+        """the whole ResnetBlock in one launch with t on chip (csrc/resblock_thin.hip): 16 mid / output channels from <= 16 input channels, or 32
+        from a 32-channel map (2 x f16 arithmetic only: its weights live in LDS)"""
+        c = p["cout"]
+        if not (self.thin_fused and self.use_split and "bn" not in p and "rms" not in p and c in (16, 32)):
+            return False
+        k = 16 if c == 16 else 32
+        return (x.ld <= k and p["c0"].CinP == k and p["c1"].CinP == k and p["res"].CinP == k and (out is None or out.ld == c) and
+                (c == 16 or self.arith == 2) and bool(self.lib.vs_resblock_thin_supported(x.ld, c, c)))
 
     def resblock_thin(self, x: Act, p, tag: str, out: Optional[Act] = None) -> Act:
-        ar = self.arith
+        ar, c = self.arith, p["cout"]
         c0, c1, cr = p["c0"].with_split(ar), p["c1"].with_split(ar), p["res"].with_split(ar)
         if out is None:
-            out = self.new_act(tag + ".o", x.B, x.H, x.W, 16)
+            out = self.new_act(tag + ".o", x.B, x.H, x.W, c)
         d = N.ResblockThinDesc()
         d.x, d.x_ld, d.B, d.H, d.W, d.Cin = N.ptr(x.t), x.ld, x.B, x.H, x.W, x.ld
         d.w0_split, d.w1_split, d.wr_split = N.ptr(c0.split), N.ptr(c1.split), N.ptr(cr.split)
         d.b0, d.b1, d.br = N.ptr(c0.bias), N.ptr(c1.bias), N.ptr(cr.bias)
-        d.arith, d.a_mul = ar, A_MUL
+        d.arith, d.Cout, d.a_mul = ar, c, A_MUL
         d.acc_mul0, d.acc_mul1, d.acc_mulr = 1.0 / (A_MUL * c0.w_mul), 1.0 / (A_MUL * c1.w_mul), 1.0 / (A_MUL * cr.w_mul)
         d.out, d.out_ld = N.ptr(out.t), out.ld
         timed = self.kernel_timers is not None and self.time_all_convs and not torch.cuda.is_current_stream_capturing()
@@ -827,7 +831,7 @@ class HipEngine:
         N.check(self.lib.vs_resblock_thin(C.byref(d), N.stream()), "vs_resblock_thin")
         if timed:
             ev1.record()
-            self.kernel_timers.append((f"resblock_thin {x.C}->16->16 @{x.H}x{x.W}", ev0, ev1, 2.0 * x.rows * 16 * (2 * 144 + 16)))
+            self.kernel_timers.append((f"resblock_thin {x.C}->{c}->{c} @{x.H}x{x.W}", ev0, ev1, 2.0 * x.rows * c * (2 * 9 * c + c)))
         return out
 
     _WHY = (f"with the 2 x f16 arithmetic an activation outside the f16 range of the operand split (|a| >= {65520.0 / A_MUL:.0f}; "

@@ -80,7 +80,7 @@ class ResblockThinDesc(C.Structure):
         ("x", C.c_void_p), ("x_ld", C.c_int64), ("B", C.c_int32), ("H", C.c_int32), ("W", C.c_int32), ("Cin", C.c_int32),
         ("w0_split", C.c_void_p), ("w1_split", C.c_void_p), ("wr_split", C.c_void_p),
         ("b0", C.c_void_p), ("b1", C.c_void_p), ("br", C.c_void_p),
-        ("arith", C.c_int32), ("reserved_", C.c_int32),
+        ("arith", C.c_int32), ("Cout", C.c_int32),
         ("a_mul", C.c_float), ("acc_mul0", C.c_float), ("acc_mul1", C.c_float), ("acc_mulr", C.c_float),
         ("out", C.c_void_p), ("out_ld", C.c_int64),
     ]
