@@ -249,16 +249,18 @@ __global__ __launch_bounds__(256, OCC) void resblock_thin_kernel(const RbArgs d,
 // `inc`.  K = 32 of the matrix instruction is ONE tap x 32 channels, the 32 output channels are two 16-row halves, and the weights
 // (2 x 36 KB + 4 KB of f16 planes) no longer fit the register file next to the accumulators: they live in LDS, row-swizzled (16-byte unit
 // kb ^ (n >> 2) of the 64-byte row of output channel n: conflict-free fragment reads without padding), and a weight fragment is read once per
-// tap and used for every pixel group of the wave (3 groups in conv0, 2 in conv1).  145 KB of LDS: one persistent workgroup per CU, one patch
+// tap and used for every pixel group of the wave.  145 KB of LDS: one persistent workgroup of EIGHT waves per CU (two per SIMD), one patch
 // buffer (the next tile's patch waits in registers), three barriers per tile.  2 x f16 arithmetic only (three planes do not fit).
 constexpr int ROWB32 = 80;                                  // 32 halves + 16 bytes of padding: conflict-free 16-lane fragment reads
+constexpr int NW32 = 8, NT32 = NW32 * 64;                   // eight waves: two per SIMD cover each other's LDS latencies (four waves: 122 us per block)
 constexpr int XITEMS32 = X_PX * 8;                          // float4 items of the patch (32 channels per pixel)
-constexpr int NXI32 = (XITEMS32 + 255) / 256;               // 8 per thread
+constexpr int NXI32 = (XITEMS32 + NT32 - 1) / NT32;         // 4 per thread
+constexpr int G0N = (12 + NW32 - 1) / NW32, G1N = 8 / NW32; // pixel groups per wave: conv0 groups w, w + 8 (< 12); conv1 row w
 constexpr int XP32_BYTES = 2 * X_PX * ROWB32, TT32_BYTES = 2 * T_PX * ROWB32;
 constexpr int W32_CONV = 9 * 2 * 2 * 16 * 64, W32_RES = 2 * 2 * 16 * 64;       // [tap][half][plane][n][64 B]
 
-__global__ __launch_bounds__(256) void resblock_thin32_kernel(const RbArgs d, const int tiles_x, const int tiles_y, const int ntiles_total,
-                                                              const int tiles_per_wg) {
+__global__ __launch_bounds__(NT32) void resblock_thin32_kernel(const RbArgs d, const int tiles_x, const int tiles_y, const int ntiles_total,
+                                                               const int tiles_per_wg) {
   using AR = Arith<2>;
   using A16 = Arith16<2>;
   __shared__ __attribute__((aligned(16))) unsigned char smem[XP32_BYTES + TT32_BYTES + 2 * W32_CONV + W32_RES];
@@ -267,11 +269,11 @@ __global__ __launch_bounds__(256) void resblock_thin32_kernel(const RbArgs d, co
   unsigned char* const Wl = Tt + TT32_BYTES;                // conv0 | conv1 | res
   const int tid = threadIdx.x;
   const int lane = tid & 63;
-  const int wave = tid >> 6;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int n = lane & 15, kb = lane >> 4;
 
   // ---- weights -> LDS (once per workgroup)
-  for (int u = tid; u < 2 * 2304; u += 256) {
+  for (int u = tid; u < 2 * 2304; u += NT32) {
     const int conv = u / 2304, r = u - conv * 2304;
     const int tap = r >> 8, r2 = r & 255;
     const int half = r2 >> 7, plane = (r2 >> 6) & 1, nn = (r2 >> 2) & 15, kbu = r2 & 3;
@@ -279,7 +281,7 @@ __global__ __launch_bounds__(256) void resblock_thin32_kernel(const RbArgs d, co
     unsigned char* dst = Wl + conv * W32_CONV + ((((tap * 2 + half) * 2 + plane) * 16 + nn) * 64) + ((kbu ^ ((nn >> 2) & 3)) * 16);
     *reinterpret_cast<u32x4*>(dst) = *reinterpret_cast<const u32x4*>(src);
   }
-  {
+  if (tid < 256) {
     const int u = tid;
     const int half = u >> 7, plane = (u >> 6) & 1, nn = (u >> 2) & 15, kbu = u & 3;
     const char* src = static_cast<const char*>(d.wr) + ((int64_t)(plane * 32 + half * 16 + nn) * 32 + kbu * 8) * 2;
@@ -297,35 +299,35 @@ __global__ __launch_bounds__(256) void resblock_thin32_kernel(const RbArgs d, co
       brv[h][e] = d.br ? d.br[c] : 0.f;
     }
 
-  // ---- patch items of this thread: 8 float4 per pixel, item = tid + 256 i -> pixel (tid >> 3) + 32 i, channels 4 (tid & 7) ..
+  // ---- patch items of this thread: 8 float4 per pixel, item = tid + NT32 i -> pixel (tid >> 3) + 64 i, channels 4 (tid & 7) ..
   const int k4 = (tid & 7) * 4;
   const bool cok = k4 < d.Cin;
   int p_dy[NXI32], p_dx[NXI32], p_lds[NXI32];
   bool p_have[NXI32];
 #pragma unroll
   for (int i = 0; i < NXI32; ++i) {
-    const int prow = (tid >> 3) + 32 * i;
+    const int prow = (tid >> 3) + (NT32 / 8) * i;
     p_have[i] = prow < X_PX;
     const int pr = p_have[i] ? prow : 0;
     p_dy[i] = pr / X_W - 2;
     p_dx[i] = pr % X_W - 2;
     p_lds[i] = pr * ROWB32 + k4 * 2;
   }
-  int a0[G0_PER_WAVE], t_i[G0_PER_WAVE];
+  int a0[G0N], t_i[G0N];
+  bool g0_have[G0N];
 #pragma unroll
-  for (int gi = 0; gi < G0_PER_WAVE; ++gi) {
-    int i = 16 * (wave * G0_PER_WAVE + gi) + n;
+  for (int gi = 0; gi < G0N; ++gi) {
+    const int g = wave + gi * NW32;
+    g0_have[gi] = g < 12;                                   // wave-uniform
+    int i = 16 * (g0_have[gi] ? g : 0) + n;
     t_i[gi] = i;
     i = i < T_PX ? i : T_PX - 1;
     a0[gi] = ((i / T_W) * X_W + (i % T_W)) * ROWB32 + kb * 16;
   }
-  int a1[G1_PER_WAVE], ar[G1_PER_WAVE];
-#pragma unroll
-  for (int gi = 0; gi < G1_PER_WAVE; ++gi) {
-    const int row = wave * G1_PER_WAVE + gi;
-    a1[gi] = (row * T_W + n) * ROWB32 + kb * 16;
-    ar[gi] = ((row + 2) * X_W + (n + 2)) * ROWB32 + kb * 16;
-  }
+  const int row1 = wave;                                    // conv1: one output row of 16 pixels per wave (G1N == 1)
+  const int a1 = (row1 * T_W + n) * ROWB32 + kb * 16;
+  const int ar = ((row1 + 2) * X_W + (n + 2)) * ROWB32 + kb * 16;
+  static_assert(G1N == 1, "one output row per wave");
   const float amul = d.a_mul, am0 = d.acc_mul0, am1 = d.acc_mul1, amr = d.acc_mulr;
 
   f32x4 rp[NXI32];
@@ -363,11 +365,11 @@ __global__ __launch_bounds__(256) void resblock_thin32_kernel(const RbArgs d, co
     if (t + 1 < t_end) load_tile(nfb, nty * TH, ntx * TW);
     const int y0 = ty * TH, x0 = tx * TW;
 
-    // ---- conv0 on the 10 x 18 tile of t: 3 pixel groups x 2 channel halves per wave
+    // ---- conv0 on the 10 x 18 tile of t: pixel groups wave, wave + 8 x 2 channel halves
     {
-      f32x4 acc[G0_PER_WAVE][2];
+      f32x4 acc[G0N][2];
 #pragma unroll
-      for (int gi = 0; gi < G0_PER_WAVE; ++gi)
+      for (int gi = 0; gi < G0N; ++gi)
 #pragma unroll
         for (int h = 0; h < 2; ++h) acc[gi][h] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -379,7 +381,8 @@ __global__ __launch_bounds__(256) void resblock_thin32_kernel(const RbArgs d, co
           for (int p = 0; p < 2; ++p) wf[h][p] = *reinterpret_cast<const bf16x8*>(Wl + ((tap * 2 + h) * 2 + p) * 1024 + aw);
         const int toff = ((tap / 3) * X_W + tap % 3) * ROWB32;
 #pragma unroll
-        for (int gi = 0; gi < G0_PER_WAVE; ++gi) {
+        for (int gi = 0; gi < G0N; ++gi) {
+          if (!g0_have[gi]) continue;
           bf16x8 xf[2];
 #pragma unroll
           for (int p = 0; p < 2; ++p) xf[p] = *reinterpret_cast<const bf16x8*>(Ps + p * X_PX * ROWB32 + a0[gi] + toff);
@@ -390,9 +393,9 @@ __global__ __launch_bounds__(256) void resblock_thin32_kernel(const RbArgs d, co
         }
       }
 #pragma unroll
-      for (int gi = 0; gi < G0_PER_WAVE; ++gi) {
+      for (int gi = 0; gi < G0N; ++gi) {
         const int i = t_i[gi];
-        if (i < T_PX) {
+        if (g0_have[gi] && i < T_PX) {
           const int gy = y0 - 1 + i / T_W, gx = x0 - 1 + i % T_W;
           const bool in = gy >= 0 && gy < d.H && gx >= 0 && gx < d.W;
 #pragma unroll
@@ -410,61 +413,48 @@ __global__ __launch_bounds__(256) void resblock_thin32_kernel(const RbArgs d, co
     }
     __syncthreads();                                            // t complete
 
-    // ---- conv1 + res_conv on the 8 x 16 output pixels: 2 rows x 2 channel halves per wave
+    // ---- conv1 + res_conv: output row `wave` x 2 channel halves
     {
-      f32x4 acc[G1_PER_WAVE][2], accr[G1_PER_WAVE][2];
+      f32x4 acc[2], accr[2];
 #pragma unroll
-      for (int gi = 0; gi < G1_PER_WAVE; ++gi)
-#pragma unroll
-        for (int h = 0; h < 2; ++h) { acc[gi][h] = f32x4{0.f, 0.f, 0.f, 0.f}; accr[gi][h] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+      for (int h = 0; h < 2; ++h) { acc[h] = f32x4{0.f, 0.f, 0.f, 0.f}; accr[h] = f32x4{0.f, 0.f, 0.f, 0.f}; }
 #pragma unroll
       for (int tap = 0; tap < 9; ++tap) {
-        bf16x8 wf[2][2];
-#pragma unroll
-        for (int h = 0; h < 2; ++h)
-#pragma unroll
-          for (int p = 0; p < 2; ++p) wf[h][p] = *reinterpret_cast<const bf16x8*>(Wl + W32_CONV + ((tap * 2 + h) * 2 + p) * 1024 + aw);
         const int toff = ((tap / 3) * T_W + tap % 3) * ROWB32;
+        bf16x8 tf[2];
 #pragma unroll
-        for (int gi = 0; gi < G1_PER_WAVE; ++gi) {
-          bf16x8 tf[2];
+        for (int p = 0; p < 2; ++p) tf[p] = *reinterpret_cast<const bf16x8*>(Tt + p * T_PX * ROWB32 + a1 + toff);
 #pragma unroll
-          for (int p = 0; p < 2; ++p) tf[p] = *reinterpret_cast<const bf16x8*>(Tt + p * T_PX * ROWB32 + a1[gi] + toff);
+        for (int h = 0; h < 2; ++h) {
+          bf16x8 wf[2];
 #pragma unroll
-          for (int h = 0; h < 2; ++h)
+          for (int p = 0; p < 2; ++p) wf[p] = *reinterpret_cast<const bf16x8*>(Wl + W32_CONV + ((tap * 2 + h) * 2 + p) * 1024 + aw);
 #pragma unroll
-            for (int q = 0; q < AR::NPROD; ++q) acc[gi][h] = A16::mfma(wf[h][AR::PB[q]], tf[AR::PA[q]], acc[gi][h]);
+          for (int q = 0; q < AR::NPROD; ++q) acc[h] = A16::mfma(wf[AR::PB[q]], tf[AR::PA[q]], acc[h]);
         }
       }
       {
-        bf16x8 wf[2][2];
+        bf16x8 xf[2];
 #pragma unroll
-        for (int h = 0; h < 2; ++h)
+        for (int p = 0; p < 2; ++p) xf[p] = *reinterpret_cast<const bf16x8*>(Ps + p * X_PX * ROWB32 + ar);
 #pragma unroll
-          for (int p = 0; p < 2; ++p) wf[h][p] = *reinterpret_cast<const bf16x8*>(Wl + 2 * W32_CONV + (h * 2 + p) * 1024 + aw);
+        for (int h = 0; h < 2; ++h) {
+          bf16x8 wf[2];
 #pragma unroll
-        for (int gi = 0; gi < G1_PER_WAVE; ++gi) {
-          bf16x8 xf[2];
+          for (int p = 0; p < 2; ++p) wf[p] = *reinterpret_cast<const bf16x8*>(Wl + 2 * W32_CONV + (h * 2 + p) * 1024 + aw);
 #pragma unroll
-          for (int p = 0; p < 2; ++p) xf[p] = *reinterpret_cast<const bf16x8*>(Ps + p * X_PX * ROWB32 + ar[gi]);
-#pragma unroll
-          for (int h = 0; h < 2; ++h)
-#pragma unroll
-            for (int q = 0; q < AR::NPROD; ++q) accr[gi][h] = A16::mfma(wf[h][AR::PB[q]], xf[AR::PA[q]], accr[gi][h]);
+          for (int q = 0; q < AR::NPROD; ++q) accr[h] = A16::mfma(wf[AR::PB[q]], xf[AR::PA[q]], accr[h]);
         }
       }
+      const int y = y0 + row1, x = x0 + n;
+      if (y < d.H && x < d.W) {
+        float* orow = d.out + (((int64_t)fb * d.H + y) * d.W + x) * d.out_ld;
 #pragma unroll
-      for (int gi = 0; gi < G1_PER_WAVE; ++gi) {
-        const int y = y0 + wave * G1_PER_WAVE + gi, x = x0 + n;
-        if (y < d.H && x < d.W) {
-          float* orow = d.out + (((int64_t)fb * d.H + y) * d.W + x) * d.out_ld;
+        for (int h = 0; h < 2; ++h) {
+          f32x4 v;
 #pragma unroll
-          for (int h = 0; h < 2; ++h) {
-            f32x4 v;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = vs_relu(acc[gi][h][e] * am1 + b1v[h][e]) + (accr[gi][h][e] * amr + brv[h][e]);
-            *reinterpret_cast<f32x4*>(orow + h * 16 + 4 * kb) = v;
-          }
+          for (int e = 0; e < 4; ++e) v[e] = vs_relu(acc[h][e] * am1 + b1v[h][e]) + (accr[h][e] * amr + brv[h][e]);
+          *reinterpret_cast<f32x4*>(orow + h * 16 + 4 * kb) = v;
         }
       }
     }
@@ -500,7 +490,7 @@ extern "C" int vs_resblock_thin(const vs_resblock_thin_desc_t* d, void* stream) 
   const int per = (int)((nt + want - 1) / want);
   const int tpw = per < 1 ? 1 : per;
   const unsigned grid = (unsigned)((nt + tpw - 1) / tpw);
-  if (C == 32) hipLaunchKernelGGL(resblock_thin32_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, a, tiles_x, tiles_y, (int)nt, tpw);
+  if (C == 32) hipLaunchKernelGGL(resblock_thin32_kernel, dim3(grid), dim3(NT32), 0, (hipStream_t)stream, a, tiles_x, tiles_y, (int)nt, tpw);
   else if (d->arith == 2) hipLaunchKernelGGL((resblock_thin_kernel<2, 2, 2>), dim3(grid), dim3(256), 0, (hipStream_t)stream, a, tiles_x, tiles_y, (int)nt, tpw);
   else hipLaunchKernelGGL((resblock_thin_kernel<3, 1, 2>), dim3(grid), dim3(256), 0, (hipStream_t)stream, a, tiles_x, tiles_y, (int)nt, tpw);
   return vs_launch_status();
