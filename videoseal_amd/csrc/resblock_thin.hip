@@ -108,6 +108,7 @@ __global__ __launch_bounds__(256, OCC) void resblock_thin_kernel(const RbArgs d,
 
   // ---- patch items of this thread (positions relative to the tile origin are constant)
   int p_dy[NXI], p_dx[NXI], p_lds[NXI];
+  unsigned p_rel[NXI];                                               // byte offset from the patch origin (interior tiles: no clamping, no 64-bit lane math)
   bool p_have[NXI];
   const int k4 = (tid & 3) * 4;
   const bool cok = k4 < d.Cin;
@@ -119,6 +120,15 @@ __global__ __launch_bounds__(256, OCC) void resblock_thin_kernel(const RbArgs d,
     p_dy[i] = prow / X_W - 2;
     p_dx[i] = prow % X_W - 2;
     p_lds[i] = prow * ROWB16 + k4 * 2;
+    p_rel[i] = (unsigned)(((int64_t)(prow / X_W) * d.x_sy + (int64_t)(prow % X_W) * d.x_sx + (cok ? k4 : 0)) * 4);
+  }
+  // tap offsets of this lane's half of every tap pair (the ninth tap has no partner: its second half re-reads tap 8 against zero weights)
+  int toffx[5], tofft[5];
+#pragma unroll
+  for (int s5 = 0; s5 < 5; ++s5) {
+    const int tap = 2 * s5 + hi < 9 ? 2 * s5 + hi : 8;
+    toffx[s5] = ((tap / 3) * X_W + tap % 3) * ROWB16;
+    tofft[s5] = ((tap / 3) * T_W + tap % 3) * ROWB16;
   }
   // ---- fragment addresses (bytes inside a plane): conv0 group gi of this wave = t pixels 16 (3 wave + gi) + n
   int a0[G0_PER_WAVE], t_i[G0_PER_WAVE];
@@ -141,6 +151,15 @@ __global__ __launch_bounds__(256, OCC) void resblock_thin_kernel(const RbArgs d,
 
   f32x4 rp[NXI];
   auto load_tile = [&](const int fb, const int y0, const int x0) __attribute__((always_inline)) {
+    if (y0 >= 2 && x0 >= 2 && y0 + TH + 2 <= d.H && x0 + TW + 2 <= d.W) {         // workgroup-uniform: the patch lies inside the image
+      const char* base = reinterpret_cast<const char*>(d.x + (int64_t)fb * d.x_sb + (int64_t)(y0 - 2) * d.x_sy + (int64_t)(x0 - 2) * d.x_sx);
+#pragma unroll
+      for (int i = 0; i < NXI; ++i) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(base + (p_have[i] ? p_rel[i] : 0u));
+        rp[i] = cok ? v : f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+      return;
+    }
 #pragma unroll
     for (int i = 0; i < NXI; ++i) {
       const int iy = y0 + p_dy[i], ix = x0 + p_dx[i];
@@ -183,8 +202,7 @@ __global__ __launch_bounds__(256, OCC) void resblock_thin_kernel(const RbArgs d,
       f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int s = 0; s < 5; ++s) {
-        const int tap0 = 2 * s, tap1 = 2 * s + 1 < 9 ? 2 * s + 1 : 8;      // (the ninth tap has no partner: zero weights on the second half)
-        const int off = a0[gi] + (hi ? ((tap1 / 3) * X_W + tap1 % 3) * ROWB16 : ((tap0 / 3) * X_W + tap0 % 3) * ROWB16);
+        const int off = a0[gi] + toffx[s];
         bf16x8 xf[NP];
 #pragma unroll
         for (int p = 0; p < NP; ++p) xf[p] = *reinterpret_cast<const bf16x8*>(Ps + p * X_PX * ROWB16 + off);
@@ -216,8 +234,7 @@ __global__ __launch_bounds__(256, OCC) void resblock_thin_kernel(const RbArgs d,
       f32x4 acc = {0.f, 0.f, 0.f, 0.f}, accr = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int s = 0; s < 5; ++s) {
-        const int tap0 = 2 * s, tap1 = 2 * s + 1 < 9 ? 2 * s + 1 : 8;
-        const int off = a1[gi] + (hi ? ((tap1 / 3) * T_W + tap1 % 3) * ROWB16 : ((tap0 / 3) * T_W + tap0 % 3) * ROWB16);
+        const int off = a1[gi] + tofft[s];
         bf16x8 tf[NP];
 #pragma unroll
         for (int p = 0; p < NP; ++p) tf[p] = *reinterpret_cast<const bf16x8*>(Tt + p * T_PX * ROWB16 + off);
