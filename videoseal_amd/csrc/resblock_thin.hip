@@ -226,6 +226,9 @@ __global__ __launch_bounds__(256, OCC) void resblock_thin_kernel(const RbArgs d,
         for (int p = 0; p < NP; ++p) *reinterpret_cast<u32x2*>(Tt + p * T_PX * ROWB16 + i * ROWB16 + 8 * kb) = pl[p];
       }
     }
+    // two patch buffers: the next patch goes to LDS HERE, before this tile's output stores are issued -- behind them its `s_waitcnt vmcnt` would
+    // also wait for the stores' completion (loads and stores share the counter); the other buffer was last read in tile t - 1
+    if (NBUF == 2 && t + 1 < t_end) store_tile(buf ^ 1);
     __syncthreads();                                              // t complete
 
     // ---- conv1 + res_conv on the 8 x 16 output pixels
@@ -260,8 +263,10 @@ __global__ __launch_bounds__(256, OCC) void resblock_thin_kernel(const RbArgs d,
         *reinterpret_cast<f32x4*>(d.out + (((int64_t)fb * d.H + y) * d.W + x) * d.out_ld + 4 * kb) = v;
       }
     }
-    if (NBUF == 1) __syncthreads();               // single patch buffer: every wave must be done reading it
-    if (t + 1 < t_end) store_tile(NBUF == 2 ? buf ^ 1 : 0);   // (two buffers: the other one was last read in tile t - 1, behind that tile's second barrier)
+    if (NBUF == 1) {                              // single patch buffer: every wave must be done reading it
+      __syncthreads();
+      if (t + 1 < t_end) store_tile(0);
+    }
     __syncthreads();                              // next patch visible; t may be overwritten
     tx = ntx; ty = nty; fb = nfb;
   }
@@ -438,6 +443,7 @@ __global__ __launch_bounds__(NT32) void resblock_thin32_kernel(const RbArgs d, c
     __syncthreads();                                            // t complete
 
     // ---- conv1 + res_conv: output row `wave` x 2 channel halves
+    f32x4 outv[2];
     {
       f32x4 acc[2], accr[2];
 #pragma unroll
@@ -470,21 +476,22 @@ __global__ __launch_bounds__(NT32) void resblock_thin32_kernel(const RbArgs d, c
           for (int q = 0; q < AR::NPROD; ++q) accr[h] = A16::mfma(wf[AR::PB[q]], xf[AR::PA[q]], accr[h]);
         }
       }
+#pragma unroll
+      for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) outv[h][e] = vs_relu(acc[h][e] * am1 + b1v[h][e]) + (accr[h][e] * amr + brv[h][e]);
+    }
+    __syncthreads();                              // every wave is done reading the patch
+    if (t + 1 < t_end) store_tile();              // (waits for the patch loads only: this tile's output stores are issued below, behind it --
+    __syncthreads();                              //  loads and stores share `vmcnt`)  next patch visible; t may be overwritten
+    {
       const int y = y0 + row1, x = x0 + n;
       if (y < d.H && x < d.W) {
         float* orow = d.out + (((int64_t)fb * d.H + y) * d.W + x) * d.out_ld;
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
-          f32x4 v;
-#pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = vs_relu(acc[h][e] * am1 + b1v[h][e]) + (accr[h][e] * amr + brv[h][e]);
-          *reinterpret_cast<f32x4*>(orow + h * 16 + 4 * kb) = v;
-        }
+        for (int h = 0; h < 2; ++h) *reinterpret_cast<f32x4*>(orow + h * 16 + 4 * kb) = outv[h];
       }
     }
-    __syncthreads();                              // every wave is done reading the patch
-    if (t + 1 < t_end) store_tile();
-    __syncthreads();                              // next patch visible; t may be overwritten
     tx = ntx; ty = nty; fb = nfb;
   }
 }
