@@ -681,7 +681,7 @@ __device__ __forceinline__ float jnd_at_ring(const float* Lr, const int cslot, c
 // (No waves-per-SIMD hint and no wrapper around the body: `__launch_bounds__(256, 3 | 4)` as well as a __forceinline__ body called from two
 // __global__ wrappers made hipcc spill 16-40 bytes per lane; a scratch reload waits for every older global load -- the row prefetch -- and the
 // JND form ran 40 % slower: 175-180 -> 245-265 us at 32 x 768^2, profiles/r04_tail_forms.md.)
-template <bool JND>
+template <bool JND, int CD>
 __global__ __launch_bounds__(256) void embed_tail_stream_kernel(TailArgs a, JndTaps k, const int strip) {
   extern __shared__ float dyn_smem[];
   float* Lr = dyn_smem;                                        // [RING][TLW] luminance ring (JND only)
@@ -689,7 +689,7 @@ __global__ __launch_bounds__(256) void embed_tail_stream_kernel(TailArgs a, JndT
   __shared__ int ty_lo[2][SUBR], ty_n[2][SUBR], s_wy0[2];
   __shared__ float ty_w[2][SUBR][4];
   __shared__ int s_xhi, s_xlo;
-  const int dwsz = a.Cd * DW_W * DW_H;
+  constexpr int dwsz = CD * DW_W * DW_H;
   const int x0 = blockIdx.x * TTW, y0 = blockIdx.y * strip, f = blockIdx.z;
   const int ys_end = min(a.H, y0 + strip);
   const int64_t plane = (int64_t)a.H * a.W;
@@ -736,8 +736,8 @@ __global__ __launch_bounds__(256) void embed_tail_stream_kernel(TailArgs a, JndT
   if (ka >= a.total_key) ka = a.total_key - 1;
   if (kb >= a.total_key) kb = a.total_key - 1;
   const int splane = a.Sh * a.Sw;
-  const float* dka = a.delta + (int64_t)ka * a.Cd * splane;
-  const float* dkb = a.delta + (int64_t)kb * a.Cd * splane;
+  const float* dka = a.delta + (int64_t)ka * CD * splane;
+  const float* dkb = a.delta + (int64_t)kb * CD * splane;
   const float* hml = a.hmap_lowres ? a.hmap_lowres + (int64_t)f * splane : nullptr;
   __syncthreads();                                             // s_xlo / s_xhi
   const int wx0 = s_xlo, dww = s_xhi - s_xlo;
@@ -759,15 +759,39 @@ __global__ __launch_bounds__(256) void embed_tail_stream_kernel(TailArgs a, JndT
       if (threadIdx.x == 0) s_wy0[b] = wy0;
     }
     float* Dw = DwB + b * dwsz;
-    for (int i = threadIdx.x; i < dwh * dww; i += 256) {
-      const int yy = i / dww, xx = i - yy * dww;
-      const int sp = (wy0 + yy) * a.Sw + wx0 + xx;
-      const float hm = hml ? hml[sp] : 1.f;
-      for (int c = 0; c < a.Cd; ++c) {
-        float v = wa * dka[c * splane + sp];
-        if (wb != 0.f) v += wb * dkb[c * splane + sp];
-        Dw[c * (DW_W * DW_H) + yy * DW_W + xx] = hm * v;
+    // the window (<= 136 x 12 elements) in batches of four per thread: every load of a batch is issued before the first value is used -- a loop
+    // that loads, combines and stores one element at a time is a chain of dependent L2 round trips, and hipcc guards the registers such a loop
+    // re-uses with `s_waitcnt vmcnt(0)`, which also waits for the row prefetch issued just before
+    const int nel = dwh * dww;
+    for (int i0 = 0; i0 < nel; i0 += 4 * 256) {
+      int sp[4], lo[4];
+      float hmv[4], da[4][CD], db[4][CD];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int i = min(i0 + q * 256 + (int)threadIdx.x, nel - 1);
+        const int yy = i / dww, xx = i - yy * dww;
+        sp[q] = (wy0 + yy) * a.Sw + wx0 + xx;
+        lo[q] = yy * DW_W + xx;
       }
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        hmv[q] = hml ? hml[sp[q]] : 1.f;
+#pragma unroll
+        for (int c = 0; c < CD; ++c) {
+          da[q][c] = dka[c * splane + sp[q]];
+          db[q][c] = wb != 0.f ? dkb[c * splane + sp[q]] : 0.f;
+        }
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        if (i0 + q * 256 + (int)threadIdx.x < nel) {
+#pragma unroll
+          for (int c = 0; c < CD; ++c) {
+            float v = wa * da[q][c];
+            if (wb != 0.f) v += wb * db[q][c];
+            Dw[c * (DW_W * DW_H) + lo[q]] = hmv[q] * v;
+          }
+        }
     }
   };
   const int ymax_need = min(a.H - 1, ys_end + (JND ? HALO - 1 : -1));     // last row any thread of this strip reads
@@ -850,17 +874,19 @@ __global__ __launch_bounds__(256) void embed_tail_stream_kernel(TailArgs a, JndT
         const int ly = (SG * it + j) & (SUBR - 1);
         float d[3] = {0.f, 0.f, 0.f};
         const int basep = (ty_lo[sb][ly] - s_wy0[sb]) * DW_W + (tx.lo - wx0);
-        tail_taps<3, DW_H>(d, Dw, a.Cd, basep, tx.n, ty_n[sb][ly], wxs, ty_w[sb][ly]);
+        tail_taps<3, DW_H>(d, Dw, CD, basep, tx.n, ty_n[sb][ly], wxs, ty_w[sb][ly]);
         const bool fwd_order = JND && a.attenuate == 2;
         if (JND && !fwd_order)
-          for (int c = 0; c < a.Cd; ++c) d[c] = hm * d[c];
+#pragma unroll
+          for (int c = 0; c < CD; ++c) d[c] = hm * d[c];
         const int64_t pix = (int64_t)y * a.W + x;
         if (a.preds_w)
-          for (int c = 0; c < a.Cd; ++c) a.preds_w[((int64_t)f * a.Cd + c) * plane + pix] = d[c];
+#pragma unroll
+          for (int c = 0; c < CD; ++c) a.preds_w[((int64_t)f * CD + c) * plane + pix] = d[c];
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
           const float p = j < 2 ? hist[j][c] : cu[j - 2][c];
-          float v = blend_px(a.scaling_i, a.scaling_w, p, d[a.Cd == 1 ? 0 : c], hm, fwd_order);
+          float v = blend_px(a.scaling_i, a.scaling_w, p, d[CD == 1 ? 0 : c], hm, fwd_order);
           if (a.clamp) v = v <= 0.f ? 0.f : (v >= 1.f ? 1.f : v);      // (NaN passes)
           outf[c * plane + pix] = v;
         }
@@ -989,8 +1015,11 @@ extern "C" int vs_embed_tail(const vs_tail_desc_t* d, void* stream) {
     if (const char* e = getenv("VS_TAIL_STRIP_TEST")) { const int v = atoi(e); if (v >= 4) strip = (v + 3) / 4 * 4; }     // tests: every strip height, per call
     dim3 gs((unsigned)cols, (d->H + strip - 1) / strip, d->F);
     const size_t lds_w = (size_t)2 * d->Cd * DW_W * DW_H * sizeof(float);
-    if (full_jnd) hipLaunchKernelGGL((embed_tail_stream_kernel<true>), gs, dim3(256), lds_w + RING * TLW * sizeof(float), (hipStream_t)stream, a, k, strip);
-    else hipLaunchKernelGGL((embed_tail_stream_kernel<false>), gs, dim3(256), lds_w, (hipStream_t)stream, a, k, strip);
+    const size_t lds_j = lds_w + RING * TLW * sizeof(float);
+    if (full_jnd && d->Cd == 1) hipLaunchKernelGGL((embed_tail_stream_kernel<true, 1>), gs, dim3(256), lds_j, (hipStream_t)stream, a, k, strip);
+    else if (full_jnd) hipLaunchKernelGGL((embed_tail_stream_kernel<true, 3>), gs, dim3(256), lds_j, (hipStream_t)stream, a, k, strip);
+    else if (d->Cd == 1) hipLaunchKernelGGL((embed_tail_stream_kernel<false, 1>), gs, dim3(256), lds_w, (hipStream_t)stream, a, k, strip);
+    else hipLaunchKernelGGL((embed_tail_stream_kernel<false, 3>), gs, dim3(256), lds_w, (hipStream_t)stream, a, k, strip);
     return vs_launch_status();
   }
   if (d->io_u8) {
