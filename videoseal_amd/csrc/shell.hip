@@ -308,7 +308,7 @@ __device__ __forceinline__ float jnd_at(const float* L, int stride, int x, int y
       gx += k.sx[i * 3 + j] * v;
       gy += k.sy[i * 3 + j] * v;
     }
-  float cm = sqrtf(gx * gx + gy * gy);
+  float cm = sqrtf(__builtin_fmaf(gx, gx, gy * gy));
   // cm^2.4 through the hardware log2/exp2 (1 ulp each): relative error <= ~1e-6 on a term that enters the frame scaled by
   // 1/255 * delta * scaling_w, i.e. < 1e-8 absolute -- ocml's powf costs ~10x the instructions
   cm = 16.f * (cm > 0.f ? __builtin_amdgcn_exp2f(2.4f * __builtin_amdgcn_logf(cm)) : 0.f) / (cm * cm + 676.f);
@@ -379,13 +379,15 @@ __device__ __forceinline__ void tail_taps(float (&d)[3], const float* Dw, const 
     for (int jy = 0; jy < NT; ++jy)
 #pragma unroll
       for (int jx = 0; jx < NT; ++jx) v[jy][jx] = p[oy[jy] + ox[jx]];
+    // explicit fma chains: `r += wx * v` with r starting at 0 leaves hipcc an `a * b + c * d` to contract, and it fuses EITHER product depending on
+    // the surrounding code -- two kernels calling this function disagreed in the last bit (round 4)
     float dc = 0.f;
 #pragma unroll
     for (int jy = 0; jy < NT; ++jy) {
       float r = 0.f;
 #pragma unroll
-      for (int jx = 0; jx < NT; ++jx) r += wx[jx] * v[jy][jx];
-      dc += wy[jy] * r;
+      for (int jx = 0; jx < NT; ++jx) r = __builtin_fmaf(wx[jx], v[jy][jx], r);
+      dc = __builtin_fmaf(wy[jy], r, dc);
     }
     d[c] = dc;
   }
@@ -403,7 +405,7 @@ __device__ __forceinline__ void tail_taps(float (&d)[3], const float* Dw, const 
 __device__ __forceinline__ float jnd_finish(float la_sum, float gx, float gy) {
   float la = la_sum / 32.f;
   la = la <= 127.f ? 17.f * (1.f - sqrtf(la / 127.f + 1e-5f)) : 3.f / 128.f * (la - 127.f) + 3.f;
-  float cm = sqrtf(gx * gx + gy * gy);
+  float cm = sqrtf(__builtin_fmaf(gx, gx, gy * gy));
   cm = 16.f * (cm > 0.f ? __builtin_amdgcn_exp2f(2.4f * __builtin_amdgcn_logf(cm)) : 0.f) / (cm * cm + 676.f);
   cm = 0.117f * cm;
   const float h = la + cm - 0.3f * fminf(la, cm);
@@ -531,7 +533,7 @@ __global__ __launch_bounds__(256) void embed_tail_kernel(TailArgs a, JndTaps k) 
       const float hm = hml ? hml[sp] : 1.f;
       for (int c = 0; c < a.Cd; ++c) {
         float v = wa * dka[c * splane + sp];
-        if (wb != 0.f) v += wb * dkb[c * splane + sp];
+        if (wb != 0.f) v = __builtin_fmaf(wb, dkb[c * splane + sp], v);
         Dw[c * (DW_W * DWH) + yy * DW_W + xx] = hm * v;
       }
     }
@@ -671,7 +673,7 @@ __device__ __forceinline__ float jnd_at_ring(const float* Lr, const int cslot, c
       gy += k.sy[i * 3 + j] * v;
     }
   }
-  float cm = sqrtf(gx * gx + gy * gy);
+  float cm = sqrtf(__builtin_fmaf(gx, gx, gy * gy));
   cm = 16.f * (cm > 0.f ? __builtin_amdgcn_exp2f(2.4f * __builtin_amdgcn_logf(cm)) : 0.f) / (cm * cm + 676.f);
   cm = 0.117f * cm;
   const float h = la + cm - 0.3f * fminf(la, cm);
@@ -788,7 +790,7 @@ __global__ __launch_bounds__(256) void embed_tail_stream_kernel(TailArgs a, JndT
 #pragma unroll
           for (int c = 0; c < CD; ++c) {
             float v = wa * da[q][c];
-            if (wb != 0.f) v += wb * db[q][c];
+            if (wb != 0.f) v = __builtin_fmaf(wb, db[q][c], v);
             Dw[c * (DW_W * DW_H) + lo[q]] = hmv[q] * v;
           }
         }
