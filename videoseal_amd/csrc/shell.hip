@@ -122,10 +122,10 @@ __global__ __launch_bounds__(256) void resize_pre_kernel(const T* __restrict__ s
       for (int jx = 0; jx < MAXT; ++jx)
         if (jx < tx.n) {
 #pragma unroll
-          for (int c = 0; c < 3; ++c) r[c] += wxs[jx] * Lp[(c * RS_WH + jy) * RS_WW + jx];
+          for (int c = 0; c < 3; ++c) r[c] = __builtin_fmaf(wxs[jx], Lp[(c * RS_WH + jy) * RS_WW + jx], r[c]);     // (explicit fma chains: see tail_taps)
         }
 #pragma unroll
-      for (int c = 0; c < 3; ++c) acc[c] += wy * r[c];
+      for (int c = 0; c < 3; ++c) acc[c] = __builtin_fmaf(wy, r[c], acc[c]);
     }
   } else {
     for (int jy = 0; jy < ty.n; ++jy) {
@@ -135,9 +135,9 @@ __global__ __launch_bounds__(256) void resize_pre_kernel(const T* __restrict__ s
       for (int jx = 0; jx < tx.n; ++jx) {
         const float wx = tap_w(tx, jx);
         for (int c = 0; c < 3; ++c)
-          if (c < C) r[c] += wx * Px<T>::ld(base, plane, c, row + jx);
+          if (c < C) r[c] = __builtin_fmaf(wx, Px<T>::ld(base, plane, c, row + jx), r[c]);
       }
-      for (int c = 0; c < 3; ++c) acc[c] += wy * r[c];
+      for (int c = 0; c < 3; ++c) acc[c] = __builtin_fmaf(wy, r[c], acc[c]);
     }
   }
   const int64_t opix = ((int64_t)oy * ow + ox);
@@ -232,7 +232,7 @@ __global__ __launch_bounds__(256) void resize_pre_stream_kernel(const float* __r
         for (int jx = 0; jx < MAXT; ++jx)
           if (jx < tx.n) {
 #pragma unroll
-            for (int c = 0; c < 3; ++c) r[c] += wxs[jx] * Lp[c * RS_INW + jx];
+            for (int c = 0; c < 3; ++c) r[c] = __builtin_fmaf(wxs[jx], Lp[c * RS_INW + jx], r[c]);
           }
 #pragma unroll
         for (int c = 0; c < 3; ++c) Hr[((row & (RS_RING - 1)) * 3 + c) * RSO_W + oxl] = r[c];
@@ -249,7 +249,7 @@ __global__ __launch_bounds__(256) void resize_pre_stream_kernel(const float* __r
         const float wy = tap_w(ty, jy);
         const float* hp = Hr + (((ty.lo + jy) & (RS_RING - 1)) * 3) * RSO_W + oxl;
 #pragma unroll
-        for (int c = 0; c < 3; ++c) acc[c] += wy * hp[c * RSO_W];
+        for (int c = 0; c < 3; ++c) acc[c] = __builtin_fmaf(wy, hp[c * RSO_W], acc[c]);
       }
       if (ox_ok) {
         const int64_t opix = ((int64_t)oy_next * ow + ox);
