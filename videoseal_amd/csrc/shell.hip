@@ -1006,13 +1006,16 @@ extern "C" int vs_embed_tail(const vs_tail_desc_t* d, void* stream) {
     // VS_TAIL_STRIP overrides the strip height
     static const int env_strip = [] { const char* e = getenv("VS_TAIL_STRIP"); return e ? atoi(e) : 0; }();
     const int64_t cols = (d->W + TTW - 1) / TTW;
-    // strip height, from tools/bench_tail_sweep.py (profiles/r04h_tail_sweep.log, 768^2; us for 16 / 32 / 128 frames): without the luminance phase
-    // short strips win (32 rows: 44 / 107 / 384 against 69 / 122 / 411 for 96); with it the strip should be tall (4 halo rows + the pipeline fill
-    // per strip) as long as the launch still has three workgroups per CU: 96 rows 138 / 177 / 661, 48 rows 91 / 180 / 671, 32 rows 107 / 183 / 684
+    // strip height, from tools/bench_tail_sweep.py (profiles/r04zz_tail_sweep.log, 768^2; us for 16 / 32 / 128 frames): without the luminance phase
+    // short strips win (32 rows 43 / 104 / 364, 48 rows 44 / 94 / 360, 96 rows 61 / 114 / 354); with it the strip should be tall (4 halo rows + the
+    // pipeline fill per strip) as long as the launch still has three workgroups per CU: 96 rows 115 / 155 / 503, 48 rows 76 / 151 / 510, 32 rows 87 / 152 / 521
     int strip = 32;
-    if (full_jnd)
+    if (full_jnd) {
       for (int cand : {96, 48})
         if (cols * ((d->H + cand - 1) / cand) * d->F >= 768) { strip = cand; break; }
+    } else if (cols * ((d->H + 47) / 48) * d->F >= 1024) {
+      strip = 48;
+    }
     if (env_strip >= 4) strip = (env_strip + 3) / 4 * 4;
     if (const char* e = getenv("VS_TAIL_STRIP_TEST")) { const int v = atoi(e); if (v >= 4) strip = (v + 3) / 4 * 4; }     // tests: every strip height, per call
     dim3 gs((unsigned)cols, (d->H + strip - 1) / strip, d->F);
