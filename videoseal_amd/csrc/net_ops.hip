@@ -89,9 +89,16 @@ __global__ __launch_bounds__(256) void layernorm_act_small_kernel(const float* _
 // [plane][c / 16][row][16] of value * a_mul; rowptr then returns planes + row * 32 bytes (out_ld = 8 floats) and the channel range is
 // padded with zeros to a multiple of 16.
 struct PlanesOut { int64_t cstride, pstride; float a_mul; int Cp; };      // bytes between 16-channel chunks / between the two planes; channels incl. padding
-template <int NT, int LPP, typename RowPtr>
+template <int NT, int LPP, bool WLDS, typename RowPtr>
 __device__ __forceinline__ void ln_rows_from_lds_impl(const float* __restrict__ s, int stride, int npx, int C, const float* __restrict__ lnw,
-                                                      const float* __restrict__ lnb, float eps, int out_ld, RowPtr rowptr, const PlanesOut pl) {
+                                                      const float* __restrict__ lnb, float eps, int out_ld, RowPtr rowptr, const PlanesOut pl,
+                                                      float* s_wb) {
+  // WLDS: the affine parameters are copied to LDS once per workgroup (one coalesced round trip) -- read per channel group from global memory they
+  // are a chain of C / (4 LPP) dependent L2 round trips in every workgroup's tail (`LD LD s_waitcnt vmcnt(0)` per group in the ISA)
+  if (WLDS) {
+    for (int i = threadIdx.x; i < C; i += NT) { s_wb[i] = lnw[i]; s_wb[C + i] = lnb[i]; }
+    __syncthreads();
+  }
   const int q = threadIdx.x & (LPP - 1);
   const int C4 = (C + 3) >> 2, O4 = pl.cstride ? pl.Cp >> 2 : out_ld >> 2;
   const float invC = 1.0f / (float)C;
@@ -125,7 +132,7 @@ __device__ __forceinline__ void ln_rows_from_lds_impl(const float* __restrict__ 
         const f32x4 v = *reinterpret_cast<const f32x4*>(r + 4 * c4);
 #pragma unroll
         for (int e = 0; e < 4; ++e)
-          if (4 * c4 + e < C) o[e] = lnw[4 * c4 + e] * ((v[e] - mean) * rden) + lnb[4 * c4 + e];
+          if (4 * c4 + e < C) o[e] = (WLDS ? s_wb[4 * c4 + e] : lnw[4 * c4 + e]) * ((v[e] - mean) * rden) + (WLDS ? s_wb[C + 4 * c4 + e] : lnb[4 * c4 + e]);
       }
       if (pl.cstride) {
         vsconv::u32x2 hi, lo;
@@ -144,12 +151,21 @@ __device__ __forceinline__ void ln_rows_from_lds_impl(const float* __restrict__ 
 template <int NT, typename RowPtr>
 __device__ __forceinline__ void ln_rows_from_lds(const float* __restrict__ s, int stride, int npx, int C, const float* __restrict__ lnw,
                                                  const float* __restrict__ lnb, float eps, int out_ld, RowPtr rowptr,
-                                                 const PlanesOut pl = PlanesOut{0, 0, 1.f, 0}) {
-  if (npx * 8 > NT) ln_rows_from_lds_impl<NT, 4>(s, stride, npx, C, lnw, lnb, eps, out_ld, rowptr, pl);
-  else if (npx * 16 > NT) ln_rows_from_lds_impl<NT, 8>(s, stride, npx, C, lnw, lnb, eps, out_ld, rowptr, pl);
-  else if (npx * 32 > NT) ln_rows_from_lds_impl<NT, 16>(s, stride, npx, C, lnw, lnb, eps, out_ld, rowptr, pl);
-  else if (npx * 64 > NT) ln_rows_from_lds_impl<NT, 32>(s, stride, npx, C, lnw, lnb, eps, out_ld, rowptr, pl);
-  else ln_rows_from_lds_impl<NT, 64>(s, stride, npx, C, lnw, lnb, eps, out_ld, rowptr, pl);
+                                                 const PlanesOut pl = PlanesOut{0, 0, 1.f, 0}, float* s_wb = nullptr) {
+  // s_wb: 2 C floats of LDS that no wave reads any more (the caller's barrier has passed), or nullptr
+  if (s_wb) {
+    if (npx * 8 > NT) ln_rows_from_lds_impl<NT, 4, true>(s, stride, npx, C, lnw, lnb, eps, out_ld, rowptr, pl, s_wb);
+    else if (npx * 16 > NT) ln_rows_from_lds_impl<NT, 8, true>(s, stride, npx, C, lnw, lnb, eps, out_ld, rowptr, pl, s_wb);
+    else if (npx * 32 > NT) ln_rows_from_lds_impl<NT, 16, true>(s, stride, npx, C, lnw, lnb, eps, out_ld, rowptr, pl, s_wb);
+    else if (npx * 64 > NT) ln_rows_from_lds_impl<NT, 32, true>(s, stride, npx, C, lnw, lnb, eps, out_ld, rowptr, pl, s_wb);
+    else ln_rows_from_lds_impl<NT, 64, true>(s, stride, npx, C, lnw, lnb, eps, out_ld, rowptr, pl, s_wb);
+    return;
+  }
+  if (npx * 8 > NT) ln_rows_from_lds_impl<NT, 4, false>(s, stride, npx, C, lnw, lnb, eps, out_ld, rowptr, pl, nullptr);
+  else if (npx * 16 > NT) ln_rows_from_lds_impl<NT, 8, false>(s, stride, npx, C, lnw, lnb, eps, out_ld, rowptr, pl, nullptr);
+  else if (npx * 32 > NT) ln_rows_from_lds_impl<NT, 16, false>(s, stride, npx, C, lnw, lnb, eps, out_ld, rowptr, pl, nullptr);
+  else if (npx * 64 > NT) ln_rows_from_lds_impl<NT, 32, false>(s, stride, npx, C, lnw, lnb, eps, out_ld, rowptr, pl, nullptr);
+  else ln_rows_from_lds_impl<NT, 64, false>(s, stride, npx, C, lnw, lnb, eps, out_ld, rowptr, pl, nullptr);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -304,10 +320,11 @@ __global__ __launch_bounds__(NT) void dwconv7_ln_tiled_kernel(const float* __res
     }
     __syncthreads();
   }
+  // (the halo tile s_in is dead behind the last chunk's barrier: its first 2 C floats hold the LayerNorm parameters)
   ln_rows_from_lds<NT>(s_out, (int)ld + 4, TH * TW, C, lnw, lnb, eps, (int)out_ld, [&](int p) -> float* {
     const int gy = y0 + p / TW, gx = x0 + p % TW;
     return (gy < H && gx < W) ? out + (((int64_t)b * H + gy) * W + gx) * out_ld : nullptr;
-  }, pl);
+  }, pl, (2 * C <= (TH + 6) * (TW + 6) * CP) ? s_in : nullptr);
 }
 
 template <int TH, int TW, int CCH, int NT>
