@@ -328,6 +328,8 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pl_kernel(const vs_conv_desc_t
     // step's first MFMA -- after that step's prefetch reads have been issued)
     __builtin_amdgcn_s_waitcnt(0xC07F);       // this wave's fragment reads have returned: the stages they came from may be refilled
     __builtin_amdgcn_s_barrier();
+    // (a barrier per TWO steps -- legal with this ring: the stage a step refills was last read two steps earlier, waits for two tiles in
+    // flight instead of three -- measured identical, 0.1828 vs 0.1832 ms: the barrier is not what the K loop waits for)
   };
   auto chunk = [&](auto parc, const int cc) __attribute__((always_inline)) {
     const bool last = cc + 1 >= spt;
@@ -404,8 +406,59 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pl_kernel(const vs_conv_desc_t
     pcls[i] = (y == 0 ? 0 : (y >= d.H - 1 ? 2 : 1)) * 3 + (x == 0 ? 0 : (x >= d.W - 1 ? 2 : 1));
   }
   scale_all<TM, TN>(acc, d.acc_mul);          // back to real units (exact: a power of two)
+  // Whole-width tiles (every layer of the shipped cards) take straight-line forms of the two epilogue sections: the general forms guard
+  // every 4-channel group against N / n_store per lane, and across those divergent regions hipcc waits vmcnt(0) in front of every use --
+  // each bias / table / residual fetch became its own dependent round trip (12 + 24 of them per wave, with one workgroup per CU nothing
+  // else covers them), and since stores count in vmcnt too, each one also waited for the previous store's acknowledge.
+  const bool full = n0 + BN <= d.N;
   if (sk == 1) {   // v = act(acc (+ border-class table) + bias1) (+ bias2: the activation sits between the two K phases)
     const float* tb = (d.tile_hint & VS_CONV_PRE) ? d.a_scale + (int64_t)fb * d.a_scale_ld : nullptr;
+    if (full && d.bias && (n2 == 0 || d.bias2)) {
+      // three passes over the register tile -- + bias1 (+ table), activation, + bias2 -- with the switch on d.act around the whole second
+      // pass: a switch per element made the section ~100 tiny basic blocks (hipcc's wait-count bookkeeping gives up across them)
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        f32x4 b1[4], tv[TM][4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) b1[q] = *reinterpret_cast<const f32x4*>(d.bias + cbase[j] + 8 * q);
+        if (tb) {
+#pragma unroll
+          for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) tv[i][q] = *reinterpret_cast<const f32x4*>(tb + pcls[i] * d.N + cbase[j] + 8 * q);
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+          for (int i = 0; i < TM; ++i) {
+            f32x4 v = grp(i, j, q) + b1[q];
+            if (tb) v += tv[i][q];
+            put(i, j, q, v);
+          }
+        __builtin_amdgcn_sched_barrier(0);      // (one channel group at a time: scheduled as one region the loads of all TN groups are hoisted and spill)
+      }
+      auto act_tile = [&](auto actc) __attribute__((always_inline)) {
+        constexpr int ACT = decltype(actc)::value;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = vs_apply_act(acc[i][j][e], ACT < 0 ? d.act : ACT);
+      };
+      if (d.act == VS_ACT_RELU) act_tile(std::integral_constant<int, VS_ACT_RELU>{});
+      else if (d.act != VS_ACT_NONE) act_tile(std::integral_constant<int, -1>{});
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        f32x4 b2[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) b2[q] = n2 > 0 ? *reinterpret_cast<const f32x4*>(d.bias2 + cbase[j] + 8 * q) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+          for (int i = 0; i < TM; ++i) put(i, j, q, grp(i, j, q) + b2[q]);
+      }
+    } else {
 #pragma unroll
     for (int j = 0; j < TN; ++j)
 #pragma unroll
@@ -422,6 +475,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pl_kernel(const vs_conv_desc_t
           put(i, j, q, v + b2);
         }
       }
+    }
   }
   if (n2 > 0) {                               // phase 2 on top: its own pipeline fill, no fragment prefetch across the (few) steps
     scale_all<TM, TN>(acc, 1.f / d.acc_mul2);
@@ -475,50 +529,69 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pl_kernel(const vs_conv_desc_t
         }
     return;
   }
+  auto store_all = [&](auto fullc) __attribute__((always_inline)) {
+    constexpr bool FULL = decltype(fullc)::value;
 #pragma unroll
-  for (int i = 0; i < TM; ++i) {
-    float* orow = d.out ? d.out + mrow[i] * d.out_ld + d.out_coff : nullptr;
-    const float* rrow = d.res ? d.res + mrow[i] * d.res_ld : nullptr;
-    char* prow = d.out_pl ? reinterpret_cast<char*>(d.out_pl) + mrow[i] * 32 : nullptr;
-    const int64_t opstride = (int64_t)(d.N / BK) * cstride;
+    for (int i = 0; i < TM; ++i) {
+      float* orow = d.out ? d.out + mrow[i] * d.out_ld + d.out_coff : nullptr;
+      const float* rrow = d.res ? d.res + mrow[i] * d.res_ld : nullptr;
+      f32x4 rv[TN][4];                            // FULL: the residual groups of this pixel block in flight at once
+      if constexpr (FULL) {
+        if (rrow) {
 #pragma unroll
-    for (int j = 0; j < TN; ++j)
+          for (int j = 0; j < TN; ++j)
 #pragma unroll
-      for (int q2 = 0; q2 < 2; ++q2) {           // the two channel groups q = 2 q2, 2 q2 + 1 of one 16-channel chunk
-        f32x4 v[2];
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-          const int n = cbase[j] + 8 * (2 * q2 + h);
-          v[h] = f32x4{0.f, 0.f, 0.f, 0.f};      // columns in [N, n_store) are written as zeros
-          if (n >= d.n_store) continue;
-          if (n < d.N) {
-            v[h] = grp(i, j, 2 * q2 + h);
-            if (rrow) v[h] += *reinterpret_cast<const f32x4*>(rrow + n);
-            if (n + 4 > d.N)
-#pragma unroll
-              for (int e = 0; e < 4; ++e)
-                if (n + e >= d.N) v[h][e] = 0.f;
-          }
-          if (orow) *reinterpret_cast<f32x4*>(orow + n) = v[h];
-        }
-        // the next conv's operand planes: hi / lo f16 of v * a_mul, [plane][n / 16][pixel][16].  A lane holds channels 4g .. 4g+3 and
-        // 8 + 4g .. 8 + 4g+3 of its pixel; v_permlane32_swap trades the middle pieces between the half-waves (same pixel, g = 0 / 1) so
-        // that g = 0 writes channels 0..7 and g = 1 channels 8..15 as ONE 16-byte store each: a tile row becomes 512 contiguous bytes
-        const int n16 = n0 + (wn * TN + j) * 32 + 16 * q2;          // wave-uniform (N % 16 == 0 with planes output)
-        if (prow && n16 < d.N) {
-          u32x2 h0, l0, h1, l1;
-          split4h(v[0], d.a_mul, h0, l0);
-          split4h(v[1], d.a_mul, h1, l1);
-          const auto sh0 = __builtin_amdgcn_permlane32_swap(h0[0], h1[0], false, false);
-          const auto sh1 = __builtin_amdgcn_permlane32_swap(h0[1], h1[1], false, false);
-          const auto sl0 = __builtin_amdgcn_permlane32_swap(l0[0], l1[0], false, false);
-          const auto sl1 = __builtin_amdgcn_permlane32_swap(l0[1], l1[1], false, false);
-          char* dst = prow + (int64_t)(n16 >> 4) * cstride + g_e * 16;
-          *reinterpret_cast<u32x4*>(dst) = u32x4{sh0[0], sh1[0], sh0[1], sh1[1]};
-          *reinterpret_cast<u32x4*>(dst + opstride) = u32x4{sl0[0], sl1[0], sl0[1], sl1[1]};
+            for (int q = 0; q < 4; ++q) rv[j][q] = *reinterpret_cast<const f32x4*>(rrow + cbase[j] + 8 * q);
         }
       }
-  }
+      char* prow = d.out_pl ? reinterpret_cast<char*>(d.out_pl) + mrow[i] * 32 : nullptr;
+      const int64_t opstride = (int64_t)(d.N / BK) * cstride;
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int q2 = 0; q2 < 2; ++q2) {           // the two channel groups q = 2 q2, 2 q2 + 1 of one 16-channel chunk
+          f32x4 v[2];
+#pragma unroll
+          for (int h = 0; h < 2; ++h) {
+            const int n = cbase[j] + 8 * (2 * q2 + h);
+            if constexpr (FULL) {
+              v[h] = grp(i, j, 2 * q2 + h);
+              if (rrow) v[h] += rv[j][2 * q2 + h];
+            } else {
+              v[h] = f32x4{0.f, 0.f, 0.f, 0.f};      // columns in [N, n_store) are written as zeros
+              if (n >= d.n_store) continue;
+              if (n < d.N) {
+                v[h] = grp(i, j, 2 * q2 + h);
+                if (rrow) v[h] += *reinterpret_cast<const f32x4*>(rrow + n);
+                if (n + 4 > d.N)
+#pragma unroll
+                  for (int e = 0; e < 4; ++e)
+                    if (n + e >= d.N) v[h][e] = 0.f;
+              }
+            }
+            if (orow) *reinterpret_cast<f32x4*>(orow + n) = v[h];
+          }
+          // the next conv's operand planes: hi / lo f16 of v * a_mul, [plane][n / 16][pixel][16].  A lane holds channels 4g .. 4g+3 and
+          // 8 + 4g .. 8 + 4g+3 of its pixel; v_permlane32_swap trades the middle pieces between the half-waves (same pixel, g = 0 / 1) so
+          // that g = 0 writes channels 0..7 and g = 1 channels 8..15 as ONE 16-byte store each: a tile row becomes 512 contiguous bytes
+          const int n16 = n0 + (wn * TN + j) * 32 + 16 * q2;          // wave-uniform (N % 16 == 0 with planes output)
+          if (prow && (FULL || n16 < d.N)) {
+            u32x2 h0, l0, h1, l1;
+            split4h(v[0], d.a_mul, h0, l0);
+            split4h(v[1], d.a_mul, h1, l1);
+            const auto sh0 = __builtin_amdgcn_permlane32_swap(h0[0], h1[0], false, false);
+            const auto sh1 = __builtin_amdgcn_permlane32_swap(h0[1], h1[1], false, false);
+            const auto sl0 = __builtin_amdgcn_permlane32_swap(l0[0], l1[0], false, false);
+            const auto sl1 = __builtin_amdgcn_permlane32_swap(l0[1], l1[1], false, false);
+            char* dst = prow + (int64_t)(n16 >> 4) * cstride + g_e * 16;
+            *reinterpret_cast<u32x4*>(dst) = u32x4{sh0[0], sh1[0], sh0[1], sh1[1]};
+            *reinterpret_cast<u32x4*>(dst + opstride) = u32x4{sl0[0], sl1[0], sl0[1], sl1[1]};
+          }
+        }
+    }
+  };
+  if (full) store_all(std::true_type{});
+  else store_all(std::false_type{});
 }
 
 // fp32 NHWC rows [rows][ld] -> operand planes [2][C/16][rows][16] f16 of x * a_mul (hi, lo): the entry of a planes chain

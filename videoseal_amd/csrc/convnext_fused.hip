@@ -64,6 +64,15 @@ struct CnxArgs {
   int abl;                    // ablation bits (tools/bench_cnx.py, VS_CNX_ABL): 1 no GELU, 2 no pwconv2 MFMAs, 4 no pwconv1 MFMAs, 8 no output stores
 };
 
+// The ablation bits are a compile-time switch (make EXTRA=-DVS_CNX_ABLATION, for tools/bench_cnx.py): as run-time branches around the MFMA
+// groups they cut the K loop into ~100 basic blocks, and at every join hipcc's wait-count bookkeeping fell back to s_waitcnt vmcnt(0) in
+// front of the first LDS read -- i.e. each iteration waited for the weight block it had just requested two iterations ahead.
+#ifdef VS_CNX_ABLATION
+#define CNX_ABL(a) ((a).abl)
+#else
+#define CNX_ABL(a) 0
+#endif
+
 template <int KS1, int PB, bool STATS>
 __global__ __launch_bounds__(256) void cnx_block_kernel(const CnxArgs a) {
   using AR = Arith<2>;
@@ -154,7 +163,7 @@ __global__ __launch_bounds__(256) void cnx_block_kernel(const CnxArgs a) {
       const bf16x8 wlo = *reinterpret_cast<const bf16x8*>(Wb + (ks * 2 + 1) * 1024 + lane * 16);
 #pragma unroll
       for (int pb = 0; pb < PB; ++pb) {
-        if (a.abl & 4) continue;
+        if (CNX_ABL(a) & 4) continue;
         f32x16& acc = (ks & 1) ? accb[pb] : acc1[pb];
         if constexpr (STATS) {      // D1[pixel][h-channel]: the same fragments with the operands swapped -- a lane then holds ONE channel for 16 pixels
           acc = AR::mfma(tnf[pb][ks][0], wlo, acc);      // (identical products and order: the values equal the APPLY pass's bit for bit)
@@ -202,7 +211,7 @@ __global__ __launch_bounds__(256) void cnx_block_kernel(const CnxArgs a) {
           for (int v = 0; v < 8; v += 2) {
             const int e = 8 * s + v;
             const f32x2 x1 = f32x2{acc1[pb][e], acc1[pb][e + 1]} * a.acc_mul1 + f32x2{b1[e >> 2][e & 3], b1[e >> 2][(e & 3) + 1]};
-            const f32x2 h = (a.abl & 1) ? x1 : gelu2(x1);
+            const f32x2 h = (CNX_ABL(a) & 1) ? x1 : gelu2(x1);
             const f32x2 h3 = h * f32x2{sc[e >> 2][e & 3], sc[e >> 2][(e & 3) + 1]} + f32x2{be[e >> 2][e & 3], be[e >> 2][(e & 3) + 1]};   // the unfused A transform (a_mul = 1)
             hi[v] = (_Float16)h3[0];
             hi[v + 1] = (_Float16)h3[1];
@@ -222,7 +231,7 @@ __global__ __launch_bounds__(256) void cnx_block_kernel(const CnxArgs a) {
           const bf16x8 wlo = *reinterpret_cast<const bf16x8*>(W2b + ((nb * 2 + s) * 2 + 1) * 1024 + lane * 16);
 #pragma unroll
           for (int pb = 0; pb < PB; ++pb) {
-            if (a.abl & 2) continue;
+            if (CNX_ABL(a) & 2) continue;
             acc2[pb][nb] = AR::mfma(alo[pb][s], whi, acc2[pb][nb]);
             acc2[pb][nb] = AR::mfma(ahi[pb][s], wlo, acc2[pb][nb]);
             acc2[pb][nb] = AR::mfma(ahi[pb][s], whi, acc2[pb][nb]);
@@ -235,31 +244,42 @@ __global__ __launch_bounds__(256) void cnx_block_kernel(const CnxArgs a) {
     __builtin_amdgcn_s_barrier();
   }
   if constexpr (!STATS) {
-    if (a.abl & 8) return;
+    if (CNX_ABL(a) & 8) return;
     // D2[pixel][channel]: lane holds channel nb * 32 + r32 of pixels 8 (e >> 2) + 4 hf + (e & 3) of its block.  Written through LDS (the weight
     // stages are free now) so that the block's 32 pixels x C channels leave as whole rows: with out_ld == C that is 32 * C * 4 contiguous bytes,
     // 16 bytes per lane -- the direct form (one 128-byte piece per store instruction, 16 * NB * PB instructions) cost 53 of 183 us.
     float* T = reinterpret_cast<float*>(smem) + wave * (32 * (C + 4));          // [32 pixels][C + 4] floats per wave (pad: bank spread)
     static_assert(4 * 32 * (C + 4) * 4 <= NST * BLK_KB * 1024, "transpose tile must fit the weight stages");
+    constexpr int C4 = C / 4, ITS = (32 * C4) / 64;
+    float b2v[NB];                               // (before the residual rows: vmcnt retires in order, the transpose below needs only these)
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) b2v[nb] = a.bias2[nb * 32 + r32];
 #pragma unroll
     for (int pb = 0; pb < PB; ++pb) {
+      const int64_t pbase = p0 + pb * 32;
+      // the residual rows first, all in flight at once (tn's registers are dead): fetched inside the store loop each one was a dependent
+      // round trip -- load, s_waitcnt vmcnt(0) (which also waits for the previous store's acknowledge), store -- 12 to 24 of them in a row
+      f32x4 rr[ITS];
+#pragma unroll
+      for (int it = 0; it < ITS; ++it) {
+        const int idx = it * 64 + lane;
+        const int px = idx / C4, c4 = idx - px * C4;
+        rr[it] = *reinterpret_cast<const f32x4*>(a.res + (pbase + px) * a.res_ld + 4 * c4);
+      }
 #pragma unroll
       for (int nb = 0; nb < NB; ++nb) {
-        const float b2 = a.bias2[nb * 32 + r32];
+        const float b2 = b2v[nb];
 #pragma unroll
         for (int e = 0; e < 16; ++e) T[(8 * (e >> 2) + 4 * hf + (e & 3)) * (C + 4) + nb * 32 + r32] = acc2[pb][nb][e] * a.acc_mul2 + b2;
       }
       __builtin_amdgcn_s_waitcnt(0xC07F);
       __builtin_amdgcn_wave_barrier();
-      const int64_t pbase = p0 + pb * 32;
-      constexpr int C4 = C / 4;
 #pragma unroll
-      for (int it = 0; it < (32 * C4) / 64; ++it) {
+      for (int it = 0; it < ITS; ++it) {
         const int idx = it * 64 + lane;
         const int px = idx / C4, c4 = idx - px * C4;
         const f32x4 t = *reinterpret_cast<const f32x4*>(T + px * (C + 4) + 4 * c4);
-        const f32x4 rr = *reinterpret_cast<const f32x4*>(a.res + (pbase + px) * a.res_ld + 4 * c4);
-        *reinterpret_cast<f32x4*>(a.out + (pbase + px) * a.out_ld + 4 * c4) = t + rr;
+        *reinterpret_cast<f32x4*>(a.out + (pbase + px) * a.out_ld + 4 * c4) = t + rr[it];
       }
       __builtin_amdgcn_s_waitcnt(0xC07F);
       __builtin_amdgcn_wave_barrier();

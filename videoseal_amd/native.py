@@ -13,7 +13,8 @@ from typing import Optional
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libvideoseal_hip.so")
+# VIDEOSEAL_LIB: another build of the same ABI (same-box A/B of two source trees, tools/ab_libs.sh); the default is the in-tree library
+LIB_PATH = os.environ.get("VIDEOSEAL_LIB") or os.path.join(_HERE, "csrc", "libvideoseal_hip.so")
 
 ACT_NONE, ACT_RELU, ACT_GELU, ACT_TANH, ACT_SILU = 0, 1, 2, 3, 4
 PAD_ZERO, PAD_REFLECT = 0, 1
