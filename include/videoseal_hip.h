@@ -320,7 +320,8 @@ int vs_absmax(const float* x, int64_t n, unsigned* bits, void* stream);
  * stats = 1 writes the GRN partial sums [rows / 32][4C] (finished by vs_grn_scale_from_partials), stats = 0 recomputes pwconv1 + GELU, applies
  * scale [B][scale_ld] / beta and runs pwconv2 (+ bias2 + res -> out; out may alias res).  tn_planes: the f16 operand planes of the LayerNorm output
  * (vs_dwconv7_ln_planes); wimg: vs_cnx_block_image_bytes(C) bytes packed by the host (engine.pack_cnx_block: per 32 h-channels the W1 rows, the
- * W2 columns in the k order the accumulator layout dictates, bias1 / beta). */
+ * W2 columns in the k order the accumulator layout dictates, bias1 / beta).  stats bit 1 (value 2) selects the serial kernel instead of the
+ * software-pipelined one (identical results; for tests and tools). */
 int vs_cnx_block_supported(int C, int64_t rows, int HW);
 int64_t vs_cnx_block_image_bytes(int C);
 int vs_cnx_block(const void* tn_planes, const void* wimg, int C, int64_t rows, int HW, int stats, float acc_mul1, float acc_mul2, const float* scale,

@@ -729,3 +729,27 @@ def test_fused_convnext_blocks_match_the_unfused_path_and_the_oracle(vs10):
     ref = R.detect(sd, spec, imgs)["preds"]
     assert (p1 - p0).abs().max() < 2e-5, float((p1 - p0).abs().max())
     assert (p1 - ref).abs().max() < 1e-4 and (p0 - ref).abs().max() < 1e-4
+
+
+def test_pipelined_convnext_block_kernel_equals_the_serial_one_bit_for_bit(vs10):
+    """csrc/convnext_fused.hip: cnx_pipe_kernel (pwconv1 of block hb + 1 issued under the GELU / GRN arithmetic of block hb, separate rings for
+    W1 and W2) multiplies the same products in the same order as cnx_block_kernel (stats bit 1 selects it): identical logits (both channel counts, 32- and 64-pixel tiles per wave)"""
+    spec, sd, model = vs10
+    imgs = synthetic_frames(4, 256, 256, seed=78).cuda()
+    eng = model._engine()
+    if eng.arith_net["X"] != 2 or not eng.fused_blocks:
+        pytest.skip("2 x f16 arithmetic with fused blocks only")
+    orig = eng.lib.vs_cnx_block
+    p_pipe = model.detect(imgs, is_video=False)["preds"].clone()
+
+    class Serial:
+        def __call__(self, *a):
+            a = list(a)
+            a[5] = int(a[5]) | 2
+            return orig(*a)
+    try:
+        eng.lib.vs_cnx_block = Serial()
+        p_serial = model.detect(imgs, is_video=False)["preds"].clone()
+    finally:
+        eng.lib.vs_cnx_block = orig
+    assert torch.equal(p_pipe, p_serial), float((p_pipe - p_serial).abs().max())

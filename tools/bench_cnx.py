@@ -34,5 +34,11 @@ for C, HW in ((96, 4096), (192, 1024)):
     st = lambda: N.check(L.vs_cnx_block(N.ptr(tn), N.ptr(img), C, rows, HW, 1, am1, am2, None, 0, None, None, 0, None, 0, N.ptr(part), N.stream()), "s")
     ap = lambda: N.check(L.vs_cnx_block(N.ptr(tn), N.ptr(img), C, rows, HW, 0, am1, am2, N.ptr(scale), 4 * C, N.ptr(b2), N.ptr(cur), C, N.ptr(cur), C, None, N.stream()), "a")
     flop1 = 2 * rows * C * 4 * C
-    ts, ta = timeit(st), timeit(ap)
-    print(f"C={C} rows={rows}: stats {ts*1e3:6.1f} us ({flop1/ts/1e9:6.0f} TF-eq)   apply {ta*1e3:6.1f} us ({2*flop1/ta/1e9:6.0f} TF-eq)   abl={os.environ.get('VS_CNX_ABL','0')}")
+    sts = lambda: N.check(L.vs_cnx_block(N.ptr(tn), N.ptr(img), C, rows, HW, 3, am1, am2, None, 0, None, None, 0, None, 0, N.ptr(part), N.stream()), "s")
+    aps = lambda: N.check(L.vs_cnx_block(N.ptr(tn), N.ptr(img), C, rows, HW, 2, am1, am2, N.ptr(scale), 4 * C, N.ptr(b2), N.ptr(cur), C, N.ptr(cur), C, None, N.stream()), "a")
+    # ablation bits only act in a build with -DVS_CNX_ABLATION (make EXTRA=-DVS_CNX_ABLATION; VIDEOSEAL_LIB=<that build>)
+    for abl in ([0] if "--abl" not in sys.argv else [0, 1, 2, 4, 6, 7, 8, 16, 17, 23]):
+        os.environ["VS_CNX_ABL"] = str(abl)
+        ts, ta, tss, tas = timeit(st), timeit(ap), timeit(sts), timeit(aps)
+        print(f"C={C} rows={rows} abl={abl:2d}: pipelined stats {ts*1e3:6.1f} us ({flop1/ts/1e9:6.0f} TF-eq) apply {ta*1e3:6.1f} us ({2*flop1/ta/1e9:6.0f} TF-eq)"
+              f"   serial stats {tss*1e3:6.1f} us apply {tas*1e3:6.1f} us", flush=True)

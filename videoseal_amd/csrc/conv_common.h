@@ -94,6 +94,42 @@ __device__ __forceinline__ void scale_all(f32x16 (&acc)[TM][TN], const float mul
       for (int e = 0; e < 16; ++e) acc[i][j][e] *= mul;
 }
 
+// Store of a WHOLE register tile in the C[row][column] layout (column = lane & 31, row = (e & 3) + 8 (e >> 2) + 4 (lane >> 5) of a 32 x 32
+// block; blocks i down, j across) without per-lane guards: `ob` / `rb` are wave-uniform addresses of the wave's first element in out / res
+// (rb may be null), every element is that base + one 32-bit lane offset + a wave-uniform row offset + j * 128 (an instruction immediate).
+// The guarded general forms keep a 64-bit address per element, and hipcc waits vmcnt(0) between a residual fetch and its store -- which
+// also waits for the previous store's acknowledge: 16 * TN dependent round trips per row group; here a row group's residual values are
+// fetched in one batch.
+template <int TM, int TN>
+__device__ __forceinline__ void store_tile_full(const f32x16 (&acc)[TM][TN], char* const ob, const int out_ld, const char* const rb, const int res_ld,
+                                                const int r_e, const int g_e) {
+  const unsigned olane = (unsigned)(4 * g_e * out_ld + r_e) * 4u;
+  const unsigned rlane = (unsigned)(4 * g_e * res_ld + r_e) * 4u;
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+    float rv[16][TN];
+    if (rb) {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const unsigned ro = (unsigned)((i * 32 + (e & 3) + 8 * (e >> 2)) * res_ld) * 4u;       // wave-uniform
+#pragma unroll
+        for (int j = 0; j < TN; ++j) rv[e][j] = *reinterpret_cast<const float*>(rb + (size_t)(ro + rlane) + j * 128);
+      }
+    }
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const unsigned oo = (unsigned)((i * 32 + (e & 3) + 8 * (e >> 2)) * out_ld) * 4u;         // wave-uniform
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        float v = acc[i][j][e];
+        if (rb) v += rv[e][j];
+        *reinterpret_cast<float*>(ob + (size_t)(oo + olane) + j * 128) = v;
+      }
+      if ((e & 3) == 3) __builtin_amdgcn_sched_barrier(0);      // (scheduled as one region, the values of the whole tile are formed first: spills)
+    }
+  }
+}
+
 template <int TM, int TN>
 __device__ __forceinline__ void apply_act_all(f32x16 (&acc)[TM][TN], const float (&b1)[TN], const float (&b2)[TN], int act) {
   // act is wave-uniform: one branch around the whole register tile instead of a switch per element

@@ -239,6 +239,11 @@ __global__ __launch_bounds__(512, 2) void gemm_pl_kernel(const vs_conv_desc_t d,
   for (int j = 0; j < TN; ++j) col[j] = n0 + (wn * TN + j) * 32 + r_e;
   if (d.split_k > 1) {
     float* ws = d.splitk_ws + (int64_t)ks * M * d.splitk_ld;
+    if (m0 + GBM <= M && n0 + BN <= d.N && (int64_t)GBM * d.splitk_ld * 4 < (1LL << 31)) {
+      store_tile_full<TM, TN>(acc, reinterpret_cast<char*>(ws + ((int64_t)m0 + wm * TM * 32) * d.splitk_ld + n0 + wn * TN * 32), (int)d.splitk_ld, nullptr, 0,
+                              r_e, g_e);
+      return;
+    }
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -259,6 +264,13 @@ __global__ __launch_bounds__(512, 2) void gemm_pl_kernel(const vs_conv_desc_t d,
   }
   apply_act_all<TM, TN>(acc, bias1, zero, d.act);
   if (d.sumsq_part) write_sumsq<TM, TN>(acc, d.sumsq_part, d.N, (int64_t)m0 + (int64_t)wm * TM * 32, M, col, g_e);
+  const bool whole = m0 + GBM <= M && n0 + BN <= d.N && (int64_t)GBM * max(d.out_ld, d.res_ld) * 4 < (1LL << 31);
+  if (whole) {       // every layer of the shipped cards: store_tile_full (conv_common.h)
+    const int64_t row0 = (int64_t)m0 + wm * TM * 32;                                   // wave-uniform
+    store_tile_full<TM, TN>(acc, reinterpret_cast<char*>(d.out + row0 * d.out_ld + d.out_coff + n0 + wn * TN * 32), (int)d.out_ld,
+                            d.res ? reinterpret_cast<const char*>(d.res + row0 * d.res_ld + n0 + wn * TN * 32) : nullptr, (int)d.res_ld, r_e, g_e);
+    return;
+  }
 #pragma unroll
   for (int i = 0; i < TM; ++i) {
 #pragma unroll
