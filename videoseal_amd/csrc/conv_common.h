@@ -100,6 +100,36 @@ __device__ __forceinline__ void scale_all(f32x16 (&acc)[TM][TN], const float mul
 // The guarded general forms keep a 64-bit address per element, and hipcc waits vmcnt(0) between a residual fetch and its store -- which
 // also waits for the previous store's acknowledge: 16 * TN dependent round trips per row group; here a row group's residual values are
 // fetched in one batch.
+// The same store for ragged tiles: rows >= rows_left / columns >= cols_left (counted from the wave's first element) are skipped, columns in
+// [cols_left, store_left) are written as zeros.  Same addressing (one 32-bit offset per lane, everything else wave-uniform): the guards are
+// the only per-lane state.
+template <int TM, int TN>
+__device__ __forceinline__ void store_tile_guarded(const f32x16 (&acc)[TM][TN], char* const ob, const int out_ld, const char* const rb, const int res_ld,
+                                                   const int r_e, const int g_e, const int rows_left, const int cols_left, const int store_left) {
+  const unsigned olane = (unsigned)(4 * g_e * out_ld + r_e) * 4u;
+  const unsigned rlane = (unsigned)(4 * g_e * res_ld + r_e) * 4u;
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int row = i * 32 + (e & 3) + 8 * (e >> 2);                                      // + 4 g_e: this lane's row
+      if (row + 4 * g_e >= rows_left) continue;
+      const unsigned oo = (unsigned)(row * out_ld) * 4u, ro = (unsigned)(row * res_ld) * 4u;   // wave-uniform
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const int c = j * 32 + r_e;
+        if (c >= store_left) continue;
+        float v = 0.f;
+        if (c < cols_left) {
+          v = acc[i][j][e];
+          if (rb) v += *reinterpret_cast<const float*>(rb + (size_t)(ro + rlane) + j * 128);
+        }
+        *reinterpret_cast<float*>(ob + (size_t)(oo + olane) + j * 128) = v;
+      }
+    }
+  }
+}
+
 template <int TM, int TN>
 __device__ __forceinline__ void store_tile_full(const f32x16 (&acc)[TM][TN], char* const ob, const int out_ld, const char* const rb, const int res_ld,
                                                 const int r_e, const int g_e) {

@@ -262,18 +262,20 @@ __device__ __forceinline__ void gemm1x1_pc_tile(const vs_conv_desc_t& d, const i
 #pragma unroll
   for (int j = 0; j < TN; ++j) col[j] = n0 + (wn * TN + j) * 32 + r;
   if constexpr (NP == 2) scale_all<TM, TN>(acc, d.acc_mul);       // back to real units (exact: a power of two), also for the K-slice partial sums
+  // (the lane id through an opaque copy: this function is the body of the persistent tile loop, and hipcc otherwise hoists the 64 lane offsets of
+  // the store helpers out of that loop -- they do not depend on the tile -- and keeps them alive, i.e. in scratch, across every K loop)
+  int lane_e = lane;
+  asm volatile("" : "+v"(lane_e));
+  const int r_e = lane_e & 31, g_e = lane_e >> 5;
+  // wave-uniform position of the wave's first element, and what is left of the matrix from there (rows / columns / stored columns)
+  const int64_t row0 = (int64_t)m0 + wm * TM * 32;
+  const int c0 = n0 + wn * TN * 32;
+  const bool whole = m0 + BM <= M && n0 + BN <= d.N;      // every layer of the shipped cards
+  const int rows_left = (int)min((int64_t)TM * 32, (int64_t)M - row0);
   if (d.split_k > 1) {                // raw partial sums -> workspace [ks][M][ws_ld]
-    float* ws = d.splitk_ws + (int64_t)ks * M * d.splitk_ld;
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        const int m = m0 + (wm * TM + i) * 32 + (e & 3) + 8 * (e >> 2) + 4 * g;
-        if (m >= M) continue;
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-          if (col[j] < d.N) ws[(int64_t)m * d.splitk_ld + col[j]] = acc[i][j][e];
-      }
+    char* const wsb = reinterpret_cast<char*>(d.splitk_ws + ((int64_t)ks * M + row0) * d.splitk_ld + c0);
+    if (whole) store_tile_full<TM, TN>(acc, wsb, (int)d.splitk_ld, nullptr, 0, r_e, g_e);
+    else store_tile_guarded<TM, TN>(acc, wsb, (int)d.splitk_ld, nullptr, 0, r_e, g_e, rows_left, d.N - c0, d.N - c0);
     return;
   }
   float bias1[TN], zero[TN];
@@ -286,25 +288,10 @@ __device__ __forceinline__ void gemm1x1_pc_tile(const vs_conv_desc_t& d, const i
   if (!(abl & 64)) apply_act_all<TM, TN>(acc, bias1, zero, d.act);
   if (d.sumsq_part) write_sumsq<TM, TN>(acc, d.sumsq_part, d.N, m0 + (int64_t)wm * TM * 32, M, col, g);
   if (abl & 32) return;
-#pragma unroll
-  for (int i = 0; i < TM; ++i) {
-#pragma unroll
-    for (int e = 0; e < 16; ++e) {
-      const int64_t m = m0 + (wm * TM + i) * 32 + (e & 3) + 8 * (e >> 2) + 4 * g;
-      if (m >= M) continue;
-#pragma unroll
-      for (int j = 0; j < TN; ++j) {
-        const int n = col[j];
-        if (n >= d.n_store) continue;
-        float v = 0.f;
-        if (n < d.N) {
-          v = acc[i][j][e];
-          if (d.res) v += d.res[m * d.res_ld + n];
-        }
-        d.out[m * d.out_ld + d.out_coff + n] = v;
-      }
-    }
-  }
+  char* const ob = reinterpret_cast<char*>(d.out + row0 * d.out_ld + d.out_coff + c0);
+  const char* const rb = d.res ? reinterpret_cast<const char*>(d.res + row0 * d.res_ld + c0) : nullptr;
+  if (whole) store_tile_full<TM, TN>(acc, ob, (int)d.out_ld, rb, (int)d.res_ld, r_e, g_e);
+  else store_tile_guarded<TM, TN>(acc, ob, (int)d.out_ld, rb, (int)d.res_ld, r_e, g_e, rows_left, d.N - c0, d.n_store - c0);
 }
 
 template <int TN, bool GRN, int NP>
