@@ -54,7 +54,7 @@ __global__ __launch_bounds__(NTH, 2) void conv3x3_patch_kernel(const vs_conv_des
   const int n2 = d.in2 ? d.Cin2P / BK : 0;
   const int64_t Ktot = (int64_t)9 * d.CinP;
   const bool reflect = d.pad_mode == VS_PAD_REFLECT;
-  const int abl = d.tile_hint >> 8;   // debug ablation (tools/bench_conv.py): 1 no B loads, 2 no MFMA, 4 no B store, 8 no barrier
+  const int abl = VS_KERNEL_ABL(d);   // debug ablation (tools/bench_conv.py): 1 no B loads, 2 no MFMA, 4 no B store, 8 no barrier
 
   // ---- patch items of this thread: (patch pixel, 4-channel group); addresses are constant across chunks
   unsigned p_off[NPI];

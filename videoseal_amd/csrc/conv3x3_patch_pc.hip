@@ -84,7 +84,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_patch_pc_kernel(const vs_conv_
   const int n1 = 9 * spt;
   const int n2 = (d.in2 && (sk == 1 || p2_slice)) ? d.Cin2P / BK : 0;
   const int total = n1 + n2;
-  const int abl = d.tile_hint >> 8;   // debug ablation (tools/bench_ppc.py): 1 no weight DMA, 4 no activation staging
+  const int abl = VS_KERNEL_ABL(d);   // debug ablation (tools/bench_ppc.py): 1 no weight DMA, 4 no activation staging
 
   if (wave >= 6) {
     // ================================================================== weight producers (waves 6-7): LDS-DMA only

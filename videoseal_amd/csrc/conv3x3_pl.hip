@@ -81,7 +81,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pl_kernel(const vs_conv_desc_t
   const int n1 = 9 * spt;
   const int n2 = (d.in2_pl && (sk == 1 || p2_slice)) ? d.Cin2P / BK : 0;
   const int64_t Mpix = (int64_t)d.B * d.H * d.W;
-  const int abl = d.tile_hint >> 8;           // ablation (tools/bench_ppc.py): 32 no output stores
+  const int abl = VS_KERNEL_ABL(d);           // ablation (tools/bench_ppc.py): 32 no output stores
 
   // ------------------------------------------------------------------ DMA issue (waves 0-3: weights, waves 4-7: activations)
   // Every per-lane source OFFSET (32 bits, relative to a wave-uniform base that is advanced with scalar arithmetic) is computed once

@@ -32,7 +32,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_small_kernel(const vs_conv_des
   const int wave = tid >> 6;
   const int r = lane & 31, g = lane >> 5;
   const bool reflect = d.pad_mode == VS_PAD_REFLECT;
-  const int abl = d.tile_hint >> 8;      // debug ablation (tools/bench_small.py): 1 no MFMA, 2 no output stores, 4 no patch loads / staging
+  const int abl = VS_KERNEL_ABL(d);      // debug ablation (tools/bench_small.py): 1 no MFMA, 2 no output stores, 4 no patch loads / staging
 
   // ---- weights of this wave: B fragment (tap, plane) = 16 bytes of row n = r at k = tap*16 + g*8  (wt_split: [3][N][144])
   const int nrow = r < d.N ? r : d.N - 1;                 // N < 32: lanes beyond N re-read a valid row (columns discarded)

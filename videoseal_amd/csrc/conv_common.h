@@ -84,6 +84,15 @@ __device__ __forceinline__ void split4n(const f32x4& v, const float amul, u32x2 
   else split4h(v, amul, p[0], p[1]);
 }
 
+// Debug ablation bits of the conv / GEMM kernels (tile_hint >> 8; tools/bench_conv.py, bench_ppc.py) exist only in a build with
+// EXTRA=-DVS_KERNEL_ABLATION: as run-time branches in a K loop they cut it into basic blocks at whose joins hipcc's wait-count bookkeeping
+// falls back to s_waitcnt vmcnt(0) (measured on the fused ConvNeXt block: 10 %).
+#ifdef VS_KERNEL_ABLATION
+#define VS_KERNEL_ABL(d) ((d).tile_hint >> 8)
+#else
+#define VS_KERNEL_ABL(d) 0
+#endif
+
 template <int TM, int TN>
 __device__ __forceinline__ void scale_all(f32x16 (&acc)[TM][TN], const float mul) {
 #pragma unroll

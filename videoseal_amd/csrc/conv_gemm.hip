@@ -72,7 +72,7 @@ __global__ __launch_bounds__(NT, (TM * TN > 4 ? 1 : 2)) void conv_gemm_kernel(co
   const int64_t Ktot = (int64_t)d.KH * d.KW * d.CinP;
   const int HoWo = d.Ho * d.Wo;
   const bool reflect = d.pad_mode == VS_PAD_REFLECT;
-  const int abl = d.tile_hint >> 8;   // debug ablation mask (tools/bench_conv.py): 1 no global loads, 2 no MFMA, 4 no LDS stores, 8 no barrier
+  const int abl = VS_KERNEL_ABL(d);   // debug ablation mask (tools/bench_conv.py): 1 no global loads, 2 no MFMA, 4 no LDS stores, 8 no barrier
   const bool chk_c = (d.Cin % BK) != 0 || (d.in2 && (d.Cin2 % BK) != 0);   // partial channel chunks exist
 
   // ---- A rows of this thread (fixed for the whole K loop)
@@ -358,23 +358,35 @@ __global__ __launch_bounds__(NT, (TM * TN > 4 ? 1 : 2)) void conv_gemm_kernel(co
     apply_act_all<TM, TN>(acc, bias1, zero, d.act);
   }
   if (d.sumsq_part) write_sumsq<TM, TN>(acc, d.sumsq_part, d.N, m0 + (int64_t)wm * TM * 32, M, col, g);
-#pragma unroll
-  for (int i = 0; i < TM; ++i) {
-#pragma unroll
-    for (int e = 0; e < 16; ++e) {
-      const int64_t m = m0 + (wm * TM + i) * 32 + (e & 3) + 8 * (e >> 2) + 4 * g;
-      if (m >= M) continue;
-#pragma unroll
-      for (int j = 0; j < TN; ++j) {
-        const int n = col[j];
-        if (n >= d.n_store) continue;
-        float v = 0.f;                      // columns in [N, n_store) are padding lanes: always zero
-        if (n < d.N) {
-          v = acc[i][j][e];
-          if (d.res) v += d.res[m * d.res_ld + n];
+  // stores through the helpers of conv_common.h: wave-uniform base + one 32-bit lane offset (whole tiles: residual values in one batch)
+  {
+    const int64_t row0 = m0 + (int64_t)wm * TM * 32;
+    const int c0 = n0 + wn * TN * 32;
+    char* const ob = reinterpret_cast<char*>(d.out + row0 * d.out_ld + d.out_coff + c0);
+    const char* const rb = d.res ? reinterpret_cast<const char*>(d.res + row0 * d.res_ld + c0) : nullptr;
+    const bool small = (int64_t)BM * max(d.out_ld, d.res_ld) * 4 < (1LL << 31);
+    if (small && m0 + BM <= M && n0 + BN <= d.N) store_tile_full<TM, TN>(acc, ob, (int)d.out_ld, rb, (int)d.res_ld, r, g);
+    else if (small) store_tile_guarded<TM, TN>(acc, ob, (int)d.out_ld, rb, (int)d.res_ld, r, g, (int)min((int64_t)TM * 32, (int64_t)M - row0), d.N - c0, d.n_store - c0);
+    else {
+  #pragma unroll
+    for (int i = 0; i < TM; ++i) {
+  #pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int64_t m = m0 + (wm * TM + i) * 32 + (e & 3) + 8 * (e >> 2) + 4 * g;
+        if (m >= M) continue;
+  #pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          const int n = col[j];
+          if (n >= d.n_store) continue;
+          float v = 0.f;                      // columns in [N, n_store) are padding lanes: always zero
+          if (n < d.N) {
+            v = acc[i][j][e];
+            if (d.res) v += d.res[m * d.res_ld + n];
+          }
+          d.out[m * d.out_ld + d.out_coff + n] = v;
         }
-        d.out[m * d.out_ld + d.out_coff + n] = v;
       }
+    }
     }
   }
 }

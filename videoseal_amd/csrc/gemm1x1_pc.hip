@@ -284,7 +284,7 @@ __device__ __forceinline__ void gemm1x1_pc_tile(const vs_conv_desc_t& d, const i
     bias1[j] = (col[j] < d.N && d.bias) ? d.bias[col[j]] : 0.f;
     zero[j] = 0.f;
   }
-  const int abl = d.tile_hint >> 8;       // ablations (tools/bench_gemm.py ksweep): 64 no activation, 32 no output stores
+  const int abl = VS_KERNEL_ABL(d);       // ablations (tools/bench_gemm.py ksweep): 64 no activation, 32 no output stores
   if (!(abl & 64)) apply_act_all<TM, TN>(acc, bias1, zero, d.act);
   if (d.sumsq_part) write_sumsq<TM, TN>(acc, d.sumsq_part, d.N, m0 + (int64_t)wm * TM * 32, M, col, g);
   if (abl & 32) return;

@@ -494,6 +494,14 @@ __global__ __launch_bounds__(256) void upconv_gather_ln_kernel(const float* __re
   const int g = (int)(gid & ((1 << tpp_log2) - 1));
   const bool live = pq < npix && vb < nblk;
   const int64_t p = live ? pq : 0;           // dead lanes still take part in the shuffles
+  // LayerNorm parameters of this lane's channels: requested first (behind the gather they were a dependent L2 round trip at the tail of the kernel)
+  constexpr int NVP = CG / 4;
+  f32x4 lwv[NVP], lbv[NVP];
+#pragma unroll
+  for (int j = 0; j < NVP; ++j) {
+    lwv[j] = *reinterpret_cast<const f32x4*>(lnw + g * CG + 4 * j);
+    lbv[j] = *reinterpret_cast<const f32x4*>(lnb + g * CG + 4 * j);
+  }
   const int W2 = 2 * W, H2 = 2 * H;
   const int X = (int)(p % W2);
   const int64_t t0 = p / W2;
@@ -547,11 +555,9 @@ __global__ __launch_bounds__(256) void upconv_gather_ln_kernel(const float* __re
   const float den = sqrtf(v / (float)Co + eps);
   if (!live) return;
   float* orow = out + p * old + g * CG;
-  const float* lw = lnw + g * CG;
-  const float* lb = lnb + g * CG;
 #pragma unroll
   for (int j = 0; j < NV; ++j) {
-    const f32x4 wv = *reinterpret_cast<const f32x4*>(lw + 4 * j), bv = *reinterpret_cast<const f32x4*>(lb + 4 * j);
+    const f32x4 wv = lwv[j], bv = lbv[j];
     f32x4 o;
 #pragma unroll
     for (int e = 0; e < 4; ++e) o[e] = vs_apply_act(wv[e] * ((acc[j][e] - mean) / den) + bv[e], act);

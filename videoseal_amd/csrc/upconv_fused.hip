@@ -157,6 +157,12 @@ __global__ __launch_bounds__(256) void upconv_fused_kernel(const float* __restri
   // ---- gather + LayerNorm + activation: 16 x 16 output pixels, 4 lanes per pixel
   constexpr int NV = CG / 4;
   const int q4 = tid & 3;
+  f32x4 lwv[NV], lbv[NV];                   // LayerNorm parameters of this lane's channels, once (inside the loop: a dependent L2 round trip per pixel)
+#pragma unroll
+  for (int j = 0; j < NV; ++j) {
+    lwv[j] = *reinterpret_cast<const f32x4*>(lnw + q4 * CG + 4 * j);
+    lbv[j] = *reinterpret_cast<const f32x4*>(lnb + q4 * CG + 4 * j);
+  }
   const int H2 = 2 * H, W2 = 2 * W;
   const float invC = 1.0f / (float)Co;
   for (int it = tid >> 2; it < ((abl & 2) ? 0 : 4 * UT * UT); it += 64) {
@@ -215,7 +221,7 @@ __global__ __launch_bounds__(256) void upconv_fused_kernel(const float* __restri
     float* orow = out + (((int64_t)b * H2 + Y) * W2 + X) * old + q4 * CG;
 #pragma unroll
     for (int j = 0; j < NV; ++j) {
-      const f32x4 wv = *reinterpret_cast<const f32x4*>(lnw + q4 * CG + 4 * j), bv = *reinterpret_cast<const f32x4*>(lnb + q4 * CG + 4 * j);
+      const f32x4 wv = lwv[j], bv = lbv[j];
       f32x4 o;
 #pragma unroll
       for (int e = 0; e < 4; ++e) o[e] = vs_apply_act(wv[e] * ((v[j][e] - mean) / den) + bv[e], act);
