@@ -246,3 +246,18 @@ def test_bench_gpus_n_without_a_launcher_refuses_cleanly_when_the_node_has_too_f
     assert len(lines) == 1
     err = json.loads(lines[0])
     assert err["n_gpus_requested"] == 2 and err["n_gpus_visible"] == torch.cuda.device_count() and "error" in err
+
+
+def test_videoseal_lib_selects_another_build_of_the_library():
+    """native.LIB_PATH: VIDEOSEAL_LIB names another build of the same ABI (tools/ab_libs.sh, same-box A/B of two source trees); unset, the
+    in-tree library is the one that loads -- checked in a child interpreter because the path is fixed at import"""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = "from videoseal_amd import native; print(native.LIB_PATH)"
+    env = dict(os.environ, VIDEOSEAL_LIB="/somewhere/else/libvideoseal_hip.so")
+    out = subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, text=True, timeout=300)
+    assert out.stdout.strip().endswith("/somewhere/else/libvideoseal_hip.so"), out.stderr
+    env.pop("VIDEOSEAL_LIB")
+    out = subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, text=True, timeout=300)
+    assert out.stdout.strip() == os.path.join(root, "videoseal_amd", "csrc", "libvideoseal_hip.so"), out.stderr
