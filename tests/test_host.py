@@ -158,6 +158,134 @@ def test_metrics_match_oracle():
     assert bit_accuracy(pix, torch.randint(0, 2, (2, 8))).shape == (2,)
 
 
+def _reference_metrics_module():
+    """the checkout's own evals/metrics.py, executed as a file (its `pytorch_msssim` import is absent here: a dummy module stands in, so
+    only the functions that do not touch it are usable)"""
+    import importlib.util
+    import sys
+    import types
+    path = "/root/reference/videoseal/evals/metrics.py"
+    if not os.path.isfile(path):
+        pytest.skip("no reference checkout in this environment")
+    added = "pytorch_msssim" not in sys.modules and importlib.util.find_spec("pytorch_msssim") is None
+    if added:
+        sys.modules["pytorch_msssim"] = types.ModuleType("pytorch_msssim")
+    try:
+        spec = importlib.util.spec_from_file_location("_ref_metrics_for_test", path)
+        mod = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(mod)
+    finally:
+        if added:
+            sys.modules.pop("pytorch_msssim", None)
+    return mod
+
+
+def test_mask_and_message_metrics_equal_the_reference_functions():
+    """train.py:65,649,667-670 / evals/full.py:46: accuracy, iou, linf, pvalue, capacity, bit_accuracy(+_1msg, masked) against the
+    unmodified evals/metrics.py on seeded inputs incl. empty masks / empty unions"""
+    R = _reference_metrics_module()
+    from videoseal_amd import metrics as M
+    g = torch.Generator().manual_seed(5)
+    preds = torch.randn(5, 1, 12, 9, generator=g)
+    targets = (torch.rand(5, 1, 12, 9, generator=g) > 0.6).float()
+    targets[3] = 0
+    preds[3] = -1.0                                                      # empty union for label 1
+    for thr in (0.0, 0.3):
+        assert torch.equal(M.accuracy(preds, targets, thr), R.accuracy(preds, targets, thr))
+        for label in (0, 1):
+            assert torch.equal(M.iou(preds.clone(), targets, thr, label), R.iou(preds.clone(), targets, thr, label))
+    a, b = torch.rand(2, 3, 20, 20, generator=g), torch.rand(2, 3, 20, 20, generator=g)
+    assert torch.equal(M.linf(a, b), R.linf(a, b)) and torch.equal(M.psnr(a, b), R.psnr(a, b)) and torch.equal(M.psnr(a, b, True), R.psnr(a, b, True))
+    bits = torch.randint(0, 2, (4, 32), generator=g)
+    logits = (bits.float() * 2 - 1) * torch.rand(4, 32, generator=g) + 0.4 * torch.randn(4, 32, generator=g)
+    logits[1] = bits[1].float() * 2 - 1                                  # a perfect row: p log p at 0
+    assert torch.equal(M.bit_accuracy(logits, bits), R.bit_accuracy(logits, bits))
+    assert torch.equal(M.pvalue(logits, bits), R.pvalue(logits, bits))
+    assert torch.equal(M.capacity(logits, bits), R.capacity(logits, bits))
+    pix = torch.randn(3, 8, 6, 6, generator=g)
+    tb = torch.randint(0, 2, (3, 8), generator=g)
+    mask = (torch.rand(3, 1, 6, 6, generator=g) > 0.5).float()
+    mask[:] = mask[0]                                                    # (masked_select + view needs equal counts, as in the reference)
+    assert torch.equal(M.bit_accuracy(pix, tb, mask), R.bit_accuracy(pix, tb, mask))
+    assert torch.equal(M.bit_accuracy_1msg(pix, tb), R.bit_accuracy_1msg(pix, tb))
+    assert torch.equal(M.bit_accuracy_1msg(pix, tb, mask), R.bit_accuracy_1msg(pix, tb, mask))
+
+
+def test_ssim_and_msssim_against_an_independent_float64_evaluation():
+    """pytorch_msssim is absent (parity unpinned against it): the torch restatement is checked against a scipy.ndimage float64 evaluation of
+    the published definition -- 11-tap Gaussian (sigma 1.5), valid region, K = (0.01, 0.03); MS-SSIM with 2x2 mean pooling"""
+    import numpy as np
+    from scipy.ndimage import correlate1d
+    from videoseal_amd.metrics import msssim, ssim
+    g = torch.Generator().manual_seed(11)
+    x = torch.rand(2, 3, 176, 163, generator=g)
+    y = (x + 0.05 * torch.randn(2, 3, 176, 163, generator=g)).clamp(0, 1)
+    c = np.arange(11) - 5.0
+    w = np.exp(-c ** 2 / (2 * 1.5 ** 2))
+    w /= w.sum()
+
+    def blur(a):
+        a = correlate1d(correlate1d(a, w, axis=-2, mode="constant"), w, axis=-1, mode="constant")
+        return a[..., 5:-5, 5:-5]
+
+    def parts(a, b):
+        c1, c2 = 0.01 ** 2, 0.03 ** 2
+        m1, m2 = blur(a), blur(b)
+        s1, s2, s12 = blur(a * a) - m1 * m1, blur(b * b) - m2 * m2, blur(a * b) - m1 * m2
+        cs = (2 * s12 + c2) / (s1 + s2 + c2)
+        return (((2 * m1 * m2 + c1) / (m1 * m1 + m2 * m2 + c1)) * cs).mean((-2, -1)), cs.mean((-2, -1))
+
+    a, b = x.double().numpy(), y.double().numpy()
+    s_ref, _ = parts(a, b)
+    assert np.abs(ssim(x, y).numpy() - s_ref.mean(1)).max() < 2e-5
+    assert torch.allclose(ssim(x, x), torch.ones(2), atol=1e-6)
+    weights = [0.0448, 0.2856, 0.3001, 0.2363, 0.1333]
+    acc = np.ones((2, 3))
+    for lv, wt in enumerate(weights):
+        s, cs = parts(a, b)
+        acc *= np.maximum(s if lv == 4 else cs, 0) ** wt
+        if lv < 4:
+            pad = [(0, 0), (0, 0), (a.shape[2] % 2, a.shape[2] % 2), (a.shape[3] % 2, a.shape[3] % 2)]     # avg_pool2d(padding=s % 2): zeros, counted
+            a, b = (np.pad(v, pad)[:, :, : (v.shape[2] + 2 * pad[2][0]) // 2 * 2, : (v.shape[3] + 2 * pad[3][0]) // 2 * 2] for v in (a, b))
+            a, b = (v.reshape(v.shape[0], v.shape[1], v.shape[2] // 2, 2, v.shape[3] // 2, 2).mean((3, 5)) for v in (a, b))
+    assert np.abs(msssim(x, y).numpy() - acc.mean(1)).max() < 5e-5
+    with pytest.raises(AssertionError):
+        msssim(x[..., :160, :], y[..., :160, :])
+
+
+def test_setup_model_from_checkpoint_reads_a_training_checkpoint(tmp_path):
+    """evals/full.py:53,313 -> utils/cfg.py:52-179: a `.pth` as train.py writes it ({'model', 'args'}; args name the config YAMLs and use the
+    pre-rename `videowam_*` keys) -> config -> Videoseal with the weights loaded; a card name goes to the card loader, a baseline raises, a
+    missing file is FileNotFoundError"""
+    from videoseal_amd import cfg as C
+    args = {"embedder_config": "configs/embedder.yaml", "extractor_config": "configs/extractor.yaml", "attenuation_config": "configs/attenuation.yaml",
+            "embedder_model": "unet_small2_yuv_quant", "extractor_model": None, "attenuation": "jnd_1_1", "nbits": 64, "hidden_size_multiplier": 1,
+            "img_size_proc": 256, "scaling_w": 0.3, "scaling_i": 1.0, "videowam_chunk_size": 16, "videowam_step_size": 2}
+    probe = C.setup_model.__wrapped__ if hasattr(C.setup_model, "__wrapped__") else None  # noqa: F841
+    ck = tmp_path / "checkpoint.pth"
+    torch.save({"model": {}, "args": args}, ck)
+    config = C.get_config_from_checkpoint(ck)
+    assert isinstance(config, C.VideosealConfig) and config.embedder.model == "unet_small2_yuv_quant"
+    ext_default = videoseal_amd.builders.load_config("extractor")["model"]
+    assert config.extractor.model == ext_default
+    m0 = C.setup_model(config, ck)                                       # strict=False: an empty state_dict loads
+    sd = {k: (torch.randn_like(v) if v.is_floating_point() else v) for k, v in m0.state_dict().items()}
+    torch.save({"model": sd, "args": args}, ck)
+    m = C.setup_model_from_checkpoint(str(ck))
+    assert isinstance(m, Videoseal) and m.chunk_size == 16 and m.step_size == 2 and m.img_size == 256
+    assert m.embedder.cfg.nbits == 64 and float(m.blender.scaling_w) == pytest.approx(0.3)
+    assert torch.equal(m.state_dict()["embedder.unet.outc.weight"], sd["embedder.unet.outc.weight"])
+    assert config.embedder.params["msg_processor"]["nbits"] == 64        # the factories write back into the config, embedder.py:258-259
+    with pytest.raises(NotImplementedError, match="baseline"):
+        C.setup_model_from_checkpoint("baseline/hidden")
+    with pytest.raises(FileNotFoundError):
+        C.setup_model_from_checkpoint("no_such_card_anywhere")
+    with pytest.raises(FileNotFoundError):
+        C.setup_model(C.get_config_from_checkpoint(ck), tmp_path / "missing.pth")
+    from videoseal.utils.cfg import setup_model_from_checkpoint as shim_fn
+    assert shim_fn is C.setup_model_from_checkpoint
+
+
 def test_videoseal_import_shim_resolves_the_reference_paths():
     """inference_streaming.py:18-20, inference_av.py:20: `import videoseal` / `videoseal.models` / `videoseal.evals.metrics` / `utils.cfg`"""
     import videoseal

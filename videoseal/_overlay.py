@@ -66,3 +66,49 @@ def fallback_getattr(pkg_name: str, sub: str):
         except AttributeError:
             raise AttributeError(f"module '{pkg_name}' has no attribute '{name}'") from None
     return __getattr__
+
+
+def _load_private(priv: str, path: str, package: str, stubs=None):
+    """execute the checkout's file `path` once as module `priv` inside package `package`; a third-party module the file needs and this
+    environment lacks surfaces as an ImportError that names it (`stubs`: {module name: factory} installed first when absent)"""
+    mod = sys.modules.get(priv)
+    if mod is not None:
+        return mod
+    for name, factory in (stubs or {}).items():
+        if name not in sys.modules and importlib.util.find_spec(name) is None:
+            sys.modules[name] = factory()
+    spec = importlib.util.spec_from_file_location(priv, path, submodule_search_locations=None)
+    mod = importlib.util.module_from_spec(spec)
+    mod.__package__ = package
+    sys.modules[priv] = mod
+    try:
+        spec.loader.exec_module(mod)
+    except ModuleNotFoundError as e:
+        sys.modules.pop(priv, None)
+        raise ImportError(f"{path} needs the third-party module '{e.name}', which is not installed here") from e
+    except BaseException:
+        sys.modules.pop(priv, None)
+        raise
+    return mod
+
+
+def fallback_module_getattr(mod_name: str, rel_file: str, stubs=None):
+    """module-level __getattr__ for a shim MODULE that shadows a file of the checkout (e.g. videoseal/evals/metrics.py): a name the shim
+    does not define is taken from the checkout's own file, executed once under a private name; names the shim defines never get here,
+    so the path's functions stay this package's"""
+    package = mod_name.rsplit(".", 1)[0]
+
+    def __getattr__(name: str):
+        if name.startswith("__"):
+            raise AttributeError(name)
+        root = os.environ.get(ENV)
+        path = os.path.join(root, "videoseal", *rel_file.split("/")) if root else None
+        if not path or not os.path.isfile(path):
+            raise AttributeError(f"module '{mod_name}' has no attribute '{name}' (the MI355X shim defines the embed / extract path only; "
+                                 f"set {ENV} to a reference checkout for the rest)")
+        mod = _load_private(mod_name + "__reference", path, package, stubs)
+        try:
+            return getattr(mod, name)
+        except AttributeError:
+            raise AttributeError(f"module '{mod_name}' has no attribute '{name}'") from None
+    return __getattr__
