@@ -1,0 +1,83 @@
+"""Codegen guard (no GPU: hipcc cross-compiles): what the hot kernels of the default arithmetic compile to, against a committed ratchet.
+
+Round 4 found its regressions by reading ISA by hand (LAB_NOTEBOOK 'Round 4, second half': a scratch reload or a compiler-inserted
+`s_waitcnt vmcnt(0)` inside a prefetching K loop costs 10-30 % of a kernel and changes no result, so no parity test sees it).  This test
+compiles every source of `tools/isa_scan.HOT_SOURCES` with `-S --cuda-device-only` and checks, for every kernel above 1 % of the image step
+(`isa_scan.HOT_KERNELS`):
+
+  * HARD: no scratch instruction inside a K loop (a leaf loop holding >= 4 MFMAs) -- a spill there is a VGPR-destination load, i.e. vmcnt(0);
+  * RATCHET (tests/golden/codegen_budget.json, refreshed by `python tools/isa_scan.py budget --write`): `.vgpr_spill_count`, the number of
+    `s_waitcnt vmcnt(0)` per K loop and the LDS size may not rise above the recorded value; kernels recorded at 0 spills stay at 0.
+
+A number that goes DOWN is reported (refresh the budget in the same commit); a kernel that disappears from the build fails.
+"""
+import json
+import os
+import shutil
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+
+BUDGET = os.path.join(ROOT, "tests", "golden", "codegen_budget.json")
+
+
+@pytest.fixture(scope="module")
+def report():
+    if shutil.which("hipcc") is None:
+        pytest.skip("no hipcc in this environment")
+    import isa_scan
+    return isa_scan.codegen_report(jobs=min(8, os.cpu_count() or 2))
+
+
+def test_every_hot_kernel_is_still_built(report):
+    import isa_scan
+    missing = [k for k in isa_scan.HOT_KERNELS if k not in report]
+    assert not missing, f"hot kernels no longer instantiated (update isa_scan.HOT_KERNELS with the profile that justifies it): {missing}"
+    assert set(json.load(open(BUDGET))) == set(isa_scan.HOT_KERNELS)
+
+
+def test_no_scratch_access_inside_a_k_loop(report):
+    bad = {k: [l for l in r["k_loops"] if l["scratch"]] for k, r in report.items()}
+    bad = {k: v for k, v in bad.items() if v}
+    assert not bad, f"scratch (spill) instructions inside MFMA K loops: {bad}"
+    assert all(r["k_loops"] for k, r in report.items() if k != "conv3x3_patch_kernel<4, 1, 1, 1, 2>"), "a hot kernel without an MFMA loop?"
+
+
+def test_spills_and_k_loop_waits_do_not_exceed_the_recorded_budget(report):
+    budget = json.load(open(BUDGET))
+    worse, better = [], []
+    for k, b in budget.items():
+        r = report[k]
+        for key in ("vgpr_spill", "lds"):
+            if r[key] > b[key]:
+                worse.append(f"{k}: {key} {b[key]} -> {r[key]}")
+            elif r[key] < b[key]:
+                better.append(f"{k}: {key} {b[key]} -> {r[key]}")
+        if len(r["k_loops"]) != len(b["k_loops"]):
+            worse.append(f"{k}: {len(b['k_loops'])} K loops -> {len(r['k_loops'])} (re-record with a reason)")
+            continue
+        for i, (lr, lb) in enumerate(zip(r["k_loops"], b["k_loops"])):
+            if lr["vm0"] > lb["vm0"]:
+                worse.append(f"{k}: K loop {i}: vmcnt(0) {lb['vm0']} -> {lr['vm0']}")
+            elif lr["vm0"] < lb["vm0"]:
+                better.append(f"{k}: K loop {i}: vmcnt(0) {lb['vm0']} -> {lr['vm0']}")
+    if better:
+        print("improved (refresh tests/golden/codegen_budget.json):", *better, sep="\n  ")
+    assert not worse, "codegen regressions against tests/golden/codegen_budget.json:\n  " + "\n  ".join(worse)
+
+
+def test_the_budget_itself_only_tolerates_known_spills():
+    """the ratchet's current debt, spelled out: every other hot kernel is recorded at zero spilled VGPRs"""
+    budget = json.load(open(BUDGET))
+    spilling = {k: b["vgpr_spill"] for k, b in budget.items() if b["vgpr_spill"]}
+    assert set(spilling) <= KNOWN_SPILLS.keys(), spilling
+    for k, v in spilling.items():
+        assert v <= KNOWN_SPILLS[k], (k, v)
+
+
+# epilogue-only spills of the TN = 3 tiles (96 accumulators + a batch of residual / bias values; none inside a K loop), round-5 values
+KNOWN_SPILLS = {"conv3x3_pl_kernel<3>": 32, "gemm_pl_kernel<3>": 67, "gemm1x1_pc_kernel<3, true, 2>": 101, "gemm1x1_pc_kernel<3, false, 2>": 96,
+                "conv3x3_patch_pc_kernel<3, 8, 2>": 90}
