@@ -180,10 +180,16 @@ def parse_args(argv=None):
     ap.add_argument("--detect-only", action="store_true", help="time model.detect() only (BASELINE config 5: ChunkySeal extractor)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timers", action="store_true")
+    ap.add_argument("--dump-preds", default=None, help="rank 0 saves the (gathered) logits of the last timed step to this path (torch.save)")
     ap.add_argument("--no-extra", action="store_true", help="default run only: skip the short legs over the other BASELINE configs "
                     "(video mode, configs[2] chain, configs[3] streaming, configs[4] ChunkySeal detect, the training step)")
     return ap.parse_args(argv)
 
+
+
+def coll_device(dev):
+    """where the scalar collectives of this file (rank count, max-over-ranks time) live: the GPU under RCCL, the host under a gloo group"""
+    return torch.device("cpu") if torch.distributed.get_backend() == "gloo" else dev
 
 
 def run(args):
@@ -198,14 +204,23 @@ def run(args):
         raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback for the product path)")
+    # VS_BENCH_COLLECTIVE=gloo: the ranks exchange through a host-side process group (logits staged in pinned memory, dist.py) and may SHARE a
+    # device (rank r -> cuda:(r mod visible devices)): RCCL refuses two ranks on one GPU, and a 1-GPU box is all the build has -- this is how the
+    # multi-rank code path of this file (sharding, gather, max-over-ranks timing, one line from rank 0) is executed before an 8-GPU node runs it
+    host_coll = os.environ.get("VS_BENCH_COLLECTIVE", "nccl") == "gloo"
+    if host_coll:
+        local_rank %= max(1, torch.cuda.device_count())
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if dist_on and not torch.distributed.is_initialized():
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        torch.distributed.init_process_group("nccl", device_id=dev)
+        if host_coll:
+            torch.distributed.init_process_group("gloo")
+        else:
+            torch.distributed.init_process_group("nccl", device_id=dev)
     n_ranks_seen = None
-    if dist_on:      # how many ranks RCCL itself sees: a sum of ones over the communicator (not the launcher's environment variable)
-        one = torch.ones(1, device=dev, dtype=torch.int32)
+    if dist_on:      # how many ranks the communicator itself sees: a sum of ones over it (not the launcher's environment variable)
+        one = torch.ones(1, device=coll_device(dev), dtype=torch.int32)
         torch.distributed.all_reduce(one)
         n_ranks_seen = int(one.item())
 
@@ -357,7 +372,7 @@ def _run(args, world, rank, dev, dist_on, n_ranks_seen):
     barrier()
     elapsed = time.perf_counter() - t0
     if dist_on:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        t = torch.tensor([elapsed], device=coll_device(dev), dtype=torch.float64)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         elapsed = float(t.item())
 
@@ -492,6 +507,11 @@ def _run(args, world, rank, dev, dist_on, n_ranks_seen):
         if allgather_ms is not None:
             line["allgather_ms"] = round(allgather_ms, 4)
             line["n_ranks_seen"] = n_ranks_seen
+            line["collective"] = ("gloo over pinned host buffers (ranks may share a device: VS_BENCH_COLLECTIVE=gloo)"
+                                  if torch.distributed.get_backend() == "gloo" else "RCCL all_gather_into_tensor")
+            line["shards"] = ([list(shard_range(args.frames, r, world, 16)) for r in range(world)] if stream else [[r * B, (r + 1) * B] for r in range(world)])
+        if args.dump_preds:          # the gathered logits of the last step, for a caller that recomputes them (tests/test_gpu_zdist.py)
+            torch.save(preds.detach().cpu(), args.dump_preds)
         if not args.no_cpu_baseline and world == 1 and not args.detect_only:
             card_path = os.path.join(ROOT, "videoseal_amd", "cards", args.card + ".yaml")
             line["cpu_baseline"] = cpu_baseline(card_path, S, args.mode, cfg.step_size)

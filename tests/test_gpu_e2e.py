@@ -646,6 +646,10 @@ def test_streaming_key_frame_groups_equal_the_per_chunk_calls(tiny, mode):
         for (_, x), (_, y) in zip(one_w, grp_w):
             assert (x - y).abs().max().item() < 1e-5
         assert (a - b).abs().max().item() < 1e-3
+        sure = a.abs() > 2e-3                      # decisions of the grouped path = decisions of the per-chunk calls (per frame and aggregated)
+        assert torch.equal((a > 0)[sure], (b > 0)[sure]) and sure.float().mean().item() > 0.9
+        ma, mb = a[:, 1:].mean(dim=0), b[:, 1:].mean(dim=0)
+        assert torch.equal((ma > 0)[ma.abs() > 1e-4], (mb > 0)[ma.abs() > 1e-4])
         # the per-chunk expansion matters: one tail launch over the whole group differs in 'interpolate' mode (frames 13-15 of a chunk)
         if mode == "interpolate":
             model.chunk_size = 8                       # embed() itself with 32-frame chunks: a different (legal) chunking of the clip
@@ -662,10 +666,68 @@ def test_streaming_key_frame_groups_equal_the_per_chunk_calls(tiny, mode):
             assert (x.int() - y.int()).abs().max().item() <= 1
             assert (x != y).float().mean().item() < 1e-4
         assert (c - d).abs().max().item() < 5e-3
+        assert torch.equal((c > 0)[c.abs() > 1e-2], (d > 0)[c.abs() > 1e-2])
+        mc, md = c[:, 1:].mean(dim=0), d[:, 1:].mean(dim=0)
+        assert torch.equal((mc > 0)[mc.abs() > 1e-3], (md > 0)[mc.abs() > 1e-3])
         with pytest.raises(ValueError):
             embed_detect_chunks(model, frames, msgs, chunk=10, group=2)
     finally:
         model.video_mode = "repeat"
+
+
+def test_configs3_stated_size_streaming_equals_the_reference_run_of_inference_streaming(vs10):
+    """BASELINE configs[3] at its STATED size and in the form bench.py's stream leg times: VideoSeal 1.0, a 128-frame 768 x 768 clip = 8
+    chunks of 16, streaming.embed_detect_chunks with its defaults (key frames of 8 chunks in one U-Net pass, extractor on 32 frames per
+    pass, detect overlapped on a second stream) against tests/golden/vs10_stream_768.npz -- the unmodified reference called chunk by chunk
+    through inference_streaming.py's own embed_video_clip / detect_video_clip (make_golden_stream.py).  fp32 clip: watermarked frames, PSNR,
+    per-frame logits, and the aggregated decision (`soft_msgs.mean(0) > 0`, inference_streaming.py:162-163) IDENTICAL; uint8 RGB24 clip (the
+    script's data format): bytes within one grey level in < 1e-4 of the pixels, soft bits, identical decision; and the literal per-chunk
+    calls (group = 1) of the same clip."""
+    from videoseal_amd.streaming import default_group, embed_detect_chunks
+    spec, sd, model = vs10
+    g = load_golden("vs10_stream_768")
+    meta = g["meta"]
+    assert (meta["n"], meta["h"], meta["chunk"]) == (128, 768, 16)
+    model.chunk_size, model.step_size, model.video_mode = meta["model_chunk_size"], meta["step"], "repeat"
+    frames = synthetic_frames(meta["n"], meta["h"], meta["w"], seed=meta["seed"])
+    msgs = synthetic_msgs(1, spec.nbits, seed=meta["seed"])
+    assert torch.equal(msgs, torch.from_numpy(g["msgs"]))
+    fr = frames.cuda()
+    assert default_group(16, model.step_size, fr[0].numel() * 4) == 8
+    gold, agg_gold = torch.from_numpy(g["preds"]), torch.from_numpy(g["agg_f32"])
+    sure = agg_gold.abs() > 1e-5                  # (a mean logit closer to zero than the fp32 noise of a 128-frame mean has no defined sign)
+    for group in (None, 1):                       # the grouped default (what the bench leg runs) and the script's literal per-chunk calls
+        got_w = []
+        preds = embed_detect_chunks(model, fr, msgs, chunk=16, lowres_attenuation=True, group=group, sink=lambda i, w: got_w.append(w.clone())).cpu()
+        torch.cuda.synchronize()
+        w = torch.cat(got_w)
+        del got_w
+        check_sub(g, "imgs_w", w, TOL_IMG, f"stream group={group} ")
+        assert abs(psnr_np(w.cpu(), frames) - meta["psnr"]) < 1e-3
+        del w
+        assert preds.shape == gold.shape and (preds - gold).abs().max().item() < TOL_LOGIT
+        safe = gold.abs() > 2 * TOL_LOGIT
+        assert ((preds > 0) == (gold > 0))[safe].all()
+        agg = preds[:, 1:].mean(dim=0)
+        assert (agg - agg_gold).abs().max().item() < 1e-4
+        assert torch.equal((agg > 0)[sure], (agg_gold > 0)[sure])
+        assert sure.all() and float(((agg > 0) == (msgs[0] > 0.5)).float().mean()) == meta["bit_acc_f32"]      # (min |mean logit| of the fixture: 2.4e-3)
+    # uint8 RGB24 in and out, as the script moves frames
+    clip = (frames * 255.0).round().to(torch.uint8).permute(0, 2, 3, 1).contiguous().cuda()
+    del fr
+    got_b = []
+    soft = embed_detect_chunks(model, clip, msgs, chunk=16, lowres_attenuation=True, sink=lambda i, w: got_b.append(w.clone()))[:, 1:].cpu()
+    torch.cuda.synchronize()
+    wb = torch.cat(got_b).cpu()
+    stride = int(g["w_u8.stats"][2])
+    assert wb.numel() == int(g["w_u8.stats"][1])
+    diff = (wb.flatten()[::stride].int() - torch.from_numpy(g["w_u8.sub"]).int()).abs()
+    assert diff.max().item() <= 1 and (diff != 0).float().mean().item() < 1e-4
+    assert abs(float(wb.double().sum()) - g["w_u8.stats"][0]) < 1e-6 * wb.numel()
+    soft_gold, agg_u8 = torch.from_numpy(g["soft_u8"]), torch.from_numpy(g["agg_u8"])
+    assert (soft - soft_gold).abs().max().item() < 5 * TOL_LOGIT          # a byte that rounds the other way moves a logit by ~1e-4
+    sure8 = agg_u8.abs() > 1e-4
+    assert torch.equal((soft.mean(dim=0) > 0)[sure8], (agg_u8 > 0)[sure8]) and sure8.float().mean() > 0.98
 
 
 def test_chunkyseal_released_size_detector_vs_oracle():

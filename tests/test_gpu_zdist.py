@@ -349,3 +349,61 @@ def test_bench_refuses_more_gpus_than_the_node_has():
     assert r.returncode == 2
     err = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
     assert err["n_gpus_requested"] == 2 and err["n_gpus_visible"] == torch.cuda.device_count() and "error" in err
+
+
+# ---- two ranks SHARING one GPU through a host-side process group (VS_BENCH_COLLECTIVE=gloo): the multi-rank code path of bench.py and dist.py
+# ---- executed on the hardware the build has, before the driver's first 8-GPU run (RCCL refuses two ranks on one device)
+def _bench_two_ranks_one_gpu(extra, tmp_path, timeout=1500):
+    import socket
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["VS_BENCH_COLLECTIVE"] = "gloo"
+    env["HIP_VISIBLE_DEVICES"] = env.get("HIP_VISIBLE_DEVICES", "0").split(",")[0]        # ONE device for both ranks
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.join(ROOT, "bench.py"), "--gpus", "2"] + extra
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=timeout, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-3000:]                 # ONE JSON line, from rank 0
+    return json.loads(lines[0])
+
+
+@pytest.mark.gpu
+def test_bench_stream_leg_with_two_ranks_on_one_gpu_gathers_the_single_process_logits(tmp_path):
+    """`bench.py --gpus 2 --mode stream --frames 64`, two ranks on ONE device, logits exchanged through gloo: rank count seen by the communicator,
+    16-aligned contiguous shards, strong scaling, and the gathered [64, 1 + nbits] logits equal what one process computes for the two shards
+    (rank r's frames are synthetic_batch(seed 1000 + r); chunks are independent, so the sharded run must reproduce them bit for bit)"""
+    dump = str(tmp_path / "preds.pt")
+    line = _bench_two_ranks_one_gpu(["--mode", "stream", "--frames", "64", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-extra",
+                                     "--no-kernel-timers", "--dump-preds", dump], tmp_path)
+    assert line["n_gpus"] == 2 and line["n_ranks_seen"] == 2 and line["scaling"] == "strong" and line["allgather_ms"] > 0
+    assert line["shards"] == [[0, 32], [32, 64]] and "gloo" in line["collective"] and line["value"] > 0
+    got = torch.load(dump)
+    assert got.shape == (64, 257)
+    sys.path.insert(0, ROOT)
+    import bench
+    import videoseal_amd
+    from videoseal_amd.streaming import embed_detect_chunks
+    model = videoseal_amd.build("videoseal_1.0", seed=0).eval().cuda()
+    model.chunk_size = max(model.chunk_size, 32)
+    msgs = torch.randint(0, 2, (1, 256), generator=torch.Generator().manual_seed(5))
+    ref = torch.cat([embed_detect_chunks(model, bench.synthetic_batch(32, 768, torch.device("cuda"), seed=1000 + r), msgs, chunk=16, lowres_attenuation=True,
+                                         overlap=True).cpu() for r in range(2)])
+    assert torch.equal(got, ref), float((got - ref).abs().max())
+
+
+@pytest.mark.gpu
+def test_bench_default_legs_with_two_ranks_on_one_gpu(tmp_path):
+    """the DEFAULT command of the driver's scaling run (`bench.py --gpus 2 --steps K --warmup W`: image-mode headline, weak scaling, plus the
+    stream_1024 and ChunkySeal legs that run at every rank count) with two ranks on one device: exits cleanly with one line"""
+    line = _bench_two_ranks_one_gpu(["--steps", "2", "--warmup", "1", "--no-kernel-timers"], tmp_path)
+    assert line["n_gpus"] == 2 and line["n_ranks_seen"] == 2 and line["scaling"] == "weak" and line["cpu_baseline"] is None
+    assert line["shards"] == [[0, 32], [32, 64]] and line["config"]["batch_per_gpu"] == 32
+    legs = line["configs"]
+    st = [v for k, v in legs.items() if k.startswith("stream_1024")][0]
+    ck = [v for k, v in legs.items() if k.startswith("chunkyseal")][0]
+    assert "error" not in st and st["n_gpus"] == 2 and st["scaling"] == "strong" and st["value"] > 0 and st["allgather_ms"] > 0
+    assert "error" not in ck and ck["n_gpus"] == 2 and ck["value"] > 0
+    assert not any(k.startswith(("video_step4", "chain", "train_step")) for k in legs)           # single-rank legs stay out of a multi-rank line

@@ -122,3 +122,26 @@ def test_metrics():
     assert R.psnr(a, b, is_video=True).ndim == 0
     preds = torch.tensor([[0.3, -0.2, 1.0, -5.0]])
     assert R.bit_accuracy(preds, torch.tensor([[1, 0, 0, 0]])).item() == 0.75
+
+
+def test_vs10_oracle_matches_the_reference_streaming_run_at_768(vs10):
+    """configs[3] at its stated frame size: the oracle's per-chunk `embed_video(lowres_attenuation=True)` + `detect` on the first two 16-frame
+    chunks of the 128-frame 768 x 768 fixture (tests/golden/make_golden_stream.py: the unmodified reference through inference_streaming.py's
+    own clip functions) -- logits of those 32 frames and the strided sample of their watermarked pixels"""
+    spec, sd = vs10
+    g = load_golden("vs10_stream_768")
+    meta = g["meta"]
+    frames = synthetic_frames(meta["n"], meta["h"], meta["w"], seed=meta["seed"])[:32]
+    msgs = synthetic_msgs(1, spec.nbits, seed=meta["seed"])
+    stride = int(g["imgs_w.stats"][3])
+    per_frame = 3 * meta["h"] * meta["w"]
+    for c in range(2):
+        w = R.embed_video(sd, spec, frames[16 * c:16 * c + 16], msgs, lowres_attenuation=True, chunk_size=meta["model_chunk_size"], step_size=meta["step"])["imgs_w"]
+        first = 16 * c * per_frame
+        k0 = -(-first // stride)                                     # first sample index that falls into this chunk
+        k1 = -(-(first + 16 * per_frame) // stride)
+        mine = w.flatten()[k0 * stride - first::stride]
+        assert mine.numel() == k1 - k0
+        assert (mine - torch.from_numpy(g["imgs_w.sub"][k0:k1])).abs().max().item() < 2e-6
+        preds = R.detect(sd, spec, w)["preds"]
+        assert (preds - torch.from_numpy(g["preds"][16 * c:16 * c + 16])).abs().max().item() < 2e-5

@@ -45,8 +45,19 @@ def gather_frame_logits(local: torch.Tensor, n_frames: int, align: int = 16, gro
     k = local.shape[1]
     pad = torch.zeros(biggest, k, device=local.device, dtype=local.dtype)
     pad[: b - a] = local
-    out = torch.empty(world * biggest, k, device=local.device, dtype=local.dtype)
-    dist.all_gather_into_tensor(out, pad, group=group)        # ONE fixed-size collective (RCCL ring over xGMI: 128 KiB per rank)
+    if local.is_cuda and dist.get_backend(group) == "gloo":
+        # a host-side process group over device tensors (several ranks sharing ONE GPU, where RCCL refuses a second rank per device -- the
+        # two-ranks-on-one-box runs of bench.py / tests; also a node without xGMI): the same single fixed-size all-gather through pinned
+        # host staging buffers
+        hin = torch.empty(biggest, k, dtype=local.dtype, pin_memory=True)
+        hin.copy_(pad, non_blocking=True)
+        torch.cuda.current_stream(local.device).synchronize()
+        hout = torch.empty(world * biggest, k, dtype=local.dtype, pin_memory=True)
+        dist.all_gather_into_tensor(hout, hin, group=group)
+        out = hout.to(local.device, non_blocking=True)
+    else:
+        out = torch.empty(world * biggest, k, device=local.device, dtype=local.dtype)
+        dist.all_gather_into_tensor(out, pad, group=group)    # ONE fixed-size collective (RCCL ring over xGMI: 128 KiB per rank)
     if all(e - s == biggest for s, e in shards):
         return out
     return torch.cat([out[r * biggest: r * biggest + e - s] for r, (s, e) in enumerate(shards)], dim=0)

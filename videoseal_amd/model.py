@@ -338,15 +338,22 @@ class Wam(nn.Module):
         self._msg_cache = (msgs, msgs._version, mi)
         return mi
 
-    def _graphed(self, key: tuple, ins: Dict[str, torch.Tensor], run):
+    def _graphed(self, key: tuple, ins: Dict[str, torch.Tensor], run, rekey=None):
         """Replay `run(static_inputs) -> dict of output tensors` from a hipGraph captured once per key.
-        The first call runs eagerly twice (workspace allocation + tile autotune), then captures."""
+        The first call runs eagerly twice (workspace allocation + tile autotune), then captures.  `rekey()` recomputes the key after the
+        eager passes: the first of them verifies new weights and may switch the network (or single layers) to 3 x bf16; the graph records
+        the kernels of the arithmetic in force at capture, so it is filed under the key a later call will compute (a stale key would
+        capture a second graph on the next call)."""
         ent = self._graphs.get(key)
         if ent is None:
             static_in = {k: v.clone() for k, v in ins.items()}
             run(static_in)
-            run(static_in)          # (the first eager pass verifies new weights and may switch the network to 3 x bf16: the capture below
-            torch.cuda.synchronize()    # then records the kernels of the arithmetic in force; keys carry arith_net, so it is found again)
+            run(static_in)
+            torch.cuda.synchronize()
+            if rekey is not None:
+                key = rekey()
+                ent = self._graphs.get(key)
+        if ent is None:
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g):
                 outs = run(static_in)
@@ -362,8 +369,9 @@ class Wam(nn.Module):
             rgb, _ = eng.resize_pre(si["fr"], S, antialias, want_rgb=True, mul=2.0, add=-1.0, tag="det.in")
             return {"preds": eng.extractor_forward(rgb)}
         if self.use_graphs and not torch.cuda.is_current_stream_capturing():
-            key = ("det", fr.dtype, tuple(fr.shape), tuple(S), antialias, id(eng), eng.arith_net["X"])
-            out = self._graphed(key, {"fr": fr}, run)["preds"].clone()
+            def key():           # the arithmetic is part of the key: network-wide split AND the layers the calibration pinned to the exact split
+                return ("det", fr.dtype, tuple(fr.shape), tuple(S), antialias, id(eng), eng.arith_net["X"], tuple(sorted(eng.layer_arith.items())))
+            out = self._graphed(key(), {"fr": fr}, run, rekey=key)["preds"].clone()
             eng.note_guard()           # the captured vs_check_finite has run: deliver its flag like an eager steady-state pass does
             return out
         return run({"fr": fr})["preds"].clone()
@@ -638,6 +646,11 @@ class Videoseal(Wam):
         step = int(self.step_size)
         if chunk % step:
             raise ValueError(f"chunk ({chunk}) must be a multiple of step_size ({step}): the key frames of the group are every step-th frame")
+        if chunk > int(self.chunk_size) * step:
+            # embed() itself walks a call in chunk_size * step_size frames (videoseal.py:291-297) and the watermark expansion restarts there;
+            # a caller chunk that spans several of them is not one expansion span
+            raise ValueError(f"chunk ({chunk}) exceeds chunk_size * step_size = {int(self.chunk_size) * step}: embed() would split such a call "
+                             f"internally; raise model.chunk_size or pass smaller chunks")
         if frames.device != eng.dev:
             raise ValueError("embed_group wants device-resident frames")
         u8 = frames.dtype == torch.uint8

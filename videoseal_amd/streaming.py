@@ -21,12 +21,19 @@ KEY_BATCH = 32      # key frames per U-Net pass at which conv3x3_pl_kernel has o
 DET_BATCH = 32      # frames per extractor pass
 
 
-def default_group(chunk: int, step: int) -> int:
-    """chunks per U-Net pass: enough for KEY_BATCH key frames; 1 (= the per-chunk calls) when the chunks' key frames are not the group's
+GROUP_BYTES = 2 << 30   # source + watermarked frames of one group (a 768 x 768 fp32 group of 8 x 16 frames is 1.8 GB; 4K fp32 chunks go one by one)
+
+
+def default_group(chunk: int, step: int, frame_bytes: int = 0) -> int:
+    """chunks per U-Net pass: enough for KEY_BATCH key frames, capped so that the group's source + output frames stay under GROUP_BYTES
+    (`frame_bytes` = bytes of one frame as passed in); 1 (= the per-chunk calls) when the chunks' key frames are not the group's
     every-step-th frames"""
     if chunk % step:
         return 1
-    return max(1, (KEY_BATCH * step + chunk - 1) // chunk)
+    g = max(1, (KEY_BATCH * step + chunk - 1) // chunk)
+    if frame_bytes > 0:
+        g = max(1, min(g, GROUP_BYTES // (2 * chunk * frame_bytes)))
+    return g
 
 
 def embed_detect_chunks(model, frames: torch.Tensor, msgs: torch.Tensor, chunk: int = 16, lowres_attenuation: bool = True,
@@ -38,7 +45,9 @@ def embed_detect_chunks(model, frames: torch.Tensor, msgs: torch.Tensor, chunk: 
     u8 = frames.dtype == torch.uint8
     step = int(model.step_size)
     if group is None:
-        group = default_group(chunk, step)
+        group = default_group(chunk, step, frames[0].numel() * frames.element_size() if frames.shape[0] else 0)
+        if chunk > int(model.chunk_size) * step:          # embed() would split such a chunk internally: the literal per-chunk calls
+            group = 1
     if group > 1 and chunk % step:
         raise ValueError(f"group > 1 needs chunk ({chunk}) to be a multiple of step_size ({step})")
     F_ = frames.shape[0]
