@@ -902,13 +902,12 @@ def test_embed_tail_forms_are_bit_identical(case):
         d.step, d.video_mode, d.total_key = step, vm, nkey
         d.attenuate, d.clamp, d.antialias = att, 1, 1
         d.scaling_i, d.scaling_w, d.io_u8, d.variant = 1.0, 0.2, 0, variant
-        if strip:
-            os.environ["VS_TAIL_STRIP_TEST"] = str(strip)
+        L.vs_debug_set(2, int(strip or 0))              # development switch: strip height of the streaming tail for this call
         try:
             N.check(L.vs_embed_tail(C.byref(d), N.stream()), "vs_embed_tail")
             torch.cuda.synchronize()
         finally:
-            os.environ.pop("VS_TAIL_STRIP_TEST", None)
+            L.vs_debug_set(2, 0)
         return out, pw
     ref, ref_pw = run(2)
     assert float(ref.min()) >= 0.0                      # every pixel written
@@ -974,13 +973,12 @@ def test_resize_pre_forms_are_bit_identical(cfg):
     def run(form, want_rgb=True, want_key=True, y=True):
         rgb = torch.full((B, oh, ow, 4), -9.0, device="cuda") if want_rgb else None
         key = torch.full((nk, oh, ow, 4), -9.0, device="cuda") if want_key else None
-        if form:
-            os.environ["VIDEOSEAL_RESIZE"] = form
+        L.vs_debug_set(0, 1 if form == "tile" else 0)   # development switch: kernel form for this call
         try:
             N.check(L.vs_resize_pre(N.ptr(x), B, 3, H, W, oh, ow, aa, N.ptr(rgb), 2.0, -1.0, N.ptr(key), step, ymat if y else None, N.stream()), "vs_resize_pre")
             torch.cuda.synchronize()
         finally:
-            os.environ.pop("VIDEOSEAL_RESIZE", None)
+            L.vs_debug_set(0, 0)
         return rgb, key
     r0, k0 = run("tile")
     r1, k1 = run(None)
@@ -992,11 +990,11 @@ def test_resize_pre_forms_are_bit_identical(cfg):
         a, b = run("tile", **kw), run(None, **kw)
         assert all((p is None and q is None) or torch.equal(p, q) for p, q in zip(a, b))
     for strip in (2, 6, 512):
-        os.environ["VS_RESIZE_STRIP_TEST"] = str(strip)
+        L.vs_debug_set(1, strip)
         try:
             r2, k2 = run(None)
         finally:
-            os.environ.pop("VS_RESIZE_STRIP_TEST", None)
+            L.vs_debug_set(1, 0)
         assert torch.equal(r2, r0) and torch.equal(k2, k0), strip
 
 

@@ -24,9 +24,9 @@ def timeit(fn, reps=20):
 for aa in (1, 0):
     ms = timeit(lambda: N.check(L.vs_resize_pre(N.ptr(x), B, 3, H, W, S, S, aa, N.ptr(rgb), 2.0, -1.0, None, 1, None, N.stream()), "r"))
     print(f"resize_pre fp32 aa={aa}: {ms*1e3:7.1f} us  {(x.numel()*4 + rgb.numel()*4)/ms/1e6:7.0f} GB/s   (row-streaming separable form)")
-    os.environ["VIDEOSEAL_RESIZE"] = "tile"
+    L.vs_debug_set(0, 1)
     ms = timeit(lambda: N.check(L.vs_resize_pre(N.ptr(x), B, 3, H, W, S, S, aa, N.ptr(rgb), 2.0, -1.0, None, 1, None, N.stream()), "r"))
-    os.environ.pop("VIDEOSEAL_RESIZE")
+    L.vs_debug_set(0, 0)
     print(f"resize_pre fp32 aa={aa}: {ms*1e3:7.1f} us  {(x.numel()*4 + rgb.numel()*4)/ms/1e6:7.0f} GB/s   (32 x 8 tile form)")
     ms = timeit(lambda: N.check(L.vs_resize_pre_u8(N.ptr(xu), B, H, W, S, S, aa, N.ptr(rgb), 2.0, -1.0, None, 1, None, N.stream()), "r"))
     print(f"resize_pre u8   aa={aa}: {ms*1e3:7.1f} us  {(xu.numel() + rgb.numel()*4)/ms/1e6:7.0f} GB/s")

@@ -54,10 +54,10 @@ for F_ in (16, 32, 128):
             ms = timeit(mk(v))
             row.append(f"v{v} {ms*1e3:6.1f}us")
         for strip in (32, 48, 64, 96, 128):
-            os.environ["VS_TAIL_STRIP_TEST"] = str(strip)
+            L.vs_debug_set(2, strip)
             ms = timeit(mk(4))
             row.append(f"s{strip} {ms*1e3:6.1f}us")
-        os.environ.pop("VS_TAIL_STRIP_TEST")
+        L.vs_debug_set(2, 0)
         ms = timeit(mk(0))
         row.append(f"default {ms*1e3:6.1f}us {nbytes/ms/1e6:5.0f}GB/s")
         print("  ".join(row), flush=True)

@@ -363,6 +363,9 @@ int launch_g(const vs_conv_desc_t& d, hipStream_t st) {
   const int pps = (pairs + sk - 1) / sk;
   if ((int64_t)(sk - 1) * pps >= pairs) return VS_ERR_BAD_ARG;           // an empty K slice
   if (mt * nt * sk > 0x7fffffffLL || M > 0x7fffffffLL) return VS_ERR_UNSUPPORTED;
+  // store_tile_full / store_tile_guarded address a tile with 32-bit byte offsets from its first element (conv_gemm.hip / gemm_pl.hip check the
+  // same bound and keep a 64-bit path; this kernel has only the 32-bit one)
+  if ((int64_t)BM * std::max<int64_t>(std::max<int64_t>(d.out_ld, d.res ? d.res_ld : 0), sk > 1 ? d.splitk_ld : 0) * 4 >= (1LL << 31)) return VS_ERR_UNSUPPORTED;
   const int ntot = (int)(mt * nt * sk);
   static const int force_grid = [] { const char* e = getenv("VS_GEMM_GRID"); return e ? atoi(e) : 0; }();      // experiments: 0 = one workgroup per CU
   const int grid = std::min(ntot, force_grid > 0 ? force_grid : vs_num_cus());

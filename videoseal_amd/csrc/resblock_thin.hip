@@ -500,7 +500,9 @@ __global__ __launch_bounds__(NT32) void resblock_thin32_kernel(const RbArgs d, c
 
 extern "C" int vs_resblock_thin_supported(int cin_ld, int cmid, int cout) {
   if (cin_ld < 4 || (cin_ld & 3)) return 0;
-  return ((cmid == 16 && cout == 16 && cin_ld <= 16) || (cmid == 32 && cout == 32 && cin_ld <= 32)) ? 1 : 0;      // (32 channels: arith 2 only)
+  // (32 channels: arith 2 only, and 155 KB of static LDS -- a device whose workgroups get 64 KiB takes the two-launch form the callers fall back to)
+  if (cmid == 32 && cout == 32 && cin_ld <= 32) return vs_max_lds_bytes() >= (int)(XP32_BYTES + TT32_BYTES + 2 * W32_CONV + W32_RES) ? 1 : 0;
+  return (cmid == 16 && cout == 16 && cin_ld <= 16) ? 1 : 0;
 }
 
 extern "C" int vs_resblock_thin(const vs_resblock_thin_desc_t* d, void* stream) {

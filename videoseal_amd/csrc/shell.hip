@@ -935,8 +935,8 @@ extern "C" int vs_resize_pre(const float* src, int B, int C, int H, int W, int o
   const float y0 = ymat3 ? ymat3[0] : 0.f, y1 = ymat3 ? ymat3[1] : 0.f, y2 = ymat3 ? ymat3[2] : 0.f;
   // row-streaming separable kernel (default) where its windows fit: 3 planes, <= 8 taps per direction, <= 448 input columns per 128 outputs
   // (scales up to 3.4); VIDEOSEAL_RESIZE=tile keeps the 32 x 8 tile kernel, VS_RESIZE_STRIP=<output rows> overrides the strip height
-  const char* const env_form = getenv("VIDEOSEAL_RESIZE");          // (read per call: tests and tools switch forms inside one process)
-  const bool tile_only = env_form && !strcmp(env_form, "tile");
+  static const bool env_tile = [] { const char* e = getenv("VIDEOSEAL_RESIZE"); return e && !strcmp(e, "tile"); }();       // process-wide default, read once
+  const bool tile_only = env_tile || vs_debug_get(VS_DBG_RESIZE_FORM) == 1;
   static const int env_strip = [] { const char* e = getenv("VS_RESIZE_STRIP"); return e ? atoi(e) : 0; }();
   const float sx = (float)W / (float)ow, sy = (float)H / (float)oh;
   const float supx = antialias ? (sx >= 1.f ? sx : 1.f) : 1.f, supy = antialias ? (sy >= 1.f ? sy : 1.f) : 1.f;
@@ -947,12 +947,14 @@ extern "C" int vs_resize_pre(const float* src, int B, int C, int H, int W, int o
     for (int cand : {64, 48, 32, 24, 16})            // tallest strip that still gives every CU two workgroups (one round at two resident per CU)
       if ((int64_t)cols * ((oh + cand - 1) / cand) * B >= 512) { strip = cand; break; }
     if (env_strip >= 2) strip = env_strip;
-    if (const char* e = getenv("VS_RESIZE_STRIP_TEST")) { const int v = atoi(e); if (v >= 1) strip = v; }     // tests: any strip height, per call
+    if (const int v = vs_debug_get(VS_DBG_RESIZE_STRIP); v >= 1) strip = v;       // tests: any strip height, per call
     dim3 gs(cols, (oh + strip - 1) / strip, B);
     const size_t lds = (size_t)(RS_GI * 3 * RS_INW + RS_RING * 3 * RSO_W) * sizeof(float);
+    if ((int64_t)lds <= vs_max_lds_bytes()) {           // 66 KiB: beyond the 64 KiB of pre-gfx950 parts -> the tile kernel below
     hipLaunchKernelGGL(resize_pre_stream_kernel, gs, dim3(256), lds, (hipStream_t)stream, src, B, H, W, oh, ow, antialias, dst_rgb, mul, add, dst_key,
                        key_step < 1 ? 1 : key_step, key_mode, y0, y1, y2, strip);
     return vs_launch_status();
+    }
   }
   dim3 grid((ow + 31) / 32, (oh + 7) / 8, B);
   hipLaunchKernelGGL(resize_pre_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, src, B, C, H, W, oh, ow, antialias, dst_rgb, mul,
@@ -1017,7 +1019,7 @@ extern "C" int vs_embed_tail(const vs_tail_desc_t* d, void* stream) {
       strip = 48;
     }
     if (env_strip >= 4) strip = (env_strip + 3) / 4 * 4;
-    if (const char* e = getenv("VS_TAIL_STRIP_TEST")) { const int v = atoi(e); if (v >= 4) strip = (v + 3) / 4 * 4; }     // tests: every strip height, per call
+    if (const int v = vs_debug_get(VS_DBG_TAIL_STRIP); v >= 4) strip = (v + 3) / 4 * 4;     // tests: every strip height, per call
     dim3 gs((unsigned)cols, (d->H + strip - 1) / strip, d->F);
     const size_t lds_w = (size_t)2 * d->Cd * DW_W * DW_H * sizeof(float);
     const size_t lds_j = lds_w + RING * TLW * sizeof(float);

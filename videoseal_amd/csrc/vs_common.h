@@ -33,6 +33,23 @@ static inline int vs_default_arith() {
   return a;
 }
 
+// Development switches of the launchers (tests / tools select a kernel form or a strip height PER CALL): set through the exported
+// vs_debug_set(key, value) -- an atomic the launch path reads; nothing on a launch path calls getenv (not thread-safe against setenv, and a
+// test hook in production code).  0 = the library's own choice.
+enum { VS_DBG_RESIZE_FORM = 0 /* 1 = 32 x 8 tile kernel */, VS_DBG_RESIZE_STRIP = 1 /* output rows */, VS_DBG_TAIL_STRIP = 2 /* rows */, VS_DBG_COUNT = 8 };
+int vs_debug_get(int key);     // api.hip
+
+// LDS a workgroup may ask for on the current device (160 KiB on gfx950, 64 KiB on earlier CDNA parts): launchers whose kernels want more than
+// 64 KiB check it and fall back to their small-LDS form instead of failing the launch
+static inline int vs_max_lds_bytes() {
+  static const int n = [] {
+    int dev = 0, v = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMaxSharedMemoryPerBlock, dev) != hipSuccess || v <= 0) v = 64 * 1024;
+    return v;
+  }();
+  return n;
+}
+
 // compute units of the current device (256 on MI355X): grid size of the persistent kernels
 static inline int vs_num_cus() {
   static const int n = [] {
