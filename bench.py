@@ -110,6 +110,32 @@ def cpu_baseline(card_path, size, mode, step_size, max_seconds=25.0):
                 w = A.hue(A.saturation(A.contrast(A.brightness(w, br), co), sa), hu)
             R.detect(sd, spec, w)
 
+    # the UNMODIFIED reference module instead of the port whenever a checkout is reachable (VIDEOSEAL_REFERENCE_ROOT, or /root/reference in the
+    # build container; the GPU box has neither -> "port").  Same state_dict, same sample; the chain's augmentations need torchvision -> port.
+    kind, ref_model = "port", None
+    ref_root = os.environ.get("VIDEOSEAL_REFERENCE_ROOT") or ("/root/reference" if os.path.isdir("/root/reference/videoseal") else None)
+    if ref_root and mode in ("image", "video") and os.environ.get("VS_BENCH_CPU_PORT") != "1":
+        try:
+            import yaml
+            sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+            import make_golden as MG                    # the stub-import recipe of SURVEY appendix A (timm / torchvision / cv2 / av stand-ins)
+            MG.REF = ref_root
+            ref_model = MG.build_reference(spec, yaml.safe_load(open(os.path.join(ref_root, "videoseal", "cards", os.path.basename(card_path))))).eval()
+            ref_model.load_state_dict(sd, strict=True)
+            ref_model.step_size = step_size
+            kind = "reference"
+        except Exception as e:                          # a checkout that does not import here: say so and time the port
+            print(f"cpu_baseline: reference at {ref_root} not usable ({e!r}); timing the port", file=sys.stderr)
+            ref_model = None
+    if ref_model is not None:
+        def run():              # noqa: F811
+            with torch.no_grad():
+                if mode == "image":
+                    w = ref_model.embed(imgs, synthetic_msgs(n, spec.nbits), is_video=False)["imgs_w"]
+                else:
+                    w = ref_model.embed(imgs, synthetic_msgs(1, spec.nbits), is_video=True)["imgs_w"]
+                ref_model.detect(w, is_video=(mode != "image"))
+
     host = os.cpu_count() or 1
     tried = {}
     # every host core is opt-in (VS_BENCH_CPU_ALL_CORES=1): on the 256-CPU GPU box 256 threads ran the same sample 83x SLOWER than
@@ -126,11 +152,13 @@ def cpu_baseline(card_path, size, mode, step_size, max_seconds=25.0):
     cal = current_profile("cpu_port_vs_reference")
     ratio = json.load(open(cal)) if cal else None
     return {"value": tried[cores], "port_over_reference": (ratio["port_over_reference"] if ratio else None),
-            "port_over_reference_note": (ratio["note"] if ratio else None), "unit": "frames/s", "cores": cores, "host_cpus": host, "kind": "port",
+            "port_over_reference_note": (ratio["note"] if ratio else None), "unit": "frames/s", "cores": cores, "host_cpus": host, "kind": kind,
             "by_threads": {str(k): v for k, v in tried.items()},
             "sample": f"{n} frames {size}x{size}, {mode} mode, embed" + ("+augment chain" if mode == "chain" else "") + "+detect, best rep after 1 warm-up per thread count, "
-                      "torch fp32 CPU oracle (restatement of the reference path pinned by tests/golden; the reference package itself "
-                      "is not present on the GPU box)"}
+                      + ("the UNMODIFIED reference module (checkout at %s, stub-import recipe of tests/golden/make_golden.py), seeded state_dict" % ref_root
+                         if kind == "reference" else
+                         "torch fp32 CPU oracle (restatement of the reference path pinned by tests/golden; the reference package itself "
+                         "is not present on the GPU box)")}
 
 
 def measure_sustained_mfma():
@@ -180,6 +208,7 @@ def parse_args(argv=None):
     ap.add_argument("--detect-only", action="store_true", help="time model.detect() only (BASELINE config 5: ChunkySeal extractor)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timers", action="store_true")
+    ap.add_argument("--cpu-baseline-only", action="store_true", help="time only the CPU leg (no GPU needed) and print its JSON object")
     ap.add_argument("--dump-preds", default=None, help="rank 0 saves the (gathered) logits of the last timed step to this path (torch.save)")
     ap.add_argument("--no-extra", action="store_true", help="default run only: skip the short legs over the other BASELINE configs "
                     "(video mode, configs[2] chain, configs[3] streaming, configs[4] ChunkySeal detect, the training step)")
@@ -405,8 +434,9 @@ def _run(args, world, rank, dev, dist_on, n_ranks_seen):
         prof_name = eng.kernel_timers[0][0]
         dom_is_bottleneck = prof_name.startswith("bott.")
         if dom_is_bottleneck:
+            res = cfg.img_size // 2 ** (len(cfg.mults) - 1)           # (videoseal_1.0: 384 channels @32x32; the 0.0 card has its own width)
             kname = (("conv3x3_pl_kernel" if getattr(eng, "planes_chain_ran", False) else "conv3x3_patch_pc_kernel")
-                     if split else "conv_gemm_kernel") + " (U-Net bottleneck 3x3 conv 384->384 @32x32, "
+                     if split else "conv_gemm_kernel") + f" (U-Net bottleneck 3x3 conv {cfg.bott}->{cfg.bott} @{res}x{res}, "
         else:       # detect-only workloads: the extractor GEMM that carries most of the step (engine.prof_extractor names it)
             kname = prof_name + " ("
         roof = {"bound": "mfma",
@@ -469,10 +499,11 @@ def _run(args, world, rank, dev, dist_on, n_ranks_seen):
         total_frames = (args.frames if stream else B * world) * args.steps
         fps = total_frames / elapsed
         # algorithmic work per frame: 28.28 GMAC embed (image) / 7.07 (video, step 4) + 6.16 GMAC detect
-        gmac = (28.28 if not is_video else 28.28 / cfg.step_size) + 6.16
+        emb_gmac = {"videoseal_1.0": 28.28, "pixelseal": 59.65}.get(args.card)        # BASELINE.md 2 (embedder GMAC per 256 x 256 pass)
+        gmac = ((emb_gmac or 0.0) if not is_video else (emb_gmac or 0.0) / cfg.step_size) + 6.16
         if args.detect_only:
             gmac = 613.6 if args.card == "chunkyseal" else 6.16
-        known_macs = args.card == "videoseal_1.0" or (args.card == "chunkyseal" and args.detect_only)     # SURVEY 8(d) counts these two networks
+        known_macs = emb_gmac is not None or (args.card == "chunkyseal" and args.detect_only)     # networks BASELINE.md 2 / SURVEY 8(d) count
         if not known_macs:
             gmac = 0.0
         if roof is not None and known_macs:
@@ -576,6 +607,12 @@ def self_launch(args):
 
 def main():
     args = parse_args()
+    if args.cpu_baseline_only:
+        import videoseal_amd           # (card -> step size; no device is touched)
+        from videoseal_amd.layout import cfg_from_card, load_card
+        card_path = os.path.join(ROOT, "videoseal_amd", "cards", args.card + ".yaml")
+        print(json.dumps(cpu_baseline(card_path, args.size, args.mode, cfg_from_card(load_card(card_path)).step_size)), flush=True)
+        return
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ and os.environ.get("VS_BENCH_FORCE_DIST") != "1":
         self_launch(args)
     line = run(args)

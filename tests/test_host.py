@@ -389,3 +389,19 @@ def test_videoseal_lib_selects_another_build_of_the_library():
     env.pop("VIDEOSEAL_LIB")
     out = subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, text=True, timeout=300)
     assert out.stdout.strip() == os.path.join(root, "videoseal_amd", "csrc", "libvideoseal_hip.so"), out.stderr
+
+
+def test_bench_cpu_leg_times_the_unmodified_reference_when_a_checkout_is_present():
+    """bench.py's cpu_baseline leg (`--cpu-baseline-only`: no GPU needed): kind 'reference' = the unmodified module (stub-import recipe) wherever a
+    checkout is reachable, kind 'port' = the oracle otherwise (VS_BENCH_CPU_PORT=1 forces it; the GPU box has no checkout)"""
+    import subprocess
+    import sys
+    have_ref = os.path.isdir("/root/reference/videoseal")
+    for force_port in (False, True):
+        env = dict(os.environ, **({"VS_BENCH_CPU_PORT": "1"} if force_port else {}))
+        env.pop("VIDEOSEAL_REFERENCE_ROOT", None)
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--cpu-baseline-only", "--size", "128"], env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+        assert d["kind"] == ("reference" if (have_ref and not force_port) else "port") and d["value"] > 0 and d["cores"] >= 1 and d["unit"] == "frames/s"
+        assert ("UNMODIFIED reference" in d["sample"]) == (d["kind"] == "reference")
