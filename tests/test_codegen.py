@@ -79,5 +79,5 @@ def test_the_budget_itself_only_tolerates_known_spills():
 
 
 # epilogue-only spills of the TN = 3 tiles (96 accumulators + a batch of residual / bias values; none inside a K loop), round-5 values
-KNOWN_SPILLS = {"conv3x3_pl_kernel<3>": 32, "gemm_pl_kernel<3>": 67, "gemm1x1_pc_kernel<3, true, 2>": 101, "gemm1x1_pc_kernel<3, false, 2>": 96,
+KNOWN_SPILLS = {"conv3x3_pl_kernel<3>": 32, "gemm_pl_kernel<3>": 67, "gemm1x1_pc_kernel<3, true, 2, 2>": 101, "gemm1x1_pc_kernel<3, false, 2, 2>": 96,
                 "conv3x3_patch_pc_kernel<3, 8, 2>": 90}

@@ -1,5 +1,6 @@
 """Per-kernel parity: every C-ABI entry point against the same op computed by torch fp32 on the CPU
 (ATen is what the reference runs).  Tolerances are written next to each check.  Needs an MI355X."""
+import os
 import ctypes as C
 import math
 
@@ -446,6 +447,13 @@ GEMM_PC_CASES = [
     (2, 16, 24, 32, 130, 2, False, True, 2, 1),       # single pair, three N tiles of which one ragged
     (3, 15, 15, 160, 96, 0, True, True, 1, 1),        # 225-row frames: tiles straddle frame boundaries at arbitrary rows (ChunkySeal)
     (2, 31, 31, 96, 200, 0, True, True, 2, 1),
+    # tile code 26 (round 5): 128 x 96 tiles, four consumer waves stacked over the rows (2 x f16 arithmetic only)
+    (2, 16, 16, 1536, 384, 0, True, True, 10, 1),     # ConvNeXt stage-2 pwconv2: the whole K in one workgroup, no K slices
+    (2, 16, 16, 96, 384, 2, False, False, 10, 1),     # GELU epilogue
+    (3, 8, 8, 768, 200, 0, True, True, 10, 1),        # ragged M (192 rows) and N (200 = 2 x 96 + 8), two frames per tile
+    (5, 8, 8, 64, 40, 3, False, False, 10, 2),        # K slices + tanh
+    (3, 15, 15, 160, 96, 0, True, True, 10, 1),       # frame boundaries at arbitrary rows
+    (2, 31, 31, 96, 200, 1, True, True, 10, 1),
 ]
 
 
@@ -455,6 +463,8 @@ def test_gemm1x1_pc(eng, case):
     if not eng.use_split:
         pytest.skip("split back-end only")
     B, H, W, K, Nn, act, grn, use_res, tl, sk = case
+    if tl == 10 and eng.arith != 2:
+        pytest.skip("tile 26 exists in the 2 x f16 arithmetic only")
     g = torch.Generator().manual_seed(hash(case) % 1000)
     h = torch.randn(B, H * W, K, generator=g)
     sc = 1 + 0.3 * torch.randn(B, K, generator=g)
@@ -722,6 +732,56 @@ def test_first_bottleneck_block_message_table(eng, Bm):
     torch.cuda.synchronize()
     assert rel_err(plain, ref) < 2e-5
     assert rel_err(out, ref) < 2e-5 and (out - plain).abs().max() < 2e-5
+
+
+@pytest.mark.parametrize("B", [32, 8])
+def test_first_bottleneck_block_on_operand_planes(eng, B):
+    """round 5: resblock_msg0(planes_out=True) -- c0 (latent planes + border-class table epilogue) and c1 (+ 1x1 phase over h3) on the all-DMA
+    planes kernel, output as the chain's operand planes.  32 frames (256 tiles, no K split): the planes equal the split of the fp32 result of
+    the wave-specialised path BIT FOR BIT (same products, same K order); 8 frames (K slices in c1): equal to fp32 rounding."""
+    if not (eng.use_split and eng.arith == 2 and eng.planes_chain):
+        pytest.skip("2 x f16 planes chain only")
+    nlat, hid, H, W, Co = 128, 256, 32, 32, 384
+    g = torch.Generator().manual_seed(52)
+    latent = torch.randn(B, nlat, H, W, generator=g)
+    msg = torch.randn(1, hid, generator=g)
+    x = torch.cat([latent, msg[:, :, None, None].expand(B, hid, H, W)], 1)
+    w0 = torch.randn(Co, nlat + hid, 3, 3, generator=g) / math.sqrt(9 * (nlat + hid))
+    w1 = torch.randn(Co, Co, 3, 3, generator=g) / math.sqrt(9 * Co)
+    wr = torch.randn(Co, nlat + hid, 1, 1, generator=g) / math.sqrt(nlat + hid)
+    b0, b1, br = (torch.randn(Co, generator=g) * 0.1 for _ in range(3))
+    xa = to_nhwc(x)
+    p = {}
+    for k, (w, b) in dict(c0=(w0, b0), c1=(w1, b1), res=(wr, br)).items():
+        wt, cp = pack_conv(w.to(DEV), rup(w.shape[1], 4))
+        p[k] = ConvW(wt, b.to(DEV), Co, w.shape[2], w.shape[3], cp)
+    p["cout"] = Co
+    lat_dev = dv(msg)
+    old = eng.resblock_msg0(xa, p, "tm", lat_dev, 1, nlat)                      # wave-specialised kernels, fp32 out
+    want = eng.to_planes(old, "tm.want").clone()
+    ghost, xpl = eng.resblock_msg0(xa, p, "tm", lat_dev, 1, nlat, planes_out=True)
+    torch.cuda.synchronize()
+    assert xpl is not None and ghost.t is None and ghost.C == Co
+    n = 2 * old.rows * Co
+    got = xpl[:n].clone()
+    if B == 32:
+        assert eng._planes_split(ghost) == 1
+        assert torch.equal(got, want[:n])
+    else:
+        assert eng._planes_split(ghost) > 1
+        def value(pl):      # hi + lo of the [2][C/16][rows][16] f16 planes, back in fp32 units
+            h = pl.view(torch.float16).float().view(2, -1)
+            return (h[0] + h[1]) / 16.0
+        ref = F.relu(F.conv2d(F.relu(F.conv2d(x, w0, b0, padding=1)), w1, b1, padding=1)) + F.conv2d(x, wr, br)
+        a, b_ = value(got), value(want[:n])
+        assert (a - b_).abs().max().item() < 2e-5 * float(ref.abs().max())
+    env = os.environ.get("VIDEOSEAL_MSG0_PLANES")
+    eng.msg0_planes = False
+    try:
+        o2, pl2 = eng.resblock_msg0(xa, p, "tm", lat_dev, 1, nlat, planes_out=True)
+        assert pl2 is None and torch.equal(o2.t, old.t)
+    finally:
+        eng.msg0_planes = env != "0"
 
 
 def test_msg_latent_and_broadcast(eng):

@@ -526,7 +526,8 @@ extern "C" int vs_conv_gemm(const vs_conv_desc_t* dp, void* stream) {
     VS_REQUIRE(small_ok);
     return vs_conv3x3_small_dispatch(d, st);
   }
-  if (tile == 17 || tile == 18) {   // wave-specialised 1x1 GEMM: dense rows, whole 32-wide K pairs, no second phase
+  if (tile == 17 || tile == 18 || tile == 26) {   // wave-specialised 1x1 GEMM: dense rows, whole 32-wide K pairs, no second phase
+    if (tile == 26) VS_REQUIRE(d.arith == 2);     // 128 x 96 tiles: 2 x f16 arithmetic only
     VS_REQUIRE(can_split0 && d.wt_blk && ((uintptr_t)d.wt_blk & 15) == 0 && !(d.tile_hint & VS_CONV_FORCE_F32));
     VS_REQUIRE(d.KH == 1 && d.KW == 1 && d.SH == 1 && d.SW == 1 && d.PH == 0 && d.PW == 0 && d.Ho == d.H && d.Wo == d.W && !d.in2);
     VS_REQUIRE(d.Cin % 32 == 0 && d.CinP == d.Cin && d.in_sy == (int64_t)d.W * d.in_sx && d.in_sb == (int64_t)d.H * d.in_sy);

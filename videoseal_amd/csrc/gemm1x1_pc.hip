@@ -39,12 +39,16 @@ __device__ __forceinline__ void dma_1k(const char* gp, unsigned char* lds_base) 
 // tile's first operands while the consumers are in the epilogue, and the 50 MB of output of a 128 x 192-tile round drain under the
 // next tile's MFMAs instead of in a stores-only phase at the end of every round (measured: stores 16.6 us + activation 6 us of a
 // 75.7 us K = 384 launch, tools/bench_gemm.py ksweep).
-template <int TN, bool GRN, int NP>
+template <int TN, bool GRN, int NP, int WN>
 __device__ __forceinline__ void gemm1x1_pc_tile(const vs_conv_desc_t& d, const int M, const int mtiles, const int ntiles,
                                                 const int pairs_per_split, const int tile, unsigned char* const smem) {
-  constexpr int TM = 2;
-  constexpr int BN = 64 * TN;
+  // WN = 2: 2 x 2 consumer waves of 64 rows x 32*TN columns (tiles 128 x 128 / 128 x 192); WN = 1 (round 5): 4 x 1 waves of 32 rows x 32*TN
+  // columns -- a 128 x 96 tile, twice as many workgroups per layer, for the GEMMs whose 128 x 192 tiles needed K slices (and a second
+  // launch to add them up) to occupy 256 CUs: ConvNeXt stage-2 pwconv2, 8192 x 384 x 1536 = 64 x 4 tiles with the whole K in one workgroup
+  constexpr int TM = WN;
+  constexpr int BN = 32 * TN * WN;
   constexpr int NG = BN / 32;
+  static_assert((NP * NG) % 2 == 0, "weight chunks per producer thread");
   using AR = Arith<NP>;
   constexpr int A_STAGE = a_stage<NP>();
   constexpr int WBLK = NP * 1024;                        // one (32 rows x 16 k) weight block, all planes
@@ -79,7 +83,7 @@ __device__ __forceinline__ void gemm1x1_pc_tile(const vs_conv_desc_t& d, const i
     // loop body is straight-line so that hipcc's s_waitcnt vmcnt(N) placement is exact.
     const int pt = tid & 255;
     constexpr int NI = BM * 8 / 256;       // 4 A items per thread per pair
-    constexpr int NBP = NP * TN;           // 16-byte weight chunks per thread per pair (2 steps * NP planes * NG * 64 / 256)
+    constexpr int NBP = NP * NG / 2;       // 16-byte weight chunks per thread per pair (2 steps * NP planes * NG * 64 / 256)
     constexpr int CPS = NP * NG * 64;      // chunks per step
     const int seg = pt & 7;
     const int HW = d.H * d.W;
@@ -197,7 +201,7 @@ __device__ __forceinline__ void gemm1x1_pc_tile(const vs_conv_desc_t& d, const i
   }
 
   // ==================================================================== consumers
-  const int wm = wave >> 1, wn = wave & 1;
+  const int wm = WN == 2 ? wave >> 1 : wave, wn = WN == 2 ? wave & 1 : 0;
   // consumer-side barrier: LDS reads retired, but NOT vmcnt(0) -- __syncthreads() would wait for the previous tile's output stores
   // (persistent kernel) before the first barrier of the next tile; the consumers exchange nothing through global memory
   auto cbar = []() __attribute__((always_inline)) {
@@ -294,12 +298,12 @@ __device__ __forceinline__ void gemm1x1_pc_tile(const vs_conv_desc_t& d, const i
   else store_tile_guarded<TM, TN>(acc, ob, (int)d.out_ld, rb, (int)d.res_ld, r_e, g_e, rows_left, d.N - c0, d.n_store - c0);
 }
 
-template <int TN, bool GRN, int NP>
+template <int TN, bool GRN, int NP, int WN = 2>
 __global__ __launch_bounds__(512, 2) void gemm1x1_pc_kernel(const vs_conv_desc_t d, const int M, const int mtiles, const int ntiles,
                                                             const int pairs_per_split, const int ntot) {
-  constexpr int B_STAGE = NP * (64 * TN) * 32;
+  constexpr int B_STAGE = NP * (32 * TN * WN) * 32;
   __shared__ __attribute__((aligned(16))) unsigned char smem[2 * a_stage<NP>() + 2 * B_STAGE];
-  for (int tile = blockIdx.x; tile < ntot; tile += gridDim.x) gemm1x1_pc_tile<TN, GRN, NP>(d, M, mtiles, ntiles, pairs_per_split, tile, smem);
+  for (int tile = blockIdx.x; tile < ntot; tile += gridDim.x) gemm1x1_pc_tile<TN, GRN, NP, WN>(d, M, mtiles, ntiles, pairs_per_split, tile, smem);
 }
 
 // out = act(sum_ks ws[ks] + bias) [+ ws[split_k] + bias2 : the 1x1 second phase of the patch kernel] (+ res); columns in
@@ -353,9 +357,9 @@ __global__ __launch_bounds__(256) void splitk_epilogue_kernel(const vs_conv_desc
   }
 }
 
-template <int TN>
+template <int TN, int WN = 2>
 int launch_g(const vs_conv_desc_t& d, hipStream_t st) {
-  constexpr int BN = 64 * TN;
+  constexpr int BN = 32 * TN * WN;
   const int64_t M = (int64_t)d.B * d.H * d.W;
   const int64_t mt = cdiv64(M, BM), nt = cdiv64(d.split_k > 1 ? d.N : d.n_store, BN);
   const int pairs = d.CinP / 32;
@@ -371,13 +375,15 @@ int launch_g(const vs_conv_desc_t& d, hipStream_t st) {
   const int grid = std::min(ntot, force_grid > 0 ? force_grid : vs_num_cus());
   if (d.arith == 2) {
     if (d.a_scale)
-      hipLaunchKernelGGL((gemm1x1_pc_kernel<TN, true, 2>), dim3(grid), dim3(512), 0, st, d, (int)M, (int)mt, (int)nt, pps, ntot);
+      hipLaunchKernelGGL((gemm1x1_pc_kernel<TN, true, 2, WN>), dim3(grid), dim3(512), 0, st, d, (int)M, (int)mt, (int)nt, pps, ntot);
     else
-      hipLaunchKernelGGL((gemm1x1_pc_kernel<TN, false, 2>), dim3(grid), dim3(512), 0, st, d, (int)M, (int)mt, (int)nt, pps, ntot);
+      hipLaunchKernelGGL((gemm1x1_pc_kernel<TN, false, 2, WN>), dim3(grid), dim3(512), 0, st, d, (int)M, (int)mt, (int)nt, pps, ntot);
+  } else if constexpr (WN == 1) {
+    return VS_ERR_UNSUPPORTED;          // 128 x 96 tiles: 2 x f16 arithmetic only (3 planes x 3 column groups do not divide over the producer threads)
   } else if (d.a_scale)
-    hipLaunchKernelGGL((gemm1x1_pc_kernel<TN, true, 3>), dim3(grid), dim3(512), 0, st, d, (int)M, (int)mt, (int)nt, pps, ntot);
+    hipLaunchKernelGGL((gemm1x1_pc_kernel<TN, true, 3, WN>), dim3(grid), dim3(512), 0, st, d, (int)M, (int)mt, (int)nt, pps, ntot);
   else
-    hipLaunchKernelGGL((gemm1x1_pc_kernel<TN, false, 3>), dim3(grid), dim3(512), 0, st, d, (int)M, (int)mt, (int)nt, pps, ntot);
+    hipLaunchKernelGGL((gemm1x1_pc_kernel<TN, false, 3, WN>), dim3(grid), dim3(512), 0, st, d, (int)M, (int)mt, (int)nt, pps, ntot);
   int rc = vs_launch_status();
   if (rc != VS_OK || sk == 1) return rc;
   return vs_splitk_epilogue(d, (int)M, st);
@@ -393,11 +399,12 @@ int vs_splitk_epilogue(const vs_conv_desc_t& d, int M, hipStream_t st) {
   return vs_launch_status();
 }
 
-// tile 17 = 128 x 128, tile 18 = 128 x 192.  Preconditions are checked by vs_conv_gemm.
+// tile 17 = 128 x 128, tile 18 = 128 x 192, tile 26 = 128 x 96 (four consumer waves stacked over the rows).  Preconditions are checked by vs_conv_gemm.
 int vs_gemm1x1_pc_dispatch(const vs_conv_desc_t& d, int tile, hipStream_t st) {
   switch (tile) {
     case 17: return launch_g<2>(d, st);
     case 18: return launch_g<3>(d, st);
+    case 26: return launch_g<3, 1>(d, st);
     default: return VS_ERR_UNSUPPORTED;
   }
 }

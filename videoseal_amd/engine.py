@@ -281,6 +281,8 @@ class HipEngine:
         self.upconv_fused = os.environ.get("VIDEOSEAL_UPCONV", "lowres") != "unfused"    # thin levels: GEMM + gather in one kernel
         self.msg_table_conv = os.environ.get("VIDEOSEAL_MSG_TABLE", "1") != "0"         # first bottleneck block: message channels as a table
         self.planes_chain = os.environ.get("VIDEOSEAL_PLANES", "1") != "0"              # bottleneck chain on pre-split operand planes
+        self.msg0_planes = os.environ.get("VIDEOSEAL_MSG0_PLANES", "1") != "0"          # ... including its first block (round 5)
+        self.pw2_narrow = os.environ.get("VIDEOSEAL_PW2_NARROW", "1") != "0"            # stage-2 pwconv2 on 128 x 96 tiles without K slices (round 5)
         self.planes_gemm = os.environ.get("VIDEOSEAL_PLANES", "1") != "0"               # ConvNeXt 1x1 GEMMs on operand planes
         self.fused_blocks = os.environ.get("VIDEOSEAL_CNX_FUSED", "1") != "0"           # stage 0 / 1 blocks with h kept on chip (convnext_fused.hip)
         self.thin_fused = os.environ.get("VIDEOSEAL_THIN_FUSED", "1") != "0"              # 16-channel ResnetBlocks in one launch (resblock_thin.hip)
@@ -754,8 +756,9 @@ class HipEngine:
                 "vs_rmsnorm_act")
         return out
 
-    def resblock_msg0(self, h3: Act, p, tag: str, lat: torch.Tensor, Bm: int, nlat: int) -> Act:
-        """First bottleneck block (unet.py:183-185) on h3 = [latent (nlat channels) | message (spatially constant)]: the 3x3 conv over
+    def resblock_msg0(self, h3: Act, p, tag: str, lat: torch.Tensor, Bm: int, nlat: int, planes_out: bool = False):
+        """planes_out: the caller continues with bottleneck_planes -> returns (activation, its operand planes or None).
+        First bottleneck block (unet.py:183-185) on h3 = [latent (nlat channels) | message (spatially constant)]: the 3x3 conv over
         the message channels is a per-frame table of nine border classes (vs_msg_pre), so the conv's K loop covers the latent channels
         only (9*128 instead of 9*384 for VideoSeal 1.0) and the table is added before bias + activation (VS_CONV_PRE)."""
         cout, c0 = p["cout"], p["c0"]
@@ -769,13 +772,41 @@ class HipEngine:
         self.conv(Act(lat, Bm, 1, 1, hidden, hidden), p["c0_msg"], P)
         pre = self.buf(tag + ".pre", Bm * 9 * cout)          # border-class table [Bm][9][N]
         N.check(self.lib.vs_msg_pre(N.ptr(P.t), Bm, cout, N.ptr(pre), N.stream()), "vs_msg_pre")
-        t = self.new_act(tag + ".t", h3.B, h3.H, h3.W, cout)
         tile = (N.CONV_TILE_HI | 0) if cout % 192 == 0 else 15
-        self.conv(h3, p["c0_lat"], t, pad=1, act=N.ACT_RELU, cin=nlat, a_scale=pre, a_scale_ld=(0 if Bm == 1 else 9 * cout), tile_hint=tile | N.CONV_PRE,
-                  prof=("bott.conv3x3.lat" if self.time_all_convs else None))
+        pre_ld = 0 if Bm == 1 else 9 * cout
+        prof0 = "bott.conv3x3.lat" if self.time_all_convs else None
+        ghost = Act(None, h3.B, h3.H, h3.W, cout, cout)
+        sk = self._planes_split(ghost) if (planes_out and self.msg0_planes and cout == h3.C and cout % 192 == 0 and nlat % 16 == 0 and
+                                           h3.H % 16 == 0 and h3.W % 16 == 0) else 0
+        if sk >= 1:
+            # round 5: the block on the all-DMA planes kernel like the rest of the chain (it ran on the wave-specialised kernel: 155 + 359 us
+            # of an image step against 228 us for the same c1 launch on planes).  The latent channels and the whole of h3 are split once
+            # (two conversion passes, 8 + 20 us), c0 reads the latent planes and adds the border-class table in its epilogue (VS_CONV_PRE),
+            # c1 reads t and h3 (its 1x1 second K phase) as planes and writes the chain's first operand planes: no fp32 t / out, and
+            # bottleneck_planes no longer converts its input.  Same products and K order as the kernels it replaces -> same bits at sk = 1.
+            # With few key frames (sk > 1: K slices) c0 keeps the wave-specialised kernel -- the table epilogue has no K-slice form.
+            ptile = N.CONV_TILE_HI | 6
+            h3pl = self.to_planes(h3, tag + ".h3pl")
+            tpl = self.buf("bott.plt", h3.rows * cout).view(torch.int16)
+            xpl = self.buf("bott.pl0", h3.rows * cout).view(torch.int16)
+            if sk == 1:
+                latpl = self.buf(tag + ".latpl", h3.rows * nlat).view(torch.int16)[: 2 * h3.rows * nlat]
+                N.check(self.lib.vs_to_planes(N.ptr(h3.t), h3.rows, nlat, h3.ld, A_MUL, N.ptr(latpl), N.stream()), "vs_to_planes")
+                self.conv(Act(None, h3.B, h3.H, h3.W, nlat, nlat), p["c0_lat"], ghost, pad=1, act=N.ACT_RELU, a_scale=pre, a_scale_ld=pre_ld,
+                          tile_hint=ptile | N.CONV_PRE, in_pl=latpl, out_pl=tpl, prof=prof0)
+            else:
+                t = self.new_act(tag + ".t", h3.B, h3.H, h3.W, cout)
+                self.conv(h3, p["c0_lat"], t, pad=1, act=N.ACT_RELU, cin=nlat, a_scale=pre, a_scale_ld=pre_ld, tile_hint=tile | N.CONV_PRE, prof=prof0)
+                N.check(self.lib.vs_to_planes(N.ptr(t.t), t.rows, cout, t.ld, A_MUL, N.ptr(tpl), N.stream()), "vs_to_planes")
+            self.conv(ghost, p["c1"], ghost, pad=1, act=N.ACT_RELU, in2=Act(None, h3.B, h3.H, h3.W, h3.C, h3.C), w2=p["res"], tile_hint=ptile,
+                      in_pl=tpl, in2_pl=h3pl, out_pl=xpl, **(dict(split_k=sk) if sk > 1 else {}))
+            self.planes_chain_ran = True
+            return ghost, xpl
+        t = self.new_act(tag + ".t", h3.B, h3.H, h3.W, cout)
+        self.conv(h3, p["c0_lat"], t, pad=1, act=N.ACT_RELU, cin=nlat, a_scale=pre, a_scale_ld=pre_ld, tile_hint=tile | N.CONV_PRE, prof=prof0)
         out = self.new_act(tag + ".o", h3.B, h3.H, h3.W, cout)
         self.conv(t, p["c1"], out, pad=1, act=N.ACT_RELU, in2=h3, w2=p["res"])
-        return out
+        return (out, None) if planes_out else out
 
     def _msg0_ok(self, h3: Act, p, nlat: int) -> bool:
         hidden = h3.C - nlat
@@ -931,7 +962,7 @@ class HipEngine:
                 x.H % 16 == 0 and x.W % 16 == 0 and self._planes_split(x) >= 1 and
                 all("bn" not in p and "rms" not in p and p["cout"] == x.C and p["c0"].CinP == x.C and p["res"].CinP == x.C for p in blocks))
 
-    def bottleneck_planes(self, x: Act, blocks, last_out: Optional[Act]) -> Act:
+    def bottleneck_planes(self, x: Act, blocks, last_out: Optional[Act], xpl: Optional[torch.Tensor] = None) -> Act:
         """ResnetBlocks `blocks` (unet.py:24-39) from the fp32 activation x, every intermediate tensor as f16 operand planes: the
         activations are split once by the epilogue that produces them instead of by every consumer, and every conv runs on the all-DMA
         kernel (tile code 22).  Only the last block writes fp32 (into last_out's columns [0, C) if given)."""
@@ -941,7 +972,8 @@ class HipEngine:
         sk = self._planes_split(x)
         kw = dict(split_k=sk) if sk > 1 else {}
         ghost = Act(None, B, H, W, C, C)                  # geometry only: the tensor exists as planes
-        xpl = self.to_planes(x, "bott.pl0")
+        if xpl is None:                                   # (the first block may hand its output over as planes already, resblock_msg0)
+            xpl = self.to_planes(x, "bott.pl0")
         tpl = self.buf("bott.plt", x.rows * C).view(torch.int16)
         ypl = self.buf("bott.pl1", x.rows * C).view(torch.int16)
         out = None
@@ -1019,14 +1051,17 @@ class HipEngine:
                 return None
             return self.new_act(f"up{k}.lcat", B, like.H, like.W, like.C + hid[nlev - k].C)
 
+        xcur_pl = None
         for j in range(c.num_blocks):
             lc = lowres_cat(0, xcur) if j == c.num_blocks - 1 else None
             if j == 0 and lc is None and self._msg0_ok(h3, E["bott"][0], c.zc[-1]):
-                xcur = self.resblock_msg0(h3, E["bott"][0], "bott0", lat, Bm, c.zc[-1])
+                nxt = Act(None, B, h3.H, h3.W, E["bott"][0]["cout"], E["bott"][0]["cout"])
+                chain = c.num_blocks > 1 and not bn_train and self._planes_ok(nxt, E["bott"][1:])
+                xcur, xcur_pl = self.resblock_msg0(h3, E["bott"][0], "bott0", lat, Bm, c.zc[-1], planes_out=chain)
                 continue
             if j >= 1 and not bn_train and self._planes_ok(xcur, E["bott"][j:]):      # the rest of the chain on operand planes
                 lc = lowres_cat(0, xcur)
-                xcur = self.bottleneck_planes(xcur, E["bott"][j:], Act(lc.t, B, lc.H, lc.W, xcur.C, lc.ld) if lc else None)
+                xcur = self.bottleneck_planes(xcur, E["bott"][j:], Act(lc.t, B, lc.H, lc.W, xcur.C, lc.ld) if lc else None, xpl=xcur_pl)
                 break
             xcur = self.resblock(xcur, E["bott"][j], f"bott{j & 1}", out=(Act(lc.t, B, lc.H, lc.W, xcur.C, lc.ld) if lc else None))
         for k in range(nlev):
@@ -1203,7 +1238,13 @@ class HipEngine:
                                                   N.ptr(hpl), st), "vs_to_planes_affine")
                     self.conv(hh, blk["pw2"], cur, res=cur, in_pl=hpl, tile_hint=ptile, split_k=sk2, a_mul=A_MUL_GRN)
                 elif (HW % 64 == 0 or not self.use_split) and not calib:
-                    self.conv(hh, blk["pw2"], cur, res=cur, a_scale=scale, a_scale_ld=hh.ld, a_shift=blk["beta"], **kwa2)
+                    kn = dict(kwa2)
+                    # round 5: where 128-row x 128-column tiles would need K slices to occupy the CUs (stage 2: 64 x 3 tiles -> 2 slices + an
+                    # epilogue launch that adds 25 MB of partial sums), 128 x 96 tiles give 64 x 4 workgroups with the whole K each: one launch
+                    if (self.pw2_narrow and self.use_split and a2 == 2 and ((cur.rows + 127) // 128) * ((Cc + 127) // 128) < 256
+                            and ((cur.rows + 127) // 128) * ((Cc + 95) // 96) >= 200 and Cc % 96 == 0 and HW >= 128):
+                        kn.update(tile_hint=N.CONV_TILE_HI | 10, split_k=1)
+                    self.conv(hh, blk["pw2"], cur, res=cur, a_scale=scale, a_scale_ld=hh.ld, a_shift=blk["beta"], **kn)
                 else:     # odd feature maps (ChunkySeal: 31 x 31): GRN applied in place + plain GEMM measured faster (109 vs 105 frames/s)
                           # than the GEMM with the fused transform, whose frame-boundary select costs registers; the calibration pass takes
                           # this form everywhere because it measures the operand h * scale + beta itself
