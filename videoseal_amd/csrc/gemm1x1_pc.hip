@@ -177,25 +177,27 @@ __device__ __forceinline__ void gemm1x1_pc_tile(const vs_conv_desc_t& d, const i
     load_pair(rs0, 3);
     __syncthreads();
     __syncthreads();        // the consumers read the fragments of step 0 between these two barriers: stage 0 is rewritten in step 0
-    // steps 2j, 2j+1 (consumers on pair j): store pair j+1 (set (j+1)%3), then reload that set with pair j+4
-    for (int j = 0; j < npairs; j += 3) {
-      store_half(rs1, 0);
+    // steps 2j, 2j+1 (consumers on pair j): store pair j+1 (set (j+1)%3), then reload that set with pair j+4.
+    // The main loop takes whole triples and has NO exit inside its body: with `if (j + 1 >= npairs) break;` between the sub-iterations (the
+    // form until round 5) hipcc's wait-count bookkeeping gave up at the loop header and the first sub-iteration of every trip waited
+    // vmcnt(0) -- for the two pairs just requested as well, i.e. the three-deep prefetch drained every third pair (ISA: vmcnt(7..0) / no
+    // waits / vmcnt(29..23) in the three sub-iterations; now vmcnt(33..26) in each).  The 0 - 2 pairs that are left run behind the loop.
+    auto sub = [&](PSet& R, const int nxt) __attribute__((always_inline)) {
+      store_half(R, 0);
       __syncthreads();
-      store_half(rs1, 1);
-      load_pair(rs1, j + 4);
+      store_half(R, 1);
+      load_pair(R, nxt);
       __syncthreads();
-      if (j + 1 >= npairs) break;
-      store_half(rs2, 0);
-      __syncthreads();
-      store_half(rs2, 1);
-      load_pair(rs2, j + 5);
-      __syncthreads();
-      if (j + 2 >= npairs) break;
-      store_half(rs0, 0);
-      __syncthreads();
-      store_half(rs0, 1);
-      load_pair(rs0, j + 6);
-      __syncthreads();
+    };
+    int j = 0;
+    for (; j + 3 <= npairs; j += 3) {
+      sub(rs1, j + 4);
+      sub(rs2, j + 5);
+      sub(rs0, j + 6);
+    }
+    if (j < npairs) {
+      sub(rs1, j + 4);
+      if (j + 1 < npairs) sub(rs2, j + 5);
     }
     return;
   }

@@ -282,7 +282,10 @@ class HipEngine:
         self.msg_table_conv = os.environ.get("VIDEOSEAL_MSG_TABLE", "1") != "0"         # first bottleneck block: message channels as a table
         self.planes_chain = os.environ.get("VIDEOSEAL_PLANES", "1") != "0"              # bottleneck chain on pre-split operand planes
         self.msg0_planes = os.environ.get("VIDEOSEAL_MSG0_PLANES", "1") != "0"          # ... including its first block (round 5)
-        self.pw2_narrow = os.environ.get("VIDEOSEAL_PW2_NARROW", "1") != "0"            # stage-2 pwconv2 on 128 x 96 tiles without K slices (round 5)
+        # stage-2 pwconv2 on 128 x 96 tiles (tile code 26) without K slices: measured NEUTRAL against 2 K slices + the epilogue launch (detect of
+        # 32 frames 3.502 / 3.509 vs 3.491 / 3.497 ms, same box, profiles/r05a_*): the K loop of the wave-specialised GEMM is bound by its
+        # producer waves (GRN apply + operand split of 128 x 16 activations per step), not by the 9 or 18 MFMAs per consumer wave -- opt-in
+        self.pw2_narrow = os.environ.get("VIDEOSEAL_PW2_NARROW", "0") == "1"
         self.planes_gemm = os.environ.get("VIDEOSEAL_PLANES", "1") != "0"               # ConvNeXt 1x1 GEMMs on operand planes
         self.fused_blocks = os.environ.get("VIDEOSEAL_CNX_FUSED", "1") != "0"           # stage 0 / 1 blocks with h kept on chip (convnext_fused.hip)
         self.thin_fused = os.environ.get("VIDEOSEAL_THIN_FUSED", "1") != "0"              # 16-channel ResnetBlocks in one launch (resblock_thin.hip)
@@ -1057,7 +1060,8 @@ class HipEngine:
             if j == 0 and lc is None and self._msg0_ok(h3, E["bott"][0], c.zc[-1]):
                 nxt = Act(None, B, h3.H, h3.W, E["bott"][0]["cout"], E["bott"][0]["cout"])
                 chain = c.num_blocks > 1 and not bn_train and self._planes_ok(nxt, E["bott"][1:])
-                xcur, xcur_pl = self.resblock_msg0(h3, E["bott"][0], "bott0", lat, Bm, c.zc[-1], planes_out=chain)
+                r0 = self.resblock_msg0(h3, E["bott"][0], "bott0", lat, Bm, c.zc[-1], planes_out=chain)
+                xcur, xcur_pl = r0 if chain else (r0, None)
                 continue
             if j >= 1 and not bn_train and self._planes_ok(xcur, E["bott"][j:]):      # the rest of the chain on operand planes
                 lc = lowres_cat(0, xcur)
