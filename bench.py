@@ -320,30 +320,30 @@ def _run(args, world, rank, dev, dist_on, n_ranks_seen):
 
     aug_timers = []
 
+    chain_seq = [None]
+
     def step_chain():
-        """BASELINE configs[2]: clip -> embed (key frames every step_size) -> the fixed-strength validation chain -> detect"""
+        """BASELINE configs[2]: clip -> embed (key frames every step_size) -> the fixed-strength validation chain -> detect.  The chain goes through
+        augmentation.Sequential as the reference's combined validation augmentations do (augmentation/__init__.py:107-123, sequential.py:8-30);
+        round 5: Sequential runs Crop + Resize + Brightness as one kernel and Contrast + Saturation + Hue as one pass (bit-identical values)."""
         from videoseal_amd import augmentation as G
+        if chain_seq[0] is None:
+            chain_seq[0] = G.Sequential(G.JPEG(), G.Crop(), G.Resize(), G.Brightness(), G.Contrast(), G.Saturation(), G.Hue())
         w = model.embed(frames, msgs, is_video=True, lowres_attenuation=args.lowres_attenuation)["imgs_w"]
-        x = w
         timed = eng_ref[0] is not None and eng_ref[0].shell_timers is not None
-        q, cs, rs, br, co, sa, hu = CHAIN_ARGS
-        th = tw = int(cs * S)
-        ops = [("jpeg_roundtrip", lambda t: G.jpeg_compress(t, q), lambda a, b: a.numel() * 4 + b.numel() * 4),
-               ("crop", lambda t: G.crop_flip(t, (S - th) // 2, (S - tw) // 2, th, tw), lambda a, b: 2 * b.numel() * 4),
-               ("resize_nchw", lambda t: G.resize(t, (int(rs * th), int(rs * tw)), True), lambda a, b: a.numel() * 4 + b.numel() * 4),
-               ("brightness", lambda t: G.color_op(t, "brightness", br), lambda a, b: 2 * b.numel() * 4),
-               ("contrast", lambda t: G.color_op(t, "contrast", co), lambda a, b: 3 * b.numel() * 4),
-               ("saturation", lambda t: G.color_op(t, "saturation", sa), lambda a, b: 2 * b.numel() * 4),
-               ("hue", lambda t: G.color_op(t, "hue", hu), lambda a, b: 2 * b.numel() * 4)]
-        for name, fn, nbytes in ops:
+        G.TIMERS = aug_timers if timed else None
+        try:
             if timed:
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
-            y = fn(x)
-            if timed:
+                x = G.jpeg_compress(w, CHAIN_ARGS[0])
                 e1.record()
-                aug_timers.append(("aug:" + name, e0, e1, nbytes(x, y)))
-            x = y
+                aug_timers.append(("aug:jpeg_roundtrip", e0, e1, 2 * w.numel() * 4))
+                x, _ = G.Sequential(*chain_seq[0].transforms[1:])(x, None, CHAIN_ARGS[1:])
+            else:
+                x, _ = chain_seq[0](w, None, CHAIN_ARGS)
+        finally:
+            G.TIMERS = None
         return model.detect(x, is_video=True)["preds"]
 
     eng_ref = [None]
@@ -525,7 +525,7 @@ def _run(args, world, rank, dev, dist_on, n_ranks_seen):
                                    f"{'low-res' if args.lowres_attenuation else 'full-res'} JND), " + ("detect only" if args.detect_only else "embed + detect")
                                    + (", all-gather of bit logits" if dist_on else "")
                                    + (f"; streaming: {args.frames}-frame clip in 16-frame chunks" + (", one embed + detect call per chunk" if (args.group == 1 or not args.overlap) else f", key frames of {args.group or 8} chunks per U-Net pass, extractor on 32 frames per pass, watermark expanded and handed on chunk by chunk") + ", low-res JND" + (", uint8 RGB24 in/out" if args.u8 else "") + (", detect overlapped with the next embed on a second stream" if args.overlap else "") if stream else "")
-                                   + (", chain JPEG(40) -> Crop(0.71) -> Resize(0.71) -> Brightness(0.5) -> Contrast(1.5) -> Saturation(1.5) -> Hue(0.1) between embed and detect" if chain else "")
+                                   + (", chain JPEG(40) -> Crop(0.71) -> Resize(0.71) -> Brightness(0.5) -> Contrast(1.5) -> Saturation(1.5) -> Hue(0.1) between embed and detect (augmentation.Sequential: Crop + Resize + Brightness one kernel, Contrast + Saturation + Hue one pass)" if chain else "")
                                    + (", hipGraph replay" if args.graphs else ""),
                        "card": args.card, "weights": "random-init (seeded), no checkpoint offline", "batch_per_gpu": B,
                        "frame": [S, S], "mode": args.mode},

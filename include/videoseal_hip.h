@@ -535,6 +535,17 @@ int vs_model_detect(vs_model_t* m, const void* imgs, int frames, int H, int W, i
 #define VS_COLOR_GRAYSCALE 4    /* valuemetric.py:196-208 0.299 R + 0.587 G + 0.114 B broadcast to 3 channels            */
 int64_t vs_aug_color_scratch_floats(int F, int H, int W);
 int vs_aug_color(const float* src, float* dst, int F, int H, int W, int op, float factor, float* scratch, void* stream);
+/* A run of n (1..6) colour ops in ONE pass (round 5; the validation chains of augmentation/__init__.py:107-123 apply Brightness -> Contrast ->
+ * Saturation -> Hue back to back): `ops` / `factors` are HOST arrays, every op is the expression of vs_aug_color applied in order on the
+ * pixel's registers -> bit-identical to the separate calls.  VS_COLOR_CONTRAST needs the mean of ITS input: only as ops[0] (scratch as for
+ * vs_aug_color); cut longer sequences there. */
+int vs_aug_color_chain(const float* src, float* dst, int F, int H, int W, int n, const int* ops, const float* factors, float* scratch, void* stream);
+/* Crop (window i0, j0, ch, cw inside the H x W frames) -> bilinear Resize to oh x ow -> n (0..6) colour ops without VS_COLOR_CONTRAST, one kernel,
+ * 3-channel frames: the cropped clip is never written, the source window of a 32 x 8 output tile is staged in LDS once; same taps in the same
+ * order as vs_resize_nchw on the cropped tensor -> bit-identical to vs_aug_crop_flip + vs_resize_nchw + vs_aug_color.  VS_ERR_UNSUPPORTED when
+ * the window does not fit 60 KB of LDS (down-scaling beyond ~5 x): use the separate calls. */
+int vs_aug_crop_resize_color(const float* src, float* dst, int F, int H, int W, int i0, int j0, int ch, int cw, int oh, int ow, int antialias,
+                             int n, const int* ops, const float* factors, void* stream);
 /* watermark masking of the training forward (augmenter.py:171-176): dst = imgs_w * m + imgs * (1 - m), m [F][1][H][W]          */
 int vs_aug_mask_blend(const float* imgs_w, const float* imgs, const float* mask, float* dst, int F, int C, int H, int W, void* stream);
 /* GaussianNoise (valuemetric.py:176-194): dst = x + noise * std over n floats; `noise` is the caller's torch.randn_like draw    */

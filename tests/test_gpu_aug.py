@@ -244,3 +244,77 @@ def test_temporal_reorder_and_window_averaging_match_the_reference_semantics():
         assert (y.cpu() - ref).abs().max() <= 1.2e-7, (ws, alpha)
     with pytest.raises(NotImplementedError, match="pyav"):
         G.VP9()(xg, None)
+
+
+# ---- round 5: fused passes of the validation chains (vs_aug_color_chain, vs_aug_crop_resize_color, Sequential's fusion) ----------------
+@pytest.mark.parametrize("ops", [
+    [("brightness", 0.5), ("contrast", 1.5), ("saturation", 1.5), ("hue", 0.1)],          # configs[2]: two runs (cut in front of contrast)
+    [("contrast", 0.7), ("contrast", 1.3), ("hue", -0.2)],                                # every contrast starts its own run
+    [("saturation", 0.3), ("grayscale", 0.0), ("brightness", 1.7), ("hue", 0.45), ("saturation", 1.9), ("brightness", 0.9), ("hue", 0.1)],   # > 6 ops
+    [("hue", 0.25)],
+])
+def test_fused_colour_chain_is_bit_identical_to_the_separate_ops(ops):
+    x = synthetic_frames(3, 93, 118, seed=33).cuda()
+    x[0, :, :4, :4] = 0.0                                      # gray pixels: the hue op's max == min branch
+    ref = x
+    for name, f in ops:
+        ref = G.color_op(ref, name, f)
+    got = G.color_chain(x, ops)
+    torch.cuda.synchronize()
+    assert torch.equal(got, ref)
+    for (name, f), fn in zip(ops[:1], [getattr(A, ops[0][0], None)]):          # and the first op against the oracle, as test_colour_ops does
+        if fn is not None and name != "grayscale":
+            assert (G.color_chain(x, ops[:1]).cpu() - fn(x.cpu(), f)).abs().max().item() < 2e-6
+
+
+@pytest.mark.parametrize("H,W,crop,size,aa", [
+    (768, 768, (111, 112, 545, 545), (386, 386), True),        # configs[2]: Crop(0.71) -> Resize(0.71)
+    (93, 118, None, (47, 200), True),                          # no crop, down in y / up in x
+    (93, 118, (0, 0, 93, 118), (150, 61), True),
+    (64, 80, (5, 7, 33, 41), (33, 41), True),                  # identity-size resize of a crop
+    (70, 66, (3, 2, 60, 60), (13, 17), True),                  # 4.6 x down: long taps
+    (70, 66, (3, 2, 60, 60), (91, 77), False),                 # plain bilinear, up
+    (40, 40, (30, 30, 10, 10), (64, 64), True),                # window at the corner
+])
+def test_fused_crop_resize_colour_is_bit_identical_to_the_separate_launches(H, W, crop, size, aa):
+    x = synthetic_frames(3, H, W, seed=H + W).cuda()
+    ops = [("brightness", 0.5), ("saturation", 1.4), ("contrast", 1.5), ("hue", 0.1)]
+    for use_ops in ([], ops):
+        y = G.crop_flip(x, *crop) if crop is not None else x
+        ref = G.resize(y, size, aa)
+        for name, f in use_ops:
+            ref = G.color_op(ref, name, f)
+        got = G.crop_resize_color(x, crop, size, use_ops, antialias=aa)
+        torch.cuda.synchronize()
+        assert got.shape == ref.shape and torch.equal(got, ref), float((got - ref).abs().max())
+    # a window the LDS cannot hold (down-scaling by 12) takes the separate launches: same answer
+    big = synthetic_frames(1, 256, 1300, seed=5).cuda()
+    assert torch.equal(G.crop_resize_color(big, None, (20, 100), []), G.resize(big, (20, 100), True))
+    with pytest.raises(N.NativeError):
+        N.check(N.lib().vs_aug_crop_resize_color(N.ptr(x), N.ptr(x), 3, H, W, 0, 0, H + 1, W, 8, 8, 1, 0, None, None, N.stream()), "crop outside the frame")
+
+
+def test_sequential_fuses_the_validation_chain_without_changing_values_or_random_draws():
+    """augmentation/sequential.py:8-30 on the chain of BASELINE configs[2] (JPEG, Crop, Resize, Brightness, Contrast, Saturation, Hue): with the
+    fused passes on and off the outputs are bit-identical -- image and mask, fixed strengths and random draws (same torch seed)"""
+    x = synthetic_frames(4, 160, 144, seed=77).cuda()
+    mask = (torch.rand(4, 1, 160, 144, generator=torch.Generator().manual_seed(3)) > 0.5).float().cuda()
+    seq = G.Sequential(G.JPEG(), G.Crop(0.5, 0.9), G.Resize(0.6, 1.3), G.Brightness(0.5, 1.5), G.Contrast(0.5, 1.5), G.Saturation(0.5, 1.5), G.Hue(-0.1, 0.1))
+    outs = {}
+    for fuse in (True, False):
+        G.FUSE = fuse
+        try:
+            res = []
+            for args in ((40, 0.71, 0.71, 0.5, 1.5, 1.5, 0.1), (55,)):           # fixed strengths; only the JPEG quality given -> the rest drawn
+                torch.manual_seed(11)
+                res.append(seq(x, mask, args))
+                torch.manual_seed(12)
+                res.append(seq(x, None, args))
+            outs[fuse] = res
+        finally:
+            G.FUSE = True
+    torch.cuda.synchronize()
+    for (ia, ma), (ib, mb) in zip(outs[True], outs[False]):
+        assert ia.shape == ib.shape and torch.equal(ia, ib)
+        assert (ma is None and mb is None) or torch.equal(ma, mb)
+    assert outs[True][0][0].shape[-2:] == (int(0.71 * int(0.71 * 160)), int(0.71 * int(0.71 * 144)))

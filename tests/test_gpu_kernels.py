@@ -194,6 +194,8 @@ class Eng(HipEngine):
         self.msg_table_conv = True
         self._ws_used = {}
         self.layer_arith = {}
+        self.planes_chain = self.planes_splitk = self.msg0_planes = True
+        self.planes_chain_ran = False
 
 
 @pytest.fixture(scope="module", params=["split", "h2", "f32"])

@@ -76,6 +76,85 @@ def resize(x: torch.Tensor, size: Tuple[int, int], antialias: bool = True) -> to
     return out
 
 
+FUSE = os.environ.get("VIDEOSEAL_AUG_FUSE", "1") != "0"     # Sequential: consecutive Crop / Resize / colour ops in fused passes (round 5)
+TIMERS = None         # bench.py: a list -> every fused / JPEG launch group appends (name, start event, end event, algorithmic bytes)
+
+
+def _timed(name: str, nbytes: int, fn):
+    if TIMERS is None or torch.cuda.is_current_stream_capturing():
+        return fn()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    out = fn()
+    e1.record()
+    TIMERS.append((name, e0, e1, nbytes))
+    return out
+
+
+def color_chain(x: torch.Tensor, ops: List[Tuple[str, float]]) -> torch.Tensor:
+    """the colour ops `ops` = [(name, factor), ...] applied in order.  Runs of ops are ONE pass over the clip each (vs_aug_color_chain); a run ends
+    in front of every 'contrast' (it needs the mean of its own input).  Same expressions in the same order as color_op -> bit-identical."""
+    if not ops:
+        return x
+    if AG.needs_grad(x) or not FUSE or len(ops) == 1:
+        for name, f in ops:
+            x = color_op(x, name, f)
+        return x
+    x = _dev(x)
+    F_, Cc, H, W = x.shape
+    if Cc != 3:
+        raise ValueError("colour augmentations expect 3-channel frames")
+    L = N.lib()
+    runs: List[List[Tuple[str, float]]] = []
+    for name, f in ops:
+        if not runs or name == "contrast" or len(runs[-1]) == 6:
+            runs.append([])
+        runs[-1].append((name, float(f)))
+    for run in runs:
+        out = torch.empty_like(x)
+        scratch = torch.empty(int(L.vs_aug_color_scratch_floats(F_, H, W)), device=x.device, dtype=torch.float32) if run[0][0] == "contrast" else None
+        oa = (C.c_int * len(run))(*[COLOR_OPS[n] for n, _ in run])
+        fa = (C.c_float * len(run))(*[f for _, f in run])
+        src = x
+        x = _timed("aug:" + "+".join(n for n, _ in run), (3 if scratch is not None else 2) * x.numel() * 4,
+                   lambda: (N.check(L.vs_aug_color_chain(N.ptr(src), N.ptr(out), F_, H, W, len(run), oa, fa, N.ptr(scratch), N.stream()),
+                                    "vs_aug_color_chain"), out)[1])
+    return x
+
+
+def crop_resize_color(x: torch.Tensor, crop: Optional[Tuple[int, int, int, int]], size: Tuple[int, int], ops: List[Tuple[str, float]],
+                      antialias: bool = True) -> torch.Tensor:
+    """crop window (i, j, h, w) (None = the whole frame) -> resize to `size` -> colour ops, fused: one kernel for crop + resize + the colour ops
+    in front of the first 'contrast' (vs_aug_crop_resize_color: the cropped clip is never materialised), color_chain for the rest.  Falls back
+    to the separate launches where the fused kernel does not apply (gradients wanted, window outside the frame, extreme down-scaling)."""
+    def separate():
+        y = crop_flip(x, *crop) if crop is not None else x
+        return color_chain(resize(y, size, antialias), ops)
+    if AG.needs_grad(x) or not FUSE or x.shape[1] != 3:
+        return separate()
+    x = _dev(x)
+    F_, _, H, W = x.shape
+    i, j, h, w = crop if crop is not None else (0, 0, H, W)
+    if i < 0 or j < 0 or i + h > H or j + w > W:
+        return separate()
+    k = 0
+    while k < len(ops) and ops[k][0] != "contrast" and k < 6:
+        k += 1
+    head, tail = ops[:k], ops[k:]
+    out = torch.empty(F_, 3, size[0], size[1], device=x.device, dtype=torch.float32)
+    oa = (C.c_int * max(1, k))(*[COLOR_OPS[n] for n, _ in head])
+    fa = (C.c_float * max(1, k))(*[float(f) for _, f in head])
+    name = "aug:" + "+".join((["crop"] if crop is not None else []) + ["resize"] + [n for n, _ in head])
+    rc = _timed(name, F_ * 3 * h * w * 4 + out.numel() * 4,
+                lambda: N.lib().vs_aug_crop_resize_color(N.ptr(x), N.ptr(out), F_, H, W, i, j, h, w, size[0], size[1], int(antialias), k, oa, fa, N.stream()))
+    if rc == N.ERR_UNSUPPORTED:
+        if TIMERS is not None and TIMERS and TIMERS[-1][0] == name:
+            TIMERS.pop()
+        return separate()
+    N.check(rc, "vs_aug_crop_resize_color")
+    return color_chain(out, tail)
+
+
 def _ste(x: torch.Tensor, fn, clamp01: bool = False) -> torch.Tensor:
     """`x + (fn(x) - x).detach()` of valuemetric.py:35, 90 / video.py:113: forward value fn(x), identity gradient (masked to 0 <= x <= 1 when
     the op clamps first)"""
@@ -172,6 +251,11 @@ class Resize(_Sized):
         out = self._out_size(image, size)
         return resize(image, out, True), (resize(mask, out, True) if mask is not None else mask)
 
+    def plan(self, shape, size=None):
+        """the parameters forward() would draw for an input of `shape` (same random draws, same order): ('resize', (oh, ow))"""
+        h, w = shape[-2:]
+        return ("resize", self.get_random_size(h, w) if size is None else (int(size * h), int(size * w)))
+
 
 class Crop(_Sized):
     def forward(self, image, mask=None, size=None):
@@ -185,6 +269,16 @@ class Crop(_Sized):
             i = torch.randint(0, h - th + 1, size=(1,)).item()
             j = torch.randint(0, w - tw + 1, size=(1,)).item()
         return crop_flip(image, i, j, th, tw), (crop_flip(mask, i, j, th, tw) if mask is not None else mask)
+
+    def plan(self, shape, size=None):
+        """('crop', (i, j, th, tw)) with forward()'s draws"""
+        h, w = shape[-2:]
+        th, tw = self.get_random_size(h, w) if size is None else (int(size * h), int(size * w))
+        if h < th or w < tw:
+            raise ValueError(f"Required crop size {(th, tw)} is larger than input image size {(h, w)}")
+        if w == tw and h == th:
+            return ("crop", (0, 0, th, tw))
+        return ("crop", (torch.randint(0, h - th + 1, size=(1,)).item(), torch.randint(0, w - tw + 1, size=(1,)).item(), th, tw))
 
 
 class _Factor(_Aug):
@@ -202,6 +296,9 @@ class _Factor(_Aug):
     def forward(self, image, mask=None, factor=None):
         factor = self.get_random_factor() if factor is None else factor
         return color_op(image, self.op, factor), mask
+
+    def plan(self, shape, factor=None):
+        return ("color", (self.op, self.get_random_factor() if factor is None else factor))
 
 
 class Brightness(_Factor):
@@ -722,8 +819,46 @@ class Sequential(nn.Module):
 
     def forward(self, image, mask, args):
         args = tuple(args) + (None,) * (len(self.transforms) - len(args))
-        for transform, aug_arg in zip(self.transforms, args):
+        items = list(zip(self.transforms, args))
+        k = 0
+        while k < len(items):
+            transform, aug_arg = items[k]
+            # round 5: a run [Crop] [Resize] [Brightness | Contrast | Saturation | Hue ...] goes through the fused passes (crop_resize_color /
+            # color_chain: same values, a third of the HBM traffic of the separate launches).  Every member's parameters are drawn by its own
+            # plan() in order -- the random stream is what the one-by-one calls would consume.
+            if FUSE and type(transform) in (Crop, Resize, Brightness, Contrast, Saturation, Hue) and not AG.needs_grad(image) and image.is_cuda \
+                    and image.dim() == 4 and image.shape[1] == 3:
+                shape = tuple(image.shape)
+                crop = size = None
+                ops = []
+                while k < len(items) and type(items[k][0]) in (Crop, Resize, Brightness, Contrast, Saturation, Hue):
+                    t, a = items[k]
+                    if isinstance(t, Crop):
+                        if crop is not None or size is not None or ops:
+                            break
+                        kind, crop = t.plan(shape, a)
+                        shape = shape[:-2] + (crop[2], crop[3])
+                    elif isinstance(t, Resize):
+                        if size is not None or ops:
+                            break
+                        kind, size = t.plan(shape, a)
+                        shape = shape[:-2] + tuple(size)
+                    else:
+                        ops.append(t.plan(shape, a)[1])
+                    k += 1
+                if size is not None:
+                    image = crop_resize_color(image, crop, size, ops)
+                    if mask is not None:
+                        mask = resize(crop_flip(mask, *crop) if crop is not None else mask, size, True)
+                else:
+                    if crop is not None:
+                        image = crop_flip(image, *crop)
+                        if mask is not None:
+                            mask = crop_flip(mask, *crop)
+                    image = color_chain(image, ops)
+                continue
             image, mask = transform(image, mask, aug_arg)
+            k += 1
         return image, mask
 
     def __repr__(self):

@@ -49,26 +49,51 @@ __device__ __forceinline__ void hue_shift(float& r, float& g, float& b, float fa
   }
 }
 
+// one colour op on one pixel (torchvision _functional_tensor semantics); `mean` = per-frame mean of the gray image for OP_CONTRAST
+__device__ __forceinline__ void apply_color(const int op, const float factor, const float mean, float& r, float& g, float& b) {
+  switch (op) {
+    case OP_BRIGHTNESS: r = clamp01(factor * r); g = clamp01(factor * g); b = clamp01(factor * b); break;   // _blend(x, 0, f)
+    case OP_CONTRAST: {
+      const float m = (1.0f - factor) * mean;
+      r = clamp01(factor * r + m); g = clamp01(factor * g + m); b = clamp01(factor * b + m);
+    } break;
+    case OP_SATURATION: {
+      const float m = (1.0f - factor) * tv_gray(r, g, b);
+      r = clamp01(factor * r + m); g = clamp01(factor * g + m); b = clamp01(factor * b + m);
+    } break;
+    case OP_HUE: hue_shift(r, g, b, factor); break;
+    default: { const float y = 0.299f * r + 0.587f * g + 0.114f * b; r = g = b = y; } break;   // valuemetric.py:205-206
+  }
+}
+
 __global__ __launch_bounds__(256) void color_kernel(const float* __restrict__ src, float* __restrict__ dst, int64_t plane, int op,
                                                     float factor, const float* __restrict__ means) {
   const int f = blockIdx.y;
   const float* s = src + (int64_t)f * 3 * plane;
   float* d = dst + (int64_t)f * 3 * plane;
+  const float mean = op == OP_CONTRAST ? means[f] : 0.f;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < plane; i += (int64_t)gridDim.x * 256) {
     float r = s[i], g = s[plane + i], b = s[2 * plane + i];
-    switch (op) {
-      case OP_BRIGHTNESS: r = clamp01(factor * r); g = clamp01(factor * g); b = clamp01(factor * b); break;   // _blend(x, 0, f)
-      case OP_CONTRAST: {
-        const float m = (1.0f - factor) * means[f];
-        r = clamp01(factor * r + m); g = clamp01(factor * g + m); b = clamp01(factor * b + m);
-      } break;
-      case OP_SATURATION: {
-        const float m = (1.0f - factor) * tv_gray(r, g, b);
-        r = clamp01(factor * r + m); g = clamp01(factor * g + m); b = clamp01(factor * b + m);
-      } break;
-      case OP_HUE: hue_shift(r, g, b, factor); break;
-      default: { const float y = 0.299f * r + 0.587f * g + 0.114f * b; r = g = b = y; } break;   // valuemetric.py:205-206
-    }
+    apply_color(op, factor, mean, r, g, b);
+    d[i] = r; d[plane + i] = g; d[2 * plane + i] = b;
+  }
+}
+
+// A run of colour ops in ONE pass over the frames (round 5: the validation chains of augmentation/__init__.py:107-123 apply Brightness ->
+// Contrast -> Saturation -> Hue back to back, each a full read + write of the clip).  Every op is the expression of color_kernel, applied
+// in order on the pixel's registers -> bit-identical to the separate launches.  Contrast needs the mean of ITS input: it may only be the
+// first op of a run (`means` = gray mean of src); the host cuts longer sequences there.
+struct ColorChain { int n; int op[6]; float factor[6]; };
+
+__global__ __launch_bounds__(256) void color_chain_kernel(const float* __restrict__ src, float* __restrict__ dst, int64_t plane, ColorChain cc,
+                                                          const float* __restrict__ means) {
+  const int f = blockIdx.y;
+  const float* s = src + (int64_t)f * 3 * plane;
+  float* d = dst + (int64_t)f * 3 * plane;
+  const float mean = (cc.n > 0 && cc.op[0] == OP_CONTRAST) ? means[f] : 0.f;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < plane; i += (int64_t)gridDim.x * 256) {
+    float r = s[i], g = s[plane + i], b = s[2 * plane + i];
+    for (int k = 0; k < cc.n; ++k) apply_color(cc.op[k], cc.factor[k], mean, r, g, b);
     d[i] = r; d[plane + i] = g; d[2 * plane + i] = b;
   }
 }
@@ -175,6 +200,52 @@ __global__ __launch_bounds__(256) void resize_nchw_kernel(const float* __restric
     acc += tap_w(ty, jy) * r;
   }
   dst[((int64_t)blockIdx.z * oh + oy) * ow + ox] = acc;
+}
+
+// Crop -> (anti-aliased) bilinear Resize -> a run of pointwise colour ops in ONE kernel (round 5; Crop / Resize / Brightness of the validation
+// chains).  The crop is an index offset of the resize's source window, so the cropped clip is never written; the 32 x 8 output tile's source
+// window of all three planes is staged once in LDS by coalesced loads (resize_nchw_kernel reads every tap from global memory: L1-bound at 0.14
+// of the HBM rate), and each output pixel evaluates the SAME taps in the SAME order as resize_nchw_kernel on the cropped tensor -- horizontal
+// sums first, then the vertical one -- followed by apply_color on its three channel values: bit-identical to the separate launches.
+__global__ __launch_bounds__(256) void crop_resize_color_kernel(const float* __restrict__ src, float* __restrict__ dst, int H, int W, int i0, int j0,
+                                                                int ch, int cw, int oh, int ow, int antialias, int win_h, int win_w, ColorChain cc) {
+  extern __shared__ float crc_win[];                                  // [3][win_h][win_w]
+  const int f = blockIdx.z;
+  const int ox0 = blockIdx.x * 32, oy0 = blockIdx.y * 8;
+  // source window of the tile (in crop coordinates): first tap of the first row / column .. last tap of the last row / column of the tile
+  int ylo, yn, xlo, xn, t0, t1;
+  tap_range(oy0, ch, oh, antialias, ylo, yn);
+  tap_range(min(oy0 + 7, oh - 1), ch, oh, antialias, t0, t1);
+  const int yhi = t0 + t1;                                            // one past the last source row
+  tap_range(ox0, cw, ow, antialias, xlo, xn);
+  tap_range(min(ox0 + 31, ow - 1), cw, ow, antialias, t0, t1);
+  const int xhi = t0 + t1;
+  const int wh = yhi - ylo, ww = xhi - xlo;                           // <= win_h, win_w (checked by the launcher's bound)
+  const float* sf = src + (int64_t)f * 3 * H * W;
+  for (int idx = threadIdx.x; idx < 3 * wh * ww; idx += 256) {
+    const int c = idx / (wh * ww), rem = idx - c * (wh * ww);
+    const int y = rem / ww, x = rem - y * ww;
+    crc_win[(c * win_h + y) * win_w + x] = sf[((int64_t)c * H + (i0 + ylo + y)) * W + (j0 + xlo + x)];
+  }
+  __syncthreads();
+  const int ox = ox0 + (threadIdx.x & 31), oy = oy0 + (threadIdx.x >> 5);
+  if (ox >= ow || oy >= oh) return;
+  const Taps ty = make_taps(oy, ch, oh, antialias), tx = make_taps(ox, cw, ow, antialias);
+  float v[3];
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    float acc = 0.f;
+    for (int jy = 0; jy < ty.n; ++jy) {
+      const float* row = crc_win + (c * win_h + (ty.lo + jy - ylo)) * win_w + (tx.lo - xlo);
+      float r = 0.f;
+      for (int jx = 0; jx < tx.n; ++jx) r += tap_w(tx, jx) * row[jx];
+      acc += tap_w(ty, jy) * r;
+    }
+    v[c] = acc;
+  }
+  for (int k = 0; k < cc.n; ++k) apply_color(cc.op[k], cc.factor[k], 0.f, v[0], v[1], v[2]);
+  float* df = dst + (int64_t)f * 3 * oh * ow + (int64_t)oy * ow + ox;
+  df[0] = v[0]; df[(int64_t)oh * ow] = v[1]; df[2 * (int64_t)oh * ow] = v[2];
 }
 
 // ------------------------------------------------------------------------------------------------ filters
@@ -503,6 +574,59 @@ extern "C" int vs_aug_color(const float* src, float* dst, int F, int H, int W, i
   hipLaunchKernelGGL(color_kernel, dim3(gridx(plane), F), dim3(256), 0, st, src, dst, plane, op, factor, means);
   return vs_launch_status();
 }
+// n colour ops (ops[k] in 0..4, OP_CONTRAST only at k = 0) in one pass; scratch as for vs_aug_color when ops[0] is OP_CONTRAST
+extern "C" int vs_aug_color_chain(const float* src, float* dst, int F, int H, int W, int n, const int* ops, const float* factors, float* scratch,
+                                  void* stream) {
+  VS_REQUIRE(src && dst && F > 0 && H > 0 && W > 0 && n >= 1 && n <= 6 && ops && factors);
+  ColorChain cc{};
+  cc.n = n;
+  for (int k = 0; k < n; ++k) {
+    VS_REQUIRE(ops[k] >= 0 && ops[k] <= 4 && (k == 0 || ops[k] != OP_CONTRAST));
+    cc.op[k] = ops[k];
+    cc.factor[k] = factors[k];
+  }
+  hipStream_t st = (hipStream_t)stream;
+  const int64_t plane = (int64_t)H * W;
+  const float* means = nullptr;
+  if (ops[0] == OP_CONTRAST) {       // the same two-stage gray mean as vs_aug_color (same partial sums, same order)
+    VS_REQUIRE(scratch);
+    const int nblk = (int)gridx(plane, 256, 256);
+    hipLaunchKernelGGL(gray_partial_kernel, dim3(nblk, F), dim3(256), 0, st, src, plane, scratch);
+    hipLaunchKernelGGL(gray_finish_kernel, dim3(F), dim3(1), 0, st, scratch, nblk, plane, scratch + (int64_t)F * nblk);
+    means = scratch + (int64_t)F * nblk;
+  }
+  hipLaunchKernelGGL(color_chain_kernel, dim3(gridx(plane), F), dim3(256), 0, st, src, dst, plane, cc, means);
+  return vs_launch_status();
+}
+
+// crop window (i0, j0, ch, cw) INSIDE the H x W frames -> resize to oh x ow -> n (0..6) colour ops without OP_CONTRAST; 3-channel frames.
+// VS_ERR_UNSUPPORTED when the source window of a 32 x 8 output tile does not fit the LDS budget (very strong down-scaling): callers fall
+// back to the separate launches.
+extern "C" int vs_aug_crop_resize_color(const float* src, float* dst, int F, int H, int W, int i0, int j0, int ch, int cw, int oh, int ow,
+                                        int antialias, int n, const int* ops, const float* factors, void* stream) {
+  VS_REQUIRE(src && dst && F > 0 && H > 0 && W > 0 && ch > 0 && cw > 0 && oh > 0 && ow > 0 && n >= 0 && n <= 6 && (n == 0 || (ops && factors)));
+  VS_REQUIRE(i0 >= 0 && j0 >= 0 && i0 + ch <= H && j0 + cw <= W);
+  ColorChain cc{};
+  cc.n = n;
+  for (int k = 0; k < n; ++k) {
+    VS_REQUIRE(ops[k] >= 0 && ops[k] <= 4 && ops[k] != OP_CONTRAST);
+    cc.op[k] = ops[k];
+    cc.factor[k] = factors[k];
+  }
+  // bound of the tile's source window: (rows or columns of the tile - 1) * scale + 2 * support + 2 (integer rounding of lo / hi), + 1 of slack
+  auto span = [&](int in, int out, int t) {
+    const float scale = (float)in / (float)out;
+    const float support = antialias ? (scale >= 1.f ? scale : 1.f) : 1.f;
+    return (int)((t - 1) * scale + 2.f * support + 4.f);
+  };
+  const int win_h = span(ch, oh, 8), win_w = span(cw, ow, 32) | 1;      // odd pitch: the 32 lanes of a row walk distinct banks
+  const size_t lds = (size_t)3 * win_h * win_w * sizeof(float);
+  if (lds > 60 * 1024) return VS_ERR_UNSUPPORTED;
+  hipLaunchKernelGGL(crop_resize_color_kernel, dim3((ow + 31) / 32, (oh + 7) / 8, F), dim3(256), lds, (hipStream_t)stream, src, dst, H, W, i0, j0,
+                     ch, cw, oh, ow, antialias, win_h, win_w, cc);
+  return vs_launch_status();
+}
+
 extern "C" int64_t vs_aug_color_scratch_floats(int F, int H, int W) {
   const int64_t plane = (int64_t)H * W;
   int64_t g = (plane + 255) / 256;

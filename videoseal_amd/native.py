@@ -25,7 +25,7 @@ EXPORTS = [
     "vs_version", "vs_arch", "vs_error_string", "vs_sizeof_conv_desc", "vs_sizeof_tail_desc", "vs_debug_set",
     "vs_model_create", "vs_model_destroy", "vs_model_workspace_bytes", "vs_model_embed", "vs_model_detect", "vs_conv_gemm", "vs_to_planes", "vs_to_planes_affine", "vs_layernorm_act", "vs_rmsnorm_act", "vs_vit_attention", "vs_dwconv7_ln", "vs_dwconv7_ln_planes", "vs_grn_scale", "vs_grn_scale_from_partials", "vs_grn_apply",
     "vs_upcat2x", "vs_upconv_supported", "vs_upconv_gather_ln", "vs_cat2_scale", "vs_msg_pre", "vs_upconv_fused_supported", "vs_upconv_fused_preferred", "vs_upconv_fused", "vs_im2col3x3", "vs_msg_latent", "vs_broadcast_channels", "vs_outc_tanh", "vs_pool_linear", "vs_resize_pre", "vs_resize_pre_u8",
-    "vs_jnd_heatmap", "vs_embed_tail", "vs_aug_color_scratch_floats", "vs_aug_color", "vs_aug_crop_flip", "vs_aug_warp", "vs_resize_nchw",
+    "vs_jnd_heatmap", "vs_embed_tail", "vs_aug_color_scratch_floats", "vs_aug_color", "vs_aug_color_chain", "vs_aug_crop_resize_color", "vs_aug_crop_flip", "vs_aug_warp", "vs_resize_nchw",
     "vs_gaussian_blur", "vs_median_filter", "vs_jpeg_workspace_bytes", "vs_jpeg_roundtrip", "vs_h264_proxy_workspace_bytes", "vs_h264_proxy_roundtrip",
     "vs_bn_partial_doubles", "vs_bn_batch_stats", "vs_bn_partial_sums", "vs_bn_finish_sums", "vs_scale_shift_act", "vs_aug_mask_blend", "vs_aug_add_scaled", "vs_aug_gather_frames", "vs_aug_window_average",
     "vs_gemm_wgrad_partial_floats", "vs_gemm_wgrad", "vs_conv3x3_wgrad", "vs_conv3x3_wgrad_supported", "vs_conv3x3_wgrad_partial_floats", "vs_pad_embed1", "vs_reflect_fold1", "vs_pack_conv", "vs_gaussian_blur_bwd", "vs_aug_warp_bwd", "vs_aug_gather_frames_bwd", "vs_aug_window_average_bwd", "vs_gelu_bwd", "vs_act_bwd", "vs_rmsnorm_act_bwd", "vs_vit_attention_bwd_scratch_floats", "vs_vit_attention_bwd", "vs_dwconv7", "vs_dwconv7_wgrad_partial_floats", "vs_dwconv7_wgrad", "vs_colreduce_partial_floats",
@@ -135,6 +135,8 @@ def lib() -> C.CDLL:
         "vs_embed_tail": [C.POINTER(TailDesc), P],
         "vs_aug_color": [P, P, I, I, I, I, F, P, P],
         "vs_aug_crop_flip": [P, P, I, I, I, I, I, I, I, I, P],
+        "vs_aug_color_chain": [P, P, I, I, I, I, C.POINTER(C.c_int), C.POINTER(C.c_float), P, P],
+        "vs_aug_crop_resize_color": [P, P, I, I, I, I, I, I, I, I, I, I, I, C.POINTER(C.c_int), C.POINTER(C.c_float), P],
         "vs_resize_nchw": [P, P, I, I, I, I, I, I, P],
         "vs_aug_warp": [P, P, I, I, I, I, I, I, P, I, P],
         "vs_gaussian_blur": [P, P, P, I, I, I, I, F, P],
@@ -234,6 +236,9 @@ def lib() -> C.CDLL:
         raise NativeError("ctypes mirrors of vs_conv_desc_t / vs_tail_desc_t are out of date with the shared library")
     _lib = L
     return L
+
+
+ERR_UNSUPPORTED = -2      # VS_ERR_UNSUPPORTED: configuration outside what a kernel implements (callers with another form fall back to it)
 
 
 def check(code: int, what: str) -> None:
