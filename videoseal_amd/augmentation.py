@@ -29,6 +29,10 @@ import torch.nn.functional as F
 from . import autograd as AG
 from . import native as N
 
+FUSE = os.environ.get("VIDEOSEAL_AUG_FUSE", "1") != "0"     # Sequential: consecutive Crop / Resize / colour ops in fused passes (round 5)
+TIMERS = None         # bench.py: a list -> every fused / JPEG launch group appends (name, start event, end event, algorithmic bytes)
+
+
 COLOR_OPS = {"brightness": 0, "contrast": 1, "saturation": 2, "hue": 3, "grayscale": 4}
 
 
@@ -72,12 +76,13 @@ def resize(x: torch.Tensor, size: Tuple[int, int], antialias: bool = True) -> to
     x = _dev(x)
     planes, H, W = _planes(x)
     out = torch.empty(x.shape[0], x.shape[1], size[0], size[1], device=x.device, dtype=torch.float32)
+    if FUSE and x.dim() == 4 and x.shape[1] == 3:      # 3-channel frames: the LDS-tiled kernel (tap weights once per tile; bit-identical values)
+        rc = N.lib().vs_aug_crop_resize_color(N.ptr(x), N.ptr(out), x.shape[0], H, W, 0, 0, H, W, size[0], size[1], int(antialias), 0, None, None, N.stream())
+        if rc != N.ERR_UNSUPPORTED:
+            N.check(rc, "vs_aug_crop_resize_color")
+            return out
     N.check(N.lib().vs_resize_nchw(N.ptr(x), N.ptr(out), planes, H, W, size[0], size[1], int(antialias), N.stream()), "vs_resize_nchw")
     return out
-
-
-FUSE = os.environ.get("VIDEOSEAL_AUG_FUSE", "1") != "0"     # Sequential: consecutive Crop / Resize / colour ops in fused passes (round 5)
-TIMERS = None         # bench.py: a list -> every fused / JPEG launch group appends (name, start event, end event, algorithmic bytes)
 
 
 def _timed(name: str, nbytes: int, fn):

@@ -16,6 +16,10 @@ namespace {
 enum { OP_BRIGHTNESS = 0, OP_CONTRAST = 1, OP_SATURATION = 2, OP_HUE = 3, OP_GRAYSCALE = 4 };
 
 __device__ __forceinline__ float clamp01(float v) { return fminf(fmaxf(v, 0.f), 1.f); }
+// The pixel arithmetic of the colour ops is compiled WITHOUT fma contraction (round 5): torchvision's tensor ops round every product before the
+// add, and left to the compiler `f * r + (1 - f) * gray` is fused around EITHER product depending on the surrounding code -- the single-op kernel
+// and the fused run of ops (color_chain_kernel, crop_resize_color_kernel) disagreed in the last bit.  One definition, one rounding sequence.
+#pragma clang fp contract(off)
 __device__ __forceinline__ float tv_gray(float r, float g, float b) { return 0.2989f * r + 0.587f * g + 0.114f * b; }
 
 __device__ __forceinline__ void hue_shift(float& r, float& g, float& b, float factor) {
@@ -66,6 +70,8 @@ __device__ __forceinline__ void apply_color(const int op, const float factor, co
   }
 }
 
+#pragma clang fp contract(fast)
+
 __global__ __launch_bounds__(256) void color_kernel(const float* __restrict__ src, float* __restrict__ dst, int64_t plane, int op,
                                                     float factor, const float* __restrict__ means) {
   const int f = blockIdx.y;
@@ -114,12 +120,14 @@ __global__ __launch_bounds__(256) void gray_partial_kernel(const float* __restri
   }
   if (threadIdx.x == 0) partial[(int64_t)f * gridDim.x + blockIdx.x] = red[0];
 }
-__global__ void gray_finish_kernel(const float* __restrict__ partial, int nblk, int64_t plane, float* __restrict__ means) {
-  const int f = blockIdx.x * blockDim.x + threadIdx.x;
-  if (f >= (int)gridDim.x * (int)blockDim.x) return;
+// one wave per frame: lane l adds the partial sums l, l + 64, ... in ascending order, then a fixed butterfly -> deterministic.  (Until round 5
+// ONE thread per frame walked the up to 256 partial sums as a chain of dependent loads: 17 us of the 38 us contrast op on 16 frames.)
+__global__ __launch_bounds__(64) void gray_finish_kernel(const float* __restrict__ partial, int nblk, int64_t plane, float* __restrict__ means) {
+  const int f = blockIdx.x;
   float s = 0.f;
-  for (int k = 0; k < nblk; ++k) s += partial[(int64_t)f * nblk + k];
-  means[f] = s / (float)plane;
+  for (int k = threadIdx.x; k < nblk; k += 64) s += partial[(int64_t)f * nblk + k];
+  s = wave_sum(s);
+  if (threadIdx.x == 0) means[f] = s / (float)plane;
 }
 
 // ------------------------------------------------------------------------------------------------ mask blend / additive noise
@@ -193,11 +201,26 @@ __global__ __launch_bounds__(256) void resize_nchw_kernel(const float* __restric
   const float* s = src + (int64_t)blockIdx.z * H * W;
   const Taps ty = make_taps(oy, H, oh, antialias), tx = make_taps(ox, W, ow, antialias);
   float acc = 0.f;
-  for (int jy = 0; jy < ty.n; ++jy) {
-    const float* row = s + (int64_t)(ty.lo + jy) * W + tx.lo;
-    float r = 0.f;
-    for (int jx = 0; jx < tx.n; ++jx) r += tap_w(tx, jx) * row[jx];
-    acc += tap_w(ty, jy) * r;
+  constexpr int MAXW = 12;
+  if (tx.n <= MAXW) {        // the column weights once per output (they were re-evaluated -- a triangle and a division each -- for every row of the window)
+    float wx[MAXW];
+#pragma unroll
+    for (int j = 0; j < MAXW; ++j) wx[j] = j < tx.n ? tap_w(tx, j) : 0.f;
+    for (int jy = 0; jy < ty.n; ++jy) {
+      const float* row = s + (int64_t)(ty.lo + jy) * W + tx.lo;
+      float r = 0.f;
+#pragma unroll
+      for (int jx = 0; jx < MAXW; ++jx)
+        if (jx < tx.n) r = __builtin_fmaf(wx[jx], row[jx], r);
+      acc = __builtin_fmaf(tap_w(ty, jy), r, acc);
+    }
+  } else {
+    for (int jy = 0; jy < ty.n; ++jy) {
+      const float* row = s + (int64_t)(ty.lo + jy) * W + tx.lo;
+      float r = 0.f;
+      for (int jx = 0; jx < tx.n; ++jx) r = __builtin_fmaf(tap_w(tx, jx), row[jx], r);
+      acc = __builtin_fmaf(tap_w(ty, jy), r, acc);
+    }
   }
   dst[((int64_t)blockIdx.z * oh + oy) * ow + ox] = acc;
 }
@@ -207,11 +230,29 @@ __global__ __launch_bounds__(256) void resize_nchw_kernel(const float* __restric
 // window of all three planes is staged once in LDS by coalesced loads (resize_nchw_kernel reads every tap from global memory: L1-bound at 0.14
 // of the HBM rate), and each output pixel evaluates the SAME taps in the SAME order as resize_nchw_kernel on the cropped tensor -- horizontal
 // sums first, then the vertical one -- followed by apply_color on its three channel values: bit-identical to the separate launches.
+constexpr int CRC_MAXW = 12;      // taps per axis whose weights are tabulated per tile (anti-aliased down-scaling up to 5.5 x)
+
 __global__ __launch_bounds__(256) void crop_resize_color_kernel(const float* __restrict__ src, float* __restrict__ dst, int H, int W, int i0, int j0,
                                                                 int ch, int cw, int oh, int ow, int antialias, int win_h, int win_w, ColorChain cc) {
-  extern __shared__ float crc_win[];                                  // [3][win_h][win_w]
+  extern __shared__ __attribute__((aligned(16))) float crc_smem[];
+  // [40][CRC_MAXW] tap weights of the tile's 32 columns and 8 rows | [40] first source index | [40] tap count | [3][win_h][win_w] source window
+  float* const wtab = crc_smem;
+  int* const tlo = reinterpret_cast<int*>(crc_smem + 40 * CRC_MAXW);
+  int* const tn = tlo + 40;
+  float* const crc_win = crc_smem + 40 * CRC_MAXW + 80;
   const int f = blockIdx.z;
   const int ox0 = blockIdx.x * 32, oy0 = blockIdx.y * 8;
+  // The tap weights once per TILE: a weight is a triangle and an IEEE division (tap_w), and evaluated per output pixel -- 24 of them, after the
+  // per-pixel tabulation -- they made the kernel instruction-bound (81 us for the configs[2] clip, ~1000 instructions per wave).  Threads 0-31
+  // tabulate the tile's columns, 32-39 its rows; every pixel then reads its two weight vectors from LDS.  Same values, same order of sums.
+  if (threadIdx.x < 40) {
+    const bool col = threadIdx.x < 32;
+    const int o = col ? min(ox0 + (int)threadIdx.x, ow - 1) : min(oy0 + (int)threadIdx.x - 32, oh - 1);
+    const Taps t = col ? make_taps(o, cw, ow, antialias) : make_taps(o, ch, oh, antialias);
+    tlo[threadIdx.x] = t.lo;
+    tn[threadIdx.x] = t.n;
+    for (int q = 0; q < CRC_MAXW; ++q) wtab[threadIdx.x * CRC_MAXW + q] = q < t.n ? tap_w(t, q) : 0.f;
+  }
   // source window of the tile (in crop coordinates): first tap of the first row / column .. last tap of the last row / column of the tile
   int ylo, yn, xlo, xn, t0, t1;
   tap_range(oy0, ch, oh, antialias, ylo, yn);
@@ -222,26 +263,74 @@ __global__ __launch_bounds__(256) void crop_resize_color_kernel(const float* __r
   const int xhi = t0 + t1;
   const int wh = yhi - ylo, ww = xhi - xlo;                           // <= win_h, win_w (checked by the launcher's bound)
   const float* sf = src + (int64_t)f * 3 * H * W;
-  for (int idx = threadIdx.x; idx < 3 * wh * ww; idx += 256) {
-    const int c = idx / (wh * ww), rem = idx - c * (wh * ww);
-    const int y = rem / ww, x = rem - y * ww;
-    crc_win[(c * win_h + y) * win_w + x] = sf[((int64_t)c * H + (i0 + ylo + y)) * W + (j0 + xlo + x)];
+  // rows of the window: 64 lanes along x (coalesced), the four waves take rows (c, y) round-robin, EIGHT rows per batch: the loads of a batch
+  // are unconditional (clamped addresses) and issued back to back, then stored -- a load -> store loop per row is a chain of ~15 dependent
+  // round trips per workgroup
+  {
+    const int l = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int nrow = 3 * wh;
+    for (int xc = 0; xc < ww; xc += 64) {
+      const int x = xc + l;
+      const int xl = x < ww ? x : ww - 1;
+      for (int r0 = wv; r0 < nrow; r0 += 32) {
+        float v[8];
+        int off[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int rowi = min(r0 + 4 * u, nrow - 1);
+          const int c = rowi / wh, y = rowi - c * wh;
+          off[u] = (c * win_h + y) * win_w;
+          v[u] = sf[((int64_t)c * H + (i0 + ylo + y)) * W + (j0 + xlo + xl)];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+          if (x < ww && r0 + 4 * u < nrow) crc_win[off[u] + x] = v[u];
+      }
+    }
   }
   __syncthreads();
-  const int ox = ox0 + (threadIdx.x & 31), oy = oy0 + (threadIdx.x >> 5);
+  const int cx = threadIdx.x & 31, cy = threadIdx.x >> 5;
+  const int ox = ox0 + cx, oy = oy0 + cy;
   if (ox >= ow || oy >= oh) return;
-  const Taps ty = make_taps(oy, ch, oh, antialias), tx = make_taps(ox, cw, ow, antialias);
+  const int nx = tn[cx], ny = tn[32 + cy], lox = tlo[cx] - xlo, loy = tlo[32 + cy] - ylo;
   float v[3];
+  if (nx <= CRC_MAXW && ny <= CRC_MAXW) {
+    float wx[CRC_MAXW], wy[CRC_MAXW];
 #pragma unroll
-  for (int c = 0; c < 3; ++c) {
-    float acc = 0.f;
-    for (int jy = 0; jy < ty.n; ++jy) {
-      const float* row = crc_win + (c * win_h + (ty.lo + jy - ylo)) * win_w + (tx.lo - xlo);
-      float r = 0.f;
-      for (int jx = 0; jx < tx.n; ++jx) r += tap_w(tx, jx) * row[jx];
-      acc += tap_w(ty, jy) * r;
+    for (int q = 0; q < CRC_MAXW; q += 4) {
+      const f32x4 a = *reinterpret_cast<const f32x4*>(wtab + cx * CRC_MAXW + q), b = *reinterpret_cast<const f32x4*>(wtab + (32 + cy) * CRC_MAXW + q);
+      wx[q] = a[0]; wx[q + 1] = a[1]; wx[q + 2] = a[2]; wx[q + 3] = a[3];
+      wy[q] = b[0]; wy[q + 1] = b[1]; wy[q + 2] = b[2]; wy[q + 3] = b[3];
     }
-    v[c] = acc;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      float acc = 0.f;
+      for (int jy = 0; jy < ny; ++jy) {
+        const float* row = crc_win + (c * win_h + (loy + jy)) * win_w + lox;
+        float r = 0.f;
+#pragma unroll
+        for (int jx = 0; jx < CRC_MAXW; ++jx)
+          if (jx < nx) r = __builtin_fmaf(wx[jx], row[jx], r);
+        float wyj = wy[0];
+#pragma unroll
+        for (int q = 1; q < CRC_MAXW; ++q) wyj = jy == q ? wy[q] : wyj;
+        acc = __builtin_fmaf(wyj, r, acc);
+      }
+      v[c] = acc;
+    }
+  } else {          // longer filters: the weights as resize_nchw_kernel evaluates them
+    const Taps ty = make_taps(oy, ch, oh, antialias), tx = make_taps(ox, cw, ow, antialias);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      float acc = 0.f;
+      for (int jy = 0; jy < ty.n; ++jy) {
+        const float* row = crc_win + (c * win_h + (loy + jy)) * win_w + lox;
+        float r = 0.f;
+        for (int jx = 0; jx < tx.n; ++jx) r = __builtin_fmaf(tap_w(tx, jx), row[jx], r);
+        acc = __builtin_fmaf(tap_w(ty, jy), r, acc);
+      }
+      v[c] = acc;
+    }
   }
   for (int k = 0; k < cc.n; ++k) apply_color(cc.op[k], cc.factor[k], 0.f, v[0], v[1], v[2]);
   float* df = dst + (int64_t)f * 3 * oh * ow + (int64_t)oy * ow + ox;
@@ -568,7 +657,7 @@ extern "C" int vs_aug_color(const float* src, float* dst, int F, int H, int W, i
     VS_REQUIRE(scratch);
     const int nblk = (int)gridx(plane, 256, 256);
     hipLaunchKernelGGL(gray_partial_kernel, dim3(nblk, F), dim3(256), 0, st, src, plane, scratch);
-    hipLaunchKernelGGL(gray_finish_kernel, dim3(F), dim3(1), 0, st, scratch, nblk, plane, scratch + (int64_t)F * nblk);
+    hipLaunchKernelGGL(gray_finish_kernel, dim3(F), dim3(64), 0, st, scratch, nblk, plane, scratch + (int64_t)F * nblk);
     means = scratch + (int64_t)F * nblk;
   }
   hipLaunchKernelGGL(color_kernel, dim3(gridx(plane), F), dim3(256), 0, st, src, dst, plane, op, factor, means);
@@ -592,7 +681,7 @@ extern "C" int vs_aug_color_chain(const float* src, float* dst, int F, int H, in
     VS_REQUIRE(scratch);
     const int nblk = (int)gridx(plane, 256, 256);
     hipLaunchKernelGGL(gray_partial_kernel, dim3(nblk, F), dim3(256), 0, st, src, plane, scratch);
-    hipLaunchKernelGGL(gray_finish_kernel, dim3(F), dim3(1), 0, st, scratch, nblk, plane, scratch + (int64_t)F * nblk);
+    hipLaunchKernelGGL(gray_finish_kernel, dim3(F), dim3(64), 0, st, scratch, nblk, plane, scratch + (int64_t)F * nblk);
     means = scratch + (int64_t)F * nblk;
   }
   hipLaunchKernelGGL(color_chain_kernel, dim3(gridx(plane), F), dim3(256), 0, st, src, dst, plane, cc, means);
@@ -620,7 +709,7 @@ extern "C" int vs_aug_crop_resize_color(const float* src, float* dst, int F, int
     return (int)((t - 1) * scale + 2.f * support + 4.f);
   };
   const int win_h = span(ch, oh, 8), win_w = span(cw, ow, 32) | 1;      // odd pitch: the 32 lanes of a row walk distinct banks
-  const size_t lds = (size_t)3 * win_h * win_w * sizeof(float);
+  const size_t lds = ((size_t)3 * win_h * win_w + 40 * CRC_MAXW + 80) * sizeof(float);
   if (lds > 60 * 1024) return VS_ERR_UNSUPPORTED;
   hipLaunchKernelGGL(crop_resize_color_kernel, dim3((ow + 31) / 32, (oh + 7) / 8, F), dim3(256), lds, (hipStream_t)stream, src, dst, H, W, i0, j0,
                      ch, cw, oh, ow, antialias, win_h, win_w, cc);

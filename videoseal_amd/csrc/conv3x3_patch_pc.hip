@@ -181,13 +181,15 @@ __global__ __launch_bounds__(512, 2) void conv3x3_patch_pc_kernel(const vs_conv_
       const int cc = c_off + ccl;                                         // global 16-channel chunk
       const char* base = reinterpret_cast<const char*>(d.in) + (int64_t)cc * (BK * 4);
       const bool cok = (cc * BK + (pt & 3) * 4) < d.Cin;
+      // every item is loaded UNCONDITIONALLY from a valid address (items outside the image / the patch have offset 0, lanes past the last
+      // channel re-read chunk 0) and zeroed by a select: with `if (have && cok) v = load` each of the NPI loads sat in its own divergent
+      // region and hipcc waited vmcnt(0) behind every one of them -- NPI dependent round trips per chunk instead of one batch (round 5)
+      const char* const basel = cok ? base : reinterpret_cast<const char*>(d.in);
+      f32x4 v[NPI];
 #pragma unroll
-      for (int i = 0; i < NPI; ++i) {
-        f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if (p_have[i] && cok) v = *reinterpret_cast<const f32x4*>(base + p_off[i]);
-        if (!p_ok[i]) v = f32x4{0.f, 0.f, 0.f, 0.f};
-        rp[i] = v;
-      }
+      for (int i = 0; i < NPI; ++i) v[i] = *reinterpret_cast<const f32x4*>(basel + p_off[i]);
+#pragma unroll
+      for (int i = 0; i < NPI; ++i) rp[i] = (p_ok[i] && cok) ? v[i] : f32x4{0.f, 0.f, 0.f, 0.f};
     };
     // item i of the patch is split + stored at tap `first + i` (first = -1: all at once): spreading the VALU burst
     // over six steps keeps these waves from arriving late at one barrier per chunk
@@ -205,11 +207,12 @@ __global__ __launch_bounds__(512, 2) void conv3x3_patch_pc_kernel(const vs_conv_
     auto load_rows2 = [&, qk4](const int c2) __attribute__((always_inline)) {      // in2 chunk c2 -> registers
       const char* base = reinterpret_cast<const char*>(d.in2) + (int64_t)c2 * (BK * 4);
       const bool cok = (c2 * BK + qk4) < d.Cin2;
+      const char* const basel = cok ? base : reinterpret_cast<const char*>(d.in2);        // (unconditional loads, as load_patch)
+      f32x4 v[NQ];
 #pragma unroll
-      for (int i = 0; i < NQ; ++i) {
-        rq[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (q_ok[i] && cok) rq[i] = *reinterpret_cast<const f32x4*>(base + q_off[i]);
-      }
+      for (int i = 0; i < NQ; ++i) v[i] = *reinterpret_cast<const f32x4*>(basel + q_off[i]);
+#pragma unroll
+      for (int i = 0; i < NQ; ++i) rq[i] = (q_ok[i] && cok) ? v[i] : f32x4{0.f, 0.f, 0.f, 0.f};
     };
     auto store_rows2 = [&, pt, qk4](const int pb) __attribute__((always_inline)) {  // as plain pixel rows 0..127
       unsigned char* Ps = Pbuf + pb * P_BYTES;
