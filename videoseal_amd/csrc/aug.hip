@@ -295,29 +295,28 @@ __global__ __launch_bounds__(256) void crop_resize_color_kernel(const float* __r
   const int nx = tn[cx], ny = tn[32 + cy], lox = tlo[cx] - xlo, loy = tlo[32 + cy] - ylo;
   float v[3];
   if (nx <= CRC_MAXW && ny <= CRC_MAXW) {
-    float wx[CRC_MAXW], wy[CRC_MAXW];
-#pragma unroll
-    for (int q = 0; q < CRC_MAXW; q += 4) {
-      const f32x4 a = *reinterpret_cast<const f32x4*>(wtab + cx * CRC_MAXW + q), b = *reinterpret_cast<const f32x4*>(wtab + (32 + cy) * CRC_MAXW + q);
-      wx[q] = a[0]; wx[q + 1] = a[1]; wx[q + 2] = a[2]; wx[q + 3] = a[3];
-      wy[q] = b[0]; wy[q + 1] = b[1]; wy[q + 2] = b[2]; wy[q + 3] = b[3];
-    }
-#pragma unroll
-    for (int c = 0; c < 3; ++c) {
-      float acc = 0.f;
-      for (int jy = 0; jy < ny; ++jy) {
-        const float* row = crc_win + (c * win_h + (loy + jy)) * win_w + lox;
-        float r = 0.f;
-#pragma unroll
-        for (int jx = 0; jx < CRC_MAXW; ++jx)
-          if (jx < nx) r = __builtin_fmaf(wx[jx], row[jx], r);
-        float wyj = wy[0];
-#pragma unroll
-        for (int q = 1; q < CRC_MAXW; ++q) wyj = jy == q ? wy[q] : wyj;
-        acc = __builtin_fmaf(wyj, r, acc);
+    // weights straight from the tile's table (one LDS read per tap and axis, shared by the three planes): register arrays indexed by the
+    // per-pixel tap count needed 12 predicated iterations per row and a 11-deep select chain per weight (~500 instructions per pixel)
+    const float* const wxp = wtab + cx * CRC_MAXW;
+    const float* const wyp = wtab + (32 + cy) * CRC_MAXW;
+    const float* const base = crc_win + loy * win_w + lox;
+    const int cs = win_h * win_w;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+    for (int jy = 0; jy < ny; ++jy) {
+      const float* row = base + jy * win_w;
+      float r0 = 0.f, r1 = 0.f, r2 = 0.f;
+      for (int jx = 0; jx < nx; ++jx) {
+        const float w = wxp[jx];
+        r0 = __builtin_fmaf(w, row[jx], r0);
+        r1 = __builtin_fmaf(w, row[cs + jx], r1);
+        r2 = __builtin_fmaf(w, row[2 * cs + jx], r2);
       }
-      v[c] = acc;
+      const float wyj = wyp[jy];
+      a0 = __builtin_fmaf(wyj, r0, a0);
+      a1 = __builtin_fmaf(wyj, r1, a1);
+      a2 = __builtin_fmaf(wyj, r2, a2);
     }
+    v[0] = a0; v[1] = a1; v[2] = a2;
   } else {          // longer filters: the weights as resize_nchw_kernel evaluates them
     const Taps ty = make_taps(oy, ch, oh, antialias), tx = make_taps(ox, cw, ow, antialias);
 #pragma unroll

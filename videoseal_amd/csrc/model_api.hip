@@ -427,7 +427,7 @@ struct Runner {
   }
   // one launch of the all-DMA 3x3 kernel on operand planes (tile code 22, conv3x3_pl.hip); out == nullptr: planes only
   void conv_pl(int B, int H, int W, const CW& w, const void* in_pl, void* out_pl, const Act* out, const CW* w2 = nullptr,
-               const void* in2_pl = nullptr) {
+               const void* in2_pl = nullptr, const float* pre_table = nullptr, int64_t pre_ld = 0) {
     vs_conv_desc_t d;
     std::memset(&d, 0, sizeof(d));
     d.B = B; d.H = H; d.W = W; d.Cin = w.CinP; d.KH = d.KW = 3; d.SH = d.SW = 1; d.PH = d.PW = 1; d.pad_mode = VS_PAD_ZERO; d.Ho = H; d.Wo = W;
@@ -441,16 +441,17 @@ struct Runner {
     d.n_store = w.N;
     if (out) { d.out = out->p; d.out_ld = out->ld; d.n_store = out->ld != rup(w.N, 4) ? w.N : out->ld; }
     d.tile_hint = VS_CONV_TILE_HI | 6;
+    if (pre_table) { d.a_scale = pre_table; d.a_scale_ld = pre_ld; d.tile_hint |= VS_CONV_PRE; }      // border-class table in the epilogue (first block)
     if (live()) chk(vs_conv_gemm(&d, st));
   }
   // engine.py::bottleneck_planes: ResnetBlocks j0.. from the fp32 activation x with every intermediate tensor as f16 operand planes
-  Act bottleneck_planes(const Act& x, int j0, const Act* last_out) {
+  Act bottleneck_planes(const Act& x, int j0, const Act* last_out, void* xpl_in = nullptr) {
     const int B = x.B, H = x.H, W = x.W, C = x.C;
     const int64_t pl_floats = x.rows() * C;               // 2 planes x rows x C f16
-    void* xpl = alloc(pl_floats);
+    void* xpl = xpl_in ? xpl_in : alloc(pl_floats);       // (the first block may hand its output over as planes already)
     void* tpl = alloc(pl_floats);
     void* ypl = alloc(pl_floats);
-    if (live()) chk(vs_to_planes(x.p, x.rows(), C, x.ld, A_MUL, xpl, st));
+    if (!xpl_in && live()) chk(vs_to_planes(x.p, x.rows(), C, x.ld, A_MUL, xpl, st));
     Act out{};
     const int nb = (int)m->bottleneck.size();
     for (int j = j0; j < nb; ++j) {
@@ -511,6 +512,7 @@ struct Runner {
       view = Act{lc.p, B, like.H, like.W, like.C, lc.ld};
       return true;
     };
+    void* cur_pl = nullptr;
     for (int j = 0; j < c.num_blocks; ++j) {
       Act view{};
       const bool direct = j == c.num_blocks - 1 && lowres_cat(0, cur, view);
@@ -522,6 +524,24 @@ struct Runner {
         conv(Act{lat, n_msgs, 1, 1, c.hidden, c.hidden}, m->b0_msg, P);
         float* table = alloc((int64_t)n_msgs * 9 * N);
         if (live()) chk(vs_msg_pre(P.p, n_msgs, N, table, st));
+        const Act nxt{nullptr, B, h3.H, h3.W, N, N};
+        if (c.num_blocks > 1 && N == h3.C && m->zc.back() % 16 == 0 && planes_ok(nxt, 1)) {
+          // engine.py::resblock_msg0(planes_out=True), round 5: the block on the all-DMA planes kernel, output handed to the chain as planes
+          const int nlat = m->zc.back();
+          void* latpl = alloc(h3.rows() * nlat);
+          void* h3pl = alloc(h3.rows() * h3.C);
+          void* tpl = alloc(h3.rows() * N);
+          void* xpl = alloc(h3.rows() * N);
+          if (live()) {
+            chk(vs_to_planes(h3.p, h3.rows(), nlat, h3.ld, A_MUL, latpl, st));
+            chk(vs_to_planes(h3.p, h3.rows(), h3.C, h3.ld, A_MUL, h3pl, st));
+          }
+          conv_pl(B, h3.H, h3.W, m->b0_lat, latpl, tpl, nullptr, nullptr, nullptr, table, n_msgs == 1 ? 0 : 9 * (int64_t)N);
+          conv_pl(B, h3.H, h3.W, rb.c1, tpl, xpl, nullptr, &rb.res, h3pl);
+          cur = nxt;
+          cur_pl = xpl;
+          continue;
+        }
         Act t = act(B, h3.H, h3.W, N);
         conv(h3, m->b0_lat, t, 1, 1, VS_PAD_ZERO, VS_ACT_RELU, 0, -1, nullptr, nullptr, nullptr, table, n_msgs == 1 ? 0 : 9 * (int64_t)N, nullptr,
              nullptr, nullptr, m->zc.back(), true);
@@ -533,7 +553,7 @@ struct Runner {
       if (j >= 1 && planes_ok(cur, j)) {                 // the rest of the chain on operand planes
         Act v2 = view;
         const bool d2 = j == c.num_blocks - 1 ? direct : lowres_cat(0, cur, v2);
-        cur = bottleneck_planes(cur, j, d2 ? &v2 : nullptr);
+        cur = bottleneck_planes(cur, j, d2 ? &v2 : nullptr, cur_pl);
         break;
       }
       cur = resblock(cur, rb, direct ? &view : nullptr);

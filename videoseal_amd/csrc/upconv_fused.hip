@@ -25,8 +25,12 @@ constexpr int UT = 8;                 // low-resolution cells per tile edge
 constexpr int UH = UT + 2;            // with halo
 constexpr int UROWS = 128;            // UH*UH = 100 halo pixels padded to 4 MFMA row blocks
 
+// NB = 5 (Co = 16, the 128^2 -> 256^2 level): two workgroups per CU (round 5).  The kernel's phases -- K loop, z tile to LDS, gather + LayerNorm -- run
+// one after the other with barriers in between; at 300 registers (220 + 80 accumulator registers) a CU held ONE workgroup of four waves and
+// nothing covered a phase's latencies.  With the activation prefetch sized to the layer (four 16-channel chunks: K = 64) and a 256-register
+// budget the compiler needs 192 registers and no scratch; 2 x 59 KB of LDS fit.
 template <int NB, int CG, int NP>
-__global__ __launch_bounds__(256) void upconv_fused_kernel(const float* __restrict__ x, int C1, int64_t ld1, const float* __restrict__ skip,
+__global__ __launch_bounds__(256, (NB <= 5 ? 2 : 1)) void upconv_fused_kernel(const float* __restrict__ x, int C1, int64_t ld1, const float* __restrict__ skip,
                                                            int C2, int64_t ld2, float sscale, const unsigned short* __restrict__ wsplit,
                                                            int H, int W, int Co, const float* __restrict__ lnw,
                                                            const float* __restrict__ lnb, float eps, int act, float* __restrict__ out,
@@ -75,7 +79,7 @@ __global__ __launch_bounds__(256) void upconv_fused_kernel(const float* __restri
   // The activation rows of up to KG chunks (128 channels) are requested in ONE burst per group -- with one chunk (8 KB per workgroup)
   // in flight the kernel paid the full HBM latency once per chunk and ran at a quarter of the bandwidth; the weight chunk of step
   // c+1 (L2-resident) is fetched while step c multiplies.
-  constexpr int KG = 8;
+  constexpr int KG = NB <= 5 ? 4 : 8;
   u32x4 rb[NBL][NP];
   auto fetch_b = [&](const int kc) __attribute__((always_inline)) {
 #pragma unroll
