@@ -385,6 +385,10 @@ GEMM_PL_CASES = [
     (2, 16, 24, 16, 130, 2, False, True, 24, 1, False),      # a single K step
     (3, 15, 15, 160, 96, 0, True, True, 25, 1, False),       # 225-row frames (ChunkySeal)
     (2, 31, 31, 96, 200, 2, False, False, 24, 1, True),      # 1922 rows: ragged last tile with GRN partials
+    # >= 4 x 256 tiles: the XCD-aware grouped tile order of round 5 (ChunkySeal's launches); 60 x 18 tiles, both edges ragged, 1080 % 8 != 0
+    (15, 31, 33, 48, 3272, 2, False, False, 24, 1, True),
+    (16, 32, 32, 64, 3072, 0, True, True, 24, 1, False),     # 64 x 16 tiles, residual
+    (10, 40, 40, 32, 2100, 0, False, False, 25, 1, False),   # 128-column tiles (tile 25): 63 x 17 = 1071 tiles, grouped order with a short last group
 ]
 
 

@@ -9,6 +9,7 @@
 // conv_gemm_kernel / gemm1x1_pc_kernel in the 2 x f16 arithmetic: bit-identical to them when K is not split.
 // Epilogue as gemm1x1_pc_kernel: bias, activation, residual, GRN sum-of-squares partials (common.py:166), or raw K-slice partial sums
 // for the shared split-K epilogue (small-M layers).
+#include <cstdlib>
 #include <type_traits>
 
 #include "conv_common.h"
@@ -38,7 +39,8 @@ template <int N>
 __device__ __forceinline__ void gwait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
 template <int TN>
-__global__ __launch_bounds__(512, 2) void gemm_pl_kernel(const vs_conv_desc_t d, const int M, const int mtiles, const int ntiles, const int sps) {
+__global__ __launch_bounds__(512, 2) void gemm_pl_kernel(const vs_conv_desc_t d, const int M, const int mtiles, const int ntiles, const int sps,
+                                                         const int per_xcd) {
   using AR = Arith<2>;
   constexpr int TM = 2;
   constexpr int BN = 2 * TN * 32;
@@ -53,9 +55,30 @@ __global__ __launch_bounds__(512, 2) void gemm_pl_kernel(const vs_conv_desc_t d,
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int r = lane & 31, g = lane >> 5;
 
-  const int bm = blockIdx.x % mtiles;
-  const int bn = (blockIdx.x / mtiles) % ntiles;
-  const int ks = blockIdx.x / (mtiles * ntiles);        // K slice (split_k > 1)
+  // Tile order.  per_xcd == 0: row tiles fastest (the order until round 5; right for the one-round launches of VideoSeal's stage 2 / 3).
+  // per_xcd > 0 (many rounds per launch: ChunkySeal's 60 x 31 tiles): workgroup b runs on XCD b % 8, so the b-th workgroup OF an XCD takes
+  // the b-th tile of that XCD's contiguous range of a grouped order -- four row tiles x all column tiles, column-major inside the group --
+  // and the 32 workgroups an XCD runs at a time cover 4 row tiles x 8 column tiles: 4 x 1.5 MB of activations + 8 x 1.1 MB of weights
+  // through its L2 instead of 32 row tiles + 1 column tile (49 MB) per round.  Same tiles, same arithmetic.
+  int bm, bn, ks;
+  if (per_xcd > 0) {
+    const int total = mtiles * ntiles;
+    const int slot = blockIdx.x % (8 * per_xcd);
+    ks = blockIdx.x / (8 * per_xcd);
+    const int v = (slot & 7) * per_xcd + (slot >> 3);
+    if (v >= total) return;                               // (the grid is padded to 8 x per_xcd slots per K slice)
+    constexpr int GROUP_M = 4;
+    const int width = GROUP_M * ntiles;
+    const int group = v / width, rem = v - group * width;
+    const int first_m = group * GROUP_M;
+    const int gsz = min(mtiles - first_m, GROUP_M);
+    bm = first_m + rem % gsz;
+    bn = rem / gsz;
+  } else {
+    bm = blockIdx.x % mtiles;
+    bn = (blockIdx.x / mtiles) % ntiles;
+    ks = blockIdx.x / (mtiles * ntiles);                  // K slice (split_k > 1)
+  }
   const int m0 = bm * GBM;
   const int n0 = bn * BN;
   const int nsteps_all = d.CinP / BK;
@@ -329,7 +352,11 @@ int launch_gpl(const vs_conv_desc_t& d, hipStream_t st) {
   const int sps = (nsteps + sk - 1) / sk;
   if (sk > 1 && (int64_t)(sk - 1) * sps >= nsteps) return VS_ERR_BAD_ARG;       // an empty K slice
   if (mt * nt * sk > 0x7fffffffLL || M > 0x7fffffffLL) return VS_ERR_UNSUPPORTED;
-  hipLaunchKernelGGL((gemm_pl_kernel<TN>), dim3((unsigned)(mt * nt * sk)), dim3(512), 0, st, d, (int)M, (int)mt, (int)nt, sps);
+  // XCD-aware grouped tile order for launches of several rounds (VS_GEMM_PL_RASTER=0: the row-major order)
+  static const bool raster = [] { const char* e = getenv("VS_GEMM_PL_RASTER"); return !(e && e[0] == '0'); }();
+  const int per_xcd = (raster && mt * nt >= 4 * vs_num_cus()) ? (int)((mt * nt + 7) / 8) : 0;
+  const int64_t grid = per_xcd > 0 ? (int64_t)8 * per_xcd * sk : mt * nt * sk;
+  hipLaunchKernelGGL((gemm_pl_kernel<TN>), dim3((unsigned)grid), dim3(512), 0, st, d, (int)M, (int)mt, (int)nt, sps, per_xcd);
   int rc = vs_launch_status();
   if (rc != VS_OK || sk == 1) return rc;
   return vs_splitk_epilogue(d, (int)M, st);
