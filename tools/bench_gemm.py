@@ -70,6 +70,15 @@ if __name__ == "__main__":
             run(f"M=8192 N=1536 K={K:4d} ablations (none / no act / no stores / neither)", 32, 16, K, 1536,
                 [(HI | 2, 1), (HI | 2 | 0x4000, 1), (HI | 2 | 0x2000, 1), (HI | 2 | 0x6000, 1)])
         sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "ksweep2":     # round 5: the same for the shapes of stage 2 as they run today (pwconv2 with the GRN transform + residual; pwconv1 on planes)
+        for K in (128, 384, 768, 1536, 3072):
+            run(f"pw2-like M=8192 N=384 K={K:4d} GRN+res", 32, 16, K, 384, [(HI | 2, 1), (HI | 2, 2), (HI | 10, 1), (HI | 1, 1)], grn=True)
+        for K in (128, 384, 768, 1536):
+            run(f"pw1-like M=8192 N=1536 K={K:4d} planes", 32, 16, K, 1536, [(HI | 8, 1), (HI | 2, 1)], planes=True)
+        for K in (384,):        # needs the library built with EXTRA=-DVS_KERNEL_ABLATION (VIDEOSEAL_LIB): none / no activation / no output stores / neither
+            run(f"pw1-like K={K} ablations planes", 32, 16, K, 1536, [(HI | 8, 1), (HI | 8 | 0x4000, 1), (HI | 8 | 0x2000, 1), (HI | 8 | 0x6000, 1)], planes=True)
+            run(f"pw2-like K=1536 ablations", 32, 16, 1536, 384, [(HI | 2, 2), (HI | 2 | 0x2000, 2), (HI | 10, 1), (HI | 10 | 0x2000, 1)], grn=True)
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "planes":      # all-DMA GEMM on operand planes (24 / 25) vs the best of the other kernels, 2 x f16
         P3, P2 = HI | 8, HI | 9
         run("s0 pw1  96->384  M=131072", 32, 64, 96, 384, [(1, 1), (HI | 1, 1), (P3, 1), (P2, 1)], planes=True)

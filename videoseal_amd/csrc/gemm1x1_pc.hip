@@ -26,6 +26,7 @@ namespace {
 using namespace vsconv;
 
 constexpr int BM = 128;
+constexpr int GRN_KCAP = 3072;      // K elements of a K slice whose GRN scale / shift rows live in LDS (36 KB)
 template <int NP> constexpr int a_stage() { return NP * BM * ROWB; }     // NP 16-bit planes of [128 rows][16 k], 48-byte rows (conflict-free b128 reads)
 
 __device__ __forceinline__ void dma_1k(const char* gp, unsigned char* lds_base) {
@@ -55,6 +56,7 @@ __device__ __forceinline__ void gemm1x1_pc_tile(const vs_conv_desc_t& d, const i
   constexpr int B_STAGE = NP * BN * 32;                  // NP planes of NG pre-swizzled 1 KiB blocks
   unsigned char* const Aring = smem;
   unsigned char* const Bring = smem + 2 * A_STAGE;
+  float* const Sc = reinterpret_cast<float*>(smem + 2 * A_STAGE + 2 * B_STAGE);      // GRN: [3][K slice] = scale of the two frames | shift
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -82,34 +84,48 @@ __device__ __forceinline__ void gemm1x1_pc_tile(const vs_conv_desc_t& d, const i
     // stages each, stage = t & 1.  Three register sets rotate (a pair is loaded 3 pairs = 6 steps before it is stored); the
     // loop body is straight-line so that hipcc's s_waitcnt vmcnt(N) placement is exact.
     const int pt = tid & 255;
-    constexpr int NI = BM * 8 / 256;       // 4 A items per thread per pair
+    constexpr int NI = BM * 8 / 256;       // 4 A items per thread per pair: 2 rows x the two K16 steps of the pair
     constexpr int NBP = NP * NG / 2;       // 16-byte weight chunks per thread per pair (2 steps * NP planes * NG * 64 / 256)
     constexpr int CPS = NP * NG * 64;      // chunks per step
-    const int seg = pt & 7;
+    // Item (j, half): 4 fp32 of row (pt >> 2) + 64 j at K offset (seg4 + 4 half) * 4 of the pair -- EVERY lane of a wave has work in both half
+    // steps.  (Until round 5 a thread's items all sat in one half -- seg = pt & 7 -- so the GRN apply + split of a half step ran with half the
+    // lanes masked off, twice per pair: the producers, not the consumers' MFMAs, set the K loop's 0.45 us per step, tools/bench_gemm.py ksweep2.)
+    // Four consecutive lanes read 64 contiguous bytes; the other half of the line is the same lanes' `half = 1` load.
+    const int seg4 = pt & 3;
     const int HW = d.H * d.W;
-    unsigned a_off[NI];
-    int l_off[NI];
+    unsigned a_off[2];
+    int l_off[2];
 #pragma unroll
-    for (int i = 0; i < NI; ++i) {
-      const int row = (pt >> 3) + i * 32;
+    for (int j2 = 0; j2 < 2; ++j2) {
+      const int row = (pt >> 2) + j2 * 64;
       int m = m0 + row;
       m = m < M ? m : M - 1;                                            // ragged last tile: re-read a valid row (discarded)
-      a_off[i] = (unsigned)(((int64_t)m * d.in_sx + seg * 4) * 4);
-      l_off[i] = ((seg >> 2) * A_STAGE) + row * ROWB + (seg & 3) * 8;   // stage parity of the step + position inside it
+      a_off[j2] = (unsigned)(((int64_t)m * d.in_sx + seg4 * 4) * 4);
+      l_off[j2] = row * ROWB + seg4 * 8;                                // position inside a stage (the half selects the stage)
     }
     // GRN scale is per (frame, channel).  A 128-row tile touches at most two frames (H*W >= 128, or H*W == 64 with aligned tiles:
-    // checked by the dispatcher): frame f_lo up to the row `rb` where the next frame starts, f_hi from there on.  (was: rows 0-63 one
-    // frame and rows 64-127 in one frame -> two scale vectors + one shift vector per thread and pair, loaded with the data
+    // checked by the dispatcher): frame f_lo up to the row `rb` where the next frame starts, f_hi from there on.  The slice's scale rows of
+    // both frames and the shift are copied to LDS once per tile (round 5: they were re-fetched from global memory with every pair, three
+    // loads and twelve registers per register set).
     const int f_lo = min(m0 / HW, d.B - 1), f_hi = min(f_lo + 1, d.B - 1);
     const int rb = (f_lo + 1) * HW - m0;              // first tile row of frame f_lo + 1 (>= 128: the tile lies in one frame)
-    bool hi_sel[NI];
+    bool hi_sel[2];
 #pragma unroll
-    for (int i = 0; i < NI; ++i) hi_sel[i] = ((pt >> 3) + i * 32) >= rb;
+    for (int j2 = 0; j2 < 2; ++j2) hi_sel[j2] = ((pt >> 2) + j2 * 64) >= rb;
     const char* const abase = reinterpret_cast<const char*>(d.in) + (int64_t)pair0 * 128;
-    constexpr bool grn = GRN;       // compile-time: a run-time branch around the scale loads makes hipcc's vmcnt counting pessimistic
-    const char* const sbase0 = reinterpret_cast<const char*>(d.a_scale) + ((int64_t)f_lo * d.a_scale_ld + pair0 * 32 + seg * 4) * 4;
-    const char* const sbase1 = reinterpret_cast<const char*>(d.a_scale) + ((int64_t)f_hi * d.a_scale_ld + pair0 * 32 + seg * 4) * 4;
-    const char* const hbase = reinterpret_cast<const char*>(d.a_shift) + ((int64_t)pair0 * 32 + seg * 4) * 4;
+    constexpr bool grn = GRN;
+    const int kslice = npairs * 32;
+    if (grn) {
+      const float* g0p = d.a_scale + (int64_t)f_lo * d.a_scale_ld + pair0 * 32;
+      const float* g1p = d.a_scale + (int64_t)f_hi * d.a_scale_ld + pair0 * 32;
+      const float* ghp = d.a_shift + pair0 * 32;
+      for (int k4 = pt * 4; k4 < kslice; k4 += 1024) {
+        *reinterpret_cast<f32x4*>(Sc + k4) = *reinterpret_cast<const f32x4*>(g0p + k4);
+        *reinterpret_cast<f32x4*>(Sc + kslice + k4) = *reinterpret_cast<const f32x4*>(g1p + k4);
+        *reinterpret_cast<f32x4*>(Sc + 2 * kslice + k4) = *reinterpret_cast<const f32x4*>(ghp + k4);
+      }
+      __syncthreads();                                // (matched by the consumers' first cbar)
+    }
     // weight chunks of this thread
     const int g0 = n0 / 32;
     const int ngroups = (d.N + 31) / 32;
@@ -133,35 +149,38 @@ __device__ __forceinline__ void gemm1x1_pc_tile(const vs_conv_desc_t& d, const i
     const float amul = NP == 2 ? d.a_mul : 1.f;
     const int lastp = npairs - 1;
 
-    struct PSet { f32x4 r[NI]; f32x4 s0, s1, h; u32x4 b[NBP]; };
+    struct PSet { f32x4 r[NI]; u32x4 b[NBP]; int pair; };
     PSet rs0, rs1, rs2;      // three rotating register sets
     auto load_pair = [&](PSet& R, int j) __attribute__((always_inline)) {
       j = j < lastp ? j : lastp;                                        // past the end: harmless re-read, keeps the body branch-free
+      R.pair = j;
       const char* base = abase + (int64_t)j * 128;
 #pragma unroll
-      for (int i = 0; i < NI; ++i) R.r[i] = *reinterpret_cast<const f32x4*>(base + a_off[i]);
-      if (grn) {
-        R.s0 = *reinterpret_cast<const f32x4*>(sbase0 + (int64_t)j * 128);
-        R.s1 = *reinterpret_cast<const f32x4*>(sbase1 + (int64_t)j * 128);
-        R.h = *reinterpret_cast<const f32x4*>(hbase + (int64_t)j * 128);
-      }
+      for (int j2 = 0; j2 < 2; ++j2)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) R.r[j2 * 2 + h] = *reinterpret_cast<const f32x4*>(base + a_off[j2] + h * 64);
       const char* wb = wbase + (int64_t)j * (2 * WBLK);
 #pragma unroll
       for (int q = 0; q < NBP; ++q) R.b[q] = *reinterpret_cast<const u32x4*>(wb + b_goff[q]);
     };
-    // half h of the pair in R -> stage h: every thread stores its A items at one of the two steps (seg 0-3: even, 4-7: odd)
+    // half h of the pair in R -> stage h: every thread splits + stores its two rows' items of that K16 step
     auto store_half = [&](const PSet& R, const int h) __attribute__((always_inline)) {
-      if ((seg >> 2) == h) {
+      f32x4 sc0, sc1, sh;
+      if (grn) {
+        const int ko = R.pair * 32 + (seg4 + 4 * h) * 4;
+        sc0 = *reinterpret_cast<const f32x4*>(Sc + ko);
+        sc1 = *reinterpret_cast<const f32x4*>(Sc + kslice + ko);
+        sh = *reinterpret_cast<const f32x4*>(Sc + 2 * kslice + ko);
+      }
 #pragma unroll
-        for (int i = 0; i < NI; ++i) {
-          f32x4 v = R.r[i];
-          if (grn) v = v * (hi_sel[i] ? R.s1 : R.s0) + R.h;            // GRN apply (same expression as conv_gemm_kernel)
-          u32x2 pl[NP];
-          split4n<NP>(v, amul, pl);
-          unsigned char* dst = Aring + l_off[i];
+      for (int j2 = 0; j2 < 2; ++j2) {
+        f32x4 v = R.r[j2 * 2 + h];
+        if (grn) v = v * (hi_sel[j2] ? sc1 : sc0) + sh;                 // GRN apply (same expression as conv_gemm_kernel)
+        u32x2 pl[NP];
+        split4n<NP>(v, amul, pl);
+        unsigned char* dst = Aring + h * A_STAGE + l_off[j2];
 #pragma unroll
-          for (int p = 0; p < NP; ++p) *reinterpret_cast<u32x2*>(dst + p * BM * ROWB) = pl[p];
-        }
+        for (int p = 0; p < NP; ++p) *reinterpret_cast<u32x2*>(dst + p * BM * ROWB) = pl[p];
       }
 #pragma unroll
       for (int q = 0; q < NBP; ++q)
@@ -244,6 +263,7 @@ __device__ __forceinline__ void gemm1x1_pc_tile(const vs_conv_desc_t& d, const i
     }
   };
 
+  if constexpr (GRN) cbar();            // the producers' copy of the GRN scale rows to LDS
   cbar();
   load_frags(F0, 0);
   __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0), see conv3x3_patch_pc.hip
@@ -304,7 +324,7 @@ template <int TN, bool GRN, int NP, int WN = 2>
 __global__ __launch_bounds__(512, 2) void gemm1x1_pc_kernel(const vs_conv_desc_t d, const int M, const int mtiles, const int ntiles,
                                                             const int pairs_per_split, const int ntot) {
   constexpr int B_STAGE = NP * (32 * TN * WN) * 32;
-  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * a_stage<NP>() + 2 * B_STAGE];
+  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * a_stage<NP>() + 2 * B_STAGE + (GRN ? 3 * GRN_KCAP * 4 : 0)];
   for (int tile = blockIdx.x; tile < ntot; tile += gridDim.x) gemm1x1_pc_tile<TN, GRN, NP, WN>(d, M, mtiles, ntiles, pairs_per_split, tile, smem);
 }
 
@@ -368,6 +388,8 @@ int launch_g(const vs_conv_desc_t& d, hipStream_t st) {
   const int sk = d.split_k > 1 ? d.split_k : 1;
   const int pps = (pairs + sk - 1) / sk;
   if ((int64_t)(sk - 1) * pps >= pairs) return VS_ERR_BAD_ARG;           // an empty K slice
+  if (d.a_scale && pps * 32 > GRN_KCAP) return VS_ERR_UNSUPPORTED;       // the GRN rows of a K slice are staged in LDS
+  if (d.a_scale && (((uintptr_t)d.a_scale | (uintptr_t)d.a_shift) & 15 || (d.a_scale_ld & 3))) return VS_ERR_UNSUPPORTED;
   if (mt * nt * sk > 0x7fffffffLL || M > 0x7fffffffLL) return VS_ERR_UNSUPPORTED;
   // store_tile_full / store_tile_guarded address a tile with 32-bit byte offsets from its first element (conv_gemm.hip / gemm_pl.hip check the
   // same bound and keep a 64-bit path; this kernel has only the 32-bit one)

@@ -285,8 +285,10 @@ __global__ __launch_bounds__(512, 2) void gemm_pl_kernel(const vs_conv_desc_t d,
     bias1[j] = (col[j] < d.N && d.bias) ? d.bias[col[j]] : 0.f;
     zero[j] = 0.f;
   }
-  apply_act_all<TM, TN>(acc, bias1, zero, d.act);
+  const int abl = VS_KERNEL_ABL(d);           // ablation build only (tools/bench_gemm.py ksweep2): 64 no activation, 32 no output stores
+  if (!(abl & 64)) apply_act_all<TM, TN>(acc, bias1, zero, d.act);
   if (d.sumsq_part) write_sumsq<TM, TN>(acc, d.sumsq_part, d.N, (int64_t)m0 + (int64_t)wm * TM * 32, M, col, g_e);
+  if (abl & 32) return;
   const bool whole = m0 + GBM <= M && n0 + BN <= d.N && (int64_t)GBM * max(d.out_ld, d.res_ld) * 4 < (1LL << 31);
   if (whole) {       // every layer of the shipped cards: store_tile_full (conv_common.h)
     const int64_t row0 = (int64_t)m0 + wm * TM * 32;                                   // wave-uniform

@@ -587,7 +587,8 @@ class HipEngine:
         """preconditions of the wave-specialised 1x1 GEMM (tile codes 17 / 18), mirrored from vs_conv_gemm"""
         return (bool(d.wt_split) and bool(d.wt_blk) and d.KH == 1 and d.KW == 1 and d.SH == 1 and d.SW == 1 and d.PH == 0 and d.PW == 0
                 and not d.in2 and d.Ho == d.H and d.Wo == d.W and d.Cin % 32 == 0 and d.CinP == d.Cin
-                and d.in_sy == d.W * d.in_sx and d.in_sb == d.H * d.in_sy and (not d.a_scale or d.H * d.W >= 128 or d.H * d.W == 64))
+                and d.in_sy == d.W * d.in_sx and d.in_sb == d.H * d.in_sy and (not d.a_scale or d.H * d.W >= 128 or d.H * d.W == 64)
+                and (not d.a_scale or d.CinP <= 3072 * max(1, d.split_k)))      # the GRN rows of a K slice are staged in LDS (<= 3072 elements)
 
     @staticmethod
     def _patch_pc_ok(d: "N.ConvDesc") -> bool:
