@@ -86,9 +86,9 @@ if __name__ == "__main__":
         run("s1 pw1 192->768  M=32768 ", 32, 32, 192, 768, [(1, 1), (HI | 2, 1), (P3, 1), (P2, 1)], planes=True)
         run("s1 pw2 768->192  M=32768 ", 32, 32, 768, 192, [(HI | 2, 1), (HI | 2, 2), (P3, 1), (P3, 2), (P2, 2)], grn=True, planes=True)
         run("s2 pw1 384->1536 M=8192  ", 32, 16, 384, 1536, [(HI | 2, 1), (P3, 1), (P2, 1)], planes=True)
-        run("s2 pw2 1536->384 M=8192  ", 32, 16, 1536, 384, [(HI | 2, 2), (HI | 2, 4), (P3, 2), (P3, 4), (P3, 8)], grn=True, planes=True)
-        run("s3 pw1 768->3072 M=2048  ", 32, 8, 768, 3072, [(HI | 2, 1), (HI | 2, 2), (P3, 1), (P3, 2)], planes=True)
-        run("s3 pw2 3072->768 M=2048  ", 32, 8, 3072, 768, [(HI | 2, 8), (P3, 8), (P3, 16)], grn=True, planes=True)
+        run("s2 pw2 1536->384 M=8192  ", 32, 16, 1536, 384, [(HI | 2, 2), (HI | 10, 1), (HI | 2, 4), (P3, 2), (P3, 4), (P3, 8)], grn=True, planes=True)
+        run("s3 pw1 768->3072 M=2048  ", 32, 8, 768, 3072, [(HI | 2, 1), (HI | 1, 1), (HI | 10, 1), (HI | 2, 2), (P3, 1), (P3, 2)], planes=True)
+        run("s3 pw2 3072->768 M=2048  ", 32, 8, 3072, 768, [(HI | 2, 8), (HI | 2, 4), (HI | 1, 4), (HI | 10, 2), (HI | 10, 4), (P3, 8), (P3, 16)], grn=True, planes=True)
         run("chunky s2 pw1 1472->5888 M=4096", 16, 16, 1472, 5888, [(HI | 2, 1), (P3, 1)], reps=5, planes=True)
         run("chunky s2 pw2 5888->1472 M=4096", 16, 16, 5888, 1472, [(HI | 2, 1), (P3, 1), (P3, 2)], grn=True, reps=5, planes=True)
         sys.exit(0)

@@ -355,6 +355,9 @@ struct Runner {
       d.tile_hint = (d.N % 192 == 0 ? (VS_CONV_TILE_HI | 0) : 15) | VS_CONV_PRE;
     } else if (sumsq) {
       d.sumsq_part = sumsq;
+    } else if (gemm_pc && a_scale && m->arith == 2 && d.N % 96 == 0 && d.H * d.W >= 128 &&
+               (((int64_t)d.B * d.H * d.W + 127) / 128) * ((d.N + 127) / 128) < 256 && (((int64_t)d.B * d.H * d.W + 127) / 128) * ((d.N + 95) / 96) >= 200) {
+      d.tile_hint = VS_CONV_TILE_HI | 10;                     // engine.py: pwconv2 on 128 x 96 tiles with the whole K per workgroup (tile 26) instead of K slices
     } else if (gemm_pc) {                                       // engine.py::_split_k_rule
       const int64_t rows = (int64_t)d.B * d.H * d.W;
       const int64_t blocks = ((rows + 127) / 128) * ((d.N + 127) / 128);
@@ -631,6 +634,13 @@ struct Runner {
         const int steps2 = hh.ld / 16;
         while (tiles2 * sk2 < 200 && steps2 / (sk2 * 2) >= 24 && steps2 % (sk2 * 2) == 0) sk2 *= 2;
         pl2 = tiles2 * sk2 >= 128;
+        if (pl2 && rows <= 2048 && HW % 64 == 0 && hh.ld % 32 == 0) {     // engine.py (round 5): small-M layers on the wave-specialised GEMM with the GRN A path
+          int skp = 1;
+          const int64_t blocks = ((rows + 127) / 128) * ((Cc + 127) / 128);
+          const int pairs = (int)(hh.ld / 32);
+          while (blocks * skp < 256 && pairs % (skp * 2) == 0 && pairs / (skp * 2) >= 4) skp *= 2;
+          if (hh.ld / skp <= 3072) pl2 = false;
+        }
       }
       // engine.py::_extractor_forward: pwconv1 -> GELU -> GRN -> pwconv2 with h on chip (statistics pass, scale, apply pass in place on cur)
       const bool fused = m->arith == 2 && !m->stages[sti].empty() && m->stages[sti][0].fuse && pw1w.CinP == Cc && vs_cnx_block_supported(Cc, rows, HW);

@@ -282,10 +282,12 @@ class HipEngine:
         self.msg_table_conv = os.environ.get("VIDEOSEAL_MSG_TABLE", "1") != "0"         # first bottleneck block: message channels as a table
         self.planes_chain = os.environ.get("VIDEOSEAL_PLANES", "1") != "0"              # bottleneck chain on pre-split operand planes
         self.msg0_planes = os.environ.get("VIDEOSEAL_MSG0_PLANES", "1") != "0"          # ... including its first block (round 5)
-        # stage-2 pwconv2 on 128 x 96 tiles (tile code 26) without K slices: measured NEUTRAL against 2 K slices + the epilogue launch (detect of
-        # 32 frames 3.502 / 3.509 vs 3.491 / 3.497 ms, same box, profiles/r05a_*): the K loop of the wave-specialised GEMM is bound by its
-        # producer waves (GRN apply + operand split of 128 x 16 activations per step), not by the 9 or 18 MFMAs per consumer wave -- opt-in
-        self.pw2_narrow = os.environ.get("VIDEOSEAL_PW2_NARROW", "0") == "1"
+        # stage-2 pwconv2 on 128 x 96 tiles (tile code 26) with the whole K per workgroup instead of 2 K slices + the epilogue launch.  Neutral while
+        # the wave-specialised GEMM's producers set its K loop's pace (profiles/r05a / r05c); with their lanes all working in both half steps the
+        # kernel alone is 49.9 us against 56.3 + 13 (tools/bench_gemm.py ksweep2) and detect of 32 frames 3.725 -> 3.651 ms (median of five
+        # alternating runs, profiles/r05o_detect_pw2_tile26.json).  VIDEOSEAL_PW2_NARROW=0: the K-slice form
+        self.pw2_narrow = os.environ.get("VIDEOSEAL_PW2_NARROW", "1") != "0"
+        self.pw2_small_pc = os.environ.get("VIDEOSEAL_PW2_SMALL_PC", "1") != "0"        # stage-3 pwconv2 on the wave-specialised GEMM instead of planes (round 5)
         self.planes_gemm = os.environ.get("VIDEOSEAL_PLANES", "1") != "0"               # ConvNeXt 1x1 GEMMs on operand planes
         self.fused_blocks = os.environ.get("VIDEOSEAL_CNX_FUSED", "1") != "0"           # stage 0 / 1 blocks with h kept on chip (convnext_fused.hip)
         self.thin_fused = os.environ.get("VIDEOSEAL_THIN_FUSED", "1") != "0"              # 16-channel ResnetBlocks in one launch (resblock_thin.hip)
@@ -1189,6 +1191,17 @@ class HipEngine:
                 while tiles2 * sk2 < 200 and steps2 // (sk2 * 2) >= 24 and steps2 % (sk2 * 2) == 0:
                     sk2 *= 2
                 pl2 = tiles2 * sk2 >= 128
+                # round 5: small-M layers (VideoSeal stage 3: 2048 rows x K = 3072) go back to the wave-specialised GEMM with the GRN transform on
+                # its A path -- with the producers' lanes all busy it is 50.9 us (4 K slices) against 15.0 (conversion pass over h) + 51.5 us on
+                # planes (tools/bench_gemm.py planes); ChunkySeal's wide layers (thousands of rows, K slices beyond the GRN rows' LDS budget) stay
+                if pl2 and cur.rows <= 2048 and HW % 64 == 0 and hh.ld % 32 == 0 and self.pw2_small_pc:
+                    skp = 1
+                    blocks = ((cur.rows + 127) // 128) * ((Cc + 127) // 128)
+                    pairs = hh.ld // 32
+                    while blocks * skp < 256 and pairs % (skp * 2) == 0 and pairs // (skp * 2) >= 4:
+                        skp *= 2
+                    if hh.ld // skp <= 3072:
+                        pl2 = False
             tnpl = self.buf(f"st{sti}.npl", cur.rows * pw1w.CinP).view(torch.int16) if pl1 else None
             hpl = self.buf(f"st{sti}.hpl", cur.rows * hh.ld).view(torch.int16) if pl2 else None
             ptile = N.CONV_TILE_HI | 8
