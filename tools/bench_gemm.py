@@ -90,7 +90,7 @@ if __name__ == "__main__":
         run("s3 pw1 768->3072 M=2048  ", 32, 8, 768, 3072, [(HI | 2, 1), (HI | 1, 1), (HI | 10, 1), (HI | 2, 2), (P3, 1), (P3, 2)], planes=True)
         run("s3 pw2 3072->768 M=2048  ", 32, 8, 3072, 768, [(HI | 2, 8), (HI | 2, 4), (HI | 1, 4), (HI | 10, 2), (HI | 10, 4), (P3, 8), (P3, 16)], grn=True, planes=True)
         run("chunky s2 pw1 1472->5888 M=4096", 16, 16, 1472, 5888, [(HI | 2, 1), (P3, 1)], reps=5, planes=True)
-        run("chunky s2 pw2 5888->1472 M=4096", 16, 16, 5888, 1472, [(HI | 2, 1), (P3, 1), (P3, 2)], grn=True, reps=5, planes=True)
+        run("chunky s2 pw2 5888->1472 M=4096", 16, 16, 5888, 1472, [(HI | 2, 2), (P3, 1), (P3, 2)], grn=True, reps=5, planes=True)      # (pc with the GRN A path: K slices of at most 3072)
         sys.exit(0)
     G = [(1, 1), (2, 1), (5, 1), (4, 1), (13, 1), (14, 1)]
     run("s0 pw1  96->384  M=131072", 32, 64, 96, 384, G + [(HI | 1, 1), (HI | 2, 1)])
