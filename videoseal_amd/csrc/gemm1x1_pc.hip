@@ -151,8 +151,12 @@ __device__ __forceinline__ void gemm1x1_pc_tile(const vs_conv_desc_t& d, const i
 
     struct PSet { f32x4 r[NI]; u32x4 b[NBP]; int pair; };
     PSet rs0, rs1, rs2;      // three rotating register sets
+#ifndef VS_PC_ABL
+#define VS_PC_ABL 0       // timing ablations of the K loop (EXTRA=-DVS_PC_ABL=<bits>, tools/bench_gemm.py ksweep2; results are garbage): 1 no GRN apply / operand
+#endif                    // split, 2 operands loaded once (no global loads in the loop), 4 no MFMAs, 8 no A stores to LDS, 16 no B stores to LDS
     auto load_pair = [&](PSet& R, int j) __attribute__((always_inline)) {
       j = j < lastp ? j : lastp;                                        // past the end: harmless re-read, keeps the body branch-free
+      if ((VS_PC_ABL & 2) && j > 2) { R.pair = j; return; }
       R.pair = j;
       const char* base = abase + (int64_t)j * 128;
 #pragma unroll
@@ -175,16 +179,27 @@ __device__ __forceinline__ void gemm1x1_pc_tile(const vs_conv_desc_t& d, const i
 #pragma unroll
       for (int j2 = 0; j2 < 2; ++j2) {
         f32x4 v = R.r[j2 * 2 + h];
-        if (grn) v = v * (hi_sel[j2] ? sc1 : sc0) + sh;                 // GRN apply (same expression as conv_gemm_kernel)
         u32x2 pl[NP];
-        split4n<NP>(v, amul, pl);
+        if (VS_PC_ABL & 1) {
+#pragma unroll
+          for (int p = 0; p < NP; ++p) pl[p] = u32x2{__float_as_uint(v[p]), __float_as_uint(v[p + 1])};
+        } else {
+          if (grn) v = v * (hi_sel[j2] ? sc1 : sc0) + sh;               // GRN apply (same expression as conv_gemm_kernel)
+          split4n<NP>(v, amul, pl);
+        }
         unsigned char* dst = Aring + h * A_STAGE + l_off[j2];
+        if (!(VS_PC_ABL & 8)) {
 #pragma unroll
-        for (int p = 0; p < NP; ++p) *reinterpret_cast<u32x2*>(dst + p * BM * ROWB) = pl[p];
+          for (int p = 0; p < NP; ++p) *reinterpret_cast<u32x2*>(dst + p * BM * ROWB) = pl[p];
+        } else {
+          asm volatile("" ::"v"(pl[0]), "v"(pl[NP - 1]));
+        }
       }
+      if (!(VS_PC_ABL & 16)) {
 #pragma unroll
-      for (int q = 0; q < NBP; ++q)
-        if (b_half[q] == (h != 0)) *reinterpret_cast<u32x4*>(Bring + b_loff[q]) = R.b[q];
+        for (int q = 0; q < NBP; ++q)
+          if (b_half[q] == (h != 0)) *reinterpret_cast<u32x4*>(Bring + b_loff[q]) = R.b[q];
+      }
     };
     // A(t) (step t) is written during step t-2 and read (prefetched) during step t-1: two stages, stage = t & 1.
     // prologue: pair 0 -> both stages; pairs 1, 2, 3 -> registers.
@@ -254,6 +269,10 @@ __device__ __forceinline__ void gemm1x1_pc_tile(const vs_conv_desc_t& d, const i
       for (int p = 0; p < NP; ++p) F.a[i][p] = *reinterpret_cast<const bf16x8*>(Ab + p * BM * ROWB + a_frag + i * 32 * ROWB);
   };
   auto mfma_all = [&](const Frags& F) __attribute__((always_inline)) {
+    if (VS_PC_ABL & 4) {
+      asm volatile("" ::"v"(F.a[0][0]), "v"(F.b[0][0]), "v"(F.a[TM - 1][NP - 1]), "v"(F.b[TN - 1][NP - 1]));
+      return;
+    }
 #pragma unroll
     for (int q = 0; q < AR::NPROD; ++q) {   // smallest partial products first; consecutive MFMAs hit different accumulators
 #pragma unroll
