@@ -21,6 +21,10 @@
 
 int vs_splitk_epilogue(const vs_conv_desc_t& d, int M, hipStream_t st);
 
+#ifndef VS_PC_PRIO
+#define VS_PC_PRIO 0      // s_setprio of the producer waves (EXTRA=-DVS_PC_PRIO=1|3): they are the second-dispatched half, i.e. the VALU arbitration
+                          // losers -- measured: no effect on any K (profiles/r05t_producer_priority.txt), so VALU issue is not what the producers wait for
+#endif
 namespace {
 
 using namespace vsconv;
@@ -75,6 +79,7 @@ __device__ __forceinline__ void gemm1x1_pc_tile(const vs_conv_desc_t& d, const i
 
   if (wave >= 4) {
     // ================================================================== producers (waves 4-7, one per SIMD)
+    if (VS_PC_PRIO) __builtin_amdgcn_s_setprio(VS_PC_PRIO);
     // All data movement, with ordinary loads only, balanced over the four SIMDs (an earlier version had two waves splitting
     // A and two waves DMA-ing B: the splitting waves were the bottleneck, 152 vs 230 TF-eq with them idle).
     //   A: item (row, seg) = 16 bytes = 4 fp32 of row `row` at K offset seg*4 inside the 32-wide pair; 8 consecutive lanes read
