@@ -170,8 +170,9 @@ def mix(text, sub, limit=4000):
 HOT_SOURCES = ["conv3x3_pl", "gemm_pl", "gemm1x1_pc", "conv3x3_patch_pc", "conv3x3_patch", "conv3x3_small", "conv_gemm", "convnext_fused",
                "resblock_thin", "upconv_fused"]
 # kernels above 1 % of the 32 x 768 x 768 image step (profiles/r04x_bench_image_b32_768_kernel_stats.csv), default 2 x f16 arithmetic
-HOT_KERNELS = ["conv3x3_pl_kernel<3>", "conv3x3_pl_kernel<2>", "gemm_pl_kernel<3>", "gemm_pl_kernel<2>", "gemm1x1_pc_kernel<3, true, 2, 2>",
-               "gemm1x1_pc_kernel<3, false, 2, 2>", "gemm1x1_pc_kernel<2, true, 2, 2>", "gemm1x1_pc_kernel<2, false, 2, 2>", "gemm1x1_pc_kernel<3, true, 2, 1>",
+HOT_KERNELS = ["conv3x3_pl_kernel<3>", "conv3x3_pl_kernel<2>", "gemm_pl_kernel<3>", "gemm_pl_kernel<2>", "gemm1x1_pc_kernel<3, true, 2, 2, 1536>",
+               "gemm1x1_pc_kernel<3, true, 2, 2, 3072>", "gemm1x1_pc_kernel<3, false, 2, 2, 3072>", "gemm1x1_pc_kernel<2, true, 2, 2, 1536>",
+               "gemm1x1_pc_kernel<2, false, 2, 2, 3072>", "gemm1x1_pc_kernel<3, true, 2, 1, 1536>", "gemm1x1_pc_kernel<3, true, 2, 1, 3072>",
                "conv3x3_patch_pc_kernel<3, 8, 2>", "conv3x3_patch_pc_kernel<2, 8, 2>", "conv3x3_patch_pc_kernel<1, 8, 2>",
                "conv3x3_patch_pc_kernel<2, 16, 2>", "conv3x3_patch_kernel<2, 2, 2, 1, 2>", "conv3x3_patch_kernel<4, 1, 1, 1, 2>",
                "conv3x3_patch_kernel<2, 2, 2, 2, 2>", "conv3x3_small_kernel<true, 2>", "conv3x3_small_kernel<false, 2>",

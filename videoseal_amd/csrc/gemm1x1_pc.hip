@@ -21,6 +21,12 @@
 
 int vs_splitk_epilogue(const vs_conv_desc_t& d, int M, hipStream_t st);
 
+#ifndef VS_PC_ABL
+#define VS_PC_ABL 0       // timing ablations of the K loop (EXTRA=-DVS_PC_ABL=<bits>, tools/bench_gemm.py ksweep2; results are garbage): 1 no GRN apply / operand
+#endif                    // split, 2 operands loaded once (no global loads in the loop), 4 no MFMAs, 8 no A stores to LDS, 16 no B stores to LDS (VS_PC_BDMA=0), 32 no wait for the weight DMA
+#ifndef VS_PC_BDMA
+#define VS_PC_BDMA 1      // weights by LDS-DMA from the consumer waves (2 x f16 arithmetic); 0: the producers copy them through registers (until round 5)
+#endif
 #ifndef VS_PC_PRIO
 #define VS_PC_PRIO 0      // s_setprio of the producer waves (EXTRA=-DVS_PC_PRIO=1|3): they are the second-dispatched half, i.e. the VALU arbitration
                           // losers -- measured: no effect on any K (profiles/r05t_producer_priority.txt), so VALU issue is not what the producers wait for
@@ -33,18 +39,25 @@ constexpr int BM = 128;
 constexpr int GRN_KCAP = 3072;      // K elements of a K slice whose GRN scale / shift rows live in LDS (36 KB)
 template <int NP> constexpr int a_stage() { return NP * BM * ROWB; }     // NP 16-bit planes of [128 rows][16 k], 48-byte rows (conflict-free b128 reads)
 
-__device__ __forceinline__ void dma_1k(const char* gp, unsigned char* lds_base) {
-  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gp,
-                                   (__attribute__((address_space(3))) void*)lds_base, 16, 0, 0);
-}
-
 // One output tile (tile id -> (row tile, column tile, K slice)).  The kernel below is PERSISTENT: a workgroup walks tiles
 // blockIdx.x, blockIdx.x + gridDim.x, ...  Both roles execute the same number of barriers per tile, all LDS fragment reads of a
 // tile are retired before its last barrier, and the consumers' output stores are not waited for -- so the producers fetch the next
 // tile's first operands while the consumers are in the epilogue, and the 50 MB of output of a 128 x 192-tile round drain under the
 // next tile's MFMAs instead of in a stores-only phase at the end of every round (measured: stores 16.6 us + activation 6 us of a
 // 75.7 us K = 384 launch, tools/bench_gemm.py ksweep).
-template <int TN, bool GRN, int NP, int WN>
+// lane l: 16 bytes at gp -> lds_base + 16 * l, written out so that hipcc does not track it as a pending LDS write (convnext_fused.hip: it would put
+// s_waitcnt vmcnt(0) in front of the next fragment read); the waits for these transfers are counted by hand
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Winline-asm"      // m0 on the clobber list is the point
+__device__ __forceinline__ void pc_dma16(const char* gp, unsigned char* lds_base) {
+  const unsigned m = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)lds_base);
+  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(gp), "s"(m) : "memory", "m0");
+}
+#pragma clang diagnostic pop
+template <int NP> constexpr bool pc_bdma() { return VS_PC_BDMA && NP == 2; }
+template <int NP> constexpr int pc_bstages() { return pc_bdma<NP>() ? 4 : 2; }
+
+template <int TN, bool GRN, int NP, int WN, int KC>
 __device__ __forceinline__ void gemm1x1_pc_tile(const vs_conv_desc_t& d, const int M, const int mtiles, const int ntiles,
                                                 const int pairs_per_split, const int tile, unsigned char* const smem) {
   // WN = 2: 2 x 2 consumer waves of 64 rows x 32*TN columns (tiles 128 x 128 / 128 x 192); WN = 1 (round 5): 4 x 1 waves of 32 rows x 32*TN
@@ -60,7 +73,12 @@ __device__ __forceinline__ void gemm1x1_pc_tile(const vs_conv_desc_t& d, const i
   constexpr int B_STAGE = NP * BN * 32;                  // NP planes of NG pre-swizzled 1 KiB blocks
   unsigned char* const Aring = smem;
   unsigned char* const Bring = smem + 2 * A_STAGE;
-  float* const Sc = reinterpret_cast<float*>(smem + 2 * A_STAGE + 2 * B_STAGE);      // GRN: [3][K slice] = scale of the two frames | shift
+  // BDMA (round 5): the weight blocks are copied verbatim, so they do not have to pass through the producers' registers and the LDS store path
+  // (79-85 B/clk per CU for the wide stores, shared by SIMD pairs: "no B stores" was worth 17 % of the K16 step, profiles/r05r_*): the four
+  // CONSUMER waves -- no other vector memory traffic in their K loop -- fetch them by LDS-DMA, a pair at a time, into a ring of two pair slots.
+  constexpr bool BDMA = pc_bdma<NP>();
+  constexpr int NBS = pc_bstages<NP>();
+  float* const Sc = reinterpret_cast<float*>(smem + 2 * A_STAGE + NBS * B_STAGE);    // GRN: [3][K slice] = scale of the two frames | shift
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -90,7 +108,8 @@ __device__ __forceinline__ void gemm1x1_pc_tile(const vs_conv_desc_t& d, const i
     // loop body is straight-line so that hipcc's s_waitcnt vmcnt(N) placement is exact.
     const int pt = tid & 255;
     constexpr int NI = BM * 8 / 256;       // 4 A items per thread per pair: 2 rows x the two K16 steps of the pair
-    constexpr int NBP = NP * NG / 2;       // 16-byte weight chunks per thread per pair (2 steps * NP planes * NG * 64 / 256)
+    constexpr int NBP = BDMA ? 0 : NP * NG / 2;       // 16-byte weight chunks per thread per pair (2 steps * NP planes * NG * 64 / 256)
+    constexpr int NBR = NBP ? NBP : 1;
     constexpr int CPS = NP * NG * 64;      // chunks per step
     // Item (j, half): 4 fp32 of row (pt >> 2) + 64 j at K offset (seg4 + 4 half) * 4 of the pair -- EVERY lane of a wave has work in both half
     // steps.  (Until round 5 a thread's items all sat in one half -- seg = pt & 7 -- so the GRN apply + split of a half step ran with half the
@@ -135,9 +154,9 @@ __device__ __forceinline__ void gemm1x1_pc_tile(const vs_conv_desc_t& d, const i
     const int g0 = n0 / 32;
     const int ngroups = (d.N + 31) / 32;
     const int nch = d.CinP / 16;
-    unsigned b_goff[NBP];
-    int b_loff[NBP];
-    bool b_half[NBP];
+    unsigned b_goff[NBR];
+    int b_loff[NBR];
+    bool b_half[NBR];
 #pragma unroll
     for (int j = 0; j < NBP; ++j) {
       const int cid = pt + j * 256;
@@ -154,11 +173,8 @@ __device__ __forceinline__ void gemm1x1_pc_tile(const vs_conv_desc_t& d, const i
     const float amul = NP == 2 ? d.a_mul : 1.f;
     const int lastp = npairs - 1;
 
-    struct PSet { f32x4 r[NI]; u32x4 b[NBP]; int pair; };
+    struct PSet { f32x4 r[NI]; u32x4 b[NBR]; int pair; };
     PSet rs0, rs1, rs2;      // three rotating register sets
-#ifndef VS_PC_ABL
-#define VS_PC_ABL 0       // timing ablations of the K loop (EXTRA=-DVS_PC_ABL=<bits>, tools/bench_gemm.py ksweep2; results are garbage): 1 no GRN apply / operand
-#endif                    // split, 2 operands loaded once (no global loads in the loop), 4 no MFMAs, 8 no A stores to LDS, 16 no B stores to LDS
     auto load_pair = [&](PSet& R, int j) __attribute__((always_inline)) {
       j = j < lastp ? j : lastp;                                        // past the end: harmless re-read, keeps the body branch-free
       if ((VS_PC_ABL & 2) && j > 2) { R.pair = j; return; }
@@ -262,7 +278,7 @@ __device__ __forceinline__ void gemm1x1_pc_tile(const vs_conv_desc_t& d, const i
   struct Frags { bf16x8 a[TM][NP]; bf16x8 b[TN][NP]; };
   Frags F0, F1;
   auto load_frags = [&, a_frag, b_frag](Frags& F, const int s) __attribute__((always_inline)) {
-    const unsigned char* Bb = Bring + (s & 1) * B_STAGE;
+    const unsigned char* Bb = Bring + (s & (NBS - 1)) * B_STAGE;
 #pragma unroll
     for (int j = 0; j < TN; ++j)
 #pragma unroll
@@ -287,6 +303,45 @@ __device__ __forceinline__ void gemm1x1_pc_tile(const vs_conv_desc_t& d, const i
     }
   };
 
+  // BDMA: pair P = the 2 NP NG weight blocks of steps 2P, 2P+1 -> stages 2 (P & 1), 2 (P & 1) + 1 (stage of step s = s & 3); wave w moves blocks
+  // w NBW .. w NBW + NBW - 1 of every pair, one 1 KiB block per instruction.  A slot is read (fragment prefetch) during steps 2P-1 and 2P, so pair
+  // P + 2 is requested at the start of step 2P+1 and has to be complete at the barrier that ends step 2P+2: each wave waits for its OWN transfers
+  // (vmcnt(0): nothing else of the K loop is in flight; after a persistent workgroup's previous tile that includes the tail of its output stores).
+  constexpr int NBW = NP * NG / 2;
+  unsigned w_goff[NBW];
+  int w_loff[NBW];
+  const char* wbase_c = nullptr;
+  if constexpr (BDMA) {
+    const int g0 = n0 / 32, ngroups = (d.N + 31) / 32, nch = d.CinP / 16;
+#pragma unroll
+    for (int q = 0; q < NBW; ++q) {
+      const int bi = wave * NBW + q;                                    // wave-uniform
+      const int half = bi / (NP * NG), c = bi - half * (NP * NG);
+      const int p = c / NG, gi = c - p * NG;
+      const int gsel = (g0 + gi) < ngroups ? g0 + gi : ngroups - 1;     // tile wider than N: re-read a valid group (columns discarded)
+      w_goff[q] = (unsigned)(((int64_t)gsel * nch + half) * WBLK + p * 1024) + lane * 16;
+      w_loff[q] = half * B_STAGE + p * (BN * 32) + gi * 1024;
+    }
+    wbase_c = reinterpret_cast<const char*>(d.wt_blk) + (int64_t)(2 * pair0) * WBLK;
+  }
+  auto dma_pair = [&](const int P) __attribute__((always_inline)) {
+    if constexpr (BDMA) {
+      const char* wb = wbase_c + (int64_t)P * (2 * WBLK);
+      unsigned char* slot = Bring + (P & 1) * (2 * B_STAGE);
+#pragma unroll
+      for (int q = 0; q < NBW; ++q) pc_dma16(wb + w_goff[q], slot + w_loff[q]);
+    }
+  };
+  auto dma_wait0 = []() __attribute__((always_inline)) {
+    if constexpr (BDMA && !(VS_PC_ABL & 32)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  };
+  const int npairs_c = total >> 1;
+  if constexpr (BDMA) {                  // (every fragment read of the previous tile retired before its last barrier: the ring is free)
+    dma_pair(0);
+    if (npairs_c > 1) dma_pair(1);
+    if (npairs_c > 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NBW) : "memory");      // pair 0 (transfers complete in order: at most pair 1's are left)
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
   if constexpr (GRN) cbar();            // the producers' copy of the GRN scale rows to LDS
   cbar();
   load_frags(F0, 0);
@@ -296,7 +351,9 @@ __device__ __forceinline__ void gemm1x1_pc_tile(const vs_conv_desc_t& d, const i
   for (; s + 2 < total; s += 2) {
     load_frags(F1, s + 1);
     mfma_all(F0);
+    dma_wait0();                          // pair s/2 + 1 (requested during step s - 1, or in the prologue)
     cbar();
+    if (BDMA && (s >> 1) + 2 < npairs_c) dma_pair((s >> 1) + 2);
     load_frags(F0, s + 2);
     mfma_all(F1);
     cbar();
@@ -344,12 +401,14 @@ __device__ __forceinline__ void gemm1x1_pc_tile(const vs_conv_desc_t& d, const i
   else store_tile_guarded<TM, TN>(acc, ob, (int)d.out_ld, rb, (int)d.res_ld, r_e, g_e, rows_left, d.N - c0, d.n_store - c0);
 }
 
-template <int TN, bool GRN, int NP, int WN = 2>
+// KC: K elements of a K slice whose GRN rows fit the LDS area (GRN_KCAP, or half of it: with the four weight stages of BDMA the 128 x 96 tile stays
+// at two workgroups per CU only with the smaller area -- ConvNeXt stage-2 pwconv2, K = 1536)
+template <int TN, bool GRN, int NP, int WN = 2, int KC = GRN_KCAP>
 __global__ __launch_bounds__(512, 2) void gemm1x1_pc_kernel(const vs_conv_desc_t d, const int M, const int mtiles, const int ntiles,
                                                             const int pairs_per_split, const int ntot) {
   constexpr int B_STAGE = NP * (32 * TN * WN) * 32;
-  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * a_stage<NP>() + 2 * B_STAGE + (GRN ? 3 * GRN_KCAP * 4 : 0)];
-  for (int tile = blockIdx.x; tile < ntot; tile += gridDim.x) gemm1x1_pc_tile<TN, GRN, NP, WN>(d, M, mtiles, ntiles, pairs_per_split, tile, smem);
+  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * a_stage<NP>() + pc_bstages<NP>() * B_STAGE + (GRN ? 3 * KC * 4 : 0)];
+  for (int tile = blockIdx.x; tile < ntot; tile += gridDim.x) gemm1x1_pc_tile<TN, GRN, NP, WN, KC>(d, M, mtiles, ntiles, pairs_per_split, tile, smem);
 }
 
 // out = act(sum_ks ws[ks] + bias) [+ ws[split_k] + bias2 : the 1x1 second phase of the patch kernel] (+ res); columns in
@@ -422,7 +481,9 @@ int launch_g(const vs_conv_desc_t& d, hipStream_t st) {
   static const int force_grid = [] { const char* e = getenv("VS_GEMM_GRID"); return e ? atoi(e) : 0; }();      // experiments: 0 = one workgroup per CU
   const int grid = std::min(ntot, force_grid > 0 ? force_grid : vs_num_cus());
   if (d.arith == 2) {
-    if (d.a_scale)
+    if (d.a_scale && pps * 32 <= GRN_KCAP / 2)
+      hipLaunchKernelGGL((gemm1x1_pc_kernel<TN, true, 2, WN, GRN_KCAP / 2>), dim3(grid), dim3(512), 0, st, d, (int)M, (int)mt, (int)nt, pps, ntot);
+    else if (d.a_scale)
       hipLaunchKernelGGL((gemm1x1_pc_kernel<TN, true, 2, WN>), dim3(grid), dim3(512), 0, st, d, (int)M, (int)mt, (int)nt, pps, ntot);
     else
       hipLaunchKernelGGL((gemm1x1_pc_kernel<TN, false, 2, WN>), dim3(grid), dim3(512), 0, st, d, (int)M, (int)mt, (int)nt, pps, ntot);
