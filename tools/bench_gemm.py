@@ -79,6 +79,14 @@ if __name__ == "__main__":
             run(f"pw1-like K={K} ablations planes", 32, 16, K, 1536, [(HI | 8, 1), (HI | 8 | 0x4000, 1), (HI | 8 | 0x2000, 1), (HI | 8 | 0x6000, 1)], planes=True)
             run(f"pw2-like K=1536 ablations", 32, 16, 1536, 384, [(HI | 2, 2), (HI | 2 | 0x2000, 2), (HI | 10, 1), (HI | 10 | 0x2000, 1)], grn=True)
         sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "bigm":        # the wave-specialised GEMM's tiles at the row counts of the stream / detect-batch-256 legs and of the image step
+        run("s2 pw2 1536->384 M=65536", 256, 16, 1536, 384, [(HI | 2, 1), (HI | 10, 1), (HI | 1, 1)], grn=True, reps=10)
+        run("s3 pw2 3072->768 M=16384", 256, 8, 3072, 768, [(HI | 2, 1), (HI | 10, 1), (HI | 2, 2), (HI | 1, 1)], grn=True, reps=10)
+        run("s3 pw1 768->3072 M=16384", 256, 8, 768, 3072, [(HI | 2, 1), (HI | 10, 1), (HI | 1, 1)], reps=10)
+        run("s3 pw1 768->3072 M=2048 ", 32, 8, 768, 3072, [(HI | 2, 1), (HI | 10, 1), (HI | 1, 1)])
+        run("s3 pw2 3072->768 M=2048 ", 32, 8, 3072, 768, [(HI | 2, 4), (HI | 10, 1), (HI | 10, 2), (HI | 10, 4)], grn=True)
+        run("up  gemm 1152->768 M=8192", 32, 16, 1152, 768, [(HI | 2, 1), (HI | 10, 1), (HI | 1, 1)])
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "planes":      # all-DMA GEMM on operand planes (24 / 25) vs the best of the other kernels, 2 x f16
         P3, P2 = HI | 8, HI | 9
         run("s0 pw1  96->384  M=131072", 32, 64, 96, 384, [(1, 1), (HI | 1, 1), (P3, 1), (P2, 1)], planes=True)
