@@ -92,16 +92,77 @@ struct PlanesOut { int64_t cstride, pstride; float a_mul; int Cp; };      // byt
 template <int NT, int LPP, bool WLDS, typename RowPtr>
 __device__ __forceinline__ void ln_rows_from_lds_impl(const float* __restrict__ s, int stride, int npx, int C, const float* __restrict__ lnw,
                                                       const float* __restrict__ lnb, float eps, int out_ld, RowPtr rowptr, const PlanesOut pl,
-                                                      float* s_wb) {
+                                                      float* s_wb, const bool prefilled = false) {
   // WLDS: the affine parameters are copied to LDS once per workgroup (one coalesced round trip) -- read per channel group from global memory they
   // are a chain of C / (4 LPP) dependent L2 round trips in every workgroup's tail (`LD LD s_waitcnt vmcnt(0)` per group in the ISA)
-  if (WLDS) {
+  if (WLDS && !prefilled) {            // (prefilled: the caller copied them at its start, in front of a barrier of its own)
     for (int i = threadIdx.x; i < C; i += NT) { s_wb[i] = lnw[i]; s_wb[C + i] = lnb[i]; }
     __syncthreads();
   }
   const int q = threadIdx.x & (LPP - 1);
   const int C4 = (C + 3) >> 2, O4 = pl.cstride ? pl.Cp >> 2 : out_ld >> 2;
   const float invC = 1.0f / (float)C;
+  // Register-resident form (round 5): a lane's share of a pixel -- up to LN_MAXV float4 -- is read from LDS ONCE, all reads issued before the first
+  // use, and stays in registers for the three passes (sum, squared deviations, output).  The loop form below reads it three times with a
+  // dependent LDS round trip per channel group and the affine parameters as eight scalar LDS reads per group: this stage was 40-50 % of the
+  // depthwise kernels (measured by leaving it out, LAB_NOTEBOOK round 5).  Same operations in the same order (which form runs depends on C and
+  // the lanes per pixel only, i.e. on the layer, never on the batch).
+  constexpr int LN_MAXV = 12;
+  if (WLDS && (C & 3) == 0 && O4 <= LN_MAXV * LPP) {
+    for (int p = threadIdx.x / LPP; p < npx; p += NT / LPP) {
+      float* orow = rowptr(p);
+      if (!orow) continue;                                  // the LPP lanes of a pixel skip together
+      const float* r = s + (int64_t)p * stride;
+      f32x4 v[LN_MAXV];
+#pragma unroll
+      for (int k = 0; k < LN_MAXV; ++k) {
+        const int c4 = q + k * LPP;
+        v[k] = *reinterpret_cast<const f32x4*>(r + 4 * (c4 < C4 ? c4 : q));       // (clamped: unconditional reads; unused slots are never added)
+      }
+      float sum = 0.f;
+#pragma unroll
+      for (int k = 0; k < LN_MAXV; ++k)
+        if (q + k * LPP < C4) sum += (v[k][0] + v[k][1]) + (v[k][2] + v[k][3]);
+#pragma unroll
+      for (int o = 1; o < LPP; o <<= 1) sum += __shfl_xor(sum, o, 64);
+      const float mean = sum * invC;
+      float var = 0.f;
+#pragma unroll
+      for (int k = 0; k < LN_MAXV; ++k)
+        if (q + k * LPP < C4) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float dl = v[k][e] - mean;               // C % 4 == 0: every channel of the group is a real one
+            var += dl * dl;
+          }
+        }
+#pragma unroll
+      for (int o = 1; o < LPP; o <<= 1) var += __shfl_xor(var, o, 64);
+      const float rden = 1.0f / sqrtf(var * invC + eps);
+#pragma unroll
+      for (int k = 0; k < LN_MAXV; ++k) {
+        const int c4 = q + k * LPP;
+        if (c4 < O4) {
+          f32x4 o = {0.f, 0.f, 0.f, 0.f};
+          if (c4 < C4) {
+            const f32x4 wv = *reinterpret_cast<const f32x4*>(s_wb + 4 * c4), bv = *reinterpret_cast<const f32x4*>(s_wb + C + 4 * c4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = wv[e] * ((v[k][e] - mean) * rden) + bv[e];
+          }
+          if (pl.cstride) {
+            vsconv::u32x2 hi, lo;
+            vsconv::split4h(o, pl.a_mul, hi, lo);
+            char* dst = reinterpret_cast<char*>(orow) + (int64_t)(c4 >> 2) * pl.cstride + (c4 & 3) * 8;
+            *reinterpret_cast<vsconv::u32x2*>(dst) = hi;
+            *reinterpret_cast<vsconv::u32x2*>(dst + pl.pstride) = lo;
+          } else {
+            *reinterpret_cast<f32x4*>(orow + 4 * c4) = o;
+          }
+        }
+      }
+    }
+    return;
+  }
   for (int p = threadIdx.x / LPP; p < npx; p += NT / LPP) {
     float* orow = rowptr(p);
     if (!orow) continue;                                  // the LPP lanes of a pixel skip together
@@ -151,14 +212,14 @@ __device__ __forceinline__ void ln_rows_from_lds_impl(const float* __restrict__ 
 template <int NT, typename RowPtr>
 __device__ __forceinline__ void ln_rows_from_lds(const float* __restrict__ s, int stride, int npx, int C, const float* __restrict__ lnw,
                                                  const float* __restrict__ lnb, float eps, int out_ld, RowPtr rowptr,
-                                                 const PlanesOut pl = PlanesOut{0, 0, 1.f, 0}, float* s_wb = nullptr) {
-  // s_wb: 2 C floats of LDS that no wave reads any more (the caller's barrier has passed), or nullptr
+                                                 const PlanesOut pl = PlanesOut{0, 0, 1.f, 0}, float* s_wb = nullptr, const bool prefilled = false) {
+  // s_wb: 2 C floats of LDS that no wave reads any more (the caller's barrier has passed) or that the caller filled itself (prefilled), or nullptr
   if (s_wb) {
-    if (npx * 8 > NT) ln_rows_from_lds_impl<NT, 4, true>(s, stride, npx, C, lnw, lnb, eps, out_ld, rowptr, pl, s_wb);
-    else if (npx * 16 > NT) ln_rows_from_lds_impl<NT, 8, true>(s, stride, npx, C, lnw, lnb, eps, out_ld, rowptr, pl, s_wb);
-    else if (npx * 32 > NT) ln_rows_from_lds_impl<NT, 16, true>(s, stride, npx, C, lnw, lnb, eps, out_ld, rowptr, pl, s_wb);
-    else if (npx * 64 > NT) ln_rows_from_lds_impl<NT, 32, true>(s, stride, npx, C, lnw, lnb, eps, out_ld, rowptr, pl, s_wb);
-    else ln_rows_from_lds_impl<NT, 64, true>(s, stride, npx, C, lnw, lnb, eps, out_ld, rowptr, pl, s_wb);
+    if (npx * 8 > NT) ln_rows_from_lds_impl<NT, 4, true>(s, stride, npx, C, lnw, lnb, eps, out_ld, rowptr, pl, s_wb, prefilled);
+    else if (npx * 16 > NT) ln_rows_from_lds_impl<NT, 8, true>(s, stride, npx, C, lnw, lnb, eps, out_ld, rowptr, pl, s_wb, prefilled);
+    else if (npx * 32 > NT) ln_rows_from_lds_impl<NT, 16, true>(s, stride, npx, C, lnw, lnb, eps, out_ld, rowptr, pl, s_wb, prefilled);
+    else if (npx * 64 > NT) ln_rows_from_lds_impl<NT, 32, true>(s, stride, npx, C, lnw, lnb, eps, out_ld, rowptr, pl, s_wb, prefilled);
+    else ln_rows_from_lds_impl<NT, 64, true>(s, stride, npx, C, lnw, lnb, eps, out_ld, rowptr, pl, s_wb, prefilled);
     return;
   }
   if (npx * 8 > NT) ln_rows_from_lds_impl<NT, 4, false>(s, stride, npx, C, lnw, lnb, eps, out_ld, rowptr, pl, nullptr);
@@ -177,7 +238,9 @@ __global__ __launch_bounds__(256) void dwconv7_ln_kernel(const float* __restrict
                                                          const float* __restrict__ lnw, const float* __restrict__ lnb,
                                                          float eps, float* __restrict__ out, int64_t out_ld, int NS,
                                                          int spr, int64_t nstrips, PlanesOut pl) {
-  extern __shared__ __attribute__((aligned(16))) float conv[];   // [NS*4][ld + 4]
+  extern __shared__ __attribute__((aligned(16))) float conv[];   // [NS*4][ld + 4] | the LayerNorm's affine parameters [2][C]
+  float* const s_wb = conv + (int64_t)NS * 4 * (ld + 4);
+  for (int i = threadIdx.x; i < C; i += 256) { s_wb[i] = lnw[i]; s_wb[C + i] = lnb[i]; }      // (visible behind the barrier below)
   const int C4 = (int)(ld >> 2);
   const int64_t s0 = (int64_t)blockIdx.x * NS;
   const int items = NS * C4;
@@ -222,7 +285,7 @@ __global__ __launch_bounds__(256) void dwconv7_ln_kernel(const float* __restrict
     if (sidx >= nstrips) return nullptr;
     const int px = (int)(sidx % spr) * 4 + (p & 3);
     return px < W ? out + ((sidx / spr) * W + px) * out_ld : nullptr;
-  }, pl);
+  }, pl, s_wb, true);
 }
 
 // LDS-tiled flavour of the same op (same FMA order per output => bit-identical to dwconv7_ln_kernel): a workgroup owns a TH x TW
@@ -236,7 +299,7 @@ __global__ __launch_bounds__(NT) void dwconv7_ln_tiled_kernel(const float* __res
                                                               const float* __restrict__ wdw, const float* __restrict__ bdw,
                                                               const float* __restrict__ lnw, const float* __restrict__ lnb,
                                                               float eps, float* __restrict__ out, int64_t out_ld, int tiles_x,
-                                                              int tiles_y, int nblk, PlanesOut pl) {
+                                                              int tiles_y, int nblk, PlanesOut pl, int wb_sep) {
   constexpr int IH = TH + 6, IW = TW + 6, CP = CCH + 4, SPR = TW / 4, N4 = CCH / 4;
   constexpr int NIN = IH * IW * N4, NWT = 50 * N4;            // float4 slots of a chunk: halo tile, taps + bias
   constexpr int LIN = (NIN + NT - 1) / NT, LWT = (NWT + NT - 1) / NT;
@@ -245,10 +308,13 @@ __global__ __launch_bounds__(NT) void dwconv7_ln_tiled_kernel(const float* __res
   float* const s_in = smem;                       // [IH][IW][CP]
   float* const s_w = s_in + IH * IW * CP;         // [50][CCH]: 49 taps + bias
   float* const s_out = s_w + 50 * CCH;            // [TH*TW][ld + 4]
+  float* const s_wbs = s_out + (int64_t)TH * TW * (ld + 4);      // wb_sep: the LayerNorm's affine parameters [2][C], copied right here
   const int tid = threadIdx.x;
   const int per = (nblk + 7) >> 3;                // XCD-aware order: neighbouring tiles (shared halos) on one XCD's L2
   const int vb = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
   if (vb >= nblk) return;
+  if (wb_sep)                                     // (visible behind the chunk loop's barriers; at the tail this was a global round trip + a barrier)
+    for (int i = tid; i < C; i += NT) { s_wbs[i] = lnw[i]; s_wbs[C + i] = lnb[i]; }
   const int tx = vb % tiles_x;
   const int t1 = vb / tiles_x;
   const int ty = t1 % tiles_y;
@@ -295,6 +361,9 @@ __global__ __launch_bounds__(NT) void dwconv7_ln_tiled_kernel(const float* __res
     }
     __syncthreads();
     if (ch + 1 < nch) fetch(c0 + CCH);             // next chunk's global loads fly during this chunk's FMAs
+#ifdef VS_DWT_ABL
+    if (!(VS_DWT_ABL & 2))          // timing ablation: no filter arithmetic
+#endif
     for (int it = tid; it < ITEMS; it += NT) {
       const int cg = it % N4, rs = it / N4;
       const int sx = rs % SPR, r = rs / SPR;
@@ -320,18 +389,23 @@ __global__ __launch_bounds__(NT) void dwconv7_ln_tiled_kernel(const float* __res
     }
     __syncthreads();
   }
+#ifdef VS_DWT_ABL
+  if (VS_DWT_ABL & 1) return;       // timing ablation: no LayerNorm stage
+#endif
   // (the halo tile s_in is dead behind the last chunk's barrier: its first 2 C floats hold the LayerNorm parameters)
   ln_rows_from_lds<NT>(s_out, (int)ld + 4, TH * TW, C, lnw, lnb, eps, (int)out_ld, [&](int p) -> float* {
     const int gy = y0 + p / TW, gx = x0 + p % TW;
     return (gy < H && gx < W) ? out + (((int64_t)b * H + gy) * W + gx) * out_ld : nullptr;
-  }, pl, (2 * C <= (TH + 6) * (TW + 6) * CP) ? s_in : nullptr);
+  }, pl, wb_sep ? s_wbs : (2 * C <= (TH + 6) * (TW + 6) * CP) ? s_in : nullptr, wb_sep != 0);
 }
 
 template <int TH, int TW, int CCH, int NT>
 static int launch_dwconv_tiled(const float* x, int B, int H, int W, int C, int64_t ld, const float* wdw, const float* bdw, const float* lnw,
                                const float* lnb, float eps, float* out, int64_t out_ld, hipStream_t st, PlanesOut pl = PlanesOut{0, 0, 1.f, 0}) {
-  const size_t smem = sizeof(float) * ((size_t)(TH + 6) * (TW + 6) * (CCH + 4) + 50 * CCH + (size_t)TH * TW * (ld + 4));
+  size_t smem = sizeof(float) * ((size_t)(TH + 6) * (TW + 6) * (CCH + 4) + 50 * CCH + (size_t)TH * TW * (ld + 4));
   if (smem > 160 * 1024 || ld % CCH != 0 || (int64_t)H * W * ld >= (1ll << 31)) return VS_ERR_UNSUPPORTED;
+  const int wb_sep = smem + 2 * sizeof(float) * (size_t)C <= 160 * 1024;       // room for the LayerNorm parameters next to the tiles
+  if (wb_sep) smem += 2 * sizeof(float) * (size_t)C;
   auto kern = dwconv7_ln_tiled_kernel<TH, TW, CCH, NT>;
   static size_t attr_set = 0;            // raise the dynamic-LDS limit once per size class (a cheap host-side call otherwise)
   if (smem > 64 * 1024 && smem > attr_set) {
@@ -342,7 +416,7 @@ static int launch_dwconv_tiled(const float* x, int B, int H, int W, int C, int64
   const int64_t nblk = (int64_t)B * tiles_x * tiles_y;
   if (nblk >= (1 << 30)) return VS_ERR_UNSUPPORTED;
   hipLaunchKernelGGL(kern, dim3((unsigned)((nblk + 7) / 8 * 8)), dim3(NT), smem, st, x, H, W, C, ld, wdw, bdw, lnw, lnb, eps, out, out_ld,
-                     tiles_x, tiles_y, (int)nblk, pl);
+                     tiles_x, tiles_y, (int)nblk, pl, wb_sep);
   return vs_launch_status();
 }
 
@@ -914,7 +988,7 @@ static int dwconv7_ln_any(const float* x, int B, int H, int W, int C, int64_t ld
   if (NS < 1) NS = 1;
   const int spr = (W + 3) / 4;
   const int64_t nstrips = (int64_t)B * H * spr;
-  const size_t smem = (size_t)NS * 4 * (ld + 4) * sizeof(float);
+  const size_t smem = ((size_t)NS * 4 * (ld + 4) + 2 * (size_t)C) * sizeof(float);
   if (smem > 160 * 1024) return VS_ERR_UNSUPPORTED;
   if (smem > 64 * 1024)
     (void)hipFuncSetAttribute((const void*)dwconv7_ln_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
