@@ -158,7 +158,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_patch_pc_kernel(const vs_conv_
       }
       const bool ok = iy >= 0 && iy < d.H && ix >= 0 && ix < d.W;
       p_ok[i] = ok && p_have[i];
-      p_off[i] = ok ? (unsigned)(((int64_t)fb * d.in_sb + (int64_t)iy * d.in_sy + (int64_t)ix * d.in_sx + k4) * 4) : 0u;
+      p_off[i] = ok ? (unsigned)(((int64_t)fb * d.in_sb + (int64_t)iy * d.in_sy + (int64_t)ix * d.in_sx) * 4) : 0u;     // (without the lane's channel offset)
       p_lds[i] = prow * ROWB + k4 * 2;
     }
     constexpr int NQ = BMP * 4 / 128;                    // in2 float4 items per thread per chunk (4)
@@ -171,7 +171,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_patch_pc_kernel(const vs_conv_
       const int y = y0 + (p >> 4), x = x0 + (p & 15);
       q_ok[i] = y < d.H && x < d.W;
       const int64_t m = ((int64_t)fb * d.H + (q_ok[i] ? y : 0)) * d.W + (q_ok[i] ? x : 0);
-      q_off[i] = (unsigned)((m * d.in2_ld + qk4) * 4);
+      q_off[i] = (unsigned)((m * d.in2_ld) * 4);                                          // (without the lane's channel offset)
     }
     const float amul = NP == 2 ? d.a_mul : 1.f;
     f32x4 rp[NPI];          // patch registers
@@ -182,9 +182,11 @@ __global__ __launch_bounds__(512, 2) void conv3x3_patch_pc_kernel(const vs_conv_
       const char* base = reinterpret_cast<const char*>(d.in) + (int64_t)cc * (BK * 4);
       const bool cok = (cc * BK + (pt & 3) * 4) < d.Cin;
       // every item is loaded UNCONDITIONALLY from a valid address (items outside the image / the patch have offset 0, lanes past the last
-      // channel re-read chunk 0) and zeroed by a select: with `if (have && cok) v = load` each of the NPI loads sat in its own divergent
-      // region and hipcc waited vmcnt(0) behind every one of them -- NPI dependent round trips per chunk instead of one batch (round 5)
-      const char* const basel = cok ? base : reinterpret_cast<const char*>(d.in);
+      // channel re-read channels 0-3 of their pixel) and zeroed by a select: with `if (have && cok) v = load` each of the NPI loads sat in its
+      // own divergent region and hipcc waited vmcnt(0) behind every one of them -- NPI dependent round trips per chunk instead of one batch
+      // (round 5).  The lane's channel offset is part of the base, NOT of the pixel offsets: a lane past the last channel that kept it read
+      // up to 48 bytes behind the last pixel of a 1 - 12-channel tensor (a sporadic memory fault in test_conv_gemm_matches_conv2d, tile 15).
+      const char* const basel = cok ? base + (pt & 3) * 16 : reinterpret_cast<const char*>(d.in);
       f32x4 v[NPI];
 #pragma unroll
       for (int i = 0; i < NPI; ++i) v[i] = *reinterpret_cast<const f32x4*>(basel + p_off[i]);
@@ -207,7 +209,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_patch_pc_kernel(const vs_conv_
     auto load_rows2 = [&, qk4](const int c2) __attribute__((always_inline)) {      // in2 chunk c2 -> registers
       const char* base = reinterpret_cast<const char*>(d.in2) + (int64_t)c2 * (BK * 4);
       const bool cok = (c2 * BK + qk4) < d.Cin2;
-      const char* const basel = cok ? base : reinterpret_cast<const char*>(d.in2);        // (unconditional loads, as load_patch)
+      const char* const basel = cok ? base + qk4 * 4 : reinterpret_cast<const char*>(d.in2);        // (unconditional loads, as load_patch)
       f32x4 v[NQ];
 #pragma unroll
       for (int i = 0; i < NQ; ++i) v[i] = *reinterpret_cast<const f32x4*>(basel + q_off[i]);
