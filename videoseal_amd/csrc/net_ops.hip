@@ -117,7 +117,7 @@ __device__ __forceinline__ void ln_rows_from_lds_impl(const float* __restrict__ 
 #pragma unroll
       for (int k = 0; k < LN_MAXV; ++k) {
         const int c4 = q + k * LPP;
-        v[k] = *reinterpret_cast<const f32x4*>(r + 4 * (c4 < C4 ? c4 : q));       // (clamped: unconditional reads; unused slots are never added)
+        v[k] = *reinterpret_cast<const f32x4*>(r + 4 * (c4 < C4 ? c4 : 0));       // (clamped: unconditional reads; unused slots are never added)
       }
       float sum = 0.f;
 #pragma unroll
