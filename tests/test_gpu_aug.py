@@ -9,7 +9,10 @@ from oracle import augment as A  # noqa: E402
 from oracle import videoseal_ref as R  # noqa: E402
 from oracle.inputs import synthetic_frames, synthetic_msgs  # noqa: E402
 from oracle.weights import make_state_dict, tiny_spec  # noqa: E402
+from tests._util import assert_decisions  # noqa: E402
 from tests.test_gpu_e2e import make_model  # noqa: E402
+
+CHAIN_MARGIN = 2e-4      # frames that went through the augmentation chain differ from the oracle's by up to 1e-5 per pixel
 from videoseal_amd import augmentation as G  # noqa: E402
 from videoseal_amd import native as N  # noqa: E402
 
@@ -209,7 +212,7 @@ def test_config3_clip_through_the_full_chain():
     preds = model.detect(aug, is_video=True)["preds"].cpu()
     pref = R.detect(sd, spec, r)["preds"]
     assert (preds - pref).abs().max() < 1e-3
-    assert ((preds > 0) == (pref > 0))[pref.abs() > 2e-3].all()
+    assert_decisions(preds, pref, margin=CHAIN_MARGIN, what="augmentation chain vs oracle", min_sure=0.99)
     acc = R.bit_accuracy(preds[:, 1:], msgs.expand(16, -1).float())
     acc_ref = R.bit_accuracy(pref[:, 1:], msgs.expand(16, -1).float())
     assert (acc - acc_ref).abs().max() < 1e-3

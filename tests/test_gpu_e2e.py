@@ -12,7 +12,7 @@ pytestmark = pytest.mark.gpu
 from oracle import videoseal_ref as R  # noqa: E402
 from oracle.inputs import synthetic_frames, synthetic_msgs  # noqa: E402
 from oracle.weights import legacy_tiny_spec, make_state_dict, spec_from_card, tiny_spec  # noqa: E402
-from tests._util import check_sub, load_golden, psnr_np  # noqa: E402
+from tests._util import DECISION_MARGIN, assert_decisions, check_sub, load_golden, psnr_np  # noqa: E402
 from tests.test_oracle_golden import CARDS, FULL, TINY, TINYC  # noqa: E402
 
 import videoseal_amd  # noqa: E402
@@ -71,8 +71,8 @@ def _run_case(spec, sd, model, name):
     gold = torch.from_numpy(g["preds"])
     # logits of OUR watermarked frames vs logits of the reference's watermarked frames
     assert (preds - gold).abs().max() < TOL_LOGIT
-    safe = gold.abs() > 2 * TOL_LOGIT
-    assert ((preds > 0) == (gold > 0))[safe].all()
+    # (uniform white noise sits on the JND mask's 3-grey-level jump, DESIGN.md section 2: isolated pixels differ by 6e-4 there)
+    assert_decisions(preds, gold, margin=2e-4 if meta["kind"] == "uniform" else DECISION_MARGIN, what=name + " preds", min_sure=0.99)
     # detector alone on identical inputs: decisions must be bit-exact
     clean = model.detect(imgs.cuda(), is_video=meta["is_video"])["preds"].cpu()
     gclean = torch.from_numpy(g["preds_clean"])
@@ -84,11 +84,14 @@ def _run_case(spec, sd, model, name):
         agg = model.detect(imgs_w, is_video=True, interpolation=na)["preds"][:, 1:].mean(dim=0).cpu()
         ref_agg = R.detect(sd, spec, imgs_w.cpu(), na)["preds"][:, 1:].mean(dim=0)
         assert (agg - ref_agg).abs().max() < 1e-4
+        # extract_message on OUR watermarked frames against the decision the REFERENCE took on its own (the golden's `msg_hat`), wherever
+        # the mean logit is further from 0 than 10 x the measured logit error; no flip allowance
         mh = model.extract_message(imgs_w).cpu()
-        ref_mh = (ref_agg > 0)[None]
-        margin = ref_agg.abs() > 1e-4          # a mean logit closer to 0 than the fp32 re-ordering noise may flip
-        assert (mh == ref_mh)[:, margin].all()
-        assert (mh != ref_mh).sum() <= 1
+        gold_mh = torch.from_numpy(g["msg_hat"]).bool()
+        sure = ref_agg.abs() > 1e-5
+        assert mh.shape == gold_mh.shape and int((~sure).sum()) <= 1
+        assert torch.equal(mh.bool()[:, sure], gold_mh[:, sure]), "extract_message differs from the reference's own decision"
+        assert torch.equal(mh.bool()[:, sure], (ref_agg > 0)[None][:, sure])
 
 
 @pytest.mark.parametrize("name", TINY)
@@ -138,6 +141,26 @@ def test_vs00_matches_reference_golden(name):
 @pytest.mark.parametrize("name", FULL)
 def test_vs10_matches_reference_golden(vs10, name):
     _run_case(*vs10, name)
+
+
+def test_configs1_stated_size_matches_the_reference_golden(vs10):
+    """BASELINE configs[1] AT ITS STATED SIZE -- the workload bench.py's `value` is measured on: 32 frames of 768 x 768, image mode (one
+    message per frame, every frame through the U-Net, full-resolution JND), embed + detect, against the unmodified reference's run of
+    exactly that (tests/golden/make_golden_cfg1.py): watermarked pixels, PSNR (whole batch and per frame), logits on watermarked and on
+    clean frames, every thresholded decision."""
+    spec, sd, model = vs10
+    _run_case(spec, sd, model, "vs10_img_768x32")
+    g = load_golden("vs10_img_768x32")
+    meta = g["meta"]
+    imgs = synthetic_frames(meta["n"], meta["h"], meta["w"], seed=meta["seed"])
+    msgs = synthetic_msgs(meta["n"], spec.nbits, seed=meta["seed"])
+    w = model.embed(imgs.cuda(), msgs, is_video=False)["imgs_w"]
+    d = 255.0 * (w.double() - imgs.cuda().double())
+    psnr_frame = (20 * torch.log10(torch.tensor(255.0, dtype=torch.float64)) - 10 * torch.log10((d ** 2).mean(dim=(1, 2, 3)).cpu()))
+    assert (psnr_frame - torch.from_numpy(g["psnr_frame"])).abs().max().item() < 1e-3
+    preds = model.detect(w, is_video=False)["preds"].cpu()
+    acc = float(((preds[:, 1:] > 0) == (msgs > 0.5)).float().mean())
+    assert acc == meta["bit_acc"], "bit accuracy against the embedded messages differs from the reference's"
 
 
 @pytest.mark.parametrize("mode,name", [("bf16x3", "vs10_img256"), ("bf16x3", "vs10_vid"), ("f32", "vs10_img256"), ("f16x2", "vs10_img_odd")])
@@ -530,7 +553,7 @@ def test_wide_chunky_detector_vs_oracle():
     ref = R.detect(sd, s, imgs)["preds"]
     got = model.detect(imgs.cuda(), is_video=True)["preds"].cpu()
     assert (got - ref).abs().max().item() < TOL_LOGIT * max(1.0, ref.abs().max().item())
-    assert ((got > 0) == (ref > 0))[ref.abs() > 1e-3].all()
+    assert_decisions(got, ref, what="wide chunky detector vs oracle")
 
 
 def test_config2_batch_partition_invariance():
@@ -546,7 +569,7 @@ def test_config2_batch_partition_invariance():
     pf = model.detect(full, is_video=True)["preds"]
     pp = torch.cat([model.detect(full[a:a + 8], is_video=True)["preds"] for a in range(0, 32, 8)])
     assert (pf - pp).abs().max().item() < 2e-5
-    assert ((pf > 0) == (pp > 0))[pf.abs() > 1e-4].all()
+    assert_decisions(pp, pf, what="32 frames vs 4 x 8 frames")
     vfull = model.embed(imgs, msgs[:1], is_video=True)["imgs_w"]           # key frames 0,4,..,28 in one chunk
     model.chunk_size = 2                                                     # 8 frames per chunk
     vparts = model.embed(imgs, msgs[:1], is_video=True)["imgs_w"]
@@ -573,7 +596,7 @@ def test_model_level_c_api(which, tiny, tinyc):
     lg = cm.detect(ref.cuda()).cpu()
     pref = R.detect(sd, spec, ref)["preds"]
     assert (lg - pref).abs().max().item() < TOL_LOGIT
-    assert ((lg > 0) == (pref > 0))[pref.abs() > 2e-3].all()
+    assert_decisions(lg, pref, what="model-level C-ABI detect vs oracle")
     # uint8 RGB24 clip in / out == the Python host's embed_u8 / detect_u8
     clip = (imgs * 255).to(torch.uint8).permute(0, 2, 3, 1).contiguous().cuda()
     model.chunk_size, model.step_size = 3, 2
@@ -646,10 +669,10 @@ def test_streaming_key_frame_groups_equal_the_per_chunk_calls(tiny, mode):
         for (_, x), (_, y) in zip(one_w, grp_w):
             assert (x - y).abs().max().item() < 1e-5
         assert (a - b).abs().max().item() < 1e-3
-        sure = a.abs() > 2e-3                      # decisions of the grouped path = decisions of the per-chunk calls (per frame and aggregated)
-        assert torch.equal((a > 0)[sure], (b > 0)[sure]) and sure.float().mean().item() > 0.9
+        # decisions of the grouped path = decisions of the per-chunk calls (per frame and aggregated)
+        assert_decisions(b, a, what=f"grouped vs per-chunk streaming ({mode})", min_sure=0.99)
         ma, mb = a[:, 1:].mean(dim=0), b[:, 1:].mean(dim=0)
-        assert torch.equal((ma > 0)[ma.abs() > 1e-4], (mb > 0)[ma.abs() > 1e-4])
+        assert torch.equal((ma > 0)[ma.abs() > 1e-5], (mb > 0)[ma.abs() > 1e-5])
         # the per-chunk expansion matters: one tail launch over the whole group differs in 'interpolate' mode (frames 13-15 of a chunk)
         if mode == "interpolate":
             model.chunk_size = 8                       # embed() itself with 32-frame chunks: a different (legal) chunking of the clip
@@ -706,8 +729,7 @@ def test_configs3_stated_size_streaming_equals_the_reference_run_of_inference_st
         assert abs(psnr_np(w.cpu(), frames) - meta["psnr"]) < 1e-3
         del w
         assert preds.shape == gold.shape and (preds - gold).abs().max().item() < TOL_LOGIT
-        safe = gold.abs() > 2 * TOL_LOGIT
-        assert ((preds > 0) == (gold > 0))[safe].all()
+        assert_decisions(preds, gold, what=f"stream 128 x 768^2 group={group}")
         agg = preds[:, 1:].mean(dim=0)
         assert (agg - agg_gold).abs().max().item() < 1e-4
         assert torch.equal((agg > 0)[sure], (agg_gold > 0)[sure])
@@ -740,7 +762,19 @@ def test_chunkyseal_released_size_detector_vs_oracle():
     ref = R.detect(sd, spec, imgs)["preds"]
     got = model.detect(imgs.cuda(), is_video=True)["preds"].cpu()
     assert (got - ref).abs().max().item() < 1e-4
-    assert ((got > 0) == (ref > 0))[ref.abs() > 1e-4].all()
+    assert_decisions(got, ref, what="ChunkySeal released size vs oracle")
+    # ... and against the UNMODIFIED reference at configs[4]'s frame size: `build_extractor` of the released card + `Wam.detect` on 2 frames
+    # of 1024 x 1024 (tests/golden/make_golden_cfg1.py --chunky; the 4:1 antialiased resize of wam.py:221-225 included)
+    g = load_golden("chunky_detect_1024x2")
+    meta = g["meta"]
+    assert meta["sd_seed"] == 2 and (meta["h"], meta["w"]) == (1024, 1024)
+    big = synthetic_frames(meta["n"], meta["h"], meta["w"], seed=meta["seed"]).cuda()
+    gold = torch.from_numpy(g["preds"])
+    for is_video in (False, True):
+        p = model.detect(big, is_video=is_video)["preds"].cpu()
+        assert p.shape == gold.shape == (2, 1025)
+        assert (p - gold).abs().max().item() < 1e-4, float((p - gold).abs().max())
+        assert_decisions(p, gold, what="ChunkySeal released size, 1024 x 1024, vs the reference golden")
     del model
     torch.cuda.empty_cache()
 
@@ -759,7 +793,7 @@ def test_vs10_768_vs_oracle(vs10):
         assert abs(R.psnr(got, imgs).mean().item() - R.psnr(ref, imgs).mean().item()) < 1e-3
         p, pr = model.detect(got.cuda(), is_video=True)["preds"].cpu(), R.detect(sd, spec, ref)["preds"]
         assert (p - pr).abs().max().item() < TOL_LOGIT
-        assert ((p > 0) == (pr > 0))[pr.abs() > 1e-4].all()
+        assert_decisions(p, pr, what="768 x 768 vs oracle")
 
 
 def test_fused_convnext_blocks_match_the_unfused_path_and_the_oracle(vs10):

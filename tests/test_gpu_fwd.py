@@ -15,7 +15,10 @@ from oracle import augment as A  # noqa: E402
 from oracle import videoseal_ref as R  # noqa: E402
 from oracle.inputs import synthetic_frames, synthetic_msgs  # noqa: E402
 from oracle.weights import make_state_dict, spec_from_card, tiny_spec  # noqa: E402
-from tests._util import GOLDEN, check_sub, load_golden  # noqa: E402
+from tests._util import GOLDEN, assert_decisions, check_sub, load_golden  # noqa: E402
+
+FWD_MARGIN = 2e-4        # train-mode forward: BatchNorm on batch statistics re-orders whole-batch sums (set from the measured error, see VS_DECISION_LOG)
+CHAIN_MARGIN = 2e-4      # frames that went through the augmentation chain differ from the oracle's by up to 1e-5 per pixel
 from tests.test_gpu_e2e import _run_case, make_model  # noqa: E402
 from tests.test_oracle_fwd import FWD_FULL, FWD_TINY, PIXELSEAL, bn_vectors  # noqa: E402
 from tests.test_oracle_golden import CARDS  # noqa: E402
@@ -55,7 +58,7 @@ def _check_fwd(spec, sd, name):
     gold = torch.from_numpy(g["preds"])
     preds = out["preds"].cpu()
     assert (preds - gold).abs().max() < 1e-3
-    assert ((preds > 0) == (gold > 0))[gold.abs() > 2e-3].all()
+    assert_decisions(preds, gold, margin=FWD_MARGIN, what=name + " train-mode forward", min_sure=0.99)
     assert (out["msgs"].cpu().numpy() == g["msgs"]).all()
     # BatchNorm buffers after the call: updated in train mode (momentum 0.1, unbiased variance), untouched otherwise
     rm, rv, nbt = bn_vectors({k: v.cpu() for k, v in model.state_dict().items()}, None)
@@ -239,12 +242,12 @@ def test_config3_full_size_vs10_clip_through_the_chain():
     with torch.no_grad():
         pref = R.detect(sd, spec, r)["preds"]
     assert (preds - pref).abs().max() < 1e-3
-    assert ((preds > 0) == (pref > 0))[pref.abs() > 2e-3].all()
+    assert_decisions(preds, pref, margin=CHAIN_MARGIN, what="configs[2] chain vs oracle", min_sure=0.99)
     m = msgs.expand(16, -1).float()
     assert (R.bit_accuracy(preds[:, 1:], m) - R.bit_accuracy(pref[:, 1:], m)).abs().max() < 1e-3
     # aggregated decision over the clip (videoseal.py:411-428)
     agg, agg_ref = preds[:, 1:].mean(0), pref[:, 1:].mean(0)
-    assert ((agg > 0) == (agg_ref > 0))[agg_ref.abs() > 1e-4].all()
+    assert ((agg > 0) == (agg_ref > 0))[agg_ref.abs() > 2e-5].all()
 
 
 @pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs")

@@ -58,7 +58,7 @@ def test_inference_streaming_clip_functions_run_unchanged():
     acc = bit_accuracy(bits, msgs.expand(16, -1)).mean()
     assert abs(float(acc) - float(R.bit_accuracy(pref, msgs.expand(16, -1)).mean())) < 1e-3
     # inference_streaming.py:160: mean of the logits over the clip, > 0
-    assert ((bits.mean(0) > 0) == (pref.mean(0) > 0))[pref.mean(0).abs() > 1e-4].all()
+    assert ((bits.mean(0) > 0) == (pref.mean(0) > 0))[pref.mean(0).abs() > 2e-5].all()
 
 
 def test_readme_quick_start_calls():

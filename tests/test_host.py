@@ -276,6 +276,18 @@ def test_setup_model_from_checkpoint_reads_a_training_checkpoint(tmp_path):
     assert m.embedder.cfg.nbits == 64 and float(m.blender.scaling_w) == pytest.approx(0.3)
     assert torch.equal(m.state_dict()["embedder.unet.outc.weight"], sd["embedder.unet.outc.weight"])
     assert config.embedder.params["msg_processor"]["nbits"] == 64        # the factories write back into the config, embedder.py:258-259
+    # train.py:562 writes the args as a YAML string (`omegaconf.OmegaConf.to_yaml(params)`), utils/cfg.py:63-64 parses it back
+    import yaml
+    ck_str = tmp_path / "checkpoint_yaml_args.pth"
+    torch.save({"model": sd, "args": yaml.safe_dump(args)}, ck_str)
+    cfg_str = C.get_config_from_checkpoint(ck_str)
+    assert cfg_str.embedder.model == "unet_small2_yuv_quant" and cfg_str.args["nbits"] == 64
+    ms = C.setup_model_from_checkpoint(str(ck_str))
+    assert isinstance(ms, Videoseal) and ms.chunk_size == 16 and ms.embedder.cfg.nbits == 64
+    assert torch.equal(ms.state_dict()["embedder.unet.outc.weight"], sd["embedder.unet.outc.weight"])
+    torch.save({"model": sd, "args": "just a scalar"}, ck_str)
+    with pytest.raises(Exception, match="params dictionary"):
+        C.get_config_from_checkpoint(ck_str)
     with pytest.raises(NotImplementedError, match="baseline"):
         C.setup_model_from_checkpoint("baseline/hidden")
     with pytest.raises(FileNotFoundError):

@@ -145,3 +145,49 @@ def test_vs10_oracle_matches_the_reference_streaming_run_at_768(vs10):
         assert (mine - torch.from_numpy(g["imgs_w.sub"][k0:k1])).abs().max().item() < 2e-6
         preds = R.detect(sd, spec, w)["preds"]
         assert (preds - torch.from_numpy(g["preds"][16 * c:16 * c + 16])).abs().max().item() < 2e-5
+
+
+def test_vs10_oracle_matches_the_reference_at_configs1_stated_size(vs10):
+    """configs[1] at its stated size (tests/golden/make_golden_cfg1.py: the unmodified reference on 32 frames of 768 x 768, image mode,
+    full-resolution JND): frames of an image-mode batch are independent (eval BatchNorm), so the oracle runs the first 6 of the 32 --
+    the strided sample of their watermarked pixels, their logits on watermarked and clean frames, decisions identical"""
+    spec, sd = vs10
+    g = load_golden("vs10_img_768x32")
+    meta = g["meta"]
+    assert (meta["n"], meta["h"], meta["w"], meta["is_video"], meta["lowres"]) == (32, 768, 768, False, False)
+    nf = 6
+    imgs = synthetic_frames(meta["n"], meta["h"], meta["w"], seed=meta["seed"])[:nf]
+    msgs = synthetic_msgs(meta["n"], spec.nbits, seed=meta["seed"])
+    assert (msgs.numpy() == g["msgs"]).all()
+    with torch.no_grad():
+        w = R.embed_image(sd, spec, imgs, msgs[:nf], lowres_attenuation=False)["imgs_w"]
+        stride = int(g["imgs_w.stats"][3])
+        k1 = -(-(nf * 3 * meta["h"] * meta["w"]) // stride)
+        assert (w.flatten()[::stride] - torch.from_numpy(g["imgs_w.sub"][:k1])).abs().max().item() < 2e-6
+        d = (255.0 * (w.double() - imgs.double()))
+        psnr_frame = 20 * torch.log10(torch.tensor(255.0, dtype=torch.float64)) - 10 * torch.log10((d ** 2).mean(dim=(1, 2, 3)))
+        assert (psnr_frame - torch.from_numpy(g["psnr_frame"][:nf])).abs().max().item() < 1e-3
+        for frames, key in ((w, "preds"), (imgs, "preds_clean")):
+            p = R.detect(sd, spec, frames)["preds"]
+            gold = torch.from_numpy(g[key][:nf])
+            assert (p - gold).abs().max().item() < 2e-5
+            assert ((p > 0) == (gold > 0)).all(), "bit decisions differ from the reference"
+
+
+def test_chunkyseal_oracle_matches_the_reference_at_its_released_size():
+    """configs[4]: the released ChunkySeal extractor (ConvNeXt 362 / 724 / 1448 / 2896, depths 3 / 3 / 27 / 3, stride-2 stem, 1024 bits;
+    773.7 M parameters) built by the reference's own `build_extractor`, 2 frames of 1024 x 1024 through `Wam.detect`
+    (tests/golden/make_golden_cfg1.py --chunky) -- until round 6 the oracle was pinned for this architecture only on the 18 / 36 / 54 /
+    90-channel `tinyc` goldens"""
+    g = load_golden("chunky_detect_1024x2")
+    meta = g["meta"]
+    spec = spec_from_card(os.path.join(CARDS, "chunkyseal.yaml"))
+    assert (spec.nbits, spec.img_size) == (meta["nbits"], meta["img_size"]) == (1024, 256)
+    sd = {k: v for k, v in make_state_dict(spec, seed=meta["sd_seed"]).items() if k.startswith("detector.")}
+    imgs = synthetic_frames(meta["n"], meta["h"], meta["w"], seed=meta["seed"])
+    with torch.no_grad():
+        p = R.detect(sd, spec, imgs)["preds"]
+    gold = torch.from_numpy(g["preds"])
+    assert p.shape == gold.shape == (2, 1025)
+    assert (p - gold).abs().max().item() < 2e-5
+    assert ((p > 0) == (gold > 0)).all(), "bit decisions differ from the reference"

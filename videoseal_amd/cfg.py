@@ -53,10 +53,15 @@ def resolve_config_path(cfg_path) -> Path:
 
 
 def _as_cfg(x):
+    """utils/cfg.py:63-64 `OmegaConf.create(checkpoint['args'])`: train.py:562 stores the args as a YAML STRING
+    (`OmegaConf.to_yaml(params)`), older checkpoints as a dict; both parse to a mapping"""
     try:
         from omegaconf import OmegaConf
-        return OmegaConf.create(x) if isinstance(x, (dict, list)) else x
+        return OmegaConf.create(x) if isinstance(x, (dict, list, str)) else x
     except ModuleNotFoundError:
+        if isinstance(x, str):
+            import yaml
+            x = yaml.safe_load(x)
         return to_attrdict(x)
 
 
