@@ -329,6 +329,10 @@ def _run(args, world, rank, dev, dist_on, n_ranks_seen):
         from videoseal_amd import augmentation as G
         if chain_seq[0] is None:
             chain_seq[0] = G.Sequential(G.JPEG(), G.Crop(), G.Resize(), G.Brightness(), G.Contrast(), G.Saturation(), G.Hue())
+            chain_seq.append(G.Sequential(*chain_seq[0].transforms[1:]))      # the same chain behind a separately timed JPEG round trip
+        # Crop.plan() draws its window with torch.randint (geometric.py:128-150): the same window every step, so that --dump-preds and the
+        # per-kernel timers see one workload from run to run
+        torch.manual_seed(1234)
         w = model.embed(frames, msgs, is_video=True, lowres_attenuation=args.lowres_attenuation)["imgs_w"]
         timed = eng_ref[0] is not None and eng_ref[0].shell_timers is not None
         G.TIMERS = aug_timers if timed else None
@@ -339,7 +343,7 @@ def _run(args, world, rank, dev, dist_on, n_ranks_seen):
                 x = G.jpeg_compress(w, CHAIN_ARGS[0])
                 e1.record()
                 aug_timers.append(("aug:jpeg_roundtrip", e0, e1, 2 * w.numel() * 4))
-                x, _ = G.Sequential(*chain_seq[0].transforms[1:])(x, None, CHAIN_ARGS[1:])
+                x, _ = chain_seq[1](x, None, CHAIN_ARGS[1:])
             else:
                 x, _ = chain_seq[0](w, None, CHAIN_ARGS)
         finally:

@@ -46,8 +46,11 @@ extern "C" {
 /* library / device introspection */
 int vs_version(void);                       /* ABI version, currently 2 (round 2: vs_conv_desc_t / vs_model_cfg_t grew the arithmetic and planes fields) */
 const char* vs_arch(void);                  /* "gfx950" */
-/* Development switch for tests / tools, per call and thread-safe (an atomic; launch paths never call getenv): key 0 = resize_pre form (1 = the
- * 32 x 8 tile kernel), 1 = resize_pre strip height in output rows, 2 = embed_tail strip height in rows; value 0 = the library's choice. */
+/* Development switch for tests / tools.  PROCESS-GLOBAL (one atomic per key: setting it is thread-safe, but a value set by one thread is seen
+ * by the resize_pre / embed_tail launches of EVERY thread and stream -- e.g. the streaming overlap stream -- until it is reset; not a per-call
+ * option, not for production hosts).  Launch paths never call getenv.  key 0 = resize_pre form (1 = the 32 x 8 tile kernel), 1 = resize_pre
+ * strip height in output rows, 2 = embed_tail strip height in rows; value 0 = the library's choice.  The environment default
+ * VIDEOSEAL_RESIZE=tile is latched ONCE per process at the first launch: toggling the variable afterwards has no effect, use this call. */
 int vs_debug_set(int key, int value);
 const char* vs_error_string(int code);
 int vs_sizeof_conv_desc(void);              /* sizeof(vs_conv_desc_t): lets a binding verify its struct mirror */

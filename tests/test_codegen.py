@@ -82,3 +82,34 @@ def test_the_budget_itself_only_tolerates_known_spills():
 # (gemm1x1_pc: 101 / 96 -> 106 / 98 when the producers' lane mapping changed, 98 / 92 with the weights fetched by LDS-DMA from the consumer waves)
 KNOWN_SPILLS = {"conv3x3_pl_kernel<3>": 32, "gemm_pl_kernel<3>": 67, "gemm1x1_pc_kernel<3, true, 2, 2, 1536>": 98, "gemm1x1_pc_kernel<3, true, 2, 2, 3072>": 98,
                 "gemm1x1_pc_kernel<3, false, 2, 2, 3072>": 92, "conv3x3_patch_pc_kernel<3, 8, 2>": 90}
+
+
+def test_untracked_lds_dma_is_m0_neutral():
+    """csrc/lds_dma.h: the hand-written `global_load_lds_dwordx4` takes its LDS base from M0, which belongs to the compiler
+    (an "m0" clobber is ignored: 'clobber list contains reserved registers').  Every inline-asm block of the built kernels that touches M0 must
+    save it into a scalar register first and restore it last -- then hipcc's own idea of M0 (the builtin form's base, a v_readlane index) stays
+    true across the statement and both DMA forms may be mixed in one kernel.  Checked on the emitted ISA of every source that uses the asm form."""
+    import re
+    if shutil.which("hipcc") is None:
+        pytest.skip("no hipcc in this environment")
+    import isa_scan
+    csrc = os.path.join(ROOT, "videoseal_amd", "csrc")
+    users = [f for f in sorted(os.listdir(csrc)) if f.endswith(".hip") and "vs_lds_dma16_untracked" in open(os.path.join(csrc, f)).read() or
+             f.endswith(".hip") and re.search(r"asm[^;]*\bm0\b", open(os.path.join(csrc, f)).read())]
+    assert {"convnext_fused.hip", "gemm1x1_pc.hip"} <= set(users)
+    # no source writes M0 in its own asm: the helper of lds_dma.h is the one place
+    for f in sorted(os.listdir(csrc)):
+        if f.endswith((".hip", ".h")) and f != "lds_dma.h":
+            assert not re.search(r"asm[^;]*\bm0\b", open(os.path.join(csrc, f)).read()), f"{f}: inline asm that names m0 outside lds_dma.h"
+    for f in users:
+        text = isa_scan.compile_s(os.path.join(csrc, f))
+        blocks = re.findall(r";;#ASMSTART\n(.*?);;#ASMEND", text, re.S)
+        dma = [[l.strip() for l in b.strip().splitlines()] for b in blocks if "m0" in b]
+        assert dma, f"{f}: no hand-written LDS-DMA in the ISA?"
+        for b in dma:
+            m = re.fullmatch(r"s_mov_b32 (s\d+), m0", b[0])
+            assert m, (f, b)
+            assert b[-1] == f"s_mov_b32 m0, {m.group(1)}", (f, b)
+            body = b[1:-1]
+            assert re.fullmatch(r"s_mov_b32 m0, \S+", body[0]) and body[-1].startswith("global_load_lds_dwordx4"), (f, b)
+            assert not any(l.startswith("s_mov_b32 m0") for l in body[1:]), (f, b)

@@ -71,8 +71,7 @@ def _run_case(spec, sd, model, name):
     gold = torch.from_numpy(g["preds"])
     # logits of OUR watermarked frames vs logits of the reference's watermarked frames
     assert (preds - gold).abs().max() < TOL_LOGIT
-    # (uniform white noise sits on the JND mask's 3-grey-level jump, DESIGN.md section 2: isolated pixels differ by 6e-4 there)
-    assert_decisions(preds, gold, margin=2e-4 if meta["kind"] == "uniform" else DECISION_MARGIN, what=name + " preds", min_sure=0.99)
+    assert_decisions(preds, gold, what=name + " preds", min_sure=0.99)        # largest measured logit error of any case: 3.5e-6
     # detector alone on identical inputs: decisions must be bit-exact
     clean = model.detect(imgs.cuda(), is_video=meta["is_video"])["preds"].cpu()
     gclean = torch.from_numpy(g["preds_clean"])
@@ -750,6 +749,55 @@ def test_configs3_stated_size_streaming_equals_the_reference_run_of_inference_st
     assert (soft - soft_gold).abs().max().item() < 5 * TOL_LOGIT          # a byte that rounds the other way moves a logit by ~1e-4
     sure8 = agg_u8.abs() > 1e-4
     assert torch.equal((soft.mean(dim=0) > 0)[sure8], (agg_u8 > 0)[sure8]) and sure8.float().mean() > 0.98
+
+
+def test_a_one_group_shard_overlaps_detect_inside_the_group(vs10, monkeypatch):
+    """configs[3] on 8 GPUs gives every rank 128 frames = ONE default group (8 chunks' key frames per U-Net pass): there is no "next embed" to
+    run the extractor under, so the overlap is cut inside the group -- the extractor starts on the first 32 watermarked frames while the tail
+    of the others is still being issued (streaming.py, `embed_group(on_tail=...)`).  (i) frames and logits BIT-EQUAL to the whole-group
+    hand-over (same U-Net batch, same extractor batches), for 'repeat' (one tail launch per 32 frames) and 'interpolate' (per chunk);
+    (ii) wall time of the 128-frame shard: not slower than the whole-group hand-over, and no more than embed-only + detect-only."""
+    import time
+    from videoseal_amd.streaming import embed_detect_chunks
+    spec, sd, model = vs10
+    frames = synthetic_frames(128, 768, 768, seed=83).cuda()
+    msgs = synthetic_msgs(1, spec.nbits, seed=83)
+    model.chunk_size, model.step_size = 32, 4
+    try:
+        for mode in ("repeat", "interpolate"):
+            model.video_mode = mode
+            res = {}
+            for fine in ("1", "0"):
+                monkeypatch.setenv("VIDEOSEAL_STREAM_FINE", fine)
+                got = []
+                p = embed_detect_chunks(model, frames, msgs, chunk=16, lowres_attenuation=True, sink=lambda i, w: got.append((i, w.clone())))
+                torch.cuda.synchronize()
+                assert [i for i, _ in got] == list(range(0, 128, 16))
+                res[fine] = (p.clone(), torch.cat([w for _, w in got]))
+            assert torch.equal(res["1"][0], res["0"][0]) and torch.equal(res["1"][1], res["0"][1]), mode
+        model.video_mode = "repeat"
+
+        def wall(fn, n=5):
+            for _ in range(2):
+                fn()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(n):
+                fn()
+            torch.cuda.synchronize()
+            return (time.perf_counter() - t0) / n
+        t = {}
+        for fine in ("1", "0"):
+            monkeypatch.setenv("VIDEOSEAL_STREAM_FINE", fine)
+            t[fine] = wall(lambda: embed_detect_chunks(model, frames, msgs, chunk=16, lowres_attenuation=True))
+        w = model.embed_group(frames, msgs, 16, lowres_attenuation=True)
+        t_emb = wall(lambda: model.embed_group(frames, msgs, 16, lowres_attenuation=True))
+        t_det = wall(lambda: model.detect(w, is_video=True))
+        print(f"128-frame shard: fine {t['1'] * 1e3:.2f} ms, whole-group {t['0'] * 1e3:.2f} ms, embed-only {t_emb * 1e3:.2f} + detect-only {t_det * 1e3:.2f} ms")
+        assert t["1"] <= 1.03 * t["0"]
+        assert t["1"] <= 1.03 * (t_emb + t_det)
+    finally:
+        model.video_mode = "repeat"
 
 
 def test_chunkyseal_released_size_detector_vs_oracle():

@@ -1098,3 +1098,84 @@ def test_resblock_thin_fused_kernel_32_channels(shape):
     assert rel_err(two, ref) < 2e-5 and rel_err(got, two) < 2e-5
     e3 = Eng(arith=3)
     assert not e3._thin_ok(xa, packed(), None)
+
+
+# ---- red zones: kernels that load unconditionally from clamped addresses and select afterwards must not let what lies
+# around a tensor reach the result, and must not write outside the output.  Every operand sits between two guard areas poisoned with signalling
+# patterns: NaN around the inputs (a value read past either end that reaches an accumulator makes the output NaN or different), a sentinel
+# around the output (a store outside the tensor changes it).  The unguarded launch of the same case is the expected value, bit for bit.
+GUARD = 4096        # floats on either side (16 KiB: more than any tile's halo)
+
+
+def _guarded(t: torch.Tensor, fill: float):
+    flat = t.contiguous().flatten()
+    buf = torch.full((GUARD + flat.numel() + GUARD,), fill, device=t.device, dtype=t.dtype)
+    buf[GUARD:GUARD + flat.numel()] = flat
+    return buf, buf[GUARD:GUARD + flat.numel()].view(t.shape)
+
+
+def _guards_intact(buf: torch.Tensor, fill: float) -> bool:
+    lo, hi = buf[:GUARD], buf[-GUARD:]
+    if fill != fill:
+        return bool(torch.isnan(lo).all() and torch.isnan(hi).all())
+    return bool((lo == fill).all() and (hi == fill).all())
+
+
+REDZONE_CONV = [c for c in CONV_CASES if c[-1] in (10, 11, 12, 15, 0x40, 0x43, 0x44, 0x45, 14)]
+
+
+@pytest.mark.parametrize("case", REDZONE_CONV)
+def test_conv_kernels_ignore_and_preserve_what_surrounds_their_tensors(eng, case):
+    """patch / wave-specialised / thin-layer conv kernels (clamped unconditional patch loads, conv3x3_patch_pc's round-5 out-of-bounds read was
+    of exactly this class): same launch with every operand between poisoned guard areas"""
+    B, Cin, H, W, Cout, k, s, p, pm, act, tile = case
+    if not eng.use_split:
+        pytest.skip("patch / wave-specialised kernels exist for the split back-end only")
+    g = torch.Generator().manual_seed(hash(case) % 1000)
+    x = torch.randn(B, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, k, k, generator=g) / math.sqrt(Cin * k * k)
+    b = torch.randn(Cout, generator=g)
+    xa = to_nhwc(x)
+    wt, cp = pack_conv(w.to(DEV), xa.ld)
+    Ho, Wo = (H + 2 * p - k) // s + 1, (W + 2 * p - k) // s + 1
+    plain = eng.new_act("rz.o", B, Ho, Wo, Cout)
+    plain.t.fill_(3.0)
+    eng.conv(xa, ConvW(wt, b.to(DEV), Cout, k, k, cp), plain, stride=s, pad=p, pad_mode=pm, act=act, tile_hint=tile)
+    torch.cuda.synchronize()
+    want = plain.t.clone()
+    xbuf, xg = _guarded(xa.t, float("nan"))
+    bbuf, bg = _guarded(b.to(DEV), float("nan"))
+    obuf, og = _guarded(torch.full_like(plain.t, 3.0), -7.0)
+    _KEEP.extend([xbuf, bbuf, obuf])
+    out = Act(og, B, Ho, Wo, Cout, plain.ld)
+    eng.conv(Act(xg, B, H, W, Cin, xa.ld), ConvW(wt, bg, Cout, k, k, cp), out, stride=s, pad=p, pad_mode=pm, act=act, tile_hint=tile)
+    torch.cuda.synchronize()
+    assert torch.isfinite(og).all(), "a value from outside the input tensor reached the output"
+    assert torch.equal(og.flatten(), want.flatten())
+    assert _guards_intact(obuf, -7.0), "a store outside the output tensor"
+    assert _guards_intact(xbuf, float("nan")) and _guards_intact(bbuf, float("nan"))
+
+
+@pytest.mark.parametrize("C_,H,W", [(96, 16, 16), (24, 9, 13), (362, 7, 7), (192, 40, 36), (20, 64, 64), (130, 17, 50)])
+def test_dwconv7_ln_ignores_and_preserves_what_surrounds_its_tensors(eng, C_, H, W):
+    """depthwise 7x7 + LayerNorm (halo tiles, ragged channel chunks): the same red-zone harness"""
+    g = torch.Generator().manual_seed(C_ + H)
+    B = 2
+    xa = to_nhwc(torch.randn(B, C_, H, W, generator=g))
+    wdw = torch.randn(49, rup(C_, 4), generator=g) * 0.1
+    wdw[:, C_:] = 0
+    wdw = dv(wdw)
+    vecs = [dv(F.pad(torch.randn(C_, generator=g), (0, rup(C_, 4) - C_))) for _ in range(3)]
+    L, st = eng.lib, N.stream()
+
+    def run(xt, ot):
+        N.check(L.vs_dwconv7_ln(N.ptr(xt), B, H, W, C_, xa.ld, N.ptr(wdw), N.ptr(vecs[0]), N.ptr(vecs[1]), N.ptr(vecs[2]), 1e-6, N.ptr(ot), xa.ld, st),
+                "vs_dwconv7_ln")
+        torch.cuda.synchronize()
+    want = torch.full_like(xa.t, 3.0)
+    run(xa.t, want)
+    xbuf, xg = _guarded(xa.t, float("nan"))
+    obuf, og = _guarded(torch.full_like(xa.t, 3.0), -7.0)
+    run(xg, og)
+    assert torch.isfinite(og).all() and torch.equal(og, want)
+    assert _guards_intact(obuf, -7.0) and _guards_intact(xbuf, float("nan"))

@@ -14,6 +14,7 @@
 // chunks in the same two buffers; consumers do not prefetch across those (short) steps.
 #include <type_traits>
 #include "conv_common.h"
+#include "lds_dma.h"
 
 int vs_splitk_epilogue(const vs_conv_desc_t& d, int M, hipStream_t st);   // gemm1x1_pc.hip
 
@@ -37,10 +38,7 @@ struct Geo {
 };
 
 // one wave moves a 1 KiB block global -> LDS (lane l: 16 bytes at gp, landing at lds_base + 16*l)
-__device__ __forceinline__ void dma_1k(const char* gp, unsigned char* lds_base) {
-  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gp,
-                                   (__attribute__((address_space(3))) void*)lds_base, 16, 0, 0);
-}
+__device__ __forceinline__ void dma_1k(const char* gp, unsigned char* lds_base) { vs_lds_dma16(gp, lds_base); }      // lds_dma.h
 
 template <int TN, int TH_, int NP>
 __global__ __launch_bounds__(512, 2) void conv3x3_patch_pc_kernel(const vs_conv_desc_t d, const int tiles_x, const int tiles_y,

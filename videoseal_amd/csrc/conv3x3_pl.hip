@@ -21,6 +21,7 @@
 #include <type_traits>
 
 #include "conv_common.h"
+#include "lds_dma.h"
 
 int vs_splitk_epilogue(const vs_conv_desc_t& d, int M, hipStream_t st);   // gemm1x1_pc.hip
 
@@ -37,10 +38,7 @@ constexpr int QX_OFF = 2 * P_BYTES;
 constexpr int RING_OFF = QX_OFF + 2 * Q_BYTES;
 constexpr int NRING = 6;
 
-__device__ __forceinline__ void dma16(const char* gp, unsigned char* lds_base) {      // lane l: 16 bytes at gp -> lds_base + 16 * l
-  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gp, (__attribute__((address_space(3))) void*)lds_base,
-                                   16, 0, 0);
-}
+__device__ __forceinline__ void dma16(const char* gp, unsigned char* lds_base) { vs_lds_dma16(gp, lds_base); }      // lds_dma.h: lane l: 16 bytes at gp -> lds_base + 16 * l
 template <int N>
 __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 

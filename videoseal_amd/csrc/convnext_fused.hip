@@ -21,24 +21,17 @@
 #include <type_traits>
 
 #include "conv_common.h"
+#include "lds_dma.h"
 
 namespace {
 
 using namespace vsconv;
 
-__device__ __forceinline__ void dma16(const char* gp, unsigned char* lds_base) {      // lane l: 16 bytes at gp -> lds_base + 16 * l
-  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gp, (__attribute__((address_space(3))) void*)lds_base,
-                                   16, 0, 0);
-}
-
-// The same instruction written out, for the pipelined kernel: hipcc tracks an LDS-DMA it knows about as a pending write to LDS and puts
-// s_waitcnt vmcnt(0) in front of the next LDS read of the same array -- in a loop that requests block hb + 3 and then reads block hb + 1 that is a
-// wait for the blocks just requested (26 of 94 us at C = 192).  The waits of this kernel are counted by hand anyway; hipcc's own vmcnt waits
-// stay correct with transfers it cannot see in flight (vmcnt retires in order: an unseen younger transfer only makes a counted wait stricter).
-__device__ __forceinline__ void dma16_asm(const char* gp, unsigned char* lds_base) {
-  const unsigned m = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)lds_base);
-  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(gp), "s"(m) : "memory", "m0");
-}
+// LDS-DMA forms (lds_dma.h): the builtin for the serial kernel, the untracked M0-neutral asm form for the pipelined one (hipcc would put
+// s_waitcnt vmcnt(0) in front of the next LDS read of the same array -- in a loop that requests block hb + 3 and then reads block hb + 1 that
+// is a wait for the blocks just requested: 26 of 94 us at C = 192; the waits of that kernel are counted by hand)
+__device__ __forceinline__ void dma16(const char* gp, unsigned char* lds_base) { vs_lds_dma16(gp, lds_base); }
+__device__ __forceinline__ void dma16_asm(const char* gp, unsigned char* lds_base) { vs_lds_dma16_untracked(gp, lds_base); }
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 // vs_gelu on two values at once: the polynomial and the blends as 2-wide fp32 operations (v_pk_fma_f32 / v_pk_mul_f32: two results per VALU slot),

@@ -18,6 +18,7 @@
 #include <cstdlib>
 
 #include "conv_common.h"
+#include "lds_dma.h"
 
 int vs_splitk_epilogue(const vs_conv_desc_t& d, int M, hipStream_t st);
 
@@ -47,13 +48,7 @@ template <int NP> constexpr int a_stage() { return NP * BM * ROWB; }     // NP 1
 // 75.7 us K = 384 launch, tools/bench_gemm.py ksweep).
 // lane l: 16 bytes at gp -> lds_base + 16 * l, written out so that hipcc does not track it as a pending LDS write (convnext_fused.hip: it would put
 // s_waitcnt vmcnt(0) in front of the next fragment read); the waits for these transfers are counted by hand
-#pragma clang diagnostic push
-#pragma clang diagnostic ignored "-Winline-asm"      // m0 on the clobber list is the point
-__device__ __forceinline__ void pc_dma16(const char* gp, unsigned char* lds_base) {
-  const unsigned m = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)lds_base);
-  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(gp), "s"(m) : "memory", "m0");
-}
-#pragma clang diagnostic pop
+__device__ __forceinline__ void pc_dma16(const char* gp, unsigned char* lds_base) { vs_lds_dma16_untracked(gp, lds_base); }      // lds_dma.h
 template <int NP> constexpr bool pc_bdma() { return VS_PC_BDMA && NP == 2; }
 template <int NP> constexpr int pc_bstages() { return pc_bdma<NP>() ? 4 : 2; }
 

@@ -13,6 +13,7 @@
 #include <type_traits>
 
 #include "conv_common.h"
+#include "lds_dma.h"
 
 int vs_splitk_epilogue(const vs_conv_desc_t& d, int M, hipStream_t st);   // gemm1x1_pc.hip
 
@@ -24,10 +25,7 @@ constexpr int GBM = 256;                       // rows per tile
 constexpr int A_STAGE = GBM * 2 * 2 * 16;      // 256 rows x 2 halves x 2 planes x 16 bytes
 constexpr int NRA = 5, NRB = 6;
 
-__device__ __forceinline__ void gdma16(const char* gp, unsigned char* lds_base) {      // lane l: 16 bytes at gp -> lds_base + 16 * l
-  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gp, (__attribute__((address_space(3))) void*)lds_base,
-                                   16, 0, 0);
-}
+__device__ __forceinline__ void gdma16(const char* gp, unsigned char* lds_base) { vs_lds_dma16(gp, lds_base); }      // lds_dma.h: lane l: 16 bytes at gp -> lds_base + 16 * l
 // a wave-uniform pointer the compiler has lost track of (loop-carried through uniform branches): back into SGPRs, so that the DMA uses the
 // scalar-base + 32-bit-VGPR-offset form instead of 64-bit per-lane addresses
 __device__ __forceinline__ const char* uniform_ptr(const char* p) {

@@ -355,14 +355,16 @@ struct Runner {
       d.tile_hint = (d.N % 192 == 0 ? (VS_CONV_TILE_HI | 0) : 15) | VS_CONV_PRE;
     } else if (sumsq) {
       d.sumsq_part = sumsq;
-    } else if (gemm_pc && a_scale && m->arith == 2 && d.N % 96 == 0 && d.H * d.W >= 128 &&
+    } else if (gemm_pc && a_scale && m->arith == 2 && d.N % 96 == 0 && d.H * d.W >= 128 && d.CinP <= 3072 &&      // (K <= 3072: the tile's GRN rows live in LDS)
                (((int64_t)d.B * d.H * d.W + 127) / 128) * ((d.N + 127) / 128) < 256 && (((int64_t)d.B * d.H * d.W + 127) / 128) * ((d.N + 95) / 96) >= 200) {
       d.tile_hint = VS_CONV_TILE_HI | 10;                     // engine.py: pwconv2 on 128 x 96 tiles with the whole K per workgroup (tile 26) instead of K slices
     } else if (gemm_pc) {                                       // engine.py::_split_k_rule
       const int64_t rows = (int64_t)d.B * d.H * d.W;
       const int64_t blocks = ((rows + 127) / 128) * ((d.N + 127) / 128);
       const int pairs = d.CinP / 32;
-      while (blocks * split_k < 256 && pairs % (split_k * 2) == 0 && pairs / (split_k * 2) >= 4) split_k *= 2;
+      int sk = 1;
+      while (blocks * sk < 256 && pairs % (sk * 2) == 0 && pairs / (sk * 2) >= 4) sk *= 2;
+      if (!a_scale || d.CinP / sk <= 3072) split_k = sk;      // engine.py::conv: the GRN rows of a K SLICE are staged in LDS; longer slices stay unsplit
     } else if (patch_pc && d.N >= 128 && d.CinP >= 128) {      // engine.py::_split_k_rule_patch
       const int64_t blocks = (int64_t)d.B * (d.H / 8) * (d.W / 16) * (d.N % 192 == 0 ? (d.N + 191) / 192 : (d.N + 127) / 128);
       const int spt = d.CinP / 16;

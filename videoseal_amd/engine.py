@@ -560,7 +560,12 @@ class HipEngine:
         if split_k is None:     # static, shape-only rule (never timing-based: a K split changes the summation order)
             split_k = 1
             if tile_hint == 0 and self._gemm_pc_ok(d):
-                split_k = self._split_k_rule(d)
+                sk = self._split_k_rule(d)
+                # the GRN rows of a K slice are staged in LDS (<= 3072 elements): the cap applies to the SLICE the rule picks (convnext_base stage 3,
+                # K = 4096, runs as two slices of 2048); a slice beyond it leaves the launch unsplit for vs_conv_gemm's generic dispatch.
+                # model_api.hip mirrors this rule line for line, so the Python engine and the C-ABI host sum K in the same order
+                if not d.a_scale or d.CinP // sk <= 3072:
+                    split_k = sk
             elif tile_hint == 0 and patch_pc:
                 split_k = self._split_k_rule_patch(d)
         if split_k > 1:
@@ -589,8 +594,7 @@ class HipEngine:
         """preconditions of the wave-specialised 1x1 GEMM (tile codes 17 / 18), mirrored from vs_conv_gemm"""
         return (bool(d.wt_split) and bool(d.wt_blk) and d.KH == 1 and d.KW == 1 and d.SH == 1 and d.SW == 1 and d.PH == 0 and d.PW == 0
                 and not d.in2 and d.Ho == d.H and d.Wo == d.W and d.Cin % 32 == 0 and d.CinP == d.Cin
-                and d.in_sy == d.W * d.in_sx and d.in_sb == d.H * d.in_sy and (not d.a_scale or d.H * d.W >= 128 or d.H * d.W == 64)
-                and (not d.a_scale or d.CinP <= 3072 * max(1, d.split_k)))      # the GRN rows of a K slice are staged in LDS (<= 3072 elements)
+                and d.in_sy == d.W * d.in_sx and d.in_sb == d.H * d.in_sy and (not d.a_scale or d.H * d.W >= 128 or d.H * d.W == 64))
 
     @staticmethod
     def _patch_pc_ok(d: "N.ConvDesc") -> bool:
@@ -1259,8 +1263,10 @@ class HipEngine:
                     kn = dict(kwa2)
                     # round 5: where 128-row x 128-column tiles would need K slices to occupy the CUs (stage 2: 64 x 3 tiles -> 2 slices + an
                     # epilogue launch that adds 25 MB of partial sums), 128 x 96 tiles give 64 x 4 workgroups with the whole K each: one launch
+                    # (tile 26 takes the whole K in one workgroup: its GRN rows must fit the kernel's LDS area, K <= 3072, whole K pairs)
                     if (self.pw2_narrow and self.use_split and a2 == 2 and ((cur.rows + 127) // 128) * ((Cc + 127) // 128) < 256
-                            and ((cur.rows + 127) // 128) * ((Cc + 95) // 96) >= 200 and Cc % 96 == 0 and HW >= 128):
+                            and ((cur.rows + 127) // 128) * ((Cc + 95) // 96) >= 200 and Cc % 96 == 0 and HW >= 128
+                            and hh.ld <= 3072 and hh.ld % 32 == 0 and hh.ld == 4 * Cc):
                         kn.update(tile_hint=N.CONV_TILE_HI | 10, split_k=1)
                     self.conv(hh, blk["pw2"], cur, res=cur, a_scale=scale, a_scale_ld=hh.ld, a_shift=blk["beta"], **kn)
                 else:     # odd feature maps (ChunkySeal: 31 x 31): GRN applied in place + plain GEMM measured faster (109 vs 105 frames/s)

@@ -415,7 +415,7 @@ class Wam(nn.Module):
 
     def _embed_frames_eager(self, eng: HipEngine, fr: torch.Tensor, msgs_i32: torch.Tensor, out: torch.Tensor, *, step: int,
                             video_mode: int, antialias: bool, lowres: bool, preds_w: Optional[torch.Tensor] = None,
-                            fwd_order: bool = False, tail_span: int = 0) -> None:
+                            fwd_order: bool = False, tail_span: int = 0, on_tail=None, tail_batch: int = 0) -> None:
         """tail_span > 0 (a multiple of `step`): `fr` is a GROUP of consecutive caller chunks of tail_span frames each.  The key frames of the
         whole group go through the U-Net as one batch (the matrix kernels want >= 32 key frames to fill 256 CUs), the watermark is then
         expanded chunk by chunk exactly as the per-chunk calls would do it (videoseal.py:303-344: the last key frame of a chunk has no
@@ -428,17 +428,31 @@ class Wam(nn.Module):
         kw = dict(step=step, video_mode=video_mode, attenuate=(2 if (att and fwd_order and not lowres) else int(att)), clamp=self.clamp,
                   antialias=antialias, scaling_i=self.blender.scaling_i, scaling_w=self.blender.scaling_w)
         F_ = fr.shape[0]
-        if tail_span <= 0 or tail_span >= F_ or video_mode == N.VIDEO_MODES["repeat"]:
-            # 'repeat' looks at one key frame per output frame: one launch over the group is the per-chunk launches
-            eng.embed_tail(fr, out, delta, hmap_low=hmap, preds_w=preds_w, **kw)
-            return
-        if tail_span % step:
+        # on_tail(a, b) (streaming.py): called on this stream's timeline every time another `tail_batch` watermarked frames [a, b) have been
+        # issued, so that the consumer (the extractor on a second stream) starts on the first frames of a group while the rest is still being
+        # blended.  The tail is a per-frame operation given (delta, hmap): cutting it at chunk boundaries does not change a value
+        cut = tail_batch if (on_tail is not None and tail_batch > 0) else 0
+        if tail_span > 0 and tail_span % step:
             raise ValueError("tail_span must be a multiple of the key-frame step")
+        if cut and cut % max(tail_span, step):
+            raise ValueError(f"tail_batch ({tail_batch}) must be a multiple of the chunk ({tail_span}) and of the key-frame step ({step})")
+        per_chunk = not (tail_span <= 0 or tail_span >= F_ or video_mode == N.VIDEO_MODES["repeat"])
+        # 'repeat' looks at one key frame per output frame: one launch over the group is the per-chunk launches
+        span = tail_span if per_chunk else (cut if cut else F_)
         hw = S[0] * S[1]
-        for a in range(0, F_, tail_span):
-            b = min(F_, a + tail_span)
-            eng.embed_tail(fr[a:b], out[a:b], delta[a // step:(b + step - 1) // step], hmap_low=(hmap[a * hw:b * hw] if hmap is not None else None),
-                           preds_w=(preds_w[a:b] if preds_w is not None else None), **kw)
+        done = 0
+        for a in range(0, F_, span):
+            b = min(F_, a + span)
+            if a == 0 and b == F_:
+                eng.embed_tail(fr, out, delta, hmap_low=hmap, preds_w=preds_w, **kw)
+            else:
+                eng.embed_tail(fr[a:b], out[a:b], delta[a // step:(b + step - 1) // step], hmap_low=(hmap[a * hw:b * hw] if hmap is not None else None),
+                               preds_w=(preds_w[a:b] if preds_w is not None else None), **kw)
+            if cut and (b - done >= cut or b == F_):
+                on_tail(done, b)
+                done = b
+        if on_tail is not None and not cut:
+            on_tail(0, F_)
 
     def _run_chunks(self, eng: HipEngine, imgs: torch.Tensor, span: int, fn, *, want_out: bool = True, extra=None):
         """Drive `fn(chunk_on_device, out_chunk_on_device, a, b)` over [a, b) frame ranges of `span` frames.  Frames that are not
@@ -632,7 +646,7 @@ class Videoseal(Wam):
 
     @torch.no_grad()
     def embed_group(self, frames: torch.Tensor, msgs: torch.Tensor, chunk: int, interpolation: dict = None,
-                    lowres_attenuation: bool = False) -> torch.Tensor:
+                    lowres_attenuation: bool = False, on_tail=None, tail_batch: int = 0) -> torch.Tensor:
         """`frames` (device-resident fp32 [F,3,H,W] or uint8 RGB24 [F,H,W,3]) = consecutive caller chunks of `chunk` frames (the last one may be
         short), `chunk` a multiple of step_size.  Returns what `torch.cat([embed(c, msgs, is_video=True)['imgs_w'] for c in chunks])` returns
         (embed_u8 for uint8), with the key frames of ALL chunks going through the U-Net as one batch: 16-frame streaming calls
@@ -660,8 +674,16 @@ class Videoseal(Wam):
         with torch.cuda.device(eng.dev):
             src = frames.contiguous() if u8 else N.f32c(frames)
             out = torch.empty_like(src)
+            if on_tail is not None and not self.use_graphs:
+                # (streaming.py) `on_tail(first, imgs_w[first:last])` as soon as another `tail_batch` watermarked frames are issued
+                self._embed_frames_eager(eng, src, self._msgs_dev(msgs, eng.dev), out, step=step, video_mode=N.VIDEO_MODES[self.video_mode],
+                                         antialias=aa, lowres=lowres_attenuation, tail_span=int(chunk), tail_batch=int(tail_batch),
+                                         on_tail=lambda a, b: on_tail(a, out[a:b]))
+                return out
             self._embed_frames(eng, src, self._msgs_dev(msgs, eng.dev), out, step=step, video_mode=N.VIDEO_MODES[self.video_mode], antialias=aa,
                                lowres=lowres_attenuation, tail_span=int(chunk))
+            if on_tail is not None:
+                on_tail(0, out)
         return out
 
     @torch.no_grad()

@@ -5,7 +5,8 @@ kernels cannot fill 256 CUs (the U-Net bottleneck conv runs at 0.19 of its ceili
   * the key frames of `group` consecutive chunks go through the U-Net as ONE batch (`Videoseal.embed_group`; default: enough chunks for
     32 key frames), the watermark is expanded chunk by chunk as the per-chunk calls would do it, and `sink` still sees chunk after chunk;
   * the extractor runs on >= 32 watermarked frames at a time, whatever the caller's chunk;
-  * detect(group i) is issued on a second HIP stream while embed(group i+1) runs on the first.
+  * detect(group i) is issued on a second HIP stream while embed(group i+1) runs on the first, and (round 6) starts on the first 32
+    watermarked frames of a group while the tail of the remaining frames is still being issued.
 
 `group=1` is exactly the sequence of per-chunk calls (bit-identical; the round-3 behaviour); larger groups differ from it only by the
 summation order of the dense layers, because whether K is split is a function of the batch shape (engine._split_k_rule*).
@@ -13,6 +14,7 @@ Stream safety: embedder and extractor use disjoint named workspace buffers, K-sp
 group is a fresh tensor (recorded on the consuming stream), and the extractor's logits are cloned on the detect stream."""
 from __future__ import annotations
 
+import os
 from typing import Callable, Optional, Tuple
 
 import torch
@@ -85,7 +87,26 @@ def embed_detect_chunks(model, frames: torch.Tensor, msgs: torch.Tensor, chunk: 
     s_emb, s_det = _streams(frames.device)
     s_emb.wait_stream(cur)
     s_det.wait_stream(cur)
+    db = int(det_batch or DET_BATCH)
+    # round 6: inside a group the extractor starts on the first `db` watermarked frames while the tail of the rest is still being issued
+    # (`embed_group(on_tail=...)`): a rank that holds ONE group (128 of the 1024 frames on 8 GPUs) has no "next embed" to hide detect under, so
+    # the only overlap it can have is inside the group.  Same U-Net batch, same extractor batches -> the logits are bit-identical to the
+    # whole-group hand-over (`fine=False`); VIDEOSEAL_STREAM_FINE=0 restores that
+    fine = (group > 1 and db % chunk == 0 and db % step == 0 and not getattr(model, "use_graphs", False)
+            and os.environ.get("VIDEOSEAL_STREAM_FINE", "1") != "0")
     for a in range(0, F_, span):
+        if fine:
+            def piece(first, wp):             # on the embed stream's timeline, right behind the tail launches of wp
+                ev = torch.cuda.Event()
+                ev.record(s_emb)
+                with torch.cuda.stream(s_det):
+                    s_det.wait_event(ev)
+                    wp.record_stream(s_det)
+                    logits.append(det(wp))
+            with torch.cuda.stream(s_emb):
+                w = model.embed_group(frames[a:a + span], msgs, chunk, lowres_attenuation=lowres_attenuation, on_tail=piece, tail_batch=db)
+                feed_sink(a, w)
+            continue
         with torch.cuda.stream(s_emb):
             w = emb(frames[a:a + span])
             feed_sink(a, w)
