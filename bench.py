@@ -28,7 +28,9 @@ import os
 import sys
 import time
 
-import torch
+T_PROCESS_START = time.time()      # (before `import torch`: the first import on a fresh box pages the image in)
+
+import torch  # noqa: E402
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
@@ -398,6 +400,7 @@ def _run(args, world, rank, dev, dist_on, n_ranks_seen):
         eng.shell_timers = []
         eng.prof_extractor = bool(args.detect_only)
     barrier()
+    t_ready = time.time()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         preds = step()
@@ -488,7 +491,14 @@ def _run(args, world, rank, dev, dist_on, n_ranks_seen):
 
     if roof is None and not args.no_kernel_timers:       # no bottleneck conv in this workload (detect only): whole-step fraction only
         roof = {"bound": "mfma", "kernel": None, "unit": "TFLOP/s", "peak": round(peak_split(eng) if eng.use_split else PEAK_F32_MFMA_TFLOPS, 1)}
-    allgather_ms = None
+    allgather_ms = host = None
+    if dist_on:          # host side of a rank (8 Python ranks per node: resident set and time from process start to the end of the warm-up), max over ranks
+        import resource
+        rss_gb = resource.getrusage(resource.RUSAGE_SELF).ru_maxrss / 1e6          # (Linux: kB)
+        hv = torch.tensor([rss_gb, t_ready - T_PROCESS_START], device=coll_device(dev), dtype=torch.float64)
+        torch.distributed.all_reduce(hv, op=torch.distributed.ReduceOp.MAX)
+        host = {"rss_gb_max_over_ranks": round(float(hv[0]), 2), "startup_s_max_over_ranks": round(float(hv[1]), 1),
+                "note": "per rank: peak resident set, seconds from process start to the first timed step (imports, random-init weights, packing, warm-up)"}
     if dist_on:          # the one collective of the path, timed on its own: RCCL all-gather of the [frames, 1 + nbits] logits
         n_tot = args.frames if stream else B * world
         loc = preds[f0:f1] if (stream and preds.shape[0] == n_tot) else preds[: (f1 - f0) if stream else B]
@@ -542,6 +552,7 @@ def _run(args, world, rank, dev, dist_on, n_ranks_seen):
         if allgather_ms is not None:
             line["allgather_ms"] = round(allgather_ms, 4)
             line["n_ranks_seen"] = n_ranks_seen
+            line["host"] = host
             line["collective"] = ("gloo over pinned host buffers (ranks may share a device: VS_BENCH_COLLECTIVE=gloo)"
                                   if torch.distributed.get_backend() == "gloo" else "RCCL all_gather_into_tensor")
             line["shards"] = ([list(shard_range(args.frames, r, world, 16)) for r in range(world)] if stream else [[r * B, (r + 1) * B] for r in range(world)])
@@ -638,7 +649,7 @@ def main():
                 return None
             roof = r.get("roofline") or {}
             return {"value": r["value"], "unit": r["unit"], "ms_per_step": r["ms_per_step"], "host_issue_ms_per_step": r.get("host_issue_ms_per_step"), "scaling": r["scaling"], "n_gpus": r["n_gpus"],
-                    "allgather_ms": r.get("allgather_ms"), "arith_used": r.get("arith_used"),
+                    "allgather_ms": r.get("allgather_ms"), "host": r.get("host"), "arith_used": r.get("arith_used"),
                     "workload": r["config"]["workload"], "model_tflops_per_s": r["model_tflops_per_s"],
                     "roofline": {k: roof.get(k) for k in ("kernel", "achieved", "peak", "unit", "frac", "avg_launch_ms", "e2e_frac") if k in roof},
                     "shell": roof.get("shell")}

@@ -353,7 +353,7 @@ def test_bench_refuses_more_gpus_than_the_node_has():
 
 # ---- two ranks SHARING one GPU through a host-side process group (VS_BENCH_COLLECTIVE=gloo): the multi-rank code path of bench.py and dist.py
 # ---- executed on the hardware the build has, before the driver's first 8-GPU run (RCCL refuses two ranks on one device)
-def _bench_two_ranks_one_gpu(extra, tmp_path, timeout=1500):
+def _bench_two_ranks_one_gpu(extra, tmp_path, timeout=1500, ranks=2):
     import socket
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
     env["VS_BENCH_COLLECTIVE"] = "gloo"
@@ -361,8 +361,8 @@ def _bench_two_ranks_one_gpu(extra, tmp_path, timeout=1500):
     with socket.socket() as sk:
         sk.bind(("127.0.0.1", 0))
         port = sk.getsockname()[1]
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1", "--master-port", str(port),
-           os.path.join(ROOT, "bench.py"), "--gpus", "2"] + extra
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={ranks}", "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.join(ROOT, "bench.py"), "--gpus", str(ranks)] + extra
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=timeout, cwd=ROOT)
     assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
@@ -407,3 +407,27 @@ def test_bench_default_legs_with_two_ranks_on_one_gpu(tmp_path):
     assert "error" not in st and st["n_gpus"] == 2 and st["scaling"] == "strong" and st["value"] > 0 and st["allgather_ms"] > 0
     assert "error" not in ck and ck["n_gpus"] == 2 and ck["value"] > 0
     assert not any(k.startswith(("video_step4", "chain", "train_step")) for k in legs)           # single-rank legs stay out of a multi-rank line
+
+
+@pytest.mark.gpu
+def test_bench_eight_ranks_on_one_gpu_preflight(tmp_path):
+    """the driver's 8-GPU command (`bench.py --gpus 8 --steps K --warmup W`, one rank per GPU under torch.distributed.run) with EIGHT Python ranks
+    on the one device the build has (gloo group, VS_BENCH_COLLECTIVE): all eight build the model, take the shards [[0, 128], ..., [896, 1024]] of the
+    1024-frame clip, gather, and exit with ONE line; the ChunkySeal leg builds 1.8 B random parameters in every rank.  The line carries the
+    host side of a rank (peak RSS, start-up seconds; max over ranks) -- recorded in DESIGN.md section 8.  (videoseal/utils/dist.py:210-213)"""
+    line = _bench_two_ranks_one_gpu(["--steps", "1", "--warmup", "1", "--no-kernel-timers"], tmp_path, timeout=2400, ranks=8)
+    assert line["n_gpus"] == 8 and line["n_ranks_seen"] == 8 and line["scaling"] == "weak"
+    assert line["shards"] == [[32 * r, 32 * r + 32] for r in range(8)] and line["allgather_ms"] > 0
+    st = [v for k, v in line["configs"].items() if k.startswith("stream_1024")][0]
+    ck = [v for k, v in line["configs"].items() if k.startswith("chunkyseal")][0]
+    assert "error" not in st and st["n_gpus"] == 8 and st["scaling"] == "strong" and st["value"] > 0
+    assert "error" not in ck and ck["n_gpus"] == 8 and ck["value"] > 0
+    host = line["host"]
+    print("8-rank preflight:", json.dumps({"host": host, "host_after_chunkyseal": ck.get("host"), "allgather_ms": line["allgather_ms"], "stream_allgather_ms": st["allgather_ms"],
+                                           "image_ms_per_step": line["ms_per_step"], "stream_ms_per_step": st["ms_per_step"]}))
+    assert host["rss_gb_max_over_ranks"] < 64 and host["startup_s_max_over_ranks"] < 900
+    assert ck["host"]["rss_gb_max_over_ranks"] < 64            # 8 ranks x (1.8 B random fp32 parameters + their packed images in flight)
+    out = os.environ.get("VS_PREFLIGHT_OUT")
+    if out:
+        with open(out, "w") as f:
+            json.dump(line, f)
