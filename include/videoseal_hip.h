@@ -44,7 +44,7 @@ extern "C" {
 #define VS_VIDEO_INTERPOLATE 2   /* videoseal.py:101-117 */
 
 /* library / device introspection */
-int vs_version(void);                       /* ABI version, currently 2 (round 2: vs_conv_desc_t / vs_model_cfg_t grew the arithmetic and planes fields) */
+int vs_version(void);                       /* ABI version, currently 3 (round 2: vs_conv_desc_t / vs_model_cfg_t grew the arithmetic and planes fields; round 6: grn_part / grn_gamma / grn_nchunk) */
 const char* vs_arch(void);                  /* "gfx950" */
 /* Development switch for tests / tools.  PROCESS-GLOBAL (one atomic per key: setting it is thread-safe, but a value set by one thread is seen
  * by the resize_pre / embed_tail launches of EVERY thread and stream -- e.g. the streaming overlap stream -- until it is reset; not a per-call
@@ -124,7 +124,11 @@ typedef struct vs_conv_desc {
   float a_mul;              /* arith = 2: power of two the activations (in and in2) are multiplied with before the f16 split       */
   float acc_mul;            /*   = 1 / (a_mul * w_mul): the accumulator of phase 1 is multiplied with it before bias / activation  */
   float acc_mul2;           /*   = 1 / (a_mul * w2_mul): the same for the products of the second phase (in2 x wt2)                 */
-  int32_t reserved_;
+  int32_t grn_nchunk;       /* ABI v3 (round 6), tile codes 17 / 18 / 26 with a_scale only: the GRN finish folded into the GEMM.  grn_part =   */
+  const float* grn_part;    /*   the ||h||^2 partials [B][grn_nchunk][CinP] a previous launch wrote through sumsq_part (grn_nchunk = H*W/32   */
+  const float* grn_gamma;   /*   <= 16), grn_gamma = GRN's gamma [CinP]: the kernel derives scale = 1 + gamma * Gx / (mean_c Gx + 1e-6) itself */
+                            /*   (bit-identical to vs_grn_scale_from_partials) and a_scale is NOT read -- it must still be a valid pointer;   */
+                            /*   every other tile code answers VS_ERR_UNSUPPORTED when grn_part is set                                        */
 } vs_conv_desc_t;
 #define VS_CONV_FORCE_F32 0x10
 #define VS_CONV_FORCE_SPLIT 0x20

@@ -196,6 +196,8 @@ class Eng(HipEngine):
         self.layer_arith = {}
         self.planes_chain = self.planes_splitk = self.msg0_planes = True
         self.planes_chain_ran = False
+        self.grn_fold = True
+        self._calib = None
 
 
 @pytest.fixture(scope="module", params=["split", "h2", "f32"])
@@ -1179,3 +1181,72 @@ def test_dwconv7_ln_ignores_and_preserves_what_surrounds_its_tensors(eng, C_, H,
     run(xg, og)
     assert torch.isfinite(og).all() and torch.equal(og, want)
     assert _guards_intact(obuf, -7.0) and _guards_intact(xbuf, float("nan"))
+
+
+@pytest.mark.parametrize("case", [
+    # B, H, W, K, N, tile, split_k                 (partials: K channels x H*W/32 <= 16 rows per frame)
+    (3, 16, 16, 1536, 384, 10, 1),                 # ConvNeXt stage-2 pwconv2 on tile 26: 8 partial rows, one frame per 128-row tile
+    (5, 8, 8, 3072, 768, 2, 4),                    # stage-3 pwconv2: two frames per tile, 4 K slices (every slice needs the mean over ALL channels)
+    (2, 8, 16, 768, 200, 1, 2),                    # 4 partial rows, ragged N
+    (2, 16, 32, 256, 96, 10, 1),                   # 16 partial rows (the cap): groups of four
+    (3, 8, 12, 384, 130, 1, 1),                    # 3 partial rows: kper = 1, an empty fourth group
+])
+def test_grn_finish_folded_into_the_gemm_equals_the_separate_launch(eng, case):
+    """ABI v3 (round 6): `grn_part / grn_gamma / grn_nchunk` make the wave-specialised 1x1 GEMM derive GRN's scale = 1 + gamma * Gx / (mean Gx + 1e-6)
+    (common.py:158-169) from pwconv1's ||h||^2 partials in its own prologue.  Against the path it replaces -- vs_grn_scale_from_partials, then the
+    same GEMM reading the scale rows -- the outputs are IDENTICAL bit for bit (same sums in the same order), and equal torch's GRN + linear."""
+    if not eng.use_split:
+        pytest.skip("split back-end only")
+    B, H, W, K, Nn, tl, sk = case
+    if tl == 10 and eng.arith != 2:
+        pytest.skip("tile 26 exists in the 2 x f16 arithmetic only")
+    HW = H * W
+    g = torch.Generator().manual_seed(sum(case))
+    h = torch.randn(B, HW, K, generator=g) * (0.5 + torch.rand(B, 1, K, generator=g))
+    gamma, beta = 0.5 * torch.randn(K, generator=g), 0.1 * torch.randn(K, generator=g)
+    w = torch.randn(Nn, K, generator=g) / math.sqrt(K)
+    bias, res = torch.randn(Nn, generator=g), torch.randn(B, HW, Nn, generator=g)
+    gx = h.double().pow(2).sum(1, keepdim=True).sqrt()
+    nx = gx / (gx.mean(-1, keepdim=True) + 1e-6)
+    ref = F.linear((gamma.double() * (h.double() * nx) + beta.double() + h.double()).float(), w, bias) + res
+    # partials as pwconv1's epilogue writes them: [B][HW / 32][K] sums of squares of 32-row groups
+    part = dv(h.pow(2).view(B, HW // 32, 32, K).sum(2))
+    ha = Act(dv(h), B, H, W, K, K)
+    wt, cp = pack_conv(w[:, :, None, None].to(DEV), K)
+    cw = ConvW(wt, dv(bias), Nn, 1, 1, cp)
+    ld = (Nn + 3) // 4 * 4
+    rr = Act(torch.zeros(B * HW * ld, device=DEV), B, H, W, Nn, ld)
+    rr.t.view(B, HW, ld)[..., :Nn] = res.to(DEV)
+    gm, bt = dv(gamma), dv(beta)
+    outs = []
+    for fold in (True, False):
+        eng.grn_fold = fold
+        scale = torch.full((B * K + 16,), float("nan"), device=DEV)          # never written in fold mode, never read either
+        ra = Act(torch.full((B * HW * ld,), float("nan"), device=DEV), B, H, W, Nn, ld)
+        try:
+            eng.conv(ha, cw, ra, res=rr, tile_hint=N.CONV_TILE_HI | tl, split_k=sk, a_scale=scale, a_scale_ld=K, a_shift=bt,
+                     grn_fold=(part, gm, B, HW, K))
+        finally:
+            eng.grn_fold = True
+        torch.cuda.synchronize()
+        assert torch.isnan(scale[:B * K]).all() == fold
+        full = ra.t.view(B, HW, ld).cpu()
+        assert rel_err(full[..., :Nn], ref) < 3e-5
+        outs.append(full)
+    assert torch.equal(outs[0], outs[1])
+    # every other tile code refuses the folded form instead of reading a scale nobody wrote
+    d_bad = Act(torch.zeros(B * HW * ld, device=DEV), B, H, W, Nn, ld)
+    with pytest.raises(N.NativeError):
+        eng.grn_fold = False
+        try:
+            import ctypes as C_
+            orig = eng.lib.vs_conv_gemm
+
+            def poke(dref, st):
+                dref._obj.grn_part, dref._obj.grn_gamma, dref._obj.grn_nchunk = N.ptr(part), N.ptr(gm), HW // 32
+                return orig(dref, st)
+            eng.lib.vs_conv_gemm = poke
+            eng.conv(ha, cw, d_bad, res=rr, tile_hint=1, a_scale=dv(torch.ones(B * K + 16)), a_scale_ld=K, a_shift=bt)
+        finally:
+            eng.lib.vs_conv_gemm = orig
+            eng.grn_fold = True

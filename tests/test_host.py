@@ -137,7 +137,7 @@ def test_c_abi_exports_every_declared_symbol():
     for sym in declared:
         assert hasattr(lib, sym), f"{sym} declared in include/videoseal_hip.h but not exported"
     assert sorted(native.EXPORTS) == declared
-    assert lib.vs_version() == 2 and lib.vs_arch() == b"gfx950"
+    assert lib.vs_version() == 3 and lib.vs_arch() == b"gfx950"
     assert b"bad argument" in lib.vs_error_string(-1)
     # argument validation happens on the host before any launch: null pointers are rejected without a GPU
     assert lib.vs_layernorm_act(None, 4, 8, 8, None, None, 1e-6, 0, None, 8, None) == -1

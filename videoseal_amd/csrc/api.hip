@@ -3,7 +3,7 @@
 
 #include "vs_common.h"
 
-extern "C" int vs_version(void) { return 2; }
+extern "C" int vs_version(void) { return 3; }
 extern "C" const char* vs_arch(void) { return "gfx950"; }
 extern "C" const char* vs_error_string(int code) {
   switch (code) {

@@ -502,6 +502,9 @@ extern "C" int vs_conv_gemm(const vs_conv_desc_t* dp, void* stream) {
     return VS_ERR_UNSUPPORTED;   // > 4 GiB operand: the caller chunks the batch
   hipStream_t st = (hipStream_t)stream;
   int tile = (d.tile_hint & 0xf) + ((d.tile_hint & VS_CONV_TILE_HI) ? 16 : 0);
+  // ABI v3: the GRN finish folded into the GEMM exists in the wave-specialised 1x1 kernel only; a_scale is not written by anybody in that
+  // mode, so every other route must refuse instead of reading it
+  if (d.grn_part && !(tile == 17 || tile == 18 || tile == 26)) return VS_ERR_UNSUPPORTED;
   const bool can_split0 = d.wt_split && (!d.in2 || d.wt2_split) && ((uintptr_t)d.wt_split & 15) == 0;
   // 3x3 / stride 1 / "same" convs on tile-aligned frames go to the patch kernel (input patch staged once per channel chunk)
   const bool patch_ok = can_split0 && d.KH == 3 && d.KW == 3 && d.SH == 1 && d.SW == 1 && d.PH == 1 && d.PW == 1 && d.Ho == d.H &&

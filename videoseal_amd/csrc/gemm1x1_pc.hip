@@ -49,6 +49,20 @@ template <int NP> constexpr int a_stage() { return NP * BM * ROWB; }     // NP 1
 // lane l: 16 bytes at gp -> lds_base + 16 * l, written out so that hipcc does not track it as a pending LDS write (convnext_fused.hip: it would put
 // s_waitcnt vmcnt(0) in front of the next fragment read); the waits for these transfers are counted by hand
 __device__ __forceinline__ void pc_dma16(const char* gp, unsigned char* lds_base) { vs_lds_dma16_untracked(gp, lds_base); }      // lds_dma.h
+// ((g0 + g1) + g2) + g3 over four groups of KPER consecutive chunk sums each, chunks added in ascending order inside a group: the association of
+// net_ops.hip::grn_finish_kernel (its four thread groups) for nch <= 16 chunks, kper = ceil(nch / 4) = KPER
+template <int KPER>
+__device__ __forceinline__ float grn_group_sums(const float (&v)[16], const int nch) {
+  float gs[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int kg = 0; kg < 4; ++kg)
+#pragma unroll
+    for (int q = 0; q < KPER; ++q) {
+      const int k = kg * KPER + q;
+      if (k < 16 && k < nch) gs[kg] += v[k < 16 ? k : 15];
+    }
+  return ((gs[0] + gs[1]) + gs[2]) + gs[3];
+}
 template <int NP> constexpr bool pc_bdma() { return VS_PC_BDMA && NP == 2; }
 template <int NP> constexpr int pc_bstages() { return pc_bdma<NP>() ? 4 : 2; }
 
@@ -134,7 +148,57 @@ __device__ __forceinline__ void gemm1x1_pc_tile(const vs_conv_desc_t& d, const i
     const char* const abase = reinterpret_cast<const char*>(d.in) + (int64_t)pair0 * 128;
     constexpr bool grn = GRN;
     const int kslice = npairs * 32;
-    if (grn) {
+    if (grn && d.grn_part) {
+      // Round 6: the GRN finish (net_ops.hip::grn_finish_kernel, one launch of ~8 us per block between pwconv1 and pwconv2) folded into this
+      // prologue.  d.grn_part = pwconv1's ||h||^2 partials [B][nchunk][K] (nchunk <= 16 chunks of 32 rows per frame): every workgroup reduces
+      // the chunks of ITS frame(s) for all K channels -- the channel mean of Gx needs them all --, keeps Gx of its K slice in the scale rows, and
+      // turns them into scale = 1 + gamma * Gx / (mean + 1e-6) (common.py:166-169).  Same sums in the same order as the kernel it replaces
+      // (per channel ((g0 + g1) + g2) + g3 over four groups of chunks; channels c = pt + 256 j ascending per thread; the 256 thread sums by the
+      // halving tree, here evaluated redundantly by every producer wave) -> the same scale values bit for bit.  48 KB of L2 reads per workgroup.
+      const int Kall = d.CinP, nch = d.grn_nchunk;
+      const int kper = (nch + 3) >> 2;
+      float* const Red = Sc + 3 * KC;                 // [2 frames][256 thread sums]
+      const int c_lo = pair0 * 32, c_hi = c_lo + kslice;
+#pragma unroll 1
+      for (int fi = 0; fi < 2; ++fi) {
+        const int f = fi ? f_hi : f_lo;
+        if (fi && f_hi == f_lo) break;
+        const float* pf = d.grn_part + (int64_t)f * nch * Kall;
+        float local = 0.f;
+#pragma unroll 2
+        for (int c = pt; c < Kall; c += 256) {
+          float v[16];
+#pragma unroll
+          for (int k = 0; k < 16; ++k) v[k] = pf[(int64_t)(k < nch ? k : nch - 1) * Kall + c];      // (chunks past nch: a valid address, value unused)
+          const float gsum = kper == 1 ? grn_group_sums<1>(v, nch) : kper == 2 ? grn_group_sums<2>(v, nch) : kper == 3 ? grn_group_sums<3>(v, nch)
+                                                                                                               : grn_group_sums<4>(v, nch);
+          const float gx = sqrtf(gsum);
+          local += gx;
+          if (c >= c_lo && c < c_hi) Sc[fi * kslice + c - c_lo] = gx;
+        }
+        Red[fi * 256 + pt] = local;
+      }
+      __syncthreads();                                // (matched by the consumers' extra cbar)
+      const float* ghp = d.a_shift + c_lo;
+      const float* gmp = d.grn_gamma + c_lo;
+      float mean[2];
+#pragma unroll
+      for (int fi = 0; fi < 2; ++fi) {
+        const float* rr = Red + (f_hi == f_lo ? 0 : fi * 256);
+        float a = (rr[lane] + rr[lane + 128]) + (rr[lane + 64] + rr[lane + 192]);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) a += __shfl_down(a, o, 64);
+        mean[fi] = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(a))) / (float)Kall;
+      }
+      for (int k = pt; k < kslice; k += 256) {
+        const float gm = gmp[k];
+        const float g0v = Sc[k], g1v = f_hi == f_lo ? g0v : Sc[kslice + k];
+        Sc[k] = 1.0f + gm * (g0v / (mean[0] + 1e-6f));
+        Sc[kslice + k] = 1.0f + gm * (g1v / (mean[1] + 1e-6f));
+        Sc[2 * kslice + k] = ghp[k];
+      }
+      __syncthreads();                                // (matched by the consumers' first cbar)
+    } else if (grn) {
       const float* g0p = d.a_scale + (int64_t)f_lo * d.a_scale_ld + pair0 * 32;
       const float* g1p = d.a_scale + (int64_t)f_hi * d.a_scale_ld + pair0 * 32;
       const float* ghp = d.a_shift + pair0 * 32;
@@ -337,7 +401,10 @@ __device__ __forceinline__ void gemm1x1_pc_tile(const vs_conv_desc_t& d, const i
     if (npairs_c > 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NBW) : "memory");      // pair 0 (transfers complete in order: at most pair 1's are left)
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   }
-  if constexpr (GRN) cbar();            // the producers' copy of the GRN scale rows to LDS
+  if constexpr (GRN) {
+    if (d.grn_part) cbar();             // the producers' Gx reduction (round 6: the GRN finish folded into this kernel)
+    cbar();                             // the producers' copy of the GRN scale rows to LDS
+  }
   cbar();
   load_frags(F0, 0);
   __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0), see conv3x3_patch_pc.hip
@@ -402,7 +469,7 @@ template <int TN, bool GRN, int NP, int WN = 2, int KC = GRN_KCAP>
 __global__ __launch_bounds__(512, 2) void gemm1x1_pc_kernel(const vs_conv_desc_t d, const int M, const int mtiles, const int ntiles,
                                                             const int pairs_per_split, const int ntot) {
   constexpr int B_STAGE = NP * (32 * TN * WN) * 32;
-  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * a_stage<NP>() + pc_bstages<NP>() * B_STAGE + (GRN ? 3 * KC * 4 : 0)];
+  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * a_stage<NP>() + pc_bstages<NP>() * B_STAGE + (GRN ? 3 * KC * 4 + 2 * 256 * 4 : 0)];
   for (int tile = blockIdx.x; tile < ntot; tile += gridDim.x) gemm1x1_pc_tile<TN, GRN, NP, WN, KC>(d, M, mtiles, ntiles, pairs_per_split, tile, smem);
 }
 
@@ -468,6 +535,7 @@ int launch_g(const vs_conv_desc_t& d, hipStream_t st) {
   if ((int64_t)(sk - 1) * pps >= pairs) return VS_ERR_BAD_ARG;           // an empty K slice
   if (d.a_scale && pps * 32 > GRN_KCAP) return VS_ERR_UNSUPPORTED;       // the GRN rows of a K slice are staged in LDS
   if (d.a_scale && (((uintptr_t)d.a_scale | (uintptr_t)d.a_shift) & 15 || (d.a_scale_ld & 3))) return VS_ERR_UNSUPPORTED;
+  if (d.grn_part && (!d.a_scale || !d.grn_gamma || d.grn_nchunk < 1 || d.grn_nchunk > 16 || d.grn_nchunk * 32 != d.H * d.W)) return VS_ERR_BAD_ARG;
   if (mt * nt * sk > 0x7fffffffLL || M > 0x7fffffffLL) return VS_ERR_UNSUPPORTED;
   // store_tile_full / store_tile_guarded address a tile with 32-bit byte offsets from its first element (conv_gemm.hip / gemm_pl.hip check the
   // same bound and keep a 64-bit path; this kernel has only the 32-bit one)

@@ -322,7 +322,8 @@ struct Runner {
   void conv(const Act& x, const CW& w, const Act& out, int stride = 1, int pad = 0, int pad_mode = VS_PAD_ZERO, int act_ = VS_ACT_NONE,
             int out_coff = 0, int n_store = -1, const Act* res = nullptr, const Act* in2 = nullptr, const CW* w2 = nullptr,
             const float* a_scale = nullptr, int64_t a_scale_ld = 0, const float* a_shift = nullptr, const int* geom = nullptr,
-            float* sumsq = nullptr, int cin_first = 0, bool pre_table = false, float a_mul_override = 0.f) {
+            float* sumsq = nullptr, int cin_first = 0, bool pre_table = false, float a_mul_override = 0.f,
+            const float* grn_part = nullptr, const float* grn_gamma = nullptr, int grn_hw = 0, int grn_c4 = 0) {
     vs_conv_desc_t d;
     std::memset(&d, 0, sizeof(d));
     int sh = stride, sw = stride, ph = pad, pw = pad, H = x.H, W = x.W, cin = x.ld;
@@ -381,6 +382,16 @@ struct Runner {
       d.splitk_ld = ws_ld;
       d.split_k = split_k;
       d.tile_hint = d.KH == 3 ? (d.N % 192 == 0 ? VS_CONV_TILE_HI | 0 : 15) : (VS_CONV_TILE_HI | (d.N % 192 == 0 ? 2 : 1));
+    }
+    if (grn_part) {
+      // engine.py::conv(grn_fold=...): GRN's finish inside the wave-specialised GEMM (ABI v3: explicit tile 17 / 18 / 26, <= 16 partial rows per frame,
+      // K == the partials' channel count) or as the separate launch in front of it; the same scale values either way
+      const int t = (d.tile_hint & 0xf) + ((d.tile_hint & VS_CONV_TILE_HI) ? 16 : 0);
+      if ((t == 17 || t == 18 || t == 26) && grn_hw % 32 == 0 && grn_hw / 32 <= 16 && d.CinP == grn_c4 && a_scale_ld == grn_c4) {
+        d.grn_part = grn_part; d.grn_gamma = grn_gamma; d.grn_nchunk = grn_hw / 32;
+      } else if (live()) {
+        chk(vs_grn_scale_from_partials(grn_part, d.B, grn_hw, grn_c4, grn_gamma, const_cast<float*>(a_scale), a_scale_ld, st));
+      }
     }
     if (live()) chk(vs_conv_gemm(&d, st));
   }
@@ -667,7 +678,8 @@ struct Runner {
         if (HW % 32 == 0) {
           if (pl1) gemm_pl(B, cur.H, cur.W, blk.pw1, tnpl, hh, VS_ACT_GELU, nullptr, part32, 1);
           else conv(tn, blk.pw1, hh, 1, 0, VS_PAD_ZERO, VS_ACT_GELU, 0, -1, nullptr, nullptr, nullptr, nullptr, 0, nullptr, nullptr, part32);
-          if (live()) chk(vs_grn_scale_from_partials(part32, B, HW, 4 * Cc, blk.gamma, scale, hh.ld, st));
+          // (the finish is deferred to pwconv2's conv() where that launch can fold it, engine.py)
+          if (!(HW % 64 == 0 && !pl2) && live()) chk(vs_grn_scale_from_partials(part32, B, HW, 4 * Cc, blk.gamma, scale, hh.ld, st));
         } else {
           if (pl1) gemm_pl(B, cur.H, cur.W, blk.pw1, tnpl, hh, VS_ACT_GELU, nullptr, nullptr, 1);
           else conv(tn, blk.pw1, hh, 1, 0, VS_PAD_ZERO, VS_ACT_GELU);
@@ -677,7 +689,9 @@ struct Runner {
           if (live()) chk(vs_to_planes_affine(hh.p, hh.rows(), hh.ld, hh.ld, A_MUL_GRN, scale, hh.ld, blk.beta, HW, hpl, st));
           gemm_pl(B, cur.H, cur.W, blk.pw2, hpl, cur, VS_ACT_NONE, &cur, nullptr, sk2, A_MUL_GRN);
         } else if (HW % 64 == 0) {
-          conv(hh, blk.pw2, cur, 1, 0, VS_PAD_ZERO, VS_ACT_NONE, 0, -1, &cur, nullptr, nullptr, scale, hh.ld, blk.beta);
+          const bool defer = HW % 32 == 0;
+          conv(hh, blk.pw2, cur, 1, 0, VS_PAD_ZERO, VS_ACT_NONE, 0, -1, &cur, nullptr, nullptr, scale, hh.ld, blk.beta, nullptr, nullptr, 0, false, 0.f,
+               defer ? part32 : nullptr, blk.gamma, HW, 4 * Cc);
         } else {
           if (live()) chk(vs_grn_apply(hh.p, B, HW, 4 * Cc, hh.ld, scale, hh.ld, blk.beta, st));
           conv(hh, blk.pw2, cur, 1, 0, VS_PAD_ZERO, VS_ACT_NONE, 0, -1, &cur, nullptr, nullptr, nullptr, 0, nullptr, nullptr, nullptr, 0, false, A_MUL_GRN);

@@ -286,6 +286,7 @@ class HipEngine:
         # the wave-specialised GEMM's producers set its K loop's pace (profiles/r05a / r05c); with their lanes all working in both half steps the
         # kernel alone is 49.9 us against 56.3 + 13 (tools/bench_gemm.py ksweep2) and detect of 32 frames 3.725 -> 3.651 ms (median of five
         # alternating runs, profiles/r05o_detect_pw2_tile26.json).  VIDEOSEAL_PW2_NARROW=0: the K-slice form
+        self.grn_fold = os.environ.get("VIDEOSEAL_GRN_FOLD", "1") != "0"                 # GRN finish inside the wave-specialised pwconv2 GEMM (round 6)
         self.pw2_narrow = os.environ.get("VIDEOSEAL_PW2_NARROW", "1") != "0"
         self.pw2_small_pc = os.environ.get("VIDEOSEAL_PW2_SMALL_PC", "1") != "0"        # stage-3 pwconv2 on the wave-specialised GEMM instead of planes (round 5)
         self.planes_gemm = os.environ.get("VIDEOSEAL_PLANES", "1") != "0"               # ConvNeXt 1x1 GEMMs on operand planes
@@ -510,6 +511,7 @@ class HipEngine:
              n_store=None, res: Optional[Act] = None, in2: Optional[Act] = None, w2: Optional[ConvW] = None,
              a_scale=None, a_scale_ld=0, a_shift=None, geom=None, tile_hint=0, prof: Optional[str] = None,
              split_k: Optional[int] = None, sumsq: Optional[torch.Tensor] = None, cin: Optional[int] = None, flops: Optional[float] = None,
+             grn_fold: Optional[tuple] = None,
              arith: Optional[int] = None, in_pl: Optional[torch.Tensor] = None, in2_pl: Optional[torch.Tensor] = None,
              out_pl: Optional[torch.Tensor] = None, a_mul: Optional[float] = None):
         """cin: read only the first `cin` channels of every pixel (pixel stride stays x.ld)"""
@@ -576,6 +578,17 @@ class HipEngine:
                 d.tile_hint = self._static_split_tile(d)
         if tile_hint == 0 and self.autotune:
             d.tile_hint = self._pick_tile(d, w, out)
+        if grn_fold is not None:
+            # grn_fold = (partials [B][HW/32][K] from pwconv1's epilogue, gamma, B, HW): GRN's finish (||h|| -> scale) either INSIDE this GEMM
+            # (round 6, csrc/gemm1x1_pc.hip: the launch is known to run on the wave-specialised kernel, tile codes 17 / 18 / 26, and a frame has
+            # <= 16 partial rows) or as the separate launch it always was.  Same scale values bit for bit either way
+            part, gamma, B_, HW_, C4 = grn_fold
+            pc_tile = (d.tile_hint & 0xf) + (16 if d.tile_hint & N.CONV_TILE_HI else 0)
+            if self.grn_fold and pc_tile in (17, 18, 26) and HW_ % 32 == 0 and HW_ // 32 <= 16 and w.CinP == a_scale_ld == C4:
+                d.grn_part, d.grn_gamma, d.grn_nchunk = N.ptr(part), N.ptr(gamma), HW_ // 32
+            else:
+                N.check(self.lib.vs_grn_scale_from_partials(N.ptr(part), B_, HW_, C4, N.ptr(gamma), N.ptr(a_scale), a_scale_ld, N.stream()),
+                        "vs_grn_scale_from_partials")
         if self.kernel_timers is not None and prof is None and self.time_all_convs:
             prof = f"conv{w.KH}x{w.KW} {x.C}->{w.N} @{out.H}x{out.W}" + ("+1x1" if in2 is not None else "")
         timed = prof is not None and self.kernel_timers is not None and not torch.cuda.is_current_stream_capturing()
@@ -1246,11 +1259,17 @@ class HipEngine:
                     kw1["prof"] = (f"{'gemm_pl_kernel' if bpl1 else 'gemm1x1_pc_kernel / conv_gemm_kernel'}: ConvNeXt stage-2 pwconv1 "
                                    f"{Cc}->{4 * Cc} @{cur.H}x{cur.W}")
                     kw1["flops"] = 2.0 * cur.rows * Cc * 4 * Cc      # algorithmic (unpadded) FLOPs
+                fold = None
                 if HW % 32 == 0:      # ||h||^2 partials come out of pwconv1's epilogue: no second pass over h
                     part32 = self.buf(f"st{sti}.gp32", B * (HW // 32) * 4 * Cc)
                     self.conv(tn, blk["pw1"], hh, act=N.ACT_GELU, sumsq=part32, **kw1)
-                    N.check(L.vs_grn_scale_from_partials(N.ptr(part32), B, HW, 4 * Cc, N.ptr(blk["gamma"]), N.ptr(scale), hh.ld, st),
-                            "vs_grn_scale_from_partials")
+                    # the finish (partials -> scale) is deferred to pwconv2's launch: conv(grn_fold=...) folds it into the wave-specialised GEMM's
+                    # prologue where that kernel runs (round 6: 12 launches fewer per extractor pass), and issues it as its own launch otherwise
+                    fold = (part32, blk["gamma"], B, HW, 4 * Cc)
+                    if not ((HW % 64 == 0 or not self.use_split) and not calib and not (pl2 and a2 == 2)):
+                        N.check(L.vs_grn_scale_from_partials(N.ptr(part32), B, HW, 4 * Cc, N.ptr(blk["gamma"]), N.ptr(scale), hh.ld, st),
+                                "vs_grn_scale_from_partials")
+                        fold = None
                 else:
                     self.conv(tn, blk["pw1"], hh, act=N.ACT_GELU, **kw1)
                     N.check(L.vs_grn_scale(N.ptr(hh.t), B, HW, 4 * Cc, hh.ld, N.ptr(blk["gamma"]), N.ptr(part), N.ptr(scale), st),
@@ -1268,7 +1287,7 @@ class HipEngine:
                             and ((cur.rows + 127) // 128) * ((Cc + 95) // 96) >= 200 and Cc % 96 == 0 and HW >= 128
                             and hh.ld <= 3072 and hh.ld % 32 == 0 and hh.ld == 4 * Cc):
                         kn.update(tile_hint=N.CONV_TILE_HI | 10, split_k=1)
-                    self.conv(hh, blk["pw2"], cur, res=cur, a_scale=scale, a_scale_ld=hh.ld, a_shift=blk["beta"], **kn)
+                    self.conv(hh, blk["pw2"], cur, res=cur, a_scale=scale, a_scale_ld=hh.ld, a_shift=blk["beta"], grn_fold=fold, **kn)
                 else:     # odd feature maps (ChunkySeal: 31 x 31): GRN applied in place + plain GEMM measured faster (109 vs 105 frames/s)
                           # than the GEMM with the fused transform, whose frame-boundary select costs registers; the calibration pass takes
                           # this form everywhere because it measures the operand h * scale + beta itself

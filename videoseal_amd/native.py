@@ -59,7 +59,7 @@ class ConvDesc(C.Structure):
         ("out", C.c_void_p), ("out_ld", C.c_int64), ("out_coff", C.c_int32), ("tile_hint", C.c_int32),
         ("wt_split", C.c_void_p), ("wt2_split", C.c_void_p), ("wt_blk", C.c_void_p), ("wt2_blk", C.c_void_p),
         ("splitk_ws", C.c_void_p), ("splitk_ld", C.c_int64), ("split_k", C.c_int32), ("arith", C.c_int32),
-        ("sumsq_part", C.c_void_p), ("in_pl", C.c_void_p), ("in2_pl", C.c_void_p), ("out_pl", C.c_void_p), ("a_mul", C.c_float), ("acc_mul", C.c_float), ("acc_mul2", C.c_float), ("reserved_", C.c_int32),
+        ("sumsq_part", C.c_void_p), ("in_pl", C.c_void_p), ("in2_pl", C.c_void_p), ("out_pl", C.c_void_p), ("a_mul", C.c_float), ("acc_mul", C.c_float), ("acc_mul2", C.c_float), ("grn_nchunk", C.c_int32), ("grn_part", C.c_void_p), ("grn_gamma", C.c_void_p),
     ]
 
 
@@ -230,8 +230,8 @@ def lib() -> C.CDLL:
         getattr(L, name).argtypes = args
     L.vs_sizeof_conv_desc.restype = C.c_int
     L.vs_sizeof_tail_desc.restype = C.c_int
-    if L.vs_version() != 2:
-        raise NativeError(f"{LIB_PATH} has ABI version {L.vs_version()}, this binding is written for 2: rebuild (make -C videoseal_amd/csrc)")
+    if L.vs_version() != 3:
+        raise NativeError(f"{LIB_PATH} has ABI version {L.vs_version()}, this binding is written for 3: rebuild (make -C videoseal_amd/csrc)")
     if L.vs_sizeof_conv_desc() != C.sizeof(ConvDesc) or L.vs_sizeof_tail_desc() != C.sizeof(TailDesc):
         raise NativeError("ctypes mirrors of vs_conv_desc_t / vs_tail_desc_t are out of date with the shared library")
     _lib = L
