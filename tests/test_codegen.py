@@ -80,9 +80,9 @@ def test_the_budget_itself_only_tolerates_known_spills():
 
 # epilogue-only spills of the TN = 3 tiles (96 accumulators + a batch of residual / bias values; none inside a K loop), round-5 values
 # (gemm1x1_pc: 101 / 96 -> 106 / 98 when the producers' lane mapping changed, 98 / 92 with the weights fetched by LDS-DMA from the consumer waves)
-# (round 6: the GRN variants carry the folded GRN finish in their prologue -- + 2 KiB of LDS for the two frames' thread sums, 98 -> 100 spilled registers
+# (round 6: the GRN variants carry the folded GRN finish in their prologue -- + 2 KiB of LDS for the two frames' thread sums, 98 -> 97 spilled registers
 # in the TN = 3 x 2 epilogue; the 128 x 96 tile that runs ConvNeXt stage 2 stays at 0)
-KNOWN_SPILLS = {"conv3x3_pl_kernel<3>": 32, "gemm_pl_kernel<3>": 67, "gemm1x1_pc_kernel<3, true, 2, 2, 1536>": 100, "gemm1x1_pc_kernel<3, true, 2, 2, 3072>": 100,
+KNOWN_SPILLS = {"conv3x3_pl_kernel<3>": 32, "gemm_pl_kernel<3>": 67, "gemm1x1_pc_kernel<3, true, 2, 2, 1536>": 97, "gemm1x1_pc_kernel<3, true, 2, 2, 3072>": 97,
                 "gemm1x1_pc_kernel<3, false, 2, 2, 3072>": 92, "conv3x3_patch_pc_kernel<3, 8, 2>": 90}
 
 

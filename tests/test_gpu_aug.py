@@ -32,6 +32,25 @@ def test_jpeg_is_bit_exact_with_pillow(hw, quality):
     assert torch.equal(got.cpu(), ref), "GPU JPEG differs from the Pillow/libjpeg round trip"
 
 
+@pytest.mark.parametrize("hw,quality", [((768, 768), 40), ((64, 96), 75), ((256, 512), 90)])
+def test_jpeg_vector_kernels_equal_the_scalar_ones(hw, quality):
+    """round 6: frames made of whole 16 x 16 MCUs take the 16-byte-access kernels (4 x 2 pixels per thread in the colour / down-sampling stage,
+    4 pixels per thread in the up-sampling / RGB stage, one launch for the blocks of all three components): the same bytes as the one-pixel-per-lane
+    kernels (development switch 3) -- and as Pillow (test above: 64 x 64, 256 x 256 and 768 x 768 run the vector form, the other sizes the scalar one)"""
+    x = synthetic_frames(3, hw[0], hw[1], seed=quality).cuda()
+    x[0, :, :7, :9] = 1.3
+    L = N.lib()
+    got, _ = G.JPEG()(x, None, quality)
+    L.vs_debug_set(3, 1)
+    try:
+        ref, _ = G.JPEG()(x, None, quality)
+        torch.cuda.synchronize()
+    finally:
+        L.vs_debug_set(3, 0)
+    assert torch.equal(got, ref)
+    assert torch.equal(got.cpu(), A.jpeg(x.cpu(), quality))
+
+
 @pytest.mark.parametrize("name,op,ref,vals", [
     ("brightness", G.Brightness, A.brightness, [0.1, 0.5, 1.5, 2.0]),
     ("contrast", G.Contrast, A.contrast, [0.1, 0.5, 1.5, 2.0]),

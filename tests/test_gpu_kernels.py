@@ -1025,7 +1025,10 @@ def test_resblock_thin_fused_kernel(arith, shape):
 
 
 @pytest.mark.parametrize("cfg", [(5, 333, 541, 96, 96, 1, 2), (3, 768, 768, 256, 256, 1, 1), (4, 200, 300, 128, 160, 0, 3), (2, 96, 80, 256, 256, 1, 1),
-                                 (3, 256, 256, 256, 256, 0, 1), (2, 700, 1100, 224, 352, 1, 4)])
+                                 (3, 256, 256, 256, 256, 0, 1), (2, 700, 1100, 224, 352, 1, 4),
+                                 # round 6: the 64-column tile of the streaming kernel (scales up to 4: BASELINE configs[4], 1024 -> 256), a 3.9 : 1 ragged
+                                 # shape, and widths that are multiples of four with window starts at every residue (16-byte row pieces)
+                                 (2, 1024, 1024, 256, 256, 1, 1), (2, 1000, 996, 256, 256, 1, 2), (3, 500, 600, 160, 192, 1, 1), (2, 772, 764, 250, 260, 1, 1)])
 def test_resize_pre_forms_are_bit_identical(cfg):
     """vs_resize_pre (wam.py:161-172 + the RGB -> Y / x*2-1 pre-processing): the row-streaming separable kernel (default: every input row fetched
     once per 128-column tile, filtered horizontally once) against the 32 x 8 tile kernel -- same expressions, same order, same bits; down- and
@@ -1189,7 +1192,7 @@ def test_dwconv7_ln_ignores_and_preserves_what_surrounds_its_tensors(eng, C_, H,
     (5, 8, 8, 3072, 768, 2, 4),                    # stage-3 pwconv2: two frames per tile, 4 K slices (every slice needs the mean over ALL channels)
     (2, 8, 16, 768, 200, 1, 2),                    # 4 partial rows, ragged N
     (2, 16, 32, 256, 96, 10, 1),                   # 16 partial rows (the cap): groups of four
-    (3, 8, 12, 384, 130, 1, 1),                    # 3 partial rows: kper = 1, an empty fourth group
+    (3, 8, 24, 384, 130, 1, 1),                    # 6 partial rows: kper = 2, an empty fourth group
 ])
 def test_grn_finish_folded_into_the_gemm_equals_the_separate_launch(eng, case):
     """ABI v3 (round 6): `grn_part / grn_gamma / grn_nchunk` make the wave-specialised 1x1 GEMM derive GRN's scale = 1 + gamma * Gx / (mean Gx + 1e-6)

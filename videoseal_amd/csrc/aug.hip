@@ -490,9 +490,18 @@ __device__ __forceinline__ void idct8(int* c, int stride, bool first) {
 struct QTab { unsigned char q[64]; };
 // stage 2: per 8x8 block: level shift, forward DCT, quantise, de-quantise, inverse DCT, range limit -- in place.
 // One thread per block (the whole block lives in registers / LDS-free private arrays with static indexing).
-__global__ __launch_bounds__(64) void jpeg_block_kernel(unsigned char* __restrict__ plane, int Wp, int bw, int64_t nblocks, QTab qt) {
-  const int64_t blk = (int64_t)blockIdx.x * 64 + threadIdx.x;
-  if (blk >= nblocks) return;
+// One launch covers the three components (round 6: three launches before): blocks [0, nby) are luma blocks of the plane at `Y`, [nby, nby + 2 nbc)
+// the blocks of the two chroma planes that follow it in the workspace (Cb, then Cr: each nbc blocks, row length Wp / 2).
+struct QTab2 { QTab l, c; };
+__global__ __launch_bounds__(64) void jpeg_block_kernel(unsigned char* __restrict__ Yp, unsigned char* __restrict__ Cbp, int Wp, int64_t nby,
+                                                        int64_t nbc, QTab2 q2) {
+  int64_t blk = (int64_t)blockIdx.x * 64 + threadIdx.x;
+  if (blk >= nby + 2 * nbc) return;
+  const bool luma = blk < nby;
+  unsigned char* plane = Yp;
+  if (!luma) { blk -= nby; plane = Cbp; Wp >>= 1; }           // (Cr follows Cb contiguously: block rows run on through both planes)
+  const QTab& qt = luma ? q2.l : q2.c;
+  const int bw = Wp / 8;
   const int64_t by = blk / bw;
   const int bx = (int)(blk - by * bw);
   unsigned char* p = plane + by * 8 * Wp + bx * 8;
@@ -563,6 +572,74 @@ __global__ __launch_bounds__(256) void jpeg_rgb_kernel(const unsigned char* __re
   d[o] = (float)min(max(R, 0), 255) / 255.0f;           // ToTensor: uint8 / 255
   d[plane + o] = (float)min(max(G, 0), 255) / 255.0f;
   d[2 * plane + o] = (float)min(max(B, 0), 255) / 255.0f;
+}
+
+// ---- round 6: the same three stages for frames that are whole MCUs (H % 16 == 0, W % 16 == 0: no edge replication anywhere) with 16-byte global
+// accesses.  The scalar kernels above moved one pixel per lane: byte stores of Y at a two-byte stride, 4-byte loads / stores of the fp32 planes -- the
+// round trip ran at 0.23 of 8 TB/s on the configs[2] clip.  Same integer expressions per pixel -> the same bytes (tests/test_gpu_aug.py: torch.equal
+// with Pillow / libjpeg and with the scalar kernels).
+// stage 1: thread = 4 x 2 pixels = 2 chroma samples: six float4 loads, two uint32 Y stores, one uint16 store per chroma plane
+__global__ __launch_bounds__(256) void jpeg_ycc4_kernel(const float* __restrict__ src, int H, int W, unsigned char* __restrict__ Y,
+                                                        unsigned char* __restrict__ Cb, unsigned char* __restrict__ Cr) {
+  const int i = blockIdx.x * 64 + (threadIdx.x & 63), j = blockIdx.y * 4 + (threadIdx.x >> 6);      // cell (4 px, 2 rows)
+  if (4 * i >= W || 2 * j >= H) return;
+  const int f = blockIdx.z;
+  const int64_t plane = (int64_t)H * W;
+  const float* s = src + (int64_t)f * 3 * plane + (int64_t)(2 * j) * W + 4 * i;
+  f32x4 px[2][3];
+#pragma unroll
+  for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+    for (int c = 0; c < 3; ++c) px[dy][c] = *reinterpret_cast<const f32x4*>(s + c * plane + (int64_t)dy * W);
+  unsigned yw[2] = {0u, 0u};
+  int sb[2] = {0, 0}, sr[2] = {0, 0};
+#pragma unroll
+  for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int R = px_u8(px[dy][0][e]), G = px_u8(px[dy][1][e]), B = px_u8(px[dy][2][e]);
+      yw[dy] |= (unsigned)((19595 * R + 38470 * G + 7471 * B + 32768) >> 16) << (8 * e);
+      sb[e >> 1] += (-11059 * R - 21709 * G + 32768 * B + (128 << 16) + 32767) >> 16;
+      sr[e >> 1] += (32768 * R - 27439 * G - 5329 * B + (128 << 16) + 32767) >> 16;
+    }
+  unsigned char* yp = Y + ((int64_t)f * H + 2 * j) * W + 4 * i;
+  *reinterpret_cast<unsigned*>(yp) = yw[0];
+  *reinterpret_cast<unsigned*>(yp + W) = yw[1];
+  // chroma samples cx = 2 i (bias 1) and 2 i + 1 (bias 2): the alternating rounding of h2v2_downsample
+  const int cw = W / 2;
+  const int64_t co = ((int64_t)f * (H / 2) + j) * cw + 2 * i;
+  *reinterpret_cast<unsigned short*>(Cb + co) = (unsigned short)(((sb[0] + 1) >> 2) | (((sb[1] + 2) >> 2) << 8));
+  *reinterpret_cast<unsigned short*>(Cr + co) = (unsigned short)(((sr[0] + 1) >> 2) | (((sr[1] + 2) >> 2) << 8));
+}
+
+// stage 3: thread = 4 pixels of a row: one uint32 of Y, the chroma bytes through chroma_up (the same function as the scalar kernel), three float4 stores
+__global__ __launch_bounds__(256) void jpeg_rgb4_kernel(const unsigned char* __restrict__ Y, const unsigned char* __restrict__ Cb,
+                                                        const unsigned char* __restrict__ Cr, int H, int W, float* __restrict__ dst) {
+  const int i = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
+  if (4 * i >= W || y >= H) return;
+  const int f = blockIdx.z;
+  const int cw = W / 2, ch = H / 2;
+  const unsigned yw = *reinterpret_cast<const unsigned*>(Y + ((int64_t)f * H + y) * W + 4 * i);
+  const unsigned char* cbp = Cb + (int64_t)f * ch * cw;
+  const unsigned char* crp = Cr + (int64_t)f * ch * cw;
+  f32x4 o[3];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const int x = 4 * i + e;
+    const int yv = (int)((yw >> (8 * e)) & 255u);
+    const int cb = chroma_up(cbp, cw, ch, cw, y, x) - 128;
+    const int cr = chroma_up(crp, cw, ch, cw, y, x) - 128;
+    const int R = yv + ((91881 * cr + 32768) >> 16);
+    const int B = yv + ((116130 * cb + 32768) >> 16);
+    const int G = yv + ((-22554 * cb + 32768 - 46802 * cr) >> 16);
+    o[0][e] = (float)min(max(R, 0), 255) / 255.0f;
+    o[1][e] = (float)min(max(G, 0), 255) / 255.0f;
+    o[2][e] = (float)min(max(B, 0), 255) / 255.0f;
+  }
+  const int64_t plane = (int64_t)H * W;
+  float* d = dst + (int64_t)f * 3 * plane + (int64_t)y * W + 4 * i;
+#pragma unroll
+  for (int c = 0; c < 3; ++c) *reinterpret_cast<f32x4*>(d + c * plane) = o[c];
 }
 
 const int BASE_L[64] = {16, 11, 10, 16, 24, 40, 51, 61, 12, 12, 14, 19, 26, 58, 60, 55, 14, 13, 16, 24, 40, 57, 69, 56, 14, 17, 22, 29, 51, 87, 80, 62,
@@ -777,14 +854,22 @@ extern "C" int vs_jpeg_roundtrip(const float* src, float* dst, int F, int H, int
   unsigned char* Y = (unsigned char*)workspace;
   unsigned char* Cb = Y + (int64_t)F * Hp * Wp;
   unsigned char* Cr = Cb + (int64_t)F * (Hp / 2) * (Wp / 2);
-  hipLaunchKernelGGL(jpeg_ycc_kernel, dim3((Wp / 2 + 31) / 32, (Hp / 2 + 7) / 8, F), dim3(256), 0, st, src, H, W, Hp, Wp, Y, Cb, Cr);
-  const QTab ql = make_qtab(BASE_L, quality), qc = make_qtab(BASE_C, quality);
-  // the frames are stacked vertically, so one launch per component covers every frame (block rows never straddle frames)
-  const int64_t nby = (int64_t)F * Hp / 8, nbc = (int64_t)F * (Hp / 2) / 8;
-  hipLaunchKernelGGL(jpeg_block_kernel, dim3((unsigned)cdiv64(nby * (Wp / 8), 64)), dim3(64), 0, st, Y, Wp, Wp / 8, nby * (Wp / 8), ql);
-  hipLaunchKernelGGL(jpeg_block_kernel, dim3((unsigned)cdiv64(nbc * (Wp / 16), 64)), dim3(64), 0, st, Cb, Wp / 2, Wp / 16, nbc * (Wp / 16), qc);
-  hipLaunchKernelGGL(jpeg_block_kernel, dim3((unsigned)cdiv64(nbc * (Wp / 16), 64)), dim3(64), 0, st, Cr, Wp / 2, Wp / 16, nbc * (Wp / 16), qc);
-  hipLaunchKernelGGL(jpeg_rgb_kernel, dim3((W + 31) / 32, (H + 7) / 8, F), dim3(256), 0, st, Y, Cb, Cr, H, W, Hp, Wp, dst);
+  // whole-MCU frames with 16-byte-aligned tensors take the vector kernels (same bytes); VIDEOSEAL_JPEG=scalar / vs_debug_set(3, 1) keep the scalar ones
+  static const bool env_scalar = [] { const char* e = getenv("VIDEOSEAL_JPEG"); return e && !strcmp(e, "scalar"); }();
+  const bool vec = !env_scalar && vs_debug_get(VS_DBG_JPEG_FORM) != 1 && H % 16 == 0 && W % 16 == 0 &&
+                   ((reinterpret_cast<uintptr_t>(src) | reinterpret_cast<uintptr_t>(dst) | reinterpret_cast<uintptr_t>(workspace)) & 15) == 0 &&
+                   ((int64_t)F * Hp * Wp) % 16 == 0;
+  if (vec) hipLaunchKernelGGL(jpeg_ycc4_kernel, dim3((W / 4 + 63) / 64, (H / 2 + 3) / 4, F), dim3(256), 0, st, src, H, W, Y, Cb, Cr);
+  else hipLaunchKernelGGL(jpeg_ycc_kernel, dim3((Wp / 2 + 31) / 32, (Hp / 2 + 7) / 8, F), dim3(256), 0, st, src, H, W, Hp, Wp, Y, Cb, Cr);
+  QTab2 q2;
+  q2.l = make_qtab(BASE_L, quality);
+  q2.c = make_qtab(BASE_C, quality);
+  // the frames are stacked vertically and Cr follows Cb, so ONE launch covers every block of every frame and component (block rows never straddle
+  // frames or planes)
+  const int64_t nby = ((int64_t)F * Hp / 8) * (Wp / 8), nbc = ((int64_t)F * (Hp / 2) / 8) * (Wp / 16);
+  hipLaunchKernelGGL(jpeg_block_kernel, dim3((unsigned)cdiv64(nby + 2 * nbc, 64)), dim3(64), 0, st, Y, Cb, Wp, nby, nbc, q2);
+  if (vec) hipLaunchKernelGGL(jpeg_rgb4_kernel, dim3((W / 4 + 63) / 64, (H + 3) / 4, F), dim3(256), 0, st, Y, Cb, Cr, H, W, dst);
+  else hipLaunchKernelGGL(jpeg_rgb_kernel, dim3((W + 31) / 32, (H + 7) / 8, F), dim3(256), 0, st, Y, Cb, Cr, H, W, Hp, Wp, dst);
   return vs_launch_status();
 }
 

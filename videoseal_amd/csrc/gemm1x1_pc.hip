@@ -50,18 +50,51 @@ template <int NP> constexpr int a_stage() { return NP * BM * ROWB; }     // NP 1
 // s_waitcnt vmcnt(0) in front of the next fragment read); the waits for these transfers are counted by hand
 __device__ __forceinline__ void pc_dma16(const char* gp, unsigned char* lds_base) { vs_lds_dma16_untracked(gp, lds_base); }      // lds_dma.h
 // ((g0 + g1) + g2) + g3 over four groups of KPER consecutive chunk sums each, chunks added in ascending order inside a group: the association of
-// net_ops.hip::grn_finish_kernel (its four thread groups) for nch <= 16 chunks, kper = ceil(nch / 4) = KPER
-template <int KPER>
-__device__ __forceinline__ float grn_group_sums(const float (&v)[16], const int nch) {
+// net_ops.hip::grn_finish_kernel (its four thread groups) for nch <= KMAX <= 16 chunks, kper = ceil(nch / 4) = KPER
+template <int KPER, int KMAX>
+__device__ __forceinline__ float grn_group_sums(const float (&v)[KMAX], const int nch) {
   float gs[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
   for (int kg = 0; kg < 4; ++kg)
 #pragma unroll
     for (int q = 0; q < KPER; ++q) {
+      constexpr int KL = KMAX - 1;
       const int k = kg * KPER + q;
-      if (k < 16 && k < nch) gs[kg] += v[k < 16 ? k : 15];
+      if (k < KMAX && k < nch) gs[kg] += v[k < KMAX ? k : KL];
     }
   return ((gs[0] + gs[1]) + gs[2]) + gs[3];
+}
+// Gx = sqrt(sum of the chunk sums) of the channels c = pt, pt + 256, ... of one frame: 48 / KMAX channels per batch, every load of a batch issued
+// before the first addition (one L2 / MALL round trip per batch: the partials were written by the previous launch on other XCDs).  Returns the
+// thread's sum of Gx (ascending channels); Gx of the K slice's channels go to `row`.
+template <int KMAX>
+__device__ __forceinline__ float grn_reduce_frame(const float* __restrict__ pf, const int nch, const int Kall, const int pt, const int c_lo,
+                                                  const int c_hi, float* __restrict__ row) {
+  constexpr int CB = 48 / KMAX;
+  const int kper = (nch + 3) >> 2;
+  float local = 0.f;
+#pragma unroll 1
+  for (int c0 = pt; c0 < Kall; c0 += 256 * CB) {
+    float v[CB][KMAX];
+#pragma unroll
+    for (int j = 0; j < CB; ++j) {
+      const int c = c0 + 256 * j, cc = c < Kall ? c : Kall - 1;
+#pragma unroll
+      for (int k = 0; k < KMAX; ++k) v[j][k] = pf[(int64_t)(k < nch ? k : nch - 1) * Kall + cc];      // (chunks past nch: a valid address, value unused)
+    }
+#pragma unroll
+    for (int j = 0; j < CB; ++j) {
+      const int c = c0 + 256 * j;
+      const float gsum = kper == 1 ? grn_group_sums<1, KMAX>(v[j], nch) : kper == 2 ? grn_group_sums<2, KMAX>(v[j], nch)
+                       : kper == 3 ? grn_group_sums<3, KMAX>(v[j], nch) : grn_group_sums<4, KMAX>(v[j], nch);
+      const float gx = sqrtf(gsum);
+      if (c < Kall) {
+        local += gx;
+        if (c >= c_lo && c < c_hi) row[c - c_lo] = gx;
+      }
+    }
+  }
+  return local;
 }
 template <int NP> constexpr bool pc_bdma() { return VS_PC_BDMA && NP == 2; }
 template <int NP> constexpr int pc_bstages() { return pc_bdma<NP>() ? 4 : 2; }
@@ -156,7 +189,6 @@ __device__ __forceinline__ void gemm1x1_pc_tile(const vs_conv_desc_t& d, const i
       // (per channel ((g0 + g1) + g2) + g3 over four groups of chunks; channels c = pt + 256 j ascending per thread; the 256 thread sums by the
       // halving tree, here evaluated redundantly by every producer wave) -> the same scale values bit for bit.  48 KB of L2 reads per workgroup.
       const int Kall = d.CinP, nch = d.grn_nchunk;
-      const int kper = (nch + 3) >> 2;
       float* const Red = Sc + 3 * KC;                 // [2 frames][256 thread sums]
       const int c_lo = pair0 * 32, c_hi = c_lo + kslice;
 #pragma unroll 1
@@ -164,19 +196,11 @@ __device__ __forceinline__ void gemm1x1_pc_tile(const vs_conv_desc_t& d, const i
         const int f = fi ? f_hi : f_lo;
         if (fi && f_hi == f_lo) break;
         const float* pf = d.grn_part + (int64_t)f * nch * Kall;
-        float local = 0.f;
-#pragma unroll 2
-        for (int c = pt; c < Kall; c += 256) {
-          float v[16];
-#pragma unroll
-          for (int k = 0; k < 16; ++k) v[k] = pf[(int64_t)(k < nch ? k : nch - 1) * Kall + c];      // (chunks past nch: a valid address, value unused)
-          const float gsum = kper == 1 ? grn_group_sums<1>(v, nch) : kper == 2 ? grn_group_sums<2>(v, nch) : kper == 3 ? grn_group_sums<3>(v, nch)
-                                                                                                               : grn_group_sums<4>(v, nch);
-          const float gx = sqrtf(gsum);
-          local += gx;
-          if (c >= c_lo && c < c_hi) Sc[fi * kslice + c - c_lo] = gx;
-        }
-        Red[fi * 256 + pt] = local;
+        float* row = Sc + fi * kslice;
+        Red[fi * 256 + pt] = nch <= 2 ? grn_reduce_frame<2>(pf, nch, Kall, pt, c_lo, c_hi, row)
+                           : nch <= 4 ? grn_reduce_frame<4>(pf, nch, Kall, pt, c_lo, c_hi, row)
+                           : nch <= 8 ? grn_reduce_frame<8>(pf, nch, Kall, pt, c_lo, c_hi, row)
+                                      : grn_reduce_frame<16>(pf, nch, Kall, pt, c_lo, c_hi, row);
       }
       __syncthreads();                                // (matched by the consumers' extra cbar)
       const float* ghp = d.a_shift + c_lo;
