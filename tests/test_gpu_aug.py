@@ -297,18 +297,30 @@ def test_fused_colour_chain_is_bit_identical_to_the_separate_ops(ops):
     (70, 66, (3, 2, 60, 60), (13, 17), True),                  # 4.6 x down: long taps
     (70, 66, (3, 2, 60, 60), (91, 77), False),                 # plain bilinear, up
     (40, 40, (30, 30, 10, 10), (64, 64), True),                # window at the corner
+    # round 6 (row-streaming form): frame widths that are multiples of four (16-byte row pieces) with crop columns at every residue, the window's
+    # right edge on the frame's, 3.3 x and 3.9 x down (the 128- and the 64-column tile), a strip taller than the weight table's 64 rows
+    (96, 128, (5, 7, 64, 100), (40, 60), True),
+    (96, 128, (1, 29, 95, 99), (120, 131), True),
+    (256, 512, (0, 2, 256, 510), (77, 154), True),
+    (400, 400, (3, 5, 390, 390), (100, 100), True),
+    (64, 1024, (0, 0, 64, 1024), (200, 300), False),
 ])
-def test_fused_crop_resize_colour_is_bit_identical_to_the_separate_launches(H, W, crop, size, aa):
+@pytest.mark.parametrize("form", ["stream", "tile"])
+def test_fused_crop_resize_colour_is_bit_identical_to_the_separate_launches(H, W, crop, size, aa, form):
     x = synthetic_frames(3, H, W, seed=H + W).cuda()
     ops = [("brightness", 0.5), ("saturation", 1.4), ("contrast", 1.5), ("hue", 0.1)]
-    for use_ops in ([], ops):
-        y = G.crop_flip(x, *crop) if crop is not None else x
-        ref = G.resize(y, size, aa)
-        for name, f in use_ops:
-            ref = G.color_op(ref, name, f)
-        got = G.crop_resize_color(x, crop, size, use_ops, antialias=aa)
-        torch.cuda.synchronize()
-        assert got.shape == ref.shape and torch.equal(got, ref), float((got - ref).abs().max())
+    N.lib().vs_debug_set(4, 1 if form == "tile" else 0)          # development switch 4: the 32 x 8 tile kernel instead of the row-streaming one
+    try:
+        for use_ops in ([], ops):
+            y = G.crop_flip(x, *crop) if crop is not None else x
+            ref = G.resize(y, size, aa)
+            for name, f in use_ops:
+                ref = G.color_op(ref, name, f)
+            got = G.crop_resize_color(x, crop, size, use_ops, antialias=aa)
+            torch.cuda.synchronize()
+            assert got.shape == ref.shape and torch.equal(got, ref), float((got - ref).abs().max())
+    finally:
+        N.lib().vs_debug_set(4, 0)
     # a window the LDS cannot hold (down-scaling by 12) takes the separate launches: same answer
     big = synthetic_frames(1, 256, 1300, seed=5).cuda()
     assert torch.equal(G.crop_resize_color(big, None, (20, 100), []), G.resize(big, (20, 100), True))

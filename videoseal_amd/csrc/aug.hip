@@ -9,6 +9,7 @@
 //                 lossless and skipped.  Pinned against Pillow in tests (oracle/jpeg_ref.py is the numpy restatement).
 #include "vs_common.h"
 #include "resize_taps.h"
+#include "resize_stream.h"
 
 namespace {
 
@@ -334,6 +335,27 @@ __global__ __launch_bounds__(256) void crop_resize_color_kernel(const float* __r
   for (int k = 0; k < cc.n; ++k) apply_color(cc.op[k], cc.factor[k], 0.f, v[0], v[1], v[2]);
   float* df = dst + (int64_t)f * 3 * oh * ow + (int64_t)oy * ow + ox;
   df[0] = v[0]; df[(int64_t)oh * ow] = v[1]; df[2 * (int64_t)oh * ow] = v[2];
+}
+
+// Round 6: the same fused pass on the row-streaming resize of resize_stream.h (the kernel `vs_resize_pre` runs on): a workgroup walks the source
+// rows of a strip once, filters every (source row, output column) pair once and applies the colour ops where the vertical sums complete.  The tile
+// kernel above spends its time on per-tile set-up and ~64 scalar LDS reads per pixel (0.18 of the HBM rate on the configs[2] clip); the streaming
+// form does 2.1 x fewer multiply-adds and reads the window with 16-byte loads.  Same taps in the same order -> the same bits
+// (tests/test_gpu_aug.py::test_sequential_fuses_the_validation_chain..., test_crop_resize_color_forms_are_bit_identical).
+struct CropResizeEpi {
+  float* dst; int oh, ow; ColorChain cc;
+  __device__ __forceinline__ void operator()(const int b, const int oy, const int ox, const float (&acc)[3]) const {
+    float v0 = acc[0], v1 = acc[1], v2 = acc[2];
+    for (int k = 0; k < cc.n; ++k) apply_color(cc.op[k], cc.factor[k], 0.f, v0, v1, v2);
+    float* df = dst + (int64_t)b * 3 * oh * ow + (int64_t)oy * ow + ox;
+    df[0] = v0; df[(int64_t)oh * ow] = v1; df[2 * (int64_t)oh * ow] = v2;
+  }
+};
+template <int OW>
+__global__ __launch_bounds__(256) void crop_resize_color_stream_kernel(const float* __restrict__ src, int H, int W, int i0, int j0, int ch, int cw,
+                                                                       int oh, int ow, int antialias, CropResizeEpi epi, int strip) {
+  extern __shared__ __attribute__((aligned(16))) float crs_smem[];
+  vs_rs::resize_stream_body<OW>(crs_smem, src, H, W, i0, j0, ch, cw, oh, ow, antialias, strip, epi);
 }
 
 // ------------------------------------------------------------------------------------------------ filters
@@ -777,6 +799,25 @@ extern "C" int vs_aug_crop_resize_color(const float* src, float* dst, int F, int
     VS_REQUIRE(ops[k] >= 0 && ops[k] <= 4 && ops[k] != OP_CONTRAST);
     cc.op[k] = ops[k];
     cc.factor[k] = factors[k];
+  }
+  // the row-streaming form where its windows fit (resize_stream.h); VIDEOSEAL_CROP_RESIZE=tile / vs_debug_set(4, 1) keep the 32 x 8 tile kernel
+  static const bool env_tile = [] { const char* e = getenv("VIDEOSEAL_CROP_RESIZE"); return e && !strcmp(e, "tile"); }();
+  const int OWsel = (env_tile || vs_debug_get(VS_DBG_CROP_RESIZE_FORM) == 1) ? 0 : vs_rs::rs_pick(ch, cw, oh, ow, antialias);
+  if (OWsel) {
+    const int cols = (ow + OWsel - 1) / OWsel;
+    int strip = 32;
+    for (int cand : {64, 48, 32, 24, 16})
+      if ((int64_t)cols * ((oh + cand - 1) / cand) * F >= 512) { strip = cand; break; }
+    const size_t lds_s = OWsel == 128 ? vs_rs::rs_lds_bytes<128>() : vs_rs::rs_lds_bytes<64>();
+    if ((int64_t)lds_s <= vs_max_lds_bytes()) {
+      dim3 gs(cols, (oh + strip - 1) / strip, F);
+      const CropResizeEpi epi{dst, oh, ow, cc};
+      if (OWsel == 128)
+        hipLaunchKernelGGL(crop_resize_color_stream_kernel<128>, gs, dim3(256), lds_s, (hipStream_t)stream, src, H, W, i0, j0, ch, cw, oh, ow, antialias, epi, strip);
+      else
+        hipLaunchKernelGGL(crop_resize_color_stream_kernel<64>, gs, dim3(256), lds_s, (hipStream_t)stream, src, H, W, i0, j0, ch, cw, oh, ow, antialias, epi, strip);
+      return vs_launch_status();
+    }
   }
   // bound of the tile's source window: (rows or columns of the tile - 1) * scale + 2 * support + 2 (integer rounding of lo / hi), + 1 of slack
   auto span = [&](int in, int out, int t) {

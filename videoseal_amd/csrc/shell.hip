@@ -5,6 +5,7 @@
 // These are the HBM-bound kernels (7.08 MB read + 7.08 MB written per 768x768 frame in the tail).
 #include "vs_common.h"
 #include "resize_taps.h"
+#include "resize_stream.h"
 
 namespace {
 
@@ -167,146 +168,33 @@ __global__ __launch_bounds__(256) void resize_pre_kernel(const T* __restrict__ s
 //   3. vertical pass: every output row whose tap window is complete is combined from the ring and stored (NHWC rgb / Y key frames).
 // The expressions and their order are those of the tile kernel (r += wx * pixel over the taps, then acc += wy * r): bit-identical outputs.
 // An input row is fetched once per 128-column tile (+ the strip's first window): ~1.15 x the frame.
-// Round 6: (1) the rows go global -> registers -> LDS as 16-byte vectors from a 16-byte-aligned window start (12 loads + 12 `ds_write_b128` per
-// thread and group instead of 48 + 48 scalar ones; frames whose width is not a multiple of four keep the scalar form); (2) the kernel is a template
-// over the tile: 128 output columns / <= 8 taps / 16 ring rows (scales up to 3.4: 768 -> 256) or 64 columns / <= 10 taps / 32 ring rows (scales up
-// to 4: 1024 -> 256, BASELINE configs[4] -- that shape had fallen back to the tile kernel at 0.6 TB/s).  Same expressions in the same order.
-constexpr int RS_GI = 8;                                 // input rows per group
-template <int OW_> struct RsGeo;
-template <> struct RsGeo<128> { static constexpr int INW = 448, MT = 8, RING = 16; };
-template <> struct RsGeo<64> { static constexpr int INW = 288, MT = 10, RING = 32; };
-
-template <int OW>
-__global__ __launch_bounds__(256) void resize_pre_stream_kernel(const float* __restrict__ src, int B, int H, int W, int oh, int ow, int antialias,
-                                                                float* __restrict__ dst_rgb, float mul, float add, float* __restrict__ dst_key,
-                                                                int key_step, int key_mode, float y0c, float y1c, float y2c, int strip) {
-  constexpr int INW = RsGeo<OW>::INW, MT = RsGeo<OW>::MT, RING = RsGeo<OW>::RING, NPART = 256 / OW, RPP = RS_GI / NPART;
-  extern __shared__ __attribute__((aligned(16))) float rs_smem[];
-  float* In = rs_smem;                                   // [RS_GI][3][INW]
-  float* Hr = rs_smem + RS_GI * 3 * INW;                 // [RING][3][OW]
-  const int ox0 = blockIdx.x * OW, oy0 = blockIdx.y * strip, b = blockIdx.z;
-  const int oy_end = min(oh, oy0 + strip);
-  const int64_t plane = (int64_t)H * W;
-  const float* base = src + (int64_t)b * 3 * plane;
-  const int tid = threadIdx.x;
-  const int oxl = tid & (OW - 1), part = tid / OW;
-  const int ox = min(ox0 + oxl, ow - 1);
-  const bool ox_ok = ox0 + oxl < ow;
-  // input window of the tile: columns [x_lo, x_lo + ww), rows [y_lo, y_end)
-  int x_lo, x_hi, n_;
-  tap_range(ox0, W, ow, antialias, x_lo, n_);
-  tap_range(min(ox0 + OW - 1, ow - 1), W, ow, antialias, x_hi, n_);
-  const bool vec = (W & 3) == 0 && (reinterpret_cast<uintptr_t>(src) & 15) == 0;       // block-uniform: 16-byte row pieces
-  const int xa = vec ? (x_lo & ~3) : x_lo;               // LDS column 0 <-> input column xa
-  const int ww = x_hi + n_ - xa;
-  const int nvec = (ww + 3) >> 2;                        // (ww <= INW - 3: checked by the launcher)
-  int y_lo, y_hi;
-  tap_range(oy0, H, oh, antialias, y_lo, n_);
-  tap_range(oy_end - 1, H, oh, antialias, y_hi, n_);
-  const int y_end = y_hi + n_;
-  const Taps tx = make_taps(ox, W, ow, antialias);
-  float wxs[MT];
-#pragma unroll
-  for (int jx = 0; jx < MT; ++jx) wxs[jx] = jx < tx.n ? tap_w(tx, jx) : 0.f;
-  const int xoff = tx.lo - xa;
-
-  // loads of one group: row-plane rp = 0 .. 23 (row = rp / 3, channel = rp % 3).  vec: thread (v = tid & 127, r2 = tid >> 7) owns the 16-byte
-  // piece v of the row-planes r2, r2 + 2, ...; scalar: elements tid and tid + 256 of every row-plane
-  const int vv = tid & 127, r2 = tid >> 7;
-  const int vcl = vv < nvec ? vv : nvec - 1;              // lanes past the window: a valid address, never stored
-  f32x4 prev[RS_GI * 3 / 2];
-  float pres[RS_GI * 3][2];
-  auto load_group = [&](const int r0) __attribute__((always_inline)) {
-    if (vec) {
-#pragma unroll
-      for (int k = 0; k < RS_GI * 3 / 2; ++k) {
-        const int rp = r2 + 2 * k;
-        const int row = r0 + rp / 3, c = rp % 3;
-        const int cy = row < y_end ? row : y_end - 1;                       // rows past the window: a valid address, never used
-        const float* p = base + c * plane + (int64_t)cy * W + xa;
-        // the last piece of the frame's last row may end behind the tensor when W - xa is not a multiple of 4: W % 4 == 0 and xa % 4 == 0
-        // make every piece of a row end inside the row
-        prev[k] = *reinterpret_cast<const f32x4*>(p + 4 * vcl);
-      }
-    } else {
-#pragma unroll
-      for (int rp = 0; rp < RS_GI * 3; ++rp) {
-        const int row = r0 + rp / 3, c = rp % 3;
-        const int cy = row < y_end ? row : y_end - 1;
-        const float* p = base + c * plane + (int64_t)cy * W + xa;
-        pres[rp][0] = p[tid < ww ? tid : ww - 1];
-        pres[rp][1] = p[tid + 256 < ww ? tid + 256 : ww - 1];
-      }
+// The row-streaming form lives in resize_stream.h (shared with aug.hip's Crop -> Resize -> colour kernel); this is its `resize_pre` epilogue:
+// NHWC(4) rgb * mul + add and / or the key frames' Y (or rgb) mapped to [-1, 1].
+struct ResizePreEpi {
+  float* dst_rgb; float* dst_key; float mul, add; int key_step, key_mode; float y0c, y1c, y2c; int oh, ow;
+  __device__ __forceinline__ void operator()(const int b, const int oy, const int ox, const float (&acc)[3]) const {
+    const int64_t opix = ((int64_t)oy * ow + ox);
+    if (dst_rgb) {
+      f32x4 v = {acc[0] * mul + add, acc[1] * mul + add, acc[2] * mul + add, 0.f};
+      *reinterpret_cast<f32x4*>(dst_rgb + ((int64_t)b * oh * ow + opix) * 4) = v;
     }
-  };
-  int oy_next = oy0 + part;                               // next output row this thread finalises (the thread parts take rows in turn)
-  load_group(y_lo);
-  for (int r0 = y_lo; r0 < y_end; r0 += RS_GI) {
-    if (vec) {
-      if (vv < nvec) {
-#pragma unroll
-        for (int k = 0; k < RS_GI * 3 / 2; ++k) *reinterpret_cast<f32x4*>(In + (r2 + 2 * k) * INW + 4 * vv) = prev[k];
+    if (dst_key && (b % key_step) == 0) {
+      f32x4 v;
+      if (key_mode == 0) {
+        const float y = y0c * acc[0] + y1c * acc[1] + y2c * acc[2];
+        v = f32x4{y * 2.f - 1.f, 0.f, 0.f, 0.f};
+      } else {
+        v = f32x4{acc[0] * 2.f - 1.f, acc[1] * 2.f - 1.f, acc[2] * 2.f - 1.f, 0.f};
       }
-    } else {
-#pragma unroll
-      for (int rp = 0; rp < RS_GI * 3; ++rp) {
-        if (tid < ww) In[rp * INW + tid] = pres[rp][0];
-        if (tid + 256 < ww) In[rp * INW + tid + 256] = pres[rp][1];
-      }
-    }
-    if (r0 + RS_GI < y_end) load_group(r0 + RS_GI);       // in flight during the two passes below
-    __syncthreads();
-    // horizontal pass: this thread's column, rows part * RPP .. + RPP - 1 of the group
-#pragma unroll
-    for (int q = 0; q < RPP; ++q) {
-      const int rl = part * RPP + q;
-      const int row = r0 + rl;
-      if (row < y_end) {
-        float r[3] = {0.f, 0.f, 0.f};
-        const float* Lp = In + rl * 3 * INW + xoff;
-#pragma unroll
-        for (int jx = 0; jx < MT; ++jx)
-          if (jx < tx.n) {
-#pragma unroll
-            for (int c = 0; c < 3; ++c) r[c] = __builtin_fmaf(wxs[jx], Lp[c * INW + jx], r[c]);
-          }
-#pragma unroll
-        for (int c = 0; c < 3; ++c) Hr[((row & (RING - 1)) * 3 + c) * OW + oxl] = r[c];
-      }
-    }
-    __syncthreads();
-    // vertical pass: output rows whose window ends inside the rows processed so far
-    const int done = min(r0 + RS_GI, y_end);
-    while (oy_next < oy_end) {
-      const Taps ty = make_taps(oy_next, H, oh, antialias);
-      if (ty.lo + ty.n > done) break;
-      float acc[3] = {0.f, 0.f, 0.f};
-      for (int jy = 0; jy < ty.n; ++jy) {
-        const float wy = tap_w(ty, jy);
-        const float* hp = Hr + (((ty.lo + jy) & (RING - 1)) * 3) * OW + oxl;
-#pragma unroll
-        for (int c = 0; c < 3; ++c) acc[c] = __builtin_fmaf(wy, hp[c * OW], acc[c]);
-      }
-      if (ox_ok) {
-        const int64_t opix = ((int64_t)oy_next * ow + ox);
-        if (dst_rgb) {
-          f32x4 v = {acc[0] * mul + add, acc[1] * mul + add, acc[2] * mul + add, 0.f};
-          *reinterpret_cast<f32x4*>(dst_rgb + ((int64_t)b * oh * ow + opix) * 4) = v;
-        }
-        if (dst_key && (b % key_step) == 0) {
-          f32x4 v;
-          if (key_mode == 0) {
-            const float y = y0c * acc[0] + y1c * acc[1] + y2c * acc[2];
-            v = f32x4{y * 2.f - 1.f, 0.f, 0.f, 0.f};
-          } else {
-            v = f32x4{acc[0] * 2.f - 1.f, acc[1] * 2.f - 1.f, acc[2] * 2.f - 1.f, 0.f};
-          }
-          *reinterpret_cast<f32x4*>(dst_key + ((int64_t)(b / key_step) * oh * ow + opix) * 4) = v;
-        }
-      }
-      oy_next += NPART;
+      *reinterpret_cast<f32x4*>(dst_key + ((int64_t)(b / key_step) * oh * ow + opix) * 4) = v;
     }
   }
+};
+template <int OW>
+__global__ __launch_bounds__(256) void resize_pre_stream_kernel(const float* __restrict__ src, int B, int H, int W, int oh, int ow, int antialias,
+                                                                ResizePreEpi epi, int strip) {
+  extern __shared__ __attribute__((aligned(16))) float rs_smem[];
+  vs_rs::resize_stream_body<OW>(rs_smem, src, H, W, 0, 0, H, W, oh, ow, antialias, strip, epi);
 }
 
 // ---- JND (jnd.py:63-108) on a luminance tile held in LDS --------------------------------------------------
@@ -974,14 +862,8 @@ extern "C" int vs_resize_pre(const float* src, int B, int C, int H, int W, int o
   static const bool env_tile = [] { const char* e = getenv("VIDEOSEAL_RESIZE"); return e && !strcmp(e, "tile"); }();       // process-wide default, read once
   const bool tile_only = env_tile || vs_debug_get(VS_DBG_RESIZE_FORM) == 1;
   static const int env_strip = [] { const char* e = getenv("VS_RESIZE_STRIP"); return e ? atoi(e) : 0; }();
-  const float sx = (float)W / (float)ow, sy = (float)H / (float)oh;
-  const float supx = antialias ? (sx >= 1.f ? sx : 1.f) : 1.f, supy = antialias ? (sy >= 1.f ? sy : 1.f) : 1.f;
-  // two tile shapes (RsGeo): 128 output columns for scales up to 3.4 (<= 8 taps), 64 columns for scales up to 4 (<= 10 taps, 1024 -> 256)
-  auto fits = [&](int OW, int INW, int MT, int RING) {
-    return 2.f * supx + 2.f <= (float)MT && 2.f * supy + 2.f <= (float)MT && (float)OW * sx + 2.f * supx + 4.f + 3.f <= (float)INW &&
-           2.f * supy + 2.f + (float)RS_GI <= (float)RING;
-  };
-  const int OWsel = fits(128, RsGeo<128>::INW, RsGeo<128>::MT, RsGeo<128>::RING) ? 128 : (fits(64, RsGeo<64>::INW, RsGeo<64>::MT, RsGeo<64>::RING) ? 64 : 0);
+  // two tile shapes (resize_stream.h): 128 output columns for scales up to 3.4 (<= 8 taps), 64 columns for scales up to 4 (<= 10 taps, 1024 -> 256)
+  const int OWsel = vs_rs::rs_pick(H, W, oh, ow, antialias);
   if (!tile_only && C == 3 && OWsel) {
     const int cols = (ow + OWsel - 1) / OWsel;
     int strip = 32;
@@ -990,15 +872,11 @@ extern "C" int vs_resize_pre(const float* src, int B, int C, int H, int W, int o
     if (env_strip >= 2) strip = env_strip;
     if (const int v = vs_debug_get(VS_DBG_RESIZE_STRIP); v >= 1) strip = v;       // tests: any strip height, per call
     dim3 gs(cols, (oh + strip - 1) / strip, B);
-    const int inw = OWsel == 128 ? RsGeo<128>::INW : RsGeo<64>::INW, ring = OWsel == 128 ? RsGeo<128>::RING : RsGeo<64>::RING;
-    const size_t lds = (size_t)(RS_GI * 3 * inw + ring * 3 * OWsel) * sizeof(float);
-    if ((int64_t)lds <= vs_max_lds_bytes()) {           // 66 KiB: beyond the 64 KiB of pre-gfx950 parts -> the tile kernel below
-      if (OWsel == 128)
-        hipLaunchKernelGGL(resize_pre_stream_kernel<128>, gs, dim3(256), lds, (hipStream_t)stream, src, B, H, W, oh, ow, antialias, dst_rgb, mul, add,
-                           dst_key, key_step < 1 ? 1 : key_step, key_mode, y0, y1, y2, strip);
-      else
-        hipLaunchKernelGGL(resize_pre_stream_kernel<64>, gs, dim3(256), lds, (hipStream_t)stream, src, B, H, W, oh, ow, antialias, dst_rgb, mul, add,
-                           dst_key, key_step < 1 ? 1 : key_step, key_mode, y0, y1, y2, strip);
+    const size_t lds = OWsel == 128 ? vs_rs::rs_lds_bytes<128>() : vs_rs::rs_lds_bytes<64>();
+    const ResizePreEpi epi{dst_rgb, dst_key, mul, add, key_step < 1 ? 1 : key_step, key_mode, y0, y1, y2, oh, ow};
+    if ((int64_t)lds <= vs_max_lds_bytes()) {           // 68 KiB: beyond the 64 KiB of pre-gfx950 parts -> the tile kernel below
+      if (OWsel == 128) hipLaunchKernelGGL(resize_pre_stream_kernel<128>, gs, dim3(256), lds, (hipStream_t)stream, src, B, H, W, oh, ow, antialias, epi, strip);
+      else hipLaunchKernelGGL(resize_pre_stream_kernel<64>, gs, dim3(256), lds, (hipStream_t)stream, src, B, H, W, oh, ow, antialias, epi, strip);
       return vs_launch_status();
     }
   }
