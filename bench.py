@@ -538,7 +538,7 @@ def _run(args, world, rank, dev, dist_on, n_ranks_seen):
                                    f"({'embedder on every frame' if not is_video else 'key frames every %d' % cfg.step_size}, "
                                    f"{'low-res' if args.lowres_attenuation else 'full-res'} JND), " + ("detect only" if args.detect_only else "embed + detect")
                                    + (", all-gather of bit logits" if dist_on else "")
-                                   + (f"; streaming: {args.frames}-frame clip in 16-frame chunks" + (", one embed + detect call per chunk" if (args.group == 1 or not args.overlap) else f", key frames of {args.group or 8} chunks per U-Net pass, extractor on 32 frames per pass, watermark expanded and handed on chunk by chunk") + ", low-res JND" + (", uint8 RGB24 in/out" if args.u8 else "") + (", detect overlapped with the next embed on a second stream" if args.overlap else "") if stream else "")
+                                   + (f"; streaming: {args.frames}-frame clip in 16-frame chunks" + (", one embed + detect call per chunk" if (args.group == 1 or not args.overlap) else f", key frames of {args.group or 8} chunks per U-Net pass, extractor on {args.det_batch or 128} frames per pass, watermark expanded and handed on chunk by chunk") + ", low-res JND" + (", uint8 RGB24 in/out" if args.u8 else "") + (", detect overlapped with the next embed on a second stream" if args.overlap else "") if stream else "")
                                    + (", chain JPEG(40) -> Crop(0.71) -> Resize(0.71) -> Brightness(0.5) -> Contrast(1.5) -> Saturation(1.5) -> Hue(0.1) between embed and detect (augmentation.Sequential: Crop + Resize + Brightness one kernel, Contrast + Saturation + Hue one pass)" if chain else "")
                                    + (", hipGraph replay" if args.graphs else ""),
                        "card": args.card, "weights": "random-init (seeded), no checkpoint offline", "batch_per_gpu": B,

@@ -49,7 +49,7 @@ const char* vs_arch(void);                  /* "gfx950" */
 /* Development switch for tests / tools.  PROCESS-GLOBAL (one atomic per key: setting it is thread-safe, but a value set by one thread is seen
  * by the resize_pre / embed_tail launches of EVERY thread and stream -- e.g. the streaming overlap stream -- until it is reset; not a per-call
  * option, not for production hosts).  Launch paths never call getenv.  key 0 = resize_pre form (1 = the 32 x 8 tile kernel), 1 = resize_pre
- * strip height in output rows, 2 = embed_tail strip height in rows, 3 = JPEG round-trip form (1 = the one-pixel-per-lane kernels), 4 = Crop -> Resize -> colour form (1 = the 32 x 8 tile kernel); value 0 = the
+ * strip height in output rows, 2 = embed_tail strip height in rows, 3 = JPEG round-trip form (1 = the one-pixel-per-lane kernels), 4 = Crop -> Resize -> colour form (1 = the 32 x 8 tile kernel), 5 = vs_to_planes_affine form (1 = one row per wave); value 0 = the
  * library's choice.  The environment default
  * VIDEOSEAL_RESIZE=tile is latched ONCE per process at the first launch: toggling the variable afterwards has no effect, use this call. */
 int vs_debug_set(int key, int value);
@@ -130,6 +130,9 @@ typedef struct vs_conv_desc {
   const float* grn_gamma;   /*   <= 16), grn_gamma = GRN's gamma [CinP]: the kernel derives scale = 1 + gamma * Gx / (mean_c Gx + 1e-6) itself */
                             /*   (bit-identical to vs_grn_scale_from_partials) and a_scale is NOT read -- it must still be a valid pointer;   */
                             /*   every other tile code answers VS_ERR_UNSUPPORTED when grn_part is set                                        */
+  int32_t sumsq_hw;         /* ABI v3, tile codes 24 / 25 with sumsq_part only: rows per frame when that is NOT a multiple of 32 (>= 32): sumsq_part */
+  int32_t reserved_;        /*   is then [ceil(M/32)][2][N] -- per 32-row group the sums of its rows in the frame of its first row | in the next      */
+                            /*   frame (vs_grn_scale_from_straddle_partials); 0 = the [M/32][N] form                                               */
 } vs_conv_desc_t;
 #define VS_CONV_FORCE_F32 0x10
 #define VS_CONV_FORCE_SPLIT 0x20
@@ -180,6 +183,10 @@ int vs_dwconv7_ln_planes(const float* x, int B, int H, int W, int C, int64_t ld,
  * over the activations. */
 int vs_grn_scale_from_partials(const float* partial, int B, int HW, int C, const float* gamma, float* scale, int64_t scale_ld,
                                void* stream);
+/* The same for frames whose HW (>= 32) is not a multiple of 32 (ChunkySeal's 31 x 31): `partial` is the [ceil(B*HW/32)][2][C] form a tile-24 / 25
+ * launch writes with vs_conv_desc_t::sumsq_hw = HW (per 32-row group: sums of its rows in the frame of its first row | in the next frame). */
+int vs_grn_scale_from_straddle_partials(const float* partial, int B, int HW, int C, const float* gamma, float* scale, int64_t scale_ld,
+                                        void* stream);
 /* GRN apply as a separate in-place pass: h = h * scale[b] + beta (common.py:168 minus the residual `+ x`, which the caller's
  * pwconv2 input convention already folds into scale = 1 + gamma*Nx).  beta must be readable up to the next multiple of 4. */
 int vs_grn_apply(float* h, int B, int HW, int C, int64_t ld, const float* scale, int64_t scale_ld, const float* beta, void* stream);

@@ -196,7 +196,7 @@ class Eng(HipEngine):
         self.layer_arith = {}
         self.planes_chain = self.planes_splitk = self.msg0_planes = True
         self.planes_chain_ran = False
-        self.grn_fold = True
+        self.grn_fold = self.grn_straddle = True
         self._calib = None
 
 
@@ -1253,3 +1253,85 @@ def test_grn_finish_folded_into_the_gemm_equals_the_separate_launch(eng, case):
         finally:
             eng.lib.vs_conv_gemm = orig
             eng.grn_fold = True
+
+
+@pytest.mark.parametrize("rows,C,ld,hw,grn", [(961 * 3, 5792, 5792, 961, True), (64, 128, 128, 32, True), (33, 16, 20, 33, False), (450, 1472, 1472, 225, True),
+                                               (1000, 144, 160, 250, True), (31, 48, 48, 31, True)])
+def test_to_planes_affine_forms_are_bit_identical(rows, C, ld, hw, grn):
+    """vs_to_planes_affine (GRN apply + f16 operand split of h in front of the planes pwconv2, gemm_pl.hip): the LDS-transposed kernel (round 6:
+    512-byte row pieces in, 1 KiB runs out) against the one-row-per-wave kernel (development switch 5) and against the split computed on the host:
+    ChunkySeal's stage-2 shape (31 x 31 frames, 5 792 channels = 45.25 channel tiles), ragged row tiles, channel strides above C, fewer than 32 rows"""
+    L = N.lib()
+    g = torch.Generator().manual_seed(rows + C)
+    x = torch.randn(rows, ld, generator=g) * 3
+    B = (rows + hw - 1) // hw
+    scale = (1 + 0.3 * torch.randn(B, C, generator=g)).contiguous()
+    shift = (0.1 * torch.randn(C, generator=g)).contiguous()
+    xd, sd, hd = dv(x), dv(scale), dv(shift)
+    outs = []
+    for form in (0, 1):
+        pl = torch.full((2 * rows * C,), 0x7777, dtype=torch.int16, device=DEV)
+        L.vs_debug_set(5, form)
+        try:
+            N.check(L.vs_to_planes_affine(N.ptr(xd), rows, C, ld, 1.0, N.ptr(sd) if grn else None, C, N.ptr(hd) if grn else None, hw, N.ptr(pl), N.stream()),
+                    "to_planes_affine")
+            torch.cuda.synchronize()
+        finally:
+            L.vs_debug_set(5, 0)
+        outs.append(pl.cpu())
+    assert torch.equal(outs[0], outs[1])
+    # planes [2][C / 16][rows][16]: hi = f16(v), lo = f16(v - hi) of v = x * scale[frame] + shift (fp32)
+    v = x[:, :C]
+    if grn:
+        v = torch.addcmul(shift[None], v, scale[torch.arange(rows) // hw])        # (one rounding of the product + sum or two: tolerance below)
+    hi = outs[0][:rows * C].view(torch.float16).view(C // 16, rows, 16).permute(1, 0, 2).reshape(rows, C).float()
+    lo = outs[0][rows * C:].view(torch.float16).view(C // 16, rows, 16).permute(1, 0, 2).reshape(rows, C).float()
+    assert ((hi + lo) - v).abs().max().item() <= 2e-6 * max(1.0, v.abs().max().item())
+
+
+@pytest.mark.parametrize("B,H,W,K,Nn", [(3, 15, 15, 160, 200), (2, 31, 31, 96, 200), (5, 7, 9, 64, 40), (16, 31, 31, 48, 724), (1, 6, 6, 32, 70)])
+def test_grn_statistics_from_straddling_row_groups(B, H, W, K, Nn):
+    """round 6 (ChunkySeal's 31 x 31 frames): `vs_conv_desc_t::sumsq_hw` makes the planes GEMM's epilogue write, per 32-row group, the sums of
+    squares of its rows in the frame of its first row | in the next frame ([rows/32][2][N]); vs_grn_scale_from_straddle_partials adds per frame the
+    slots that belong to it.  Against common.py:166-168 evaluated on the stored fp32 activations, and against vs_grn_scale (the separate pass over
+    h it replaces); the GEMM's output is untouched by the option; other tile codes refuse it."""
+    eng = Eng(arith=2)
+    HW = H * W
+    g = torch.Generator().manual_seed(B * HW + Nn)
+    x = torch.randn(B, HW, K, generator=g)
+    w = torch.randn(Nn, K, generator=g) / math.sqrt(K)
+    bias, gamma = torch.randn(Nn, generator=g), 0.5 * torch.randn(Nn, generator=g)
+    xa = Act(dv(x), B, H, W, K, K)
+    wt, cp = pack_conv(w[:, :, None, None].to(DEV), K)
+    cw = ConvW(wt, dv(bias), Nn, 1, 1, cp)
+    pl = torch.empty(B * HW * K * 2, dtype=torch.int16, device=DEV)
+    N.check(eng.lib.vs_to_planes(N.ptr(xa.t), xa.rows, K, xa.ld, 16.0, N.ptr(pl), N.stream()), "to_planes")
+    ld = (Nn + 3) // 4 * 4
+    outs = []
+    for straddle in (True, False):
+        out = Act(torch.full((B * HW * ld,), float("nan"), device=DEV), B, H, W, Nn, ld)
+        parts = torch.full((((B * HW + 31) // 32) * 2 * Nn,), float("nan"), device=DEV)
+        kw = dict(sumsq=parts, sumsq_hw=HW) if straddle else {}
+        eng.conv(xa, cw, out, act=N.ACT_GELU, tile_hint=N.CONV_TILE_HI | 8, in_pl=pl, a_mul=16.0, arith=2, **kw)
+        outs.append((out, parts))
+    torch.cuda.synchronize()
+    assert torch.equal(outs[0][0].t, outs[1][0].t)
+    h = outs[0][0].t.view(B, HW, ld)[..., :Nn]
+    gm = dv(gamma)
+    if HW >= 32:
+        scale = torch.full((B, ld), float("nan"), device=DEV)
+        N.check(eng.lib.vs_grn_scale_from_straddle_partials(N.ptr(outs[0][1]), B, HW, Nn, N.ptr(gm), N.ptr(scale), ld, N.stream()), "straddle finish")
+        scale2 = torch.full((B, ld), float("nan"), device=DEV)
+        part = torch.empty(((HW + 63) // 64) * B * Nn, device=DEV)
+        N.check(eng.lib.vs_grn_scale(N.ptr(outs[0][0].t), B, HW, Nn, ld, N.ptr(gm), N.ptr(part), N.ptr(scale2), N.stream()), "vs_grn_scale")
+        torch.cuda.synchronize()
+        gx = h.double().pow(2).sum(1).sqrt()
+        ref = 1 + gamma.double().to(DEV) * gx / (gx.mean(-1, keepdim=True) + 1e-6)
+        assert (scale[:, :Nn].double() - ref).abs().max().item() < 1e-5 * ref.abs().max().item()
+        assert (scale[:, :Nn] - scale2[:, :Nn]).abs().max().item() < 1e-5 * ref.abs().max().item()
+        assert (scale[:, Nn:] == 0).all()
+    else:      # frames shorter than a row group could straddle three frames: refused
+        with pytest.raises(N.NativeError):
+            N.check(eng.lib.vs_grn_scale_from_straddle_partials(N.ptr(outs[0][1]), B, HW, Nn, N.ptr(gm), N.ptr(outs[0][1]), ld, N.stream()), "HW < 32")
+    with pytest.raises(N.NativeError):      # the generic kernel has no such epilogue
+        eng.conv(xa, cw, outs[1][0], act=N.ACT_GELU, tile_hint=1, sumsq=outs[1][1], sumsq_hw=max(HW, 32), arith=2)

@@ -8,11 +8,17 @@ from videoseal_amd import native as N
 L = N.lib()
 B = 32
 print("VS_DWCONV =", os.environ.get("VS_DWCONV", "auto"))
-for HW, Cc in ((64, 96), (32, 192), (16, 384), (8, 768)):
+SHAPES = ((64, 96), (32, 192), (16, 384), (8, 768))
+if "chunky" in sys.argv:        # ChunkySeal's extractor, 16 frames: channel strides padded to 32 (engine._xld)
+    B = 16
+    SHAPES = ((127, 384), (63, 736), (31, 1472), (15, 2912))
+for HW, Cc in SHAPES:
     g = torch.Generator(device="cuda").manual_seed(HW)
     x = torch.randn(B, HW, HW, Cc, device="cuda", generator=g); out = torch.empty_like(x)
     wdw = torch.randn(49, Cc, device="cuda", generator=g); v = [torch.randn(Cc, device="cuda", generator=g) for _ in range(3)]
-    fn = lambda: N.check(L.vs_dwconv7_ln(N.ptr(x), B, HW, HW, Cc, Cc, N.ptr(wdw), N.ptr(v[0]), N.ptr(v[1]), N.ptr(v[2]), 1e-6, N.ptr(out), Cc, N.stream()), "dw")
+    fn = lambda: L.vs_dwconv7_ln(N.ptr(x), B, HW, HW, Cc, Cc, N.ptr(wdw), N.ptr(v[0]), N.ptr(v[1]), N.ptr(v[2]), 1e-6, N.ptr(out), Cc, N.stream())
+    if fn() != 0:
+        print(f'dwconv7_ln {HW}x{HW} C={Cc}: unsupported by this configuration'); continue
     for _ in range(3): fn()
     torch.cuda.synchronize()
     best = 1e9

@@ -232,4 +232,36 @@ __device__ __forceinline__ void write_sumsq(const f32x16 (&acc)[TM][TN], float* 
     }
 }
 
+// The same statistics for frames whose row count HW is NOT a multiple of 32 (ChunkySeal: 31 x 31 = 961): a 32-row group may then straddle two
+// frames (never three: HW >= 32), so every group writes TWO sums -- slot 0: its rows inside the frame f0 its first row lies in, slot 1: its rows in
+// frame f0 + 1.  part is [ceil(M / 32)][2][N]; vs_grn_scale_from_straddle_partials adds, per frame, the slots that belong to it in ascending
+// group order.  Round 6: replaces a separate pass over h (356 MB per ConvNeXt block at ChunkySeal's size, 6 % of its extractor pass).
+template <int TM, int TN>
+__device__ __forceinline__ void write_sumsq_straddle(const f32x16 (&acc)[TM][TN], float* part, const int N, const int64_t mrow0, const int M,
+                                                     const int (&col)[TN], const int g, const int HW) {
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+    const int64_t mg = mrow0 + i * 32;
+    const int64_t bnd = (mg / HW + 1) * HW;          // first row of the next frame
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int64_t m = mg + (e & 3) + 8 * (e >> 2) + 4 * g;
+        const float v = acc[i][j][e];
+        const float q = m < M ? v * v : 0.f;
+        s0 += m < bnd ? q : 0.f;
+        s1 += m < bnd ? 0.f : q;
+      }
+      s0 += __shfl_xor(s0, 32);
+      s1 += __shfl_xor(s1, 32);
+      if (g == 0 && col[j] < N && mg < M) {
+        part[((mg >> 5) * 2) * N + col[j]] = s0;
+        part[((mg >> 5) * 2 + 1) * N + col[j]] = s1;
+      }
+    }
+  }
+}
+
 }  // namespace vsconv

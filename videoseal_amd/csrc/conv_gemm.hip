@@ -466,6 +466,7 @@ static int gemm_planes(const vs_conv_desc_t& d, int tile, hipStream_t st) {
   VS_REQUIRE(d.n_store >= d.N && d.out_coff >= 0 && d.out_coff + d.n_store <= d.out_ld);
   if (d.res) VS_REQUIRE(d.res_ld >= d.N);
   if (d.sumsq_part) VS_REQUIRE(d.split_k <= 1 && !d.res);
+  if (d.sumsq_hw) VS_REQUIRE(d.sumsq_part && d.sumsq_hw >= 32 && d.sumsq_hw == d.H * d.W);      // straddling 32-row groups: [M/32][2][N] partials
   if (d.split_k > 1) VS_REQUIRE(d.splitk_ws && d.splitk_ld >= d.N && d.split_k <= d.CinP / BK);
   const int64_t M = (int64_t)d.B * d.H * d.W;
   if (2 * M * d.CinP * 2 >= 0xffffffffLL) return VS_ERR_UNSUPPORTED;          // 32-bit DMA offsets
@@ -505,6 +506,7 @@ extern "C" int vs_conv_gemm(const vs_conv_desc_t* dp, void* stream) {
   // ABI v3: the GRN finish folded into the GEMM exists in the wave-specialised 1x1 kernel only; a_scale is not written by anybody in that
   // mode, so every other route must refuse instead of reading it
   if (d.grn_part && !(tile == 17 || tile == 18 || tile == 26)) return VS_ERR_UNSUPPORTED;
+  if (d.sumsq_hw && !(tile == 24 || tile == 25)) return VS_ERR_UNSUPPORTED;                      // (the [M/32][2][N] partials exist in gemm_pl.hip only)
   const bool can_split0 = d.wt_split && (!d.in2 || d.wt2_split) && ((uintptr_t)d.wt_split & 15) == 0;
   // 3x3 / stride 1 / "same" convs on tile-aligned frames go to the patch kernel (input patch staged once per channel chunk)
   const bool patch_ok = can_split0 && d.KH == 3 && d.KW == 3 && d.SH == 1 && d.SW == 1 && d.PH == 1 && d.PW == 1 && d.Ho == d.H &&

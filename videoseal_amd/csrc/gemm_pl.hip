@@ -285,7 +285,10 @@ __global__ __launch_bounds__(512, 2) void gemm_pl_kernel(const vs_conv_desc_t d,
   }
   const int abl = VS_KERNEL_ABL(d);           // ablation build only (tools/bench_gemm.py ksweep2): 64 no activation, 32 no output stores
   if (!(abl & 64)) apply_act_all<TM, TN>(acc, bias1, zero, d.act);
-  if (d.sumsq_part) write_sumsq<TM, TN>(acc, d.sumsq_part, d.N, (int64_t)m0 + (int64_t)wm * TM * 32, M, col, g_e);
+  if (d.sumsq_part) {
+    if (d.sumsq_hw > 0) write_sumsq_straddle<TM, TN>(acc, d.sumsq_part, d.N, (int64_t)m0 + (int64_t)wm * TM * 32, M, col, g_e, d.sumsq_hw);
+    else write_sumsq<TM, TN>(acc, d.sumsq_part, d.N, (int64_t)m0 + (int64_t)wm * TM * 32, M, col, g_e);
+  }
   if (abl & 32) return;
   const bool whole = m0 + GBM <= M && n0 + BN <= d.N && (int64_t)GBM * max(d.out_ld, d.res_ld) * 4 < (1LL << 31);
   if (whole) {       // every layer of the shipped cards: store_tile_full (conv_common.h)
@@ -342,6 +345,61 @@ __global__ __launch_bounds__(256) void to_planes_affine_kernel(const float* __re
   *reinterpret_cast<u32x4*>(dst + (int64_t)(C / 16) * rows * 32) = u32x4{al[0], al[1], bl[0], bl[1]};
 }
 
+// Round 6: the same conversion through an LDS transpose.  The kernel above maps a wave onto 64 consecutive 8-channel pieces of ONE row: its reads are
+// 2 KiB of contiguous row memory, but its writes are 32-byte pieces rows * 32 bytes apart (one piece per 16-channel chunk) -- a quarter of a cache
+// line each; on ChunkySeal's h tensors (15 376 x 5 792: 356 MB in, 356 MB out, 33 launches per extractor pass) it ran at 2.5 TB/s, 10.5 % of the
+// step.  Here a workgroup owns 32 rows x 128 channels: 512-byte row pieces in, the split planes staged in LDS as [plane][chunk][row][32 B], and
+// every (plane, chunk) goes out as ONE contiguous 1 KiB run (32 rows x 32 bytes).  Same expression per element -> the same bits.
+__global__ __launch_bounds__(256) void to_planes_affine_tiled_kernel(const float* __restrict__ x, const int64_t rows, const int C, const int64_t ld,
+                                                                     const float a_mul, const float* __restrict__ scale, const int64_t scale_ld,
+                                                                     const float* __restrict__ shift, const int rows_per_frame,
+                                                                     char* __restrict__ pl) {
+  __shared__ __attribute__((aligned(16))) unsigned char stage[2 * 8 * 32 * 32];      // 16 KiB
+  const int64_t row0 = (int64_t)blockIdx.x * 32;
+  const int c0 = blockIdx.y * 128;
+  const int t = threadIdx.x;
+  const int c4 = t & 31, rl = t >> 5;                      // float4 column of the tile, row lane (rows rl + 8 j)
+  const int c = c0 + 4 * c4;
+  const bool c_ok = c < C;                                 // (C % 16 == 0: a float4 is inside or outside as a whole)
+  f32x4 v[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int64_t row = row0 + rl + 8 * j;
+    const int64_t rr = row < rows ? row : rows - 1;        // ragged last tile: a valid row, never written
+    v[j] = *reinterpret_cast<const f32x4*>(x + rr * ld + (c_ok ? c : 0));
+  }
+  if (scale) {
+    const f32x4 h4 = *reinterpret_cast<const f32x4*>(shift + (c_ok ? c : 0));
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int64_t row = row0 + rl + 8 * j;
+      const int64_t rr = row < rows ? row : rows - 1;
+      const f32x4 s4 = *reinterpret_cast<const f32x4*>(scale + (rr / rows_per_frame) * scale_ld + (c_ok ? c : 0));
+      v[j] = v[j] * s4 + h4;
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    u32x2 hi, lo;
+    split4h(v[j], a_mul, hi, lo);
+    const int off = (((c4 >> 2) * 32) + rl + 8 * j) * 32 + (c4 & 3) * 8;
+    *reinterpret_cast<u32x2*>(stage + off) = hi;
+    *reinterpret_cast<u32x2*>(stage + 8 * 32 * 32 + off) = lo;
+  }
+  __syncthreads();
+  const int nrow = (int)(rows - row0 < 32 ? rows - row0 : 32);
+  const int64_t pstride = (int64_t)(C / 16) * rows * 32;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int seg = (t >> 6) + 4 * j;                      // (plane, chunk of the tile): 1 KiB = 64 lanes x 16 bytes
+    const int plane = seg >> 3, ch = seg & 7;
+    const int chunk = (c0 >> 4) + ch;
+    const int o = (t & 63) * 16;
+    if (chunk * 16 < C && o < nrow * 32)
+      *reinterpret_cast<u32x4*>(pl + plane * pstride + ((int64_t)chunk * rows + row0) * 32 + o) = *reinterpret_cast<const u32x4*>(stage + seg * 1024 + o);
+  }
+}
+
 template <int TN>
 int launch_gpl(const vs_conv_desc_t& d, hipStream_t st) {
   constexpr int BN = 2 * TN * 32;
@@ -378,6 +436,12 @@ extern "C" int vs_to_planes_affine(const float* x, int64_t rows, int C, int64_t 
   VS_REQUIRE(x && planes && rows > 0 && C > 0 && C % 16 == 0 && ld >= C && ld % 4 == 0 && a_mul > 0.f);
   VS_REQUIRE(((uintptr_t)x & 15) == 0 && ((uintptr_t)planes & 15) == 0);
   if (scale) VS_REQUIRE(shift && rows_per_frame > 0 && scale_ld % 4 == 0 && ((uintptr_t)scale & 15) == 0 && ((uintptr_t)shift & 15) == 0);
+  // the LDS-transposed form for tensors of at least a few tiles (development switch 5 = 1 keeps the one-row-per-wave kernel)
+  if (rows >= 32 && vs_debug_get(VS_DBG_TO_PLANES_FORM) != 1 && cdiv64(rows, 32) <= 0x7fffffffLL && (C + 127) / 128 <= 65535) {
+    hipLaunchKernelGGL(to_planes_affine_tiled_kernel, dim3((unsigned)cdiv64(rows, 32), (unsigned)((C + 127) / 128)), dim3(256), 0, (hipStream_t)stream,
+                       x, rows, C, ld, a_mul, scale, scale_ld, shift, rows_per_frame, static_cast<char*>(planes));
+    return vs_launch_status();
+  }
   const int64_t items = rows * (C / 8);
   hipLaunchKernelGGL(to_planes_affine_kernel, dim3((unsigned)cdiv64(items, 256)), dim3(256), 0, (hipStream_t)stream, x, rows, C, ld, a_mul,
                      scale, scale_ld, shift, rows_per_frame, static_cast<char*>(planes));

@@ -422,7 +422,7 @@ struct Runner {
   }
   // 1x1 GEMM on operand planes (tile code 24, gemm_pl.hip): out = act(in_pl x w + bias) (+ res), optional GRN partials / K split
   void gemm_pl(int B, int H, int W, const CW& w, const void* in_pl, const Act& out, int act_, const Act* res, float* sumsq, int split_k,
-               float am = A_MUL) {
+               float am = A_MUL, int sumsq_hw = 0) {
     vs_conv_desc_t d;
     std::memset(&d, 0, sizeof(d));
     d.B = B; d.H = H; d.W = W; d.Cin = w.CinP; d.KH = d.KW = 1; d.SH = d.SW = 1; d.Ho = H; d.Wo = W;
@@ -432,6 +432,7 @@ struct Runner {
     d.out = out.p; d.out_ld = out.ld; d.n_store = out.ld;
     if (res) { d.res = res->p; d.res_ld = res->ld; }
     d.sumsq_part = sumsq;
+    d.sumsq_hw = sumsq_hw;
     if (split_k > 1) {
       const int ws_ld = rup(w.N, 4);
       d.splitk_ws = alloc((int64_t)split_k * out.rows() * ws_ld);
@@ -636,6 +637,7 @@ struct Runner {
       float* part = alloc((int64_t)((HW + 63) / 64) * B * 4 * Cc);
       float* part32 = alloc((int64_t)B * ((HW + 31) / 32) * 4 * Cc);
       float* scale = alloc((int64_t)B * hh.ld + 16);
+      float* parts = (HW % 32 != 0 && HW >= 32) ? alloc((((int64_t)B * HW + 31) / 32) * 2 * 4 * Cc) : nullptr;
       // engine.py::extractor_forward: the GEMMs on operand planes where the 256-row tiles fill the chip (pwconv1), resp. for long K (pwconv2)
       const int64_t rows = cur.rows();
       const CW& pw1w = m->stages[sti].empty() ? m->stem : m->stages[sti][0].pw1;
@@ -680,6 +682,9 @@ struct Runner {
           else conv(tn, blk.pw1, hh, 1, 0, VS_PAD_ZERO, VS_ACT_GELU, 0, -1, nullptr, nullptr, nullptr, nullptr, 0, nullptr, nullptr, part32);
           // (the finish is deferred to pwconv2's conv() where that launch can fold it, engine.py)
           if (!(HW % 64 == 0 && !pl2) && live()) chk(vs_grn_scale_from_partials(part32, B, HW, 4 * Cc, blk.gamma, scale, hh.ld, st));
+        } else if (pl1 && HW >= 32) {      // engine.py (round 6): straddling 32-row-group partials from the planes GEMM's epilogue
+          gemm_pl(B, cur.H, cur.W, blk.pw1, tnpl, hh, VS_ACT_GELU, nullptr, parts, 1, A_MUL, HW);
+          if (live()) chk(vs_grn_scale_from_straddle_partials(parts, B, HW, 4 * Cc, blk.gamma, scale, hh.ld, st));
         } else {
           if (pl1) gemm_pl(B, cur.H, cur.W, blk.pw1, tnpl, hh, VS_ACT_GELU, nullptr, nullptr, 1);
           else conv(tn, blk.pw1, hh, 1, 0, VS_PAD_ZERO, VS_ACT_GELU);

@@ -995,6 +995,9 @@ static int dwconv7_ln_any(const float* x, int B, int H, int W, int C, int64_t ld
     else if (cfg == 5) rc = launch_dwconv_tiled<4, 16, 48, 256>(x, B, H, W, C, ld, wdw, bdw, lnw, lnb, eps, out, out_ld, (hipStream_t)stream, pl);
     else if (cfg == 6) rc = launch_dwconv_tiled<4, 8, 128, 256>(x, B, H, W, C, ld, wdw, bdw, lnw, lnb, eps, out, out_ld, (hipStream_t)stream, pl);
     else if (cfg == 7) rc = launch_dwconv_tiled<4, 4, 128, 128>(x, B, H, W, C, ld, wdw, bdw, lnw, lnb, eps, out, out_ld, (hipStream_t)stream, pl);
+    else if (cfg == 8) rc = launch_dwconv_tiled<4, 4, 64, 128>(x, B, H, W, C, ld, wdw, bdw, lnw, lnb, eps, out, out_ld, (hipStream_t)stream, pl);
+    else if (cfg == 9) rc = launch_dwconv_tiled<4, 4, 32, 128>(x, B, H, W, C, ld, wdw, bdw, lnw, lnb, eps, out, out_ld, (hipStream_t)stream, pl);
+    else if (cfg == 10) rc = launch_dwconv_tiled<2, 8, 64, 128>(x, B, H, W, C, ld, wdw, bdw, lnw, lnb, eps, out, out_ld, (hipStream_t)stream, pl);
     if (rc == VS_ERR_UNSUPPORTED && force < 0 && cfg == 3)      // tile does not fit / ld % 32: the other tiled shape
       rc = launch_dwconv_tiled<4, 16, 48, 256>(x, B, H, W, C, ld, wdw, bdw, lnw, lnb, eps, out, out_ld, (hipStream_t)stream, pl);
     if (rc != VS_ERR_UNSUPPORTED) return rc;
@@ -1071,6 +1074,58 @@ extern "C" int vs_grn_scale_from_partials(const float* partial, int B, int HW, i
   VS_REQUIRE(partial && gamma && scale && B > 0 && HW > 0 && HW % 32 == 0 && C > 0 && scale_ld >= C);
   hipLaunchKernelGGL(grn_finish_kernel, dim3((unsigned)B), dim3(1024), 0, (hipStream_t)stream, partial, HW / 32, B, C, gamma,
                      scale, scale_ld, 1);
+  return vs_launch_status();
+}
+
+// Gx of frame b from the straddling 32-row-group partials of conv_common.h::write_sumsq_straddle ([groups][2][C]): the groups g_lo .. g_hi that
+// overlap the frame's rows, ascending; a group whose first row lies in the frame contributes slot 0, the one that starts in frame b - 1 slot 1.
+// One workgroup per frame, a thread walks channels c = tid, tid + 1024, ...; eight groups' loads are issued before the first addition.
+__global__ __launch_bounds__(1024) void grn_finish_straddle_kernel(const float* __restrict__ partial, int HW, int C, const float* __restrict__ gamma,
+                                                                   float* __restrict__ scale, int64_t sld) {
+  __shared__ float red[1024];
+  const int b = blockIdx.x;
+  const int64_t r_lo = (int64_t)b * HW, r_hi = r_lo + HW - 1;
+  const int g_lo = (int)(r_lo >> 5), g_hi = (int)(r_hi >> 5);
+  float local = 0.f;
+  for (int c = threadIdx.x; c < C; c += 1024) {
+    float s = 0.f;
+    int g = g_lo;
+    for (; g + 8 <= g_hi + 1; g += 8) {
+      float v[8];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const int slot = ((int64_t)(g + q) * 32) / HW == b ? 0 : 1;
+        v[q] = partial[((int64_t)(g + q) * 2 + slot) * C + c];
+      }
+#pragma unroll
+      for (int q = 0; q < 8; ++q) s += v[q];
+    }
+    for (; g <= g_hi; ++g) {
+      const int slot = ((int64_t)g * 32) / HW == b ? 0 : 1;
+      s += partial[((int64_t)g * 2 + slot) * C + c];
+    }
+    const float gx = sqrtf(s);
+    scale[(int64_t)b * sld + c] = gx;
+    local += gx;
+  }
+  red[threadIdx.x] = local;
+  __syncthreads();
+  for (int o = 512; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+    __syncthreads();
+  }
+  const float mean = red[0] / (float)C;
+  for (int c = threadIdx.x; c < (int)sld; c += 1024) {
+    float v = 0.f;
+    if (c < C) v = 1.0f + gamma[c] * (scale[(int64_t)b * sld + c] / (mean + 1e-6f));
+    scale[(int64_t)b * sld + c] = v;
+  }
+}
+
+extern "C" int vs_grn_scale_from_straddle_partials(const float* partial, int B, int HW, int C, const float* gamma, float* scale,
+                                                   int64_t scale_ld, void* stream) {
+  VS_REQUIRE(partial && gamma && scale && B > 0 && HW >= 32 && C > 0 && scale_ld >= C);
+  hipLaunchKernelGGL(grn_finish_straddle_kernel, dim3((unsigned)B), dim3(1024), 0, (hipStream_t)stream, partial, HW, C, gamma, scale, scale_ld);
   return vs_launch_status();
 }
 

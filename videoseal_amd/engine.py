@@ -286,6 +286,7 @@ class HipEngine:
         # the wave-specialised GEMM's producers set its K loop's pace (profiles/r05a / r05c); with their lanes all working in both half steps the
         # kernel alone is 49.9 us against 56.3 + 13 (tools/bench_gemm.py ksweep2) and detect of 32 frames 3.725 -> 3.651 ms (median of five
         # alternating runs, profiles/r05o_detect_pw2_tile26.json).  VIDEOSEAL_PW2_NARROW=0: the K-slice form
+        self.grn_straddle = os.environ.get("VIDEOSEAL_GRN_STRADDLE", "1") != "0"         # GRN statistics from the planes GEMM's epilogue for HW % 32 != 0 (round 6)
         self.grn_fold = os.environ.get("VIDEOSEAL_GRN_FOLD", "1") != "0"                 # GRN finish inside the wave-specialised pwconv2 GEMM (round 6)
         self.pw2_narrow = os.environ.get("VIDEOSEAL_PW2_NARROW", "1") != "0"
         self.pw2_small_pc = os.environ.get("VIDEOSEAL_PW2_SMALL_PC", "1") != "0"        # stage-3 pwconv2 on the wave-specialised GEMM instead of planes (round 5)
@@ -511,7 +512,7 @@ class HipEngine:
              n_store=None, res: Optional[Act] = None, in2: Optional[Act] = None, w2: Optional[ConvW] = None,
              a_scale=None, a_scale_ld=0, a_shift=None, geom=None, tile_hint=0, prof: Optional[str] = None,
              split_k: Optional[int] = None, sumsq: Optional[torch.Tensor] = None, cin: Optional[int] = None, flops: Optional[float] = None,
-             grn_fold: Optional[tuple] = None,
+             grn_fold: Optional[tuple] = None, sumsq_hw: int = 0,
              arith: Optional[int] = None, in_pl: Optional[torch.Tensor] = None, in2_pl: Optional[torch.Tensor] = None,
              out_pl: Optional[torch.Tensor] = None, a_mul: Optional[float] = None):
         """cin: read only the first `cin` channels of every pixel (pixel stride stays x.ld)"""
@@ -557,6 +558,7 @@ class HipEngine:
                 d.n_store = w.N
         if sumsq is not None:       # GRN partial sums of squares from the epilogue ([rows/32][N])
             d.sumsq_part = N.ptr(sumsq)
+            d.sumsq_hw = int(sumsq_hw)       # > 0: frames of sumsq_hw rows (not a multiple of 32) -> the straddling [rows/32][2][N] form (tile codes 24 / 25)
             split_k = 1
         patch_pc = self._patch_pc_ok(d)
         if split_k is None:     # static, shape-only rule (never timing-based: a K split changes the summation order)
@@ -1270,6 +1272,13 @@ class HipEngine:
                         N.check(L.vs_grn_scale_from_partials(N.ptr(part32), B, HW, 4 * Cc, N.ptr(blk["gamma"]), N.ptr(scale), hh.ld, st),
                                 "vs_grn_scale_from_partials")
                         fold = None
+                elif bpl1 and HW >= 32 and self.grn_straddle:
+                    # round 6 (ChunkySeal: 31 x 31 frames): the planes GEMM's epilogue writes the partial sums of its 32-row groups split at the frame
+                    # boundary a group may straddle -- the separate pass over h (356 MB per block at ChunkySeal's size) is gone
+                    parts = self.buf(f"st{sti}.gps", ((cur.rows + 31) // 32) * 2 * 4 * Cc)
+                    self.conv(tn, blk["pw1"], hh, act=N.ACT_GELU, sumsq=parts, sumsq_hw=HW, **kw1)
+                    N.check(L.vs_grn_scale_from_straddle_partials(N.ptr(parts), B, HW, 4 * Cc, N.ptr(blk["gamma"]), N.ptr(scale), hh.ld, st),
+                            "vs_grn_scale_from_straddle_partials")
                 else:
                     self.conv(tn, blk["pw1"], hh, act=N.ACT_GELU, **kw1)
                     N.check(L.vs_grn_scale(N.ptr(hh.t), B, HW, 4 * Cc, hh.ld, N.ptr(blk["gamma"]), N.ptr(part), N.ptr(scale), st),

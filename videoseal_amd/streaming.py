@@ -4,7 +4,7 @@ kernels cannot fill 256 CUs (the U-Net bottleneck conv runs at 0.19 of its ceili
 
   * the key frames of `group` consecutive chunks go through the U-Net as ONE batch (`Videoseal.embed_group`; default: enough chunks for
     32 key frames), the watermark is expanded chunk by chunk as the per-chunk calls would do it, and `sink` still sees chunk after chunk;
-  * the extractor runs on >= 32 watermarked frames at a time, whatever the caller's chunk;
+  * the extractor runs on up to DET_BATCH (128) watermarked frames at a time, whatever the caller's chunk;
   * detect(group i) is issued on a second HIP stream while embed(group i+1) runs on the first, and (round 6) starts on the first 32
     watermarked frames of a group while the tail of the remaining frames is still being issued.
 
@@ -20,7 +20,10 @@ from typing import Callable, Optional, Tuple
 import torch
 
 KEY_BATCH = 32      # key frames per U-Net pass at which conv3x3_pl_kernel has one 256-pixel tile x 192 channels per CU (B * 4 * 2 = 256)
-DET_BATCH = 32      # frames per extractor pass
+DET_BATCH = 128     # frames per extractor pass.  Round 6: 32 -> 128 (= one default group of 8 x 16 frames): the extractor's stage-2 / 3 GEMMs are one-round
+                    # launches at 32 frames (256 tiles on 256 CUs, every launch pays its fill, epilogue and store drain once per 32 frames); same box,
+                    # bench.py --detect-only: 2.96 ms per 32 frames at batch 32, 2.61 at batch 64; stream leg 1024 frames 7586 / 8189 / 8332 frames/s and a
+                    # 128-frame shard 7243 / 7857 / 8248 frames/s at 32 / 64 / 128 frames per pass (profiles/r06f_det_batch_sweep.json)
 
 
 GROUP_BYTES = 2 << 30   # source + watermarked frames of one group (a 768 x 768 fp32 group of 8 x 16 frames is 1.8 GB; 4K fp32 chunks go one by one)
