@@ -657,6 +657,9 @@ struct Runner {
           if (hh.ld / skp <= 3072) pl2 = false;
         }
       }
+      else if (m->arith == 2 && hh.ld % 16 == 0 && HW % 64 != 0 && ((rows + 255) / 256) * ((Cc + 191) / 192) >= 200) {
+        pl2 = true; sk2 = 1;      // engine.py (round 6): odd frames pay a pass over h anyway -- make it the planes conversion
+      }
       // engine.py::_extractor_forward: pwconv1 -> GELU -> GRN -> pwconv2 with h on chip (statistics pass, scale, apply pass in place on cur)
       const bool fused = m->arith == 2 && !m->stages[sti].empty() && m->stages[sti][0].fuse && pw1w.CinP == Cc && vs_cnx_block_supported(Cc, rows, HW);
       void* tnpl = (pl1 || fused) ? alloc(rows * pw1w.CinP) : nullptr;

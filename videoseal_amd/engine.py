@@ -1221,6 +1221,12 @@ class HipEngine:
                         skp *= 2
                     if hh.ld // skp <= 3072:
                         pl2 = False
+            elif (self.planes_gemm and self.use_split and self.arith == 2 and hh.ld % 16 == 0 and HW % 64 != 0
+                  and ((cur.rows + 255) // 256) * ((Cc + 191) // 192) >= 200):
+                # round 6 (ChunkySeal stages 0 / 1: 127 x 127 and 63 x 63 frames, K = 1448 / 2896 < 2048 at stage 0): frames that do not align with the
+                # wave-specialised GEMM's 64-row halves pay a full pass over h anyway (vs_grn_apply in place) and then run the slower kernel -- the
+                # planes conversion IS that pass, and the all-DMA GEMM behind it is twice as fast (1.6 -> 0.85 ms per launch at 258 064 x 1448 x 362)
+                pl2, sk2 = True, 1
             tnpl = self.buf(f"st{sti}.npl", cur.rows * pw1w.CinP).view(torch.int16) if pl1 else None
             hpl = self.buf(f"st{sti}.hpl", cur.rows * hh.ld).view(torch.int16) if pl2 else None
             ptile = N.CONV_TILE_HI | 8
