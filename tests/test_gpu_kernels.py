@@ -1335,3 +1335,35 @@ def test_grn_statistics_from_straddling_row_groups(B, H, W, K, Nn):
             N.check(eng.lib.vs_grn_scale_from_straddle_partials(N.ptr(outs[0][1]), B, HW, Nn, N.ptr(gm), N.ptr(outs[0][1]), ld, N.stream()), "HW < 32")
     with pytest.raises(N.NativeError):      # the generic kernel has no such epilogue
         eng.conv(xa, cw, outs[1][0], act=N.ACT_GELU, tile_hint=1, sumsq=outs[1][1], sumsq_hw=max(HW, 32), arith=2)
+
+
+@pytest.mark.parametrize("C_,H,W", [(1448, 31, 31), (1030, 9, 5), (96, 6, 7), (2896, 15, 15), (362, 7, 7)])
+def test_dwconv7_ln_two_row_strips_are_bit_identical(C_, H, W):
+    """round 6: the one-row depthwise 7x7 + LayerNorm kernel with strips of 4 x 2 output pixels (ChunkySeal's 1448- / 2896-channel maps: 10 instead of
+    17.5 input fetches per output) against single rows (development switch 6): fp32 rows and operand planes, odd heights (a half strip at the bottom)"""
+    L = N.lib()
+    g = torch.Generator().manual_seed(C_ + H)
+    B = 2
+    ld = rup(C_, 32) if C_ >= 128 else rup(C_, 4)
+    xa = to_nhwc(torch.randn(B, C_, H, W, generator=g), ld)
+    wdw = torch.zeros(49, ld); wdw[:, :C_] = torch.randn(49, C_, generator=g) * 0.1
+    wdw = dv(wdw)
+    vecs = [dv(F.pad(torch.randn(C_, generator=g), (0, ld - C_))) for _ in range(3)]
+    Cp = rup(C_, 32)
+    outs = []
+    import os
+    for rows in (2, 1):
+        L.vs_debug_set(6, rows)
+        try:
+            o = torch.full((B * H * W * ld,), 3.0, device=DEV)
+            pl = torch.full((2 * B * H * W * Cp,), 77, dtype=torch.int16, device=DEV)
+            # VS_DWCONV=0 is process-wide; these shapes take the one-row kernel anyway (tile + LayerNorm buffer beyond the LDS) except the small ones
+            N.check(L.vs_dwconv7_ln(N.ptr(xa.t), B, H, W, C_, ld, N.ptr(wdw), N.ptr(vecs[0]), N.ptr(vecs[1]), N.ptr(vecs[2]), 1e-6, N.ptr(o), ld, N.stream()), "dw")
+            N.check(L.vs_dwconv7_ln_planes(N.ptr(xa.t), B, H, W, C_, ld, N.ptr(wdw), N.ptr(vecs[0]), N.ptr(vecs[1]), N.ptr(vecs[2]), 1e-6, 16.0, Cp, N.ptr(pl),
+                                           N.stream()), "dw planes")
+            torch.cuda.synchronize()
+        finally:
+            L.vs_debug_set(6, 0)
+        outs.append((o.cpu(), pl.cpu()))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    assert torch.isfinite(outs[0][0]).all()

@@ -233,15 +233,20 @@ __device__ __forceinline__ void ln_rows_from_lds(const float* __restrict__ s, in
 // Depthwise 7x7 (pad 3) + bias, then LayerNorm over C, per pixel (convnext.py:43-46).
 // A work item = (strip of 4 consecutive x, group of 4 channels): 70 float4 loads feed 16 outputs x 4 channels,
 // results go to LDS [pixel][channel]; then one wave per pixel does the LayerNorm and the coalesced store.
+// R = output rows per strip (round 6: R = 2 for the wide small maps of ChunkySeal -- 31 x 31 x 1448 -- where one strip of all channels already fills a
+// workgroup: a 4 x 2 strip reads 8 input rows x 10 columns for 8 outputs instead of 7 x 10 for 4, i.e. 10 instead of 17.5 fetches per output through
+// L1 / L2, which is what bounds this kernel; per output the taps are still accumulated in (ky, kx) order: bit-identical to R = 1 and to the tiled kernels)
+template <int R>
 __global__ __launch_bounds__(256) void dwconv7_ln_kernel(const float* __restrict__ x, int B, int H, int W, int C, int64_t ld,
                                                          const float* __restrict__ wdw, const float* __restrict__ bdw,
                                                          const float* __restrict__ lnw, const float* __restrict__ lnb,
                                                          float eps, float* __restrict__ out, int64_t out_ld, int NS,
                                                          int spr, int64_t nstrips, PlanesOut pl) {
-  extern __shared__ __attribute__((aligned(16))) float conv[];   // [NS*4][ld + 4] | the LayerNorm's affine parameters [2][C]
-  float* const s_wb = conv + (int64_t)NS * 4 * (ld + 4);
+  extern __shared__ __attribute__((aligned(16))) float conv[];   // [NS*4*R][ld + 4] | the LayerNorm's affine parameters [2][C]
+  float* const s_wb = conv + (int64_t)NS * 4 * R * (ld + 4);
   for (int i = threadIdx.x; i < C; i += 256) { s_wb[i] = lnw[i]; s_wb[C + i] = lnb[i]; }      // (visible behind the barrier below)
   const int C4 = (int)(ld >> 2);
+  const int HR = (H + R - 1) / R;                  // strip rows per frame
   const int64_t s0 = (int64_t)blockIdx.x * NS;
   const int items = NS * C4;
   for (int it = threadIdx.x; it < items; it += blockDim.x) {
@@ -251,16 +256,18 @@ __global__ __launch_bounds__(256) void dwconv7_ln_kernel(const float* __restrict
     const int c = cg * 4;
     const int xs = (int)(sidx % spr);
     const int64_t t = sidx / spr;
-    const int y = (int)(t % H);
-    const int b = (int)(t / H);
+    const int y = (int)(t % HR) * R;
+    const int b = (int)(t / HR);
     const int x0 = xs * 4;
-    f32x4 acc[4];
+    f32x4 acc[R][4];
     const f32x4 bv = *reinterpret_cast<const f32x4*>(bdw + c);
 #pragma unroll
-    for (int p = 0; p < 4; ++p) acc[p] = bv;
+    for (int r = 0; r < R; ++r)
+#pragma unroll
+      for (int p = 0; p < 4; ++p) acc[r][p] = bv;
     const float* base = x + (int64_t)b * H * W * ld + c;
-    for (int ky = 0; ky < 7; ++ky) {
-      const int iy = y + ky - 3;
+    for (int kr = 0; kr < 6 + R; ++kr) {           // input row y - 3 + kr feeds output row r with ky = kr - r
+      const int iy = y + kr - 3;
       if (iy < 0 || iy >= H) continue;
       f32x4 in[10];
 #pragma unroll
@@ -270,21 +277,32 @@ __global__ __launch_bounds__(256) void dwconv7_ln_kernel(const float* __restrict
                                     : f32x4{0.f, 0.f, 0.f, 0.f};
       }
 #pragma unroll
-      for (int kx = 0; kx < 7; ++kx) {
-        const f32x4 wv = *reinterpret_cast<const f32x4*>(wdw + (int64_t)(ky * 7 + kx) * ld + c);
+      for (int r = 0; r < R; ++r) {
+        const int ky = kr - r;
+        if (ky < 0 || ky > 6) continue;
 #pragma unroll
-        for (int p = 0; p < 4; ++p) acc[p] += in[p + kx] * wv;
+        for (int kx = 0; kx < 7; ++kx) {
+          const f32x4 wv = *reinterpret_cast<const f32x4*>(wdw + (int64_t)(ky * 7 + kx) * ld + c);
+#pragma unroll
+          for (int p = 0; p < 4; ++p) acc[r][p] += in[p + kx] * wv;
+        }
       }
     }
 #pragma unroll
-    for (int p = 0; p < 4; ++p) *reinterpret_cast<f32x4*>(conv + (int64_t)(sl * 4 + p) * (ld + 4) + c) = acc[p];
+    for (int r = 0; r < R; ++r)
+#pragma unroll
+      for (int p = 0; p < 4; ++p) *reinterpret_cast<f32x4*>(conv + (int64_t)((sl * R + r) * 4 + p) * (ld + 4) + c) = acc[r][p];
   }
   __syncthreads();
-  ln_rows_from_lds<256>(conv, (int)ld + 4, NS * 4, C, lnw, lnb, eps, (int)out_ld, [&](int p) -> float* {
-    const int64_t sidx = s0 + (p >> 2);
+  ln_rows_from_lds<256>(conv, (int)ld + 4, NS * 4 * R, C, lnw, lnb, eps, (int)out_ld, [&](int p) -> float* {
+    const int64_t sidx = s0 + p / (4 * R);
     if (sidx >= nstrips) return nullptr;
+    const int r = (p / 4) % R;
     const int px = (int)(sidx % spr) * 4 + (p & 3);
-    return px < W ? out + ((sidx / spr) * W + px) * out_ld : nullptr;
+    const int64_t t = sidx / spr;
+    const int y = (int)(t % HR) * R + r;
+    const int64_t b = t / HR;
+    return (px < W && y < H) ? out + ((b * H + y) * W + px) * out_ld : nullptr;
   }, pl, s_wb, true);
 }
 
@@ -1006,12 +1024,25 @@ static int dwconv7_ln_any(const float* x, int B, int H, int W, int C, int64_t ld
   int NS = 256 / C4;
   if (NS < 1) NS = 1;
   const int spr = (W + 3) / 4;
-  const int64_t nstrips = (int64_t)B * H * spr;
-  const size_t smem = ((size_t)NS * 4 * (ld + 4) + 2 * (size_t)C) * sizeof(float);
+  // two output rows per strip where ONE strip of all channels fills the workgroup (C4 >= 256: ChunkySeal's 1448- / 2896-channel maps) and the strips
+  // still outnumber the CUs; VS_DWCONV_ROWS=1 keeps single rows
+  static const int force_rows = [] { const char* e = getenv("VS_DWCONV_ROWS"); return e ? atoi(e) : 0; }();
+  const int dbg_rows = vs_debug_get(VS_DBG_DWCONV_ROWS);                    // tests: 1 / 2 rows per strip whatever the shape
+  const bool two = dbg_rows ? dbg_rows == 2 : force_rows ? force_rows == 2 : (C4 >= 256 && H >= 2 && (int64_t)B * ((H + 1) / 2) * spr >= 2 * vs_num_cus());
+  const int R = two ? 2 : 1;
+  const int64_t nstrips = (int64_t)B * ((H + R - 1) / R) * spr;
+  const size_t smem = ((size_t)NS * 4 * R * (ld + 4) + 2 * (size_t)C) * sizeof(float);
   if (smem > 160 * 1024) return VS_ERR_UNSUPPORTED;
+  if (two) {
+    if (smem > 64 * 1024)
+      (void)hipFuncSetAttribute((const void*)dwconv7_ln_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    hipLaunchKernelGGL(dwconv7_ln_kernel<2>, dim3((unsigned)cdiv64(nstrips, NS)), dim3(256), smem, (hipStream_t)stream, x, B, H, W,
+                       C, ld, wdw, bdw, lnw, lnb, eps, out, out_ld, NS, spr, nstrips, pl);
+    return vs_launch_status();
+  }
   if (smem > 64 * 1024)
-    (void)hipFuncSetAttribute((const void*)dwconv7_ln_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-  hipLaunchKernelGGL(dwconv7_ln_kernel, dim3((unsigned)cdiv64(nstrips, NS)), dim3(256), smem, (hipStream_t)stream, x, B, H, W,
+    (void)hipFuncSetAttribute((const void*)dwconv7_ln_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+  hipLaunchKernelGGL(dwconv7_ln_kernel<1>, dim3((unsigned)cdiv64(nstrips, NS)), dim3(256), smem, (hipStream_t)stream, x, B, H, W,
                      C, ld, wdw, bdw, lnw, lnb, eps, out, out_ld, NS, spr, nstrips, pl);
   return vs_launch_status();
 }
@@ -1086,19 +1117,19 @@ __global__ __launch_bounds__(1024) void grn_finish_straddle_kernel(const float* 
   const int b = blockIdx.x;
   const int64_t r_lo = (int64_t)b * HW, r_hi = r_lo + HW - 1;
   const int g_lo = (int)(r_lo >> 5), g_hi = (int)(r_hi >> 5);
-  // a thread owns the channels c = tid + 1024 j (up to CPT = 8 of them per pass: C <= 8192 in one pass); the loads of four groups x CPT channels are
+  // a thread owns the channels c = tid + 1024 j (up to CPT = 6 of them per pass: ChunkySeal's 5 792 in one pass); the loads of eight groups x CPT channels are
   // issued before the first addition (the first version walked one channel at a time: ~24 dependent L2 round trips per thread on ChunkySeal's
   // 5 792 channels x 31 groups, 16 workgroups on the whole chip)
-  constexpr int CPT = 8;
+  constexpr int CPT = 6, GB = 8;
   float local = 0.f;
   for (int cb = 0; cb < C; cb += 1024 * CPT) {
     float s[CPT];
 #pragma unroll
     for (int j = 0; j < CPT; ++j) s[j] = 0.f;
-    for (int g0 = g_lo; g0 <= g_hi; g0 += 4) {
-      float v[4][CPT];
+    for (int g0 = g_lo; g0 <= g_hi; g0 += GB) {
+      float v[GB][CPT];
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
+      for (int q = 0; q < GB; ++q) {
         const int g = g0 + q <= g_hi ? g0 + q : g_hi;              // (past the last group: a valid address, value unused)
         const int slot = ((int64_t)g * 32) / HW == b ? 0 : 1;
         const float* row = partial + ((int64_t)g * 2 + slot) * C;
@@ -1109,7 +1140,7 @@ __global__ __launch_bounds__(1024) void grn_finish_straddle_kernel(const float* 
         }
       }
 #pragma unroll
-      for (int q = 0; q < 4; ++q)
+      for (int q = 0; q < GB; ++q)
         if (g0 + q <= g_hi) {
 #pragma unroll
           for (int j = 0; j < CPT; ++j) s[j] += v[q][j];
