@@ -1338,9 +1338,9 @@ def test_grn_statistics_from_straddling_row_groups(B, H, W, K, Nn):
 
 
 @pytest.mark.parametrize("C_,H,W", [(1448, 31, 31), (1030, 9, 5), (96, 6, 7), (2896, 15, 15), (362, 7, 7)])
-def test_dwconv7_ln_two_row_strips_are_bit_identical(C_, H, W):
+def test_dwconv7_ln_two_row_strips_equal_single_rows(C_, H, W):
     """round 6: the one-row depthwise 7x7 + LayerNorm kernel with strips of 4 x 2 output pixels (ChunkySeal's 1448- / 2896-channel maps: 10 instead of
-    17.5 input fetches per output) against single rows (development switch 6): fp32 rows and operand planes, odd heights (a half strip at the bottom)"""
+    17.5 input fetches per output) against single rows (development switch 6): fp32 rows and operand planes agree to fp32 rounding, odd heights (a half strip at the bottom)"""
     L = N.lib()
     g = torch.Generator().manual_seed(C_ + H)
     B = 2
@@ -1365,5 +1365,17 @@ def test_dwconv7_ln_two_row_strips_are_bit_identical(C_, H, W):
         finally:
             L.vs_debug_set(6, 0)
         outs.append((o.cpu(), pl.cpu()))
-    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
-    assert torch.isfinite(outs[0][0]).all()
+    # same depthwise sums (same tap order per output); the LayerNorm behind them spreads a pixel's channels over more or fewer lanes depending on the
+    # pixels per workgroup, so the two forms agree to fp32 rounding
+    a, b = outs[0][0].view(B * H * W, ld), outs[1][0].view(B * H * W, ld)
+    assert torch.isfinite(a).all() and (a - b).abs().max().item() < 2e-6 * max(1.0, b.abs().max().item())
+    def deq(pl):
+        hi = pl[:B * H * W * Cp].view(torch.float16).float()
+        lo = pl[B * H * W * Cp:].view(torch.float16).float()
+        return (hi + lo) / 16.0
+    assert (deq(outs[0][1]) - deq(outs[1][1])).abs().max().item() < 2e-6 * max(1.0, b.abs().max().item())
+    # and the planes are the split of the fp32 rows
+    full = torch.zeros(B * H * W, Cp)
+    full[:, :C_] = a[:, :C_]
+    got = deq(outs[0][1]).view(Cp // 16, B * H * W, 16).permute(1, 0, 2).reshape(B * H * W, Cp)
+    assert (got - full).abs().max().item() < 2e-6 * max(1.0, b.abs().max().item())

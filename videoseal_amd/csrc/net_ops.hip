@@ -1024,11 +1024,14 @@ static int dwconv7_ln_any(const float* x, int B, int H, int W, int C, int64_t ld
   int NS = 256 / C4;
   if (NS < 1) NS = 1;
   const int spr = (W + 3) / 4;
-  // two output rows per strip where ONE strip of all channels fills the workgroup (C4 >= 256: ChunkySeal's 1448- / 2896-channel maps) and the strips
-  // still outnumber the CUs; VS_DWCONV_ROWS=1 keeps single rows
+  // two output rows per strip where ONE strip of all channels fills the workgroup (more than 512 channels: ChunkySeal's 1448- / 2896-channel maps,
+  // VideoSeal's 8 x 8 x 768 stage) and the strips still cover the CUs; VS_DWCONV_ROWS=1 keeps single rows.  Measured (tools/bench_dwconv.py, one box):
+  // 31 x 31 x 1472, 16 frames 161.6 -> 112.4 us; 15 x 15 x 2912 97.1 -> 86.5; 8 x 8 x 768, 32 frames 22.8 -> 15.1 us.  The conv values are bit-identical
+  // to the single-row strips; the LayerNorm behind them sums a pixel's channels over more or fewer lanes depending on the pixels per workgroup
+  // (ln_rows_from_lds), so the outputs agree to fp32 rounding, not bit for bit
   static const int force_rows = [] { const char* e = getenv("VS_DWCONV_ROWS"); return e ? atoi(e) : 0; }();
   const int dbg_rows = vs_debug_get(VS_DBG_DWCONV_ROWS);                    // tests: 1 / 2 rows per strip whatever the shape
-  const bool two = dbg_rows ? dbg_rows == 2 : force_rows ? force_rows == 2 : (C4 >= 256 && H >= 2 && (int64_t)B * ((H + 1) / 2) * spr >= 2 * vs_num_cus());
+  const bool two = dbg_rows ? dbg_rows == 2 : force_rows ? force_rows == 2 : (NS == 1 && H >= 2 && (int64_t)B * ((H + 1) / 2) * spr >= vs_num_cus());
   const int R = two ? 2 : 1;
   const int64_t nstrips = (int64_t)B * ((H + R - 1) / R) * spr;
   const size_t smem = ((size_t)NS * 4 * R * (ld + 4) + 2 * (size_t)C) * sizeof(float);
