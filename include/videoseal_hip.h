@@ -104,6 +104,8 @@ typedef struct vs_conv_desc {
                             /* 22 = 256x192, 23 = 256x128: all-DMA 3x3 kernel on pre-split planes (arith 2, in_pl, H % 16 == W % 16 == 0);  */
                             /* 24 = 256x192, 25 = 256x128: all-DMA 1x1 GEMM on pre-split planes (arith 2, in_pl; split_k, sumsq_part, res);  */
                             /* 26 = 128x96: the wave-specialised 1x1 GEMM with four consumer waves stacked over the rows (arith 2; round 5); */
+                            /* 27 = 256x256: the all-DMA planes GEMM with ONE wave per SIMD (128 x 128 per wave, four 32 KiB stages; round 6:  */
+                            /*      15 % fewer operand bytes per FLOP than tile 24 for the GEMMs that are LDS-DMA-bound -- ChunkySeal);          */
                             /* | VS_CONV_TILE_HI: tile code + 16;                                                     */
                             /* | VS_CONV_FORCE_F32: v_mfma_f32_32x32x2_f32 path; | VS_CONV_FORCE_SPLIT */
   const void* wt_split;     /* optional [P][N][Ktot] 16-bit planes (P = 3 bf16 / 2 f16, see arith): wt split into P terms; when set */

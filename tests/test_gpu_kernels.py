@@ -1379,3 +1379,53 @@ def test_dwconv7_ln_two_row_strips_equal_single_rows(C_, H, W):
     full[:, :C_] = a[:, :C_]
     got = deq(outs[0][1]).view(Cp // 16, B * H * W, 16).permute(1, 0, 2).reshape(B * H * W, Cp)
     assert (got - full).abs().max().item() < 2e-6 * max(1.0, b.abs().max().item())
+
+
+@pytest.mark.parametrize("case", [
+    # B, H, W, K, N, act, res, split_k, sumsq (0 / 1 / HW = straddling groups)
+    (2, 16, 16, 96, 384, 2, False, 1, 1),          # pwconv1-like: GELU + GRN partials, 2 x 1.5 tiles
+    (3, 15, 15, 160, 520, 0, True, 1, 0),          # ragged rows (675) and columns, residual
+    (2, 31, 31, 48, 724, 2, False, 1, 961),        # ChunkySeal-like: straddling GRN partials
+    (16, 31, 31, 64, 1448, 0, True, 1, 0),         # 61 x 6 tiles: the XCD-grouped order
+    (1, 8, 8, 3072, 768, 0, True, 8, 0),           # K slices + epilogue kernel
+    (5, 8, 8, 16, 40, 1, False, 1, 0),             # a single K step, one ragged tile
+    (2, 16, 24, 48, 300, 3, False, 1, 0),          # three K steps (odd count), tanh
+])
+def test_gemm_planes_big_tile(case):
+    """tile code 27 (round 6): the all-DMA planes GEMM on 256 x 256 tiles with one wave per SIMD (128 x 128 per wave, rotating fragment banks, four
+    32 KiB LDS stages) multiplies the same products in the same K order as tile 24 -> identical outputs and GRN partials, bit for bit"""
+    B, H, W, K, Nn, act, res, sk, sumsq = case
+    eng = Eng(arith=2)
+    g = torch.Generator().manual_seed(41 + K + Nn)
+    HW = H * W
+    x = torch.randn(B, HW, K, generator=g)
+    w = torch.randn(Nn, K, generator=g) / math.sqrt(K)
+    bias = torch.randn(Nn, generator=g)
+    r = torch.randn(B, HW, Nn, generator=g)
+    ref = F.linear(x, w, bias)
+    ref = {0: ref, 1: F.relu(ref), 2: F.gelu(ref), 3: torch.tanh(ref)}[act]
+    if res:
+        ref = ref + r
+    xa = Act(dv(x), B, H, W, K, K)
+    wt, cp = pack_conv(w[:, :, None, None].to(DEV), K)
+    cw = ConvW(wt, dv(bias), Nn, 1, 1, cp)
+    ld = (Nn + 3) // 4 * 4
+    ra = Act(torch.zeros(B * HW * ld, device=DEV), B, H, W, Nn, ld)
+    ra.t.view(B, HW, ld)[..., :Nn] = r.to(DEV)
+    pl = torch.empty(B * HW * K * 2, dtype=torch.int16, device=DEV)
+    N.check(eng.lib.vs_to_planes(N.ptr(xa.t), xa.rows, K, xa.ld, 16.0, N.ptr(pl), N.stream()), "to_planes")
+    outs = []
+    for t in (N.CONV_TILE_HI | 11, N.CONV_TILE_HI | 8):
+        out = Act(torch.full((B * HW * ld,), float("nan"), device=DEV), B, H, W, Nn, ld)
+        part = torch.full((((B * HW + 31) // 32) * 2 * Nn,), float("nan"), device=DEV) if sumsq else None
+        kw = dict(sumsq=part, sumsq_hw=(sumsq if sumsq > 1 else 0)) if sumsq else {}
+        eng.conv(xa, cw, out, act=act, res=(ra if res else None), tile_hint=t, in_pl=pl, split_k=sk, a_mul=16.0, arith=2, **kw)
+        torch.cuda.synchronize()
+        got = out.t.view(B, HW, ld)
+        assert rel_err(got[..., :Nn].cpu(), ref) < 2e-5
+        assert (got[..., Nn:] == 0).all()
+        outs.append((out.t.clone(), part))
+    assert torch.equal(outs[0][0], outs[1][0])
+    if sumsq:
+        n = ((B * HW + 31) // 32) * (2 if sumsq > 1 else 1) * Nn
+        assert torch.equal(outs[0][1][:n], outs[1][1][:n])

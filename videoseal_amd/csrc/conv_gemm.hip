@@ -478,7 +478,7 @@ extern "C" int vs_conv_gemm(const vs_conv_desc_t* dp, void* stream) {
   {
     const int t = (dp->tile_hint & 0xf) + ((dp->tile_hint & VS_CONV_TILE_HI) ? 16 : 0);
     if (t == 22 || t == 23) return conv_planes(*dp, t, (hipStream_t)stream);
-    if (t == 24 || t == 25) return gemm_planes(*dp, t, (hipStream_t)stream);
+    if (t == 24 || t == 25 || t == 27) return gemm_planes(*dp, t, (hipStream_t)stream);
   }
   VS_REQUIRE(dp->in && dp->wt && dp->out);
   const vs_conv_desc_t& d = *dp;
@@ -506,7 +506,7 @@ extern "C" int vs_conv_gemm(const vs_conv_desc_t* dp, void* stream) {
   // ABI v3: the GRN finish folded into the GEMM exists in the wave-specialised 1x1 kernel only; a_scale is not written by anybody in that
   // mode, so every other route must refuse instead of reading it
   if (d.grn_part && !(tile == 17 || tile == 18 || tile == 26)) return VS_ERR_UNSUPPORTED;
-  if (d.sumsq_hw && !(tile == 24 || tile == 25)) return VS_ERR_UNSUPPORTED;                      // (the [M/32][2][N] partials exist in gemm_pl.hip only)
+  if (d.sumsq_hw && !(tile == 24 || tile == 25 || tile == 27)) return VS_ERR_UNSUPPORTED;                      // (the [M/32][2][N] partials exist in gemm_pl.hip only)
   const bool can_split0 = d.wt_split && (!d.in2 || d.wt2_split) && ((uintptr_t)d.wt_split & 15) == 0;
   // 3x3 / stride 1 / "same" convs on tile-aligned frames go to the patch kernel (input patch staged once per channel chunk)
   const bool patch_ok = can_split0 && d.KH == 3 && d.KW == 3 && d.SH == 1 && d.SW == 1 && d.PH == 1 && d.PW == 1 && d.Ho == d.H &&

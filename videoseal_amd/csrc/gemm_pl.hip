@@ -318,6 +318,228 @@ __global__ __launch_bounds__(512, 2) void gemm_pl_kernel(const vs_conv_desc_t d,
   }
 }
 
+// ---- round 6: 256-row x 384-column tiles, ONE wave per SIMD (tile code 27) ---------------------------------------------------------------
+// gemm_pl_kernel moves 28 KiB global -> LDS per K16 step and workgroup for 4.7 MFLOP; measured 0.92 us per step against 0.55 us of matrix time:
+// the chip-wide LDS-DMA stream (6.4-6.8 TB/s, MI355X_MICROARCH.md) is the bound, not the matrix cores (LAB_NOTEBOOK round 5).  A 256 x 384 tile
+// moves 40 KiB for 9.4 MFLOP -- 30 % fewer operand bytes per FLOP.  Its 96 accumulator registers per 32 x 32 block row do not fit two waves per
+// SIMD: four waves (2 x 2, each 128 rows x 192 columns = 24 blocks = 384 accumulator registers, upper half of the register file) run one per
+// SIMD, so nothing but the wave's own schedule hides its LDS latencies: the four fragment banks (lo_a 16 | hi_b 24 | hi_a 16 | lo_b 24 registers)
+// rotate -- the fragments of step s + 1 are read into the bank whose last use in step s has issued, one 24-MFMA group (~770 cycles) ahead of
+// their first use.  Four 40 KiB stages (the whole 160 KiB of LDS): tile s + 3 is requested during step s, tile s + 2 has landed at its end.
+// Same products in the same order per accumulator as gemm_pl_kernel (q0 = lo_a x hi_b, q1 = hi_a x lo_b, q2 = hi_a x hi_b per K16 step):
+// bit-identical outputs (tests/test_gpu_kernels.py::test_gemm_planes_big_tile).
+constexpr int BIG_NS = 4;
+template <int TN>
+__global__ __launch_bounds__(256, 1) void gemm_pl_big_kernel(const vs_conv_desc_t d, const int M, const int mtiles, const int ntiles, const int sps,
+                                                            const int per_xcd) {
+  using AR = Arith<2>;
+  constexpr int TM = 4;
+  constexpr int BN = 2 * TN * 32;                // 384 (TN = 6), 256 (TN = 4)
+  constexpr int NG = BN / 32;
+  constexpr int WBLK = 2048;
+  constexpr int B_STAGE = NG * WBLK;             // 24 KiB
+  constexpr int STAGE = A_STAGE + B_STAGE;       // 40 KiB
+  __shared__ __attribute__((aligned(16))) unsigned char smem[BIG_NS * STAGE];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r = lane & 31, g = lane >> 5;
+  int bm, bn, ks;
+  if (per_xcd > 0) {                              // XCD-aware grouped order, as gemm_pl_kernel
+    const int total = mtiles * ntiles;
+    const int slot = blockIdx.x % (8 * per_xcd);
+    ks = blockIdx.x / (8 * per_xcd);
+    const int v = (slot & 7) * per_xcd + (slot >> 3);
+    if (v >= total) return;
+    constexpr int GROUP_M = 4;
+    const int width = GROUP_M * ntiles;
+    const int group = v / width, rem = v - group * width;
+    const int first_m = group * GROUP_M;
+    const int gsz = min(mtiles - first_m, GROUP_M);
+    bm = first_m + rem % gsz;
+    bn = rem / gsz;
+  } else {
+    bm = blockIdx.x % mtiles;
+    bn = (blockIdx.x / mtiles) % ntiles;
+    ks = blockIdx.x / (mtiles * ntiles);
+  }
+  const int m0 = bm * GBM;
+  const int n0 = bn * BN;
+  const int nsteps_all = d.CinP / BK;
+  const int step0 = ks * sps;
+  const int nsteps = min(sps, nsteps_all - step0);
+
+  // ---- DMA: every wave requests 4 activation pieces + 6 weight pieces of 1 KiB per step
+  const int64_t cstride = (int64_t)M * 32;
+  const char* const wbase = reinterpret_cast<const char*>(d.wt_blk) + (int64_t)step0 * WBLK;
+  const char* const abase = reinterpret_cast<const char*>(d.in_pl) + (int64_t)step0 * cstride;
+  constexpr int NWP = NG * 2 / 4;                // weight pieces per wave and step
+  unsigned aoff[4], woff[NWP];
+  int wdst[NWP];
+  {
+    const unsigned pstride = (unsigned)(nsteps_all * cstride);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {                 // unit U = 64 (wave + 4 j) + lane of [plane][256 rows][2 halves]
+      const int U = (wave + 4 * j) * 64 + lane;
+      const int plane = U >> 9;
+      const int u = U & 511;
+      const int p = u >> 1;
+      const int hs = (u & 1) ^ ((p >> 3) & 1);
+      const int m = min(m0 + p, M - 1);
+      aoff[j] = plane * pstride + (unsigned)m * 32u + hs * 16;
+    }
+    const int g0 = n0 / 32, ngroups = (d.N + 31) / 32;
+#pragma unroll
+    for (int jj = 0; jj < NWP; ++jj) {
+      const int idx = wave * NWP + jj;            // (plane, column group)
+      const int p = idx / NG, gi = idx - p * NG;
+      const int gs = (g0 + gi) < ngroups ? g0 + gi : ngroups - 1;
+      woff[jj] = (unsigned)(gs * nsteps_all) * WBLK + p * 1024 + lane * 16;
+      wdst[jj] = __builtin_amdgcn_readfirstlane(A_STAGE + p * (BN * 32) + gi * 1024);
+    }
+  }
+  auto dma = [&](const int t) __attribute__((always_inline)) {
+    unsigned char* st = smem + (t % BIG_NS) * STAGE;
+    const char* ab = abase + t * cstride;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) gdma16(ab + aoff[j], st + wave * 1024 + j * 4096);
+    const char* wb = wbase + (int64_t)t * WBLK;
+#pragma unroll
+    for (int jj = 0; jj < NWP; ++jj) gdma16(wb + woff[jj], st + wdst[jj]);
+  };
+
+  // ---- consumers: 2 (rows) x 2 (columns) waves of 128 x 32 TN
+  const int wm = wave >> 1, wn = wave & 1;
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+  int a_frag[TM];
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+    const int p = (wm * TM + i) * 32 + r;
+    a_frag[i] = (2 * p + (g ^ ((p >> 3) & 1))) * 16;
+  }
+  const int b_frag = A_STAGE + (wn * TN) * 1024 + (2 * r + (g ^ ((r >> 3) & 1))) * 16;
+  bf16x8 X[TM], Y[TN], Z[TM], W[TN];             // fragment banks (roles rotate, see below)
+  auto ld_a = [&](bf16x8 (&F)[TM], const int s, const int plane) __attribute__((always_inline)) {
+    const unsigned char* Ab = smem + (s % BIG_NS) * STAGE + plane * (512 * 16);
+#pragma unroll
+    for (int i = 0; i < TM; ++i) F[i] = *reinterpret_cast<const bf16x8*>(Ab + a_frag[i]);
+  };
+  auto ld_b = [&](bf16x8 (&F)[TN], const int s, const int plane) __attribute__((always_inline)) {
+    const unsigned char* Bb = smem + (s % BIG_NS) * STAGE + b_frag + plane * (BN * 32);
+#pragma unroll
+    for (int j = 0; j < TN; ++j) F[j] = *reinterpret_cast<const bf16x8*>(Bb + j * 1024);
+  };
+  auto mm = [&](const bf16x8 (&A)[TM], const bf16x8 (&B)[TN]) __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j) acc[i][j] = AR::mfma(A[i], B[j], acc[i][j]);
+  };
+  auto finish = [&](const int s) __attribute__((always_inline)) {      // tile s + 2 landed, everybody done with stage s
+    if (s + BIG_NS - 1 < nsteps) gwait_vm<4 + NWP>();
+    else gwait_vm<0>();
+    __builtin_amdgcn_s_waitcnt(0xC07F);
+    __builtin_amdgcn_s_barrier();
+  };
+
+  for (int t = 0; t < BIG_NS - 1 && t < nsteps; ++t) dma(t);
+  gwait_vm<0>();
+  __builtin_amdgcn_s_barrier();
+  // One K16 step with the banks in the roles (LOA, HIB, HIA, LOB).  Its own hi_a / lo_b are read at its start (behind the previous step's
+  // barrier; first needed by q1, one MFMA group later); lo_a of step s + 1 goes to LOA as soon as q0 has issued, hi_b of step s + 1 to the LOB
+  // bank as soon as q1 has issued -- so the next step runs with HIB and LOB swapped.
+  auto step = [&](const int s, bf16x8 (&LOA)[TM], bf16x8 (&HIB)[TN], bf16x8 (&HIA)[TM], bf16x8 (&LOB)[TN], auto first) __attribute__((always_inline)) {
+    if constexpr (!decltype(first)::value) {
+      ld_a(HIA, s, 0);
+      ld_b(LOB, s, 1);
+    }
+    mm(LOA, HIB);                                 // q0: lo_a x hi_b
+    __builtin_amdgcn_sched_barrier(0);
+    if (s + BIG_NS - 1 < nsteps) dma(s + BIG_NS - 1);
+    const bool more = s + 1 < nsteps;
+    if (more) ld_a(LOA, s + 1, 1);
+    mm(HIA, LOB);                                 // q1: hi_a x lo_b
+    __builtin_amdgcn_sched_barrier(0);
+    if (more) ld_b(LOB, s + 1, 0);
+    mm(HIA, HIB);                                 // q2: hi_a x hi_b
+    finish(s);
+  };
+  ld_a(X, 0, 1);
+  ld_b(Y, 0, 0);
+  ld_a(Z, 0, 0);
+  ld_b(W, 0, 1);
+  __builtin_amdgcn_s_waitcnt(0xC07F);
+  step(0, X, Y, Z, W, std::true_type{});
+  int s = 1;
+  for (; s + 1 < nsteps; s += 2) {
+    step(s, X, W, Z, Y, std::false_type{});
+    step(s + 1, X, Y, Z, W, std::false_type{});
+  }
+  if (s < nsteps) step(s, X, W, Z, Y, std::false_type{});
+
+  // ---- epilogue (as gemm_pl_kernel)
+  scale_all<TM, TN>(acc, d.acc_mul);
+  int lane_e = lane;
+  asm volatile("" : "+v"(lane_e));
+  const int r_e = lane_e & 31, g_e = lane_e >> 5;
+  int col[TN];
+#pragma unroll
+  for (int j = 0; j < TN; ++j) col[j] = n0 + (wn * TN + j) * 32 + r_e;
+  const int64_t row0 = (int64_t)m0 + wm * TM * 32;
+  const bool whole = m0 + GBM <= M && n0 + BN <= d.N && (int64_t)GBM * max(max(d.out_ld, d.res_ld), d.split_k > 1 ? d.splitk_ld : 0) * 4 < (1LL << 31);
+  if (d.split_k > 1) {
+    float* ws = d.splitk_ws + (int64_t)ks * M * d.splitk_ld;
+    if (whole) store_tile_full<TM, TN>(acc, reinterpret_cast<char*>(ws + row0 * d.splitk_ld + n0 + wn * TN * 32), (int)d.splitk_ld, nullptr, 0, r_e, g_e);
+    else store_tile_guarded<TM, TN>(acc, reinterpret_cast<char*>(ws + row0 * d.splitk_ld + n0 + wn * TN * 32), (int)d.splitk_ld, nullptr, 0, r_e, g_e,
+                                    (int)min<int64_t>(M - row0, TM * 32), d.N - (n0 + wn * TN * 32), d.N - (n0 + wn * TN * 32));
+    return;
+  }
+  float bias1[TN], zero[TN];
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    bias1[j] = (col[j] < d.N && d.bias) ? d.bias[col[j]] : 0.f;
+    zero[j] = 0.f;
+  }
+  apply_act_all<TM, TN>(acc, bias1, zero, d.act);
+  if (d.sumsq_part) {
+    if (d.sumsq_hw > 0) write_sumsq_straddle<TM, TN>(acc, d.sumsq_part, d.N, row0, M, col, g_e, d.sumsq_hw);
+    else write_sumsq<TM, TN>(acc, d.sumsq_part, d.N, row0, M, col, g_e);
+  }
+  char* const ob = reinterpret_cast<char*>(d.out + row0 * d.out_ld + d.out_coff + n0 + wn * TN * 32);
+  const char* const rb = d.res ? reinterpret_cast<const char*>(d.res + row0 * d.res_ld + n0 + wn * TN * 32) : nullptr;
+  if (whole) store_tile_full<TM, TN>(acc, ob, (int)d.out_ld, rb, (int)d.res_ld, r_e, g_e);
+  else store_tile_guarded<TM, TN>(acc, ob, (int)d.out_ld, rb, (int)d.res_ld, r_e, g_e, (int)min<int64_t>(M - row0, TM * 32), d.N - (n0 + wn * TN * 32),
+                                  d.n_store - (n0 + wn * TN * 32));
+}
+
+template <int TN>
+int launch_gpl_big(const vs_conv_desc_t& d, hipStream_t st) {
+  constexpr int BN = 64 * TN;
+  const int64_t M = (int64_t)d.B * d.H * d.W;
+  const int sk = d.split_k > 1 ? d.split_k : 1;
+  const int64_t mt = cdiv64(M, GBM), nt = cdiv64(sk > 1 ? d.N : d.n_store, BN);
+  const int nsteps = d.CinP / BK;
+  const int sps = (nsteps + sk - 1) / sk;
+  if (sk > 1 && (int64_t)(sk - 1) * sps >= nsteps) return VS_ERR_BAD_ARG;
+  if (mt * nt * sk > 0x7fffffffLL || M > 0x7fffffffLL) return VS_ERR_UNSUPPORTED;
+  if ((int64_t)GBM * std::max<int64_t>(std::max<int64_t>(d.out_ld, d.res ? d.res_ld : 0), sk > 1 ? d.splitk_ld : 0) * 4 >= (1LL << 31)) return VS_ERR_UNSUPPORTED;
+  if (vs_max_lds_bytes() < BIG_NS * (A_STAGE + 2 * TN * 2048)) return VS_ERR_UNSUPPORTED;
+  static const bool raster = [] { const char* e = getenv("VS_GEMM_PL_RASTER"); return !(e && e[0] == '0'); }();
+  const int per_xcd = (raster && mt * nt >= 2 * vs_num_cus()) ? (int)((mt * nt + 7) / 8) : 0;
+  const int64_t grid = per_xcd > 0 ? (int64_t)8 * per_xcd * sk : mt * nt * sk;
+  hipLaunchKernelGGL((gemm_pl_big_kernel<TN>), dim3((unsigned)grid), dim3(256), 0, st, d, (int)M, (int)mt, (int)nt, sps, per_xcd);
+  int rc = vs_launch_status();
+  if (rc != VS_OK || sk == 1) return rc;
+  return vs_splitk_epilogue(d, (int)M, st);
+}
+
 // fp32 rows [rows][ld] (optionally x * scale[frame][c] + shift[c]: GRN apply, common.py:166-169) -> operand planes [2][C/16][rows][16]
 __global__ __launch_bounds__(256) void to_planes_affine_kernel(const float* __restrict__ x, const int64_t rows, const int C, const int64_t ld,
                                                                const float a_mul, const float* __restrict__ scale, const int64_t scale_ld,
@@ -422,11 +644,13 @@ int launch_gpl(const vs_conv_desc_t& d, hipStream_t st) {
 
 }  // namespace
 
-// tile 24 = 256 rows x 192 columns, tile 25 = 256 rows x 128 columns.  Preconditions are checked by vs_conv_gemm.
+// tile 24 = 256 rows x 192 columns, tile 25 = 256 rows x 128 columns, tile 27 = 256 rows x 384 columns (one wave per SIMD).  Preconditions are
+// checked by vs_conv_gemm.
 int vs_gemm_pl_dispatch(const vs_conv_desc_t& d, int tile, hipStream_t st) {
   switch (tile) {
     case 24: return launch_gpl<3>(d, st);
     case 25: return launch_gpl<2>(d, st);
+    case 27: return launch_gpl_big<4>(d, st);
     default: return VS_ERR_UNSUPPORTED;
   }
 }

@@ -286,6 +286,7 @@ class HipEngine:
         # the wave-specialised GEMM's producers set its K loop's pace (profiles/r05a / r05c); with their lanes all working in both half steps the
         # kernel alone is 49.9 us against 56.3 + 13 (tools/bench_gemm.py ksweep2) and detect of 32 frames 3.725 -> 3.651 ms (median of five
         # alternating runs, profiles/r05o_detect_pw2_tile26.json).  VIDEOSEAL_PW2_NARROW=0: the K-slice form
+        self.gemm_big = os.environ.get("VIDEOSEAL_GEMM_BIG", "0") == "1"                  # planes GEMMs of >= 3 rounds on 256 x 256 tiles, one wave per SIMD (round 6)
         self.grn_straddle = os.environ.get("VIDEOSEAL_GRN_STRADDLE", "1") != "0"         # GRN statistics from the planes GEMM's epilogue for HW % 32 != 0 (round 6)
         self.grn_fold = os.environ.get("VIDEOSEAL_GRN_FOLD", "1") != "0"                 # GRN finish inside the wave-specialised pwconv2 GEMM (round 6)
         self.pw2_narrow = os.environ.get("VIDEOSEAL_PW2_NARROW", "1") != "0"
@@ -1230,6 +1231,12 @@ class HipEngine:
             tnpl = self.buf(f"st{sti}.npl", cur.rows * pw1w.CinP).view(torch.int16) if pl1 else None
             hpl = self.buf(f"st{sti}.hpl", cur.rows * hh.ld).view(torch.int16) if pl2 else None
             ptile = N.CONV_TILE_HI | 8
+            # round 6: 256 x 256 tiles with one wave per SIMD (tile 27) for the GEMMs with several rounds of 256 x 192 tiles per launch -- those run at the
+            # chip's LDS-DMA stream rate, and the larger tile moves 15 % fewer operand bytes per FLOP (ChunkySeal; VIDEOSEAL_GEMM_BIG=0 keeps tile 24)
+            big1 = self.gemm_big and pl1 and ((cur.rows + 255) // 256) * ((4 * Cc + 255) // 256) >= 3 * 256
+            big2 = self.gemm_big and pl2 and sk2 == 1 and ((cur.rows + 255) // 256) * ((Cc + 255) // 256) >= 3 * 256
+            ptile1 = (N.CONV_TILE_HI | 11) if big1 else ptile
+            ptile2 = (N.CONV_TILE_HI | 11) if big2 else ptile
             fused = (self.fused_blocks and self.arith == 2 and X["stages"][sti] and X["stages"][sti][0].get("fuse") is not None
                      and pw1w.CinP == Cc and bool(L.vs_cnx_block_supported(Cc, cur.rows, HW)))
             if fused and tnpl is None:
@@ -1262,7 +1269,7 @@ class HipEngine:
                     N.check(L.vs_dwconv7_ln(N.ptr(cur.t), B, cur.H, cur.W, Cc, cur.ld, N.ptr(blk["wdw"]), N.ptr(blk["bdw"]), N.ptr(blk["lnw"]),
                                             N.ptr(blk["lnb"]), 1e-6, N.ptr(tn.t), tn.ld, st), "vs_dwconv7_ln")
                     self._note_absmax((sti, bj, "pw1"), tn.t, tn.rows * tn.ld)
-                kw1 = dict(in_pl=tnpl, tile_hint=ptile) if bpl1 else dict(kwa1)
+                kw1 = dict(in_pl=tnpl, tile_hint=ptile1) if bpl1 else dict(kwa1)
                 if self.prof_extractor and sti == 2:      # bench.py --detect-only: the dominant GEMM of an extractor-only workload
                     kw1["prof"] = (f"{'gemm_pl_kernel' if bpl1 else 'gemm1x1_pc_kernel / conv_gemm_kernel'}: ConvNeXt stage-2 pwconv1 "
                                    f"{Cc}->{4 * Cc} @{cur.H}x{cur.W}")
@@ -1292,7 +1299,7 @@ class HipEngine:
                 if bpl2:              # GRN apply + operand split in one pass over h, then the planes GEMM (K split by the shape rule)
                     N.check(L.vs_to_planes_affine(N.ptr(hh.t), hh.rows, hh.ld, hh.ld, A_MUL_GRN, N.ptr(scale), hh.ld, N.ptr(blk["beta"]), HW,
                                                   N.ptr(hpl), st), "vs_to_planes_affine")
-                    self.conv(hh, blk["pw2"], cur, res=cur, in_pl=hpl, tile_hint=ptile, split_k=sk2, a_mul=A_MUL_GRN)
+                    self.conv(hh, blk["pw2"], cur, res=cur, in_pl=hpl, tile_hint=ptile2, split_k=sk2, a_mul=A_MUL_GRN)
                 elif (HW % 64 == 0 or not self.use_split) and not calib:
                     kn = dict(kwa2)
                     # round 5: where 128-row x 128-column tiles would need K slices to occupy the CUs (stage 2: 64 x 3 tiles -> 2 slices + an
