@@ -22,5 +22,13 @@ done
 for P in FETCH_SIZE WRITE_SIZE; do
   timeout 200 rocprofv3 --pmc $P --output-format csv -d $O/calib -o $P -- python $R/tools/calib_fetch.py > $O/calib_$P.log 2>&1
 done
+# round 6: the extractor alone and the ChunkySeal leg (kernel statistics), and the standing out-of-bounds probe -- the kernel / augmentation / end-to-end
+# tests once more with every tensor its own hipMalloc (tests/conftest.py --no-caching-allocator; hipGraph tests skipped)
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O -o detect -- python $R/bench.py --detect-only --no-cpu-baseline --no-kernel-timers --steps 20 --warmup 2 > $O/detect.log 2>&1
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O -o chunky -- python $R/bench.py --detect-only --card chunkyseal --size 1024 --batch 16 --steps 12 --warmup 2 --no-cpu-baseline --no-kernel-timers > $O/chunky.log 2>&1
+cd $R
+python bench.py --detect-only --no-cpu-baseline --steps 40 --warmup 5 > $O/bench_detect_only.json 2> $O/bench_detect_only.err
+timeout 1200 python -m pytest tests/test_gpu_kernels.py tests/test_gpu_aug.py tests/test_gpu_e2e.py tests/test_gpu_fwd.py -m gpu -q --no-caching-allocator > $O/pytest_no_caching_allocator.log 2>&1
+tail -2 $O/pytest_no_caching_allocator.log
 rm -f $O/*_kernel_trace.csv $O/*agent_info.csv $O/pmc/*agent_info.csv $O/calib/*agent_info.csv
 ls $O $O/pmc
