@@ -639,6 +639,12 @@ def main():
         # the other BASELINE configs as short legs of the same command, each with its own roofline fractions
         def leg(extra, steps=5, warmup=2):
             a = parse_args(["--gpus", str(args.gpus), "--steps", str(steps), "--warmup", str(warmup), "--no-cpu-baseline", "--no-extra"] + extra)
+            # the previous leg's model and workspace are garbage by now, but torch's caching allocator keeps their blocks RESERVED in this process:
+            # hand them back before the next leg builds its own (ChunkySeal's 1.8 B parameters + packed images are ~33 GB per rank; with the
+            # one-device preflight's eight ranks sharing 288 GB the reserved leftovers of the earlier legs were the difference to an out-of-memory)
+            import gc
+            gc.collect()
+            torch.cuda.empty_cache()
             try:
                 r = run(a)
             except Exception as e:          # the headline line must survive a failing extra leg (one process: with several ranks a
