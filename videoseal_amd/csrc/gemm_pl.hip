@@ -425,22 +425,16 @@ __global__ __launch_bounds__(256, 1) void gemm_pl_big_kernel(const vs_conv_desc_
     a_frag[i] = (2 * p + (g ^ ((p >> 3) & 1))) * 16;
   }
   const int b_frag = A_STAGE + (wn * TN) * 1024 + (2 * r + (g ^ ((r >> 3) & 1))) * 16;
-  // two complete fragment sets (lo_a, hi_a, lo_b, hi_b: 4 x 16 registers each at TN = 4): ALL fragments of step s + 1 are requested at the start of
-  // step s, a whole step (48 MFMAs, ~1500 cycles) before their first use.  (The first version rotated four single banks and read each bank one MFMA
-  // group ahead; hipcc's `s_waitcnt lgkmcnt(0)` in front of the next group then also waited for the reads just issued: 9 % slower than tile 24.)
-  struct Frag { bf16x8 lo_a[TM], hi_a[TM], lo_b[TN], hi_b[TN]; };
-  Frag F0, F1;
-  auto load = [&](Frag& F, const int s) __attribute__((always_inline)) {
-    const unsigned char* Ab = smem + (s % BIG_NS) * STAGE;
-    const unsigned char* Bb = Ab + b_frag;
+  bf16x8 X[TM], Y[TN], Z[TM], W[TN];             // fragment banks (roles rotate, see below)
+  auto ld_a = [&](bf16x8 (&F)[TM], const int s, const int plane) __attribute__((always_inline)) {
+    const unsigned char* Ab = smem + (s % BIG_NS) * STAGE + plane * (512 * 16);
 #pragma unroll
-    for (int i = 0; i < TM; ++i) F.hi_a[i] = *reinterpret_cast<const bf16x8*>(Ab + a_frag[i]);
+    for (int i = 0; i < TM; ++i) F[i] = *reinterpret_cast<const bf16x8*>(Ab + a_frag[i]);
+  };
+  auto ld_b = [&](bf16x8 (&F)[TN], const int s, const int plane) __attribute__((always_inline)) {
+    const unsigned char* Bb = smem + (s % BIG_NS) * STAGE + b_frag + plane * (BN * 32);
 #pragma unroll
-    for (int i = 0; i < TM; ++i) F.lo_a[i] = *reinterpret_cast<const bf16x8*>(Ab + 512 * 16 + a_frag[i]);
-#pragma unroll
-    for (int j = 0; j < TN; ++j) F.hi_b[j] = *reinterpret_cast<const bf16x8*>(Bb + j * 1024);
-#pragma unroll
-    for (int j = 0; j < TN; ++j) F.lo_b[j] = *reinterpret_cast<const bf16x8*>(Bb + BN * 32 + j * 1024);
+    for (int j = 0; j < TN; ++j) F[j] = *reinterpret_cast<const bf16x8*>(Bb + j * 1024);
   };
   auto mm = [&](const bf16x8 (&A)[TM], const bf16x8 (&B)[TN]) __attribute__((always_inline)) {
 #pragma unroll
@@ -454,31 +448,41 @@ __global__ __launch_bounds__(256, 1) void gemm_pl_big_kernel(const vs_conv_desc_
     __builtin_amdgcn_s_waitcnt(0xC07F);
     __builtin_amdgcn_s_barrier();
   };
-  auto step = [&](const Frag& Fc, Frag& Fn, const int s, auto more) __attribute__((always_inline)) {
-    if constexpr (decltype(more)::value) load(Fn, s + 1);      // (tile s + 1 has landed: finish(s - 1))
-    if (s + BIG_NS - 1 < nsteps) dma(s + BIG_NS - 1);
-    mm(Fc.lo_a, Fc.hi_b);                         // q0
-    mm(Fc.hi_a, Fc.lo_b);                         // q1
-    mm(Fc.hi_a, Fc.hi_b);                         // q2
-    finish(s);
-  };
 
   for (int t = 0; t < BIG_NS - 1 && t < nsteps; ++t) dma(t);
   gwait_vm<0>();
   __builtin_amdgcn_s_barrier();
-  load(F0, 0);
+  // One K16 step with the banks in the roles (LOA, HIB, HIA, LOB).  Its own hi_a / lo_b are read at its start (behind the previous step's
+  // barrier; first needed by q1, one MFMA group later); lo_a of step s + 1 goes to LOA as soon as q0 has issued, hi_b of step s + 1 to the LOB
+  // bank as soon as q1 has issued -- so the next step runs with HIB and LOB swapped.
+  auto step = [&](const int s, bf16x8 (&LOA)[TM], bf16x8 (&HIB)[TN], bf16x8 (&HIA)[TM], bf16x8 (&LOB)[TN], auto first) __attribute__((always_inline)) {
+    if constexpr (!decltype(first)::value) {
+      ld_a(HIA, s, 0);
+      ld_b(LOB, s, 1);
+    }
+    mm(LOA, HIB);                                 // q0: lo_a x hi_b
+    __builtin_amdgcn_sched_barrier(0);
+    if (s + BIG_NS - 1 < nsteps) dma(s + BIG_NS - 1);
+    const bool more = s + 1 < nsteps;
+    if (more) ld_a(LOA, s + 1, 1);
+    mm(HIA, LOB);                                 // q1: hi_a x lo_b
+    __builtin_amdgcn_sched_barrier(0);
+    if (more) ld_b(LOB, s + 1, 0);
+    mm(HIA, HIB);                                 // q2: hi_a x hi_b
+    finish(s);
+  };
+  ld_a(X, 0, 1);
+  ld_b(Y, 0, 0);
+  ld_a(Z, 0, 0);
+  ld_b(W, 0, 1);
   __builtin_amdgcn_s_waitcnt(0xC07F);
-  int s = 0;
-  for (; s + 2 < nsteps; s += 2) {
-    step(F0, F1, s, std::true_type{});
-    step(F1, F0, s + 1, std::true_type{});
+  step(0, X, Y, Z, W, std::true_type{});
+  int s = 1;
+  for (; s + 1 < nsteps; s += 2) {
+    step(s, X, W, Z, Y, std::false_type{});
+    step(s + 1, X, Y, Z, W, std::false_type{});
   }
-  if (s + 1 < nsteps) {
-    step(F0, F1, s, std::true_type{});
-    step(F1, F0, s + 1, std::false_type{});
-  } else {
-    step(F0, F1, s, std::false_type{});
-  }
+  if (s < nsteps) step(s, X, W, Z, Y, std::false_type{});
 
   // ---- epilogue (as gemm_pl_kernel)
   scale_all<TM, TN>(acc, d.acc_mul);
