@@ -1429,3 +1429,102 @@ def test_gemm_planes_big_tile(case):
     if sumsq:
         n = ((B * HW + 31) // 32) * (2 if sumsq > 1 else 1) * Nn
         assert torch.equal(outs[0][1][:n], outs[1][1][:n])
+
+
+def _guard_i16(t: torch.Tensor):
+    """int16 operand planes between two areas of f16 NaNs (0x7E00)"""
+    flat = t.contiguous().flatten()
+    buf = torch.full((2 * GUARD + flat.numel() + 2 * GUARD,), 0x7E00, device=t.device, dtype=torch.int16)
+    buf[2 * GUARD:2 * GUARD + flat.numel()] = flat
+    return buf, buf[2 * GUARD:2 * GUARD + flat.numel()]
+
+
+@pytest.mark.parametrize("case", [c for c in GEMM_PC_CASES if c[9] == 1] + [c for c in GEMM_PC_CASES if c[9] > 1][:2])
+def test_wave_specialised_gemm_ignores_and_preserves_what_surrounds_its_tensors(eng, case):
+    """red zones around the operands of gemm1x1_pc (tile codes 17 / 18 / 26): activations, GRN scale rows, residual and bias between NaN guards, the
+    output between sentinels -- the ragged last tiles re-read clamped rows / column groups whose values must never reach a stored element"""
+    if not eng.use_split:
+        pytest.skip("split back-end only")
+    B, H, W, K, Nn, act, grn, use_res, tl, sk = case
+    if tl == 10 and eng.arith != 2:
+        pytest.skip("tile 26 exists in the 2 x f16 arithmetic only")
+    g = torch.Generator().manual_seed(hash(case) % 1000)
+    HW = H * W
+    h = torch.randn(B, HW, K, generator=g)
+    sc = (1 + 0.3 * torch.randn(B, K, generator=g)).contiguous()
+    sh = (0.1 * torch.randn(K, generator=g)).contiguous()
+    w = torch.randn(Nn, K, generator=g) / math.sqrt(K)
+    bias = torch.randn(Nn, generator=g)
+    ld = (Nn + 3) // 4 * 4
+    res = torch.zeros(B, HW, ld)
+    res[..., :Nn] = torch.randn(B, HW, Nn, generator=g)
+    wt, cp = pack_conv(w[:, :, None, None].to(DEV), K)
+
+    def run(guarded):
+        keep = []
+        def place(t, fill):
+            if not guarded:
+                return dv(t)
+            buf, view = _guarded(t.to(DEV), fill)
+            keep.append((buf, fill))
+            return view
+        hd, scd, shd, bd, rd = place(h, float("nan")), place(sc, float("nan")), place(sh, float("nan")), place(bias, float("nan")), place(res, float("nan"))
+        od = place(torch.full((B * HW * ld,), 3.0), -7.0)
+        kw = dict(act=act)
+        if grn:
+            kw.update(a_scale=scd, a_scale_ld=K, a_shift=shd)
+        eng.conv(Act(hd, B, H, W, K, K), ConvW(wt, bd, Nn, 1, 1, cp), Act(od, B, H, W, Nn, ld), res=(Act(rd, B, H, W, Nn, ld) if use_res else None),
+                 tile_hint=N.CONV_TILE_HI | tl, split_k=sk, **kw)
+        torch.cuda.synchronize()
+        for buf, fill in keep:
+            assert _guards_intact(buf, fill)
+        return od.clone()
+    want, got = run(False), run(True)
+    assert torch.isfinite(got).all() and torch.equal(got, want)
+
+
+@pytest.mark.parametrize("case", [c for c in GEMM_PL_CASES if c[9] == 1][:7] + [GEMM_PL_CASES[3]])
+def test_planes_gemm_ignores_and_preserves_what_surrounds_its_tensors(case):
+    """the same for the all-DMA planes GEMM (tile codes 24 / 25 and the one-wave-per-SIMD tile 27): operand planes between f16 NaNs, residual / bias between
+    fp32 NaNs, output and GRN partials between sentinels"""
+    B, H, W, K, Nn, act, grn, res, tile, sk, sumsq = case
+    eng = Eng(arith=2)
+    g = torch.Generator().manual_seed(77)
+    HW = H * W
+    x = torch.randn(B, HW, K, generator=g)
+    w = torch.randn(Nn, K, generator=g) / math.sqrt(K)
+    bias = torch.randn(Nn, generator=g)
+    r = torch.randn(B, HW, Nn, generator=g)
+    wt, cp = pack_conv(w[:, :, None, None].to(DEV), K)
+    pl0 = torch.empty(B * HW * K * 2, dtype=torch.int16, device=DEV)
+    xd = dv(x)
+    N.check(eng.lib.vs_to_planes(N.ptr(xd), B * HW, K, K, 16.0, N.ptr(pl0), N.stream()), "to_planes")
+    torch.cuda.synchronize()
+    for t in (tile, 27):
+        outs = []
+        for guarded in (False, True):
+            keep = []
+            def place(tt, fill):
+                if not guarded:
+                    return dv(tt)
+                buf, view = _guarded(tt.to(DEV), fill)
+                keep.append((buf, fill))
+                return view
+            if guarded:
+                pbuf, pl = _guard_i16(pl0)
+            else:
+                pbuf, pl = None, pl0
+            bd, rd = place(bias, float("nan")), place(r.contiguous(), float("nan"))
+            od = place(torch.full((B * HW * Nn,), 3.0), -7.0)
+            part = place(torch.full((((B * HW + 31) // 32) * Nn,), 5.0), -7.0) if sumsq else None
+            eng.conv(Act(xd, B, H, W, K, K), ConvW(wt, bd, Nn, 1, 1, cp), Act(od, B, H, W, Nn, Nn), act=act, res=(Act(rd, B, H, W, Nn, Nn) if res else None),
+                     tile_hint=N.CONV_TILE_HI | (t - 16), in_pl=pl, split_k=sk, sumsq=part, a_mul=16.0, arith=2)
+            torch.cuda.synchronize()
+            for buf, fill in keep:
+                assert _guards_intact(buf, fill)
+            if pbuf is not None:
+                assert (pbuf[:2 * GUARD] == 0x7E00).all() and (pbuf[-2 * GUARD:] == 0x7E00).all()
+            outs.append((od.clone(), part.clone() if part is not None else None))
+        assert torch.isfinite(outs[1][0]).all() and torch.equal(outs[0][0], outs[1][0])
+        if sumsq:
+            assert torch.equal(outs[0][1], outs[1][1])
