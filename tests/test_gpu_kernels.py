@@ -1528,3 +1528,33 @@ def test_planes_gemm_ignores_and_preserves_what_surrounds_its_tensors(case):
         assert torch.isfinite(outs[1][0]).all() and torch.equal(outs[0][0], outs[1][0])
         if sumsq:
             assert torch.equal(outs[0][1], outs[1][1])
+
+
+@pytest.mark.parametrize("C_,ld,rows,act", [(96, 96, 4099, 0), (192, 192, 1000, 2), (384, 384, 257, 0), (768, 768, 130, 2), (724, 736, 63 * 5, 0), (1448, 1472, 97, 0),
+                                            (2896, 2912, 33, 2), (20, 20, 77, 1), (100, 128, 50, 0)])
+def test_layernorm_lanes_form_equals_the_wave_per_row_form(C_, ld, rows, act):
+    """vs_layernorm_act, round 6: LPP lanes per row with the row in registers (8 lanes for 96 channels ... 64 lanes x 12 float4 for ChunkySeal's 2896)
+    against the one-wave-per-row kernel (development switch 7) and torch: the mean / variance sums run in another order -> fp32 rounding; pad lanes of
+    the output (ld > C) are written as zeros by both"""
+    L = N.lib()
+    g = torch.Generator().manual_seed(C_ + rows)
+    x = torch.zeros(rows, ld)
+    x[:, :C_] = torch.randn(rows, C_, generator=g) * 2 + 0.5
+    w, b = torch.rand(C_, generator=g) + 0.5, torch.randn(C_, generator=g) * 0.1
+    xd, wd, bd = dv(x), dv(w), dv(b)
+    outs = []
+    for form in (0, 1):
+        o = torch.full((rows, ld), 9.0, device=DEV)
+        L.vs_debug_set(7, form)
+        try:
+            N.check(L.vs_layernorm_act(N.ptr(xd), rows, C_, ld, N.ptr(wd), N.ptr(bd), 1e-6, act, N.ptr(o), ld, N.stream()), "ln")
+            torch.cuda.synchronize()
+        finally:
+            L.vs_debug_set(7, 0)
+        outs.append(o.cpu())
+    ref = F.layer_norm(x[:, :C_], (C_,), w, b, 1e-6)
+    ref = {0: ref, 1: F.relu(ref), 2: F.gelu(ref)}[act]
+    for o in outs:
+        assert (o[:, :C_] - ref).abs().max().item() < 3e-6 * max(1.0, ref.abs().max().item())
+        assert (o[:, C_:] == 0).all()
+    assert (outs[0] - outs[1]).abs().max().item() < 3e-6 * max(1.0, ref.abs().max().item())

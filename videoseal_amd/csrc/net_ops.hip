@@ -4,6 +4,7 @@
 // All activations are NHWC fp32 with a channel stride `ld` (multiple of 4, pad lanes kept at zero).
 #include <algorithm>
 #include <cstdlib>
+#include <cstring>
 
 #include "conv_common.h"
 
@@ -34,6 +35,68 @@ __global__ __launch_bounds__(256) void layernorm_act_kernel(const float* __restr
     float y = 0.f;
     if (c < C) y = vs_apply_act(w[c] * ((xr[c] - mean) / den) + b[c], act);
     orow[c] = y;
+  }
+}
+
+// Round 6: LPP lanes per row, the row in registers as 16-byte vectors (<= VMAX float4 per lane), 256 / LPP rows per workgroup.  The wave-per-row
+// kernel above reads a 96-channel row with 1.5 scalar passes per phase, three phases and two 6-step butterflies per row -- one 384-byte row per wave
+// at a time: 52 us for the 50 MB stem / first down-sampler tensors (1.9 TB/s in + out).  Here eight lanes share a 96-channel row (three float4 each,
+// 128 contiguous bytes per row and load instruction), the two reductions are log2(LPP) xor steps, and a wave normalises eight rows at once.  Same
+// expression per element (w * ((x - mean) / den) + b); the sums of the mean and the variance run over the row in a different order: fp32 rounding.
+template <int LPP, int VMAX>
+__global__ __launch_bounds__(256) void layernorm_act_lanes_kernel(const float* __restrict__ x, int64_t rows, int C, int64_t ld,
+                                                                  const float* __restrict__ w, const float* __restrict__ b, float eps, int act,
+                                                                  float* __restrict__ out, int64_t out_ld) {
+  constexpr int RPB = 256 / LPP;
+  const int q = threadIdx.x & (LPP - 1);
+  const int64_t row = (int64_t)blockIdx.x * RPB + (threadIdx.x / LPP);
+  const bool live = row < rows;
+  const int C4 = (C + 3) >> 2, O4 = (int)(out_ld >> 2);
+  const float* xr = x + (live ? row : rows - 1) * ld;          // (rows past the end: a valid address, nothing stored -- the shuffles need every lane)
+  f32x4 v[VMAX];
+  float s = 0.f;
+#pragma unroll
+  for (int k = 0; k < VMAX; ++k) {
+    const int c4 = q + k * LPP;
+    v[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (c4 < C4) {
+      v[k] = *reinterpret_cast<const f32x4*>(xr + 4 * c4);
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        if (4 * c4 + e < C) s += v[k][e];
+    }
+  }
+#pragma unroll
+  for (int o = LPP / 2; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+  const float mean = s / (float)C;
+  float qv = 0.f;
+#pragma unroll
+  for (int k = 0; k < VMAX; ++k) {
+    const int c4 = q + k * LPP;
+    if (c4 < C4) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        if (4 * c4 + e < C) { const float dlt = v[k][e] - mean; qv += dlt * dlt; }
+    }
+  }
+#pragma unroll
+  for (int o = LPP / 2; o > 0; o >>= 1) qv += __shfl_xor(qv, o, 64);
+  const float den = sqrtf(qv / (float)C + eps);
+  if (!live) return;
+  float* orow = out + row * out_ld;
+#pragma unroll
+  for (int k = 0; k < VMAX; ++k) {
+    const int c4 = q + k * LPP;
+    if (c4 < O4) {
+      f32x4 o = {0.f, 0.f, 0.f, 0.f};
+      if (c4 < C4) {
+        const f32x4 wv = *reinterpret_cast<const f32x4*>(w + 4 * c4), bv = *reinterpret_cast<const f32x4*>(b + 4 * c4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          if (4 * c4 + e < C) o[e] = vs_apply_act(wv[e] * ((v[k][e] - mean) / den) + bv[e], act);
+      }
+      *reinterpret_cast<f32x4*>(orow + 4 * c4) = o;
+    }
   }
 }
 
@@ -983,6 +1046,23 @@ extern "C" int vs_layernorm_act(const float* x, int64_t rows, int C, int64_t ld,
     if (C <= 16) hipLaunchKernelGGL(layernorm_act_small_kernel<4>, dim3(g), dim3(256), 0, (hipStream_t)stream, x, rows, C, ld, w, b, eps, act, out, out_ld);
     else if (C <= 32) hipLaunchKernelGGL(layernorm_act_small_kernel<8>, dim3(g), dim3(256), 0, (hipStream_t)stream, x, rows, C, ld, w, b, eps, act, out, out_ld);
     else hipLaunchKernelGGL(layernorm_act_small_kernel<16>, dim3(g), dim3(256), 0, (hipStream_t)stream, x, rows, C, ld, w, b, eps, act, out, out_ld);
+    return vs_launch_status();
+  }
+  // lanes-per-row form (round 6): 16-byte aligned rows, the output's pad lanes within reach of the lanes that own the row; the affine parameters
+  // must be readable in whole float4 (the engine pads them to ld; vs_layernorm_act's contract says C entries: only C % 4 == 0 takes this form then)
+  const int C4 = (C + 3) / 4, O4 = (int)(out_ld / 4);
+  static const bool env_wave = [] { const char* e = getenv("VIDEOSEAL_LN"); return e && !strcmp(e, "wave"); }();      // A/B handle
+  if (!env_wave && vs_debug_get(VS_DBG_LN_FORM) != 1 && ld % 4 == 0 && out_ld % 4 == 0 && C % 4 == 0 && O4 <= 64 * 12 &&
+      (((uintptr_t)x | (uintptr_t)out | (uintptr_t)w | (uintptr_t)b) & 15) == 0 && rows < (1LL << 31)) {
+    const int n4 = O4 > C4 ? O4 : C4;
+    hipStream_t st = (hipStream_t)stream;
+#define VS_LN_LAUNCH(LPP, VMAX) hipLaunchKernelGGL((layernorm_act_lanes_kernel<LPP, VMAX>), dim3((unsigned)cdiv64(rows, 256 / LPP)), dim3(256), 0, st, x, rows, C, ld, w, b, eps, act, out, out_ld)
+    if (n4 <= 8 * 4) VS_LN_LAUNCH(8, 4);
+    else if (n4 <= 16 * 4) VS_LN_LAUNCH(16, 4);
+    else if (n4 <= 32 * 4) VS_LN_LAUNCH(32, 4);
+    else if (n4 <= 64 * 4) VS_LN_LAUNCH(64, 4);
+    else VS_LN_LAUNCH(64, 12);
+#undef VS_LN_LAUNCH
     return vs_launch_status();
   }
   hipLaunchKernelGGL(layernorm_act_kernel, dim3((unsigned)cdiv64(rows, 4)), dim3(256), 0, (hipStream_t)stream, x, rows, C, ld,
