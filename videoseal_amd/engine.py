@@ -975,6 +975,9 @@ class HipEngine:
         if not self.planes_splitk:
             return 0
         spt = x.C // 16
+        force = int(os.environ.get("VIDEOSEAL_PLANES_SK", "0"))        # experiments only (tools/r06_sk.sh): another slice count for launches below 200 tiles
+        if force > 1 and spt % force == 0:
+            return force
         for sk in (2, 3, 4, 6, 8, 12):
             cps = (spt + sk - 1) // sk
             if cps >= 2 and (sk - 1) * cps < spt and tiles * sk >= 192:
