@@ -153,6 +153,10 @@ int vs_to_planes_affine(const float* x, int64_t rows, int C, int64_t ld, float a
 /* LayerNorm over the channel dim of [rows][ld] (+ optional activation).  common.py:131-155 (both data formats). */
 int vs_layernorm_act(const float* x, int64_t rows, int C, int64_t ld, const float* w, const float* b, float eps,
                      int act, float* out, int64_t out_ld, void* stream);
+/* (round 6) The LayerNorm in front of a 2 x 2 / stride-2 down-sampling conv (convnext.py:109-117) written as that conv's patch matrix:
+ * out [B][H/2][W/2][4 C], tap-major (ky, kx) then channel -- the conv is then a 1x1 vs_conv_gemm over rows of K = 4 C with the same packed weights.
+ * C % 4 == 0 and 16-byte aligned operands, else VS_ERR_UNSUPPORTED (keep vs_layernorm_act + the strided conv). */
+int vs_layernorm_patch2x2(const float* x, int B, int H, int W, int C, int64_t ld, const float* w, const float* b, float eps, float* out, void* stream);
 
 /* ChanRMSNorm over the channel dim of [rows][ld] (common.py:172-179: F.normalize(x, dim=1) * sqrt(C) * gamma, i.e.
  * x / max(||x||_2, 1e-12) * sqrt(C) * gamma[c]) + activation (+ add[row][c]: the ResnetBlock's res_conv branch, unet.py:38-39).

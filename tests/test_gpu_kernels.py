@@ -1558,3 +1558,37 @@ def test_layernorm_lanes_form_equals_the_wave_per_row_form(C_, ld, rows, act):
         assert (o[:, :C_] - ref).abs().max().item() < 3e-6 * max(1.0, ref.abs().max().item())
         assert (o[:, C_:] == 0).all()
     assert (outs[0] - outs[1]).abs().max().item() < 3e-6 * max(1.0, ref.abs().max().item())
+
+
+@pytest.mark.parametrize("B,H,W,C_", [(3, 8, 12, 96), (2, 9, 7, 192), (2, 16, 16, 384), (1, 2, 2, 8), (2, 5, 6, 724)])
+def test_layernorm_into_the_patch_matrix_of_the_downsampling_conv(B, H, W, C_):
+    """vs_layernorm_patch2x2 (round 6): LayerNorm of every pixel written as the patch matrix [B][H/2][W/2][4C] of the 2 x 2 / stride-2 conv behind it
+    (convnext.py:109-117), tap-major (ky, kx): equals vs_layernorm_act followed by the rearrangement (bit for bit: same kernel, other store address);
+    odd maps drop the last row / column like the conv; and the 1x1 GEMM on it with the conv's packed weights equals F.conv2d(stride 2)"""
+    L = N.lib()
+    g = torch.Generator().manual_seed(H * W + C_)
+    x = torch.randn(B, C_, H, W, generator=g) * 2
+    w, b = torch.rand(C_, generator=g) + 0.5, torch.randn(C_, generator=g) * 0.1
+    xa = to_nhwc(x, C_)
+    wd, bd = dv(w), dv(b)
+    flat = torch.empty(B * H * W * C_, device=DEV)
+    N.check(L.vs_layernorm_act(N.ptr(xa.t), B * H * W, C_, C_, N.ptr(wd), N.ptr(bd), 1e-6, 0, N.ptr(flat), C_, N.stream()), "ln")
+    Ho, Wo = H // 2, W // 2
+    pat = torch.full((B * Ho * Wo * 4 * C_,), float("nan"), device=DEV)
+    N.check(L.vs_layernorm_patch2x2(N.ptr(xa.t), B, H, W, C_, C_, N.ptr(wd), N.ptr(bd), 1e-6, N.ptr(pat), N.stream()), "ln patch")
+    torch.cuda.synchronize()
+    ln = flat.view(B, H, W, C_)[:, :2 * Ho, :2 * Wo]
+    want = ln.reshape(B, Ho, 2, Wo, 2, C_).permute(0, 1, 3, 2, 4, 5).reshape(B, Ho, Wo, 4 * C_)
+    assert torch.equal(pat.view(B, Ho, Wo, 4 * C_), want)
+    if C_ % 8 == 0 and Ho * Wo > 0:
+        from videoseal_amd.engine import pack_patch_conv
+        eng = Eng(arith=2)
+        Co = 40
+        cw_ = torch.randn(Co, C_, 2, 2, generator=g) / math.sqrt(4 * C_)
+        cb = torch.randn(Co, generator=g)
+        wt, cp = pack_patch_conv(cw_.to(DEV), C_)
+        out = eng.new_act("dp.o", B, Ho, Wo, Co)
+        eng.conv(Act(pat, B, Ho, Wo, 4 * C_, 4 * C_), ConvW(wt, dv(cb), Co, 1, 1, 2 * cp), out)
+        torch.cuda.synchronize()
+        ref = F.conv2d(F.layer_norm(x.permute(0, 2, 3, 1), (C_,), w, b, 1e-6).permute(0, 3, 1, 2), cw_, cb, stride=2)
+        assert rel_err(from_nhwc(out), ref) < 3e-5

@@ -29,7 +29,7 @@ struct CW {                      // one conv / linear layer on the device
 };
 struct RB { CW c0, c1, res; int cout = 0; };
 struct Up { CW conv; CW gemm; bool lowres = false; float* lnw = nullptr; float* lnb = nullptr; RB rb; };   // gemm: nine taps at the low resolution (vs_upconv_gather_ln)
-struct Down { float* lnw = nullptr; float* lnb = nullptr; CW conv; };
+struct Down { float* lnw = nullptr; float* lnb = nullptr; CW conv, gemm; };      // gemm: the same weights as a 1x1 GEMM on the patch matrix (vs_layernorm_patch2x2)
 struct Blk {
   float *wdw = nullptr, *bdw = nullptr, *lnw = nullptr, *lnb = nullptr, *gamma = nullptr, *beta = nullptr; CW pw1, pw2;
   void* fuse = nullptr; float fm1 = 1.f, fm2 = 1.f;      // weight image of the fused block kernel (vs_cnx_block) and its two power-of-two scales
@@ -241,7 +241,7 @@ struct Packer {
     finish(cw, wt, {}, false);
   }
   // engine.py::pack_patch_conv: kw pixels of a row are one run of kw*pix_ld floats -> KH x 1 conv with Cin' = kw*pix_ld
-  void patch_conv(CW& cw, const std::string& wkey, int cin, int k, int pix_ld, const std::string& bias_key) {
+  void patch_conv(CW& cw, const std::string& wkey, int cin, int k, int pix_ld, const std::string& bias_key, CW* as_gemm = nullptr) {
     const HostT& w = get(wkey);
     if (!w.p) return;
     const int n = (int)(w.n / ((int64_t)cin * k * k));
@@ -255,7 +255,7 @@ struct Packer {
     const HostT& bt = get(bias_key);
     std::vector<float> b;
     if (bt.p) b.assign(bt.p, bt.p + bt.n);
-    finish(cw, wt, b, bt.p != nullptr);
+    finish(cw, wt, b, bt.p != nullptr, as_gemm);
   }
   void bn_fold(const std::string& p, std::vector<float>& s, std::vector<float>& b) {          // engine.py::_bn_fold
     const HostT &w = get(p + ".weight"), &bi = get(p + ".bias"), &mu = get(p + ".running_mean"), &var = get(p + ".running_var");
@@ -623,13 +623,22 @@ struct Runner {
     for (int sti = 0; sti < 4; ++sti) {
       if (sti > 0) {
         const Down& dn = m->down[sti - 1];
-        Act ln = act(B, cur.H, cur.W, cur.C, cur.ld);
-        layernorm(cur, dn.lnw, dn.lnb, ln);
         Ho = cur.H / 2; Wo = cur.W / 2;
-        Act nxt = act(B, Ho, Wo, c.dims[sti], xld(c.dims[sti]));
-        const int geom[7] = {Wo, 2 * ln.ld, 2 * ln.ld, 2, 1, 0, 0};
-        conv(ln, dn.conv, nxt, 1, 0, VS_PAD_ZERO, VS_ACT_NONE, 0, -1, nullptr, nullptr, nullptr, nullptr, 0, nullptr, geom);
-        cur = nxt;
+        if (cur.ld == cur.C && cur.C % 8 == 0 && dn.gemm.CinP == 4 * cur.C && Ho > 0 && Wo > 0) {
+          // engine.py (round 6): LayerNorm straight into the 2 x 2 patch matrix, the conv as a dense GEMM
+          Act lnp = act(B, Ho, Wo, 4 * cur.C, 4 * cur.C);
+          Act nxt = act(B, Ho, Wo, c.dims[sti], xld(c.dims[sti]));
+          if (live()) chk(vs_layernorm_patch2x2(cur.p, B, cur.H, cur.W, cur.C, cur.ld, dn.lnw, dn.lnb, 1e-6f, lnp.p, st));
+          conv(lnp, dn.gemm, nxt);
+          cur = nxt;
+        } else {
+          Act ln = act(B, cur.H, cur.W, cur.C, cur.ld);
+          layernorm(cur, dn.lnw, dn.lnb, ln);
+          Act nxt = act(B, Ho, Wo, c.dims[sti], xld(c.dims[sti]));
+          const int geom[7] = {Wo, 2 * ln.ld, 2 * ln.ld, 2, 1, 0, 0};
+          conv(ln, dn.conv, nxt, 1, 0, VS_PAD_ZERO, VS_ACT_NONE, 0, -1, nullptr, nullptr, nullptr, nullptr, 0, nullptr, geom);
+          cur = nxt;
+        }
       }
       const int Cc = c.dims[sti], HW = cur.H * cur.W;
       Act tn = act(B, cur.H, cur.W, Cc, xld(Cc));
@@ -821,7 +830,7 @@ extern "C" int vs_model_create(const vs_model_cfg_t* cfg, const vs_tensor_t* ten
     const std::string p = cn + ".downsample_layers." + std::to_string(i + 1);
     m->down[i].lnw = P.vec(p + ".0.weight");
     m->down[i].lnb = P.vec(p + ".0.bias");
-    P.patch_conv(m->down[i].conv, p + ".1.weight", cfg->dims[i], 2, xld(cfg->dims[i]), p + ".1.bias");
+    P.patch_conv(m->down[i].conv, p + ".1.weight", cfg->dims[i], 2, xld(cfg->dims[i]), p + ".1.bias", &m->down[i].gemm);
   }
   for (int s = 0; s < 4; ++s) {
     const int Cc = cfg->dims[s], ld = xld(Cc), ld4 = xld(4 * Cc);

@@ -43,14 +43,17 @@ __global__ __launch_bounds__(256) void layernorm_act_kernel(const float* __restr
 // at a time: 52 us for the 50 MB stem / first down-sampler tensors (1.9 TB/s in + out).  Here eight lanes share a 96-channel row (three float4 each,
 // 128 contiguous bytes per row and load instruction), the two reductions are log2(LPP) xor steps, and a wave normalises eight rows at once.  Same
 // expression per element (w * ((x - mean) / den) + b); the sums of the mean and the variance run over the row in a different order: fp32 rounding.
+// pW > 0 (vs_layernorm_patch2x2, round 6): the rows are the pixels of B frames of pH x pW, and pixel (y, x) is stored as tap (y & 1) * 2 + (x & 1) of output
+// row (y / 2, x / 2) -- [B][pH / 2][pW / 2][4 C] dense: the 2 x 2 / stride-2 down-sampling conv behind this LayerNorm (convnext.py:109-117) is then a
+// plain GEMM over rows of K = 4 C (same (ky, kx, c) order as its packed weights), which the wave-specialised kernel runs instead of the generic one.
 template <int LPP, int VMAX>
 __global__ __launch_bounds__(256) void layernorm_act_lanes_kernel(const float* __restrict__ x, int64_t rows, int C, int64_t ld,
                                                                   const float* __restrict__ w, const float* __restrict__ b, float eps, int act,
-                                                                  float* __restrict__ out, int64_t out_ld) {
+                                                                  float* __restrict__ out, int64_t out_ld, int pH, int pW) {
   constexpr int RPB = 256 / LPP;
   const int q = threadIdx.x & (LPP - 1);
   const int64_t row = (int64_t)blockIdx.x * RPB + (threadIdx.x / LPP);
-  const bool live = row < rows;
+  bool live = row < rows;
   const int C4 = (C + 3) >> 2, O4 = (int)(out_ld >> 2);
   const float* xr = x + (live ? row : rows - 1) * ld;          // (rows past the end: a valid address, nothing stored -- the shuffles need every lane)
   f32x4 v[VMAX];
@@ -82,8 +85,17 @@ __global__ __launch_bounds__(256) void layernorm_act_lanes_kernel(const float* _
 #pragma unroll
   for (int o = LPP / 2; o > 0; o >>= 1) qv += __shfl_xor(qv, o, 64);
   const float den = sqrtf(qv / (float)C + eps);
-  if (!live) return;
   float* orow = out + row * out_ld;
+  if (pW > 0 && live) {
+    const int px = (int)(row % pW);
+    const int64_t t = row / pW;
+    const int py = (int)(t % pH);
+    const int64_t fb = t / pH;
+    const int oh = pH >> 1, ow = pW >> 1;
+    live = (py >> 1) < oh && (px >> 1) < ow;             // odd maps: the last row / column has no output pixel (floor, as the stride-2 conv)
+    orow = out + ((fb * oh + (py >> 1)) * ow + (px >> 1)) * (4 * (int64_t)C) + ((py & 1) * 2 + (px & 1)) * C;
+  }
+  if (!live) return;
 #pragma unroll
   for (int k = 0; k < VMAX; ++k) {
     const int c4 = q + k * LPP;
@@ -1056,7 +1068,7 @@ extern "C" int vs_layernorm_act(const float* x, int64_t rows, int C, int64_t ld,
       (((uintptr_t)x | (uintptr_t)out | (uintptr_t)w | (uintptr_t)b) & 15) == 0 && rows < (1LL << 31)) {
     const int n4 = O4 > C4 ? O4 : C4;
     hipStream_t st = (hipStream_t)stream;
-#define VS_LN_LAUNCH(LPP, VMAX) hipLaunchKernelGGL((layernorm_act_lanes_kernel<LPP, VMAX>), dim3((unsigned)cdiv64(rows, 256 / LPP)), dim3(256), 0, st, x, rows, C, ld, w, b, eps, act, out, out_ld)
+#define VS_LN_LAUNCH(LPP, VMAX) hipLaunchKernelGGL((layernorm_act_lanes_kernel<LPP, VMAX>), dim3((unsigned)cdiv64(rows, 256 / LPP)), dim3(256), 0, st, x, rows, C, ld, w, b, eps, act, out, out_ld, 0, 0)
     if (n4 <= 8 * 4) VS_LN_LAUNCH(8, 4);
     else if (n4 <= 16 * 4) VS_LN_LAUNCH(16, 4);
     else if (n4 <= 32 * 4) VS_LN_LAUNCH(32, 4);
@@ -1067,6 +1079,29 @@ extern "C" int vs_layernorm_act(const float* x, int64_t rows, int C, int64_t ld,
   }
   hipLaunchKernelGGL(layernorm_act_kernel, dim3((unsigned)cdiv64(rows, 4)), dim3(256), 0, (hipStream_t)stream, x, rows, C, ld,
                      w, b, eps, act, out, out_ld);
+  return vs_launch_status();
+}
+
+// LayerNorm of every pixel of [B][H][W] (C channels, stride ld) written as the patch matrix of a 2 x 2 / stride-2 conv: out [B][H/2][W/2][4 C]
+// (tap-major (ky, kx), then channel; odd H / W: the last row / column is dropped).  C % 4 == 0, 16-byte aligned operands; otherwise unsupported
+// (the caller keeps vs_layernorm_act + the strided conv).
+extern "C" int vs_layernorm_patch2x2(const float* x, int B, int H, int W, int C, int64_t ld, const float* w, const float* b, float eps, float* out,
+                                     void* stream) {
+  VS_REQUIRE(x && w && b && out && B > 0 && H >= 2 && W >= 2 && C > 0 && ld >= C);
+  const int C4 = C / 4;
+  if (C % 4 != 0 || ld % 4 != 0 || C4 > 64 * 12 || (((uintptr_t)x | (uintptr_t)out | (uintptr_t)w | (uintptr_t)b) & 15) != 0) return VS_ERR_UNSUPPORTED;
+  const int64_t rows = (int64_t)B * H * W;
+  if (rows >= (1LL << 31)) return VS_ERR_UNSUPPORTED;
+  hipStream_t st = (hipStream_t)stream;
+  const int act = VS_ACT_NONE;
+  const int64_t out_ld = C;
+#define VS_LNP_LAUNCH(LPP, VMAX) hipLaunchKernelGGL((layernorm_act_lanes_kernel<LPP, VMAX>), dim3((unsigned)cdiv64(rows, 256 / LPP)), dim3(256), 0, st, x, rows, C, ld, w, b, eps, act, out, out_ld, H, W)
+  if (C4 <= 8 * 4) VS_LNP_LAUNCH(8, 4);
+  else if (C4 <= 16 * 4) VS_LNP_LAUNCH(16, 4);
+  else if (C4 <= 32 * 4) VS_LNP_LAUNCH(32, 4);
+  else if (C4 <= 64 * 4) VS_LNP_LAUNCH(64, 4);
+  else VS_LNP_LAUNCH(64, 12);
+#undef VS_LNP_LAUNCH
   return vs_launch_status();
 }
 

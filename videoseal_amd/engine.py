@@ -287,6 +287,7 @@ class HipEngine:
         # kernel alone is 49.9 us against 56.3 + 13 (tools/bench_gemm.py ksweep2) and detect of 32 frames 3.725 -> 3.651 ms (median of five
         # alternating runs, profiles/r05o_detect_pw2_tile26.json).  VIDEOSEAL_PW2_NARROW=0: the K-slice form
         self.gemm_big = os.environ.get("VIDEOSEAL_GEMM_BIG", "0") == "1"                  # planes GEMMs of >= 3 rounds on 256 x 256 tiles, one wave per SIMD (round 6)
+        self.down_patch = os.environ.get("VIDEOSEAL_DOWN_PATCH", "1") != "0"              # down-sampler LayerNorm -> patch matrix -> dense GEMM (round 6)
         self.grn_straddle = os.environ.get("VIDEOSEAL_GRN_STRADDLE", "1") != "0"         # GRN statistics from the planes GEMM's epilogue for HW % 32 != 0 (round 6)
         self.grn_fold = os.environ.get("VIDEOSEAL_GRN_FOLD", "1") != "0"                 # GRN finish inside the wave-specialised pwconv2 GEMM (round 6)
         self.pw2_narrow = os.environ.get("VIDEOSEAL_PW2_NARROW", "1") != "0"
@@ -447,6 +448,8 @@ class HipEngine:
             X["down"].append(dict(lnw=g(f"{cn}.downsample_layers.{i+1}.0.weight").float().contiguous(),
                                   lnb=g(f"{cn}.downsample_layers.{i+1}.0.bias").float().contiguous(),
                                   conv=ConvW(wd, g(f"{cn}.downsample_layers.{i+1}.1.bias").float().contiguous(), d[i + 1], 2, 1, cp)))
+            # round 6: the same rows [N][ky][kx * ld + c] read as ONE K run of 4 * ld = a 1x1 GEMM on the patch matrix vs_layernorm_patch2x2 writes
+            X["down"][-1]["gemm"] = ConvW(wd, X["down"][-1]["conv"].bias, d[i + 1], 1, 1, 2 * cp)
         X["stages"] = []
         for st in range(4):
             blocks = []
@@ -1189,11 +1192,22 @@ class HipEngine:
         for sti in range(4):
             if sti > 0:
                 dn = X["down"][sti - 1]
-                ln = self.new_act(f"st{sti}.dln", B, cur.H, cur.W, cur.C, cur.ld)
-                self.layernorm(cur, dn["lnw"], dn["lnb"], ln)
                 Ho, Wo = cur.H // 2, cur.W // 2
                 nxt = self.new_act(f"st{sti}.x", B, Ho, Wo, d[sti], self._xld(d[sti]))
-                self.conv(ln, dn["conv"], nxt, geom=(Wo, 2 * ln.ld, 2 * ln.ld, 2, 1, 0, 0))
+                done = False
+                if self.down_patch and cur.ld == cur.C and cur.C % 8 == 0 and dn["gemm"].CinP == 4 * cur.C and Ho > 0 and Wo > 0:
+                    # round 6: LayerNorm straight into the patch matrix [B][H/2][W/2][4C] of the 2 x 2 / stride-2 conv, which then is a dense 1x1
+                    # GEMM (the wave-specialised kernel by the library's rule) instead of the generic strided conv: 72 -> 3x us at 96 -> 192 @32^2
+                    lnp = Act(self.buf(f"st{sti}.dlnp", B * Ho * Wo * 4 * cur.C), B, Ho, Wo, 4 * cur.C, 4 * cur.C)
+                    rc = L.vs_layernorm_patch2x2(N.ptr(cur.t), B, cur.H, cur.W, cur.C, cur.ld, N.ptr(dn["lnw"]), N.ptr(dn["lnb"]), 1e-6, N.ptr(lnp.t), st)
+                    if rc != N.ERR_UNSUPPORTED:
+                        N.check(rc, "vs_layernorm_patch2x2")
+                        self.conv(lnp, dn["gemm"], nxt)
+                        done = True
+                if not done:
+                    ln = self.new_act(f"st{sti}.dln", B, cur.H, cur.W, cur.C, cur.ld)
+                    self.layernorm(cur, dn["lnw"], dn["lnb"], ln)
+                    self.conv(ln, dn["conv"], nxt, geom=(Wo, 2 * ln.ld, 2 * ln.ld, 2, 1, 0, 0))
                 cur = nxt
             Cc = d[sti]
             HW = cur.H * cur.W
