@@ -1579,7 +1579,10 @@ def test_layernorm_into_the_patch_matrix_of_the_downsampling_conv(B, H, W, C_):
     torch.cuda.synchronize()
     ln = flat.view(B, H, W, C_)[:, :2 * Ho, :2 * Wo]
     want = ln.reshape(B, Ho, 2, Wo, 2, C_).permute(0, 1, 3, 2, 4, 5).reshape(B, Ho, Wo, 4 * C_)
-    assert torch.equal(pat.view(B, Ho, Wo, 4 * C_), want)
+    if C_ > 64:
+        assert torch.equal(pat.view(B, Ho, Wo, 4 * C_), want)
+    else:       # (vs_layernorm_act takes its thread-per-row kernel for C <= 64: other summation order)
+        assert (pat.view(B, Ho, Wo, 4 * C_) - want).abs().max().item() < 2e-6 * max(1.0, want.abs().max().item())
     if C_ % 8 == 0 and Ho * Wo > 0:
         from videoseal_amd.engine import pack_patch_conv
         eng = Eng(arith=2)
