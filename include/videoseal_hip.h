@@ -157,6 +157,11 @@ int vs_layernorm_act(const float* x, int64_t rows, int C, int64_t ld, const floa
  * out [B][H/2][W/2][4 C], tap-major (ky, kx) then channel -- the conv is then a 1x1 vs_conv_gemm over rows of K = 4 C with the same packed weights.
  * C % 4 == 0 and 16-byte aligned operands, else VS_ERR_UNSUPPORTED (keep vs_layernorm_act + the strided conv). */
 int vs_layernorm_patch2x2(const float* x, int B, int H, int W, int C, int64_t ld, const float* w, const float* b, float eps, float* out, void* stream);
+/* (round 6) The ConvNeXt stem in one kernel: 4 x 4 patchify conv (3 -> CO channels, stride 4 or 2; convnext.py:100-104) + its LayerNorm, exact fp32
+ * multiply-adds on the vector ALUs.  x: NHWC frames with 4 floats per pixel (rgb + zero lane), wt: the conv's packed rows [CO][4 ky][16 = 4 kx x 4],
+ * out [B][Ho][Wo][out_ld].  CO in {64, 96, 128}, out_ld == CO, 16-byte aligned operands; else VS_ERR_UNSUPPORTED (keep vs_conv_gemm + vs_layernorm_act). */
+int vs_stem_conv_ln(const float* x, int B, int H, int W, int stride, const float* wt, const float* bias, const float* lnw, const float* lnb, float eps,
+                    int CO, float* out, int64_t out_ld, void* stream);
 
 /* ChanRMSNorm over the channel dim of [rows][ld] (common.py:172-179: F.normalize(x, dim=1) * sqrt(C) * gamma, i.e.
  * x / max(||x||_2, 1e-12) * sqrt(C) * gamma[c]) + activation (+ add[row][c]: the ResnetBlock's res_conv branch, unet.py:38-39).

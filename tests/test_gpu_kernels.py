@@ -1595,3 +1595,33 @@ def test_layernorm_into_the_patch_matrix_of_the_downsampling_conv(B, H, W, C_):
         torch.cuda.synchronize()
         ref = F.conv2d(F.layer_norm(x.permute(0, 2, 3, 1), (C_,), w, b, 1e-6).permute(0, 3, 1, 2), cw_, cb, stride=2)
         assert rel_err(from_nhwc(out), ref) < 3e-5
+
+
+@pytest.mark.parametrize("stride,Co,S,B", [(4, 96, 64, 3), (2, 96, 37, 2), (4, 64, 20, 1), (4, 128, 256, 2), (2, 128, 12, 5)])
+def test_stem_conv_and_layernorm_in_one_kernel(stride, Co, S, B):
+    """vs_stem_conv_ln (round 6): the ConvNeXt stem -- 4 x 4 patchify conv + LayerNorm (convnext.py:100-104) -- as exact fp32 multiply-adds on the vector
+    ALUs, four lanes per pixel: against torch (conv2d + layer_norm) and against the two launches it replaces (split-operand GEMM + vs_layernorm_act)"""
+    L = N.lib()
+    g = torch.Generator().manual_seed(stride + Co + S)
+    x = torch.rand(B, 3, S, S + 4, generator=g) * 2 - 1
+    w = torch.randn(Co, 3, 4, 4, generator=g) / 7
+    b = torch.randn(Co, generator=g) * 0.2
+    lw, lb = torch.rand(Co, generator=g) + 0.5, torch.randn(Co, generator=g) * 0.1
+    ref = F.layer_norm(F.conv2d(x, w, b, stride=stride).permute(0, 2, 3, 1), (Co,), lw, lb, 1e-6)
+    xa = to_nhwc(x, 4)
+    wt, cp = pack_patch_conv(w.to(DEV), 4)
+    Ho, Wo = (S - 4) // stride + 1, (S + 4 - 4) // stride + 1
+    out = torch.full((B, Ho, Wo, Co), float("nan"), device=DEV)
+    bd, lwd, lbd = dv(b), dv(lw), dv(lb)
+    N.check(L.vs_stem_conv_ln(N.ptr(xa.t), B, S, S + 4, stride, N.ptr(wt), N.ptr(bd), N.ptr(lwd), N.ptr(lbd), 1e-6, Co, N.ptr(out), Co, N.stream()), "stem")
+    torch.cuda.synchronize()
+    assert (out.cpu() - ref).abs().max().item() < 5e-6 * max(1.0, ref.abs().max().item())
+    eng = Eng(arith=2)
+    t = eng.new_act("stem2.c", B, Ho, Wo, Co)
+    eng.conv(xa, ConvW(wt, bd, Co, 4, 1, cp), t, geom=(Wo, stride * 4, 16, stride, 1, 0, 0))
+    two = torch.empty(B * Ho * Wo * Co, device=DEV)
+    N.check(L.vs_layernorm_act(N.ptr(t.t), B * Ho * Wo, Co, t.ld, N.ptr(lwd), N.ptr(lbd), 1e-6, 0, N.ptr(two), Co, N.stream()), "ln")
+    torch.cuda.synchronize()
+    assert (out.flatten() - two).abs().max().item() < 1e-5 * max(1.0, ref.abs().max().item())
+    # unsupported widths are refused, not mangled
+    assert L.vs_stem_conv_ln(N.ptr(xa.t), B, S, S + 4, stride, N.ptr(wt), N.ptr(bd), N.ptr(lwd), N.ptr(lbd), 1e-6, 100, N.ptr(out), 100, N.stream()) == N.ERR_UNSUPPORTED

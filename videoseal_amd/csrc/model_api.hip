@@ -616,10 +616,16 @@ struct Runner {
     const vs_model_cfg_t& c = m->c;
     const int B = x.B, s = c.stem_stride;
     int Ho = (x.H - 4) / s + 1, Wo = (x.W - 4) / s + 1;
-    Act t = act(B, Ho, Wo, c.dims[0]);
-    { const int geom[7] = {Wo, s * 4, 16, s, 1, 0, 0}; conv(x, m->stem, t, 1, 0, VS_PAD_ZERO, VS_ACT_NONE, 0, -1, nullptr, nullptr, nullptr, nullptr, 0, nullptr, geom); }
     Act cur = act(B, Ho, Wo, c.dims[0], xld(c.dims[0]));
-    layernorm(t, m->stem_lnw, m->stem_lnb, cur);
+    const int co = c.dims[0];
+    if (x.ld == 4 && cur.ld == co && (co == 64 || co == 96 || co == 128) && m->stem.bias) {
+      // engine.py (round 6): patchify conv + LayerNorm in one kernel on the vector ALUs
+      if (live()) chk(vs_stem_conv_ln(x.p, B, x.H, x.W, s, m->stem.wt, m->stem.bias, m->stem_lnw, m->stem_lnb, 1e-6f, co, cur.p, cur.ld, st));
+    } else {
+      Act t = act(B, Ho, Wo, c.dims[0]);
+      { const int geom[7] = {Wo, s * 4, 16, s, 1, 0, 0}; conv(x, m->stem, t, 1, 0, VS_PAD_ZERO, VS_ACT_NONE, 0, -1, nullptr, nullptr, nullptr, nullptr, 0, nullptr, geom); }
+      layernorm(t, m->stem_lnw, m->stem_lnb, cur);
+    }
     for (int sti = 0; sti < 4; ++sti) {
       if (sti > 0) {
         const Down& dn = m->down[sti - 1];

@@ -1105,6 +1105,105 @@ extern "C" int vs_layernorm_patch2x2(const float* x, int B, int H, int W, int C,
   return vs_launch_status();
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Round 6: the extractor's stem -- 4 x 4 patchify conv (3 -> CO channels, stride 4 or 2; convnext.py:100-104) + its LayerNorm -- in ONE kernel on the
+// vector ALUs.  The pair ran as a generic-GEMM launch (K = 48 of the 16-wide matrix instruction's step: 40 us, memory-bound at 2 TB/s) plus a LayerNorm
+// launch over the 50 MB it had just written (25 us).  0.6 GMAC for 32 frames is nothing for fp32 FMAs (exact fp32 products, fp32 accumulation: at least the
+// accuracy of the split-operand matrix path), and the LayerNorm is two 2-step shuffles when FOUR lanes share a pixel (CO / 4 channels each): the lanes of a
+// pixel write 4 x (CO) bytes contiguously, a wave 16 pixels = 6 KiB at CO = 96.  Weights: the packed rows of the conv ([CO][4 ky][16 = 4 kx x (3 + pad)])
+// transposed into LDS as [k][CO] once per workgroup.
+template <int CO>
+__global__ __launch_bounds__(256) void stem_conv_ln_kernel(const float* __restrict__ x, int B, int H, int W, int Ho, int Wo, int stride,
+                                                           const float* __restrict__ wt, const float* __restrict__ bias, const float* __restrict__ lnw,
+                                                           const float* __restrict__ lnb, float eps, float* __restrict__ out, int64_t out_ld) {
+  constexpr int CQ = CO / 4, Q4 = CQ / 4;                   // channels / float4 per lane
+  __shared__ __attribute__((aligned(16))) float s_w[48 * CO];          // [k = ky * 12 + kx * 3 + c][CO]
+  for (int i = threadIdx.x; i < 48 * CO; i += 256) {
+    const int k = i / CO, n = i - k * CO;
+    const int ky = k / 12, r = k - ky * 12, kx = r / 3, c = r - kx * 3;
+    s_w[i] = wt[(int64_t)n * 64 + ky * 16 + kx * 4 + c];
+  }
+  __syncthreads();
+  const int qd = threadIdx.x & 3;
+  const int64_t npix = (int64_t)B * Ho * Wo;
+  const int64_t pix = (int64_t)blockIdx.x * 64 + (threadIdx.x >> 2);
+  const bool live = pix < npix;
+  const int64_t pc = live ? pix : npix - 1;                 // (past the end: a valid pixel, nothing stored -- the shuffles need every lane)
+  const int ox = (int)(pc % Wo);
+  const int64_t t = pc / Wo;
+  const int oy = (int)(t % Ho);
+  const int64_t b = t / Ho;
+  const float* xp = x + ((b * H + (int64_t)oy * stride) * W + (int64_t)ox * stride) * 4;
+  f32x4 acc[Q4];
+#pragma unroll
+  for (int j = 0; j < Q4; ++j) acc[j] = *reinterpret_cast<const f32x4*>(bias + qd * CQ + 4 * j);
+#pragma unroll
+  for (int ky = 0; ky < 4; ++ky) {
+    f32x4 in[4];
+#pragma unroll
+    for (int kx = 0; kx < 4; ++kx) in[kx] = *reinterpret_cast<const f32x4*>(xp + ((int64_t)ky * W + kx) * 4);
+#pragma unroll
+    for (int kx = 0; kx < 4; ++kx)
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        const float v = in[kx][c];
+        const float* wr = s_w + (ky * 12 + kx * 3 + c) * CO + qd * CQ;
+#pragma unroll
+        for (int j = 0; j < Q4; ++j) {
+          const f32x4 wv = *reinterpret_cast<const f32x4*>(wr + 4 * j);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) acc[j][e] = __builtin_fmaf(v, wv[e], acc[j][e]);
+        }
+      }
+  }
+  // LayerNorm over the pixel's CO channels (four lanes): mean, then the squared deviations (common.py:147-155)
+  float sm = 0.f;
+#pragma unroll
+  for (int j = 0; j < Q4; ++j)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) sm += acc[j][e];
+  sm += __shfl_xor(sm, 1, 64);
+  sm += __shfl_xor(sm, 2, 64);
+  const float mean = sm / (float)CO;
+  float qv = 0.f;
+#pragma unroll
+  for (int j = 0; j < Q4; ++j)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { const float dlt = acc[j][e] - mean; qv += dlt * dlt; }
+  qv += __shfl_xor(qv, 1, 64);
+  qv += __shfl_xor(qv, 2, 64);
+  const float den = sqrtf(qv / (float)CO + eps);
+  if (!live) return;
+  float* orow = out + pix * out_ld + qd * CQ;
+#pragma unroll
+  for (int j = 0; j < Q4; ++j) {
+    const f32x4 wv = *reinterpret_cast<const f32x4*>(lnw + qd * CQ + 4 * j), bv = *reinterpret_cast<const f32x4*>(lnb + qd * CQ + 4 * j);
+    f32x4 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) o[e] = wv[e] * ((acc[j][e] - mean) / den) + bv[e];
+    *reinterpret_cast<f32x4*>(orow + 4 * j) = o;
+  }
+}
+
+// x: NHWC frames with 4 floats per pixel (rgb + a zero lane), wt: the stem's packed rows [CO][64] (engine.pack_patch_conv(w, 4)), out [B][Ho][Wo][out_ld].
+// CO in {64, 96, 128} and out_ld == CO, 16-byte aligned operands; otherwise unsupported (the caller keeps the conv + vs_layernorm_act pair).
+extern "C" int vs_stem_conv_ln(const float* x, int B, int H, int W, int stride, const float* wt, const float* bias, const float* lnw, const float* lnb,
+                               float eps, int CO, float* out, int64_t out_ld, void* stream) {
+  VS_REQUIRE(x && wt && bias && lnw && lnb && out && B > 0 && H >= 4 && W >= 4 && (stride == 4 || stride == 2));
+  if ((CO != 64 && CO != 96 && CO != 128) || out_ld != CO ||
+      (((uintptr_t)x | (uintptr_t)wt | (uintptr_t)bias | (uintptr_t)lnw | (uintptr_t)lnb | (uintptr_t)out) & 15) != 0)
+    return VS_ERR_UNSUPPORTED;
+  const int Ho = (H - 4) / stride + 1, Wo = (W - 4) / stride + 1;
+  const int64_t npix = (int64_t)B * Ho * Wo;
+  if (npix >= (1LL << 31) * 16) return VS_ERR_UNSUPPORTED;
+  const dim3 grid((unsigned)cdiv64(npix, 64));
+  hipStream_t st = (hipStream_t)stream;
+  if (CO == 96) hipLaunchKernelGGL(stem_conv_ln_kernel<96>, grid, dim3(256), 0, st, x, B, H, W, Ho, Wo, stride, wt, bias, lnw, lnb, eps, out, out_ld);
+  else if (CO == 64) hipLaunchKernelGGL(stem_conv_ln_kernel<64>, grid, dim3(256), 0, st, x, B, H, W, Ho, Wo, stride, wt, bias, lnw, lnb, eps, out, out_ld);
+  else hipLaunchKernelGGL(stem_conv_ln_kernel<128>, grid, dim3(256), 0, st, x, B, H, W, Ho, Wo, stride, wt, bias, lnw, lnb, eps, out, out_ld);
+  return vs_launch_status();
+}
+
 static int dwconv7_ln_any(const float* x, int B, int H, int W, int C, int64_t ld, const float* wdw, const float* bdw,
                           const float* lnw, const float* lnb, float eps, float* out, int64_t out_ld, void* stream, PlanesOut pl) {
   VS_REQUIRE(x && wdw && bdw && lnw && lnb && out && B > 0 && H > 0 && W > 0 && C > 0);

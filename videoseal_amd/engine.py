@@ -287,6 +287,7 @@ class HipEngine:
         # kernel alone is 49.9 us against 56.3 + 13 (tools/bench_gemm.py ksweep2) and detect of 32 frames 3.725 -> 3.651 ms (median of five
         # alternating runs, profiles/r05o_detect_pw2_tile26.json).  VIDEOSEAL_PW2_NARROW=0: the K-slice form
         self.gemm_big = os.environ.get("VIDEOSEAL_GEMM_BIG", "0") == "1"                  # planes GEMMs of >= 3 rounds on 256 x 256 tiles, one wave per SIMD (round 6)
+        self.stem_fused = os.environ.get("VIDEOSEAL_STEM_FUSED", "1") != "0"              # stem conv + LayerNorm in one VALU kernel (round 6)
         self.down_patch = os.environ.get("VIDEOSEAL_DOWN_PATCH", "1") != "0"              # down-sampler LayerNorm -> patch matrix -> dense GEMM (round 6)
         self.grn_straddle = os.environ.get("VIDEOSEAL_GRN_STRADDLE", "1") != "0"         # GRN statistics from the planes GEMM's epilogue for HW % 32 != 0 (round 6)
         self.grn_fold = os.environ.get("VIDEOSEAL_GRN_FOLD", "1") != "0"                 # GRN finish inside the wave-specialised pwconv2 GEMM (round 6)
@@ -1185,10 +1186,18 @@ class HipEngine:
         s = c.stem_stride
         Ho, Wo = (x.H - 4) // s + 1, (x.W - 4) // s + 1
         d = c.dims
-        t = self.new_act("stem.c", B, Ho, Wo, d[0])
-        self.conv(x, X["stem"], t, geom=(Wo, s * 4, 16, s, 1, 0, 0))
         cur = self.new_act("st0.x", B, Ho, Wo, d[0], self._xld(d[0]))
-        self.layernorm(t, X["stem_ln"][0], X["stem_ln"][1], cur)
+        rc = N.ERR_UNSUPPORTED
+        if self.stem_fused and x.ld == 4 and cur.ld == d[0] and X["stem"].bias is not None:
+            # round 6: patchify conv + LayerNorm in one kernel on the vector ALUs (exact fp32 FMAs; 65 -> ~25 us for 32 frames)
+            rc = L.vs_stem_conv_ln(N.ptr(x.t), B, x.H, x.W, s, N.ptr(X["stem"].wt), N.ptr(X["stem"].bias), N.ptr(X["stem_ln"][0]), N.ptr(X["stem_ln"][1]),
+                                   1e-6, d[0], N.ptr(cur.t), cur.ld, st)
+            if rc != N.ERR_UNSUPPORTED:
+                N.check(rc, "vs_stem_conv_ln")
+        if rc == N.ERR_UNSUPPORTED:
+            t = self.new_act("stem.c", B, Ho, Wo, d[0])
+            self.conv(x, X["stem"], t, geom=(Wo, s * 4, 16, s, 1, 0, 0))
+            self.layernorm(t, X["stem_ln"][0], X["stem_ln"][1], cur)
         for sti in range(4):
             if sti > 0:
                 dn = X["down"][sti - 1]

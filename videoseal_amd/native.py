@@ -23,7 +23,7 @@ VIDEO_MODES = {"repeat": 0, "alternate": 1, "interpolate": 2}
 
 EXPORTS = [
     "vs_version", "vs_arch", "vs_error_string", "vs_sizeof_conv_desc", "vs_sizeof_tail_desc", "vs_debug_set",
-    "vs_model_create", "vs_model_destroy", "vs_model_workspace_bytes", "vs_model_embed", "vs_model_detect", "vs_conv_gemm", "vs_to_planes", "vs_to_planes_affine", "vs_layernorm_act", "vs_layernorm_patch2x2", "vs_rmsnorm_act", "vs_vit_attention", "vs_dwconv7_ln", "vs_dwconv7_ln_planes", "vs_grn_scale", "vs_grn_scale_from_partials", "vs_grn_scale_from_straddle_partials", "vs_grn_apply",
+    "vs_model_create", "vs_model_destroy", "vs_model_workspace_bytes", "vs_model_embed", "vs_model_detect", "vs_conv_gemm", "vs_to_planes", "vs_to_planes_affine", "vs_layernorm_act", "vs_layernorm_patch2x2", "vs_stem_conv_ln", "vs_rmsnorm_act", "vs_vit_attention", "vs_dwconv7_ln", "vs_dwconv7_ln_planes", "vs_grn_scale", "vs_grn_scale_from_partials", "vs_grn_scale_from_straddle_partials", "vs_grn_apply",
     "vs_upcat2x", "vs_upconv_supported", "vs_upconv_gather_ln", "vs_cat2_scale", "vs_msg_pre", "vs_upconv_fused_supported", "vs_upconv_fused_preferred", "vs_upconv_fused", "vs_im2col3x3", "vs_msg_latent", "vs_broadcast_channels", "vs_outc_tanh", "vs_pool_linear", "vs_resize_pre", "vs_resize_pre_u8",
     "vs_jnd_heatmap", "vs_embed_tail", "vs_aug_color_scratch_floats", "vs_aug_color", "vs_aug_color_chain", "vs_aug_crop_resize_color", "vs_aug_crop_flip", "vs_aug_warp", "vs_resize_nchw",
     "vs_gaussian_blur", "vs_median_filter", "vs_jpeg_workspace_bytes", "vs_jpeg_roundtrip", "vs_h264_proxy_workspace_bytes", "vs_h264_proxy_roundtrip",
@@ -110,6 +110,7 @@ def lib() -> C.CDLL:
         "vs_to_planes_affine": [P, I64, I, I64, F, P, I64, P, I, P, P],
         "vs_layernorm_act": [P, I64, I, I64, P, P, F, I, P, I64, P],
         "vs_layernorm_patch2x2": [P, I, I, I, I, I64, P, P, F, P, P],
+        "vs_stem_conv_ln": [P, I, I, I, I, P, P, P, P, F, I, P, I64, P],
         "vs_rmsnorm_act": [P, I64, I, I64, P, I, P, I64, P, I64, P],
         "vs_vit_attention": [P, I, I, I, I, I, I, P, P, P, P],
         "vs_dwconv7_ln": [P, I, I, I, I, I64, P, P, P, P, F, P, I64, P],
