@@ -618,7 +618,8 @@ struct Runner {
     int Ho = (x.H - 4) / s + 1, Wo = (x.W - 4) / s + 1;
     Act cur = act(B, Ho, Wo, c.dims[0], xld(c.dims[0]));
     const int co = c.dims[0];
-    if (x.ld == 4 && cur.ld == co && (co == 64 || co == 96 || co == 128) && m->stem.bias) {
+    static const bool stem_fused = [] { const char* e = getenv("VIDEOSEAL_STEM_FUSED"); return e && e[0] == '1'; }();      // (measured neutral: opt-in, as engine.py)
+    if (stem_fused && x.ld == 4 && cur.ld == co && (co == 64 || co == 96 || co == 128) && m->stem.bias) {
       // engine.py (round 6): patchify conv + LayerNorm in one kernel on the vector ALUs
       if (live()) chk(vs_stem_conv_ln(x.p, B, x.H, x.W, s, m->stem.wt, m->stem.bias, m->stem_lnw, m->stem_lnb, 1e-6f, co, cur.p, cur.ld, st));
     } else {

@@ -1124,81 +1124,64 @@ __global__ __launch_bounds__(256) void stem_conv_ln_kernel(const float* __restri
     s_w[i] = wt[(int64_t)n * 64 + ky * 16 + kx * 4 + c];
   }
   __syncthreads();
-  // four lanes share a pixel (CO / 4 channels each), and a thread carries PX = 4 consecutive pixels of a row through the taps: every weight vector read
-  // from LDS is used for four pixels (one pixel per thread made the kernel LDS-bound: 288 ds_read_b128 per 1152 FMAs -- no faster than the two launches)
-  constexpr int PX = 4;
   const int qd = threadIdx.x & 3;
-  const int wq = (Wo + PX - 1) / PX;                        // pixel quads per output row
-  const int64_t nquad = (int64_t)B * Ho * wq;
-  const int64_t quad = (int64_t)blockIdx.x * 64 + (threadIdx.x >> 2);
-  const bool live = quad < nquad;
-  const int64_t qc = live ? quad : nquad - 1;               // (past the end: a valid quad, nothing stored -- the shuffles need every lane)
-  const int oxq = (int)(qc % wq) * PX;
-  const int64_t t = qc / wq;
+  const int64_t npix = (int64_t)B * Ho * Wo;
+  const int64_t pix = (int64_t)blockIdx.x * 64 + (threadIdx.x >> 2);
+  const bool live = pix < npix;
+  const int64_t pc = live ? pix : npix - 1;                 // (past the end: a valid pixel, nothing stored -- the shuffles need every lane)
+  const int ox = (int)(pc % Wo);
+  const int64_t t = pc / Wo;
   const int oy = (int)(t % Ho);
   const int64_t b = t / Ho;
-  f32x4 acc[PX][Q4];
+  const float* xp = x + ((b * H + (int64_t)oy * stride) * W + (int64_t)ox * stride) * 4;
+  f32x4 acc[Q4];
 #pragma unroll
-  for (int p = 0; p < PX; ++p)
-#pragma unroll
-    for (int j = 0; j < Q4; ++j) acc[p][j] = *reinterpret_cast<const f32x4*>(bias + qd * CQ + 4 * j);
-  const float* xrow = x + ((b * H + (int64_t)oy * stride) * W) * 4;
+  for (int j = 0; j < Q4; ++j) acc[j] = *reinterpret_cast<const f32x4*>(bias + qd * CQ + 4 * j);
 #pragma unroll
   for (int ky = 0; ky < 4; ++ky) {
-    f32x4 in[PX][4];
+    f32x4 in[4];
 #pragma unroll
-    for (int p = 0; p < PX; ++p) {
-      const int ox = min(oxq + p, Wo - 1);                  // ragged last quad: a valid pixel, not stored
-#pragma unroll
-      for (int kx = 0; kx < 4; ++kx) in[p][kx] = *reinterpret_cast<const f32x4*>(xrow + ((int64_t)ky * W + (int64_t)ox * stride + kx) * 4);
-    }
+    for (int kx = 0; kx < 4; ++kx) in[kx] = *reinterpret_cast<const f32x4*>(xp + ((int64_t)ky * W + kx) * 4);
 #pragma unroll
     for (int kx = 0; kx < 4; ++kx)
 #pragma unroll
       for (int c = 0; c < 3; ++c) {
+        const float v = in[kx][c];
         const float* wr = s_w + (ky * 12 + kx * 3 + c) * CO + qd * CQ;
 #pragma unroll
         for (int j = 0; j < Q4; ++j) {
           const f32x4 wv = *reinterpret_cast<const f32x4*>(wr + 4 * j);
 #pragma unroll
-          for (int p = 0; p < PX; ++p) {
-            const float v = in[p][kx][c];
-#pragma unroll
-            for (int e = 0; e < 4; ++e) acc[p][j][e] = __builtin_fmaf(v, wv[e], acc[p][j][e]);
-          }
+          for (int e = 0; e < 4; ++e) acc[j][e] = __builtin_fmaf(v, wv[e], acc[j][e]);
         }
       }
   }
-  // LayerNorm over each pixel's CO channels (four lanes): mean, then the squared deviations (common.py:147-155)
+  // LayerNorm over the pixel's CO channels (four lanes): mean, then the squared deviations (common.py:147-155)
+  float sm = 0.f;
 #pragma unroll
-  for (int p = 0; p < PX; ++p) {
-    float sm = 0.f;
+  for (int j = 0; j < Q4; ++j)
 #pragma unroll
-    for (int j = 0; j < Q4; ++j)
+    for (int e = 0; e < 4; ++e) sm += acc[j][e];
+  sm += __shfl_xor(sm, 1, 64);
+  sm += __shfl_xor(sm, 2, 64);
+  const float mean = sm / (float)CO;
+  float qv = 0.f;
 #pragma unroll
-      for (int e = 0; e < 4; ++e) sm += acc[p][j][e];
-    sm += __shfl_xor(sm, 1, 64);
-    sm += __shfl_xor(sm, 2, 64);
-    const float mean = sm / (float)CO;
-    float qv = 0.f;
+  for (int j = 0; j < Q4; ++j)
 #pragma unroll
-    for (int j = 0; j < Q4; ++j)
+    for (int e = 0; e < 4; ++e) { const float dlt = acc[j][e] - mean; qv += dlt * dlt; }
+  qv += __shfl_xor(qv, 1, 64);
+  qv += __shfl_xor(qv, 2, 64);
+  const float den = sqrtf(qv / (float)CO + eps);
+  if (!live) return;
+  float* orow = out + pix * out_ld + qd * CQ;
 #pragma unroll
-      for (int e = 0; e < 4; ++e) { const float dlt = acc[p][j][e] - mean; qv += dlt * dlt; }
-    qv += __shfl_xor(qv, 1, 64);
-    qv += __shfl_xor(qv, 2, 64);
-    const float den = sqrtf(qv / (float)CO + eps);
-    if (live && oxq + p < Wo) {
-      float* orow = out + (((b * Ho + oy) * Wo) + oxq + p) * out_ld + qd * CQ;
+  for (int j = 0; j < Q4; ++j) {
+    const f32x4 wv = *reinterpret_cast<const f32x4*>(lnw + qd * CQ + 4 * j), bv = *reinterpret_cast<const f32x4*>(lnb + qd * CQ + 4 * j);
+    f32x4 o;
 #pragma unroll
-      for (int j = 0; j < Q4; ++j) {
-        const f32x4 wv = *reinterpret_cast<const f32x4*>(lnw + qd * CQ + 4 * j), bv = *reinterpret_cast<const f32x4*>(lnb + qd * CQ + 4 * j);
-        f32x4 o;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) o[e] = wv[e] * ((acc[p][j][e] - mean) / den) + bv[e];
-        *reinterpret_cast<f32x4*>(orow + 4 * j) = o;
-      }
-    }
+    for (int e = 0; e < 4; ++e) o[e] = wv[e] * ((acc[j][e] - mean) / den) + bv[e];
+    *reinterpret_cast<f32x4*>(orow + 4 * j) = o;
   }
 }
 
@@ -1211,9 +1194,9 @@ extern "C" int vs_stem_conv_ln(const float* x, int B, int H, int W, int stride, 
       (((uintptr_t)x | (uintptr_t)wt | (uintptr_t)bias | (uintptr_t)lnw | (uintptr_t)lnb | (uintptr_t)out) & 15) != 0)
     return VS_ERR_UNSUPPORTED;
   const int Ho = (H - 4) / stride + 1, Wo = (W - 4) / stride + 1;
-  const int64_t nquad = (int64_t)B * Ho * ((Wo + 3) / 4);
-  if (nquad >= (1LL << 31) * 16) return VS_ERR_UNSUPPORTED;
-  const dim3 grid((unsigned)cdiv64(nquad, 64));
+  const int64_t npix = (int64_t)B * Ho * Wo;
+  if (npix >= (1LL << 31) * 16) return VS_ERR_UNSUPPORTED;
+  const dim3 grid((unsigned)cdiv64(npix, 64));
   hipStream_t st = (hipStream_t)stream;
   if (CO == 96) hipLaunchKernelGGL(stem_conv_ln_kernel<96>, grid, dim3(256), 0, st, x, B, H, W, Ho, Wo, stride, wt, bias, lnw, lnb, eps, out, out_ld);
   else if (CO == 64) hipLaunchKernelGGL(stem_conv_ln_kernel<64>, grid, dim3(256), 0, st, x, B, H, W, Ho, Wo, stride, wt, bias, lnw, lnb, eps, out, out_ld);

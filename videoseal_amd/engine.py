@@ -287,7 +287,7 @@ class HipEngine:
         # kernel alone is 49.9 us against 56.3 + 13 (tools/bench_gemm.py ksweep2) and detect of 32 frames 3.725 -> 3.651 ms (median of five
         # alternating runs, profiles/r05o_detect_pw2_tile26.json).  VIDEOSEAL_PW2_NARROW=0: the K-slice form
         self.gemm_big = os.environ.get("VIDEOSEAL_GEMM_BIG", "0") == "1"                  # planes GEMMs of >= 3 rounds on 256 x 256 tiles, one wave per SIMD (round 6)
-        self.stem_fused = os.environ.get("VIDEOSEAL_STEM_FUSED", "1") != "0"              # stem conv + LayerNorm in one VALU kernel (round 6)
+        self.stem_fused = os.environ.get("VIDEOSEAL_STEM_FUSED", "0") == "1"              # stem conv + LayerNorm in one VALU kernel (round 6; measured neutral: opt-in)
         self.down_patch = os.environ.get("VIDEOSEAL_DOWN_PATCH", "1") != "0"              # down-sampler LayerNorm -> patch matrix -> dense GEMM (round 6)
         self.grn_straddle = os.environ.get("VIDEOSEAL_GRN_STRADDLE", "1") != "0"         # GRN statistics from the planes GEMM's epilogue for HW % 32 != 0 (round 6)
         self.grn_fold = os.environ.get("VIDEOSEAL_GRN_FOLD", "1") != "0"                 # GRN finish inside the wave-specialised pwconv2 GEMM (round 6)
