@@ -78,12 +78,13 @@ def test_the_budget_itself_only_tolerates_known_spills():
         assert v <= KNOWN_SPILLS[k], (k, v)
 
 
-# epilogue-only spills of the TN = 3 tiles (96 accumulators + a batch of residual / bias values; none inside a K loop), round-5 values
-# (gemm1x1_pc: 101 / 96 -> 106 / 98 when the producers' lane mapping changed, 98 / 92 with the weights fetched by LDS-DMA from the consumer waves)
-# (round 6: the GRN variants carry the folded GRN finish in their prologue -- + 2 KiB of LDS for the two frames' thread sums, 98 -> 97 spilled registers
-# in the TN = 3 x 2 epilogue; the 128 x 96 tile that runs ConvNeXt stage 2 stays at 0)
-KNOWN_SPILLS = {"conv3x3_pl_kernel<3>": 32, "gemm_pl_kernel<3>": 67, "gemm1x1_pc_kernel<3, true, 2, 2, 1536>": 97, "gemm1x1_pc_kernel<3, true, 2, 2, 3072>": 97,
-                "gemm1x1_pc_kernel<3, false, 2, 2, 3072>": 92, "conv3x3_patch_pc_kernel<3, 8, 2>": 90}
+# Kernels allowed to spill at all, with a ceiling each (none inside a K loop).  Round 5 had six entries of 32 - 98 registers, all TN = 3 tiles
+# (96 accumulators per lane).  Round 6 removed four: gemm_pl<3> 67 -> 0 and gemm1x1_pc<3, *, 2, 2, *> 92 - 97 -> 0 by (a) one store path for K-slice
+# partial sums and final outputs instead of two inlined copies, (b) building those register tiles without the tanh epilogue (refused by their
+# launchers: test_wide_register_tiles_refuse_tanh), (c) passing the thread id of the GRN prologue through an opaque copy so that its per-thread
+# addresses are not hoisted out of the persistent tile loop.  What is left: the dominant 3x3 kernel's 32 (20 saved once before the K loop and
+# restored after the last store, 12 around its unrolled first taps) and the 128 x 192 patch kernel's 90 (halo staging before the first chunk).
+KNOWN_SPILLS = {"conv3x3_pl_kernel<3>": 32, "conv3x3_patch_pc_kernel<3, 8, 2>": 90}
 
 
 def test_untracked_lds_dma_is_m0_neutral():

@@ -1415,7 +1415,8 @@ def test_gemm_planes_big_tile(case):
     pl = torch.empty(B * HW * K * 2, dtype=torch.int16, device=DEV)
     N.check(eng.lib.vs_to_planes(N.ptr(xa.t), xa.rows, K, xa.ld, 16.0, N.ptr(pl), N.stream()), "to_planes")
     outs = []
-    for t in (N.CONV_TILE_HI | 11, N.CONV_TILE_HI | 8):
+    # (tanh: tile 24's 128 x 192 register tile does not carry the tanh variant any more -- the 128-column tile 25 is the twin there)
+    for t in (N.CONV_TILE_HI | 11, N.CONV_TILE_HI | (9 if act == 3 else 8)):
         out = Act(torch.full((B * HW * ld,), float("nan"), device=DEV), B, H, W, Nn, ld)
         part = torch.full((((B * HW + 31) // 32) * 2 * Nn,), float("nan"), device=DEV) if sumsq else None
         kw = dict(sumsq=part, sumsq_hw=(sumsq if sumsq > 1 else 0)) if sumsq else {}
@@ -1429,6 +1430,36 @@ def test_gemm_planes_big_tile(case):
     if sumsq:
         n = ((B * HW + 31) // 32) * (2 if sumsq > 1 else 1) * Nn
         assert torch.equal(outs[0][1][:n], outs[1][1][:n])
+
+
+@pytest.mark.parametrize("tile", [2, 8])
+def test_wide_register_tiles_refuse_tanh(tile):
+    """round 6: the TN = 3 register tiles (tile codes 18 and 24, 96 accumulators per lane at 128 x 192) are built without the tanh epilogue -- it was
+    what their epilogues spilled registers for, and no layer of a shipped card takes it there (the only tanh is the 1-channel output conv).  An explicit
+    request is refused with VS_ERR_UNSUPPORTED and leaves the output untouched; with K slices (the activation then runs in the epilogue kernel) and
+    on every narrower tile tanh still works (GEMM_PL_CASES / GEMM_PC_CASES), and the automatic choice never lands on the refused form."""
+    B, H, W, K, Nn = 2, 16, 24, 64, 300
+    eng = Eng(arith=2)
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(B, H * W, K, generator=g)
+    w = torch.randn(Nn, K, generator=g) / math.sqrt(K)
+    bias = torch.randn(Nn, generator=g)
+    ref = torch.tanh(F.linear(x, w, bias))
+    xa = Act(dv(x), B, H, W, K, K)
+    wt, cp = pack_conv(w[:, :, None, None].to(DEV), K)
+    cw = ConvW(wt, dv(bias), Nn, 1, 1, cp)
+    pl = torch.empty(B * H * W * K * 2, dtype=torch.int16, device=DEV)
+    N.check(eng.lib.vs_to_planes(N.ptr(xa.t), xa.rows, K, xa.ld, 16.0, N.ptr(pl), N.stream()), "to_planes")
+    kw = dict(in_pl=pl, a_mul=16.0) if tile == 8 else {}
+    out = Act(torch.full((B * H * W * Nn,), float("nan"), device=DEV), B, H, W, Nn, Nn)
+    with pytest.raises(N.NativeError, match="code -2"):
+        eng.conv(xa, cw, out, act=3, tile_hint=N.CONV_TILE_HI | tile, arith=2, **kw)
+    torch.cuda.synchronize()
+    assert torch.isnan(out.t).all()
+    for hint, sk in ((N.CONV_TILE_HI | tile, 2), (0, 1)):         # K slices on the same tile; the dispatcher's own choice
+        eng.conv(xa, cw, out, act=3, tile_hint=hint, split_k=sk, arith=2, **kw)
+        torch.cuda.synchronize()
+        assert rel_err(out.t.view(B, H * W, Nn).cpu(), ref) < 2e-5
 
 
 def _guard_i16(t: torch.Tensor):

@@ -169,7 +169,10 @@ __device__ __forceinline__ void store_tile_full(const f32x16 (&acc)[TM][TN], cha
   }
 }
 
-template <int TM, int TN>
+// TANH = false (round 6: the TN = 3 register tiles of gemm_pl / gemm1x1_pc): the tanh variant is not compiled in -- no shipped layer takes it on those
+// tiles (the network's only tanh is the 1-channel output conv), and it alone accounted for 45 of 67 (gemm_pl) / 56 of 97 (gemm1x1_pc) spilled registers
+// of their epilogues; their dispatchers refuse VS_ACT_TANH instead (tile codes 18 / 24 / 26 without K slices).
+template <int TM, int TN, bool TANH = true>
 __device__ __forceinline__ void apply_act_all(f32x16 (&acc)[TM][TN], const float (&b1)[TN], const float (&b2)[TN], int act) {
   // act is wave-uniform: one branch around the whole register tile instead of a switch per element
   if (act == VS_ACT_RELU) {
@@ -189,7 +192,7 @@ __device__ __forceinline__ void apply_act_all(f32x16 (&acc)[TM][TN], const float
           acc[i][j][e] = vs_gelu(acc[i][j][e] + b1[j]) + b2[j];
           if ((e & 7) == 7) __builtin_amdgcn_sched_barrier(0);   // keep the expansions from being interleaved across the whole tile (VGPRs)
         }
-  } else if (act == VS_ACT_TANH) {
+  } else if (TANH && act == VS_ACT_TANH) {
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll

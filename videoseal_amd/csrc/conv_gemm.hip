@@ -558,7 +558,7 @@ extern "C" int vs_conv_gemm(const vs_conv_desc_t* dp, void* stream) {
                          d.Cin % 32 == 0 && d.CinP == d.Cin && d.in_sy == (int64_t)d.W * d.in_sx && d.in_sb == (int64_t)d.H * d.in_sy &&
                          (!d.a_scale || d.H * d.W >= 128 || d.H * d.W == 64) && !(d.sumsq_part && d.res) &&
                          (!d.a_scale || (int64_t)((d.CinP / 32 + std::max(1, d.split_k) - 1) / std::max(1, d.split_k)) * 32 <= 3072);   // GRN rows of a K slice in LDS
-    if (gemm_ok && d.CinP >= 384 && d.N > 128) return vs_gemm1x1_pc_dispatch(d, 18, st);
+    if (gemm_ok && d.CinP >= 384 && d.N > 128 && !(d.act == VS_ACT_TANH && d.split_k <= 1)) return vs_gemm1x1_pc_dispatch(d, 18, st);      // (tile 18 has no tanh epilogue)
     if (d.KH == 1 && d.KW == 1 && d.CinP < 384 && d.N >= 256) tile = 1;
     else tile = d.N <= 32 ? 3 : (d.N <= 64 ? 2 : (d.N <= 96 ? 5 : ((d.N % 192 == 0 || (d.N > 128 && d.N <= 192)) ? 4 : 1)));
     // few output tiles (down-sampling convs, the 8x8 head conv): smaller tiles until the 256 CUs have work

@@ -181,6 +181,10 @@ __device__ __forceinline__ void gemm1x1_pc_tile(const vs_conv_desc_t& d, const i
     const char* const abase = reinterpret_cast<const char*>(d.in) + (int64_t)pair0 * 128;
     constexpr bool grn = GRN;
     const int kslice = npairs * 32;
+    // (the thread id of the GRN prologue through an opaque copy, as the consumers' lane id in the epilogue below: hipcc otherwise hoists the prologue's
+    // per-thread addresses out of the persistent tile loop and keeps them alive across every K loop -- 14 spilled registers of the TN = 3 x 2 tile)
+    int pt_o = pt;
+    asm volatile("" : "+v"(pt_o));
     if (grn && d.grn_part) {
       // Round 6: the GRN finish (net_ops.hip::grn_finish_kernel, one launch of ~8 us per block between pwconv1 and pwconv2) folded into this
       // prologue.  d.grn_part = pwconv1's ||h||^2 partials [B][nchunk][K] (nchunk <= 16 chunks of 32 rows per frame): every workgroup reduces
@@ -197,10 +201,10 @@ __device__ __forceinline__ void gemm1x1_pc_tile(const vs_conv_desc_t& d, const i
         if (fi && f_hi == f_lo) break;
         const float* pf = d.grn_part + (int64_t)f * nch * Kall;
         float* row = Sc + fi * kslice;
-        Red[fi * 256 + pt] = nch <= 2 ? grn_reduce_frame<2>(pf, nch, Kall, pt, c_lo, c_hi, row)
-                           : nch <= 4 ? grn_reduce_frame<4>(pf, nch, Kall, pt, c_lo, c_hi, row)
-                           : nch <= 8 ? grn_reduce_frame<8>(pf, nch, Kall, pt, c_lo, c_hi, row)
-                                      : grn_reduce_frame<16>(pf, nch, Kall, pt, c_lo, c_hi, row);
+        Red[fi * 256 + pt_o] = nch <= 2 ? grn_reduce_frame<2>(pf, nch, Kall, pt_o, c_lo, c_hi, row)
+                           : nch <= 4 ? grn_reduce_frame<4>(pf, nch, Kall, pt_o, c_lo, c_hi, row)
+                           : nch <= 8 ? grn_reduce_frame<8>(pf, nch, Kall, pt_o, c_lo, c_hi, row)
+                                      : grn_reduce_frame<16>(pf, nch, Kall, pt_o, c_lo, c_hi, row);
       }
       __syncthreads();                                // (matched by the consumers' extra cbar)
       const float* ghp = d.a_shift + c_lo;
@@ -214,7 +218,7 @@ __device__ __forceinline__ void gemm1x1_pc_tile(const vs_conv_desc_t& d, const i
         for (int o = 32; o > 0; o >>= 1) a += __shfl_down(a, o, 64);
         mean[fi] = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(a))) / (float)Kall;
       }
-      for (int k = pt; k < kslice; k += 256) {
+      for (int k = pt_o; k < kslice; k += 256) {
         const float gm = gmp[k];
         const float g0v = Sc[k], g1v = f_hi == f_lo ? g0v : Sc[kslice + k];
         Sc[k] = 1.0f + gm * (g0v / (mean[0] + 1e-6f));
@@ -226,7 +230,7 @@ __device__ __forceinline__ void gemm1x1_pc_tile(const vs_conv_desc_t& d, const i
       const float* g0p = d.a_scale + (int64_t)f_lo * d.a_scale_ld + pair0 * 32;
       const float* g1p = d.a_scale + (int64_t)f_hi * d.a_scale_ld + pair0 * 32;
       const float* ghp = d.a_shift + pair0 * 32;
-      for (int k4 = pt * 4; k4 < kslice; k4 += 1024) {
+      for (int k4 = pt_o * 4; k4 < kslice; k4 += 1024) {
         *reinterpret_cast<f32x4*>(Sc + k4) = *reinterpret_cast<const f32x4*>(g0p + k4);
         *reinterpret_cast<f32x4*>(Sc + kslice + k4) = *reinterpret_cast<const f32x4*>(g1p + k4);
         *reinterpret_cast<f32x4*>(Sc + 2 * kslice + k4) = *reinterpret_cast<const f32x4*>(ghp + k4);
@@ -465,26 +469,28 @@ __device__ __forceinline__ void gemm1x1_pc_tile(const vs_conv_desc_t& d, const i
   const int c0 = n0 + wn * TN * 32;
   const bool whole = m0 + BM <= M && n0 + BN <= d.N;      // every layer of the shipped cards
   const int rows_left = (int)min((int64_t)TM * 32, (int64_t)M - row0);
-  if (d.split_k > 1) {                // raw partial sums -> workspace [ks][M][ws_ld]
-    char* const wsb = reinterpret_cast<char*>(d.splitk_ws + ((int64_t)ks * M + row0) * d.splitk_ld + c0);
-    if (whole) store_tile_full<TM, TN>(acc, wsb, (int)d.splitk_ld, nullptr, 0, r_e, g_e);
-    else store_tile_guarded<TM, TN>(acc, wsb, (int)d.splitk_ld, nullptr, 0, r_e, g_e, rows_left, d.N - c0, d.N - c0);
-    return;
-  }
-  float bias1[TN], zero[TN];
+  // ONE store path for the K-slice partial sums and the final output (round 6, as gemm_pl.hip: two inlined copies of the store helpers next to each other
+  // and the tanh variant of the activation were what the TN = 3 x 2 tile spilled 92 - 97 registers for)
+  const bool sk = d.split_k > 1;
+  if (!sk) {
+    float bias1[TN], zero[TN];
 #pragma unroll
-  for (int j = 0; j < TN; ++j) {
-    bias1[j] = (col[j] < d.N && d.bias) ? d.bias[col[j]] : 0.f;
-    zero[j] = 0.f;
+    for (int j = 0; j < TN; ++j) {
+      bias1[j] = (col[j] < d.N && d.bias) ? d.bias[col[j]] : 0.f;
+      zero[j] = 0.f;
+    }
+    const int abl = VS_KERNEL_ABL(d);       // ablations (tools/bench_gemm.py ksweep): 64 no activation, 32 no output stores
+    if (!(abl & 64)) apply_act_all<TM, TN, (TN * WN < 6)>(acc, bias1, zero, d.act);
+    if (d.sumsq_part) write_sumsq<TM, TN>(acc, d.sumsq_part, d.N, m0 + (int64_t)wm * TM * 32, M, col, g);
+    if (abl & 32) return;
   }
-  const int abl = VS_KERNEL_ABL(d);       // ablations (tools/bench_gemm.py ksweep): 64 no activation, 32 no output stores
-  if (!(abl & 64)) apply_act_all<TM, TN>(acc, bias1, zero, d.act);
-  if (d.sumsq_part) write_sumsq<TM, TN>(acc, d.sumsq_part, d.N, m0 + (int64_t)wm * TM * 32, M, col, g);
-  if (abl & 32) return;
-  char* const ob = reinterpret_cast<char*>(d.out + row0 * d.out_ld + d.out_coff + c0);
-  const char* const rb = d.res ? reinterpret_cast<const char*>(d.res + row0 * d.res_ld + c0) : nullptr;
-  if (whole) store_tile_full<TM, TN>(acc, ob, (int)d.out_ld, rb, (int)d.res_ld, r_e, g_e);
-  else store_tile_guarded<TM, TN>(acc, ob, (int)d.out_ld, rb, (int)d.res_ld, r_e, g_e, rows_left, d.N - c0, d.n_store - c0);
+  // raw partial sums -> workspace [ks][M][ws_ld]; or the output (+ residual)
+  char* const ob = sk ? reinterpret_cast<char*>(d.splitk_ws + ((int64_t)ks * M + row0) * d.splitk_ld + c0)
+                      : reinterpret_cast<char*>(d.out + row0 * d.out_ld + d.out_coff + c0);
+  const char* const rb = (!sk && d.res) ? reinterpret_cast<const char*>(d.res + row0 * d.res_ld + c0) : nullptr;
+  const int o_ld = sk ? (int)d.splitk_ld : (int)d.out_ld;
+  if (whole) store_tile_full<TM, TN>(acc, ob, o_ld, rb, (int)d.res_ld, r_e, g_e);
+  else store_tile_guarded<TM, TN>(acc, ob, o_ld, rb, (int)d.res_ld, r_e, g_e, rows_left, d.N - c0, sk ? d.N - c0 : d.n_store - c0);
 }
 
 // KC: K elements of a K slice whose GRN rows fit the LDS area (GRN_KCAP, or half of it: with the four weight stages of BDMA the 128 x 96 tile stays
@@ -561,6 +567,7 @@ int launch_g(const vs_conv_desc_t& d, hipStream_t st) {
   if (d.a_scale && (((uintptr_t)d.a_scale | (uintptr_t)d.a_shift) & 15 || (d.a_scale_ld & 3))) return VS_ERR_UNSUPPORTED;
   if (d.grn_part && (!d.a_scale || !d.grn_gamma || d.grn_nchunk < 1 || d.grn_nchunk > 16 || d.grn_nchunk * 32 != d.H * d.W)) return VS_ERR_BAD_ARG;
   if (mt * nt * sk > 0x7fffffffLL || M > 0x7fffffffLL) return VS_ERR_UNSUPPORTED;
+  if (TN * WN >= 6 && sk == 1 && d.act == VS_ACT_TANH) return VS_ERR_UNSUPPORTED;      // (the 128 x 192 register tile is compiled without the tanh epilogue)
   // store_tile_full / store_tile_guarded address a tile with 32-bit byte offsets from its first element (conv_gemm.hip / gemm_pl.hip check the
   // same bound and keep a 64-bit path; this kernel has only the 32-bit one)
   if ((int64_t)BM * std::max<int64_t>(std::max<int64_t>(d.out_ld, d.res ? d.res_ld : 0), sk > 1 ? d.splitk_ld : 0) * 4 >= (1LL << 31)) return VS_ERR_UNSUPPORTED;

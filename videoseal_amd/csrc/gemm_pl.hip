@@ -258,13 +258,36 @@ __global__ __launch_bounds__(512, 2) void gemm_pl_kernel(const vs_conv_desc_t d,
   int col[TN];
 #pragma unroll
   for (int j = 0; j < TN; ++j) col[j] = n0 + (wn * TN + j) * 32 + r_e;
-  if (d.split_k > 1) {
-    float* ws = d.splitk_ws + (int64_t)ks * M * d.splitk_ld;
-    if (m0 + GBM <= M && n0 + BN <= d.N && (int64_t)GBM * d.splitk_ld * 4 < (1LL << 31)) {
-      store_tile_full<TM, TN>(acc, reinterpret_cast<char*>(ws + ((int64_t)m0 + wm * TM * 32) * d.splitk_ld + n0 + wn * TN * 32), (int)d.splitk_ld, nullptr, 0,
-                              r_e, g_e);
-      return;
-    }
+  // ONE store path for the K-slice partial sums and the final output (round 6): with the two inlined copies of store_tile_full next to each other
+  // hipcc spilled 22 registers of the TN = 3 tile (either copy alone: 0; conv_common.h::apply_act_all for the other 45 of the 67)
+  const bool sk = d.split_k > 1;
+  float* const wsb = sk ? d.splitk_ws + (int64_t)ks * M * d.splitk_ld : nullptr;
+  const int o_ld = sk ? (int)d.splitk_ld : (int)d.out_ld;
+  const bool whole = m0 + GBM <= M && n0 + BN <= d.N && (int64_t)GBM * max((int64_t)o_ld, sk ? (int64_t)0 : d.res_ld) * 4 < (1LL << 31);
+  if (!sk) {
+  float bias1[TN], zero[TN];
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    bias1[j] = (col[j] < d.N && d.bias) ? d.bias[col[j]] : 0.f;
+    zero[j] = 0.f;
+  }
+  const int abl = VS_KERNEL_ABL(d);           // ablation build only (tools/bench_gemm.py ksweep2): 64 no activation, 32 no output stores
+  if (!(abl & 64)) apply_act_all<TM, TN, (TN < 3)>(acc, bias1, zero, d.act);
+  if (d.sumsq_part) {
+    if (d.sumsq_hw > 0) write_sumsq_straddle<TM, TN>(acc, d.sumsq_part, d.N, (int64_t)m0 + (int64_t)wm * TM * 32, M, col, g_e, d.sumsq_hw);
+    else write_sumsq<TM, TN>(acc, d.sumsq_part, d.N, (int64_t)m0 + (int64_t)wm * TM * 32, M, col, g_e);
+  }
+    if (abl & 32) return;
+  }
+  if (whole) {       // every layer of the shipped cards: store_tile_full (conv_common.h)
+    const int64_t row0 = (int64_t)m0 + wm * TM * 32;                                   // wave-uniform
+    char* const ob = sk ? reinterpret_cast<char*>(wsb + row0 * d.splitk_ld + n0 + wn * TN * 32)
+                        : reinterpret_cast<char*>(d.out + row0 * d.out_ld + d.out_coff + n0 + wn * TN * 32);
+    const char* const rb = (!sk && d.res) ? reinterpret_cast<const char*>(d.res + row0 * d.res_ld + n0 + wn * TN * 32) : nullptr;
+    store_tile_full<TM, TN>(acc, ob, o_ld, rb, (int)d.res_ld, r_e, g_e);
+    return;
+  }
+  if (sk) {
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -273,28 +296,8 @@ __global__ __launch_bounds__(512, 2) void gemm_pl_kernel(const vs_conv_desc_t d,
         if (m >= M) continue;
 #pragma unroll
         for (int j = 0; j < TN; ++j)
-          if (col[j] < d.N) ws[(int64_t)m * d.splitk_ld + col[j]] = acc[i][j][e];
+          if (col[j] < d.N) wsb[(int64_t)m * d.splitk_ld + col[j]] = acc[i][j][e];
       }
-    return;
-  }
-  float bias1[TN], zero[TN];
-#pragma unroll
-  for (int j = 0; j < TN; ++j) {
-    bias1[j] = (col[j] < d.N && d.bias) ? d.bias[col[j]] : 0.f;
-    zero[j] = 0.f;
-  }
-  const int abl = VS_KERNEL_ABL(d);           // ablation build only (tools/bench_gemm.py ksweep2): 64 no activation, 32 no output stores
-  if (!(abl & 64)) apply_act_all<TM, TN>(acc, bias1, zero, d.act);
-  if (d.sumsq_part) {
-    if (d.sumsq_hw > 0) write_sumsq_straddle<TM, TN>(acc, d.sumsq_part, d.N, (int64_t)m0 + (int64_t)wm * TM * 32, M, col, g_e, d.sumsq_hw);
-    else write_sumsq<TM, TN>(acc, d.sumsq_part, d.N, (int64_t)m0 + (int64_t)wm * TM * 32, M, col, g_e);
-  }
-  if (abl & 32) return;
-  const bool whole = m0 + GBM <= M && n0 + BN <= d.N && (int64_t)GBM * max(d.out_ld, d.res_ld) * 4 < (1LL << 31);
-  if (whole) {       // every layer of the shipped cards: store_tile_full (conv_common.h)
-    const int64_t row0 = (int64_t)m0 + wm * TM * 32;                                   // wave-uniform
-    store_tile_full<TM, TN>(acc, reinterpret_cast<char*>(d.out + row0 * d.out_ld + d.out_coff + n0 + wn * TN * 32), (int)d.out_ld,
-                            d.res ? reinterpret_cast<const char*>(d.res + row0 * d.res_ld + n0 + wn * TN * 32) : nullptr, (int)d.res_ld, r_e, g_e);
     return;
   }
 #pragma unroll
@@ -632,6 +635,7 @@ int launch_gpl(const vs_conv_desc_t& d, hipStream_t st) {
   const int sps = (nsteps + sk - 1) / sk;
   if (sk > 1 && (int64_t)(sk - 1) * sps >= nsteps) return VS_ERR_BAD_ARG;       // an empty K slice
   if (mt * nt * sk > 0x7fffffffLL || M > 0x7fffffffLL) return VS_ERR_UNSUPPORTED;
+  if (TN == 3 && sk == 1 && d.act == VS_ACT_TANH) return VS_ERR_UNSUPPORTED;       // (the TN = 3 register tile is compiled without the tanh epilogue; tile 25 / 27 have it)
   // XCD-aware grouped tile order for launches of several rounds (VS_GEMM_PL_RASTER=0: the row-major order)
   static const bool raster = [] { const char* e = getenv("VS_GEMM_PL_RASTER"); return !(e && e[0] == '0'); }();
   const int per_xcd = (raster && mt * nt >= 4 * vs_num_cus()) ? (int)((mt * nt + 7) / 8) : 0;
