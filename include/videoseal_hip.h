@@ -106,6 +106,9 @@ typedef struct vs_conv_desc {
                             /* 26 = 128x96: the wave-specialised 1x1 GEMM with four consumer waves stacked over the rows (arith 2; round 5); */
                             /* 27 = 256x256: the all-DMA planes GEMM with ONE wave per SIMD (128 x 128 per wave, four 32 KiB stages; round 6:  */
                             /*      15 % fewer operand bytes per FLOP than tile 24 for the GEMMs that are LDS-DMA-bound -- ChunkySeal);          */
+                            /* round 6: the 96-accumulator register tiles -- 18 and 24 -- are built without the tanh epilogue: an explicit request */
+                            /*      for VS_ACT_TANH there with split_k <= 1 answers VS_ERR_UNSUPPORTED (tile 0 = auto never picks them for tanh;   */
+                            /*      17 / 25 / 26 / 27 and every K-sliced launch carry it);                                                          */
                             /* | VS_CONV_TILE_HI: tile code + 16;                                                     */
                             /* | VS_CONV_FORCE_F32: v_mfma_f32_32x32x2_f32 path; | VS_CONV_FORCE_SPLIT */
   const void* wt_split;     /* optional [P][N][Ktot] 16-bit planes (P = 3 bf16 / 2 f16, see arith): wt split into P terms; when set */
