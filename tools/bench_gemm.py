@@ -95,6 +95,13 @@ if __name__ == "__main__":
         run("down 768->384 M=4096    ", 16, 16, 768, 384, [(HI | 2, 4), (HI | 2, 2), (HI | 10, 2), (HI | 10, 1), (HI | 1, 2)])
         run("down 1536->768 M=1024   ", 16, 8, 1536, 768, [(HI | 2, 8), (HI | 2, 4), (HI | 10, 4), (HI | 10, 2), (HI | 1, 4)])
         sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "b32":        # the same at 32 frames: the down-samplers (dense GEMMs on the LayerNorm's patch matrix) and stage 3
+        run("down 384->192 M=32768   ", 32, 32, 384, 192, [(HI | 2, 1), (HI | 10, 1), (HI | 1, 1)])
+        run("down 768->384 M=8192    ", 32, 16, 768, 384, [(HI | 2, 2), (HI | 10, 1), (HI | 1, 2), (HI | 1, 1)])
+        run("down 1536->768 M=2048   ", 32, 8, 1536, 768, [(HI | 2, 4), (HI | 10, 2), (HI | 10, 4), (HI | 10, 1), (HI | 1, 4), (HI | 1, 2)])
+        run("s3 pw1 768->3072 M=2048 ", 32, 8, 768, 3072, [(HI | 2, 1), (HI | 10, 1), (HI | 1, 1)])
+        run("s3 pw2 3072->768 M=2048 ", 32, 8, 3072, 768, [(HI | 2, 4), (HI | 2, 2), (HI | 10, 2), (HI | 10, 4), (HI | 1, 4)], grn=True)
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "planes":      # all-DMA GEMM on operand planes (24 / 25) vs the best of the other kernels, 2 x f16
         P3, P2 = HI | 8, HI | 9
         run("s0 pw1  96->384  M=131072", 32, 64, 96, 384, [(1, 1), (HI | 1, 1), (P3, 1), (P2, 1)], planes=True)
