@@ -184,8 +184,10 @@ def measure_sustained_mfma():
 def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=3)
+    # (defaults: 30 timed steps -- the barrier + synchronize pair that brackets the timed region costs ~0.9 ms, 1.2 % of ten 7.6 ms steps and 0.4 % of thirty:
+    #  profiles/r06zj_bench_steps_sweep.txt)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--mode", choices=["image", "video", "stream", "chain"], default="image",
                     help="stream = BASELINE config 4: --frames frames processed as 16-frame embed(lowres_attenuation)+detect calls; "
                          "chain = BASELINE config 3: 16-frame clip -> embed -> JPEG/Crop/Resize/colour chain -> detect")
@@ -637,7 +639,7 @@ def main():
                    and not args.detect_only and not args.graphs and not args.pipeline and not args.no_extra)
     if default_run:
         # the other BASELINE configs as short legs of the same command, each with its own roofline fractions
-        def leg(extra, steps=5, warmup=2):
+        def leg(extra, steps=20, warmup=3):
             a = parse_args(["--gpus", str(args.gpus), "--steps", str(steps), "--warmup", str(warmup), "--no-cpu-baseline", "--no-extra"] + extra)
             # the previous leg's model and workspace are garbage by now, but torch's caching allocator keeps their blocks RESERVED in this process:
             # hand them back before the next leg builds its own (ChunkySeal's 1.8 B parameters + packed images are ~33 GB per rank; with the
@@ -665,15 +667,15 @@ def main():
             legs["image 32x768 on the exact 3 x bf16 split (what the range guard falls back to: worst-case arithmetic)"] = leg(["--conv", "bf16x3"])
             legs["video_step4 (configs[1], video mode)"] = leg(["--mode", "video"])
             legs["chain (configs[2])"] = leg(["--mode", "chain"])
-        legs["stream_1024 (configs[3], strong scaling over the ranks)"] = leg(["--mode", "stream", "--frames", "1024"], steps=2, warmup=1)
+        legs["stream_1024 (configs[3], strong scaling over the ranks)"] = leg(["--mode", "stream", "--frames", "1024"], steps=4, warmup=1)
         # (ranks SHARING a device -- the one-device preflight of tests/test_gpu_zdist.py, VS_BENCH_COLLECTIVE=gloo -- take 4 frames per rank: eight
         # ranks x (21.6 GB of ChunkySeal weights + packed images + the 16-frame workspace) is 272 of the device's 288 GB, too close to an out-of-memory
         # for a plumbing test; one rank per GPU runs the stated 16)
         shared = os.environ.get("VS_BENCH_COLLECTIVE", "nccl") == "gloo" and world > max(1, torch.cuda.device_count())
-        legs["chunkyseal_detect_16x1024 (configs[4])"] = leg(["--card", "chunkyseal", "--size", "1024", "--batch", "4" if shared else "16", "--detect-only"], steps=3, warmup=1)
+        legs["chunkyseal_detect_16x1024 (configs[4])"] = leg(["--card", "chunkyseal", "--size", "1024", "--batch", "4" if shared else "16", "--detect-only"], steps=5, warmup=1)
         if world == 1:      # the other released cards on the configs[1] workload (no MAC count from the survey: frames/s only)
-            legs["pixelseal image mode 32x768"] = leg(["--card", "pixelseal"], steps=5, warmup=2)
-            legs["videoseal_0.0 (RMSNorm U-Net + ViT extractor) image mode 32x768"] = leg(["--card", "videoseal_0.0"], steps=5, warmup=2)
+            legs["pixelseal image mode 32x768"] = leg(["--card", "pixelseal"], steps=10, warmup=2)
+            legs["videoseal_0.0 (RMSNorm U-Net + ViT extractor) image mode 32x768"] = leg(["--card", "videoseal_0.0"], steps=10, warmup=2)
         if world == 1 and rank == 0:
             try:
                 legs["train_step"] = gen_step_leg(torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0"))))
