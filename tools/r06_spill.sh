@@ -1,7 +1,7 @@
 #!/bin/bash
 # spill removal in the TN = 3 GEMM tiles: kernel + end-to-end tests on the new build, then a same-box A/B against the previous build
 # (videoseal_amd/csrc/libvideoseal_prev.so, built from the parent commit) on the detect-only, image and ChunkySeal lines + bit-identity of the decisions
-O=gpurun_out/r06sp; mkdir -p $O
+O=gpurun_out/r06pk; mkdir -p $O
 timeout 1500 python -m pytest tests/test_gpu_kernels.py -m gpu -q -x > $O/pytest_kernels.log 2>&1; tail -3 $O/pytest_kernels.log
 PREV=$PWD/videoseal_amd/csrc/libvideoseal_prev.so
 for i in 1 2 3; do

@@ -188,9 +188,11 @@ __device__ __forceinline__ void apply_act_all(f32x16 (&acc)[TM][TN], const float
 #pragma unroll
       for (int j = 0; j < TN; ++j)
 #pragma unroll
-        for (int e = 0; e < 16; ++e) {
-          acc[i][j][e] = vs_gelu(acc[i][j][e] + b1[j]) + b2[j];
-          if ((e & 7) == 7) __builtin_amdgcn_sched_barrier(0);   // keep the expansions from being interleaved across the whole tile (VGPRs)
+        for (int e = 0; e < 16; e += 2) {          // two values per VALU slot (vs_common.h::vs_gelu2: the same values as vs_gelu)
+          const vs_f32x2 y = vs_gelu2(vs_f32x2{acc[i][j][e] + b1[j], acc[i][j][e + 1] + b1[j]});
+          acc[i][j][e] = y[0] + b2[j];
+          acc[i][j][e + 1] = y[1] + b2[j];
+          if ((e & 7) == 6) __builtin_amdgcn_sched_barrier(0);   // keep the expansions from being interleaved across the whole tile (VGPRs)
         }
   } else if (TANH && act == VS_ACT_TANH) {
 #pragma unroll

@@ -84,6 +84,29 @@ __device__ __forceinline__ float vs_gelu(float v) {
   const float e = vs_erfc_sqrt2(a);
   return fmaxf(v, 0.f) - (0.5f * a) * e;
 }
+// vs_gelu on two values at once (round 6: the GEMM epilogues; the fused ConvNeXt block has had its own copy since round 4): polynomial and blends as
+// 2-wide fp32 operations -- v_pk_fma_f32 / v_pk_mul_f32, two results per VALU slot, 23 instead of 40 instructions per pair --, only min / max / exp2
+// stay scalar.  Same coefficients and operation order; every multiply-add is an explicit fma with contraction off, which is what hipcc makes of
+// vs_gelu's `max - (0.5 a) e` -> the same values bit for bit (tests/test_gpu_kernels.py compares the epilogues that use it with those that do not).
+typedef float vs_f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ vs_f32x2 vs_gelu2(const vs_f32x2 v) {
+#pragma clang fp contract(off)
+  const vs_f32x2 a = {fabsf(v[0]), fabsf(v[1])};
+  const vs_f32x2 u = {fminf(a[0], 5.65685424949238f), fminf(a[1], 5.65685424949238f)};
+  vs_f32x2 q = {5.128553084e-07f, 5.128553084e-07f};
+  q = __builtin_elementwise_fma(q, u, vs_f32x2{-9.560153558e-06f, -9.560153558e-06f});
+  q = __builtin_elementwise_fma(q, u, vs_f32x2{7.497344632e-05f, 7.497344632e-05f});
+  q = __builtin_elementwise_fma(q, u, vs_f32x2{-2.843466646e-04f, -2.843466646e-04f});
+  q = __builtin_elementwise_fma(q, u, vs_f32x2{1.498938855e-05f, 1.498938855e-05f});
+  q = __builtin_elementwise_fma(q, u, vs_f32x2{6.931120995e-03f, 6.931120995e-03f});
+  q = __builtin_elementwise_fma(q, u, vs_f32x2{-5.243476480e-02f, -5.243476480e-02f});
+  q = __builtin_elementwise_fma(q, u, vs_f32x2{-4.592214525e-01f, -4.592214525e-01f});
+  q = __builtin_elementwise_fma(q, u, vs_f32x2{-1.151104212e+00f, -1.151104212e+00f});
+  const vs_f32x2 t = q * u;
+  const vs_f32x2 e = {__builtin_amdgcn_exp2f(t[0]), __builtin_amdgcn_exp2f(t[1])};
+  const vs_f32x2 m = {fmaxf(v[0], 0.f), fmaxf(v[1], 0.f)};
+  return __builtin_elementwise_fma(a * -0.5f, e, m);
+}
 // d gelu / dv = Phi(v) + v phi(v),  Phi(v) = 1 - erfc(v / sqrt2) / 2
 __device__ __forceinline__ float vs_gelu_grad(float v) {
   const float e = vs_erfc_sqrt2(fabsf(v));
