@@ -49,7 +49,7 @@ const char* vs_arch(void);                  /* "gfx950" */
 /* Development switch for tests / tools.  PROCESS-GLOBAL (one atomic per key: setting it is thread-safe, but a value set by one thread is seen
  * by the resize_pre / embed_tail launches of EVERY thread and stream -- e.g. the streaming overlap stream -- until it is reset; not a per-call
  * option, not for production hosts).  Launch paths never call getenv.  key 0 = resize_pre form (1 = the 32 x 8 tile kernel), 1 = resize_pre
- * strip height in output rows, 2 = embed_tail strip height in rows, 3 = JPEG round-trip form (1 = the one-pixel-per-lane kernels), 4 = Crop -> Resize -> colour form (1 = the 32 x 8 tile kernel), 5 = vs_to_planes_affine form (1 = one row per wave), 6 = output rows per strip of the one-row depthwise kernel (1 / 2), 7 = vs_layernorm_act form (1 = one wave per row); value 0 = the
+ * strip height in output rows, 2 = embed_tail strip height in rows, 3 = JPEG round-trip form (1 = the one-pixel-per-lane kernels), 4 = Crop -> Resize -> colour form (1 = the 32 x 8 tile kernel), 5 = vs_to_planes_affine form (1 = one row per wave), 6 = output rows per strip of the one-row depthwise kernel (1 / 2), 7 = vs_layernorm_act form (1 = one wave per row), 8 = K-slice epilogue form (1 = the first kernel, one load in flight per thread); value 0 = the
  * library's choice.  The environment default
  * VIDEOSEAL_RESIZE=tile is latched ONCE per process at the first launch: toggling the variable afterwards has no effect, use this call. */
 int vs_debug_set(int key, int value);

@@ -147,6 +147,61 @@ def test_conv3x3_planes_kernel_with_k_slices(cfg):
     assert torch.equal(pls[1][: want.numel()], want)
 
 
+@pytest.mark.parametrize("kind,cfg", [("pl", (2, 96, 16, 16, 192, True, 3)), ("pl", (1, 384, 16, 32, 384, False, 8)), ("pl", (1, 384, 16, 16, 384, True, 12)),
+                                      ("pc", (3, 8, 8, 768, 200, 1, True, True, 1, 4)), ("pc", (5, 8, 8, 64, 40, 3, False, False, 1, 2)),
+                                      ("pc", (2, 15, 15, 192, 96, 2, True, True, 1, 3)), ("pc", (1, 8, 8, 3072, 768, 0, True, True, 2, 8))])
+def test_k_slice_epilogue_forms_are_bit_identical(kind, cfg):
+    """round 6: splitk_epilogue_vec_kernel issues every load of an item -- all K slices, bias, the slice of the second phase, residual -- before the
+    first use (one round trip; the first kernel waited behind each of them in turn: 9 - 13 us for a few MB) and adds in the same order: fp32 output and
+    operand planes identical bit for bit to the first form (vs_debug_set key 8 = 1), for compile-time slice counts (2 / 3 / 4 / 6 / 8) and the run-time one."""
+    eng = Eng(arith=2)
+    g = torch.Generator().manual_seed(77)
+    res_by_form = []
+    for form in (1, 0):
+        N.check(eng.lib.vs_debug_set(8, form), "vs_debug_set")
+        try:
+            if kind == "pl":
+                B, C, H, W, Co, two, sk = cfg
+                gg = torch.Generator().manual_seed(31)
+                x, x2 = torch.randn(B, C, H, W, generator=gg), torch.randn(B, C, H, W, generator=gg)
+                w1 = torch.randn(Co, C, 3, 3, generator=gg) / math.sqrt(C * 9)
+                w2 = torch.randn(Co, C, 1, 1, generator=gg) / math.sqrt(C)
+                b1, b2 = torch.randn(Co, generator=gg), torch.randn(Co, generator=gg)
+                xa, xa2 = to_nhwc(x), to_nhwc(x2)
+                wt1, cp1 = pack_conv(w1.to(DEV), xa.ld)
+                wt2, cp2 = pack_conv(w2.to(DEV), xa2.ld)
+                cw1, cw2 = ConvW(wt1, b1.to(DEV), Co, 3, 3, cp1), ConvW(wt2, b2.to(DEV), Co, 1, 1, cp2)
+                xpl, x2pl = eng.to_planes(xa, "t.xpl"), eng.to_planes(xa2, "t.x2pl")
+                out = eng.new_act(f"t.ef{form}", B, H, W, Co)
+                out.t.fill_(3.0)
+                opl = eng.buf(f"t.efpl{form}", B * H * W * Co).view(torch.int16)
+                kw = dict(in2=xa2, w2=cw2, in2_pl=x2pl) if two else {}
+                eng.conv(xa, cw1, out, pad=1, act=N.ACT_RELU, tile_hint=N.CONV_TILE_HI | 6, arith=2, in_pl=xpl, out_pl=opl, split_k=sk, **kw)
+                torch.cuda.synchronize()
+                res_by_form.append((out.t.clone(), opl.clone()))
+            else:
+                B, H, W, K, Nn, act, grn, use_res, tl, sk = cfg
+                gg = torch.Generator().manual_seed(5 + K)
+                h = torch.randn(B, H * W, K, generator=gg)
+                sc, sh = 1 + 0.3 * torch.randn(B, K, generator=gg), 0.1 * torch.randn(K, generator=gg)
+                w = torch.randn(Nn, K, generator=gg) / math.sqrt(K)
+                bias, res = torch.randn(Nn, generator=gg), torch.randn(B, H * W, Nn, generator=gg)
+                xa = Act(dv(h), B, H, W, K, K)
+                wt, cp = pack_conv(w[:, :, None, None].to(DEV), K)
+                cw = ConvW(wt, dv(bias), Nn, 1, 1, cp)
+                ra = Act(dv(res), B, H, W, Nn, Nn)
+                out = Act(torch.full((B * H * W * Nn,), float("nan"), device=DEV), B, H, W, Nn, Nn)
+                kw = dict(a_scale=dv(sc), a_scale_ld=K, a_shift=dv(sh)) if grn else {}
+                eng.conv(xa, cw, out, act=act, res=(ra if use_res else None), tile_hint=N.CONV_TILE_HI | tl, split_k=sk, arith=2, **kw)
+                torch.cuda.synchronize()
+                assert torch.isfinite(out.t).all()
+                res_by_form.append((out.t.clone(),))
+        finally:
+            N.check(eng.lib.vs_debug_set(8, 0), "vs_debug_set")
+    for a_, b_ in zip(*res_by_form):
+        assert torch.equal(a_, b_)
+
+
 @pytest.mark.parametrize("cx", [16, 1])
 def test_conv3x3_small_two_phase(eng, cx):
     """thin-layer kernel with the fused 1x1 res_conv (unet.py:38-39) + residual at a channel offset; bit-identical to the patch kernel."""

@@ -554,6 +554,80 @@ __global__ __launch_bounds__(256) void splitk_epilogue_kernel(const vs_conv_desc
   }
 }
 
+// The same for the shapes every shipped layer has (N % 4 == 0, 16-byte aligned out / res / bias rows): round 6.  The kernel above is a chain of
+// dependent round trips -- hipcc waits vmcnt(0) behind every slice's load in its run-time loop, and bias / second-phase / residual values arrive as
+// twelve scalar loads with a wait each (tools/isa_scan.py order: `LOOP LD vmcnt(0)` x split_k, then `LD vmcnt(0)` x 12) -- 9 - 13 us for a few MB.
+// Here EVERY load of an item is issued before the first use: SK 16-byte slice loads (compile-time count; SK = 0: run-time count, four in flight),
+// bias, second-phase slice + bias2, residual.  Same additions in the same order per element -> the same values bit for bit.
+template <int SK>
+__global__ __launch_bounds__(256) void splitk_epilogue_vec_kernel(const vs_conv_desc_t d, const int M) {
+  const int ncol4 = d.n_store / 4;
+  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= (int64_t)M * ncol4) return;
+  const int64_t m = idx / ncol4;
+  const int n4 = (int)(idx % ncol4) * 4;
+  float* const o = d.out ? d.out + m * d.out_ld + d.out_coff + n4 : nullptr;
+  if (n4 >= d.N) {                          // columns in [N, n_store): zeros
+    if (o) *reinterpret_cast<f32x4*>(o) = f32x4{0.f, 0.f, 0.f, 0.f};
+    return;
+  }
+  const float* const w0 = d.splitk_ws + m * d.splitk_ld + n4;
+  const int64_t sstride = (int64_t)M * d.splitk_ld;
+  const bool two = d.in2 || d.in2_pl;
+  const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+  f32x4 bv = z4, b2v = z4, p2 = z4, rv = z4;
+  f32x4 v = z4;
+  if constexpr (SK > 0) {
+    f32x4 t[SK];
+#pragma unroll
+    for (int k = 0; k < SK; ++k) t[k] = *reinterpret_cast<const f32x4*>(w0 + k * sstride);
+    if (d.bias) bv = *reinterpret_cast<const f32x4*>(d.bias + n4);
+    if (two) {
+      p2 = *reinterpret_cast<const f32x4*>(w0 + SK * sstride);
+      if (d.bias2) b2v = *reinterpret_cast<const f32x4*>(d.bias2 + n4);
+    }
+    if (d.res) rv = *reinterpret_cast<const f32x4*>(d.res + m * d.res_ld + n4);
+#pragma unroll
+    for (int k = 0; k < SK; ++k) v += t[k];
+  } else {
+    const int sk = d.split_k;
+    if (d.bias) bv = *reinterpret_cast<const f32x4*>(d.bias + n4);
+    if (two) {
+      p2 = *reinterpret_cast<const f32x4*>(w0 + sk * sstride);
+      if (d.bias2) b2v = *reinterpret_cast<const f32x4*>(d.bias2 + n4);
+    }
+    if (d.res) rv = *reinterpret_cast<const f32x4*>(d.res + m * d.res_ld + n4);
+    int k = 0;
+    for (; k + 4 <= sk; k += 4) {
+      f32x4 t[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) t[q] = *reinterpret_cast<const f32x4*>(w0 + (k + q) * sstride);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) v += t[q];
+    }
+    for (; k < sk; ++k) v += *reinterpret_cast<const f32x4*>(w0 + k * sstride);
+  }
+  float r[4];
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    float t = v[c] + bv[c];                  // (bias absent: + 0.f, as `v + (d.bias ? .. : 0.f)` above)
+    if (d.act == VS_ACT_RELU) t = vs_relu(t);
+    else if (d.act == VS_ACT_GELU) t = vs_gelu(t);
+    else if (d.act == VS_ACT_TANH) t = tanhf(t);
+    if (two) t += p2[c] + b2v[c];
+    if (d.res) t += rv[c];
+    r[c] = t;
+  }
+  if (d.out_pl) {      // the next conv's operand planes (conv3x3_pl.hip): hi / lo f16 of v * a_mul, [plane][N / 16][pixel][16]
+    vsconv::u32x2 hi, lo;
+    vsconv::split4h(f32x4{r[0], r[1], r[2], r[3]}, d.a_mul, hi, lo);
+    char* dst = reinterpret_cast<char*>(d.out_pl) + ((int64_t)(n4 >> 4) * M + m) * 32 + (n4 & 15) * 2;
+    *reinterpret_cast<vsconv::u32x2*>(dst) = hi;
+    *reinterpret_cast<vsconv::u32x2*>(dst + (int64_t)(d.N / 16) * M * 32) = lo;
+  }
+  if (o) *reinterpret_cast<f32x4*>(o) = f32x4{r[0], r[1], r[2], r[3]};
+}
+
 template <int TN, int WN = 2>
 int launch_g(const vs_conv_desc_t& d, hipStream_t st) {
   constexpr int BN = 32 * TN * WN;
@@ -598,6 +672,22 @@ int vs_splitk_epilogue(const vs_conv_desc_t& d, int M, hipStream_t st) {
   const int64_t items = (int64_t)M * ((d.n_store + 3) / 4);
   if ((d.splitk_ld & 3) || ((uintptr_t)d.splitk_ws & 15)) return VS_ERR_BAD_ARG;
   const int vec = ((d.out_ld & 3) == 0 && (d.out_coff & 3) == 0 && ((uintptr_t)d.out & 15) == 0) ? 1 : 0;
+  // every operand in whole 16-byte pieces: the form with all loads of an item in flight at once (VS_SPLITK_EPI=scalar keeps the first form; experiments)
+  static const bool scalar_only = [] { const char* e = getenv("VS_SPLITK_EPI"); return e && e[0] == 's'; }();
+  const bool wide = !scalar_only && vs_debug_get(VS_DBG_SPLITK_EPI) != 1 && (vec || !d.out) && (d.N & 3) == 0 && (d.n_store & 3) == 0 && (!d.bias || ((uintptr_t)d.bias & 15) == 0) &&
+                    (!d.bias2 || ((uintptr_t)d.bias2 & 15) == 0) && (!d.res || (((uintptr_t)d.res & 15) == 0 && (d.res_ld & 3) == 0));
+  if (wide) {
+    const dim3 grid((unsigned)cdiv64((int64_t)M * (d.n_store / 4), 256));
+    switch (d.split_k) {
+      case 2: hipLaunchKernelGGL(splitk_epilogue_vec_kernel<2>, grid, dim3(256), 0, st, d, M); break;
+      case 3: hipLaunchKernelGGL(splitk_epilogue_vec_kernel<3>, grid, dim3(256), 0, st, d, M); break;
+      case 4: hipLaunchKernelGGL(splitk_epilogue_vec_kernel<4>, grid, dim3(256), 0, st, d, M); break;
+      case 6: hipLaunchKernelGGL(splitk_epilogue_vec_kernel<6>, grid, dim3(256), 0, st, d, M); break;
+      case 8: hipLaunchKernelGGL(splitk_epilogue_vec_kernel<8>, grid, dim3(256), 0, st, d, M); break;
+      default: hipLaunchKernelGGL(splitk_epilogue_vec_kernel<0>, grid, dim3(256), 0, st, d, M); break;
+    }
+    return vs_launch_status();
+  }
   hipLaunchKernelGGL(splitk_epilogue_kernel, dim3((unsigned)cdiv64(items, 256)), dim3(256), 0, st, d, M, vec);
   return vs_launch_status();
 }

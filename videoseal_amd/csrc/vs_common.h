@@ -36,7 +36,7 @@ static inline int vs_default_arith() {
 // Development switches of the launchers (tests / tools select a kernel form or a strip height PER CALL): set through the exported
 // vs_debug_set(key, value) -- an atomic the launch path reads; nothing on a launch path calls getenv (not thread-safe against setenv, and a
 // test hook in production code).  0 = the library's own choice.
-enum { VS_DBG_RESIZE_FORM = 0 /* 1 = 32 x 8 tile kernel */, VS_DBG_RESIZE_STRIP = 1 /* output rows */, VS_DBG_TAIL_STRIP = 2 /* rows */, VS_DBG_JPEG_FORM = 3 /* 1 = scalar kernels */, VS_DBG_CROP_RESIZE_FORM = 4 /* 1 = 32 x 8 tile kernel */, VS_DBG_TO_PLANES_FORM = 5 /* 1 = one row per wave */, VS_DBG_DWCONV_ROWS = 6 /* rows per strip of the one-row depthwise kernel */, VS_DBG_LN_FORM = 7 /* 1 = wave per row */, VS_DBG_COUNT = 8 };
+enum { VS_DBG_RESIZE_FORM = 0 /* 1 = 32 x 8 tile kernel */, VS_DBG_RESIZE_STRIP = 1 /* output rows */, VS_DBG_TAIL_STRIP = 2 /* rows */, VS_DBG_JPEG_FORM = 3 /* 1 = scalar kernels */, VS_DBG_CROP_RESIZE_FORM = 4 /* 1 = 32 x 8 tile kernel */, VS_DBG_TO_PLANES_FORM = 5 /* 1 = one row per wave */, VS_DBG_DWCONV_ROWS = 6 /* rows per strip of the one-row depthwise kernel */, VS_DBG_LN_FORM = 7 /* 1 = wave per row */, VS_DBG_SPLITK_EPI = 8 /* 1 = the first (scalar-load) K-slice epilogue kernel */, VS_DBG_COUNT = 9 };
 int vs_debug_get(int key);     // api.hip
 
 // LDS a workgroup may ask for on the current device (160 KiB on gfx950, 64 KiB on earlier CDNA parts): launchers whose kernels want more than
