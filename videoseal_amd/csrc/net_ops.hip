@@ -531,13 +531,15 @@ __global__ __launch_bounds__(256) void grn_partial_kernel(const float* __restric
 // One workgroup of 1024 threads per frame: 256 channels x 4 groups of chunks at a time; every group adds its chunks in
 // order and the four group sums are combined in a fixed order -> deterministic, with 4x the loads in flight of a
 // one-thread-per-channel loop (frame-major partials are up to HW/32 = 128 chunks deep).
+// (round 6: NB x KB = 32 loads in flight per thread whatever C: with NB = 8 a 384-channel frame used two of the eight block slots and walked its
+//  32 chunk rows per group four at a time -- eight dependent round trips; <2, 16> does it in two.  Same additions in the same order.)
+template <int NB, int KB>
 __global__ __launch_bounds__(1024) void grn_finish_kernel(const float* __restrict__ partial, int nchunk, int B, int C,
                                                           const float* __restrict__ gamma, float* __restrict__ scale,
                                                           int64_t sld, int frame_major) {
   // Channel blocks of 256 are walked NB at a time: the chunk sums of NB blocks are independent loads issued back to back, ONE barrier pair per
   // NB blocks (one pair per block made the kernel a chain of C / 256 dependent round trips: 11.6 us for 18 launches per extractor pass, whatever
   // the stage).  Same sums in the same order as before: per channel ((g0 + g1) + g2) + g3, per thread the blocks in ascending order.
-  constexpr int NB = 8;
   __shared__ float grp[NB][4][256];
   __shared__ float red[256];
   const int b = blockIdx.x;
@@ -554,19 +556,35 @@ __global__ __launch_bounds__(1024) void grn_finish_kernel(const float* __restric
     const int64_t kstride = frame_major ? (int64_t)C : (int64_t)B * C;
     const float* rowp = frame_major ? partial + ((int64_t)b * nchunk + k0) * C : partial + ((int64_t)k0 * B + b) * C;
     int k = k0;
-    for (; k + 4 <= k1; k += 4, rowp += 4 * kstride) {
-      float v[4][NB];
+    for (; k + KB <= k1; k += KB, rowp += KB * kstride) {
+      float v[KB][NB];
 #pragma unroll
-      for (int q = 0; q < 4; ++q)
+      for (int q = 0; q < KB; ++q)
 #pragma unroll
         for (int j = 0; j < NB; ++j) {
           const int c = cb0 + j * 256 + cl;
           v[q][j] = c < C ? rowp[q * kstride + c] : 0.f;
         }
 #pragma unroll
-      for (int q = 0; q < 4; ++q)
+      for (int q = 0; q < KB; ++q)
 #pragma unroll
         for (int j = 0; j < NB; ++j) s[j] += v[q][j];
+    }
+    if constexpr (KB > 4) {           // what is left of the group, four rows at a time as before
+      for (; k + 4 <= k1; k += 4, rowp += 4 * kstride) {
+        float v[4][NB];
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+          for (int j = 0; j < NB; ++j) {
+            const int c = cb0 + j * 256 + cl;
+            v[q][j] = c < C ? rowp[q * kstride + c] : 0.f;
+          }
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+          for (int j = 0; j < NB; ++j) s[j] += v[q][j];
+      }
     }
     for (; k < k1; ++k, rowp += kstride) {
 #pragma unroll
@@ -1284,7 +1302,11 @@ extern "C" int vs_grn_scale(const float* h, int B, int HW, int C, int64_t ld, co
   const int nchunk = (HW + GRN_ROWS - 1) / GRN_ROWS;
   hipLaunchKernelGGL(grn_partial_kernel, dim3((unsigned)((C + 255) / 256), (unsigned)nchunk, (unsigned)B), dim3(256), 0,
                      (hipStream_t)stream, h, HW, C, ld, partial, B);
-  hipLaunchKernelGGL(grn_finish_kernel, dim3((unsigned)B), dim3(1024), 0, (hipStream_t)stream, partial, nchunk, B, C, gamma,
+  if (C <= 512) hipLaunchKernelGGL((grn_finish_kernel<2, 16>), dim3((unsigned)B), dim3(1024), 0, (hipStream_t)stream, partial, nchunk, B, C, gamma,
+                     scale, ld, 0);
+  else if (C <= 1024) hipLaunchKernelGGL((grn_finish_kernel<4, 8>), dim3((unsigned)B), dim3(1024), 0, (hipStream_t)stream, partial, nchunk, B, C, gamma,
+                     scale, ld, 0);
+  else hipLaunchKernelGGL((grn_finish_kernel<8, 4>), dim3((unsigned)B), dim3(1024), 0, (hipStream_t)stream, partial, nchunk, B, C, gamma,
                      scale, ld, 0);
   return vs_launch_status();
 }
@@ -1320,7 +1342,11 @@ extern "C" int vs_grn_apply(float* h, int B, int HW, int C, int64_t ld, const fl
 extern "C" int vs_grn_scale_from_partials(const float* partial, int B, int HW, int C, const float* gamma, float* scale,
                                           int64_t scale_ld, void* stream) {
   VS_REQUIRE(partial && gamma && scale && B > 0 && HW > 0 && HW % 32 == 0 && C > 0 && scale_ld >= C);
-  hipLaunchKernelGGL(grn_finish_kernel, dim3((unsigned)B), dim3(1024), 0, (hipStream_t)stream, partial, HW / 32, B, C, gamma,
+  if (C <= 512) hipLaunchKernelGGL((grn_finish_kernel<2, 16>), dim3((unsigned)B), dim3(1024), 0, (hipStream_t)stream, partial, HW / 32, B, C, gamma,
+                     scale, scale_ld, 1);
+  else if (C <= 1024) hipLaunchKernelGGL((grn_finish_kernel<4, 8>), dim3((unsigned)B), dim3(1024), 0, (hipStream_t)stream, partial, HW / 32, B, C, gamma,
+                     scale, scale_ld, 1);
+  else hipLaunchKernelGGL((grn_finish_kernel<8, 4>), dim3((unsigned)B), dim3(1024), 0, (hipStream_t)stream, partial, HW / 32, B, C, gamma,
                      scale, scale_ld, 1);
   return vs_launch_status();
 }
