@@ -911,10 +911,28 @@ __global__ __launch_bounds__(256) void pool_linear_kernel(const float* __restric
   }
   __syncthreads();
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  // (round 6, second pass: the weight row of an output was read one value per loop iteration with a wait behind each -- C / 64 = 12 dependent L2 round
+  //  trips per output, four or five outputs per wave: 28 us for a 32 x 257 result.  Now the row's values are requested first and multiplied in the
+  //  same lane order: the same sums.)
+  constexpr int CM = 16;                     // lanes x 16 = up to 1024 channels with every weight of a row in flight
   for (int n = blockIdx.y * 4 + wv; n < N; n += 4 * gridDim.y) {
     const float* wr = w + (int64_t)n * C;
     float s = 0.f;
-    for (int c = lane; c < C; c += 64) s += pooled[c] * wr[c];
+    if (C <= 64 * CM) {
+      float wv_[CM];
+#pragma unroll
+      for (int j = 0; j < CM; ++j) {
+        const int c = lane + 64 * j;
+        wv_[j] = c < C ? wr[c] : 0.f;
+      }
+#pragma unroll
+      for (int j = 0; j < CM; ++j) {
+        const int c = lane + 64 * j;
+        if (c < C) s += pooled[c] * wv_[j];
+      }
+    } else {
+      for (int c = lane; c < C; c += 64) s += pooled[c] * wr[c];
+    }
     s = wave_sum(s);
     if (lane == 0) out[(int64_t)b * N + n] = s + bias[n];
   }
