@@ -9,6 +9,8 @@ L = N.lib()
 B = 32
 print("VS_DWCONV =", os.environ.get("VS_DWCONV", "auto"))
 SHAPES = ((64, 96), (32, 192), (16, 384), (8, 768))
+if "b16" in sys.argv:          # the chain leg's extractor pass
+    B = 16
 if "chunky" in sys.argv:        # ChunkySeal's extractor, 16 frames: channel strides padded to 32 (engine._xld)
     B = 16
     SHAPES = ((127, 384), (63, 736), (31, 1472), (15, 2912))
