@@ -116,13 +116,15 @@ __global__ __launch_bounds__(NTH, 2) void conv3x3_patch_kernel(const vs_conv_des
   u32x4 rb[NB][NP];
 
   auto load_patch = [&, tid](const int cc) __attribute__((always_inline)) {      // channel chunk cc -> registers
-    const char* base = reinterpret_cast<const char*>(d.in) + (int64_t)cc * (BK * 4);
     const bool cok = (cc * BK + (tid & 3) * 4) < d.Cin;
 #pragma unroll
     for (int i = 0; i < NPI; ++i) {
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (p_have[i] && cok) v = *reinterpret_cast<const f32x4*>(base + p_off[i]);
-      if (!p_ok[i]) v = f32x4{0.f, 0.f, 0.f, 0.f};
+      // (branch-free since round 6, as the weight loads below: a load inside an `if` region is waited for at the join.  Lanes without a slot or
+      //  beyond Cin read the tensor's first 16 bytes -- an offset select, always inside the allocation -- and are zeroed as before)
+      const bool ld_ok = p_have[i] && cok;
+      const unsigned off = ld_ok ? p_off[i] + (unsigned)cc * (BK * 4) : 0u;
+      f32x4 v = *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(d.in) + off);
+      if (!(ld_ok && p_ok[i])) v = f32x4{0.f, 0.f, 0.f, 0.f};
       rp[i] = v;
     }
   };
@@ -139,20 +141,18 @@ __global__ __launch_bounds__(NTH, 2) void conv3x3_patch_kernel(const vs_conv_des
   auto load_b = [&](const int cc, const int tap) __attribute__((always_inline)) {
     const char* bbase = wbase + ((int64_t)tap * d.CinP + (int64_t)cc * BK) * 2;
 #pragma unroll
-    for (int i = 0; i < NB; ++i)
-      if (b_have[i]) {
-#pragma unroll
-        for (int p = 0; p < NP; ++p) rb[i][p] = *reinterpret_cast<const u32x4*>(bbase + p * plane1 + b_off[i]);
-      }
+    for (int i = 0; i < NB; ++i) {      // (unconditional since round 6: b_off of a thread without a slot is a clamped, valid weight row -- a load inside an
+#pragma unroll                          //  `if (b_have)` region made hipcc wait vmcnt(0) for it BEFORE the step's MFMAs; only the LDS store stays guarded)
+      for (int p = 0; p < NP; ++p) rb[i][p] = *reinterpret_cast<const u32x4*>(bbase + p * plane1 + b_off[i]);
+    }
   };
   auto load_b2 = [&](const int c2) __attribute__((always_inline)) {
     const char* bbase = wbase2 + (int64_t)c2 * (BK * 2);
 #pragma unroll
-    for (int i = 0; i < NB; ++i)
-      if (b_have[i]) {
+    for (int i = 0; i < NB; ++i) {
 #pragma unroll
-        for (int p = 0; p < NP; ++p) rb[i][p] = *reinterpret_cast<const u32x4*>(bbase + p * plane2 + b_off2[i]);
-      }
+      for (int p = 0; p < NP; ++p) rb[i][p] = *reinterpret_cast<const u32x4*>(bbase + p * plane2 + b_off2[i]);
+    }
   };
   auto store_b = [&](const int buf) __attribute__((always_inline)) {
     unsigned char* Bb = Bs0 + buf * B_BYTES;
