@@ -98,14 +98,16 @@ __global__ __launch_bounds__(256, (NB <= 5 ? 2 : 1)) void upconv_fused_kernel(co
     f32x4 ra[KG][2];
 #pragma unroll
     for (int c = 0; c < KG; ++c) {
-      const int kc = kg + c * BK;
-      if (kc < K) {
-        const bool from_x = kc < C1;                      // C1 % 16 == 0: a chunk never straddles the concat boundary
+      // (branch-free since round 6: with the loads inside `if (kc < K)` / `if (from_x) .. else ..` regions hipcc waited for every chunk's pair at the
+      //  join -- four dependent round trips per group instead of the ONE burst this loop is for (tools/isa_scan.py order: `LDx2 vmcnt(0)` x 8).  A chunk
+      //  past K re-reads the last one (its registers are never stored); x * 1.0f is exact)
+      const int kc = kg + c * BK < K ? kg + c * BK : K - BK;
+      const bool from_x = kc < C1;                        // C1 % 16 == 0: a chunk never straddles the concat boundary
+      const float mul = from_x ? 1.0f : sscale;
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-          if (from_x) ra[c][i] = *reinterpret_cast<const f32x4*>(x + a_pix[i] * ld1 + kc + k4);
-          else ra[c][i] = *reinterpret_cast<const f32x4*>(skip + a_pix[i] * ld2 + (kc - C1) + k4) * sscale;
-        }
+      for (int i = 0; i < 2; ++i) {
+        const float* src = from_x ? x + a_pix[i] * ld1 + kc + k4 : skip + a_pix[i] * ld2 + (kc - C1) + k4;
+        ra[c][i] = *reinterpret_cast<const f32x4*>(src) * mul;
       }
     }
 #pragma unroll
