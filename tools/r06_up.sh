@@ -1,7 +1,7 @@
 #!/bin/bash
-O=gpurun_out/r06up; mkdir -p $O
+O=gpurun_out/r06rb; mkdir -p $O
 PREV=$PWD/videoseal_amd/csrc/libvideoseal_prev.so
-timeout 900 python -m pytest tests/test_gpu_kernels.py -m gpu -q -x -k "upconv or upsample or unet" 2>&1 | tail -1
+timeout 900 python -m pytest tests/test_gpu_kernels.py -m gpu -q -x -k "resblock or thin or unet" 2>&1 | tail -1
 for m in image video; do
   X=""; [ $m = video ] && X="--mode video"
   python bench.py $X --no-cpu-baseline --steps 2 --warmup 1 --no-extra --dump-preds $O/p_new_$m.pt > /dev/null 2>&1
@@ -18,6 +18,6 @@ cd /tmp && export TMPDIR=/tmp
 for v in new prev; do
   L=$GRAFT_REPO_ROOT/videoseal_amd/csrc/libvideoseal_hip.so; [ $v = prev ] && L=$PREV
   VIDEOSEAL_LIB=$L timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$O -o img_$v -- python $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --no-kernel-timers --no-extra --steps 10 --warmup 2 > $GRAFT_REPO_ROOT/$O/img_$v.log 2>&1
-  echo "== $v"; grep -E "upconv_fused|conv3x3_patch_kernel" $GRAFT_REPO_ROOT/$O/img_${v}_kernel_stats.csv | cut -c1-150
+  echo "== $v"; grep -E "resblock_thin|upconv_fused|conv3x3_patch_kernel" $GRAFT_REPO_ROOT/$O/img_${v}_kernel_stats.csv | cut -c1-150
 done
 rm -f $GRAFT_REPO_ROOT/$O/*_kernel_trace.csv $GRAFT_REPO_ROOT/$O/*agent_info.csv

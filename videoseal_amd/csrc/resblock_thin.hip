@@ -108,7 +108,6 @@ __global__ __launch_bounds__(256, OCC) void resblock_thin_kernel(const RbArgs d,
 
   // ---- patch items of this thread (positions relative to the tile origin are constant)
   int p_dy[NXI], p_dx[NXI], p_lds[NXI];
-  unsigned p_rel[NXI];                                               // byte offset from the patch origin (interior tiles: no clamping, no 64-bit lane math)
   bool p_have[NXI];
   const int k4 = (tid & 3) * 4;
   const bool cok = k4 < d.Cin;
@@ -120,7 +119,6 @@ __global__ __launch_bounds__(256, OCC) void resblock_thin_kernel(const RbArgs d,
     p_dy[i] = prow / X_W - 2;
     p_dx[i] = prow % X_W - 2;
     p_lds[i] = prow * ROWB16 + k4 * 2;
-    p_rel[i] = (unsigned)(((int64_t)(prow / X_W) * d.x_sy + (int64_t)(prow % X_W) * d.x_sx + (cok ? k4 : 0)) * 4);
   }
   // tap offsets of this lane's half of every tap pair (the ninth tap has no partner: its second half re-reads tap 8 against zero weights)
   int toffx[5], tofft[5];
@@ -151,15 +149,9 @@ __global__ __launch_bounds__(256, OCC) void resblock_thin_kernel(const RbArgs d,
 
   f32x4 rp[NXI];
   auto load_tile = [&](const int fb, const int y0, const int x0) __attribute__((always_inline)) {
-    if (y0 >= 2 && x0 >= 2 && y0 + TH + 2 <= d.H && x0 + TW + 2 <= d.W) {         // workgroup-uniform: the patch lies inside the image
-      const char* base = reinterpret_cast<const char*>(d.x + (int64_t)fb * d.x_sb + (int64_t)(y0 - 2) * d.x_sy + (int64_t)(x0 - 2) * d.x_sx);
-#pragma unroll
-      for (int i = 0; i < NXI; ++i) {
-        const f32x4 v = *reinterpret_cast<const f32x4*>(base + (p_have[i] ? p_rel[i] : 0u));
-        rp[i] = cok ? v : f32x4{0.f, 0.f, 0.f, 0.f};
-      }
-      return;
-    }
+    // (round 6: ONE branch-free form.  The interior fast path of round 5 -- a workgroup-uniform `if` around its own loads -- and the `if (t + 1 < t_end)`
+    //  around this call made hipcc wait for the prefetch at the join, in front of the tile's MFMAs: "in flight during this tile's products" was not true
+    //  in the emitted code, tools/isa_scan.py order.  The clamped form costs a few integer operations per item and nothing else.)
 #pragma unroll
     for (int i = 0; i < NXI; ++i) {
       const int iy = y0 + p_dy[i], ix = x0 + p_dx[i];
@@ -192,7 +184,10 @@ __global__ __launch_bounds__(256, OCC) void resblock_thin_kernel(const RbArgs d,
     const int buf = NBUF == 2 ? (t - t_begin) & 1 : 0;
     int ntx = tx + 1, nty = ty, nfb = fb;
     if (ntx == tiles_x) { ntx = 0; if (++nty == tiles_y) { nty = 0; ++nfb; } }
-    if (t + 1 < t_end) load_tile(nfb, nty * TH, ntx * TW);      // in flight during this tile's products
+    {                                                           // in flight during this tile's products; the last tile re-reads itself (values unused)
+      const bool more = t + 1 < t_end;
+      load_tile(more ? nfb : fb, (more ? nty : ty) * TH, (more ? ntx : tx) * TW);
+    }
     const unsigned char* Ps = smem + buf * XP_BYTES;
     const int y0 = ty * TH, x0 = tx * TW;
 
@@ -391,7 +386,10 @@ __global__ __launch_bounds__(NT32) void resblock_thin32_kernel(const RbArgs d, c
   for (int t = t_begin; t < t_end; ++t) {
     int ntx = tx + 1, nty = ty, nfb = fb;
     if (ntx == tiles_x) { ntx = 0; if (++nty == tiles_y) { nty = 0; ++nfb; } }
-    if (t + 1 < t_end) load_tile(nfb, nty * TH, ntx * TW);
+    {                                                           // (branch-free, as in resblock_thin_kernel: the last tile re-reads itself)
+      const bool more = t + 1 < t_end;
+      load_tile(more ? nfb : fb, (more ? nty : ty) * TH, (more ? ntx : tx) * TW);
+    }
     const int y0 = ty * TH, x0 = tx * TW;
 
     // ---- conv0 on the 10 x 18 tile of t: pixel groups wave, wave + 8 x 2 channel halves
